@@ -1,0 +1,90 @@
+"""ctypes mirror of include/c8p_rx.h (the C ABI of libc8p_rx.so).
+
+Field order and sizes must match the header exactly; tests/test_abi.py checks the sizes
+against the values the library itself reports.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+MEM_HOST, MEM_DEVICE = 0, 1
+F_L, F_HT, F_VHT, F_VHT_CHAN = 0, 1, 2, 20
+CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
+ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
+BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN = range(7)
+K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_COUNT = range(6)
+K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish"]
+TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
+    TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
+NDP_TOTAL = 1024
+NDP_BLOB_BYTES = 1027
+
+
+class PktIn(C.Structure):
+    _fields_ = [("iq_off", C.c_uint64 * 2), ("n_items", C.c_uint32), ("chan_off", C.c_uint32),
+                ("lsig_mcs", C.c_int32), ("lsig_len", C.c_int32), ("lsig_nsamp", C.c_int32),
+                ("seq", C.c_int32), ("cfo", C.c_float), ("snr", C.c_float), ("rssi", C.c_float),
+                ("n_ant", C.c_uint8), ("mupos", C.c_uint8), ("rsv", C.c_uint8 * 2)]
+
+
+class PktTags(C.Structure):
+    _fields_ = [("status", C.c_int32), ("format", C.c_int32), ("mcs", C.c_int32), ("len", C.c_int32),
+                ("cr", C.c_int32), ("ampdu", C.c_int32), ("trellis", C.c_int32), ("total", C.c_int32),
+                ("nsym", C.c_int32), ("nss", C.c_int32), ("nltf", C.c_int32), ("ncbps", C.c_int32),
+                ("ncbpss", C.c_int32), ("ndbps", C.c_int32), ("nbpscs", C.c_int32), ("nsymsamp", C.c_int32),
+                ("sumu", C.c_int32), ("is_ndp", C.c_int32), ("data_off", C.c_int32), ("seq", C.c_int32),
+                ("cfo", C.c_float), ("snr", C.c_float), ("rssi", C.c_float),
+                ("sssnr0", C.c_float), ("sssnr1", C.c_float), ("rsv", C.c_uint32),
+                ("llr_off", C.c_uint64)]
+
+
+class PktOut(C.Structure):
+    _fields_ = [("n_pdu", C.c_int32), ("n_crc_fail", C.c_int32), ("pdu_bytes", C.c_uint32),
+                ("rsv", C.c_uint32), ("pdu_off", C.c_uint64), ("bits_off", C.c_uint64)]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("profile", C.c_int32),
+                ("keep_bits", C.c_int32), ("stream", C.c_void_p)]
+
+
+class BatchIn(C.Structure):
+    _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("pkts", C.c_void_p), ("iq", C.c_void_p),
+                ("n_iq", C.c_uint64), ("chan", C.c_void_p), ("n_chan", C.c_uint64)]
+
+
+class DecodeIn(C.Structure):
+    _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("tags", C.c_void_p), ("llr", C.c_void_p),
+                ("n_llr", C.c_uint64), ("mu2x1chan", C.c_void_p)]
+
+
+def _np_dtype(struct):
+    """numpy structured dtype with the same layout as a ctypes.Structure."""
+    names, formats, offsets = [], [], []
+    for name, ctype in struct._fields_:
+        names.append(name)
+        offsets.append(getattr(struct, name).offset)
+        if hasattr(ctype, "_length_"):
+            formats.append((np.dtype(ctype._type_), (ctype._length_,)))
+        else:
+            formats.append(np.dtype(ctype))
+    return np.dtype({"names": names, "formats": formats, "offsets": offsets,
+                     "itemsize": C.sizeof(struct)})
+
+
+PKT_IN_DT = _np_dtype(PktIn)
+PKT_TAGS_DT = _np_dtype(PktTags)
+PKT_OUT_DT = _np_dtype(PktOut)
+
+TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
+
+
+def split_pdus(area: bytes, n_pdu: int):
+    """PDU area = n_pdu records of {u16 len LE, len bytes}."""
+    out, o = [], 0
+    for _ in range(n_pdu):
+        n = area[o] | (area[o + 1] << 8)
+        out.append(bytes(area[o + 2:o + 2 + n]))
+        o += 2 + n
+    return out

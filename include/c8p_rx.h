@@ -1,0 +1,209 @@
+/*
+ * c8p_rx.h — C ABI of the MI355X-native 802.11 OFDM RX hot path (libc8p_rx.so).
+ *
+ * This is the drop-in boundary for the reference's demod / demod2 / decode blocks
+ * (all citations are relative to the reference tree):
+ *
+ *   c8p_demod()   replaces  demod_impl::general_work   lib/demod_impl.cc:59-342
+ *                 and       demod2_impl::general_work  lib/demod2_impl.cc:58-349
+ *   c8p_decode()  replaces  decode_impl::general_work  lib/decode_impl.cc:60-162
+ *   c8p_rx()      = c8p_demod() + c8p_decode() with the LLR stream kept in HBM
+ *
+ * A "packet" is what one pass of the reference state machines handles: the items between
+ * two tag sets on the stream.  The GNU Radio blocks stream packets one by one; this engine
+ * takes a batch of them (descriptors + arenas) and processes all of them in parallel.
+ *
+ * Conventions
+ *   - plain C types only, no torch / GNU Radio / HIP types in signatures;
+ *   - every pointer is caller-owned; the engine never frees or keeps caller memory past
+ *     c8p_sync(); engine-owned result arenas stay valid until the next submit on that ctx;
+ *   - errors are negative return codes, never exceptions or abort();
+ *   - one ctx per block instance / per thread; a ctx is not internally locked;
+ *   - there is no CPU fallback: c8p_create() fails if no HIP device is usable.
+ */
+#ifndef C8P_RX_H
+#define C8P_RX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C8P_ABI_VERSION 1
+
+/* return codes */
+#define C8P_OK          0
+#define C8P_EINVAL     (-22)
+#define C8P_ENOMEM     (-12)
+#define C8P_ENODEV     (-19)
+#define C8P_EHIP       (-5)
+#define C8P_ERANGE     (-34)
+
+/* where a caller buffer lives */
+#define C8P_MEM_HOST    0
+#define C8P_MEM_DEVICE  1
+
+/* packet formats: lib/cloud80211phy.h:35-40 */
+#define C8P_F_L         0
+#define C8P_F_HT        1
+#define C8P_F_VHT       2
+#define C8P_F_VHT_CHAN  20
+/* coding rates: lib/cloud80211phy.h:46-49 */
+#define C8P_CR_12 0
+#define C8P_CR_23 1
+#define C8P_CR_34 2
+#define C8P_CR_56 3
+
+/* limits: lib/decode_impl.h:35-36, lib/cloud80211phy.h:29-31 */
+#define C8P_DECODE_B_MAX   4095
+#define C8P_DECODE_T_MAX   32782
+#define C8P_MAX_N_CBPSS    416
+#define C8P_NDP_TOTAL      1024
+#define C8P_NDP_BLOB_BYTES 1027
+
+/* per-packet status after demod (which reference state ended the packet) */
+#define C8P_ST_OK            0   /* tags written, LLRs (or the NDP dummy items) follow  */
+#define C8P_ST_REJ_VHT       1   /* DEMOD_S_VHT sanity check failed  demod_impl.cc:159-170 */
+#define C8P_ST_REJ_HT        2   /* DEMOD_S_HT sanity check failed   demod_impl.cc:186-198 */
+#define C8P_ST_REJ_SHORT     3   /* fewer items on the port than the state machine needs  */
+#define C8P_ST_REJ_UNSUP     4   /* reference behaviour undefined (stale state / unwritten output), see DESIGN.md */
+
+typedef struct { float re, im; } c8p_c32;   /* gr_complex */
+
+/*
+ * One packet at the signal -> demod boundary.  Fields = the tags written by
+ * signal_impl.cc:135-143 on the first item of the packet, plus where its items are.
+ */
+typedef struct c8p_pkt_in {
+  uint64_t iq_off[2];   /* item offset of the packet's first item inside the iq arena, per input port */
+  uint32_t n_items;     /* items present on each port for this packet (reference: nsamp + 320)         */
+  uint32_t chan_off;    /* item offset of chan[64] (tag "chan", FFT order) inside the chan arena       */
+  int32_t  lsig_mcs;    /* tag "mcs"   L-SIG rate index 0..7                                           */
+  int32_t  lsig_len;    /* tag "len"   L-SIG LENGTH                                                    */
+  int32_t  lsig_nsamp;  /* tag "nsamp"                                                                 */
+  int32_t  seq;         /* tag "seq"                                                                   */
+  float    cfo;         /* tag "cfo"                                                                   */
+  float    snr;         /* tag "snr"                                                                   */
+  float    rssi;        /* tag "rssi"                                                                  */
+  uint8_t  n_ant;       /* 1: demod (1 port), 2: demod2 (2 ports)                                      */
+  uint8_t  mupos;       /* demod::make(mupos, mugid): MU-MIMO user position 0/1                        */
+  uint8_t  rsv[2];
+} c8p_pkt_in;
+
+/*
+ * demod -> decode tags (demod_impl.cc:224-253, demod2_impl.cc:230-250) plus the descriptor
+ * fields the engine keeps for the data path.
+ */
+typedef struct c8p_pkt_tags {
+  int32_t status;       /* C8P_ST_* ; tags below are valid only for C8P_ST_OK                          */
+  int32_t format;       /* tag "format"                                                                */
+  int32_t mcs;          /* tag "mcs"                                                                   */
+  int32_t len;          /* tag "len"                                                                   */
+  int32_t cr;           /* tag "cr"                                                                    */
+  int32_t ampdu;        /* tag "ampdu"                                                                 */
+  int32_t trellis;      /* tag "trellis"                                                               */
+  int32_t total;        /* tag "total"  = nSym*nCBPS, or 1024 for an NDP                               */
+  int32_t nsym, nss, nltf, ncbps, ncbpss, ndbps, nbpscs, nsymsamp;
+  int32_t sumu;         /* VHT MU flag                                                                 */
+  int32_t is_ndp;       /* nSym == 0: tag "mu2x1chan" present                                          */
+  int32_t data_off;     /* item offset of the first data symbol inside the packet                      */
+  int32_t seq;
+  float   cfo, snr, rssi;   /* tags "cfo","snr","rssi" (pass-through)                                  */
+  float   sssnr0, sssnr1;   /* tags "sssnr0"/"sssnr1" (VHT only)                                       */
+  uint32_t rsv;
+  uint64_t llr_off;     /* float offset of the packet's LLR items inside the LLR arena                 */
+} c8p_pkt_tags;
+
+/* decode result for one packet */
+typedef struct c8p_pkt_out {
+  int32_t  n_pdu;       /* PDUs published on port "out" for this packet (FCS-correct subframes / NDP report) */
+  int32_t  n_crc_fail;  /* (sub)frames whose CRC-32 residue was wrong                                   */
+  uint32_t pdu_bytes;   /* bytes used in this packet's PDU area: n_pdu records of {u16 len LE, len bytes} */
+  uint32_t rsv;
+  uint64_t pdu_off;     /* byte offset of the packet's PDU area inside the PDU arena                     */
+  uint64_t bits_off;    /* byte offset of the packet's decoded bits (1 bit per byte) inside the bits arena */
+} c8p_pkt_out;
+
+typedef struct c8p_cfg {
+  int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
+  int32_t device;           /* HIP device ordinal                                                      */
+  int32_t profile;          /* 1: bracket every kernel with HIP events (c8p_kernel_time)               */
+  int32_t keep_bits;        /* 1: also store descrambled bits (v_unCodedBits) and v_scramBits          */
+  void*   stream;           /* hipStream_t to launch on; NULL = engine-owned stream                    */
+} c8p_cfg;
+
+typedef struct c8p_batch_in {
+  int32_t n_pkt;
+  int32_t mem;              /* C8P_MEM_* of pkts, iq and chan (all three the same)                     */
+  const c8p_pkt_in* pkts;   /* [n_pkt]                                                                 */
+  const c8p_c32*    iq;     /* iq arena                                                                */
+  uint64_t          n_iq;   /* items in the iq arena                                                   */
+  const c8p_c32*    chan;   /* chan arena                                                              */
+  uint64_t          n_chan; /* items in the chan arena                                                 */
+} c8p_batch_in;
+
+typedef struct c8p_decode_in {
+  int32_t n_pkt;
+  int32_t mem;              /* C8P_MEM_* of tags, llr and mu2x1chan                                    */
+  const c8p_pkt_tags* tags; /* [n_pkt]  llr_off locates each packet's `total` items                    */
+  const float*   llr;       /* LLR arena (reference demod output stream layout)                        */
+  uint64_t       n_llr;
+  const c8p_c32* mu2x1chan; /* [n_pkt][128] tag "mu2x1chan" (only read for NDP packets); may be NULL   */
+} c8p_decode_in;
+
+/* result arenas (device memory, engine-owned) */
+#define C8P_BUF_TAGS   0    /* c8p_pkt_tags[n_pkt]                    */
+#define C8P_BUF_LLR    1    /* float, per packet at tags[p].llr_off   */
+#define C8P_BUF_OUT    2    /* c8p_pkt_out[n_pkt]                     */
+#define C8P_BUF_PDU    3    /* bytes, per packet at out[p].pdu_off    */
+#define C8P_BUF_BITS   4    /* bytes (keep_bits), descrambled bits    */
+#define C8P_BUF_SBITS  5    /* bytes (keep_bits), bits before descrambling */
+#define C8P_BUF_MUCHAN 6    /* c8p_c32[n_pkt][128] NDP time-domain LTF capture */
+
+/* kernels, for c8p_kernel_time() */
+#define C8P_K_LAYOUT   0
+#define C8P_K_CLASSIFY 1
+#define C8P_K_DEMOD    2
+#define C8P_K_VITERBI  3
+#define C8P_K_FINISH   4
+#define C8P_K_COUNT    5
+
+typedef struct c8p_ctx c8p_ctx;
+
+c8p_ctx* c8p_create(const c8p_cfg* cfg);
+void     c8p_destroy(c8p_ctx* ctx);
+const char* c8p_last_error(const c8p_ctx* ctx);
+
+/* Enqueue on the ctx stream; return before the GPU work is done. */
+int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCHAN              */
+int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
+int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */
+int c8p_sync  (c8p_ctx* ctx);
+
+/* Device pointer / size in bytes of a result arena of the last submit. */
+const void* c8p_buffer(c8p_ctx* ctx, int which, uint64_t* bytes);
+/* Copy [offset, offset+bytes) of a result arena to host memory (synchronises the stream). */
+int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
+
+/* profile=1: accumulated HIP-event time and launch count of one kernel since the last reset. */
+int c8p_kernel_time(c8p_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
+int c8p_profile_reset(c8p_ctx* ctx);
+
+/* Constant tables the engine generated (for tests): returns element count, copies at most cap ints. */
+#define C8P_TAB_DEINT_L      0   /* + nbpsc index 0..3 (1,2,4,6)  in `sub`  */
+#define C8P_TAB_DEINT_NL     1   /* + nbpsc index 0..4 (1,2,4,6,8)           */
+#define C8P_TAB_DEINT_NL2    2
+#define C8P_TAB_SIG_DEMAP_NL 3
+#define C8P_TAB_DEINT_SIGB   4
+#define C8P_TAB_SV_OUT       5
+#define C8P_TAB_PILOT_P      6   /* as ints +1/-1 */
+#define C8P_TAB_LTF_NL       7   /* as ints +1/-1/0 */
+#define C8P_TAB_LTF_NL_VHT22 8
+int c8p_table(int which, int sub, int32_t* dst, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C8P_RX_H */

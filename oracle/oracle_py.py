@@ -1,0 +1,134 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.c8po_init()
+        L.c8po_cabsf.restype = C.c_float
+        L.c8po_crc32.restype = C.c_uint32
+        L.c8po_rx_batch.restype = C.c_long
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def table(which, sub=0):
+    buf = np.zeros(512, np.int32)
+    n = lib().c8po_table(which, sub, _p(buf), 512)
+    assert n >= 0
+    return buf[:n].copy()
+
+
+def fft64(x):
+    x = np.ascontiguousarray(x, np.complex64)
+    out = np.zeros(64, np.complex64)
+    lib().c8po_fft64(_p(x), _p(out))
+    return out
+
+
+def signal(raw):
+    """raw: complex64 starting at the sync index (LTF start + 24), >= 224 items."""
+    raw = np.ascontiguousarray(raw[:224], np.complex64)
+    h = np.zeros(64, np.complex64)
+    mcs, ln, ns = C.c_int(0), C.c_int(0), C.c_int(0)
+    llr = np.zeros(48, np.float32)
+    bits = np.zeros(24, np.uint8)
+    ok = lib().c8po_signal(_p(raw), _p(h), C.byref(mcs), C.byref(ln), C.byref(ns), _p(llr), _p(bits))
+    return bool(ok), h, mcs.value, ln.value, ns.value, llr, bits
+
+
+def sig_viterbi(llr, L):
+    llr = np.ascontiguousarray(llr, np.float32)
+    bits = np.zeros(L, np.uint8)
+    lib().c8po_sig_viterbi(_p(llr), _p(bits), L)
+    return bits
+
+
+def viterbi(llr, trellis, cr):
+    llr = np.ascontiguousarray(llr, np.float32)
+    sb = np.zeros(trellis, np.uint8)
+    used = lib().c8po_viterbi(_p(llr), len(llr), trellis, cr, _p(sb))
+    return sb, used
+
+
+def descramble(sbits):
+    sbits = np.ascontiguousarray(sbits, np.uint8)
+    out = np.zeros(len(sbits), np.uint8)
+    lib().c8po_descramble(_p(sbits), len(sbits), _p(out))
+    return out
+
+
+def demod(pkts, iq, chan, p):
+    """Run the demod oracle on packet p of a batch. Returns (tags record, llr[total], mu2x1chan[128])."""
+    from_abi = _abi()
+    tags = np.zeros(1, from_abi.PKT_TAGS_DT)
+    n_items = int(pkts[p]["n_items"])
+    llr = np.zeros((n_items // 72 + 1) * 832 + 1024, np.float32)
+    mu = np.zeros(128, np.complex64)
+    lib().c8po_demod(C.c_void_p(pkts.ctypes.data + p * pkts.dtype.itemsize), _p(iq), _p(chan), _p(tags), _p(llr), _p(mu))
+    total = int(tags[0]["total"]) if tags[0]["status"] == 0 else 0
+    return tags[0], llr[:total].copy(), mu
+
+
+def decode(tag, llr, mu=None, pdu_cap=1 << 15):
+    from_abi = _abi()
+    t = np.zeros(1, from_abi.PKT_TAGS_DT)
+    t[0] = tag
+    T = max(int(t[0]["trellis"]), 1)
+    sb = np.zeros(T, np.uint8)
+    ub = np.zeros(T + 8, np.uint8)
+    pdu = np.zeros(pdu_cap, np.uint8)
+    out = np.zeros(1, from_abi.PKT_OUT_DT)
+    llr = np.ascontiguousarray(llr, np.float32)
+    mup = _p(np.ascontiguousarray(mu, np.complex64)) if mu is not None else None
+    lib().c8po_decode(_p(t), _p(llr), mup, _p(sb), _p(ub), _p(pdu), pdu_cap, _p(out))
+    pdus = from_abi.split_pdus(pdu.tobytes(), int(out[0]["n_pdu"]))
+    return out[0], pdus, sb, ub[:T]
+
+
+def rx_batch(pkts, iq, chan, pdu_stride=8192):
+    from_abi = _abi()
+    n = len(pkts)
+    tags = np.zeros(n, from_abi.PKT_TAGS_DT)
+    outs = np.zeros(n, from_abi.PKT_OUT_DT)
+    pdu = np.zeros(n * pdu_stride, np.uint8)
+    npdu = lib().c8po_rx_batch(_p(pkts), n, _p(iq), _p(chan), _p(tags), _p(outs), _p(pdu), pdu_stride)
+    return tags, outs, pdu, npdu
+
+
+def _abi():
+    import importlib.util
+    import sys
+    if "gr_ieee80211_amd" in sys.modules:
+        return sys.modules["gr_ieee80211_amd"].abi
+    root = os.path.dirname(_HERE)
+    pkg = os.path.join(root, "gr-ieee80211_amd")
+    spec = importlib.util.spec_from_file_location("gr_ieee80211_amd", os.path.join(pkg, "__init__.py"),
+                                                  submodule_search_locations=[pkg])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["gr_ieee80211_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod.abi

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite only read
+the files this script wrote.  Nothing of the reference's source text is stored: the outputs are
+ (a) vectors produced by *importing and running* the reference's Python toolbox
+     (tools/phy80211.py, phy80211header.py, mac80211.py) — TX IQ, PSDU bytes, coded bits, Viterbi
+     decisions, CRC-8 values, scrambler output, interleaver permutations;
+ (b) SHA-256 digests of the literal constant tables in lib/cloud80211phy.cc (digest only).
+
+    MPLBACKEND=Agg python tests/golden/gen_golden.py
+"""
+import hashlib
+import json
+import os
+import re
+import sys
+import zlib
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REF, "tools"))
+os.environ.setdefault("MPLBACKEND", "Agg")
+import mac80211          # noqa: E402
+import phy80211          # noqa: E402
+import phy80211header as p8h  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+MULT = 12.0   # tools/pktGenExample.py:187
+
+
+# ----------------------------------------------------------------------------- (b) table digests
+def table_digests():
+    src = open(os.path.join(REF, "lib", "cloud80211phy.cc")).read()
+    names_int = ["SV_PUNC_12", "SV_PUNC_23", "SV_PUNC_34", "SV_PUNC_56", "SV_STATE_NEXT", "SV_STATE_OUTPUT",
+                 "mapDeintLegacyBpsk", "mapDeintLegacyQpsk", "mapDeintLegacy16Qam", "mapDeintLegacy64Qam",
+                 "mapDeintNonlegacyBpsk", "mapDeintNonlegacyQpsk", "mapDeintNonlegacy16Qam",
+                 "mapDeintNonlegacy64Qam", "mapDeintNonlegacy256Qam",
+                 "mapDeintNonlegacyBpsk2", "mapDeintNonlegacyQpsk2", "mapDeintNonlegacy16Qam2",
+                 "mapDeintNonlegacy64Qam2", "mapDeintNonlegacy256Qam2",
+                 "mapDeintVhtSigB20", "mapIntelVhtSigB20", "FFT_NL_SIG_DEMAP", "FFT_L_SIG_DEMAP", "C8P_LEGACY_D_SC"]
+    names_flt = ["PILOT_P", "PILOT_L", "PILOT_HT_1", "PILOT_HT_2_1", "PILOT_HT_2_2", "PILOT_VHT",
+                 "LTF_L_26_F_FLOAT", "LTF_L_26_F_FLOAT2", "LTF_NL_28_F_FLOAT", "LTF_NL_28_F_FLOAT_VHT22",
+                 "LTF_NL_28_F_FLOAT2"]
+    out = {}
+    for name, kind in [(n, "i") for n in names_int] + [(n, "f") for n in names_flt]:
+        m = re.search(r"const\s+(?:int|float)\s+" + re.escape(name) + r"\s*(?:\[[^\]]*\])+\s*=\s*\{(.*?)\};", src, re.S)
+        assert m, name
+        body = re.sub(r"//[^\n]*", "", m.group(1))
+        toks = re.findall(r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?f?", body)
+        vals = [float(t.rstrip("f")) for t in toks]
+        arr = np.array(vals, np.float32 if kind == "f" else np.int32)
+        out[name] = {"n": int(arr.size), "dtype": "f32" if kind == "f" else "i32",
+                     "sha256": hashlib.sha256(arr.tobytes()).hexdigest()}
+    return out
+
+
+# ----------------------------------------------------------------------------- (a) small function vectors
+def small_vectors(rng):
+    v = {}
+    # CRC-8 of the SIG fields: genBitBitCrc8 (phy80211header.py:87)
+    bits = rng.integers(0, 2, size=(16, 34)).astype(np.uint8)
+    v["crc8_in"] = bits
+    v["crc8_out"] = np.array([p8h.genBitBitCrc8([int(b) for b in row]) for row in bits], np.uint8)
+    # scrambler sequence (procScramble :800) for all 127 seeds on zeros = the sequence itself
+    v["scr_seed"] = np.arange(1, 128, dtype=np.int32)
+    v["scr_seq"] = np.array([p8h.procScramble([0] * 140, int(s)) for s in range(1, 128)], np.uint8)
+    # BCC + puncture of random bits (procBcc :763)
+    msg = rng.integers(0, 2, size=120).astype(np.uint8)
+    v["bcc_in"] = msg
+    for cr, nm in [(p8h.CR.CR12, "12"), (p8h.CR.CR23, "23"), (p8h.CR.CR34, "34"), (p8h.CR.CR56, "56")]:
+        v["bcc_" + nm] = np.array(p8h.procBcc([int(b) for b in msg], cr), np.uint8)
+    # interleaver permutations (procInterleaveLegacy :851, procInterleaveNonLegacy :868) applied to an index ramp
+    for mcs in (0, 2, 4, 6):
+        mod = p8h.modulation(p8h.F.L, mcs, p8h.BW.BW20, 1, False)
+        mod.nSym = 1
+        ramp = [list(range(mod.nCBPS))]
+        v["intl_L_%d" % mod.nBPSCS] = np.array(p8h.procInterleaveLegacy(ramp, mod)[0], np.int32)
+    for mcs in (0, 1, 3, 5, 8):
+        for nss in (1, 2):
+            mod = p8h.modulation(p8h.F.VHT, mcs, p8h.BW.BW20, nss, False)
+            mod.nSym = 1
+            ramp = [list(range(mod.nCBPSS)) for _ in range(nss)]
+            r = p8h.procInterleaveNonLegacy(ramp, mod)
+            for s in range(nss):
+                v["intl_NL_%d_ss%d_of%d" % (mod.nBPSCS, s, nss)] = np.array(r[s], np.int32)
+    # QAM map tables (C_QAM_MODU_TAB) so the demapper's sign conventions can be checked
+    for idx, nm in [(0, "bpsk"), (2, "qpsk"), (3, "16qam"), (4, "64qam"), (5, "256qam")]:
+        v["qam_" + nm] = np.array(p8h.C_QAM_MODU_TAB[idx], np.complex64)
+    return v
+
+
+def viterbi_vectors(rng):
+    """procViterbiDecoder (phy80211header.py:980-1045) on LLRs quantised to 1/8 so that double (Python)
+    and float32 (C++/HIP) path metrics are both exact — ties included."""
+    v = {}
+    crs = [(p8h.CR.CR12, 0), (p8h.CR.CR23, 1), (p8h.CR.CR34, 2), (p8h.CR.CR56, 3)]
+    k = 0
+    for cr, cri in crs:
+        for mode in ("coded", "random", "coarse"):
+            T = int(rng.integers(180, 420))
+            msg = list(rng.integers(0, 2, size=T - 6)) + [0] * 6
+            coded = np.array(p8h.procBcc([int(b) for b in msg], cr), np.float64)
+            if mode == "coded":
+                llr = (2 * coded - 1) * 2.0 + rng.normal(0, 1.6, size=coded.size)
+                llr = np.clip(np.round(llr * 8) / 8, -7.875, 7.875)
+            elif mode == "random":
+                llr = np.round(rng.uniform(-4, 4, size=coded.size) * 8) / 8
+            else:   # very coarse: integers in {-1,0,1} → ties everywhere
+                llr = rng.integers(-1, 2, size=coded.size).astype(np.float64)
+            bits = p8h.procViterbiDecoder([float(x) for x in llr], T, cr)
+            v["vit%d_llr" % k] = llr.astype(np.float32)
+            v["vit%d_T" % k] = np.int32(T)
+            v["vit%d_cr" % k] = np.int32(cri)
+            v["vit%d_bits" % k] = np.array(bits, np.uint8)
+            k += 1
+    v["n"] = np.int32(k)
+    return v
+
+
+# ----------------------------------------------------------------------------- (a) packets from the reference TX
+def mpdu_bytes(rng, n):
+    body = bytes(rng.integers(0, 256, size=n - 4, dtype=np.uint8))
+    return body + zlib.crc32(body).to_bytes(4, "little")
+
+
+def gen_packet(fmt, mcs, nss, mpdu, rng):
+    ins = phy80211.phy80211(ifDebug=False)
+    if fmt == "L":
+        mod = p8h.modulation(p8h.F.L, mcs, p8h.BW.BW20, 1, False)
+        ins.genFromMpdu(mpdu, mod)
+        psdu = mpdu
+    elif fmt == "HT":
+        mod = p8h.modulation(p8h.F.HT, mcs, p8h.BW.BW20, nss, False)
+        ins.genFromMpdu(mpdu, mod)
+        psdu = mpdu
+    else:
+        mod = p8h.modulation(p8h.F.VHT, mcs, p8h.BW.BW20, nss, False)
+        psdu = mac80211.genAmpduVHT([mpdu]) if len(mpdu) else b""
+        ins.genFromAmpdu(psdu, mod, vhtPartialAid=0, vhtGroupId=0)
+    assert mod.initRes
+    mult = MULT * (np.sqrt(2) if nss == 2 else 1.0)     # pktGenExample.py:187,210
+    sig = ins.genFinalSig(multiplier=mult, cfoHz=0.0, num=1, gap=False, gapLen=0)
+    tx = np.array(sig, np.complex64)
+    coded = np.array(ins.esCodedBits[0], np.uint8) if len(mpdu) else np.zeros(0, np.uint8)
+    fcode = {"L": 0, "HT": 1, "VHT": 2}[fmt]
+    if len(mpdu):
+        pdu = bytes([fcode, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs])
+    else:
+        pdu = b""
+    return {"tx": tx, "mpdu": np.frombuffer(mpdu, np.uint8), "pdu": np.frombuffer(pdu, np.uint8),
+            "coded": coded, "fmt": np.int32(fcode), "mcs": np.int32(mcs), "nss": np.int32(nss),
+            "nsym": np.int32(ins.m.nSym), "psdu_len": np.int32(len(psdu)),
+            "lsig_len": np.int32(ins.m.legacyLen)}
+
+
+def gen_mu(rng):
+    """SURVEY Appendix B config-5 loop: NDP -> per-station feedback (reference Python) -> ZF Q
+    (tools/cmu_v3/cmu_ap.py:182-189) -> 2-user MU packet (genAmpduMu)."""
+    h = np.array([[1 + 0.2j, 0.5 - 0.4j], [0.3 + 0.6j, -0.9 + 0.1j]], np.complex64)
+    ndp = gen_packet("VHT", 0, 2, b"", rng)
+    tx = ndp["tx"]
+    vfb = []
+    for u in range(2):
+        rx = h[u, 0] * tx[0] + h[u, 1] * tx[1]
+        base = 184 + 224 + 240          # sync + consumed-by-signal + (SIG-A 160 + STF 80)
+        chan = [complex(x) for x in rx[base + 8: base + 72]] + [complex(x) for x in rx[base + 88: base + 152]]
+        ltf = []
+        for k in range(2):
+            ltf.append(p8h.procRemovePilots(p8h.procToneDescaling(p8h.procRmDcNonDataSc(
+                p8h.procFftDemod(chan[64 * k:64 * k + 64]), p8h.F.VHT),
+                p8h.C_SCALENTF_LTF_VHT[p8h.BW.BW20.value], 2)))
+        vfb.append(p8h.procVhtChannelFeedback(ltf, p8h.BW.BW20, 2, 1))
+    bfQ = []
+    for k in range(len(vfb[0])):
+        H11, H21 = vfb[0][k][0][0][0], vfb[0][k][0][0][1]
+        H12, H22 = vfb[1][k][0][0][0], vfb[1][k][0][0][1]
+        d1 = np.sqrt(abs(H21) ** 2 + abs(H11) ** 2)
+        d2 = np.sqrt(abs(H22) ** 2 + abs(H12) ** 2)
+        bfQ.append(np.array([[-1 * H22 / d2, -1 * H21 / d1], [H12 / d2, H11 / d1]]))
+    one = np.ones_like(bfQ[0])
+    bfQf = [one] * 4 + bfQ[0:28] + [one] + bfQ[28:56] + [one] * 3
+    m0, m1 = mpdu_bytes(rng, 100), mpdu_bytes(rng, 60)
+    ins = phy80211.phy80211(ifDebug=False)
+    ins.genAmpduMu(nUser=2, bfQ=bfQf, groupId=2,
+                   ampdu0=mac80211.genAmpduVHT([m0]), mod0=p8h.modulation(p8h.F.VHT, 3, p8h.BW.BW20, 1, False),
+                   ampdu1=mac80211.genAmpduVHT([m1]), mod1=p8h.modulation(p8h.F.VHT, 3, p8h.BW.BW20, 1, False))
+    sig = ins.genFinalSig(multiplier=MULT * np.sqrt(2), cfoHz=0.0, num=1, gap=False, gapLen=0)
+    mu_tx = np.array(sig, np.complex64)
+    return {"h": h, "ndp_tx": tx, "mu_tx": mu_tx,
+            "mpdu0": np.frombuffer(m0, np.uint8), "mpdu1": np.frombuffer(m1, np.uint8),
+            "pdu0": np.frombuffer(bytes([2, 100, 0]) + m0 + bytes([3]), np.uint8),
+            "pdu1": np.frombuffer(bytes([2, 60, 0]) + m1 + bytes([3]), np.uint8),
+            "lsig_len": np.int32(ins.m.legacyLen)}
+
+
+def flat(prefix, d):
+    return {prefix + "/" + k: v for k, v in d.items()}
+
+
+def main():
+    rng = np.random.default_rng(80211)
+    json.dump(table_digests(), open(os.path.join(OUT, "table_digests.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **small_vectors(rng))
+    np.savez_compressed(os.path.join(OUT, "viterbi_vectors.npz"), **viterbi_vectors(rng))
+
+    # BASELINE.json configs
+    cfg = {}
+    body = bytes([(5 * i + 1) & 255 for i in range(96)])
+    cfg.update(flat("cfg1_L_mcs0_100B", gen_packet("L", 0, 1, body + zlib.crc32(body).to_bytes(4, "little"), rng)))
+    for p in range(4):
+        r = np.random.default_rng(8021100 + p)
+        cfg.update(flat("cfg2_VHT_mcs7_1458B_%d" % p, gen_packet("VHT", 7, 1, mpdu_bytes(r, 1458), r)))
+    cfg.update(flat("cfg3_HT_mcs15_2x2_1458B", gen_packet("HT", 15, 2, mpdu_bytes(rng, 1458), rng)))
+    cfg.update(flat("cfg4_VHT_mcs8_1458B", gen_packet("VHT", 8, 1, mpdu_bytes(rng, 1458), rng)))
+    np.savez_compressed(os.path.join(OUT, "packets_cfg.npz"), **cfg)
+
+    # every supported MCS with a short MPDU
+    sweep = {}
+    for mcs in range(8):
+        sweep.update(flat("L_%d" % mcs, gen_packet("L", mcs, 1, mpdu_bytes(rng, 40 + mcs), rng)))
+    for mcs in range(8):
+        sweep.update(flat("HT_%d" % mcs, gen_packet("HT", mcs, 1, mpdu_bytes(rng, 40 + mcs), rng)))
+    for mcs in range(9):
+        sweep.update(flat("VHT_%d" % mcs, gen_packet("VHT", mcs, 1, mpdu_bytes(rng, 40 + mcs), rng)))
+    for mcs in range(8, 16):
+        sweep.update(flat("HT2_%d" % mcs, gen_packet("HT", mcs, 2, mpdu_bytes(rng, 40 + mcs), rng)))
+    for mcs in range(9):
+        sweep.update(flat("VHT2_%d" % mcs, gen_packet("VHT", mcs, 2, mpdu_bytes(rng, 40 + mcs), rng)))
+    sweep.update(flat("VHT_NDP", gen_packet("VHT", 0, 2, b"", rng)))
+    np.savez_compressed(os.path.join(OUT, "packets_sweep.npz"), **sweep)
+
+    np.savez_compressed(os.path.join(OUT, "packets_mu.npz"), **gen_mu(rng))
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
