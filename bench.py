@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — RX packets/s of the demod+decode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of c8p_rx() over one batch of BASELINE.json configs[1]: 4096 packets of 20 MHz VHT MCS7,
+1458-byte MPDU (46 OFDM symbols, 4400 complex64 boundary items, 11960 trellis steps each).  The batch (IQ + legacy
+channel estimates) is resident in HBM before the timed region; packet descriptors (48 B each) are host structs, as
+they are in the GNU Radio block, and their upload is inside the timed region.  Packets are independent, so N GPUs
+each take their own batch (weak scaling, no data-path collective); the only collectives are the barrier and the
+MAX-reduction of the elapsed time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+B_ALG = 8 * 4400 + 512 + 32 + 1462       # algorithmic bytes per packet, SURVEY.md §8(d) = 37 206
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
+    ap.add_argument("--snr", type=float, default=30.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from c8p_cases import cfg2_batch
+    from c8p_testlib import abi
+    from gr_ieee80211_amd import engine
+
+    # ---- synthetic workload (host), then resident in HBM
+    t_gen = time.time()
+    b, expected = cfg2_batch(args.batch, snr_db=args.snr, seed=8021200 + 100000 * rank)
+    pk, iq, chan = b.arrays()
+    n_pkt = len(pk)
+    iq_d = torch.from_numpy(iq.view(np.float32)).to(dev)
+    chan_d = torch.from_numpy(chan.view(np.float32)).to(dev)
+    iq_dev = engine.DevArray(iq_d.data_ptr(), iq.size, iq_d)
+    chan_dev = engine.DevArray(chan_d.data_ptr(), chan.size, chan_d)
+    t_gen = time.time() - t_gen
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    eng = engine.Engine(device=local, profile=True, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.rx(pk, iq_dev, chan_dev)
+    eng.sync()
+    # correctness gate (outside the timed region): every published PDU is the transmitted MPDU
+    res = eng.results(want_llr=False)
+    n_ok = 0
+    for r, e in zip(res, expected):
+        if r["pdus"]:
+            assert r["pdus"] == [e], "PDU mismatch"
+            n_ok += 1
+    eng.profile_reset()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.rx(pk, iq_dev, chan_dev)
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kt = eng.kernel_times()
+
+    out = None
+    if rank == 0:
+        total_pkts = n_pkt * world * args.steps
+        value = total_pkts / elapsed
+        kern = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in kt.items()}
+        dom = max(("classify", "demod_sym", "viterbi_fwd", "finish"), key=lambda k: kern[k])
+        dom_s = kern[dom] * 1e-3
+        achieved = (B_ALG * n_pkt / dom_s) / 1e9 if dom_s > 0 else 0.0
+        out = {
+            "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": value, "unit": "packets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU, %d packets/GPU/step, "
+                                   "AWGN %.0f dB, random-phase flat channel" % (n_pkt, args.snr),
+                       "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1),
+                       "parallelism": "packet-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_packet": B_ALG, "packets_per_launch": n_pkt,
+                         "avg_launch_ms": {k: round(v, 4) for k, v in kern.items()}},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
+            out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(pk, iq, chan, budget_s=12.0):
+    """The oracle (scalar CPU restatement, "port") timed on one host core over a bounded sample of the same batch."""
+    from c8p_testlib import oracle
+    o = oracle()
+    t = time.perf_counter()
+    o.rx_batch(pk[:8], iq, chan)
+    per = (time.perf_counter() - t) / 8
+    n = int(max(16, min(len(pk), budget_s / max(per, 1e-6))))
+    t = time.perf_counter()
+    _, outs, _, npdu = o.rx_batch(pk[:n], iq, chan)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "packets/s", "cores": 1, "kind": "port",
+            "sample": "first %d packets of the same batch, oracle demod+decode, 1 thread, %.1f s, %d PDUs" % (n, dt, npdu)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+// c8p_dev.h — device-side structures and arithmetic helpers shared by the gfx950 kernels.
+//
+// Arithmetic contract (DESIGN.md "Arithmetic model"): float32 everywhere, no FMA contraction
+// (-ffp-contract=off), complex*complex as (ac-bd, ad+bc), complex/complex evaluated in double and
+// rounded once (what libgcc's __divsc3 does for the reference build), |z| = (float)sqrt((double)x*x+(double)y*y).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "c8p_rx.h"
+
+#define C8P_NEG_INIT (-1000000000000000.0f)   // decode_impl.cc:174
+#define C8P_WAVE 64
+
+typedef float2 cf;
+
+struct PktLayout {          // per-packet placement inside the engine arenas (written by k_layout)
+  uint64_t llr_off;         // floats
+  uint64_t surv_off;        // ulonglong2 entries
+  uint64_t bits_off;        // bytes
+  uint64_t pdu_off;         // bytes
+  uint32_t sym_base;        // first symbol-wave of this packet in k_demod_sym's grid
+  uint32_t nsym_bound;
+  uint32_t pdu_cap;
+  uint32_t trellis_cap;
+};
+
+struct Mimo {               // demod2_impl.h:95-105
+  cf H[64][4];
+  cf INV[64][4];
+  cf pil1[4], pil2[4];
+};
+
+struct DevTables {
+  int16_t deintL[4][288];         // mapDeintLegacy*      cloud80211phy.cc:1413-1500
+  int16_t deintNL[5][416];        // mapDeintNonlegacy*   :1711-1831
+  int16_t deint2ss[2][5][416];    // de-interleave (stream 1 / stream 2 map) fused with procSymDepasNL :2442
+  int8_t  sigDemapNL[128];        // FFT_NL_SIG_DEMAP :31
+  int8_t  deintSigB[52];          // mapDeintVhtSigB20 :1503
+  int8_t  intlSigB[52];           // mapIntelVhtSigB20
+  float   pilotP[127];            // PILOT_P :160
+  float   ltfNL[64];              // LTF_NL_28_F_FLOAT :113
+  float   ltfNLvht22[64];         // LTF_NL_28_F_FLOAT_VHT22 :131
+  float2  tw[32];                 // e^{-j 2 pi k / 64}, k = 0..31
+  uint8_t bitrev6[64];
+  uint8_t scrSeq[127];            // x^7+x^4+1 sequence from the all-ones state
+  uint8_t scrPhase[128];          // phase of a 7-bit state inside scrSeq
+  uint32_t crc32[256];
+  uint32_t x2n[32];               // x^(2^n) mod P, reflected CRC-32 domain
+};
+
+// ---------------------------------------------------------------------------------------------- complex helpers
+__device__ __forceinline__ cf mk(float a, float b) { return make_float2(a, b); }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cneg(cf a) { return mk(-a.x, -a.y); }
+__device__ __forceinline__ cf cconj(cf a) { return mk(a.x, -a.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cmulf(cf a, float f) { return mk(a.x * f, a.y * f); }
+__device__ __forceinline__ cf cdivf(cf a, float f) { return mk(a.x / f, a.y / f); }
+__device__ __forceinline__ cf cdiv(cf a, cf b)
+{
+  double aa = a.x, bb = a.y, cc = b.x, dd = b.y;
+  double denom = (cc * cc) + (dd * dd);
+  double x = ((aa * cc) + (bb * dd)) / denom;
+  double y = ((bb * cc) - (aa * dd)) / denom;
+  return mk((float)x, (float)y);
+}
+__device__ __forceinline__ float cabs_(cf a)
+{
+  double x = a.x, y = a.y;
+  return (float)sqrt(x * x + y * y);
+}
+
+// ---------------------------------------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ cf shfl_c(cf v, int src) { return mk(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); }
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// lane l keeps `val` (wave-uniform), the others keep `old`; no writelane builtin in this toolchain
+__device__ __forceinline__ unsigned long long writelane_u64(unsigned long long val, int l, unsigned long long old)
+{
+  return lane_id() == l ? val : old;
+}
+
+// 64-point forward DFT across the 64 lanes of a wave: lane n holds x[n] on entry, X[n] on return.
+// Radix-2 decimation-in-frequency, 6 exchange stages, bit-reversal at the end.
+__device__ __forceinline__ cf wave_fft64(cf x, const DevTables* __restrict__ T)
+{
+  const int lane = lane_id();
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    const int half = 32 >> s;
+    cf xp = mk(__shfl_xor(x.x, half, 64), __shfl_xor(x.y, half, 64));
+    const bool up = (lane & half) != 0;
+    cf y;
+    if (!up) {
+      y = cadd(x, xp);
+    } else {
+      cf d = csub(xp, x);
+      const int e = (lane & (half - 1)) << s;
+      y = cmul(d, T->tw[e]);
+    }
+    x = y;
+  }
+  return shfl_c(x, T->bitrev6[lane]);
+}
+
+__device__ __forceinline__ bool is_null_nl(int i) { return i == 0 || (i >= 29 && i <= 35); }
+__device__ __forceinline__ bool is_null_l(int i) { return i == 0 || (i >= 27 && i <= 37); }
+__device__ __forceinline__ bool is_pilot(int i) { return i == 7 || i == 21 || i == 43 || i == 57; }
+// position j of FFT bin i in the q[] order of nonLegacyChanUpdate (demod_impl.cc:434-446): -28..-1 -> 0..25, +1..+28 -> 26..51
+__device__ __forceinline__ int qidx_nl(int i)
+{
+  return i <= 28 ? 26 + (i - 1 - (i > 7) - (i > 21)) : (i - 36 - (i > 43) - (i > 57));
+}
+__device__ __forceinline__ int qidx_l(int i)
+{
+  return i <= 26 ? 24 + (i - 1 - (i > 7) - (i > 21)) : (i - 38 - (i > 43) - (i > 57));
+}
+__device__ __forceinline__ int nbpsc_index(int nb)
+{
+  return nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 6 ? 3 : 4;
+}
+
+// branch-metric class of the transition into next-state n from predecessor 2(n&31)+j  (SV_STATE_OUTPUT :1877)
+__device__ __forceinline__ int sv_out(int i, int b)
+{
+  int x0 = b, x1 = (i >> 5) & 1, x2 = (i >> 4) & 1, x3 = (i >> 3) & 1, x5 = (i >> 1) & 1, x6 = i & 1;
+  int A = x0 ^ x2 ^ x3 ^ x5 ^ x6;
+  int B = x0 ^ x1 ^ x2 ^ x3 ^ x6;
+  return 2 * A + B;
+}
+__device__ __forceinline__ float bm_sel(int c, float t0, float t1, float t01)
+{
+  return c == 0 ? 0.0f : (c == 1 ? t1 : (c == 2 ? t0 : t01));
+}
+
+// One add-compare-select step for next-state = lane.  Exactly the reference recurrence
+// (decode_impl.cc:237-259) restated per next-state: candidates arrive in ascending predecessor order,
+// strict '>' against a -1e15 pre-fill.  Returns the new metric; take1 / none are the survivor facts.
+__device__ __forceinline__ float acs_step(float pre, int src0, int cA, int cB, float t0, float t1, bool& take1, bool& none)
+{
+  const float t01 = t1 + t0;
+  const float p0 = __shfl(pre, src0, 64);
+  const float p1 = __shfl(pre, src0 + 1, 64);
+  const float a0 = p0 + bm_sel(cA, t0, t1, t01);
+  const float a1 = p1 + bm_sel(cB, t0, t1, t01);
+  const float base = a0 > C8P_NEG_INIT ? a0 : C8P_NEG_INIT;
+  take1 = a1 > base;
+  const float cur = take1 ? a1 : base;
+  none = (cur == C8P_NEG_INIT);
+  return cur;
+}
+
+// Short rate-1/2 decoder of the SIG fields (svSigDecoder::decode cloud80211phy.cc:2001-2088), L <= 48.
+// llr in LDS (2L floats), bits out to LDS; w1/w0: 49-entry scratch in LDS.
+__device__ __forceinline__ void wave_sig_viterbi(const float* llr, uint8_t* bits, int L,
+                                                 unsigned long long* w1, unsigned long long* w0)
+{
+  const int lane = lane_id();
+  const int m = lane & 31, b = lane >> 5;
+  const int cA = sv_out(2 * m, b), cB = sv_out(2 * m + 1, b);
+  float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;
+  for (int t = 0; t < L; t++) {
+    bool take1, none;
+    pre = acs_step(pre, 2 * m, cA, cB, llr[2 * t], llr[2 * t + 1], take1, none);
+    unsigned long long b1 = __ballot(take1), b0 = __ballot(none);
+    if (lane == 0) { w1[t] = b1; w0[t] = b0; }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int st = 0;
+    for (int t = L - 1; t >= 0; t--) {
+      int prev = ((w0[t] >> st) & 1ull) ? 0 : (2 * (st & 31) + (int)((w1[t] >> st) & 1ull));
+      bits[t] = (st == ((prev >> 1) | 32)) ? 1 : 0;
+      st = prev;
+    }
+  }
+  __syncthreads();
+}

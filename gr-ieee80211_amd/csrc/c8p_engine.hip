@@ -1,0 +1,529 @@
+// c8p_engine.hip — host side of libc8p_rx.so: the C ABI of include/c8p_rx.h on top of the gfx950 kernels.
+//
+// One ctx owns a HIP stream (or borrows the caller's), the constant tables, and a set of device arenas that
+// only ever grow.  A submit computes the per-packet arena layout on the host from the packet descriptors
+// (sizes depend only on n_items / trellis, never on device results), uploads descriptors + layout in one pinned
+// staging copy, and enqueues the kernels back to back — no host round trip between them.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "c8p_kernels.h"
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return C8P_EHIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ tables
+// Generated from the 802.11 formulas, not copied; tests compare them with SHA-256
+// digests of the reference's literals and with the Python toolbox's interleavers.
+static void build_deint(int16_t* map, int ncbps, int nbpsc, int ncol, bool second_stream)
+{
+  const int s = std::max(nbpsc / 2, 1);
+  const int nrow = ncbps / ncol;
+  for (int k = 0; k < ncbps; k++) {
+    const int i = nrow * (k % ncol) + k / ncol;
+    const int j = s * (i / s) + (i + ncbps - (ncol * i) / ncbps) % s;
+    int r = j;
+    if (second_stream) r = ((j - 2 * 11 * nbpsc) % ncbps + ncbps) % ncbps;
+    map[r] = (int16_t)k;
+  }
+}
+
+static uint32_t h_multmodp(uint32_t a, uint32_t b)
+{
+  uint32_t m = 1u << 31, p = 0;
+  for (int i = 0; i < 32; i++) {
+    if (a & m) p ^= b;
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+  }
+  return p;
+}
+
+static const DevTables& host_tables()
+{
+  static DevTables T;
+  static bool init = false;
+  if (init) return T;
+  memset(&T, 0, sizeof(T));
+  static const int nbL[4] = {1, 2, 4, 6}, nbNL[5] = {1, 2, 4, 6, 8};
+  for (int m = 0; m < 4; m++) build_deint(T.deintL[m], 48 * nbL[m], nbL[m], 16, false);
+  int16_t ss2[416];
+  for (int m = 0; m < 5; m++) {
+    const int nb = nbNL[m], n = 52 * nb, sz = std::max(nb / 2, 1);
+    build_deint(T.deintNL[m], n, nb, 13, false);
+    build_deint(ss2, n, nb, 13, true);
+    // fuse procSymDepasNL: position r of stream ss lands at ((r / sz) * 2 + ss) * sz + r % sz
+    for (int i = 0; i < n; i++) {
+      const int r0 = T.deintNL[m][i], r1 = ss2[i];
+      T.deint2ss[0][m][i] = (int16_t)(((r0 / sz) * 2 + 0) * sz + r0 % sz);
+      T.deint2ss[1][m][i] = (int16_t)(((r1 / sz) * 2 + 1) * sz + r1 % sz);
+    }
+  }
+  for (int i = 0; i < 52; i++) { T.deintSigB[i] = (int8_t)T.deintNL[0][i]; }
+  for (int i = 0; i < 52; i++) { T.intlSigB[T.deintSigB[i]] = (int8_t)i; }
+  {
+    int rank = 0, dsc[64];
+    for (int i = 0; i < 64; i++) dsc[i] = -1;
+    for (int sc = -26; sc <= 26; sc++) {
+      if (sc == 0 || sc == -21 || sc == -7 || sc == 7 || sc == 21) continue;
+      dsc[(sc + 64) % 64] = rank++;
+    }
+    for (int i = 0; i < 64; i++) {
+      const int v = dsc[i] < 0 ? -1 : T.deintL[0][dsc[i]];
+      T.sigDemapNL[i] = (int8_t)v;
+      T.sigDemapNL[i + 64] = (int8_t)(v < 0 ? -1 : v + 48);
+    }
+  }
+  {
+    int st = 0x7f;
+    for (int k = 0; k < 128; k++) T.scrPhase[k] = 0;
+    for (int n = 0; n < 127; n++) {
+      T.scrPhase[st] = (uint8_t)n;
+      const int fb = ((st >> 6) & 1) ^ ((st >> 3) & 1);
+      T.scrSeq[n] = (uint8_t)fb;
+      T.pilotP[n] = fb ? -1.0f : 1.0f;
+      st = ((st << 1) & 0x7e) | fb;
+    }
+  }
+  {
+    static const signed char lltf[53] = {1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                                         1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1};
+    for (int sc = -26; sc <= 26; sc++) T.ltfNL[(sc + 64) % 64] = (float)lltf[sc + 26];
+    T.ltfNL[36] = 1; T.ltfNL[37] = 1; T.ltfNL[27] = -1; T.ltfNL[28] = -1;
+    for (int i = 0; i < 64; i++) T.ltfNLvht22[i] = T.ltfNL[i];
+    const int pil[4] = {7, 21, 43, 57};
+    for (int k = 0; k < 4; k++) T.ltfNLvht22[pil[k]] = -T.ltfNL[pil[k]];
+  }
+  for (int k = 0; k < 32; k++) {
+    const double a = 2.0 * M_PI * (double)k / 64.0;
+    T.tw[k] = make_float2((float)cos(a), (float)(-sin(a)));
+  }
+  T.tw[0] = make_float2(1.f, 0.f);
+  T.tw[16] = make_float2(0.f, -1.f);
+  for (int i = 0; i < 64; i++) {
+    int r = 0;
+    for (int b = 0; b < 6; b++) if (i & (1 << b)) r |= 1 << (5 - b);
+    T.bitrev6[i] = (uint8_t)r;
+  }
+  for (uint32_t n = 0; n < 256; n++) {
+    uint32_t c = n;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+    T.crc32[n] = c;
+  }
+  {
+    uint32_t p = 1u << 30;
+    T.x2n[0] = p;
+    for (int n = 1; n < 32; n++) T.x2n[n] = p = h_multmodp(p, p);
+  }
+  init = true;
+  return T;
+}
+
+extern "C" int c8p_table(int which, int sub, int32_t* dst, int cap)
+{
+  const DevTables& T = host_tables();
+  static const int nbL[4] = {1, 2, 4, 6}, nbNL[5] = {1, 2, 4, 6, 8};
+  std::vector<int32_t> v;
+  switch (which) {
+    case C8P_TAB_DEINT_L: if (sub < 0 || sub > 3) return C8P_EINVAL; for (int i = 0; i < 48 * nbL[sub]; i++) v.push_back(T.deintL[sub][i]); break;
+    case C8P_TAB_DEINT_NL: if (sub < 0 || sub > 4) return C8P_EINVAL; for (int i = 0; i < 52 * nbNL[sub]; i++) v.push_back(T.deintNL[sub][i]); break;
+    case C8P_TAB_DEINT_NL2: {
+      if (sub < 0 || sub > 4) return C8P_EINVAL;
+      // undo the fused stream de-parse to expose the plain stream-2 de-interleaver
+      const int nb = nbNL[sub], sz = std::max(nb / 2, 1);
+      for (int i = 0; i < 52 * nb; i++) { const int pos = T.deint2ss[1][sub][i]; v.push_back(((pos / sz - 1) / 2) * sz + pos % sz); }
+      break;
+    }
+    case C8P_TAB_SIG_DEMAP_NL: for (int i = 0; i < 128; i++) v.push_back(T.sigDemapNL[i]); break;
+    case C8P_TAB_DEINT_SIGB: for (int i = 0; i < 52; i++) v.push_back(T.deintSigB[i]); break;
+    case C8P_TAB_SV_OUT:
+      for (int i = 0; i < 64; i++) for (int b = 0; b < 2; b++) {
+        int x0 = b, x1 = (i >> 5) & 1, x2 = (i >> 4) & 1, x3 = (i >> 3) & 1, x5 = (i >> 1) & 1, x6 = i & 1;
+        v.push_back(2 * (x0 ^ x2 ^ x3 ^ x5 ^ x6) + (x0 ^ x1 ^ x2 ^ x3 ^ x6));
+      }
+      break;
+    case C8P_TAB_PILOT_P: for (int i = 0; i < 127; i++) v.push_back((int)T.pilotP[i]); break;
+    case C8P_TAB_LTF_NL: for (int i = 0; i < 64; i++) v.push_back((int)T.ltfNL[i]); break;
+    case C8P_TAB_LTF_NL_VHT22: for (int i = 0; i < 64; i++) v.push_back((int)T.ltfNLvht22[i]); break;
+    default: return C8P_EINVAL;
+  }
+  for (size_t i = 0; i < v.size() && (int)i < cap; i++) dst[i] = v[i];
+  return (int)v.size();
+}
+
+// ------------------------------------------------------------------------------------------------ ctx
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct c8p_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int profile = 0, keep_bits = 0;
+  std::string err;
+  DevTables* d_tab = nullptr;
+  // staging
+  void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
+  Buf d_stage;                                       // descriptors + layout (+ sym_base)
+  Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
+  // results / scratch
+  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu;
+  // last submit
+  int n_pkt = 0;
+  size_t used[7] = {0, 0, 0, 0, 0, 0, 0};
+  const void* ptr[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // profiling
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double k_ms[C8P_K_COUNT] = {0, 0, 0, 0, 0};
+  int64_t k_cnt[C8P_K_COUNT] = {0, 0, 0, 0, 0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
+{
+  if (bytes <= b.cap) return C8P_OK;
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return C8P_ENOMEM; }
+  b.cap = want;
+  return C8P_OK;
+}
+static int ensure_host(c8p_ctx* c, size_t bytes)
+{
+  if (bytes <= c->h_stage_cap) return C8P_OK;
+  if (c->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->h_stage)); c->h_stage = nullptr; }
+  size_t want = bytes + bytes / 4 + 4096;
+  HIPCHK(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+  c->h_stage_cap = want;
+  return C8P_OK;
+}
+
+static hipEvent_t get_event(c8p_ctx* c)
+{
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+struct KTimer {   // brackets one launch with events on the ctx stream when profiling is on
+  c8p_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr;
+  KTimer(c8p_ctx* c_, int k_) : c(c_), k(k_) { if (c->profile) { a = get_event(c); b = get_event(c); hipEventRecord(a, c->stream); } }
+  ~KTimer() { if (c->profile) { hipEventRecord(b, c->stream); c->pending.push_back({k, {a, b}}); } }
+};
+static void drain_events(c8p_ctx* c)
+{
+  for (auto& pe : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) { c->k_ms[pe.first] += ms; c->k_cnt[pe.first]++; }
+    c->ev_pool.push_back(pe.second.first); c->ev_pool.push_back(pe.second.second);
+  }
+  c->pending.clear();
+}
+
+extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
+{
+  if (!cfg || cfg->abi_version != C8P_ABI_VERSION) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return nullptr;
+  if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+  c8p_ctx* c = new c8p_ctx();
+  c->device = cfg->device; c->profile = cfg->profile; c->keep_bits = cfg->keep_bits;
+  if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    c->own_stream = true;
+  }
+  if (hipMalloc((void**)&c->d_tab, sizeof(DevTables)) != hipSuccess) { delete c; return nullptr; }
+  const DevTables& T = host_tables();
+  if (hipMemcpy(c->d_tab, &T, sizeof(DevTables), hipMemcpyHostToDevice) != hipSuccess) { hipFree(c->d_tab); delete c; return nullptr; }
+  return c;
+}
+
+extern "C" void c8p_destroy(c8p_ctx* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  drain_events(c);
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  Buf* bufs[] = {&c->d_stage, &c->d_iq, &c->d_chan, &c->d_llr_in, &c->d_mu_in, &c->d_tags, &c->d_outs, &c->d_H, &c->d_mimo,
+                 &c->d_muchan, &c->d_llr, &c->d_surv, &c->d_bits, &c->d_sbits, &c->d_pdu};
+  for (Buf* b : bufs) if (b->p) hipFree(b->p);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_tab) hipFree(c->d_tab);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char* c8p_last_error(const c8p_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+// ------------------------------------------------------------------------------------------------ submit helpers
+struct Plan {
+  std::vector<PktLayout> lay;
+  std::vector<uint32_t> sym_base;
+  size_t llr = 0, surv = 0, bits = 0, pdu = 0;
+  uint32_t syms = 0;
+};
+
+static uint32_t pdu_cap_for(uint32_t tcap)
+{
+  uint32_t pcap = tcap / 8u + 16u;
+  if (pcap < C8P_NDP_BLOB_BYTES + 5u) pcap = C8P_NDP_BLOB_BYTES + 5u;
+  return (pcap + 15u) & ~15u;
+}
+
+// Worst-case sizes from n_items alone: at most n_items/72+1 symbols (72 = short-GI symbol), 416 LLRs per
+// symbol and antenna, 347 trellis steps per symbol and antenna (416 * 5/6).
+static int plan_demod(c8p_ctx* c, const c8p_batch_in* in, Plan& P)
+{
+  const int n = in->n_pkt;
+  P.lay.resize(n); P.sym_base.resize(n + 1);
+  for (int p = 0; p < n; p++) {
+    const c8p_pkt_in& k = in->pkts[p];
+    if (k.n_ant != 1 && k.n_ant != 2) { c->err = "n_ant must be 1 or 2"; return C8P_EINVAL; }
+    for (int a = 0; a < k.n_ant; a++)
+      if (k.iq_off[a] + k.n_items > in->n_iq) { c->err = "packet items outside the iq arena"; return C8P_ERANGE; }
+    if ((uint64_t)k.chan_off + 64 > in->n_chan) { c->err = "chan outside the chan arena"; return C8P_ERANGE; }
+    const uint32_t nsb = k.n_items / 72u + 1u, nant = k.n_ant;
+    uint32_t llr_cap = nsb * 416u * nant;
+    if (llr_cap < C8P_NDP_TOTAL) llr_cap = C8P_NDP_TOTAL;
+    uint32_t tcap = nsb * 347u * nant;
+    if (tcap > C8P_DECODE_T_MAX) tcap = C8P_DECODE_T_MAX;
+    PktLayout& L = P.lay[p];
+    L.llr_off = P.llr; L.surv_off = P.surv; L.bits_off = P.bits; L.pdu_off = P.pdu;
+    L.sym_base = P.syms; L.nsym_bound = nsb; L.pdu_cap = pdu_cap_for(tcap); L.trellis_cap = tcap;
+    P.sym_base[p] = P.syms;
+    P.llr += llr_cap; P.surv += tcap + 1u; P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap; P.syms += nsb;
+  }
+  P.sym_base[n] = P.syms;
+  return C8P_OK;
+}
+
+static int plan_decode(c8p_ctx* c, const c8p_decode_in* in, Plan& P)
+{
+  const int n = in->n_pkt;
+  P.lay.resize(n); P.sym_base.assign(n + 1, 0);
+  for (int p = 0; p < n; p++) {
+    const c8p_pkt_tags& t = in->tags[p];
+    uint32_t tcap = 0;
+    if (t.status == C8P_ST_OK && t.trellis > 0 && t.trellis <= C8P_DECODE_T_MAX) tcap = (uint32_t)t.trellis;
+    if (t.status == C8P_ST_OK && t.total > 0 && t.llr_off + (uint64_t)t.total > in->n_llr) { c->err = "LLR items outside the llr arena"; return C8P_ERANGE; }
+    PktLayout& L = P.lay[p];
+    L.llr_off = t.llr_off; L.surv_off = P.surv; L.bits_off = P.bits; L.pdu_off = P.pdu;
+    L.sym_base = 0; L.nsym_bound = 0; L.pdu_cap = pdu_cap_for(tcap); L.trellis_cap = tcap;
+    P.surv += tcap + 1u; P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap;
+  }
+  return C8P_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
+                              const cf* d_mu, const Plan& P)
+{
+  int rc;
+  if ((rc = ensure(c, c->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_surv, sizeof(ulonglong2) * P.surv)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_pdu, P.pdu)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
+  {
+    KTimer kt(c, C8P_K_VITERBI);
+    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p, n);
+  }
+  {
+    KTimer kt(c, C8P_K_FINISH);
+    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, (const ulonglong2*)c->d_surv.p, d_mu,
+                       (const DevTables*)c->d_tab, (c8p_pkt_out*)c->d_outs.p, (uint8_t*)c->d_pdu.p, (uint8_t*)c->d_bits.p,
+                       (uint8_t*)c->d_sbits.p, c->keep_bits, n);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->ptr[C8P_BUF_OUT] = c->d_outs.p;
+  c->used[C8P_BUF_PDU] = P.pdu; c->ptr[C8P_BUF_PDU] = c->d_pdu.p;
+  c->used[C8P_BUF_BITS] = c->keep_bits ? P.bits : 0; c->ptr[C8P_BUF_BITS] = c->d_bits.p;
+  c->used[C8P_BUF_SBITS] = c->keep_bits ? P.bits : 0; c->ptr[C8P_BUF_SBITS] = c->d_sbits.p;
+  return C8P_OK;
+}
+
+static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->pkts || !in->iq || !in->chan))) { c->err = "bad batch"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  drain_events(c);
+  const int n = in->n_pkt;
+  c->n_pkt = n;
+  for (int i = 0; i < 7; i++) { c->used[i] = 0; c->ptr[i] = nullptr; }
+  if (n == 0) return C8P_OK;
+  Plan P;
+  int rc = plan_demod(c, in, P);
+  if (rc != C8P_OK) return rc;
+
+  // descriptors + layout + sym_base in one pinned staging copy
+  const size_t o_pk = 0, o_lay = align256(o_pk + sizeof(c8p_pkt_in) * (size_t)n);
+  const size_t o_sb = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  const size_t stage_bytes = align256(o_sb + sizeof(uint32_t) * (size_t)(n + 1));
+  if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_stage, stage_bytes)) != C8P_OK) return rc;
+  // the previous submit's async copy out of the pinned buffer must have finished before we overwrite it
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy((char*)c->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
+  memcpy((char*)c->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  memcpy((char*)c->h_stage + o_sb, P.sym_base.data(), sizeof(uint32_t) * (size_t)(n + 1));
+  {
+    KTimer kt(c, C8P_K_LAYOUT);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage, stage_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->d_stage.p + o_pk);
+  const PktLayout* d_lay = (const PktLayout*)((char*)c->d_stage.p + o_lay);
+  const uint32_t* d_sb = (const uint32_t*)((char*)c->d_stage.p + o_sb);
+
+  const cf* d_iq = (const cf*)in->iq;
+  const cf* d_chan = (const cf*)in->chan;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, c->d_iq, sizeof(cf) * in->n_iq)) != C8P_OK) return rc;
+    if ((rc = ensure(c, c->d_chan, sizeof(cf) * in->n_chan)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_iq.p, in->iq, sizeof(cf) * in->n_iq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_chan.p, in->chan, sizeof(cf) * in->n_chan, hipMemcpyHostToDevice, c->stream));
+    d_iq = (const cf*)c->d_iq.p; d_chan = (const cf*)c->d_chan.p;
+  }
+  if ((rc = ensure(c, c->d_tags, sizeof(c8p_pkt_tags) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_H, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
+
+  {
+    KTimer kt(c, C8P_K_CLASSIFY);
+    hipLaunchKernelGGL(k_classify, dim3(n), dim3(64), 0, c->stream, d_pk, d_iq, d_chan, d_lay, (const DevTables*)c->d_tab,
+                       (c8p_pkt_tags*)c->d_tags.p, (cf*)c->d_H.p, (Mimo*)c->d_mimo.p, (cf*)c->d_muchan.p, n);
+  }
+  {
+    KTimer kt(c, C8P_K_DEMOD);
+    hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->stream, d_pk, d_iq, d_chan, d_sb,
+                       (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->d_tags.p, (const cf*)c->d_H.p,
+                       (const Mimo*)c->d_mimo.p, (float*)c->d_llr.p, n, P.syms);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = c->d_tags.p;
+  c->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->ptr[C8P_BUF_LLR] = c->d_llr.p;
+  c->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->ptr[C8P_BUF_MUCHAN] = c->d_muchan.p;
+  if (!with_decode) return C8P_OK;
+  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->d_tags.p, d_lay, (const float*)c->d_llr.p, (const cf*)c->d_muchan.p, P);
+}
+
+extern "C" int c8p_demod(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, false); }
+extern "C" int c8p_rx(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, true); }
+
+extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->tags || !in->llr))) { c->err = "bad batch"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  drain_events(c);
+  const int n = in->n_pkt;
+  c->n_pkt = n;
+  for (int i = 0; i < 7; i++) { c->used[i] = 0; c->ptr[i] = nullptr; }
+  if (n == 0) return C8P_OK;
+  Plan P;
+  int rc = plan_decode(c, in, P);
+  if (rc != C8P_OK) return rc;
+  const size_t o_tg = 0, o_lay = align256(sizeof(c8p_pkt_tags) * (size_t)n);
+  const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_stage, stage_bytes)) != C8P_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy((char*)c->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
+  memcpy((char*)c->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  {
+    KTimer kt(c, C8P_K_LAYOUT);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage, stage_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  const c8p_pkt_tags* d_tags = (const c8p_pkt_tags*)((char*)c->d_stage.p + o_tg);
+  const PktLayout* d_lay = (const PktLayout*)((char*)c->d_stage.p + o_lay);
+  const float* d_llr = in->llr;
+  const cf* d_mu = (const cf*)in->mu2x1chan;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, c->d_llr_in, sizeof(float) * in->n_llr)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_llr_in.p, in->llr, sizeof(float) * in->n_llr, hipMemcpyHostToDevice, c->stream));
+    d_llr = (const float*)c->d_llr_in.p;
+    if (in->mu2x1chan) {
+      if ((rc = ensure(c, c->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->d_mu_in.p, in->mu2x1chan, sizeof(cf) * 128 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+      d_mu = (const cf*)c->d_mu_in.p;
+    }
+  }
+  if (!d_mu) {   // NDP reports then carry zeros
+    if ((rc = ensure(c, c->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_mu_in.p, 0, sizeof(cf) * 128 * (size_t)n, c->stream));
+    d_mu = (const cf*)c->d_mu_in.p;
+  }
+  c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = d_tags;
+  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P);
+}
+
+extern "C" int c8p_sync(c8p_ctx* c)
+{
+  if (!c) return C8P_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  return C8P_OK;
+}
+
+extern "C" const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
+{
+  if (!c || which < 0 || which > 6) return nullptr;
+  if (bytes) *bytes = c->used[which];
+  return c->ptr[which];
+}
+
+extern "C" int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
+{
+  if (!c || which < 0 || which > 6 || !dst) return C8P_EINVAL;
+  if (offset + bytes > c->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  return C8P_OK;
+}
+
+extern "C" int c8p_kernel_time(c8p_ctx* c, int kernel, double* total_ms, int64_t* launches)
+{
+  if (!c || kernel < 0 || kernel >= C8P_K_COUNT) return C8P_EINVAL;
+  if (total_ms) *total_ms = c->k_ms[kernel];
+  if (launches) *launches = c->k_cnt[kernel];
+  return C8P_OK;
+}
+extern "C" int c8p_profile_reset(c8p_ctx* c)
+{
+  if (!c) return C8P_EINVAL;
+  for (int k = 0; k < C8P_K_COUNT; k++) { c->k_ms[k] = 0; c->k_cnt[k] = 0; }
+  return C8P_OK;
+}
+
+// sizes of the ABI structs as compiled, for the Python binding's self-check
+extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
+{
+  const int32_t v[] = {C8P_ABI_VERSION, (int32_t)sizeof(c8p_pkt_in), (int32_t)sizeof(c8p_pkt_tags), (int32_t)sizeof(c8p_pkt_out),
+                       (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in)};
+  for (int i = 0; i < 7 && i < cap; i++) dst[i] = v[i];
+  return 7;
+}

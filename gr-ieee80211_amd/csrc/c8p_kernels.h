@@ -1,0 +1,805 @@
+// c8p_kernels.h — gfx950 kernels of the 802.11 OFDM RX hot path.
+//
+//   (arena layout is computed on the host from the descriptors and uploaded with them)
+//   k_classify    wave / packet   format detection, SIG decode, channel estimate, SIG-B  (demod_impl.cc:106-219)
+//   k_demod_sym   wave / symbol   FFT -> equalise -> pilot phase -> LLR -> de-interleave  (demod_impl.cc:279-314)
+//   k_viterbi_fwd wave / packet   depuncture + 64-state ACS, lane = next state, survivors as ballot words
+//   k_finish      wave / packet   traceback, descramble, A-MPDU walk, CRC-32, PDU records (decode_impl.cc:282-520)
+//
+// Every kernel is a single-wave (64-lane) program per unit of work: lane = FFT bin in the demod kernels,
+// lane = trellis state in the decoder.  All reference citations are relative to /root/reference/lib/.
+#pragma once
+#include "c8p_dev.h"
+
+// ================================================================================================ parsers (uniform code)
+struct ModD {
+  int format, sumu, ampdu, nSym, nSymSamp, nSS, nLTF, mcs, len, cr, nBPSCS, nDBPS, nCBPS, nCBPSS, valid;
+};
+
+__device__ __forceinline__ bool crc8_check(const uint8_t* b, int len, const uint8_t* crc)   // checkBitCrc8 :1367-1403
+{
+  unsigned c = 0xff;
+  for (int i = 0; i < len; i++) {
+    unsigned fb = (c >> 7) & 1u;
+    c = (c << 1) & 0xffu;
+    if (fb) c ^= 0x07u;
+    if (b[i]) c ^= 0x07u;
+  }
+  for (int i = 0; i < 8; i++) if (crc[i]) c ^= (1u << (7 - i));
+  return (c & 0xffu) == 0xffu;
+}
+__device__ __forceinline__ bool check_vht_a(const uint8_t* b)   // signalCheckVhtA :753-771
+{
+  if ((b[2] != 1) || (b[23] != 1) || (b[33] != 1)) return false;
+  if (!crc8_check(b, 34, &b[34])) return false;
+  if (b[0] + b[1]) return false;
+  return true;
+}
+__device__ __forceinline__ bool check_ht(const uint8_t* b)      // signalCheckHt :730-751
+{
+  if (b[26] != 1) return false;
+  if (!crc8_check(b, 34, &b[34])) return false;
+  if (b[5] + b[6] + b[7] + b[28] + b[29] + b[30] + b[32] + b[33]) return false;
+  return true;
+}
+__device__ __forceinline__ void set_rate(ModD& m)               // :1294-1322
+{
+  m.nCBPSS = m.nBPSCS * 52;
+  m.nCBPS = m.nCBPSS * m.nSS;
+  m.nDBPS = m.cr == C8P_CR_12 ? m.nCBPS / 2 : m.cr == C8P_CR_23 ? (m.nCBPS * 2) / 3 : m.cr == C8P_CR_34 ? (m.nCBPS * 3) / 4 : (m.nCBPS * 5) / 6;
+  if (m.nSS == 1) m.nLTF = 1; else if (m.nSS == 2) m.nLTF = 2; else if (m.nSS <= 4) m.nLTF = 4;
+}
+__device__ __forceinline__ bool mod_vht(int mcs, ModD& m)       // modParserVht :1225-1323
+{
+  m.mcs = mcs;
+  if (mcs < 0 || mcs > 9) { m.valid = 0; return false; }
+  const int nb = mcs == 0 ? 1 : mcs <= 2 ? 2 : mcs <= 4 ? 4 : mcs <= 7 ? 6 : 8;
+  const int cr = (mcs == 0 || mcs == 1 || mcs == 3) ? C8P_CR_12 : (mcs == 5) ? C8P_CR_23 : (mcs == 7 || mcs == 9) ? C8P_CR_56 : C8P_CR_34;
+  m.nBPSCS = nb; m.cr = cr;
+  set_rate(m);
+  return true;
+}
+__device__ __forceinline__ void parse_legacy(int mcs, int len, ModD& m)   // signalParserL :773-850
+{
+  m = ModD{};
+  m.valid = (mcs >= 0 && mcs <= 7);
+  if (!m.valid) return;
+  const int nb = mcs < 2 ? 1 : mcs < 4 ? 2 : mcs < 6 ? 4 : 6;
+  const int ndbps = mcs == 0 ? 24 : mcs == 1 ? 36 : mcs == 2 ? 48 : mcs == 3 ? 72 : mcs == 4 ? 96 : mcs == 5 ? 144 : mcs == 6 ? 192 : 216;
+  m.mcs = mcs; m.nBPSCS = nb; m.nDBPS = ndbps; m.nCBPS = 48 * nb; m.nCBPSS = m.nCBPS;
+  m.cr = (mcs == 6) ? C8P_CR_23 : (mcs & 1) ? C8P_CR_34 : C8P_CR_12;
+  m.len = len; m.nSS = 1; m.sumu = 0; m.nLTF = 0; m.format = C8P_F_L; m.nSymSamp = 80; m.ampdu = 0;
+  m.nSym = (len * 8 + 22) / ndbps + (((len * 8 + 22) % ndbps) != 0);
+}
+__device__ __forceinline__ void parse_ht(const uint8_t* b, ModD& m)       // signalParserHt :852-998
+{
+  m = ModD{};
+  int mcs = 0, len = 0;
+  for (int i = 0; i < 7; i++) mcs |= ((int)b[i]) << i;
+  for (int i = 0; i < 16; i++) len |= ((int)b[i + 8]) << i;
+  m.valid = 1; m.format = C8P_F_HT; m.sumu = 0;
+  m.nSymSamp = b[31] ? 72 : 80;
+  m.ampdu = b[27] ? 1 : 0;
+  m.mcs = mcs;
+  const int k = mcs & 7;
+  m.nBPSCS = k == 0 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : 6;
+  m.cr = (k == 0 || k == 1 || k == 3) ? C8P_CR_12 : (k == 5) ? C8P_CR_23 : (k == 7) ? C8P_CR_56 : C8P_CR_34;
+  m.len = len; m.nSS = mcs / 8 + 1;
+  set_rate(m);
+  m.nSym = (len * 8 + 22) / m.nDBPS + (((len * 8 + 22) % m.nDBPS) != 0);
+}
+__device__ __forceinline__ void parse_vht_a(const uint8_t* b, ModD& m)    // signalParserVhtA :1090-1178
+{
+  m = ModD{};
+  m.valid = 1;
+  int gid = 0;
+  for (int i = 0; i < 6; i++) gid |= ((int)b[i + 4]) << i;
+  m.format = C8P_F_VHT;
+  m.nSymSamp = b[24] ? 72 : 80;
+  m.ampdu = 1;
+  if (gid == 0 || gid == 63) {
+    int nsts = 0, mcs = 0;
+    for (int i = 0; i < 3; i++) nsts |= ((int)b[i + 10]) << i;
+    for (int i = 0; i < 4; i++) mcs |= ((int)b[i + 28]) << i;
+    m.sumu = 0; m.nSS = nsts + 1;
+    if (m.nSS > 4) m.valid = 0;
+    mod_vht(mcs, m);
+  } else {
+    m.sumu = 1; m.nLTF = 2; m.nSS = 1;
+  }
+}
+__device__ __forceinline__ void parse_vht_b(const uint8_t* b, ModD& m)    // signalParserVhtB :1180-1223
+{
+  int len = 0, mcs = 0;
+  if (m.sumu) {
+    for (int i = 0; i < 16; i++) len |= ((int)b[i]) << i;
+    for (int i = 0; i < 4; i++) mcs |= ((int)b[i + 16]) << i;
+    if (!mod_vht(mcs, m)) return;
+    m.len = len * 4;
+    m.nSym = (m.len * 8 + 16 + 6) / m.nDBPS + (((m.len * 8 + 16 + 6) % m.nDBPS) != 0);
+    m.nLTF = 2;
+  } else {
+    if ((b[17] + b[18] + b[19]) == 3) {
+      for (int i = 0; i < 17; i++) len |= ((int)b[i]) << i;
+      m.len = len * 4;
+      m.nSym = (m.len * 8 + 16 + 6) / m.nDBPS + (((m.len * 8 + 16 + 6) % m.nDBPS) != 0);
+    } else {
+      uint32_t pat = 0;
+      for (int i = 0; i < 20; i++) pat |= ((uint32_t)b[i]) << i;
+      if (pat == 0x422E0u) { m.len = 0; m.nSym = 0; } else { m.len = -1; m.nSym = -1; }
+    }
+  }
+}
+
+// ================================================================================================ classify
+struct ClsShared {
+  float llr_ht[96], llr_vht[96];
+  float inted[52], coded[52];
+  cf q0[52], q1[52];
+  uint8_t bits[48], bbits[32], intd[52];
+  unsigned long long w1[49], w0[49];
+  float sssnr[2];
+};
+
+// gather the four pilot-bin values of a per-lane quantity and fold them in the reference's left-to-right order
+__device__ __forceinline__ cf pilot_fold_sigb(cf s)   // conj(s7 - s21 + s43 + s57)  (demod_impl.cc:466, cloud80211phy.cc:632)
+{
+  cf a = shfl_c(s, 7), b = shfl_c(s, 21), c = shfl_c(s, 43), d = shfl_c(s, 57);
+  return cconj(cadd(cadd(csub(a, b), c), d));
+}
+
+// SIG-B tail: de-interleave, 26-step Viterbi, re-encode, per-stream noise -> sssnr (demod_impl.cc:483-504, demod2_impl.cc:710-757)
+__device__ __forceinline__ void sigb_finish(ClsShared& S, const DevTables* T, int nss)
+{
+  const int lane = lane_id();
+  if (lane < 52) S.coded[T->deintSigB[lane]] = S.inted[lane];
+  __syncthreads();
+  wave_sig_viterbi(S.coded, S.bbits, 26, S.w1, S.w0);
+  if (lane < 52) {
+    const int k = lane >> 1;
+    int st = 0;
+    for (int j = 0; j < 7; j++) if (k - j >= 0 && S.bbits[k - j]) st |= 1 << j;
+    const int enc = __popc(st & ((lane & 1) ? 0117 : 0155)) & 1;
+    S.intd[T->intlSigB[lane]] = (uint8_t)enc;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double n0 = 0.0, n1 = 0.0;
+    for (int i = 0; i < 52; i++) {
+      const float ref = S.intd[i] ? 1.0f : -1.0f;
+      float re = S.q0[i].x - ref, im = S.q0[i].y - 0.0f;
+      n0 += (double)(re * re + im * im);
+      if (nss == 2) {
+        re = S.q1[i].x - ref; im = S.q1[i].y - 0.0f;
+        n1 += (double)(re * re + im * im);
+      }
+    }
+    S.sssnr[0] = (float)(log10(52.0 / n0) * 10.0);
+    S.sssnr[1] = nss == 2 ? (float)(log10(52.0 / n1) * 10.0) : 0.0f;
+  }
+  __syncthreads();
+}
+
+// 2x2 channel estimate, lane = bin (demod2_impl.cc:372-463)
+__device__ __forceinline__ void chan_est_2x2(cf f11, cf f21, cf f12, cf f22, bool vht, const DevTables* T,
+                                             cf H[4], cf INV[4], cf pil1[4], cf pil2[4])
+{
+  const int lane = lane_id();
+  const float l2 = T->ltfNL[lane] * 0.5f;
+  H[0] = cmulf(csub(f11, f12), l2);
+  H[1] = cmulf(csub(f21, f22), l2);
+  H[2] = cmulf(cadd(f11, f12), l2);
+  H[3] = cmulf(cadd(f21, f22), l2);
+  if (vht) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      cf lo = shfl_c(H[c], (lane + 63) & 63), hi = shfl_c(H[c], (lane + 1) & 63);
+      if (is_pilot(lane)) H[c] = cdivf(cadd(lo, hi), 2.0f);
+    }
+  }
+  cf a = cadd(cmul(H[0], cconj(H[0])), cmul(H[1], cconj(H[1])));
+  cf b = cadd(cmul(H[0], cconj(H[2])), cmul(H[1], cconj(H[3])));
+  cf c = cadd(cmul(H[2], cconj(H[0])), cmul(H[3], cconj(H[1])));
+  cf d = cadd(cmul(H[2], cconj(H[2])), cmul(H[3], cconj(H[3])));
+  cf k = cdiv(mk(1.0f, 0.0f), csub(cmul(a, d), cmul(b, c)));
+  INV[0] = cmul(k, d);
+  INV[1] = cmul(cneg(k), b);
+  INV[2] = cmul(cneg(k), c);
+  INV[3] = cmul(k, a);
+  cf t1 = cadd(cmul(f11, cconj(H[0])), cmul(f21, cconj(H[1])));
+  cf t2 = cadd(cmul(f11, cconj(H[2])), cmul(f21, cconj(H[3])));
+  cf s1 = cadd(cmul(t1, INV[0]), cmul(t2, INV[2]));
+  cf s2 = cadd(cmul(t1, INV[1]), cmul(t2, INV[3]));
+  if (lane == 57) { s1 = cneg(s1); s2 = cneg(s2); }
+  s1 = cconj(s1); s2 = cconj(s2);
+  pil1[2] = shfl_c(s1, 7);  pil2[2] = shfl_c(s2, 7);
+  pil1[3] = shfl_c(s1, 21); pil2[3] = shfl_c(s2, 21);
+  pil1[0] = shfl_c(s1, 43); pil2[0] = shfl_c(s2, 43);
+  pil1[1] = shfl_c(s1, 57); pil2[1] = shfl_c(s2, 57);
+}
+
+__device__ __forceinline__ void zf_2x2(cf y1, cf y2, const cf H[4], const cf INV[4], cf& s1, cf& s2)   // demod2_impl.cc:515-518
+{
+  cf t1 = cadd(cmul(y1, cconj(H[0])), cmul(y2, cconj(H[1])));
+  cf t2 = cadd(cmul(y1, cconj(H[2])), cmul(y2, cconj(H[3])));
+  s1 = cadd(cmul(t1, INV[0]), cmul(t2, INV[2]));
+  s2 = cadd(cmul(t1, INV[1]), cmul(t2, INV[3]));
+}
+
+__global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
+                                                 const cf* __restrict__ chan, const PktLayout* __restrict__ lay,
+                                                 const DevTables* __restrict__ T, c8p_pkt_tags* __restrict__ tags,
+                                                 cf* __restrict__ Hout, Mimo* __restrict__ mimo, cf* __restrict__ muchan, int n)
+{
+  __shared__ ClsShared S;
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const int lane = lane_id();
+  const c8p_pkt_in P = pk[p];
+  const bool two = P.n_ant == 2;
+  const cf* in1 = iq + P.iq_off[0];
+  const cf* in2 = two ? iq + P.iq_off[1] : in1;
+  const int nitems = (int)P.n_items;
+  const cf HL = chan[P.chan_off + lane];
+
+  ModD m = ModD{};
+  int status = C8P_ST_REJ_SHORT;
+  int fmt = C8P_F_L;
+  cf H = mk(0.f, 0.f);
+  cf H4[4], INV4[4], pil1[4], pil2[4];
+  for (int c = 0; c < 4; c++) { H4[c] = INV4[c] = pil1[c] = pil2[c] = mk(0.f, 0.f); }
+  float sssnr0 = 0.f, sssnr1 = 0.f;
+  int data_off = 0, trellis = 0, is_ndp = 0;
+  bool done = false;
+
+  muchan[(size_t)p * 128 + lane] = mk(0.f, 0.f);
+  muchan[(size_t)p * 128 + 64 + lane] = mk(0.f, 0.f);
+
+  // ---- DEMOD_S_FORMAT (demod_impl.cc:106-148)
+  if (!(P.lsig_mcs > 0)) {
+    if (nitems < 160) { done = true; }
+    else {
+      cf f1 = wave_fft64(in1[8 + lane], T);
+      cf f2 = wave_fft64(in1[88 + lane], T);
+      cf d1 = cdiv(f1, HL), d2 = cdiv(f2, HL);          // procNLSigDemodDeint cloud80211phy.cc:629-648
+      cf p1 = pilot_fold_sigb(d1), p2 = pilot_fold_sigb(d2);
+      float a1 = cabs_(p1), a2 = cabs_(p2);
+      cf m1 = cdivf(cmul(d1, p1), a1), m2 = cdivf(cmul(d2, p2), a2);
+      const int idx = T->sigDemapNL[lane];
+      if (idx >= 0) {
+        S.llr_ht[idx] = m1.y; S.llr_ht[idx + 48] = m2.y;
+        S.llr_vht[idx] = m1.x; S.llr_vht[idx + 48] = m2.y;
+      }
+      __syncthreads();
+      wave_sig_viterbi(S.llr_vht, S.bits, 48, S.w1, S.w0);
+      if (check_vht_a(S.bits)) { parse_vht_a(S.bits, m); fmt = C8P_F_VHT; }
+      else {
+        __syncthreads();
+        wave_sig_viterbi(S.llr_ht, S.bits, 48, S.w1, S.w0);
+        if (check_ht(S.bits)) { parse_ht(S.bits, m); fmt = C8P_F_HT; }
+      }
+    }
+  }
+
+  if (!done && fmt == C8P_F_VHT) {
+    // ---- DEMOD_S_VHT (demod_impl.cc:150-178, demod2_impl.cc:150-180)
+    if (!m.valid && !m.sumu) { status = C8P_ST_REJ_UNSUP; done = true; }
+    else if (m.nSS > 2) { status = C8P_ST_REJ_VHT; done = true; }
+    else if (nitems < 160 + 80 + m.nLTF * 80 + 80) { done = true; }
+    else if (two && m.sumu) { status = C8P_ST_REJ_UNSUP; done = true; }
+    else {
+      const cf* l1 = in1 + 240;
+      const cf* l2 = in2 + 240;
+      int nss_eff = 1;
+      if (!two || m.nSS == 1) {
+        cf f1 = wave_fft64(l1[8 + lane], T);
+        if (!two && m.sumu) {                                   // demod_impl.cc:347-379
+          cf f2 = wave_fft64(l1[88 + lane], T);
+          if (P.mupos == 0) H = cdivf(csub(f1, f2), T->ltfNL[lane] * 2.0f);
+          else H = cdivf(cadd(cdivf(f1, T->ltfNL[lane]), cdivf(f2, T->ltfNLvht22[lane])), 2.0f);
+        } else {
+          if (!two && !(m.nSS == 1 && m.nLTF == 1)) {           // :393-410 channel-sounding capture
+            muchan[(size_t)p * 128 + lane] = l1[8 + lane];
+            muchan[(size_t)p * 128 + 64 + lane] = l1[88 + lane];
+          }
+          H = cdivf(f1, T->ltfNL[lane]);
+        }
+        cf fb = wave_fft64(l1[m.nLTF * 80 + 8 + lane], T);      // vhtSigBDemod :449-481
+        cf sig = cdiv(fb, H);
+        cf ps = pilot_fold_sigb(sig);
+        float pa = cabs_(ps);
+        if (!is_null_nl(lane) && !is_pilot(lane)) {
+          const int j = qidx_nl(lane);
+          cf q = cdivf(cmul(sig, ps), pa);
+          S.q0[j] = q; S.inted[j] = q.x;
+        }
+      } else {
+        cf f11 = wave_fft64(l1[8 + lane], T), f21 = wave_fft64(l2[8 + lane], T);
+        cf f12 = wave_fft64(l1[88 + lane], T), f22 = wave_fft64(l2[88 + lane], T);
+        chan_est_2x2(f11, f21, f12, f22, true, T, H4, INV4, pil1, pil2);
+        cf y1 = wave_fft64(l1[m.nLTF * 80 + 8 + lane], T), y2 = wave_fft64(l2[m.nLTF * 80 + 8 + lane], T);
+        cf s1, s2;
+        zf_2x2(y1, y2, H4, INV4, s1, s2);
+        // demod2_impl.cc:679-688
+        cf acc = cmul(shfl_c(s1, 7), pil1[2]);
+        acc = csub(acc, cmul(shfl_c(s1, 21), pil1[3]));
+        acc = cadd(acc, cmul(shfl_c(s1, 43), pil1[0]));
+        acc = cadd(acc, cmul(shfl_c(s1, 57), pil1[1]));
+        acc = cadd(acc, cmul(shfl_c(s2, 7), pil2[2]));
+        acc = csub(acc, cmul(shfl_c(s2, 21), pil2[3]));
+        acc = cadd(acc, cmul(shfl_c(s2, 43), pil2[0]));
+        acc = cadd(acc, cmul(shfl_c(s2, 57), pil2[1]));
+        cf ps = cconj(acc);
+        float pa = cabs_(ps);
+        if (!is_null_nl(lane) && !is_pilot(lane)) {
+          const int j = qidx_nl(lane);
+          cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
+          S.q0[j] = qa; S.q1[j] = qb;
+          S.inted[j] = (qa.x + qb.x) / 2.0f;
+        }
+        nss_eff = 2;
+      }
+      __syncthreads();
+      sigb_finish(S, T, nss_eff);
+      sssnr0 = S.sssnr[0]; sssnr1 = S.sssnr[1];
+      parse_vht_b(S.bbits, m);
+      const int nSymL = (P.lsig_len * 8 + 22 + 23) / 24;
+      const bool len_ok = two ? (m.len > 0) : (m.len >= 0);
+      if (!m.valid) { status = C8P_ST_REJ_UNSUP; done = true; }
+      else if (!(len_ok && m.len <= 4095 && m.nSS <= 2 && (nSymL * 80) >= (m.nSym * m.nSymSamp + 160 + 80 + m.nLTF * 80 + 80))) {
+        status = C8P_ST_REJ_VHT; done = true;
+      } else {
+        trellis = m.nSym * m.nDBPS;
+        data_off = 160 + 80 + m.nLTF * 80 + 80;
+        is_ndp = (m.nSym == 0);
+        if (!two && m.nSS == 2 && !is_ndp) { status = C8P_ST_REJ_UNSUP; done = true; }
+      }
+    }
+  } else if (!done && fmt == C8P_F_HT) {
+    // ---- DEMOD_S_HT (demod_impl.cc:180-205, demod2_impl.cc:182-214)
+    if (m.nSS > 2) { status = C8P_ST_REJ_HT; done = true; }
+    else if (nitems < 160 + 80 + m.nLTF * 80) { done = true; }
+    else {
+      const cf* l1 = in1 + 240;
+      const cf* l2 = in2 + 240;
+      if (!two || m.nSS == 1) {
+        cf f1 = wave_fft64(l1[8 + lane], T);
+        H = cdivf(f1, T->ltfNL[lane]);
+      } else {
+        cf f11 = wave_fft64(l1[8 + lane], T), f21 = wave_fft64(l2[8 + lane], T);
+        cf f12 = wave_fft64(l1[88 + lane], T), f22 = wave_fft64(l2[88 + lane], T);
+        chan_est_2x2(f11, f21, f12, f22, false, T, H4, INV4, pil1, pil2);
+      }
+      const int nSymL = (P.lsig_len * 8 + 22 + 23) / 24;
+      if (!(m.len > 0 && m.len <= 4095 && m.nSS <= 2 && (nSymL * 80) >= (m.nSym * m.nSymSamp + 160 + 80 + m.nLTF * 80))) {
+        status = C8P_ST_REJ_HT; done = true;
+      } else if (!two && m.nSS == 2) { status = C8P_ST_REJ_UNSUP; done = true; }
+      else {
+        trellis = m.len * 8 + 22;
+        data_off = 160 + 80 + m.nLTF * 80;
+      }
+    }
+  } else if (!done) {
+    // ---- DEMOD_S_LEGACY (demod_impl.cc:207-219)
+    parse_legacy(P.lsig_mcs, P.lsig_len, m);
+    if (!m.valid) { status = C8P_ST_REJ_UNSUP; done = true; }
+    else { trellis = m.len * 8 + 22; data_off = 0; }
+  }
+
+  if (!done) {
+    if (!is_ndp && data_off + m.nSym * m.nSymSamp >= nitems) status = C8P_ST_REJ_SHORT;   // DEMOD loop bound :283
+    else status = C8P_ST_OK;
+  }
+
+  // ---- DEMOD_S_WRTAG (demod_impl.cc:221-277)
+  if (lane == 0) {
+    c8p_pkt_tags t;
+    memset(&t, 0, sizeof(t));
+    t.status = status;
+    t.cfo = P.cfo; t.snr = P.snr; t.rssi = P.rssi; t.seq = P.seq;
+    t.llr_off = lay[p].llr_off;
+    if (status == C8P_ST_OK) {
+      t.format = m.format; t.mcs = m.mcs; t.len = m.len; t.cr = m.cr; t.ampdu = m.ampdu;
+      t.trellis = trellis; t.total = is_ndp ? C8P_NDP_TOTAL : m.nSym * m.nCBPS;
+      t.nsym = m.nSym; t.nss = m.nSS; t.nltf = m.nLTF; t.ncbps = m.nCBPS; t.ncbpss = m.nCBPSS;
+      t.ndbps = m.nDBPS; t.nbpscs = m.nBPSCS; t.nsymsamp = m.nSymSamp; t.sumu = m.sumu;
+      t.is_ndp = is_ndp; t.data_off = data_off; t.sssnr0 = sssnr0; t.sssnr1 = sssnr1;
+    }
+    tags[p] = t;
+  }
+  Hout[(size_t)p * 64 + lane] = H;
+  if (two) {
+    Mimo* M = &mimo[p];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { M->H[lane][c] = H4[c]; M->INV[lane][c] = INV4[c]; }
+    if (lane < 4) { M->pil1[lane] = pil1[lane]; M->pil2[lane] = pil2[lane]; }
+  }
+}
+
+// ================================================================================================ data symbols
+// procSymQamToLlr (cloud80211phy.cc:2090-2148) for one subcarrier; o[0..nb)
+__device__ __forceinline__ void qam_to_llr(cf q, int nb, float* o)
+{
+  if (nb == 1) { o[0] = q.x; return; }
+  const float sc = nb == 2 ? 1.4142135623730951f : nb == 4 ? 3.1622776601683795f : nb == 6 ? 6.48074069840786f : 13.038404810405298f;
+  q = cmulf(q, sc);
+  const int h = nb >> 1;
+  const float A = nb == 4 ? 2.0f : nb == 6 ? 4.0f : 8.0f;
+  float r = q.x, i = q.y;
+  o[0] = r; o[h] = i;
+  if (nb >= 4) {
+    float r1 = A - fabsf(r), i1 = A - fabsf(i);
+    o[1] = r1; o[h + 1] = i1;
+    if (nb >= 6) {
+      float r2 = A * 0.5f - fabsf(r1), i2 = A * 0.5f - fabsf(i1);
+      o[2] = r2; o[h + 2] = i2;
+      if (nb == 8) { o[3] = 2.0f - fabsf(r2); o[h + 3] = 2.0f - fabsf(i2); }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
+                                                   const cf* __restrict__ chan, const uint32_t* __restrict__ sym_base,
+                                                   const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
+                                                   const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
+                                                   float* __restrict__ llr, int n, uint32_t total_syms)
+{
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (w >= total_syms) return;
+  const int lane = lane_id();
+  // binary search: largest p with sym_base[p] <= w
+  int lo = 0, hi = n;
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sym_base[mid] <= w) lo = mid; else hi = mid; }
+  const int p = lo;
+  const int s = (int)(w - sym_base[p]);
+  const c8p_pkt_tags t = tags[p];
+  if (t.status != C8P_ST_OK) return;
+  float* out = llr + t.llr_off;
+  if (t.is_ndp) {                                  // 1024 dummy items (demod_impl.cc:265-271), zero-filled
+    if (s == 0) for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
+    return;
+  }
+  if (s >= t.nsym) return;
+  const c8p_pkt_in P = pk[p];
+  const bool two = P.n_ant == 2;
+  const cf* x1 = iq + P.iq_off[0] + t.data_off + s * t.nsymsamp + 8;
+  out += (size_t)s * t.ncbps;
+  const int nb = t.nbpscs;
+  const int mi = nbpsc_index(nb);
+  cf f1 = wave_fft64(x1[lane], T);
+
+  if (t.format == C8P_F_L) {
+    // legacyChanUpdate demod_impl.cc:507-539
+    const float Pp = T->pilotP[(1 + s) % 127];
+    cf sig = cdiv(f1, chan[P.chan_off + lane]);
+    cf acc = cmulf(cmulf(shfl_c(sig, 7), 1.0f), Pp);
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), -1.0f), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), 1.0f), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), 1.0f), Pp));
+    cf ps = cconj(acc);
+    float pa = cabs_(ps);
+    if (!is_null_l(lane) && !is_pilot(lane)) {
+      cf q = cdivf(cmul(sig, ps), pa);
+      float o[8];
+      qam_to_llr(q, nb, o);
+      const int j = qidx_l(lane);
+      for (int b = 0; b < nb; b++) out[T->deintL[mi][j * nb + b]] = o[b];
+    }
+    return;
+  }
+
+  const int p0 = t.format == C8P_F_VHT ? 4 : 3;
+  const float Pp = T->pilotP[(p0 + s) % 127];
+  // pilot patterns rotated left by s (pilotShift demod_impl.cc:549-557); base patterns cloud80211phy.cc:170-174
+  float pa_[4], pb_[4];
+  {
+    const bool ht2 = (t.format == C8P_F_HT) && two && t.nss == 2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int kk = (k + s) & 3;
+      const float l4 = kk == 3 ? -1.0f : 1.0f;                       // {1,1,1,-1}
+      const float h21 = kk >= 2 ? -1.0f : 1.0f;                      // {1,1,-1,-1}
+      const float h22 = (kk == 1 || kk == 2) ? -1.0f : 1.0f;         // {1,-1,-1,1}
+      pa_[k] = ht2 ? h21 : l4;
+      pb_[k] = (t.format == C8P_F_VHT) ? l4 : h22;
+    }
+  }
+
+  if (!(two && t.nss == 2)) {
+    // nonLegacyChanUpdate demod_impl.cc:413-447 (== demod2 nSS==1 branches)
+    cf sig = cdiv(f1, Hin[(size_t)p * 64 + lane]);
+    cf acc = cmulf(cmulf(shfl_c(sig, 7), pa_[2]), Pp);
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), pa_[3]), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), pa_[0]), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), pa_[1]), Pp));
+    cf ps = cconj(acc);
+    float pa = cabs_(ps);
+    if (!is_null_nl(lane) && !is_pilot(lane)) {
+      cf q = cdivf(cmul(sig, ps), pa);
+      float o[8];
+      qam_to_llr(q, nb, o);
+      const int j = qidx_nl(lane);
+      for (int b = 0; b < nb; b++) out[T->deintNL[mi][j * nb + b]] = o[b];
+    }
+    return;
+  }
+
+  // 2x2: htChanUpdate demod2_impl.cc:471-551 / vhtChanUpdate :553-630
+  const cf* x2 = iq + P.iq_off[1] + t.data_off + s * t.nsymsamp + 8;
+  cf f2 = wave_fft64(x2[lane], T);
+  const Mimo* M = &mimo[p];
+  cf H4[4], INV4[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { H4[c] = M->H[lane][c]; INV4[c] = M->INV[lane][c]; }
+  cf s1, s2;
+  zf_2x2(f1, f2, H4, INV4, s1, s2);
+  cf acc = cmul(cmulf(cmulf(shfl_c(s1, 7), pa_[2]), Pp), M->pil1[2]);
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 21), pa_[3]), Pp), M->pil1[3]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 43), pa_[0]), Pp), M->pil1[0]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 57), pa_[1]), Pp), M->pil1[1]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 7), pb_[2]), Pp), M->pil2[2]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 21), pb_[3]), Pp), M->pil2[3]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 43), pb_[0]), Pp), M->pil2[0]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 57), pb_[1]), Pp), M->pil2[1]));
+  cf ps = cconj(acc);
+  float pa = cabs_(ps);
+  if (!is_null_nl(lane) && !is_pilot(lane)) {
+    cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
+    float oa[8], ob[8];
+    qam_to_llr(qa, nb, oa);
+    qam_to_llr(qb, nb, ob);
+    const int j = qidx_nl(lane);
+    for (int b = 0; b < nb; b++) {
+      out[T->deint2ss[0][mi][j * nb + b]] = oa[b];
+      out[T->deint2ss[1][mi][j * nb + b]] = ob[b];
+    }
+  }
+}
+
+// ================================================================================================ Viterbi forward
+// LLR positions consumed by trellis step t for each puncture pattern (SV_PUNC_* cloud80211phy.cc:1857-1860);
+// -1 = punctured (metric input 0.0f).
+__device__ __forceinline__ void llr_index(int cr, int t, int& i0, int& i1)
+{
+  if (cr == C8P_CR_12) { i0 = 2 * t; i1 = 2 * t + 1; }
+  else if (cr == C8P_CR_23) { int q = t >> 1, r = t & 1; i0 = 3 * q + (r ? 2 : 0); i1 = r ? -1 : 3 * q + 1; }
+  else if (cr == C8P_CR_34) {
+    int q = t / 3, r = t - 3 * q;
+    i0 = r == 0 ? 4 * q : (r == 1 ? 4 * q + 2 : -1);
+    i1 = r == 0 ? 4 * q + 1 : (r == 2 ? 4 * q + 3 : -1);
+  } else {
+    int q = t / 5, r = t - 5 * q;
+    i0 = r == 0 ? 6 * q : r == 1 ? 6 * q + 2 : r == 3 ? 6 * q + 4 : -1;
+    i1 = r == 0 ? 6 * q + 1 : r == 2 ? 6 * q + 3 : r == 4 ? 6 * q + 5 : -1;
+  }
+}
+__device__ __forceinline__ int llr_needed(int cr, int T)   // LLRs consumed by T steps
+{
+  int i0, i1, m = 0;
+  for (int t = T - 1; t >= 0 && t >= T - 5; t--) { llr_index(cr, t, i0, i1); if (i0 + 1 > m) m = i0 + 1; if (i1 + 1 > m) m = i1 + 1; }
+  return m;
+}
+__device__ __forceinline__ bool decodable(const c8p_pkt_tags& t)   // decode_impl.cc:93-97 + stream long enough
+{
+  return t.status == C8P_ST_OK && t.len <= C8P_DECODE_B_MAX && t.trellis <= C8P_DECODE_T_MAX && t.trellis > 0 &&
+         t.cr >= 0 && t.cr <= 3 && llr_needed(t.cr, t.trellis) <= t.total;
+}
+
+// One wave per packet, lane = next state.  Survivors: per step two ballot words
+//   .x bit n: the odd predecessor 2(n&31)+1 won            (v_state_his = 2m+1)
+//   .y bit n: neither candidate beat the -1e15 pre-fill   (v_state_his stays 0)
+__global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                    const float* __restrict__ llr, ulonglong2* __restrict__ surv, int n)
+{
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const c8p_pkt_tags t = tags[p];
+  if (!decodable(t)) return;
+  const int lane = lane_id();
+  const int m = lane & 31, b = lane >> 5;
+  const int cA = sv_out(2 * m, b), cB = sv_out(2 * m + 1, b);
+  const float* L = llr + t.llr_off;
+  ulonglong2* SV = surv + lay[p].surv_off;
+  const int Tn = t.trellis;
+  float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;
+  for (int t0 = 0; t0 < Tn; t0 += 64) {
+    const int ts = t0 + lane;
+    int i0, i1;
+    llr_index(t.cr, ts, i0, i1);
+    const float T0 = (ts < Tn && i0 >= 0) ? L[i0] : 0.0f;
+    const float T1 = (ts < Tn && i1 >= 0) ? L[i1] : 0.0f;
+    unsigned long long W1 = 0, W0 = 0;
+    const int nst = min(64, Tn - t0);
+    for (int l = 0; l < nst; l++) {
+      bool take1, none;
+      pre = acs_step(pre, 2 * m, cA, cB, readlane_f(T0, l), readlane_f(T1, l), take1, none);
+      const unsigned long long b1 = __ballot(take1), b0 = __ballot(none);
+      W1 = writelane_u64(b1, l, W1);
+      W0 = writelane_u64(b0, l, W0);
+    }
+    if (ts < Tn) SV[ts] = make_ulonglong2(W1, W0);
+  }
+}
+
+// ================================================================================================ finish
+#define CRC_POLY 0xedb88320u
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b)   // a(x)*b(x) mod P, reflected
+{
+  uint32_t mm = 1u << 31, pr = 0;
+#pragma unroll 4
+  for (int i = 0; i < 32; i++) {
+    if (a & mm) pr ^= b;
+    mm >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+  }
+  return pr;
+}
+__device__ __forceinline__ uint32_t x8n_modp(uint32_t nbytes, const DevTables* T)   // x^(8 n) mod P
+{
+  uint32_t pr = 1u << 31;
+  uint32_t k = 3;
+  while (nbytes) {
+    if (nbytes & 1u) pr = multmodp(T->x2n[k & 31], pr);
+    nbytes >>= 1; k++;
+  }
+  return pr;
+}
+__device__ __forceinline__ uint32_t byte_at(const unsigned long long* bw, int bitoff)   // bitoff % 8 == 0
+{
+  return (uint32_t)((bw[bitoff >> 6] >> (bitoff & 63)) & 0xffull);
+}
+// zlib-compatible CRC-32 of `len` bytes starting at bit offset `bitoff` of the packed bit words, wave-parallel.
+__device__ __forceinline__ uint32_t wave_crc32(const unsigned long long* bw, int bitoff, int len, const DevTables* T)
+{
+  const int lane = lane_id();
+  const int seg = (len + 63) >> 6;
+  int beg = lane * seg, end = beg + seg;
+  if (beg > len) beg = len;
+  if (end > len) end = len;
+  uint32_t c = lane == 0 ? 0xffffffffu : 0u;
+  for (int i = beg; i < end; i++) c = T->crc32[(c ^ byte_at(bw, bitoff + 8 * i)) & 0xff] ^ (c >> 8);
+  if (c != 0u && len - end > 0) c = multmodp(x8n_modp((uint32_t)(len - end), T), c);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) c ^= (uint32_t)__shfl_xor((int)c, o, 64);
+  return c ^ 0xffffffffu;
+}
+
+__device__ __forceinline__ void emit_pdu(uint8_t* area, uint32_t cap, uint32_t& used, const unsigned long long* bw, int bitoff,
+                                         int len, int format, int mcs)
+{
+  // record = {u16 n} + blob {format, len lo, len hi, MPDU[len], mcs}   (decode_impl.cc:359-361,414-419)
+  const int lane = lane_id();
+  const uint32_t n = (uint32_t)len + 4u;
+  if (used + 2u + n > cap) return;
+  uint8_t* r = area + used;
+  if (lane == 0) {
+    r[0] = (uint8_t)(n & 0xff); r[1] = (uint8_t)(n >> 8);
+    r[2] = (uint8_t)format; r[3] = (uint8_t)(len % 256); r[4] = (uint8_t)(len / 256);
+    r[5 + len] = (uint8_t)mcs;
+  }
+  for (int i = lane; i < len; i += 64) r[5 + i] = (uint8_t)byte_at(bw, bitoff + 8 * i);
+  used += 2u + n;
+}
+
+__global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                               const ulonglong2* __restrict__ surv, const cf* __restrict__ muchan,
+                                               const DevTables* __restrict__ T, c8p_pkt_out* __restrict__ outs,
+                                               uint8_t* __restrict__ pdu, uint8_t* __restrict__ bits_o,
+                                               uint8_t* __restrict__ sbits_o, int keep_bits, int n)
+{
+  __shared__ unsigned long long bw[(C8P_DECODE_T_MAX + 63) / 64 + 2];
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const int lane = lane_id();
+  const c8p_pkt_tags t = tags[p];
+  const PktLayout Lp = lay[p];
+  uint8_t* area = pdu + Lp.pdu_off;
+  uint32_t used = 0;
+  int n_pdu = 0, n_fail = 0;
+
+  if (t.status == C8P_ST_OK && t.len <= C8P_DECODE_B_MAX && t.trellis <= C8P_DECODE_T_MAX && t.trellis == 0) {
+    // NDP channel report (decode_impl.cc:100-121)
+    const uint32_t nb = C8P_NDP_BLOB_BYTES;
+    if (lane == 0) {
+      area[0] = (uint8_t)(nb & 0xff); area[1] = (uint8_t)(nb >> 8);
+      area[2] = C8P_F_VHT_CHAN; area[3] = 0; area[4] = 4;
+    }
+    const uint8_t* src = (const uint8_t*)(muchan + (size_t)p * 128);
+    for (int i = lane; i < 1024; i += 64) area[5 + i] = src[i];
+    used = 2u + nb; n_pdu = 1;
+  } else if (decodable(t)) {
+    const int Tn = t.trellis;
+    const ulonglong2* SV = surv + Lp.surv_off;
+    const int nch = (Tn + 63) >> 6;
+    // ---- traceback from state 0 (vstb_end decode_impl.cc:282-302)
+    int st = 0;
+    for (int c = nch - 1; c >= 0; c--) {
+      const int ts = c * 64 + lane;
+      ulonglong2 wv = ts < Tn ? SV[ts] : make_ulonglong2(0ull, 0ull);
+      const int last = min(63, Tn - 1 - c * 64);
+      unsigned long long mask = 0;
+      for (int l = last; l >= 0; l--) {
+        const unsigned long long w1 = readlane_u64(wv.x, l), w0 = readlane_u64(wv.y, l);
+        const int prev = ((w0 >> st) & 1ull) ? 0 : (2 * (st & 31) + (int)((w1 >> st) & 1ull));
+        if (st == ((prev >> 1) | 32)) mask |= 1ull << l;
+        st = prev;
+      }
+      if (lane == 0) bw[c] = mask;
+    }
+    __syncthreads();
+    if (keep_bits) {
+      uint8_t* so = sbits_o + Lp.bits_off;
+      for (int i = lane; i < Tn; i += 64) so[i] = (uint8_t)((bw[i >> 6] >> (i & 63)) & 1ull);
+    }
+    // ---- descramble (decode_impl.cc:304-323)
+    int state = 0;
+    {
+      const unsigned long long w = bw[0];
+      for (int i = 0; i < 7; i++) if ((w >> i) & 1ull) state |= 1 << (6 - i);
+    }
+    const int ph = T->scrPhase[state];
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+      const int i = c * 64 + lane;
+      int ub = 0;
+      if (i >= 7 && i < Tn) {
+        const int sb = (int)((bw[c] >> lane) & 1ull);
+        const int fb = state ? T->scrSeq[(ph + (i - 7)) % 127] : 0;
+        ub = sb ^ fb;
+      }
+      const unsigned long long word = __ballot(ub != 0);
+      __syncthreads();
+      if (lane == 0) bw[c] = word;
+    }
+    if (lane == 0) bw[nch] = 0ull;
+    __syncthreads();
+    if (keep_bits) {
+      uint8_t* uo = bits_o + Lp.bits_off;
+      for (int i = lane; i < Tn; i += 64) uo[i] = (uint8_t)((bw[i >> 6] >> (i & 63)) & 1ull);
+    }
+    // ---- packetAssemble (decode_impl.cc:325-520)
+    if (t.format == C8P_F_VHT) {
+      int procd = 16;
+      if (procd < Tn) {
+        int bp = 16;
+        int tmpLen = 0;
+        while (true) {
+          procd += 32;
+          if (procd > Tn) break;
+          const uint32_t d = (uint32_t)((bw[bp >> 6] >> (bp & 63)) & 0xffffull);   // bp % 16 == 0: never straddles a word
+          const int eof = d & 1;
+          tmpLen |= (int)((d >> 2) & 1u) << 12;
+          tmpLen |= (int)((d >> 3) & 1u) << 13;
+          tmpLen |= (int)((d >> 4) & 0xfffu);
+          const int padded = ((tmpLen / 4 + ((tmpLen % 4) != 0)) * 4 * 8);
+          procd += padded;
+          if (procd > Tn) break;
+          bp += 32;
+          const uint32_t crc = wave_crc32(bw, bp, tmpLen, T);
+          if (crc != 558161692u) n_fail++;
+          else {
+            const uint32_t before = used;
+            emit_pdu(area, Lp.pdu_cap, used, bw, bp, tmpLen, t.format, t.mcs);
+            if (used != before) n_pdu++;
+          }
+          bp += padded;
+          if (eof) break;
+        }
+      }
+    } else if (!t.ampdu) {
+      const uint32_t crc = wave_crc32(bw, 16, t.len, T);
+      if (crc != 558161692u) n_fail++;
+      else {
+        const uint32_t before = used;
+        emit_pdu(area, Lp.pdu_cap, used, bw, 16, t.len, t.format, t.mcs);
+        if (used != before) n_pdu++;
+      }
+    }
+  }
+  if (lane == 0) {
+    c8p_pkt_out o;
+    o.n_pdu = n_pdu; o.n_crc_fail = n_fail; o.pdu_bytes = used; o.rsv = 0;
+    o.pdu_off = Lp.pdu_off; o.bits_off = Lp.bits_off;
+    outs[p] = o;
+  }
+}

@@ -1,0 +1,195 @@
+"""ctypes binding of libc8p_rx.so (the HIP engine).  Plumbing only: no arithmetic happens here.
+
+There is deliberately no fallback: if the shared library is missing or a symbol of include/c8p_rx.h is
+not exported, loading fails loudly; if no HIP device is usable, Engine() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc8p_rx.so")
+
+# every entry point include/c8p_rx.h declares
+SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
+           "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes"]
+
+_LIB = None
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libc8p_rx.so is not built (run `python __graft_entry__.py` / make -C gr-ieee80211_amd/csrc); "
+                           "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(L, s):
+            raise RuntimeError("libc8p_rx.so does not export %s" % s)
+    L.c8p_create.restype = C.c_void_p
+    L.c8p_create.argtypes = [C.POINTER(abi.Cfg)]
+    L.c8p_destroy.argtypes = [C.c_void_p]
+    L.c8p_last_error.restype = C.c_char_p
+    L.c8p_last_error.argtypes = [C.c_void_p]
+    for f in ("c8p_demod", "c8p_rx"):
+        getattr(L, f).argtypes = [C.c_void_p, C.POINTER(abi.BatchIn)]
+    L.c8p_decode.argtypes = [C.c_void_p, C.POINTER(abi.DecodeIn)]
+    L.c8p_sync.argtypes = [C.c_void_p]
+    L.c8p_buffer.restype = C.c_void_p
+    L.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.c8p_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.c8p_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.c8p_profile_reset.argtypes = [C.c_void_p]
+    L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
+    sizes = np.zeros(7, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 7)
+    want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
+            C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn)]
+    if list(sizes) != want:
+        raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
+    _LIB = L
+    return L
+
+
+def table(which, sub=0):
+    buf = np.zeros(512, np.int32)
+    n = load_library().c8p_table(which, sub, buf.ctypes.data_as(C.c_void_p), 512)
+    if n < 0:
+        raise ValueError("c8p_table(%d,%d) -> %d" % (which, sub, n))
+    return buf[:n].copy()
+
+
+class DevArray:
+    """A caller-owned device buffer (e.g. torch tensor storage): raw pointer + item count."""
+
+    def __init__(self, ptr, n, keepalive=None):
+        self.ptr, self.n, self.keepalive = int(ptr), int(n), keepalive
+
+
+class Engine:
+    def __init__(self, device=0, profile=False, keep_bits=False, stream=None):
+        self.L = load_library()
+        cfg = abi.Cfg(abi.ABI_VERSION, device, int(profile), int(keep_bits), stream)
+        self.ctx = self.L.c8p_create(C.byref(cfg))
+        if not self.ctx:
+            raise RuntimeError("c8p_create failed: no usable HIP device %d (there is no CPU fallback)" % device)
+        self._keep = None
+
+    def close(self):
+        if self.ctx:
+            self.L.c8p_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("c8p error %d: %s" % (rc, self.L.c8p_last_error(self.ctx).decode()))
+
+    @staticmethod
+    def _arena(x, dtype):
+        if isinstance(x, DevArray):
+            return x.ptr, x.n, abi.MEM_DEVICE, x
+        a = np.ascontiguousarray(x, dtype)
+        return a.ctypes.data, a.size, abi.MEM_HOST, a
+
+    def _batch(self, pk, iq, chan):
+        pk = np.ascontiguousarray(pk, abi.PKT_IN_DT)
+        iq_p, n_iq, m1, k1 = self._arena(iq, np.complex64)
+        ch_p, n_ch, m2, k2 = self._arena(chan, np.complex64)
+        if m1 != m2:
+            raise ValueError("iq and chan must live in the same memory kind")
+        b = abi.BatchIn(len(pk), m1, pk.ctypes.data, iq_p, n_iq, ch_p, n_ch)
+        self._keep = (pk, k1, k2, b)
+        self.n = len(pk)
+        return b
+
+    def demod(self, pk, iq, chan):
+        self._chk(self.L.c8p_demod(self.ctx, C.byref(self._batch(pk, iq, chan))))
+
+    def rx(self, pk, iq, chan):
+        self._chk(self.L.c8p_rx(self.ctx, C.byref(self._batch(pk, iq, chan))))
+
+    def decode(self, tags, llr, mu=None):
+        tags = np.ascontiguousarray(tags, abi.PKT_TAGS_DT)
+        l_p, n_l, m, k1 = self._arena(llr, np.float32)
+        mu_p, k2 = None, None
+        if mu is not None:
+            mu_p, _, m2, k2 = self._arena(mu, np.complex64)
+            if m2 != m:
+                raise ValueError("llr and mu2x1chan must live in the same memory kind")
+        d = abi.DecodeIn(len(tags), m, tags.ctypes.data, l_p, n_l, mu_p)
+        self._keep = (tags, k1, k2, d)
+        self.n = len(tags)
+        self._chk(self.L.c8p_decode(self.ctx, C.byref(d)))
+
+    def sync(self):
+        self._chk(self.L.c8p_sync(self.ctx))
+
+    def buffer(self, which):
+        nbytes = C.c_uint64(0)
+        p = self.L.c8p_buffer(self.ctx, which, C.byref(nbytes))
+        return p, nbytes.value
+
+    def fetch(self, which, dtype, offset_items=0, n_items=None):
+        dt = np.dtype(dtype)
+        _, nbytes = self.buffer(which)
+        if n_items is None:
+            n_items = nbytes // dt.itemsize - offset_items
+        out = np.zeros(n_items, dt)
+        self._chk(self.L.c8p_fetch(self.ctx, which, out.ctypes.data, offset_items * dt.itemsize, n_items * dt.itemsize))
+        return out
+
+    def tags(self):
+        return self.fetch(abi.BUF_TAGS, abi.PKT_TAGS_DT)
+
+    def outs(self):
+        return self.fetch(abi.BUF_OUT, abi.PKT_OUT_DT)
+
+    def kernel_times(self):
+        res = {}
+        for k in range(abi.K_COUNT):
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            self.L.c8p_kernel_time(self.ctx, k, C.byref(ms), C.byref(cnt))
+            res[abi.K_NAMES[k]] = (ms.value, cnt.value)
+        return res
+
+    def profile_reset(self):
+        self.L.c8p_profile_reset(self.ctx)
+
+    # convenience: everything of a finished rx() as python objects (test / smoke use)
+    def results(self, want_llr=True, want_bits=False):
+        self.sync()
+        tags, outs = self.tags(), self.outs()
+        pdu = self.fetch(abi.BUF_PDU, np.uint8)
+        llr = self.fetch(abi.BUF_LLR, np.float32) if want_llr and self.buffer(abi.BUF_LLR)[1] else None
+        mu = self.fetch(abi.BUF_MUCHAN, np.complex64) if self.buffer(abi.BUF_MUCHAN)[1] else None
+        bits = self.fetch(abi.BUF_BITS, np.uint8) if want_bits else None
+        sbits = self.fetch(abi.BUF_SBITS, np.uint8) if want_bits else None
+        res = []
+        for p in range(len(tags)):
+            t, o = tags[p], outs[p]
+            r = dict(tags=t, out=o)
+            area = pdu[int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes()
+            r["pdus"] = abi.split_pdus(area, int(o["n_pdu"]))
+            if llr is not None:
+                tot = int(t["total"]) if t["status"] == abi.ST_OK else 0
+                r["llr"] = llr[int(t["llr_off"]):int(t["llr_off"]) + tot]
+            if mu is not None:
+                r["mu"] = mu[128 * p:128 * p + 128]
+            if want_bits:
+                T = int(t["trellis"]) if t["status"] == abi.ST_OK else 0
+                r["bits"] = bits[int(o["bits_off"]):int(o["bits_off"]) + T]
+                r["sbits"] = sbits[int(o["bits_off"]):int(o["bits_off"]) + T]
+            res.append(r)
+        return res

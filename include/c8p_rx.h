@@ -163,7 +163,7 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_MUCHAN 6    /* c8p_c32[n_pkt][128] NDP time-domain LTF capture */
 
 /* kernels, for c8p_kernel_time() */
-#define C8P_K_LAYOUT   0
+#define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */
 #define C8P_K_CLASSIFY 1
 #define C8P_K_DEMOD    2
 #define C8P_K_VITERBI  3
@@ -202,6 +202,9 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL       7   /* as ints +1/-1/0 */
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
+
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in} as compiled into the library. */
+int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,63 @@
+"""Builds the mixed-format parity batches from the committed fixtures (used by GPU tests and smoke)."""
+import os
+
+import numpy as np
+
+from c8p_testlib import GOLD, H22, Batch, load_npz, through_channel
+
+
+def dewindow(tx):
+    """Undo the toolbox's half-amplitude symbol edges (procConcat2Symbol, phy80211header.py:894-899) so that a
+    noiseless frame is a clean OFDM signal: every 80-sample symbol boundary carries two halved samples."""
+    tx = np.array(tx, np.complex64, copy=True)
+    n = tx.shape[-1]
+    for b in range(160, n, 80):          # boundaries after L-STF(160), L-LTF(160) and every 80-sample field
+        if b == 160 or b >= 320:
+            tx[..., b - 1] *= 2
+            tx[..., b] *= 2
+    return tx
+
+
+def sweep_batch(snr_db=None, seed=1, dewin=False):
+    """All 42 sweep packets + the BASELINE configs + NDP + both MU users in one batch.
+    Returns (Batch, meta list)."""
+    rng = np.random.default_rng(seed)
+    b, meta = Batch(), []
+    for fn in ("packets_sweep.npz", "packets_cfg.npz"):
+        for name, d in load_npz(fn).items():
+            nss = int(d["nss"])
+            tx = dewindow(d["tx"]) if dewin else d["tx"]
+            if name == "VHT_NDP":
+                rx = through_channel(tx, np.array([[1 + 0.2j, 0.5 - 0.4j]], np.complex64), snr_db, rng)
+                assert b.add_rx(rx, n_ant=1) >= 0
+                meta.append((name + "/siso", d))
+                rx = through_channel(tx, H22, snr_db, rng)
+                assert b.add_rx(rx, n_ant=2) >= 0
+                meta.append((name + "/2ant", d))
+                continue
+            rx = through_channel(tx, H22 if nss == 2 else None, snr_db, rng)
+            if b.add_rx(rx, n_ant=nss) >= 0:
+                meta.append((name, d))
+    mu = np.load(os.path.join(GOLD, "packets_mu.npz"))
+    for u in range(2):
+        rx = through_channel(mu["mu_tx"], mu["h"][u:u + 1], snr_db, rng)
+        if b.add_rx(rx, n_ant=1, mupos=u) >= 0:
+            meta.append(("MU_user%d" % u, {"pdu": mu["pdu%d" % u]}))
+    return b, meta
+
+
+def cfg2_batch(n, snr_db=30.0, seed=8021200, dewin=True):
+    """n VHT MCS7 1458-byte packets (BASELINE.json configs[1]): the 4 reference-TX fixture frames, each sent
+    through a per-packet random-phase flat channel plus AWGN."""
+    g = load_npz("packets_cfg.npz")
+    frames = [g["cfg2_VHT_mcs7_1458B_%d" % k] for k in range(4)]
+    txs = [dewindow(f["tx"]) if dewin else f["tx"] for f in frames]
+    b, exp = Batch(), []
+    for p in range(n):
+        rng = np.random.default_rng(seed + p)
+        th = rng.uniform(0, 2 * np.pi)
+        h = np.array([[np.exp(1j * th)]], np.complex64)
+        rx = through_channel(txs[p % 4], h, snr_db, rng)
+        if b.add_rx(rx, n_ant=1) >= 0:
+            exp.append(frames[p % 4]["pdu"].tobytes())
+    return b, exp

@@ -1,0 +1,35 @@
+"""__graft_entry__.smoke(): one small mixed batch through c8p_rx on cuda:0, checked against the oracle."""
+import numpy as np
+
+from c8p_cases import sweep_batch
+from c8p_testlib import abi, oracle_rx
+from gr_ieee80211_amd import engine
+
+
+def compare(res, ref, llr_tol=1e-5):
+    n_pdu = 0
+    for p, (g, o) in enumerate(zip(res, ref)):
+        assert g["tags"]["status"] == o["tags"]["status"], p
+        if o["tags"]["status"] != abi.ST_OK:
+            continue
+        for k in abi.TAG_KEYS + ("nsym", "nss", "is_ndp"):
+            assert g["tags"][k] == o["tags"][k], (p, k)
+        assert abs(float(g["tags"]["sssnr0"]) - float(o["tags"]["sssnr0"])) < 1e-4, p
+        assert len(g["llr"]) == len(o["llr"])
+        if len(o["llr"]):
+            assert np.max(np.abs(g["llr"] - o["llr"])) <= llr_tol, (p, np.max(np.abs(g["llr"] - o["llr"])))
+        assert g["pdus"] == o["pdus"], p
+        n_pdu += len(o["pdus"])
+    return n_pdu
+
+
+def run():
+    b, meta = sweep_batch()
+    pk, iq, chan = b.arrays()
+    eng = engine.Engine(device=0)
+    eng.rx(pk, iq, chan)
+    res = eng.results()
+    ref = oracle_rx(pk, iq, chan)
+    n = compare(res, ref)
+    eng.close()
+    print("smoke ok: %d packets, %d PDUs identical to the oracle" % (len(pk), n))
