@@ -40,7 +40,7 @@ struct DevTables {
   float   pilotP[127];            // PILOT_P :160
   float   ltfNL[64];              // LTF_NL_28_F_FLOAT :113
   float   ltfNLvht22[64];         // LTF_NL_28_F_FLOAT_VHT22 :131
-  float2  tw[32];                 // e^{-j 2 pi k / 64}, k = 0..31
+  double2 tw[32];                 // e^{-j 2 pi k / 64}, k = 0..31 (double: the FFT runs in fp64, see wave_fft64)
   uint8_t bitrev6[64];
   uint8_t scrSeq[127];            // x^7+x^4+1 sequence from the all-ones state
   uint8_t scrPhase[128];          // phase of a 7-bit state inside scrSeq
@@ -92,26 +92,42 @@ __device__ __forceinline__ unsigned long long writelane_u64(unsigned long long v
 }
 
 // 64-point forward DFT across the 64 lanes of a wave: lane n holds x[n] on entry, X[n] on return.
-// Radix-2 decimation-in-frequency, 6 exchange stages, bit-reversal at the end.
-__device__ __forceinline__ cf wave_fft64(cf x, const DevTables* __restrict__ T)
+// Radix-2 decimation-in-frequency, 6 exchange stages, bit-reversal at the end.  The butterflies run in fp64 and
+// the result is rounded to float once: the reference's FFT is FFTW3f (third party, plan-dependent rounding), the
+// oracle pins it to "exact DFT rounded to float", and fp64 butterflies reproduce that to the last float bit in all
+// but ~1e-8 of the outputs, which keeps the whole LLR stream inside the 1e-5 parity bound even for |LLR| > 20.
+__device__ __forceinline__ double shfl_xor_d(double v, int m)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T)
 {
   const int lane = lane_id();
+  double xr = xin.x, xi = xin.y;
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const int half = 32 >> s;
-    cf xp = mk(__shfl_xor(x.x, half, 64), __shfl_xor(x.y, half, 64));
+    const double pr = shfl_xor_d(xr, half), pi = shfl_xor_d(xi, half);
     const bool up = (lane & half) != 0;
-    cf y;
     if (!up) {
-      y = cadd(x, xp);
+      xr = xr + pr; xi = xi + pi;
     } else {
-      cf d = csub(xp, x);
-      const int e = (lane & (half - 1)) << s;
-      y = cmul(d, T->tw[e]);
+      const double dr = pr - xr, di = pi - xi;
+      const double2 w = T->tw[(lane & (half - 1)) << s];
+      xr = dr * w.x - di * w.y;
+      xi = dr * w.y + di * w.x;
     }
-    x = y;
   }
-  return shfl_c(x, T->bitrev6[lane]);
+  const int src = T->bitrev6[lane];
+  return mk((float)shfl_d(xr, src), (float)shfl_d(xi, src));
 }
 
 __device__ __forceinline__ bool is_null_nl(int i) { return i == 0 || (i >= 29 && i <= 35); }

@@ -106,10 +106,10 @@ static const DevTables& host_tables()
   }
   for (int k = 0; k < 32; k++) {
     const double a = 2.0 * M_PI * (double)k / 64.0;
-    T.tw[k] = make_float2((float)cos(a), (float)(-sin(a)));
+    T.tw[k] = make_double2(cos(a), -sin(a));
   }
-  T.tw[0] = make_float2(1.f, 0.f);
-  T.tw[16] = make_float2(0.f, -1.f);
+  T.tw[0] = make_double2(1.0, 0.0);
+  T.tw[16] = make_double2(0.0, -1.0);
   for (int i = 0; i < 64; i++) {
     int r = 0;
     for (int b = 0; b < 6; b++) if (i & (1 << b)) r |= 1 << (5 - b);
@@ -216,13 +216,13 @@ static hipEvent_t get_event(c8p_ctx* c)
 {
   if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 struct KTimer {   // brackets one launch with events on the ctx stream when profiling is on
   c8p_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr;
-  KTimer(c8p_ctx* c_, int k_) : c(c_), k(k_) { if (c->profile) { a = get_event(c); b = get_event(c); hipEventRecord(a, c->stream); } }
-  ~KTimer() { if (c->profile) { hipEventRecord(b, c->stream); c->pending.push_back({k, {a, b}}); } }
+  KTimer(c8p_ctx* c_, int k_) : c(c_), k(k_) { if (c->profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); } }
+  ~KTimer() { if (c->profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back({k, {a, b}}); } }
 };
 static void drain_events(c8p_ctx* c)
 {
@@ -249,23 +249,23 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   }
   if (hipMalloc((void**)&c->d_tab, sizeof(DevTables)) != hipSuccess) { delete c; return nullptr; }
   const DevTables& T = host_tables();
-  if (hipMemcpy(c->d_tab, &T, sizeof(DevTables), hipMemcpyHostToDevice) != hipSuccess) { hipFree(c->d_tab); delete c; return nullptr; }
+  if (hipMemcpy(c->d_tab, &T, sizeof(DevTables), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(c->d_tab); delete c; return nullptr; }
   return c;
 }
 
 extern "C" void c8p_destroy(c8p_ctx* c)
 {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
   drain_events(c);
-  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   Buf* bufs[] = {&c->d_stage, &c->d_iq, &c->d_chan, &c->d_llr_in, &c->d_mu_in, &c->d_tags, &c->d_outs, &c->d_H, &c->d_mimo,
                  &c->d_muchan, &c->d_llr, &c->d_surv, &c->d_bits, &c->d_sbits, &c->d_pdu};
-  for (Buf* b : bufs) if (b->p) hipFree(b->p);
-  if (c->h_stage) hipHostFree(c->h_stage);
-  if (c->d_tab) hipFree(c->d_tab);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+  for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->d_tab) (void)hipFree(c->d_tab);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 

@@ -56,14 +56,20 @@ def test_all_formats_match_oracle(eng, snr):
     res = eng.results(want_bits=True)
     ref = oracle_rx(pk, iq, chan)
     compare(res, ref, LLR_TOL)
-    # decoded bits (before and after descrambling) bit-exact whenever the LLR streams are bit-identical,
-    # and in every case when the decoder is fed the oracle's own LLRs (next test)
-    same = 0
+    # decoded bits (before and after descrambling) are bit-exact on every frame whose FCS passes; frames that
+    # fail may differ in a near-tie because the LLRs differ by an FFT rounding (<= 1e-5) - the decoder itself is
+    # bit-exact on identical LLRs (next test).  Report, do not hide, how many failing frames differ.
+    ok = differ = 0
     for g, o in zip(res, ref):
-        if o["tags"]["status"] == abi.ST_OK and o["tags"]["trellis"] > 0 and np.array_equal(g["llr"], o["llr"]):
-            assert np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"])
-            same += 1
-    assert same >= 1
+        if o["tags"]["status"] == abi.ST_OK and o["tags"]["trellis"] > 0:
+            eq = np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"])
+            if o["out"]["n_pdu"] > 0:
+                assert eq
+                ok += 1
+            elif not eq:
+                differ += 1
+    print("snr %s: %d FCS-passing frames bit-exact, %d FCS-failing frames with differing bits" % (snr, ok, differ))
+    assert ok >= (40 if snr is None else 1)
 
 
 @pytest.mark.parametrize("snr", [None, 12.0, 5.0])
