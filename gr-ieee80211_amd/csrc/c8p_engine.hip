@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -179,7 +180,8 @@ struct c8p_ctx {
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
   // results / scratch
-  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu;
+  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags;
+  int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
   // last submit
   int n_pkt = 0;
   size_t used[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -242,6 +244,7 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile; c->keep_bits = cfg->keep_bits;
+  { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
   if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
@@ -261,7 +264,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   drain_events(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   Buf* bufs[] = {&c->d_stage, &c->d_iq, &c->d_chan, &c->d_llr_in, &c->d_mu_in, &c->d_tags, &c->d_outs, &c->d_H, &c->d_mimo,
-                 &c->d_muchan, &c->d_llr, &c->d_surv, &c->d_bits, &c->d_sbits, &c->d_pdu};
+                 &c->d_muchan, &c->d_llr, &c->d_surv, &c->d_bits, &c->d_sbits, &c->d_pdu, &c->d_flags};
   for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_tab) (void)hipFree(c->d_tab);
@@ -341,15 +344,21 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   if ((rc = ensure(c, c->d_pdu, P.pdu)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->d_flags.p;
   {
+    // forward pass: lean kernel for every packet, then the clamp-exact kernel for the (rare) packets it flagged
     KTimer kt(c, C8P_K_VITERBI);
-    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p, n);
+    if (!c->exact_only)
+      hipLaunchKernelGGL(k_viterbi_lean, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p,
+                         (uint32_t*)c->d_flags.p, n);
+    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p, d_flags, n);
   }
   {
     KTimer kt(c, C8P_K_FINISH);
     hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, (const ulonglong2*)c->d_surv.p, d_mu,
                        (const DevTables*)c->d_tab, (c8p_pkt_out*)c->d_outs.p, (uint8_t*)c->d_pdu.p, (uint8_t*)c->d_bits.p,
-                       (uint8_t*)c->d_sbits.p, c->keep_bits, n);
+                       (uint8_t*)c->d_sbits.p, d_flags, c->keep_bits, n);
   }
   HIPCHK(c, hipGetLastError());
   c->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->ptr[C8P_BUF_OUT] = c->d_outs.p;

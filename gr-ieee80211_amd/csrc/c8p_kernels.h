@@ -10,6 +10,7 @@
 // lane = trellis state in the decoder.  All reference citations are relative to /root/reference/lib/.
 #pragma once
 #include "c8p_dev.h"
+#include "c8p_viterbi_lean.h"
 
 // ================================================================================================ parsers (uniform code)
 struct ModD {
@@ -589,10 +590,12 @@ __device__ __forceinline__ bool decodable(const c8p_pkt_tags& t)   // decode_imp
 //   .x bit n: the odd predecessor 2(n&31)+1 won            (v_state_his = 2m+1)
 //   .y bit n: neither candidate beat the -1e15 pre-fill   (v_state_his stays 0)
 __global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                                    const float* __restrict__ llr, ulonglong2* __restrict__ surv, int n)
+                                                    const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                    const uint32_t* __restrict__ flags, int n)
 {
   const int p = blockIdx.x;
   if (p >= n) return;
+  if (flags && flags[p] == 0) return;      // the lean kernel already produced exact survivors for this packet
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
   const int lane = lane_id();
@@ -619,6 +622,28 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restri
     }
     if (ts < Tn) SV[ts] = make_ulonglong2(W1, W0);
   }
+}
+
+// The fast path (c8p_viterbi_lean.h).  flags[p] = 1 asks k_viterbi_fwd to redo the packet with the clamp-exact recurrence.
+__global__ __launch_bounds__(64) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                     const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                     uint32_t* __restrict__ flags, int n)
+{
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const c8p_pkt_tags t = tags[p];
+  unsigned bad = 0;
+  if (decodable(t)) {
+    const float* L = llr + t.llr_off;
+    unsigned long long* sv = (unsigned long long*)(surv + lay[p].surv_off);
+    switch (t.cr) {
+      case C8P_CR_12: bad = lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv); break;
+      case C8P_CR_23: bad = lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv); break;
+      case C8P_CR_34: bad = lean_forward<C8P_CR_34>(L, t.total, t.trellis, sv); break;
+      default:        bad = lean_forward<C8P_CR_56>(L, t.total, t.trellis, sv); break;
+    }
+  }
+  if (lane_id() == 0) flags[p] = bad;
 }
 
 // ================================================================================================ finish
@@ -685,7 +710,8 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                const ulonglong2* __restrict__ surv, const cf* __restrict__ muchan,
                                                const DevTables* __restrict__ T, c8p_pkt_out* __restrict__ outs,
                                                uint8_t* __restrict__ pdu, uint8_t* __restrict__ bits_o,
-                                               uint8_t* __restrict__ sbits_o, int keep_bits, int n)
+                                               uint8_t* __restrict__ sbits_o, const uint32_t* __restrict__ flags,
+                                               int keep_bits, int n)
 {
   __shared__ unsigned long long bw[(C8P_DECODE_T_MAX + 63) / 64 + 2];
   const int p = blockIdx.x;
@@ -711,6 +737,40 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
     const int Tn = t.trellis;
     const ulonglong2* SV = surv + Lp.surv_off;
     const int nch = (Tn + 63) >> 6;
+    if (flags && flags[p] == 0) {
+      // ---- lean survivors (one word per step, rotating lane map): segment-parallel traceback.
+      // Lane j walks steps [j*S, (j+1)*S) backwards from an assumed end lane; the assumption of segment j is the
+      // begin lane segment j+1 computed.  Iterating to a fixed point makes every boundary consistent with the
+      // true end (lane 0 = state 0 at T), i.e. the result is the reference's full traceback (vstb_end :282-302).
+      const unsigned long long* SW = (const unsigned long long*)SV;
+      const int S = 64 * ((Tn + 4095) / 4096);
+      const int nseg = (Tn + S - 1) / S;
+      const int tbeg = lane * S;
+      const int tend = min(tbeg + S, Tn);
+      int Dend = 0, Dbeg = 0;
+      bool redo = lane < nseg;
+      for (int it = 0; it < 66; it++) {
+        if (redo) {
+          int D = Dend;
+          unsigned long long mask = 0;
+          int q = (tend - 1) % 6;
+          for (int tt = tend - 1; tt >= tbeg; tt--) {
+            const unsigned long long w = SW[tt];
+            const int take = (int)((w >> D) & 1ull);
+            if ((D >> q) & 1) mask |= 1ull << (tt & 63);
+            D = (D & ~(1 << q)) | (take << q);
+            q = q == 0 ? 5 : q - 1;
+            if ((tt & 63) == 0) { bw[tt >> 6] = mask; mask = 0; }
+          }
+          Dbeg = D;
+        }
+        int nd = __shfl_down(Dbeg, 1, 64);
+        if (lane >= nseg - 1) nd = 0;
+        redo = (lane < nseg) && (nd != Dend);
+        Dend = nd;
+        if (!__any(redo)) break;
+      }
+    } else {
     // ---- traceback from state 0 (vstb_end decode_impl.cc:282-302)
     int st = 0;
     for (int c = nch - 1; c >= 0; c--) {
@@ -725,6 +785,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         st = prev;
       }
       if (lane == 0) bw[c] = mask;
+    }
     }
     __syncthreads();
     if (keep_bits) {
