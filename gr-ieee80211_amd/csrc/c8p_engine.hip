@@ -336,7 +336,7 @@ static int plan_decode(c8p_ctx* c, const c8p_decode_in* in, Plan& P)
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
-                              const cf* d_mu, const Plan& P)
+                              const cf* d_mu, const Plan& P, bool flags_ready)
 {
   int rc;
   if ((rc = ensure(c, c->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
@@ -347,11 +347,14 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   if ((rc = ensure(c, c->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
   const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->d_flags.p;
   {
-    // forward pass: lean kernel for every packet, then the clamp-exact kernel for the (rare) packets it flagged
+    // forward pass: lean kernel for every packet whose LLRs passed the range check, clamp-exact kernel for the rest
     KTimer kt(c, C8P_K_VITERBI);
-    if (!c->exact_only)
+    if (!c->exact_only) {
+      if (!flags_ready)
+        hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, c->stream, d_tags, d_llr, (uint32_t*)c->d_flags.p, n);
       hipLaunchKernelGGL(k_viterbi_lean, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p,
-                         (uint32_t*)c->d_flags.p, n);
+                         d_flags, n);
+    }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p, d_flags, n);
   }
   {
@@ -416,24 +419,25 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if ((rc = ensure(c, c->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
 
   {
     KTimer kt(c, C8P_K_CLASSIFY);
     hipLaunchKernelGGL(k_classify, dim3(n), dim3(64), 0, c->stream, d_pk, d_iq, d_chan, d_lay, (const DevTables*)c->d_tab,
-                       (c8p_pkt_tags*)c->d_tags.p, (cf*)c->d_H.p, (Mimo*)c->d_mimo.p, (cf*)c->d_muchan.p, n);
+                       (c8p_pkt_tags*)c->d_tags.p, (cf*)c->d_H.p, (Mimo*)c->d_mimo.p, (cf*)c->d_muchan.p, (uint32_t*)c->d_flags.p, n);
   }
   {
     KTimer kt(c, C8P_K_DEMOD);
     hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->stream, d_pk, d_iq, d_chan, d_sb,
                        (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->d_tags.p, (const cf*)c->d_H.p,
-                       (const Mimo*)c->d_mimo.p, (float*)c->d_llr.p, n, P.syms);
+                       (const Mimo*)c->d_mimo.p, (float*)c->d_llr.p, (uint32_t*)c->d_flags.p, n, P.syms);
   }
   HIPCHK(c, hipGetLastError());
   c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = c->d_tags.p;
   c->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->ptr[C8P_BUF_LLR] = c->d_llr.p;
   c->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->ptr[C8P_BUF_MUCHAN] = c->d_muchan.p;
   if (!with_decode) return C8P_OK;
-  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->d_tags.p, d_lay, (const float*)c->d_llr.p, (const cf*)c->d_muchan.p, P);
+  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->d_tags.p, d_lay, (const float*)c->d_llr.p, (const cf*)c->d_muchan.p, P, true);
 }
 
 extern "C" int c8p_demod(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, false); }
@@ -484,7 +488,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
     d_mu = (const cf*)c->d_mu_in.p;
   }
   c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = d_tags;
-  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P);
+  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, false);
 }
 
 extern "C" int c8p_sync(c8p_ctx* c)

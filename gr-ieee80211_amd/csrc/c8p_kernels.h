@@ -230,7 +230,8 @@ __device__ __forceinline__ void zf_2x2(cf y1, cf y2, const cf H[4], const cf INV
 __global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                  const cf* __restrict__ chan, const PktLayout* __restrict__ lay,
                                                  const DevTables* __restrict__ T, c8p_pkt_tags* __restrict__ tags,
-                                                 cf* __restrict__ Hout, Mimo* __restrict__ mimo, cf* __restrict__ muchan, int n)
+                                                 cf* __restrict__ Hout, Mimo* __restrict__ mimo, cf* __restrict__ muchan,
+                                                 uint32_t* __restrict__ flags, int n)
 {
   __shared__ ClsShared S;
   const int p = blockIdx.x;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ 
   int data_off = 0, trellis = 0, is_ndp = 0;
   bool done = false;
 
+  if (lane == 0) flags[p] = 0;        // k_demod_sym raises it when an LLR fails the lean decoder's range check
   muchan[(size_t)p * 128 + lane] = mk(0.f, 0.f);
   muchan[(size_t)p * 128 + 64 + lane] = mk(0.f, 0.f);
 
@@ -443,7 +445,8 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
                                                    const cf* __restrict__ chan, const uint32_t* __restrict__ sym_base,
                                                    const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
                                                    const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
-                                                   float* __restrict__ llr, int n, uint32_t total_syms)
+                                                   float* __restrict__ llr, uint32_t* __restrict__ flags, int n,
+                                                   uint32_t total_syms)
 {
   const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (w >= total_syms) return;
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
   out += (size_t)s * t.ncbps;
   const int nb = t.nbpscs;
   const int mi = nbpsc_index(nb);
+  bool bad = false;                       // an LLR outside the lean decoder's exactness range (or NaN)
   cf f1 = wave_fft64(x1[lane], T);
 
   if (t.format == C8P_F_L) {
@@ -484,8 +488,9 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
       float o[8];
       qam_to_llr(q, nb, o);
       const int j = qidx_l(lane);
-      for (int b = 0; b < nb; b++) out[T->deintL[mi][j * nb + b]] = o[b];
+      for (int b = 0; b < nb; b++) { out[T->deintL[mi][j * nb + b]] = o[b]; bad |= bad_llr(o[b]); }
     }
+    if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
     return;
   }
 
@@ -520,8 +525,9 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
       float o[8];
       qam_to_llr(q, nb, o);
       const int j = qidx_nl(lane);
-      for (int b = 0; b < nb; b++) out[T->deintNL[mi][j * nb + b]] = o[b];
+      for (int b = 0; b < nb; b++) { out[T->deintNL[mi][j * nb + b]] = o[b]; bad |= bad_llr(o[b]); }
     }
+    if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
     return;
   }
 
@@ -553,8 +559,10 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
     for (int b = 0; b < nb; b++) {
       out[T->deint2ss[0][mi][j * nb + b]] = oa[b];
       out[T->deint2ss[1][mi][j * nb + b]] = ob[b];
+      bad |= bad_llr(oa[b]) | bad_llr(ob[b]);
     }
   }
+  if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
 }
 
 // ================================================================================================ Viterbi forward
@@ -624,26 +632,41 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restri
   }
 }
 
-// The fast path (c8p_viterbi_lean.h).  flags[p] = 1 asks k_viterbi_fwd to redo the packet with the clamp-exact recurrence.
-__global__ __launch_bounds__(64) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                                     const float* __restrict__ llr, ulonglong2* __restrict__ surv,
-                                                     uint32_t* __restrict__ flags, int n)
+// Range check of an LLR stream handed in by the caller (c8p_decode): flags[p] = 1 sends the packet to the exact kernel.
+__global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict__ tags, const float* __restrict__ llr,
+                                                  uint32_t* __restrict__ flags, int n)
 {
   const int p = blockIdx.x;
   if (p >= n) return;
   const c8p_pkt_tags t = tags[p];
-  unsigned bad = 0;
+  bool bad = false;
   if (decodable(t)) {
     const float* L = llr + t.llr_off;
-    unsigned long long* sv = (unsigned long long*)(surv + lay[p].surv_off);
-    switch (t.cr) {
-      case C8P_CR_12: bad = lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv); break;
-      case C8P_CR_23: bad = lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv); break;
-      case C8P_CR_34: bad = lean_forward<C8P_CR_34>(L, t.total, t.trellis, sv); break;
-      default:        bad = lean_forward<C8P_CR_56>(L, t.total, t.trellis, sv); break;
-    }
+    for (int i = lane_id(); i < t.total; i += 64) bad |= bad_llr(L[i]);
   }
-  if (lane_id() == 0) flags[p] = bad;
+  const unsigned long long any = __ballot(bad);
+  if (lane_id() == 0) flags[p] = any ? 1u : 0u;
+}
+
+// The fast path (c8p_viterbi_lean.h).  Packets whose LLR stream failed the range check (flags[p] != 0) are left to
+// k_viterbi_fwd, the clamp-exact recurrence.
+__global__ __launch_bounds__(64) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                     const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                     const uint32_t* __restrict__ flags, int n)
+{
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  if (flags[p] != 0) return;
+  const c8p_pkt_tags t = tags[p];
+  if (!decodable(t)) return;
+  const float* L = llr + t.llr_off;
+  unsigned long long* sv = (unsigned long long*)(surv + lay[p].surv_off);
+  switch (t.cr) {
+    case C8P_CR_12: lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv); break;
+    case C8P_CR_23: lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv); break;
+    case C8P_CR_34: lean_forward<C8P_CR_34>(L, t.total, t.trellis, sv); break;
+    default:        lean_forward<C8P_CR_56>(L, t.total, t.trellis, sv); break;
+  }
 }
 
 // ================================================================================================ finish

@@ -18,8 +18,8 @@
 // Exactness.  The kernel drops the reference's -1e15 clamp and its "neither candidate beat the pre-fill" record.
 // For LLRs that are all finite with |LLR| <= 2^20 this is the identical function (DESIGN.md "lean = exact"):
 // unreachable metrics stay exactly -1e15 (|bm| is far below half an ulp of 1e15), real metrics stay far above it,
-// and the traceback from state 0 at T >= 6 only ever visits reachable states.  Every LLR is range-checked on the
-// scalar unit while it is consumed; a packet that violates the bound is flagged and re-run by the exact kernel.
+// and the traceback from state 0 at T >= 6 only ever visits reachable states.  Every LLR is range-checked where it is
+// produced (k_demod_sym) or handed in (k_llr_check); a flagged packet is skipped here and run by the exact kernel.
 #pragma once
 #include "c8p_dev.h"
 
@@ -35,57 +35,83 @@ template <int Q> __device__ __forceinline__ unsigned long long lane_bit_mask()
          Q == 3 ? 0xFF00FF00FF00FF00ull : Q == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
 }
 
-// v = pre[lane ^ (1<<Q)] + bm.  The DPP forms live in inline asm, which the compiler's hazard recogniser cannot
-// see into: a VGPR written by the previous VALU instruction needs 2 wait states before a DPP read, hence "s_nop 1".
-template <int Q> __device__ __forceinline__ float partner_add(float pre, float bm)
-{
-  float v;
-  if (Q == 0) {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(pre), "v"(bm));
-  } else if (Q == 1) {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(pre), "v"(bm));
-  } else if (Q == 2) {
-    float tq;   // lane^3 then lane^7 (mirror inside 8) = lane^4
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf" : "=v"(tq) : "v"(pre));
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(tq), "v"(bm));
-  } else if (Q == 3) {
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(pre), "v"(bm));
-  } else if (Q == 4) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(pre), __float_as_uint(pre), false, false);
-    const float part = (lane_id() & 16) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
-    v = part + bm;
-  } else {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(pre), __float_as_uint(pre), false, false);
-    const float part = (lane_id() & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
-    v = part + bm;
-  }
-  return v;
-}
-
+// ---- one trellis step ------------------------------------------------------------------------------------------
+// Every lane owns one predecessor metric `pre` (even predecessor if its lane bit q is 0, odd if 1) and computes the
+// two candidates that run through it:
+//     keep = pre + tab[c_keep]   candidate for the next state that stays in this lane
+//     send = pre + tab[c_send]   candidate for the partner lane's next state           (c_send = 3 - c_keep)
+// then receives the partner's `send` as `recv`.  The reference takes the odd predecessor only on strict '>':
+//     lane bit q = 0:  a0 = keep, a1 = recv   take1 = recv > keep
+//     lane bit q = 1:  a0 = recv, a1 = keep   take1 = keep > recv
+// New metric = max(keep, recv) in both cases.  With d = recv - keep the decision is a per-lane float-class test of d
+// (positive classes for bit-0 lanes, negative classes for bit-1 lanes; d == 0 is a tie -> even predecessor), so one
+// v_cmp_class produces the whole survivor word.  For q = 4,5 a permlane swap delivers a0 in one register and a1 in
+// the other for every lane, and the decision is a plain a1 > a0.
+//
+// DPP operands sit inside inline asm, invisible to the compiler's hazard recogniser: a VGPR written by VALU needs
+// 2 wait states before a DPP read, hence the leading "s_nop 1" of every DPP block.
 struct LeanK {          // lane constants for one exchange phase q
-  float a, b;           // own-candidate coefficients   tab[c]   = a*t0 + b*t1
-  float a2, b2;         // partner-candidate            tab[3-c] = a2*t0 + b2*t1
+  float ka, kb;         // keep coefficients   tab[c]   = ka*t0 + kb*t1
+  float sa, sb;         // send coefficients   tab[3-c] = sa*t0 + sb*t1
+  int cls;              // v_cmp_class mask for d = recv - keep (q <= 3)
 };
 
-// HAVE0/HAVE1: which of (t0, t1) exist at this trellis step (puncturing); a missing one is 0.0f in the reference.
-template <int Q, bool HAVE0, bool HAVE1>
-__device__ __forceinline__ float lean_step(float pre, const LeanK& k, float t0, float t1, unsigned long long* __restrict__ sv_word)
+#define C8P_CLS_POS 0x380   // +denormal | +normal | +inf
+#define C8P_CLS_NEG 0x01C   // -inf | -normal | -denormal
+
+template <bool HAVE0, bool HAVE1>
+__device__ __forceinline__ float cand(float pre, float ca, float cb, float t0, float t1)
 {
-  float bmU, bmV;
-  if (HAVE0 && HAVE1) { bmU = __builtin_fmaf(k.a, t0, k.b * t1); bmV = __builtin_fmaf(k.a2, t0, k.b2 * t1); }
-  else if (HAVE0) { bmU = k.a * t0; bmV = k.a2 * t0; }
-  else { bmU = k.b * t1; bmV = k.b2 * t1; }
-  const float u = pre + bmU;                    // candidate through this lane's own metric
-  const float v = partner_add<Q>(pre, bmV);     // candidate through the partner's metric
-  // lanes with bit q clear: own = even predecessor, a0 = u, a1 = v; bit q set: a0 = v, a1 = u.  take1 = a1 > a0.
-  const unsigned long long c1 = __ballot(v > u), c2 = __ballot(u > v);
-  const unsigned long long M = lane_bit_mask<Q>();
-  const unsigned long long W = (c1 & ~M) | (c2 & M);
-  asm volatile("s_store_dwordx2 %0, %1, 0x0" ::"s"(W), "s"(sv_word) : "memory");
-  return (v > u) ? v : u;                       // = the surviving metric in both cases (ties keep a0 = same value)
+  if (HAVE0 && HAVE1) return pre + __builtin_fmaf(ca, t0, cb * t1);   // tab[3] = t1 + t0 rounded once, then + pre
+  if (HAVE0) return __builtin_fmaf(ca, t0, pre);                        // pre + (t0 or 0): the product is exact
+  return __builtin_fmaf(cb, t1, pre);
 }
 
-__device__ __forceinline__ unsigned bad_llr(float x) { return ((__float_as_uint(x) & 0x7fffffffu) > C8P_LLR_BOUND_BITS) ? 1u : 0u; }
+template <int Q, bool HAVE0, bool HAVE1>
+__device__ __forceinline__ float lean_step(float pre, const LeanK& k, float t0, float t1, unsigned long long& W)
+{
+  // for q = 4,5 the constants are laid out so that `keep` is the even-predecessor candidate slot (see lean_forward)
+  const float keep = cand<HAVE0, HAVE1>(pre, k.ka, k.kb, t0, t1);
+  const float send = cand<HAVE0, HAVE1>(pre, k.sa, k.sb, t0, t1);
+  float nxt;
+  if (Q <= 3) {
+    float d;
+    if (Q == 0) {
+      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+    } else if (Q == 1) {
+      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+    } else if (Q == 2) {   // lane^3 inside the quad, then mirror inside 8 lanes (lane^7): together lane^4
+      float tq;
+      asm("s_nop 1\n\tv_mov_b32_dpp %0, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+          "v_sub_f32_dpp %1, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %2, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
+          : "=&v"(tq), "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+    } else {
+      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+    }
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(W) : "v"(d), "v"(k.cls));
+  } else {
+    // `keep`/`send` are here the candidates this lane computes for the a0-register / a1-register respectively;
+    // the swap moves each to the lane that needs it: afterwards r[0] = a0 and r[1] = a1 in every lane.
+    float a0, a1;
+    if (Q == 4) {
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(keep), __float_as_uint(send), false, false);
+      a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+    } else {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(keep), __float_as_uint(send), false, false);
+      a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+    }
+    W = __ballot(a1 > a0);
+    asm("v_max_f32 %0, %1, %2" : "=v"(nxt) : "v"(a0), "v"(a1));
+  }
+  return nxt;
+}
+
+// range check applied where LLRs are produced (k_demod_sym) or handed in (k_llr_check), one flag per packet
+__device__ __forceinline__ bool bad_llr(float x) { return (__float_as_uint(x) & 0x7fffffffu) > C8P_LLR_BOUND_BITS; }
 
 // One super-iteration = PER trellis steps (lcm of the 6 exchange phases and the puncture period), NL LLRs.
 template <int CR> struct RateInfo;
@@ -110,24 +136,53 @@ template <int CR> __device__ __forceinline__ constexpr int idx1(int j)
        : ((j % 5) == 0 ? 6 * (j / 5) + 1 : (j % 5) == 2 ? 6 * (j / 5) + 3 : (j % 5) == 4 ? 6 * (j / 5) + 5 : -1);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// survivor words leave through the scalar unit; two consecutive steps share one 16-byte store (the scalar store
+// path is limited by store count, not bytes: 8-byte stores cost 40 % of the kernel, measured)
+template <int OFF> __device__ __forceinline__ void store_w1(unsigned long long w, unsigned long long* __restrict__ base)
+{
+#ifndef C8P_EXP_NOSTORE
+  asm volatile("s_store_dwordx2 %0, %1, %2\n\ts_nop 3" ::"s"(w), "s"(base), "n"(OFF) : "memory");
+#else
+  asm volatile("; W %0 %1" ::"s"(w), "s"(base));
+#endif
+}
+template <int OFF> __device__ __forceinline__ void store_w2(unsigned long long w0, unsigned long long w1, unsigned long long* __restrict__ base)
+{
+  u32x4 q;
+  q.x = (unsigned)w0; q.y = (unsigned)(w0 >> 32); q.z = (unsigned)w1; q.w = (unsigned)(w1 >> 32);
+#ifndef C8P_EXP_NOSTORE
+  asm volatile("s_store_dwordx4 %0, %1, %2\n\ts_nop 3" ::"s"(q), "s"(base), "n"(OFF) : "memory");
+#else
+  asm volatile("; W %0 %1" ::"s"(q), "s"(base));
+#endif
+}
+
 template <int CR, int J, bool GUARD>
 __device__ __forceinline__ void lean_steps(float& pre, const LeanK (&K)[6], const float (&x)[RateInfo<CR>::NL],
                                            unsigned long long* __restrict__ sv, int tb, int Tn)
 {
-  if constexpr (J < RateInfo<CR>::PER) {
+  if constexpr (J < RateInfo<CR>::PER) {       // PER is even: steps go in pairs (J, J+1), J even => 16-byte aligned
     if (!GUARD || tb + J < Tn) {
-      constexpr int i0 = idx0<CR>(J), i1 = idx1<CR>(J);
-      constexpr int Q = J % 6;
-      const float t0 = i0 >= 0 ? x[i0 >= 0 ? i0 : 0] : 0.0f;
-      const float t1 = i1 >= 0 ? x[i1 >= 0 ? i1 : 0] : 0.0f;
-      pre = lean_step<Q, (i0 >= 0), (i1 >= 0)>(pre, K[Q], t0, t1, sv + tb + J);
-      lean_steps<CR, J + 1, GUARD>(pre, K, x, sv, tb, Tn);
+      constexpr int i0 = idx0<CR>(J), i1 = idx1<CR>(J), j0 = idx0<CR>(J + 1), j1 = idx1<CR>(J + 1);
+      unsigned long long W0, W1;
+      pre = lean_step<J % 6, (i0 >= 0), (i1 >= 0)>(pre, K[J % 6], i0 >= 0 ? x[i0 >= 0 ? i0 : 0] : 0.0f,
+                                                    i1 >= 0 ? x[i1 >= 0 ? i1 : 0] : 0.0f, W0);
+      if (!GUARD || tb + J + 1 < Tn) {
+        pre = lean_step<(J + 1) % 6, (j0 >= 0), (j1 >= 0)>(pre, K[(J + 1) % 6], j0 >= 0 ? x[j0 >= 0 ? j0 : 0] : 0.0f,
+                                                            j1 >= 0 ? x[j1 >= 0 ? j1 : 0] : 0.0f, W1);
+        store_w2<8 * J>(W0, W1, sv + tb);
+        lean_steps<CR, J + 2, GUARD>(pre, K, x, sv, tb, Tn);
+      } else {
+        store_w1<8 * J>(W0, sv + tb);
+      }
     }
   }
 }
 
 template <int CR>
-__device__ __forceinline__ unsigned lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned long long* __restrict__ sv)
+__device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned long long* __restrict__ sv)
 {
   constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL;
   const int lane = lane_id();
@@ -135,31 +190,33 @@ __device__ __forceinline__ unsigned lean_forward(const float* __restrict__ Lg, i
 #pragma unroll
   for (int q = 0; q < 6; q++) {
     const int nst = rotr6(lane, (q + 1) % 6);          // state held by this lane at time t+1, t mod 6 == q
-    const int m = nst & 31, b = nst >> 5;
-    const int cU = b ? sv_out(2 * m + 1, 1) : sv_out(2 * m, 0);
-    K[q].a = (cU >> 1) ? 1.0f : 0.0f; K[q].b = (cU & 1) ? 1.0f : 0.0f;
-    K[q].a2 = 1.0f - K[q].a; K[q].b2 = 1.0f - K[q].b;
+    const int m = nst & 31, b = nst >> 5;              // b == lane bit q
+    const int cK = b ? sv_out(2 * m + 1, 1) : sv_out(2 * m, 0);   // class of the candidate that stays in this lane
+    const int cS = 3 - cK;                                         // class of the candidate sent to the partner
+    // q <= 3: (ka,kb) = keep, (sa,sb) = send.
+    // q >= 4: the swap exchanges the upper halves of the first register with the lower halves of the second, so the
+    //         first register must hold {bit 0: keep (= a0), bit 1: send (partner's a0)} and the second
+    //         {bit 0: send (partner's a1), bit 1: keep (= a1)}.
+    const int c1 = (q >= 4 && b) ? cS : cK;
+    const int c2 = (q >= 4 && b) ? cK : cS;
+    K[q].ka = (c1 >> 1) ? 1.0f : 0.0f; K[q].kb = (c1 & 1) ? 1.0f : 0.0f;
+    K[q].sa = (c2 >> 1) ? 1.0f : 0.0f; K[q].sb = (c2 & 1) ? 1.0f : 0.0f;
+    K[q].cls = b ? C8P_CLS_NEG : C8P_CLS_POS;
   }
   c4float* L = (c4float*)Lg;
   float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;      // state 0 sits in lane 0 under every rotation
-  unsigned bad = 0;
   int tb = 0, lb = 0;
   float x[NL];
   // full super-iterations
   for (; tb + PER <= Tn; tb += PER, lb += NL) {
 #pragma unroll
     for (int i = 0; i < NL; i++) { x[i] = L[lb + i]; }
-#pragma unroll
-    for (int i = 0; i < NL; i++) { bad |= bad_llr(x[i]); }
     lean_steps<CR, 0, false>(pre, K, x, sv, tb, Tn);
   }
   if (tb < Tn) {   // tail: fewer than PER steps left, loads clamped to the packet's own LLRs
 #pragma unroll
     for (int i = 0; i < NL; i++) { const int li = lb + i; x[i] = li < n_llr ? L[li] : 0.0f; }
-#pragma unroll
-    for (int i = 0; i < NL; i++) { bad |= bad_llr(x[i]); }
     lean_steps<CR, 0, true>(pre, K, x, sv, tb, Tn);
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  return bad;
 }
