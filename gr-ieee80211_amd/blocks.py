@@ -1,0 +1,139 @@
+"""ctypes driver of libc8p_blocks.so — the C++ mirror of gr::ieee80211::demod / demod2 / decode.
+
+Feeds tagged item streams through general_work() in scheduler-sized chunks and collects the output stream,
+its tags, and the published PDUs.  Plumbing for tests and examples; a GNU Radio install uses the C++ classes
+directly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libc8p_blocks.so")
+ENGINE_LIB = os.path.join(_HERE, "libc8p_rx.so")
+_LIB = None
+
+DEMOD, DEMOD2, DECODE = 0, 1, 2
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libc8p_blocks.so is not built (make -C gr-ieee80211_amd/host)")
+        L = C.CDLL(LIB_PATH)
+        L.c8ph_create.restype = C.c_void_p
+        L.c8ph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.c8ph_destroy.argtypes = [C.c_void_p]
+        L.c8ph_push_items.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        L.c8ph_push_tag_long.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_long]
+        L.c8ph_push_tag_float.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_float]
+        L.c8ph_push_tag_c32.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_void_p, C.c_int]
+        L.c8ph_run.restype = C.c_long
+        L.c8ph_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.c8ph_error.restype = C.c_char_p
+        L.c8ph_error.argtypes = [C.c_void_p]
+        for f in ("c8ph_out_count", "c8ph_tag_count", "c8ph_msg_count", "c8ph_dbg_count"):
+            getattr(L, f).restype = C.c_long
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.c8ph_out_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.c8ph_tag_get.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_uint64), C.c_char_p, C.c_int, C.POINTER(C.c_long),
+                                   C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.c8ph_tag_vec.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.c8ph_msg_len.restype = C.c_long
+        L.c8ph_msg_len.argtypes = [C.c_void_p, C.c_long]
+        L.c8ph_msg_copy.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.c8ph_dbg_get.argtypes = [C.c_void_p, C.c_long, C.c_char_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+class Block:
+    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True):
+        self.L = lib()
+        err = C.create_string_buffer(512)
+        self.h = self.L.c8ph_create(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
+                                    int(flush_when_idle), err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        self.kind = kind
+
+    def close(self):
+        if self.h:
+            self.L.c8ph_destroy(self.h)
+            self.h = None
+
+    def push_items(self, port, arr):
+        a = np.ascontiguousarray(arr)
+        self.L.c8ph_push_items(self.h, port, a.ctypes.data, len(a))
+
+    def push_tag(self, offset, key, value):
+        k = key.encode()
+        if isinstance(value, (int, np.integer)):
+            self.L.c8ph_push_tag_long(self.h, offset, k, int(value))
+        elif isinstance(value, (float, np.floating)):
+            self.L.c8ph_push_tag_float(self.h, offset, k, float(value))
+        else:
+            v = np.ascontiguousarray(value, np.complex64)
+            self.L.c8ph_push_tag_c32(self.h, offset, k, v.ctypes.data, len(v))
+
+    def run(self, chunk=4096, nout=8192, flush_at_end=True):
+        n = self.L.c8ph_run(self.h, chunk, nout, int(flush_at_end))
+        if n < 0:
+            raise RuntimeError(self.L.c8ph_error(self.h).decode())
+        return n
+
+    def output(self):
+        n = self.L.c8ph_out_count(self.h)
+        out = np.zeros(n, np.float32)
+        if n:
+            self.L.c8ph_out_copy(self.h, out.ctypes.data)
+        return out
+
+    def tags(self):
+        res = []
+        for i in range(self.L.c8ph_tag_count(self.h)):
+            off, l, f, vn = C.c_uint64(0), C.c_long(0), C.c_float(0), C.c_int(0)
+            key = C.create_string_buffer(64)
+            kind = self.L.c8ph_tag_get(self.h, i, C.byref(off), key, 64, C.byref(l), C.byref(f), C.byref(vn))
+            if kind == 0:
+                val = l.value
+            elif kind == 1:
+                val = f.value
+            else:
+                v = np.zeros(vn.value, np.complex64)
+                self.L.c8ph_tag_vec(self.h, i, v.ctypes.data)
+                val = v
+            res.append((off.value, key.value.decode(), val))
+        return res
+
+    def messages(self):
+        res = []
+        for i in range(self.L.c8ph_msg_count(self.h)):
+            n = self.L.c8ph_msg_len(self.h, i)
+            b = np.zeros(n, np.uint8)
+            self.L.c8ph_msg_copy(self.h, i, b.ctypes.data)
+            res.append((n, b.tobytes()))
+        return res
+
+    def debug_lines(self):
+        res = []
+        for i in range(self.L.c8ph_dbg_count(self.h)):
+            buf = C.create_string_buffer(1024)
+            self.L.c8ph_dbg_get(self.h, i, buf, 1024)
+            res.append(buf.value.decode())
+        return res
+
+
+def feed_demod(blk, pk, iq, chan):
+    """Lay a batch out as the tagged stream signal/signal2 would produce: packets back to back."""
+    pos = 0
+    for p in pk:
+        n = int(p["n_items"])
+        for a in range(int(p["n_ant"])):
+            blk.push_items(a, iq[int(p["iq_off"][a]):int(p["iq_off"][a]) + n])
+        blk.push_tag(pos, "cfo", float(p["cfo"])); blk.push_tag(pos, "snr", float(p["snr"])); blk.push_tag(pos, "rssi", float(p["rssi"]))
+        blk.push_tag(pos, "seq", int(p["seq"])); blk.push_tag(pos, "mcs", int(p["lsig_mcs"])); blk.push_tag(pos, "len", int(p["lsig_len"]))
+        blk.push_tag(pos, "nsamp", int(p["lsig_nsamp"])); blk.push_tag(pos, "chan", chan[int(p["chan_off"]):int(p["chan_off"]) + 64])
+        pos += n

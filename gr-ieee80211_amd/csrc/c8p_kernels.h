@@ -736,7 +736,9 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                uint8_t* __restrict__ sbits_o, const uint32_t* __restrict__ flags,
                                                int keep_bits, int n)
 {
+  constexpr int TB = 8;                                   // survivor steps per segment staged per tile
   __shared__ unsigned long long bw[(C8P_DECODE_T_MAX + 63) / 64 + 2];
+  __shared__ unsigned long long tile[64][TB + 1];          // +1: rows land in different LDS banks
   const int p = blockIdx.x;
   if (p >= n) return;
   const int lane = lane_id();
@@ -765,28 +767,48 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       // Lane j walks steps [j*S, (j+1)*S) backwards from an assumed end lane; the assumption of segment j is the
       // begin lane segment j+1 computed.  Iterating to a fixed point makes every boundary consistent with the
       // true end (lane 0 = state 0 at T), i.e. the result is the reference's full traceback (vstb_end :282-302).
+      // Survivor words are staged through LDS in tiles of TB steps per segment, loaded with coalesced 16-byte
+      // reads (a naive per-lane walk issues 64 separate cache-line requests per step and is request-bound).
       const unsigned long long* SW = (const unsigned long long*)SV;
-      const int S = 64 * ((Tn + 4095) / 4096);
+      const int S = 64 * ((Tn + 4095) / 4096);          // steps per segment (multiple of 64)
       const int nseg = (Tn + S - 1) / S;
       const int tbeg = lane * S;
       const int tend = min(tbeg + S, Tn);
+      const int nblk = S / TB;
       int Dend = 0, Dbeg = 0;
       bool redo = lane < nseg;
       for (int it = 0; it < 66; it++) {
-        if (redo) {
-          int D = Dend;
-          unsigned long long mask = 0;
-          int q = (tend - 1) % 6;
-          for (int tt = tend - 1; tt >= tbeg; tt--) {
-            const unsigned long long w = SW[tt];
-            const int take = (int)((w >> D) & 1ull);
-            if ((D >> q) & 1) mask |= 1ull << (tt & 63);
-            D = (D & ~(1 << q)) | (take << q);
-            q = q == 0 ? 5 : q - 1;
-            if ((tt & 63) == 0) { bw[tt >> 6] = mask; mask = 0; }
+        int D = Dend;
+        unsigned long long mask = 0;
+        for (int kb = nblk - 1; kb >= 0; kb--) {
+          // tile[row][c] = SW[row*S + kb*TB + c]; 4 lanes fetch one row (16 B each), 16 rows per load instruction
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = r * 16 + (lane >> 2), c2 = (lane & 3) * 2;
+            const long long idx = (long long)row * S + kb * TB + c2;
+            ulonglong2 v = make_ulonglong2(0ull, 0ull);
+            if (row < nseg && idx + 1 < (long long)Tn + 1) v = *(const ulonglong2*)(SW + idx);   // idx even: 16-byte aligned
+            tile[row][c2] = v.x; tile[row][c2 + 1] = v.y;
           }
-          Dbeg = D;
+          __syncthreads();
+          if (redo) {
+            const int t0 = tbeg + kb * TB;
+#pragma unroll
+            for (int k = TB - 1; k >= 0; k--) {
+              const int tt = t0 + k;
+              if (tt < tend) {
+                const int q = tt % 6;
+                const unsigned long long w = tile[lane][k];
+                const int take = (int)((w >> D) & 1ull);
+                if ((D >> q) & 1) mask |= 1ull << (tt & 63);
+                D = (D & ~(1 << q)) | (take << q);
+                if ((tt & 63) == 0) { bw[tt >> 6] = mask; mask = 0; }
+              }
+            }
+          }
         }
+        if (redo) Dbeg = D;
         int nd = __shfl_down(Dbeg, 1, 64);
         if (lane >= nseg - 1) nd = 0;
         redo = (lane < nseg) && (nd != Dend);

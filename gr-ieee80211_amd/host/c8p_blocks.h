@@ -1,0 +1,127 @@
+// c8p_blocks.h — host-side mirror of the reference's block API for the hot path:
+//
+//   gr::ieee80211::demod::make(int mupos, int mugid)   include/gnuradio/ieee80211/demod.h:35
+//   gr::ieee80211::demod2::make()                       include/gnuradio/ieee80211/demod2.h
+//   gr::ieee80211::decode::make(bool ifdebug)           include/gnuradio/ieee80211/decode.h
+//
+// Same factories, same general_work()/forecast() contract, same stream-tag keys and PDU layout as
+// lib/{demod,demod2,decode}_impl.cc, but every block is a *batching front* for the C ABI of include/c8p_rx.h:
+// it cuts the tagged item stream into packets, hands complete packets to c8p_demod()/c8p_decode() in batches,
+// and replays the results (LLR items + tags, or PDUs) in arrival order.
+//
+// GNU Radio is not installed in the build image, so the runtime services a gr::block gets from the scheduler
+// (item counters, tag access, consume, message ports) are reached through the small `block_io` interface below.
+// INTEGRATION.md shows the 1:1 adapter onto gr::block / pmt for a machine that has GNU Radio 3.10.
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "c8p_rx.h"
+
+typedef std::complex<float> gr_complex;
+typedef std::vector<int> gr_vector_int;
+typedef std::vector<const void*> gr_vector_const_void_star;
+typedef std::vector<void*> gr_vector_void_star;
+
+namespace gr {
+namespace ieee80211 {
+
+// value of a stream tag: the three PMT kinds the hot path uses (long, float, c32vector)
+struct tag_value {
+  enum kind_t { LONG, FLOAT, C32VECTOR } kind = LONG;
+  long l = 0;
+  float f = 0.f;
+  std::vector<gr_complex> v;
+  static tag_value from_long(long x) { tag_value t; t.kind = LONG; t.l = x; return t; }
+  static tag_value from_float(float x) { tag_value t; t.kind = FLOAT; t.f = x; return t; }
+  static tag_value from_c32vector(const std::vector<gr_complex>& x) { tag_value t; t.kind = C32VECTOR; t.v = x; return t; }
+};
+struct tag_t {
+  uint64_t offset = 0;
+  std::string key;
+  tag_value value;
+};
+// a published message: pmt::cons(dict{"len": len}, blob)
+struct pdu_t {
+  long len = 0;
+  std::vector<uint8_t> blob;
+};
+
+// the slice of gr::block a general_work() needs
+class block_io
+{
+public:
+  virtual ~block_io() {}
+  virtual uint64_t nitems_read(unsigned port) = 0;
+  virtual uint64_t nitems_written(unsigned port) = 0;
+  virtual void get_tags_in_range(std::vector<tag_t>& v, unsigned port, uint64_t start, uint64_t end) = 0;
+  virtual void add_item_tag(unsigned port, uint64_t offset, const std::string& key, const tag_value& value) = 0;
+  virtual void consume_each(int n) = 0;
+  virtual void message_port_pub(const std::string& port, const pdu_t& msg) = 0;
+  virtual void debug_print(const std::string& line) = 0;     // the reference's `dout` (std::cout when ifdebug)
+};
+
+// the C ABI the blocks call; defaults to the symbols of libc8p_rx.so, tests inject another table
+struct c8p_api {
+  c8p_ctx* (*create)(const c8p_cfg*);
+  void (*destroy)(c8p_ctx*);
+  const char* (*last_error)(const c8p_ctx*);
+  int (*demod)(c8p_ctx*, const c8p_batch_in*);
+  int (*decode)(c8p_ctx*, const c8p_decode_in*);
+  int (*sync)(c8p_ctx*);
+  const void* (*buffer)(c8p_ctx*, int, uint64_t*);
+  int (*fetch)(c8p_ctx*, int, void*, uint64_t, uint64_t);
+};
+// resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
+c8p_api load_c8p_api(const std::string& so_path);
+
+struct batching_cfg {
+  int max_batch = 256;          // packets per c8p_* call
+  bool flush_when_idle = true;  // submit a partial batch when the input runs dry (bounds latency in a live flowgraph)
+  int device = 0;
+};
+
+class c8p_block
+{
+public:
+  virtual ~c8p_block() {}
+  virtual void forecast(int noutput_items, gr_vector_int& ninput_items_required) = 0;
+  virtual int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                           gr_vector_void_star& output_items) = 0;
+  // end of stream: submit whatever is buffered (a live flowgraph never calls this)
+  virtual void flush() = 0;
+  void set_io(block_io* io) { d_io = io; }
+
+protected:
+  block_io* d_io = nullptr;
+};
+
+class demod : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<demod> sptr;
+  static sptr make(int mupos, int mugid);
+  static sptr make(int mupos, int mugid, const c8p_api& api, const batching_cfg& cfg);
+};
+class demod2 : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<demod2> sptr;
+  static sptr make();
+  static sptr make(const c8p_api& api, const batching_cfg& cfg);
+};
+class decode : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<decode> sptr;
+  static sptr make(bool ifdebug);
+  static sptr make(bool ifdebug, const c8p_api& api, const batching_cfg& cfg);
+};
+
+} // namespace ieee80211
+} // namespace gr

@@ -1,0 +1,155 @@
+// c8p_host_capi.cc — C entry points around the block mirror, used by the Python tests and by INTEGRATION examples:
+// an in-memory block_io (tagged item streams in, items/tags/messages out) plus a tiny run loop that calls
+// general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+#include "c8p_blocks.h"
+
+using namespace gr::ieee80211;
+
+namespace {
+
+struct harness : public block_io {
+  std::shared_ptr<c8p_block> blk;
+  int nports = 1;
+  size_t item_size = sizeof(gr_complex);
+  std::vector<std::vector<uint8_t>> in;         // per port, remaining bytes from read position
+  std::vector<tag_t> in_tags;                   // port 0, absolute offsets
+  uint64_t n_read = 0, n_written = 0;
+  int consumed_this_call = 0;
+  std::vector<float> out_items;
+  std::vector<tag_t> out_tags;
+  std::vector<pdu_t> msgs;
+  std::vector<std::string> dbg;
+  std::string err;
+
+  uint64_t nitems_read(unsigned) override { return n_read; }
+  uint64_t nitems_written(unsigned) override { return n_written; }
+  void get_tags_in_range(std::vector<tag_t>& v, unsigned, uint64_t a, uint64_t b) override
+  {
+    v.clear();
+    for (const auto& t : in_tags) if (t.offset >= a && t.offset < b) v.push_back(t);
+  }
+  void add_item_tag(unsigned, uint64_t off, const std::string& key, const tag_value& val) override
+  {
+    tag_t t; t.offset = off; t.key = key; t.value = val; out_tags.push_back(t);
+  }
+  void consume_each(int n) override { consumed_this_call = n; }
+  void message_port_pub(const std::string&, const pdu_t& m) override { msgs.push_back(m); }
+  void debug_print(const std::string& s) override { dbg.push_back(s); }
+};
+
+} // namespace
+
+extern "C" {
+
+void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, char* errbuf, int errcap)
+{
+  try {
+    harness* h = new harness();
+    c8p_api api = load_c8p_api(lib);
+    batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
+    if (kind == 0) { h->blk = demod::make(mupos, 0, api, cfg); h->nports = 1; }
+    else if (kind == 1) { h->blk = demod2::make(api, cfg); h->nports = 2; }
+    else { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
+    h->in.resize(h->nports);
+    h->blk->set_io(h);
+    return h;
+  } catch (const std::exception& e) {
+    if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
+    return nullptr;
+  }
+}
+void c8ph_destroy(void* p) { delete static_cast<harness*>(p); }
+
+void c8ph_push_items(void* p, int port, const void* data, long n_items)
+{
+  harness* h = static_cast<harness*>(p);
+  const uint8_t* b = static_cast<const uint8_t*>(data);
+  h->in[port].insert(h->in[port].end(), b, b + (size_t)n_items * h->item_size);
+}
+void c8ph_push_tag_long(void* p, uint64_t off, const char* key, long v)
+{
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_long(v); static_cast<harness*>(p)->in_tags.push_back(t);
+}
+void c8ph_push_tag_float(void* p, uint64_t off, const char* key, float v)
+{
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_float(v); static_cast<harness*>(p)->in_tags.push_back(t);
+}
+void c8ph_push_tag_c32(void* p, uint64_t off, const char* key, const float* reim, int n)
+{
+  std::vector<gr_complex> v(n);
+  for (int i = 0; i < n; i++) v[i] = gr_complex(reim[2 * i], reim[2 * i + 1]);
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_c32vector(v); static_cast<harness*>(p)->in_tags.push_back(t);
+}
+
+// Run until the input is exhausted; `chunk` = max items offered per call, `nout` = noutput_items per call.
+// Returns the number of general_work calls, or -1 on error (c8ph_error()).
+long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
+{
+  harness* h = static_cast<harness*>(p);
+  try {
+    long calls = 0;
+    int idle = 0;
+    std::vector<float> obuf((size_t)std::max(nout, 1));
+    while (idle < 4) {
+      size_t avail = h->in[0].size() / h->item_size;
+      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->in[q].size() / h->item_size);
+      const int n = (int)std::min<size_t>(avail, (size_t)chunk);
+      gr_vector_int nin(h->nports, n);
+      gr_vector_const_void_star ins(h->nports);
+      for (int q = 0; q < h->nports; q++) ins[q] = h->in[q].data();
+      gr_vector_void_star outs(1, obuf.data());
+      h->consumed_this_call = 0;
+      const int produced = h->blk->general_work(nout, nin, ins, outs);
+      calls++;
+      for (int q = 0; q < h->nports; q++)
+        h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->item_size);
+      h->n_read += h->consumed_this_call;
+      h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + produced);
+      h->n_written += produced;
+      idle = (produced == 0 && h->consumed_this_call == 0) ? idle + 1 : 0;
+      if (idle == 2 && flush_at_end && avail == 0) h->blk->flush();
+    }
+    return calls;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return -1;
+  }
+}
+const char* c8ph_error(void* p) { return static_cast<harness*>(p)->err.c_str(); }
+
+long c8ph_out_count(void* p) { return (long)static_cast<harness*>(p)->out_items.size(); }
+void c8ph_out_copy(void* p, float* dst) { harness* h = static_cast<harness*>(p); memcpy(dst, h->out_items.data(), h->out_items.size() * 4); }
+long c8ph_tag_count(void* p) { return (long)static_cast<harness*>(p)->out_tags.size(); }
+// kind: 0 long, 1 float, 2 c32vector (vec_n = element count)
+int c8ph_tag_get(void* p, long i, uint64_t* off, char* key, int keycap, long* l, float* f, int* vec_n)
+{
+  const tag_t& t = static_cast<harness*>(p)->out_tags[(size_t)i];
+  *off = t.offset; strncpy(key, t.key.c_str(), keycap - 1); key[keycap - 1] = 0;
+  *l = t.value.l; *f = t.value.f; *vec_n = (int)t.value.v.size();
+  return (int)t.value.kind;
+}
+void c8ph_tag_vec(void* p, long i, float* reim)
+{
+  const tag_t& t = static_cast<harness*>(p)->out_tags[(size_t)i];
+  for (size_t k = 0; k < t.value.v.size(); k++) { reim[2 * k] = t.value.v[k].real(); reim[2 * k + 1] = t.value.v[k].imag(); }
+}
+long c8ph_msg_count(void* p) { return (long)static_cast<harness*>(p)->msgs.size(); }
+long c8ph_msg_len(void* p, long i) { return static_cast<harness*>(p)->msgs[(size_t)i].len; }
+void c8ph_msg_copy(void* p, long i, uint8_t* dst)
+{
+  const pdu_t& m = static_cast<harness*>(p)->msgs[(size_t)i];
+  memcpy(dst, m.blob.data(), m.blob.size());
+}
+long c8ph_dbg_count(void* p) { return (long)static_cast<harness*>(p)->dbg.size(); }
+int c8ph_dbg_get(void* p, long i, char* dst, int cap)
+{
+  const std::string& s = static_cast<harness*>(p)->dbg[(size_t)i];
+  strncpy(dst, s.c_str(), cap - 1); dst[cap - 1] = 0;
+  return (int)s.size();
+}
+
+} // extern "C"

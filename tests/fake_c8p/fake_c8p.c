@@ -1,0 +1,76 @@
+/* TEST-ONLY stand-in for libc8p_rx.so: the same C entry points on top of the CPU oracle, so the host-side block
+ * mirror (batching, tag replay, PDU publishing) can be exercised without a GPU.  Never shipped, never used by the
+ * product path, bench.py or smoke(). */
+#include <stdlib.h>
+#include <string.h>
+#include "c8p_rx.h"
+#include "c8p_oracle.h"
+
+struct c8p_ctx {
+  int n;
+  c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu;
+};
+#define PDU_STRIDE 8192
+
+c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); return (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); }
+static void drop(c8p_ctx* c) { free(c->tags); free(c->outs); free(c->llr); free(c->pdu); free(c->mu); memset(c, 0, sizeof(*c)); }
+void c8p_destroy(c8p_ctx* c) { if (c) { drop(c); free(c); } }
+const char* c8p_last_error(const c8p_ctx* c) { (void)c; return "fake backend"; }
+
+int c8p_demod(c8p_ctx* c, const c8p_batch_in* in)
+{
+  drop(c);
+  c->n = in->n_pkt;
+  c->tags = (c8p_pkt_tags*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_tags));
+  c->mu = (c8p_c32*)calloc((size_t)in->n_pkt * 128 + 1, sizeof(c8p_c32));
+  uint64_t cap = 0;
+  for (int p = 0; p < in->n_pkt; p++) cap += (uint64_t)(in->pkts[p].n_items / 72 + 1) * 832 + 1024;
+  c->llr = (float*)calloc(cap + 1, sizeof(float));
+  uint64_t off = 0;
+  for (int p = 0; p < in->n_pkt; p++) {
+    c8po_demod(&in->pkts[p], in->iq, in->chan, &c->tags[p], c->llr + off, c->mu + 128 * p);
+    c->tags[p].llr_off = off;
+    off += (uint64_t)(in->pkts[p].n_items / 72 + 1) * 832 + 1024;
+  }
+  c->n_llr = cap;
+  return C8P_OK;
+}
+
+int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
+{
+  free(c->outs); free(c->pdu);
+  c->outs = (c8p_pkt_out*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_out));
+  c->pdu = (uint8_t*)calloc((size_t)in->n_pkt * PDU_STRIDE + 1, 1);
+  c->n_pdu = (uint64_t)in->n_pkt * PDU_STRIDE;
+  c->n = in->n_pkt;
+  for (int p = 0; p < in->n_pkt; p++) {
+    c8po_decode(&in->tags[p], in->llr + in->tags[p].llr_off, in->mu2x1chan ? in->mu2x1chan + 128 * p : NULL, NULL, NULL,
+                c->pdu + (size_t)p * PDU_STRIDE, PDU_STRIDE, &c->outs[p]);
+    c->outs[p].pdu_off = (uint64_t)p * PDU_STRIDE;
+  }
+  return C8P_OK;
+}
+int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
+
+const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
+{
+  const void* p = NULL; uint64_t b = 0;
+  switch (which) {
+    case C8P_BUF_TAGS: p = c->tags; b = (uint64_t)c->n * sizeof(c8p_pkt_tags); break;
+    case C8P_BUF_LLR: p = c->llr; b = c->n_llr * sizeof(float); break;
+    case C8P_BUF_OUT: p = c->outs; b = (uint64_t)c->n * sizeof(c8p_pkt_out); break;
+    case C8P_BUF_PDU: p = c->pdu; b = c->n_pdu; break;
+    case C8P_BUF_MUCHAN: p = c->mu; b = (uint64_t)c->n * 128 * sizeof(c8p_c32); break;
+    default: break;
+  }
+  if (!p) b = 0;
+  if (bytes) *bytes = b;
+  return p;
+}
+int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
+{
+  uint64_t b; const void* p = c8p_buffer(c, which, &b);
+  if (offset + bytes > b) return C8P_ERANGE;
+  memcpy(dst, (const char*)p + offset, bytes);
+  return C8P_OK;
+}
