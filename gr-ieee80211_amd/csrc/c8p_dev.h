@@ -94,7 +94,7 @@ __device__ __forceinline__ unsigned long long writelane_u64(unsigned long long v
 // 64-point forward DFT across the 64 lanes of a wave: lane n holds x[n] on entry, X[n] on return.
 // Radix-2 decimation-in-frequency, 6 exchange stages, bit-reversal at the end.  The butterflies run in fp64 and
 // the result is rounded to float once: the reference's FFT is FFTW3f (third party, plan-dependent rounding), the
-// oracle pins it to "exact DFT rounded to float", and fp64 butterflies reproduce that to the last float bit in all
+// parity tests pin it to "exact DFT rounded to float", and fp64 butterflies reproduce that to the last float bit in all
 // but ~1e-8 of the outputs, which keeps the whole LLR stream inside the 1e-5 parity bound even for |LLR| > 20.
 __device__ __forceinline__ double shfl_xor_d(double v, int m)
 {
