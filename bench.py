@@ -65,10 +65,12 @@ def main():
     chan_dev = engine.DevArray(chan_d.data_ptr(), chan.size, chan_d)
     t_gen = time.time() - t_gen
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    eng = engine.Engine(device=local, profile=True, stream=stream)
+    # engine-owned streams: consecutive batches are software-pipelined across C8P_SLOTS slots (upload / classify /
+    # symbol demod of batch i+1 overlap the decoder of batch i); eng.sync() joins all of them
+    eng = engine.Engine(device=local, profile=True)
 
     def barrier():
+        eng.sync()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -99,6 +101,13 @@ def main():
         elapsed = float(t.item())
     kt = eng.kernel_times()
 
+    # exclusive per-kernel durations: the same batch once more with a sync after every step (no overlap between slots)
+    eng.profile_reset()
+    for _ in range(3):
+        eng.rx(pk, iq_dev, chan_dev)
+        eng.sync()
+    kt_excl = eng.kernel_times()
+
     out = None
     if rank == 0:
         total_pkts = n_pkt * world * args.steps
@@ -107,6 +116,8 @@ def main():
         dom = max(("classify", "demod_sym", "viterbi_fwd", "finish"), key=lambda k: kern[k])
         dom_s = kern[dom] * 1e-3
         achieved = (B_ALG * n_pkt / dom_s) / 1e9 if dom_s > 0 else 0.0
+        kern_x = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in kt_excl.items()}
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": value, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -117,9 +128,12 @@ def main():
                        "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1),
                        "parallelism": "packet-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_packet": B_ALG, "packets_per_launch": n_pkt,
-                         "avg_launch_ms": {k: round(v, 4) for k, v in kern.items()}},
+                         "avg_launch_ms": {k: round(v, 4) for k, v in kern.items()},
+                         "note": "durations in the timed region overlap across pipeline slots; exclusive = same launches, one batch at a time",
+                         "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
+                         "achieved_exclusive": (B_ALG * n_pkt / (kern_x[dom] * 1e-3)) / 1e9 if kern_x[dom] > 0 else 0.0},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
@@ -130,6 +144,26 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic(dom):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, profiles/*/pmc_hbm.json).  FETCH_SIZE is taken as reported for the scalar-cache reads
+    of the lean decoder (64-byte requests); see DESIGN.md §7."""
+    name = {"viterbi_fwd": "k_viterbi_lean", "finish": "k_finish", "demod_sym": "k_demod_sym", "classify": "k_classify"}[dom]
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, d, "pmc_hbm.json")
+        if os.path.exists(f):
+            best = f
+    if not best:
+        return None, None
+    j = json.load(open(best))
+    k = j["kernels"].get(name)
+    if not k:
+        return None, None
+    return (k["fetch_size_kb_raw"] + k["write_size_kb"]) * 1024.0, os.path.relpath(best, ROOT)
 
 
 def cpu_baseline(pk, iq, chan, budget_s=12.0):

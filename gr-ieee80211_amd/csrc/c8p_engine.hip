@@ -168,26 +168,31 @@ struct Buf {
   size_t cap = 0;
 };
 
-struct c8p_ctx {
-  int device = 0;
+// One in-flight batch: its own stream, staging and result arenas.  A ctx owns several slots and rotates through
+// them, so that the latency-bound kernels of batch i+1 (upload, classify, symbol demod) overlap the VALU-bound
+// decoder of batch i on the same GPU.
+struct Slot {
   hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int profile = 0, keep_bits = 0;
-  std::string err;
-  DevTables* d_tab = nullptr;
-  // staging
   void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
-  // results / scratch
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags;
-  int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
-  // last submit
   int n_pkt = 0;
   size_t used[7] = {0, 0, 0, 0, 0, 0, 0};
   const void* ptr[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct c8p_ctx {
+  int device = 0;
+  bool own_stream = false;
+  int profile = 0, keep_bits = 0;
+  int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
+  std::string err;
+  DevTables* d_tab = nullptr;
+  std::vector<Slot> slots;
+  Slot* s = nullptr;                                 // slot of the most recent submit
+  int cur = -1;
   // profiling
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double k_ms[C8P_K_COUNT] = {0, 0, 0, 0, 0};
   int64_t k_cnt[C8P_K_COUNT] = {0, 0, 0, 0, 0};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -197,7 +202,7 @@ struct c8p_ctx {
 static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
 {
   if (bytes <= b.cap) return C8P_OK;
-  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
   size_t want = bytes + bytes / 4 + 4096;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return C8P_ENOMEM; }
@@ -206,11 +211,11 @@ static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
 }
 static int ensure_host(c8p_ctx* c, size_t bytes)
 {
-  if (bytes <= c->h_stage_cap) return C8P_OK;
-  if (c->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->h_stage)); c->h_stage = nullptr; }
+  if (bytes <= c->s->h_stage_cap) return C8P_OK;
+  if (c->s->h_stage) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipHostFree(c->s->h_stage)); c->s->h_stage = nullptr; }
   size_t want = bytes + bytes / 4 + 4096;
-  HIPCHK(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
-  c->h_stage_cap = want;
+  HIPCHK(c, hipHostMalloc(&c->s->h_stage, want, hipHostMallocDefault));
+  c->s->h_stage_cap = want;
   return C8P_OK;
 }
 
@@ -223,17 +228,20 @@ static hipEvent_t get_event(c8p_ctx* c)
 }
 struct KTimer {   // brackets one launch with events on the ctx stream when profiling is on
   c8p_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr;
-  KTimer(c8p_ctx* c_, int k_) : c(c_), k(k_) { if (c->profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); } }
-  ~KTimer() { if (c->profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back({k, {a, b}}); } }
+  KTimer(c8p_ctx* c_, int k_) : c(c_), k(k_) { if (c->profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->s->stream); } }
+  ~KTimer() { if (c->profile) { (void)hipEventRecord(b, c->s->stream); c->pending.push_back({k, {a, b}}); } }
 };
 static void drain_events(c8p_ctx* c)
 {
+  // only finished launches are folded in; launches of batches still in flight on other slots stay pending
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> keep;
   for (auto& pe : c->pending) {
+    if (hipEventQuery(pe.second.second) != hipSuccess) { keep.push_back(pe); continue; }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) { c->k_ms[pe.first] += ms; c->k_cnt[pe.first]++; }
     c->ev_pool.push_back(pe.second.first); c->ev_pool.push_back(pe.second.second);
   }
-  c->pending.clear();
+  c->pending.swap(keep);
 }
 
 extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
@@ -245,10 +253,20 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile; c->keep_bits = cfg->keep_bits;
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
-  if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
-  else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-    c->own_stream = true;
+  {
+    // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 3) engine-owned streams.
+    int nslot = 3;
+    const char* e = getenv("C8P_SLOTS");
+    if (e && atoi(e) >= 1 && atoi(e) <= 8) nslot = atoi(e);
+    if (cfg->stream) nslot = 1;
+    c->slots.resize(nslot);
+    c->own_stream = cfg->stream == nullptr;
+    for (int i = 0; i < nslot; i++) {
+      if (cfg->stream) c->slots[i].stream = (hipStream_t)cfg->stream;
+      else if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    }
+    c->s = &c->slots[0];
+    c->cur = 0;
   }
   if (hipMalloc((void**)&c->d_tab, sizeof(DevTables)) != hipSuccess) { delete c; return nullptr; }
   const DevTables& T = host_tables();
@@ -260,15 +278,17 @@ extern "C" void c8p_destroy(c8p_ctx* c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  for (Slot& sl : c->slots) (void)hipStreamSynchronize(sl.stream);
   drain_events(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  Buf* bufs[] = {&c->d_stage, &c->d_iq, &c->d_chan, &c->d_llr_in, &c->d_mu_in, &c->d_tags, &c->d_outs, &c->d_H, &c->d_mimo,
-                 &c->d_muchan, &c->d_llr, &c->d_surv, &c->d_bits, &c->d_sbits, &c->d_pdu, &c->d_flags};
-  for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (Slot& sl : c->slots) {
+    Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
+                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags};
+    for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (c->own_stream) (void)hipStreamDestroy(sl.stream);
+  }
   if (c->d_tab) (void)hipFree(c->d_tab);
-  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -339,35 +359,35 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
                               const cf* d_mu, const Plan& P, bool flags_ready)
 {
   int rc;
-  if ((rc = ensure(c, c->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_surv, sizeof(ulonglong2) * P.surv)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_pdu, P.pdu)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
-  const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->d_flags.p;
+  if ((rc = ensure(c, c->s->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_surv, sizeof(ulonglong2) * P.surv)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_pdu, P.pdu)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->s->d_flags.p;
   {
     // forward pass: lean kernel for every packet whose LLRs passed the range check, clamp-exact kernel for the rest
     KTimer kt(c, C8P_K_VITERBI);
     if (!c->exact_only) {
       if (!flags_ready)
-        hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, c->stream, d_tags, d_llr, (uint32_t*)c->d_flags.p, n);
-      hipLaunchKernelGGL(k_viterbi_lean, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p,
+        hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
+      hipLaunchKernelGGL(k_viterbi_lean, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                          d_flags, n);
     }
-    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->d_surv.p, d_flags, n);
+    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
   }
   {
     KTimer kt(c, C8P_K_FINISH);
-    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, c->stream, d_tags, d_lay, (const ulonglong2*)c->d_surv.p, d_mu,
-                       (const DevTables*)c->d_tab, (c8p_pkt_out*)c->d_outs.p, (uint8_t*)c->d_pdu.p, (uint8_t*)c->d_bits.p,
-                       (uint8_t*)c->d_sbits.p, d_flags, c->keep_bits, n);
+    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, (const ulonglong2*)c->s->d_surv.p, d_mu,
+                       (const DevTables*)c->d_tab, (c8p_pkt_out*)c->s->d_outs.p, (uint8_t*)c->s->d_pdu.p, (uint8_t*)c->s->d_bits.p,
+                       (uint8_t*)c->s->d_sbits.p, d_flags, c->keep_bits, n);
   }
   HIPCHK(c, hipGetLastError());
-  c->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->ptr[C8P_BUF_OUT] = c->d_outs.p;
-  c->used[C8P_BUF_PDU] = P.pdu; c->ptr[C8P_BUF_PDU] = c->d_pdu.p;
-  c->used[C8P_BUF_BITS] = c->keep_bits ? P.bits : 0; c->ptr[C8P_BUF_BITS] = c->d_bits.p;
-  c->used[C8P_BUF_SBITS] = c->keep_bits ? P.bits : 0; c->ptr[C8P_BUF_SBITS] = c->d_sbits.p;
+  c->s->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->s->ptr[C8P_BUF_OUT] = c->s->d_outs.p;
+  c->s->used[C8P_BUF_PDU] = P.pdu; c->s->ptr[C8P_BUF_PDU] = c->s->d_pdu.p;
+  c->s->used[C8P_BUF_BITS] = c->keep_bits ? P.bits : 0; c->s->ptr[C8P_BUF_BITS] = c->s->d_bits.p;
+  c->s->used[C8P_BUF_SBITS] = c->keep_bits ? P.bits : 0; c->s->ptr[C8P_BUF_SBITS] = c->s->d_sbits.p;
   return C8P_OK;
 }
 
@@ -377,10 +397,14 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->pkts || !in->iq || !in->chan))) { c->err = "bad batch"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
+  // next slot; its previous batch (submitted slots.size() submits ago) must be done before its arenas are reused
+  c->cur = (c->cur + 1) % (int)c->slots.size();
+  c->s = &c->slots[c->cur];
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
   const int n = in->n_pkt;
-  c->n_pkt = n;
-  for (int i = 0; i < 7; i++) { c->used[i] = 0; c->ptr[i] = nullptr; }
+  c->s->n_pkt = n;
+  for (int i = 0; i < 7; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
   if (n == 0) return C8P_OK;
   Plan P;
   int rc = plan_demod(c, in, P);
@@ -391,53 +415,53 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   const size_t o_sb = align256(o_lay + sizeof(PktLayout) * (size_t)n);
   const size_t stage_bytes = align256(o_sb + sizeof(uint32_t) * (size_t)(n + 1));
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_stage, stage_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
   // the previous submit's async copy out of the pinned buffer must have finished before we overwrite it
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy((char*)c->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
-  memcpy((char*)c->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
-  memcpy((char*)c->h_stage + o_sb, P.sym_base.data(), sizeof(uint32_t) * (size_t)(n + 1));
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
+  memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_sb, P.sym_base.data(), sizeof(uint32_t) * (size_t)(n + 1));
   {
     KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage, stage_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
   }
-  const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->d_stage.p + o_pk);
-  const PktLayout* d_lay = (const PktLayout*)((char*)c->d_stage.p + o_lay);
-  const uint32_t* d_sb = (const uint32_t*)((char*)c->d_stage.p + o_sb);
+  const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
+  const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
+  const uint32_t* d_sb = (const uint32_t*)((char*)c->s->d_stage.p + o_sb);
 
   const cf* d_iq = (const cf*)in->iq;
   const cf* d_chan = (const cf*)in->chan;
   if (in->mem == C8P_MEM_HOST) {
-    if ((rc = ensure(c, c->d_iq, sizeof(cf) * in->n_iq)) != C8P_OK) return rc;
-    if ((rc = ensure(c, c->d_chan, sizeof(cf) * in->n_chan)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_iq.p, in->iq, sizeof(cf) * in->n_iq, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_chan.p, in->chan, sizeof(cf) * in->n_chan, hipMemcpyHostToDevice, c->stream));
-    d_iq = (const cf*)c->d_iq.p; d_chan = (const cf*)c->d_chan.p;
+    if ((rc = ensure(c, c->s->d_iq, sizeof(cf) * in->n_iq)) != C8P_OK) return rc;
+    if ((rc = ensure(c, c->s->d_chan, sizeof(cf) * in->n_chan)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s->d_iq.p, in->iq, sizeof(cf) * in->n_iq, hipMemcpyHostToDevice, c->s->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s->d_chan.p, in->chan, sizeof(cf) * in->n_chan, hipMemcpyHostToDevice, c->s->stream));
+    d_iq = (const cf*)c->s->d_iq.p; d_chan = (const cf*)c->s->d_chan.p;
   }
-  if ((rc = ensure(c, c->d_tags, sizeof(c8p_pkt_tags) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_H, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_tags, sizeof(c8p_pkt_tags) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_H, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
 
   {
     KTimer kt(c, C8P_K_CLASSIFY);
-    hipLaunchKernelGGL(k_classify, dim3(n), dim3(64), 0, c->stream, d_pk, d_iq, d_chan, d_lay, (const DevTables*)c->d_tab,
-                       (c8p_pkt_tags*)c->d_tags.p, (cf*)c->d_H.p, (Mimo*)c->d_mimo.p, (cf*)c->d_muchan.p, (uint32_t*)c->d_flags.p, n);
+    hipLaunchKernelGGL(k_classify, dim3(n), dim3(64), 0, c->s->stream, d_pk, d_iq, d_chan, d_lay, (const DevTables*)c->d_tab,
+                       (c8p_pkt_tags*)c->s->d_tags.p, (cf*)c->s->d_H.p, (Mimo*)c->s->d_mimo.p, (cf*)c->s->d_muchan.p, (uint32_t*)c->s->d_flags.p, n);
   }
   {
     KTimer kt(c, C8P_K_DEMOD);
-    hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->stream, d_pk, d_iq, d_chan, d_sb,
-                       (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->d_tags.p, (const cf*)c->d_H.p,
-                       (const Mimo*)c->d_mimo.p, (float*)c->d_llr.p, (uint32_t*)c->d_flags.p, n, P.syms);
+    hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, d_sb,
+                       (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->s->d_tags.p, (const cf*)c->s->d_H.p,
+                       (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, n, P.syms);
   }
   HIPCHK(c, hipGetLastError());
-  c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = c->d_tags.p;
-  c->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->ptr[C8P_BUF_LLR] = c->d_llr.p;
-  c->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->ptr[C8P_BUF_MUCHAN] = c->d_muchan.p;
+  c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = c->s->d_tags.p;
+  c->s->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
+  c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
   if (!with_decode) return C8P_OK;
-  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->d_tags.p, d_lay, (const float*)c->d_llr.p, (const cf*)c->d_muchan.p, P, true);
+  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, true);
 }
 
 extern "C" int c8p_demod(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, false); }
@@ -449,10 +473,14 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->tags || !in->llr))) { c->err = "bad batch"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
+  // next slot; its previous batch (submitted slots.size() submits ago) must be done before its arenas are reused
+  c->cur = (c->cur + 1) % (int)c->slots.size();
+  c->s = &c->slots[c->cur];
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
   const int n = in->n_pkt;
-  c->n_pkt = n;
-  for (int i = 0; i < 7; i++) { c->used[i] = 0; c->ptr[i] = nullptr; }
+  c->s->n_pkt = n;
+  for (int i = 0; i < 7; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
   if (n == 0) return C8P_OK;
   Plan P;
   int rc = plan_decode(c, in, P);
@@ -460,34 +488,34 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   const size_t o_tg = 0, o_lay = align256(sizeof(c8p_pkt_tags) * (size_t)n);
   const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->d_stage, stage_bytes)) != C8P_OK) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy((char*)c->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
-  memcpy((char*)c->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
+  memcpy((char*)c->s->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
   {
     KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, c->h_stage, stage_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
   }
-  const c8p_pkt_tags* d_tags = (const c8p_pkt_tags*)((char*)c->d_stage.p + o_tg);
-  const PktLayout* d_lay = (const PktLayout*)((char*)c->d_stage.p + o_lay);
+  const c8p_pkt_tags* d_tags = (const c8p_pkt_tags*)((char*)c->s->d_stage.p + o_tg);
+  const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
   const float* d_llr = in->llr;
   const cf* d_mu = (const cf*)in->mu2x1chan;
   if (in->mem == C8P_MEM_HOST) {
-    if ((rc = ensure(c, c->d_llr_in, sizeof(float) * in->n_llr)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_llr_in.p, in->llr, sizeof(float) * in->n_llr, hipMemcpyHostToDevice, c->stream));
-    d_llr = (const float*)c->d_llr_in.p;
+    if ((rc = ensure(c, c->s->d_llr_in, sizeof(float) * in->n_llr)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s->d_llr_in.p, in->llr, sizeof(float) * in->n_llr, hipMemcpyHostToDevice, c->s->stream));
+    d_llr = (const float*)c->s->d_llr_in.p;
     if (in->mu2x1chan) {
-      if ((rc = ensure(c, c->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
-      HIPCHK(c, hipMemcpyAsync(c->d_mu_in.p, in->mu2x1chan, sizeof(cf) * 128 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-      d_mu = (const cf*)c->d_mu_in.p;
+      if ((rc = ensure(c, c->s->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->s->d_mu_in.p, in->mu2x1chan, sizeof(cf) * 128 * (size_t)n, hipMemcpyHostToDevice, c->s->stream));
+      d_mu = (const cf*)c->s->d_mu_in.p;
     }
   }
   if (!d_mu) {   // NDP reports then carry zeros
-    if ((rc = ensure(c, c->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_mu_in.p, 0, sizeof(cf) * 128 * (size_t)n, c->stream));
-    d_mu = (const cf*)c->d_mu_in.p;
+    if ((rc = ensure(c, c->s->d_mu_in, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->s->d_mu_in.p, 0, sizeof(cf) * 128 * (size_t)n, c->s->stream));
+    d_mu = (const cf*)c->s->d_mu_in.p;
   }
-  c->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->ptr[C8P_BUF_TAGS] = d_tags;
+  c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = d_tags;
   return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, false);
 }
 
@@ -495,7 +523,7 @@ extern "C" int c8p_sync(c8p_ctx* c)
 {
   if (!c) return C8P_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (Slot& sl : c->slots) HIPCHK(c, hipStreamSynchronize(sl.stream));
   drain_events(c);
   return C8P_OK;
 }
@@ -503,17 +531,17 @@ extern "C" int c8p_sync(c8p_ctx* c)
 extern "C" const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
 {
   if (!c || which < 0 || which > 6) return nullptr;
-  if (bytes) *bytes = c->used[which];
-  return c->ptr[which];
+  if (bytes) *bytes = c->s->used[which];
+  return c->s->ptr[which];
 }
 
 extern "C" int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
 {
   if (!c || which < 0 || which > 6 || !dst) return C8P_EINVAL;
-  if (offset + bytes > c->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
+  if (offset + bytes > c->s->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
   HIPCHK(c, hipSetDevice(c->device));
-  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->s->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->s->stream));
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
   return C8P_OK;
 }

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
     for (int b = 0; b < nb; b++) {
       out[T->deint2ss[0][mi][j * nb + b]] = oa[b];
       out[T->deint2ss[1][mi][j * nb + b]] = ob[b];
-      bad |= bad_llr(oa[b]) | bad_llr(ob[b]);
+      bad |= bad_llr(oa[b]) || bad_llr(ob[b]);
     }
   }
   if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
