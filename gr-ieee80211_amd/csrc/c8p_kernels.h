@@ -421,23 +421,46 @@ __global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ 
 
 // ================================================================================================ data symbols
 // procSymQamToLlr (cloud80211phy.cc:2090-2148) for one subcarrier; o[0..nb)
-__device__ __forceinline__ void qam_to_llr(cf q, int nb, float* o)
+template <int NB> __device__ __forceinline__ void qam_to_llr(cf q, float (&o)[NB])
 {
-  if (nb == 1) { o[0] = q.x; return; }
-  const float sc = nb == 2 ? 1.4142135623730951f : nb == 4 ? 3.1622776601683795f : nb == 6 ? 6.48074069840786f : 13.038404810405298f;
-  q = cmulf(q, sc);
-  const int h = nb >> 1;
-  const float A = nb == 4 ? 2.0f : nb == 6 ? 4.0f : 8.0f;
-  float r = q.x, i = q.y;
-  o[0] = r; o[h] = i;
-  if (nb >= 4) {
-    float r1 = A - fabsf(r), i1 = A - fabsf(i);
-    o[1] = r1; o[h + 1] = i1;
-    if (nb >= 6) {
-      float r2 = A * 0.5f - fabsf(r1), i2 = A * 0.5f - fabsf(i1);
-      o[2] = r2; o[h + 2] = i2;
-      if (nb == 8) { o[3] = 2.0f - fabsf(r2); o[h + 3] = 2.0f - fabsf(i2); }
+  if constexpr (NB == 1) { o[0] = q.x; }
+  else {
+    constexpr float sc = NB == 2 ? 1.4142135623730951f : NB == 4 ? 3.1622776601683795f : NB == 6 ? 6.48074069840786f : 13.038404810405298f;
+    constexpr int h = NB / 2;
+    constexpr float A = NB == 4 ? 2.0f : NB == 6 ? 4.0f : 8.0f;
+    q = cmulf(q, sc);
+    const float r = q.x, i = q.y;
+    o[0] = r; o[h] = i;
+    if constexpr (NB >= 4) {
+      const float r1 = A - fabsf(r), i1 = A - fabsf(i);
+      o[1] = r1; o[h + 1] = i1;
+      if constexpr (NB >= 6) {
+        const float r2 = A * 0.5f - fabsf(r1), i2 = A * 0.5f - fabsf(i1);
+        o[2] = r2; o[h + 2] = i2;
+        if constexpr (NB == 8) { o[3] = 2.0f - fabsf(r2); o[h + 3] = 2.0f - fabsf(i2); }
+      }
     }
+  }
+}
+
+// LLRs of one subcarrier scattered through a de-interleave map (procSymDeint* cloud80211phy.cc:2150-2338): out[map[j*NB+b]] = llr[b]
+template <int NB> __device__ __forceinline__ bool llr_scatter(cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out)
+{
+  float o[NB];
+  qam_to_llr<NB>(q, o);
+  bool bad = false;
+#pragma unroll
+  for (int b = 0; b < NB; b++) { out[map[j * NB + b]] = o[b]; bad = bad || bad_llr(o[b]); }
+  return bad;
+}
+__device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out)
+{
+  switch (nb) {   // uniform per wave
+    case 1: return llr_scatter<1>(q, j, map, out);
+    case 2: return llr_scatter<2>(q, j, map, out);
+    case 4: return llr_scatter<4>(q, j, map, out);
+    case 6: return llr_scatter<6>(q, j, map, out);
+    default: return llr_scatter<8>(q, j, map, out);
   }
 }
 
@@ -485,10 +508,7 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
     float pa = cabs_(ps);
     if (!is_null_l(lane) && !is_pilot(lane)) {
       cf q = cdivf(cmul(sig, ps), pa);
-      float o[8];
-      qam_to_llr(q, nb, o);
-      const int j = qidx_l(lane);
-      for (int b = 0; b < nb; b++) { out[T->deintL[mi][j * nb + b]] = o[b]; bad |= bad_llr(o[b]); }
+      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out);
     }
     if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
     return;
@@ -522,10 +542,7 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
     float pa = cabs_(ps);
     if (!is_null_nl(lane) && !is_pilot(lane)) {
       cf q = cdivf(cmul(sig, ps), pa);
-      float o[8];
-      qam_to_llr(q, nb, o);
-      const int j = qidx_nl(lane);
-      for (int b = 0; b < nb; b++) { out[T->deintNL[mi][j * nb + b]] = o[b]; bad |= bad_llr(o[b]); }
+      bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out);
     }
     if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
     return;
@@ -552,15 +569,10 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
   float pa = cabs_(ps);
   if (!is_null_nl(lane) && !is_pilot(lane)) {
     cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
-    float oa[8], ob[8];
-    qam_to_llr(qa, nb, oa);
-    qam_to_llr(qb, nb, ob);
     const int j = qidx_nl(lane);
-    for (int b = 0; b < nb; b++) {
-      out[T->deint2ss[0][mi][j * nb + b]] = oa[b];
-      out[T->deint2ss[1][mi][j * nb + b]] = ob[b];
-      bad |= bad_llr(oa[b]) || bad_llr(ob[b]);
-    }
+    const bool b1 = llr_scatter_nb(nb, qa, j, T->deint2ss[0][mi], out);
+    const bool b2 = llr_scatter_nb(nb, qb, j, T->deint2ss[1][mi], out);
+    bad = b1 || b2;
   }
   if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
 }

@@ -59,20 +59,29 @@ struct LeanK {          // lane constants for one exchange phase q
 #define C8P_CLS_POS 0x380   // +denormal | +normal | +inf
 #define C8P_CLS_NEG 0x01C   // -inf | -normal | -denormal
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// keep and send are the same arithmetic on (ka,kb) and (sa,sb): one packed-f32 instruction does both
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are two independent IEEE operations, no cross-element effects).
 template <bool HAVE0, bool HAVE1>
-__device__ __forceinline__ float cand(float pre, float ca, float cb, float t0, float t1)
+__device__ __forceinline__ v2f cand2(float pre, const LeanK& k, float t0, float t1)
 {
-  if (HAVE0 && HAVE1) return pre + __builtin_fmaf(ca, t0, cb * t1);   // tab[3] = t1 + t0 rounded once, then + pre
-  if (HAVE0) return __builtin_fmaf(ca, t0, pre);                        // pre + (t0 or 0): the product is exact
-  return __builtin_fmaf(cb, t1, pre);
+  const v2f A = {k.ka, k.sa}, B = {k.kb, k.sb}, P = {pre, pre};
+  if (HAVE0 && HAVE1) {
+    const v2f T0 = {t0, t0}, T1 = {t1, t1};
+    return P + __builtin_elementwise_fma(A, T0, B * T1);     // pre + tab[c], tab[3] = t1 + t0 rounded once
+  }
+  if (HAVE0) { const v2f T0 = {t0, t0}; return __builtin_elementwise_fma(A, T0, P); }   // pre + (t0 or 0): exact product
+  const v2f T1 = {t1, t1};
+  return __builtin_elementwise_fma(B, T1, P);
 }
 
 template <int Q, bool HAVE0, bool HAVE1>
 __device__ __forceinline__ float lean_step(float pre, const LeanK& k, float t0, float t1, unsigned long long& W)
 {
   // for q = 4,5 the constants are laid out so that `keep` is the even-predecessor candidate slot (see lean_forward)
-  const float keep = cand<HAVE0, HAVE1>(pre, k.ka, k.kb, t0, t1);
-  const float send = cand<HAVE0, HAVE1>(pre, k.sa, k.sb, t0, t1);
+  const v2f ks = cand2<HAVE0, HAVE1>(pre, k, t0, t1);
+  const float keep = ks.x, send = ks.y;
   float nxt;
   if (Q <= 3) {
     float d;

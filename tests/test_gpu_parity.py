@@ -186,3 +186,61 @@ def test_decode_limits_and_nan_llrs(eng):
         if tags[k]["len"] <= 4095 and tags[k]["trellis"] <= 32782:
             assert np.array_equal(res[k]["sbits"], sb), k
             assert np.array_equal(res[k]["bits"], ub), k
+
+
+def test_device_resident_inputs_and_pipelined_submits(eng):
+    """iq/chan handed over as device pointers (C8P_MEM_DEVICE, as bench.py does) and several batches in flight on the
+    engine's rotating slots: the last submit's results are the ones read back, and they equal the host-memory run."""
+    import torch
+    b, meta = sweep_batch(snr_db=22.0, seed=21)
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    want = eng.results(want_llr=True)
+    dev = torch.device("cuda", 0)
+    iq_d = torch.from_numpy(iq.view(np.float32)).to(dev)
+    ch_d = torch.from_numpy(chan.view(np.float32)).to(dev)
+    b2, _ = sweep_batch(snr_db=9.0, seed=22)           # a different batch submitted in between
+    pk2, iq2, chan2 = b2.arrays()
+    for _ in range(4):
+        eng.rx(pk2, iq2, chan2)
+        eng.rx(pk, engine.DevArray(iq_d.data_ptr(), iq.size, iq_d), engine.DevArray(ch_d.data_ptr(), chan.size, ch_d))
+    got = eng.results(want_llr=True)
+    for g, w in zip(got, want):
+        assert g["pdus"] == w["pdus"]
+        assert g["tags"]["status"] == w["tags"]["status"]
+        assert np.array_equal(g["llr"], w["llr"])
+
+
+def test_exact_kernel_agrees_with_lean_kernel(eng, monkeypatch):
+    """C8P_EXACT_VITERBI=1 routes every packet through the clamp-exact recurrence: identical bits and PDUs."""
+    b, meta = sweep_batch(snr_db=8.0, seed=31)
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    lean = eng.results(want_bits=True)
+    monkeypatch.setenv("C8P_EXACT_VITERBI", "1")
+    e2 = engine.Engine(device=0, keep_bits=True)
+    e2.rx(pk, iq, chan)
+    exact = e2.results(want_bits=True)
+    e2.close()
+    n = 0
+    for a, c in zip(lean, exact):
+        assert a["pdus"] == c["pdus"]
+        if a["tags"]["status"] == abi.ST_OK and a["tags"]["trellis"] > 0:
+            assert np.array_equal(a["sbits"], c["sbits"]) and np.array_equal(a["bits"], c["bits"])
+            n += 1
+    assert n > 40
+
+
+def test_error_paths(eng):
+    b, meta = sweep_batch()
+    pk, iq, chan = b.arrays()
+    bad = pk.copy()
+    bad["iq_off"][3][0] = len(iq)                       # packet items outside the arena
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.rx(bad, iq, chan)
+    bad = pk.copy()
+    bad["n_ant"][0] = 3
+    with pytest.raises(RuntimeError, match="n_ant"):
+        eng.rx(bad, iq, chan)
+    eng.rx(pk, iq, chan)                                # the ctx stays usable after an error
+    assert sum(len(r["pdus"]) for r in eng.results(want_llr=False)) == 50
