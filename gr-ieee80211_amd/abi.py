@@ -12,9 +12,9 @@ MEM_HOST, MEM_DEVICE = 0, 1
 F_L, F_HT, F_VHT, F_VHT_CHAN = 0, 1, 2, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
-BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN = range(7)
-K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_COUNT = range(6)
-K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish"]
+BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN = range(10)
+K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_COUNT = range(7)
+K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal"]
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
 NDP_TOTAL = 1024
@@ -54,6 +54,15 @@ class BatchIn(C.Structure):
                 ("n_iq", C.c_uint64), ("chan", C.c_void_p), ("n_chan", C.c_uint64)]
 
 
+class SigIn(C.Structure):
+    _fields_ = [("raw_off", C.c_uint64 * 2), ("n_avail", C.c_uint32), ("cfo_rad", C.c_float), ("snr", C.c_float),
+                ("rssi", C.c_float), ("n_ant", C.c_uint8), ("rsv", C.c_uint8 * 3)]
+
+
+class SignalIn(C.Structure):
+    _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64)]
+
+
 class DecodeIn(C.Structure):
     _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("tags", C.c_void_p), ("llr", C.c_void_p),
                 ("n_llr", C.c_uint64), ("mu2x1chan", C.c_void_p)]
@@ -76,6 +85,7 @@ def _np_dtype(struct):
 PKT_IN_DT = _np_dtype(PktIn)
 PKT_TAGS_DT = _np_dtype(PktTags)
 PKT_OUT_DT = _np_dtype(PktOut)
+SIG_IN_DT = _np_dtype(SigIn)
 
 TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
 

@@ -38,6 +38,7 @@ struct DevTables {
   int8_t  deintSigB[52];          // mapDeintVhtSigB20 :1503
   int8_t  intlSigB[52];           // mapIntelVhtSigB20
   float   pilotP[127];            // PILOT_P :160
+  float   ltfL[64];               // LTF_L_26_F_FLOAT :77
   float   ltfNL[64];              // LTF_NL_28_F_FLOAT :113
   float   ltfNLvht22[64];         // LTF_NL_28_F_FLOAT_VHT22 :131
   double2 tw[32];                 // e^{-j 2 pi k / 64}, k = 0..31 (double: the FFT runs in fp64, see wave_fft64)

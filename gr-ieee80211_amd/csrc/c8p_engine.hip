@@ -99,7 +99,7 @@ static const DevTables& host_tables()
   {
     static const signed char lltf[53] = {1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
                                          1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1};
-    for (int sc = -26; sc <= 26; sc++) T.ltfNL[(sc + 64) % 64] = (float)lltf[sc + 26];
+    for (int sc = -26; sc <= 26; sc++) { T.ltfNL[(sc + 64) % 64] = (float)lltf[sc + 26]; T.ltfL[(sc + 64) % 64] = (float)lltf[sc + 26]; }
     T.ltfNL[36] = 1; T.ltfNL[37] = 1; T.ltfNL[27] = -1; T.ltfNL[28] = -1;
     for (int i = 0; i < 64; i++) T.ltfNLvht22[i] = T.ltfNL[i];
     const int pil[4] = {7, 21, 43, 57};
@@ -177,9 +177,10 @@ struct Slot {
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags;
+  Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
   int n_pkt = 0;
-  size_t used[7] = {0, 0, 0, 0, 0, 0, 0};
-  const void* ptr[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t used[C8P_BUF_COUNT] = {};
+  const void* ptr[C8P_BUF_COUNT] = {};
 };
 
 struct c8p_ctx {
@@ -193,8 +194,8 @@ struct c8p_ctx {
   Slot* s = nullptr;                                 // slot of the most recent submit
   int cur = -1;
   // profiling
-  double k_ms[C8P_K_COUNT] = {0, 0, 0, 0, 0};
-  int64_t k_cnt[C8P_K_COUNT] = {0, 0, 0, 0, 0};
+  double k_ms[C8P_K_COUNT] = {};
+  int64_t k_cnt[C8P_K_COUNT] = {};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -283,7 +284,8 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
-                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags};
+                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags,
+                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
@@ -404,7 +406,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   drain_events(c);
   const int n = in->n_pkt;
   c->s->n_pkt = n;
-  for (int i = 0; i < 7; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
   if (n == 0) return C8P_OK;
   Plan P;
   int rc = plan_demod(c, in, P);
@@ -480,7 +482,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   drain_events(c);
   const int n = in->n_pkt;
   c->s->n_pkt = n;
-  for (int i = 0; i < 7; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
   if (n == 0) return C8P_OK;
   Plan P;
   int rc = plan_decode(c, in, P);
@@ -519,6 +521,61 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, false);
 }
 
+extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->n_evt < 0 || (in->n_evt > 0 && (!in->evts || !in->raw))) { c->err = "bad batch"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cur = (c->cur + 1) % (int)c->slots.size();
+  c->s = &c->slots[c->cur];
+  HIPCHK(c, hipStreamSynchronize(c->s->stream));
+  drain_events(c);
+  const int n = in->n_evt;
+  c->s->n_pkt = n;
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
+  if (n == 0) return C8P_OK;
+  std::vector<uint64_t> off(n);
+  uint64_t tot = 0;
+  for (int e = 0; e < n; e++) {
+    const c8p_sig_in& k = in->evts[e];
+    if (k.n_ant != 1 && k.n_ant != 2) { c->err = "n_ant must be 1 or 2"; return C8P_EINVAL; }
+    for (int a = 0; a < k.n_ant; a++)
+      if (k.raw_off[a] + k.n_avail > in->n_raw) { c->err = "sync event items outside the raw arena"; return C8P_ERANGE; }
+    const uint64_t cap = (k.n_avail >= 224u ? k.n_avail - 224u : 0u) + 320u;
+    off[e] = tot;
+    tot += cap * k.n_ant;
+  }
+  int rc;
+  const size_t o_ev = 0, o_off = align256(sizeof(c8p_sig_in) * (size_t)n);
+  const size_t stage_bytes = align256(o_off + sizeof(uint64_t) * (size_t)n);
+  if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
+  memcpy((char*)c->s->h_stage + o_ev, in->evts, sizeof(c8p_sig_in) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_off, off.data(), sizeof(uint64_t) * (size_t)n);
+  HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+  const cf* d_raw = (const cf*)in->raw;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, c->s->d_sig_raw, sizeof(cf) * in->n_raw)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s->d_sig_raw.p, in->raw, sizeof(cf) * in->n_raw, hipMemcpyHostToDevice, c->s->stream));
+    d_raw = (const cf*)c->s->d_sig_raw.p;
+  }
+  if ((rc = ensure(c, c->s->d_sig_pkt, sizeof(c8p_pkt_in) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_iq, sizeof(cf) * tot)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_chan, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
+  {
+    KTimer kt(c, C8P_K_SIGNAL);
+    hipLaunchKernelGGL(k_signal, dim3(n), dim3(64), 0, c->s->stream, (const c8p_sig_in*)((char*)c->s->d_stage.p + o_ev), d_raw,
+                       (const uint64_t*)((char*)c->s->d_stage.p + o_off), (const DevTables*)c->d_tab,
+                       (c8p_pkt_in*)c->s->d_sig_pkt.p, (cf*)c->s->d_sig_iq.p, (cf*)c->s->d_sig_chan.p, n);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->s->used[C8P_BUF_SIG_PKT] = sizeof(c8p_pkt_in) * (size_t)n; c->s->ptr[C8P_BUF_SIG_PKT] = c->s->d_sig_pkt.p;
+  c->s->used[C8P_BUF_SIG_IQ] = sizeof(cf) * tot; c->s->ptr[C8P_BUF_SIG_IQ] = c->s->d_sig_iq.p;
+  c->s->used[C8P_BUF_SIG_CHAN] = sizeof(cf) * 64 * (size_t)n; c->s->ptr[C8P_BUF_SIG_CHAN] = c->s->d_sig_chan.p;
+  return C8P_OK;
+}
+
 extern "C" int c8p_sync(c8p_ctx* c)
 {
   if (!c) return C8P_EINVAL;
@@ -530,14 +587,14 @@ extern "C" int c8p_sync(c8p_ctx* c)
 
 extern "C" const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
 {
-  if (!c || which < 0 || which > 6) return nullptr;
+  if (!c || which < 0 || which >= C8P_BUF_COUNT) return nullptr;
   if (bytes) *bytes = c->s->used[which];
   return c->s->ptr[which];
 }
 
 extern "C" int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
 {
-  if (!c || which < 0 || which > 6 || !dst) return C8P_EINVAL;
+  if (!c || which < 0 || which >= C8P_BUF_COUNT || !dst) return C8P_EINVAL;
   if (offset + bytes > c->s->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
   HIPCHK(c, hipSetDevice(c->device));
   if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->s->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->s->stream));
@@ -564,7 +621,8 @@ extern "C" int c8p_profile_reset(c8p_ctx* c)
 extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
 {
   const int32_t v[] = {C8P_ABI_VERSION, (int32_t)sizeof(c8p_pkt_in), (int32_t)sizeof(c8p_pkt_tags), (int32_t)sizeof(c8p_pkt_out),
-                       (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in)};
-  for (int i = 0; i < 7 && i < cap; i++) dst[i] = v[i];
-  return 7;
+                       (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
+                       (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in)};
+  for (int i = 0; i < 9 && i < cap; i++) dst[i] = v[i];
+  return 9;
 }

@@ -8,6 +8,8 @@
  *                 and       demod2_impl::general_work  lib/demod2_impl.cc:58-349
  *   c8p_decode()  replaces  decode_impl::general_work  lib/decode_impl.cc:60-162
  *   c8p_rx()      = c8p_demod() + c8p_decode() with the LLR stream kept in HBM
+ *   c8p_signal()  replaces  signal_impl::general_work  lib/signal_impl.cc:62-206   (the producer of the boundary;
+ *                 and       signal2_impl::general_work lib/signal2_impl.cc          SURVEY.md §8f-1, optional)
  *
  * A "packet" is what one pass of the reference state machines handles: the items between
  * two tag sets on the stream.  The GNU Radio blocks stream packets one by one; this engine
@@ -126,6 +128,19 @@ typedef struct c8p_pkt_out {
   uint64_t bits_off;    /* byte offset of the packet's decoded bits (1 bit per byte) inside the bits arena */
 } c8p_pkt_out;
 
+/*
+ * One sync event at the sync -> signal boundary: the item where the sync block raised its flag (L-LTF start + 24)
+ * with the tags of sync_impl.cc:124-141 ("rad" = CFO in rad/sample, "snr", "rssi").
+ */
+typedef struct c8p_sig_in {
+  uint64_t raw_off[2];  /* item offset of the sync item inside the raw arena, per antenna                     */
+  uint32_t n_avail;     /* raw items available from the sync item on (a packet needs 224 + nsamp)             */
+  float    cfo_rad;     /* tag "rad"                                                                          */
+  float    snr, rssi;   /* tags "snr", "rssi" (pass-through)                                                  */
+  uint8_t  n_ant;       /* 1: signal, 2: signal2                                                              */
+  uint8_t  rsv[3];
+} c8p_sig_in;
+
 typedef struct c8p_cfg {
   int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
   int32_t device;           /* HIP device ordinal                                                      */
@@ -144,6 +159,14 @@ typedef struct c8p_batch_in {
   uint64_t          n_chan; /* items in the chan arena                                                 */
 } c8p_batch_in;
 
+typedef struct c8p_signal_in {
+  int32_t n_evt;
+  int32_t mem;              /* C8P_MEM_* of raw                                                        */
+  const c8p_sig_in* evts;   /* [n_evt], host memory                                                    */
+  const c8p_c32*    raw;    /* raw (not yet CFO-corrected) sample arena                                */
+  uint64_t          n_raw;
+} c8p_signal_in;
+
 typedef struct c8p_decode_in {
   int32_t n_pkt;
   int32_t mem;              /* C8P_MEM_* of tags, llr and mu2x1chan                                    */
@@ -161,6 +184,10 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_BITS   4    /* bytes (keep_bits), descrambled bits    */
 #define C8P_BUF_SBITS  5    /* bytes (keep_bits), bits before descrambling */
 #define C8P_BUF_MUCHAN 6    /* c8p_c32[n_pkt][128] NDP time-domain LTF capture */
+#define C8P_BUF_SIG_PKT  7  /* c8p_pkt_in[n_evt]: the boundary descriptors signal produced (n_items = 0: L-SIG check failed) */
+#define C8P_BUF_SIG_IQ   8  /* CFO-corrected items, per packet at pkt.iq_off[a] (nsamp items + 320 zero pad)   */
+#define C8P_BUF_SIG_CHAN 9  /* c8p_c32[n_evt][64] legacy channel estimates (tag "chan")                        */
+#define C8P_BUF_COUNT    10
 
 /* kernels, for c8p_kernel_time() */
 #define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */
@@ -168,7 +195,8 @@ typedef struct c8p_decode_in {
 #define C8P_K_DEMOD    2
 #define C8P_K_VITERBI  3
 #define C8P_K_FINISH   4
-#define C8P_K_COUNT    5
+#define C8P_K_SIGNAL   5
+#define C8P_K_COUNT    6
 
 typedef struct c8p_ctx c8p_ctx;
 
@@ -180,6 +208,7 @@ const char* c8p_last_error(const c8p_ctx* ctx);
 int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCHAN              */
 int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */
+int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
 int c8p_sync  (c8p_ctx* ctx);
 
 /* Device pointer / size in bytes of a result arena of the last submit. */
@@ -203,7 +232,7 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
 
-/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in} as compiled into the library. */
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

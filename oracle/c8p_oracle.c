@@ -517,6 +517,63 @@ int c8po_signal(const cf* raw, cf* h, int* mcs, int* len, int* nsamp, float* llr
   return 1;
 }
 
+static cf rot(cf x, float th) { return cmul(x, C(cosf(th), sinf(th))); }
+
+int c8po_signal_event(const c8p_sig_in* ev, const cf* raw_arena, c8p_pkt_in* pkt, cf* h, cf* out0, cf* out1)
+{
+  c8po_init();
+  const cf* in1 = raw_arena + ev->raw_off[0];
+  const cf* in2 = ev->n_ant == 2 ? raw_arena + ev->raw_off[1] : NULL;
+  memset(pkt, 0, sizeof(*pkt));
+  pkt->n_ant = ev->n_ant; pkt->snr = ev->snr; pkt->rssi = ev->rssi;
+  pkt->cfo = ev->cfo_rad * 3183098.8618379068f;       /* signal_impl.cc:136 */
+  for (int i = 0; i < 64; i++) h[i] = C(0, 0);
+  if (ev->n_avail < 224) return 0;
+  cf t1[64], t2[64], ts[64], f1[64], f2[64], fs[64];
+  for (int i = 0; i < 64; i++) {                       /* signal_impl.cc:115-120 */
+    t1[i] = rot(in1[8 + i], (float)(i + 8) * ev->cfo_rad);
+    t2[i] = rot(in1[8 + 64 + i], (float)(i + 8 + 64) * ev->cfo_rad);
+    ts[i] = rot(in1[8 + 144 + i], (float)(i + 8 + 144) * ev->cfo_rad);
+  }
+  c8po_fft64(t1, f1); c8po_fft64(t2, f2); c8po_fft64(ts, fs);
+  float llr[48]; uint8_t bits[24];
+  const int pil[4] = {7, 21, 43, 57};
+  for (int k = 0; k < 4; k++) { int i = pil[k]; h[i] = cdivf(cadd(f1[i], f2[i]), LTF_L[i] * 2.0f); }
+  cf ps = cconj(cadd(cadd(csub(cdiv(fs[7], h[7]), cdiv(fs[21], h[21])), cdiv(fs[43], h[43])), cdiv(fs[57], h[57])));
+  float pa = cabsf_(ps);
+  for (int i = 0; i < 64; i++) {
+    if (SIG_DEMAP_NL[i] > -1) {
+      h[i] = cdivf(cadd(f1[i], f2[i]), LTF_L[i] * 2.0f);
+      llr[SIG_DEMAP_NL[i]] = cdivf(cmul(cdiv(fs[i], h[i]), ps), pa).re;
+    }
+  }
+  c8po_sig_viterbi(llr, bits, 24);
+  if (!bits[3] || bits[4]) return 0;
+  int par = 0; for (int i = 0; i < 17; i++) par += bits[i];
+  if ((par & 1) ^ bits[17]) return 0;
+  int rate = 0; for (int i = 0; i < 4; i++) rate |= ((int)bits[i]) << i;
+  int mcs, ndbps;
+  switch (rate) {
+    case 11: mcs = 0; ndbps = 24; break; case 15: mcs = 1; ndbps = 36; break;
+    case 10: mcs = 2; ndbps = 48; break; case 14: mcs = 3; ndbps = 72; break;
+    case 9:  mcs = 4; ndbps = 96; break; case 13: mcs = 5; ndbps = 144; break;
+    case 8:  mcs = 6; ndbps = 192; break; case 12: mcs = 7; ndbps = 216; break;
+    default: mcs = 0; ndbps = 24; break;
+  }
+  int len = 0; for (int i = 0; i < 12; i++) len |= ((int)bits[i + 5]) << i;
+  if (len > 4095 || len < 14) return 0;
+  const int nsamp = ((len * 8 + 22 + ndbps - 1) / ndbps) * 80;
+  if ((uint32_t)(224 + nsamp) > ev->n_avail) return 0;        /* the stream would have to wait for more items */
+  for (int k = 0; k < nsamp; k++) {                            /* S_COPY signal_impl.cc:164-192 */
+    const float th = (float)(k + 224) * ev->cfo_rad;
+    out0[k] = rot(in1[224 + k], th);
+    if (in2) out1[k] = rot(in2[224 + k], th);
+  }
+  for (int k = nsamp; k < nsamp + 320; k++) { out0[k] = C(0, 0); if (in2) out1[k] = C(0, 0); }
+  pkt->lsig_mcs = mcs; pkt->lsig_len = len; pkt->lsig_nsamp = nsamp; pkt->n_items = (uint32_t)nsamp + 320u;
+  return 1;
+}
+
 /* ------------------------------------------------------------------ demod */
 static int is_null_nl(int i) { return i == 0 || (i >= 29 && i <= 35); }
 static int is_null_l(int i) { return i == 0 || (i >= 27 && i <= 37); }

@@ -132,3 +132,28 @@ def _abi():
     sys.modules["gr_ieee80211_amd"] = mod
     spec.loader.exec_module(mod)
     return mod.abi
+
+
+def signal_events(evts, raw):
+    """signal / signal2 oracle over a list of sync events.  Returns (pkts, iq arena, chan arena) laid out like the
+    engine's C8P_BUF_SIG_* buffers (per event cap = n_avail-224+320 items per antenna)."""
+    a = _abi()
+    evts = np.ascontiguousarray(evts, a.SIG_IN_DT)
+    raw = np.ascontiguousarray(raw, np.complex64)
+    n = len(evts)
+    pk = np.zeros(n, a.PKT_IN_DT)
+    caps = [max(int(e["n_avail"]) - 224, 0) + 320 for e in evts]
+    offs = np.concatenate([[0], np.cumsum([c * int(e["n_ant"]) for c, e in zip(caps, evts)])]).astype(np.int64)
+    iq = np.zeros(int(offs[-1]) + 1, np.complex64)
+    chan = np.zeros(64 * n, np.complex64)
+    for e in range(n):
+        o0 = iq[offs[e]:]
+        o1 = iq[offs[e] + caps[e]:]
+        ok = lib().c8po_signal_event(C.c_void_p(evts.ctypes.data + e * evts.dtype.itemsize), _p(raw),
+                                     C.c_void_p(pk.ctypes.data + e * pk.dtype.itemsize), _p(chan[64 * e:]), _p(o0), _p(o1))
+        pk[e]["iq_off"][0] = offs[e]
+        pk[e]["iq_off"][1] = offs[e] + caps[e] if evts[e]["n_ant"] == 2 else 0
+        pk[e]["chan_off"] = 64 * e
+        if not ok:
+            pk[e]["n_items"] = 0
+    return pk, iq[:-1], chan
