@@ -61,3 +61,16 @@ def cfg2_batch(n, snr_db=30.0, seed=8021200, dewin=True):
         if b.add_rx(rx, n_ant=1) >= 0:
             exp.append(frames[p % 4]["pdu"].tobytes())
     return b, exp
+
+
+def replicated_batch(frame, n, n_ant, snr_db=30.0, seed=0, H=None, mupos=0):
+    """n noisy copies of one reference-TX fixture frame (de-windowed), each through its own random-phase channel."""
+    tx = dewindow(frame["tx"])
+    b = Batch()
+    for p in range(n):
+        rng = np.random.default_rng(seed + p)
+        th = rng.uniform(0, 2 * np.pi)
+        Hp = (np.eye(tx.shape[0], dtype=np.complex64) if H is None else np.asarray(H, np.complex64)) * np.exp(1j * th)
+        rx = through_channel(tx, Hp.astype(np.complex64), snr_db, rng)
+        assert b.add_rx(rx, n_ant=n_ant, mupos=mupos) >= 0
+    return b

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from c8p_cases import cfg2_batch, sweep_batch
+from c8p_cases import cfg2_batch, replicated_batch, sweep_batch
+from c8p_testlib import H22, load_npz
 from c8p_smoke import compare
 from c8p_testlib import GOLD, Batch, abi, oracle, oracle_rx
 from gr_ieee80211_amd import engine
@@ -244,3 +245,42 @@ def test_error_paths(eng):
         eng.rx(bad, iq, chan)
     eng.rx(pk, iq, chan)                                # the ctx stays usable after an error
     assert sum(len(r["pdus"]) for r in eng.results(want_llr=False)) == 50
+
+
+def test_baseline_configs_at_full_size(eng):
+    """BASELINE.json configs at their stated sizes, checked through size-independent properties: TX -> channel -> RX
+    round trip (every published PDU is the transmitted MPDU), FCS pass rate, and a spot check against the oracle."""
+    cfg = load_npz("packets_cfg.npz")
+    mu = np.load(os.path.join(GOLD, "packets_mu.npz"))
+    cases = [
+        ("cfg2 VHT MCS7 x4096", cfg["cfg2_VHT_mcs7_1458B_0"], 4096, 1, None, 0),
+        ("cfg3 HT MCS15 2x2 x1024", cfg["cfg3_HT_mcs15_2x2_1458B"], 1024, 2, H22, 0),
+        ("cfg4 VHT MCS8 x8192 (one GPU's share of 64k)", cfg["cfg4_VHT_mcs8_1458B"], 8192, 1, None, 0),
+    ]
+    for name, frame, n, n_ant, H, mupos in cases:
+        snr = 30.0 if "MCS8" not in name else 36.0
+        b = replicated_batch(frame, n, n_ant, snr_db=snr, seed=7000 + 10000 * n_ant + n, H=H)
+        pk, iq, chan = b.arrays()
+        eng.rx(pk, iq, chan)
+        res = eng.results(want_llr=False)
+        want = frame["pdu"].tobytes()
+        ok = 0
+        for r in res:
+            if r["pdus"]:
+                assert r["pdus"] == [want], name
+                ok += 1
+        assert ok >= 0.99 * n, (name, ok, n)
+        ref = oracle_rx(pk[:4], iq, chan)
+        for g, o in zip(res[:4], ref):
+            assert g["pdus"] == o["pdus"]
+    # cfg5: 1024 MU-MIMO packets per station
+    for u in range(2):
+        frame = {"tx": mu["mu_tx"]}
+        b = replicated_batch(frame, 1024, 1, snr_db=30.0, seed=500 + u, H=mu["h"][u:u + 1], mupos=u)
+        pk, iq, chan = b.arrays()
+        eng.rx(pk, iq, chan)
+        res = eng.results(want_llr=False)
+        want = mu["pdu%d" % u].tobytes()
+        ok = sum(1 for r in res if r["pdus"] == [want])
+        assert all(r["pdus"] in ([], [want]) for r in res)
+        assert ok >= 0.97 * 1024, (u, ok)
