@@ -374,7 +374,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
-      hipLaunchKernelGGL(k_viterbi_lean, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                          d_flags, n);
     }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);

@@ -736,11 +736,13 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
 
 // The fast path (c8p_viterbi_lean.h).  Packets whose LLR stream failed the range check (flags[p] != 0) are left to
 // k_viterbi_fwd, the clamp-exact recurrence.
-__global__ __launch_bounds__(64) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                                     const float* __restrict__ llr, ulonglong2* __restrict__ surv,
-                                                     const uint32_t* __restrict__ flags, int n)
+// 4 packets per 256-thread workgroup: the four waves of a workgroup land on the four SIMDs of one CU, which keeps the
+// 4096 equally long waves of a batch evenly spread (single-wave workgroups were observed to pile up on some SIMDs).
+__global__ __launch_bounds__(256) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                      const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                      const uint32_t* __restrict__ flags, int n)
 {
-  const int p = blockIdx.x;
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
   if (flags[p] != 0) return;
   const c8p_pkt_tags t = tags[p];

@@ -11,7 +11,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libc8p_rx.so")
+# C8P_LIB: load another build of the same library (A/B runs of kernel variants); still no fallback
+LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 
 # every entry point include/c8p_rx.h declares
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
