@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +84,7 @@ def main():
     res = eng.results(want_llr=False)
     n_ok = 0
     for r, e in zip(res, expected):
-        if r["pdus"]:
+        if r["pdus"] and not args.no_check:
             assert r["pdus"] == [e], "PDU mismatch"
             n_ok += 1
     eng.profile_reset()
@@ -122,7 +123,7 @@ def main():
             "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": value, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.no_check else "INVALID (--no-check experiment)",
             "config": {"workload": "BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU, %d packets/GPU/step, "
                                    "AWGN %.0f dB, random-phase flat channel" % (n_pkt, args.snr),
                        "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1),

@@ -304,6 +304,10 @@ struct Plan {
   uint32_t syms = 0;
 };
 
+// survivor slots (16 bytes each) of one packet: the clamp-exact kernel writes one slot per step, the lean kernel one
+// 256-byte block per 30 steps (8.5 bytes per step + the partial last block)
+static uint32_t surv_slots(uint32_t tcap) { return tcap + 17u; }
+
 static uint32_t pdu_cap_for(uint32_t tcap)
 {
   uint32_t pcap = tcap / 8u + 16u;
@@ -332,7 +336,7 @@ static int plan_demod(c8p_ctx* c, const c8p_batch_in* in, Plan& P)
     L.llr_off = P.llr; L.surv_off = P.surv; L.bits_off = P.bits; L.pdu_off = P.pdu;
     L.sym_base = P.syms; L.nsym_bound = nsb; L.pdu_cap = pdu_cap_for(tcap); L.trellis_cap = tcap;
     P.sym_base[p] = P.syms;
-    P.llr += llr_cap; P.surv += tcap + 1u; P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap; P.syms += nsb;
+    P.llr += llr_cap; P.surv += surv_slots(tcap); P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap; P.syms += nsb;
   }
   P.sym_base[n] = P.syms;
   return C8P_OK;
@@ -350,7 +354,7 @@ static int plan_decode(c8p_ctx* c, const c8p_decode_in* in, Plan& P)
     PktLayout& L = P.lay[p];
     L.llr_off = t.llr_off; L.surv_off = P.surv; L.bits_off = P.bits; L.pdu_off = P.pdu;
     L.sym_base = 0; L.nsym_bound = 0; L.pdu_cap = pdu_cap_for(tcap); L.trellis_cap = tcap;
-    P.surv += tcap + 1u; P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap;
+    P.surv += surv_slots(tcap); P.bits += (tcap + 15u) & ~15u; P.pdu += L.pdu_cap;
   }
   return C8P_OK;
 }

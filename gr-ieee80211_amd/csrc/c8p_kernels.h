@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_viterbi_lean(const c8p_pkt_tags* __rest
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
   const float* L = llr + t.llr_off;
-  unsigned long long* sv = (unsigned long long*)(surv + lay[p].surv_off);
+  unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
   switch (t.cr) {
     case C8P_CR_12: lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv); break;
     case C8P_CR_23: lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv); break;
@@ -824,9 +824,15 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                uint8_t* __restrict__ sbits_o, const uint32_t* __restrict__ flags,
                                                int keep_bits, int n)
 {
-  constexpr int TB = 8;                                   // survivor steps per segment staged per tile
-  __shared__ unsigned long long bw[(C8P_DECODE_T_MAX + 63) / 64 + 2];
-  __shared__ unsigned long long tile[64][TB + 1];          // +1: rows land in different LDS banks
+  constexpr int TS = 68;                                  // tile row stride in dwords (16-byte aligned rows, banks shifted by 4)
+  constexpr int NSNAP = (C8P_DECODE_T_MAX + 5) / 6 + 2;
+  // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
+  // memory holds bw[], the decoded bits packed 64 per word.
+  __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
+  __shared__ uint8_t snaps[(NSNAP + 7) & ~7];              // lane D at the entry of every 6-step group = 6 decoded bits
+  __shared__ uint16_t s_btop[64];
+  unsigned long long* bw = (unsigned long long*)tile;      // (C8P_DECODE_T_MAX + 63) / 64 + 2 words <= 64 * TS / 2
+  static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= 64 * TS * 4, "bw must fit in the tile");
   const int p = blockIdx.x;
   if (p >= n) return;
   const int lane = lane_id();
@@ -851,57 +857,99 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
     const ulonglong2* SV = surv + Lp.surv_off;
     const int nch = (Tn + 63) >> 6;
     if (flags && flags[p] == 0) {
-      // ---- lean survivors (one word per step, rotating lane map): segment-parallel traceback.
+      // ---- lean survivors (blocks of 30 steps, dword[lane] per block, rotating lane map): segment-parallel traceback.
       // Lane j walks steps [j*S, (j+1)*S) backwards from an assumed end lane; the assumption of segment j is the
       // begin lane segment j+1 computed.  Iterating to a fixed point makes every boundary consistent with the
       // true end (lane 0 = state 0 at T), i.e. the result is the reference's full traceback (vstb_end :282-302).
-      // Survivor words are staged through LDS in tiles of TB steps per segment, loaded with coalesced 16-byte
-      // reads (a naive per-lane walk issues 64 separate cache-line requests per step and is request-bound).
-      const unsigned long long* SW = (const unsigned long long*)SV;
-      const int S = 64 * ((Tn + 4095) / 4096);          // steps per segment (multiple of 64)
+      //  * state bit k lives in lane bit (k+t) mod 6, so lane D at time 6m+6 spells the six decoded bits of times
+      //    6m..6m+5 (bit j = time 6m+j): the walk only records D at the entry of every 6-step group (snaps[]).
+      //  * a re-walk stops as soon as it meets the previous iteration's path (same D at a tile entry): everything
+      //    below is unchanged, so later iterations only touch the ~2 blocks it takes survivor paths to merge.
+      //  * a tile = the current 256-byte block of every active segment, prefetched into registers with coalesced
+      //    16-byte loads while the previous tile is walked, then staged in LDS; the walk reads tile[segment][D].
+      const uint32_t* SW = (const uint32_t*)SV;
+      const int S = 192 * ((Tn + 64 * 192 - 1) / (64 * 192));   // steps per segment: multiple of 64 (bw words) and 6 (groups)
       const int nseg = (Tn + S - 1) / S;
+      const bool have = lane < nseg;
       const int tbeg = lane * S;
       const int tend = min(tbeg + S, Tn);
-      const int nblk = S / TB;
+      const int btop = have ? (tend - 1) / C8P_SV_BLK : 0;                 // highest block of this segment
+      const int nblk = have ? btop - tbeg / C8P_SV_BLK + 1 : 0;
+      s_btop[lane] = (uint16_t)btop;
+      int ntile = nblk;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) ntile = max(ntile, __shfl_xor(ntile, o, 64));
       int Dend = 0, Dbeg = 0;
-      bool redo = lane < nseg;
+      bool redo = have;
+      __syncthreads();
+      // rows this lane fetches: instruction j covers rows 4j .. 4j+3, 16 lanes x 16 bytes per row
+      const int frow = lane >> 4, fcol = (lane & 15) * 4;
+      // 16 in-flight 16-byte loads per lane, kept in named registers (an indexed array ends up in scratch)
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define C8P_DECL(j) const int fb##j = s_btop[j * 4 + frow]; uint4 pf##j;
+      C8P_ROWS16(C8P_DECL)
+#define C8P_LOAD(j) pf##j = *(const uint4*)(SW + (((rows_ >> (j * 4 + frow)) & 1ull) ? (size_t)(fb##j - i_) * 64 + fcol : (size_t)fcol));
+#define C8P_PREFETCH(i, rows) do { const int i_ = (i); const unsigned long long rows_ = (rows); C8P_ROWS16(C8P_LOAD) } while (0)
+#define C8P_STAGE(j) *(uint4*)(&tile[(j * 4 + frow) * TS + fcol]) = pf##j;
       for (int it = 0; it < 66; it++) {
         int D = Dend;
-        unsigned long long mask = 0;
-        for (int kb = nblk - 1; kb >= 0; kb--) {
-          // tile[row][c] = SW[row*S + kb*TB + c]; 4 lanes fetch one row (16 B each), 16 rows per load instruction
+        bool act = redo;
+        unsigned long long am = __ballot(act && 0 < nblk);
+        C8P_PREFETCH(0, am);                              // idle rows re-read block 0
+        for (int i = 0; i < ntile && am; i++) {
           __syncthreads();
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = r * 16 + (lane >> 2), c2 = (lane & 3) * 2;
-            const long long idx = (long long)row * S + kb * TB + c2;
-            ulonglong2 v = make_ulonglong2(0ull, 0ull);
-            if (row < nseg && idx + 1 < (long long)Tn + 1) v = *(const ulonglong2*)(SW + idx);   // idx even: 16-byte aligned
-            tile[row][c2] = v.x; tile[row][c2 + 1] = v.y;
-          }
+          C8P_ROWS16(C8P_STAGE)
           __syncthreads();
-          if (redo) {
-            const int t0 = tbeg + kb * TB;
+          C8P_PREFETCH(i + 1, __ballot(act && i + 1 < nblk));   // in flight during the walk below
+          if (act && i < nblk) {
+            const int blk = btop - i, b0 = blk * C8P_SV_BLK;
+            const int hi = min(tend, b0 + C8P_SV_BLK) - 1 - b0, lo = max(tbeg, b0) - b0;   // active steps k in [lo, hi]
+            const int gtop = blk * 5 + hi / 6;                                             // group of the first step walked
+            if (it > 0 && snaps[gtop] == (uint8_t)D) {
+              act = false;                                 // met the previous path
+              D = Dbeg;
+            } else {
+              const uint32_t A = (hi >= 31 ? 0xffffffffu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+              const uint32_t* row = &tile[lane * TS];
 #pragma unroll
-            for (int k = TB - 1; k >= 0; k--) {
-              const int tt = t0 + k;
-              if (tt < tend) {
-                const int q = tt % 6;
-                const unsigned long long w = tile[lane][k];
-                const int take = (int)((w >> D) & 1ull);
-                if ((D >> q) & 1) mask |= 1ull << (tt & 63);
-                D = (D & ~(1 << q)) | (take << q);
-                if ((tt & 63) == 0) { bw[tt >> 6] = mask; mask = 0; }
+              for (int g = 4; g >= 0; g--) {
+                if (A & (63u << (6 * g))) snaps[blk * 5 + g] = (uint8_t)D;
+#pragma unroll
+                for (int q = 5; q >= 0; q--) {
+                  constexpr int dummy = 0; (void)dummy;
+                  const int k = 6 * g + q;                 // step b0 + k moves lane bit q  ((b0 + k) % 6 == q)
+                  const uint32_t w = row[D];
+                  const uint32_t sel = ((A >> k) & 1u) << q;             // 0 for steps outside [lo, hi]
+                  const int sh = (C8P_SV_BLK - 1 - k) - q;               // decision bit (29 - k) -> bit q
+                  const uint32_t wq = sh >= 0 ? (w >> sh) : (w << -sh);
+                  D = (int)((wq & sel) | ((uint32_t)D & ~sel));
+                }
               }
             }
           }
+          am = __ballot(act && i + 1 < nblk);
         }
         if (redo) Dbeg = D;
         int nd = __shfl_down(Dbeg, 1, 64);
         if (lane >= nseg - 1) nd = 0;
-        redo = (lane < nseg) && (nd != Dend);
+        redo = have && (nd != Dend);
         Dend = nd;
         if (!__any(redo)) break;
+      }
+      // ---- decoded bits: word c = times 64c .. 64c+63, gathered from the 6-bit group snapshots
+      __syncthreads();
+      const int ngrp = (Tn + 5) / 6;                       // (the tile is dead from here on: its memory becomes bw[])
+      for (int c = lane; c < nch; c += 64) {
+        unsigned long long word = 0;
+        const int base = 64 * c, g0 = base / 6;
+        for (int g = g0; g < g0 + 12 && g < ngrp; g++) {
+          const unsigned long long v = snaps[g] & 63u;
+          const int sh = 6 * g - base;
+          if (sh >= 64) break;
+          word |= sh >= 0 ? (v << sh) : (v >> -sh);
+        }
+        if (base + 64 > Tn) word &= (1ull << (Tn - base)) - 1ull;
+        bw[c] = word;
       }
     } else {
     // ---- traceback from state 0 (vstb_end decode_impl.cc:282-302)
