@@ -167,7 +167,7 @@ __device__ __forceinline__ void lean_steps(float& pre, const LeanK (&K)[6], cons
 template <int CR>
 __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv)
 {
-  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER;
+  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;   // NLB: LLRs per block
   const int lane = lane_id();
   LeanK K[6];
 #pragma unroll
@@ -193,15 +193,36 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
   float x[NL];
   unsigned* out = sv + lane;
   // full survivor blocks: REP super-iterations of PER steps each
+  // touch registers: loop-carried ("+s") so that they can never share an SGPR with x[] — the touches are still in
+  // flight when the next block's real loads are issued, and scalar loads may return in any order
+  unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
   for (; tb + C8P_SV_BLK <= Tn; tb += C8P_SV_BLK, out += 64) {
 #pragma unroll
     for (int r = 0; r < REP; r++, lb += NL) {
 #pragma unroll
       for (int i = 0; i < NL; i++) { x[i] = L[lb + i]; }
+      if (r == 0) {
+        // Scalar loads return out of order, so the only usable wait is lgkmcnt(0): a real prefetch of the next block
+        // would be drained by the wait of this one.  Instead, right after that wait (the x[] inputs force it before
+        // this statement), touch the scalar-cache lines of the NEXT block with throw-away loads: they complete during
+        // the 30 steps below, and the next block's loads hit the scalar cache instead of stalling on L2 / HBM.
+        const int nb = lb + NLB;                    // first LLR of the next block
+        c4float* nx = L + (nb + NLB <= n_llr ? nb : lb);   // never touch past the packet's own LLRs (no branch: a join
+                                                           // would make the compiler drain the touches right away)
+        if (NLB * 4 > 192)
+          asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
+                       "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, %8"
+                       : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4) : "s"(nx), "s"(x[0]), "s"(x[NL - 1]), "n"(NLB * 4 - 4));
+        else
+          asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\t"
+                       "s_load_dword %3, %4, %7"
+                       : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3) : "s"(nx), "s"(x[0]), "s"(x[NL - 1]), "n"(NLB * 4 - 4));
+      }
       lean_steps<CR, 0, false>(pre, K, x, acc, PER);
     }
     *out = acc;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4));   // last touches land before anything reuses the registers
   if (tb < Tn) {   // last, partial block: loads clamped to the packet's own LLRs, decisions left-aligned like a full block
     const int rem = Tn - tb;
 #pragma unroll
