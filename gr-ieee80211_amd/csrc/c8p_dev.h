@@ -45,6 +45,7 @@ struct DevTables {
   uint8_t bitrev6[64];
   uint8_t scrSeq[127];            // x^7+x^4+1 sequence from the all-ones state
   uint8_t scrPhase[128];          // phase of a 7-bit state inside scrSeq
+  uint64_t scrW[4];               // scrSeq repeated, packed: bit i = scrSeq[i % 127], i = 0..255
   uint32_t crc32[256];
   uint32_t x2n[32];               // x^(2^n) mod P, reflected CRC-32 domain
 };

@@ -95,6 +95,7 @@ static const DevTables& host_tables()
       T.pilotP[n] = fb ? -1.0f : 1.0f;
       st = ((st << 1) & 0x7e) | fb;
     }
+    for (int i = 0; i < 256; i++) if (T.scrSeq[i % 127]) T.scrW[i >> 6] |= 1ull << (i & 63);
   }
   {
     static const signed char lltf[53] = {1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
@@ -176,7 +177,7 @@ struct Slot {
   void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
-  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags;
+  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt;
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
   int n_pkt = 0;
   size_t used[C8P_BUF_COUNT] = {};
@@ -284,7 +285,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
-                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags,
+                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt,
                    &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
@@ -416,24 +417,21 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   int rc = plan_demod(c, in, P);
   if (rc != C8P_OK) return rc;
 
-  // descriptors + layout + sym_base in one pinned staging copy
+  // descriptors + layout in one pinned staging copy
   const size_t o_pk = 0, o_lay = align256(o_pk + sizeof(c8p_pkt_in) * (size_t)n);
-  const size_t o_sb = align256(o_lay + sizeof(PktLayout) * (size_t)n);
-  const size_t stage_bytes = align256(o_sb + sizeof(uint32_t) * (size_t)(n + 1));
+  const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
   // the previous submit's async copy out of the pinned buffer must have finished before we overwrite it
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
   memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
-  memcpy((char*)c->s->h_stage + o_sb, P.sym_base.data(), sizeof(uint32_t) * (size_t)(n + 1));
   {
     KTimer kt(c, C8P_K_LAYOUT);
     HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
   }
   const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
-  const uint32_t* d_sb = (const uint32_t*)((char*)c->s->d_stage.p + o_sb);
 
   const cf* d_iq = (const cf*)in->iq;
   const cf* d_chan = (const cf*)in->chan;
@@ -450,15 +448,17 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if ((rc = ensure(c, c->s->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sym2pkt, sizeof(uint32_t) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
 
   {
     KTimer kt(c, C8P_K_CLASSIFY);
     hipLaunchKernelGGL(k_classify, dim3(n), dim3(64), 0, c->s->stream, d_pk, d_iq, d_chan, d_lay, (const DevTables*)c->d_tab,
-                       (c8p_pkt_tags*)c->s->d_tags.p, (cf*)c->s->d_H.p, (Mimo*)c->s->d_mimo.p, (cf*)c->s->d_muchan.p, (uint32_t*)c->s->d_flags.p, n);
+                       (c8p_pkt_tags*)c->s->d_tags.p, (cf*)c->s->d_H.p, (Mimo*)c->s->d_mimo.p, (cf*)c->s->d_muchan.p, (uint32_t*)c->s->d_flags.p,
+                       (uint32_t*)c->s->d_sym2pkt.p, n);
   }
   {
     KTimer kt(c, C8P_K_DEMOD);
-    hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, d_sb,
+    hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, (const uint32_t*)c->s->d_sym2pkt.p, d_lay,
                        (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->s->d_tags.p, (const cf*)c->s->d_H.p,
                        (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, n, P.syms);
   }

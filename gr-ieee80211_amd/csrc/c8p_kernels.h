@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ 
                                                  const cf* __restrict__ chan, const PktLayout* __restrict__ lay,
                                                  const DevTables* __restrict__ T, c8p_pkt_tags* __restrict__ tags,
                                                  cf* __restrict__ Hout, Mimo* __restrict__ mimo, cf* __restrict__ muchan,
-                                                 uint32_t* __restrict__ flags, int n)
+                                                 uint32_t* __restrict__ flags, uint32_t* __restrict__ sym2pkt, int n)
 {
   __shared__ ClsShared S;
   const int p = blockIdx.x;
@@ -329,6 +329,10 @@ __global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ 
   bool done = false;
 
   if (lane == 0) flags[p] = 0;        // k_demod_sym raises it when an LLR fails the lean decoder's range check
+  {                                   // symbol-wave -> packet map of k_demod_sym's grid (no search there)
+    const uint32_t sb = lay[p].sym_base, nsb = lay[p].nsym_bound;
+    for (uint32_t i = lane; i < nsb; i += 64) sym2pkt[sb + i] = (uint32_t)p;
+  }
   muchan[(size_t)p * 128 + lane] = mk(0.f, 0.f);
   muchan[(size_t)p * 128 + 64 + lane] = mk(0.f, 0.f);
 
@@ -539,8 +543,8 @@ __device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_
 }
 
 __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
-                                                   const cf* __restrict__ chan, const uint32_t* __restrict__ sym_base,
-                                                   const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
+                                                   const cf* __restrict__ chan, const uint32_t* __restrict__ sym2pkt,
+                                                   const PktLayout* __restrict__ lay, const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
                                                    const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
                                                    float* __restrict__ llr, uint32_t* __restrict__ flags, int n,
                                                    uint32_t total_syms)
@@ -548,11 +552,8 @@ __global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict_
   const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (w >= total_syms) return;
   const int lane = lane_id();
-  // binary search: largest p with sym_base[p] <= w
-  int lo = 0, hi = n;
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (sym_base[mid] <= w) lo = mid; else hi = mid; }
-  const int p = lo;
-  const int s = (int)(w - sym_base[p]);
+  const int p = (int)sym2pkt[w];                   // written by k_classify
+  const int s = (int)(w - lay[p].sym_base);
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   float* out = llr + t.llr_off;
@@ -785,7 +786,7 @@ __device__ __forceinline__ uint32_t byte_at(const unsigned long long* bw, int bi
   return (uint32_t)((bw[bitoff >> 6] >> (bitoff & 63)) & 0xffull);
 }
 // zlib-compatible CRC-32 of `len` bytes starting at bit offset `bitoff` of the packed bit words, wave-parallel.
-__device__ __forceinline__ uint32_t wave_crc32(const unsigned long long* bw, int bitoff, int len, const DevTables* T)
+__device__ __forceinline__ uint32_t wave_crc32(const unsigned long long* bw, int bitoff, int len, const DevTables* T, const uint32_t* crcT)
 {
   const int lane = lane_id();
   const int seg = (len + 63) >> 6;
@@ -793,7 +794,7 @@ __device__ __forceinline__ uint32_t wave_crc32(const unsigned long long* bw, int
   if (beg > len) beg = len;
   if (end > len) end = len;
   uint32_t c = lane == 0 ? 0xffffffffu : 0u;
-  for (int i = beg; i < end; i++) c = T->crc32[(c ^ byte_at(bw, bitoff + 8 * i)) & 0xff] ^ (c >> 8);
+  for (int i = beg; i < end; i++) c = crcT[(c ^ byte_at(bw, bitoff + 8 * i)) & 0xff] ^ (c >> 8);
   if (c != 0u && len - end > 0) c = multmodp(x8n_modp((uint32_t)(len - end), T), c);
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) c ^= (uint32_t)__shfl_xor((int)c, o, 64);
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
   // memory holds bw[], the decoded bits packed 64 per word.
   __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
-  __shared__ uint8_t snaps[(NSNAP + 7) & ~7];              // lane D at the entry of every 6-step group = 6 decoded bits
+  __shared__ __attribute__((aligned(16))) uint8_t snaps[(NSNAP + 7) & ~7];              // lane D at the entry of every 6-step group = 6 decoded bits
   __shared__ uint16_t s_btop[64];
   unsigned long long* bw = (unsigned long long*)tile;      // (C8P_DECODE_T_MAX + 63) / 64 + 2 words <= 64 * TS / 2
   static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= 64 * TS * 4, "bw must fit in the tile");
@@ -981,19 +982,24 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
     }
     const int ph = T->scrPhase[state];
     __syncthreads();
-    for (int c = 0; c < nch; c++) {
-      const int i = c * 64 + lane;
-      int ub = 0;
-      if (i >= 7 && i < Tn) {
-        const int sb = (int)((bw[c] >> lane) & 1ull);
-        const int fb = state ? T->scrSeq[(ph + (i - 7)) % 127] : 0;
-        ub = sb ^ fb;
+    // word c = bits 64c..64c+63: scrambler output (ph + i - 7) mod 127 for bit i, 64 at a time out of the packed
+    // doubled sequence scrW; bits 0..6 and bits >= T are 0
+    for (int c = lane; c < nch; c += 64) {
+      unsigned long long fbw = 0;
+      if (state) {
+        const int o = (ph + 120 + 64 * c) % 127, wi = o >> 6, sh = o & 63;
+        fbw = T->scrW[wi] >> sh;
+        if (sh) fbw |= T->scrW[wi + 1] << (64 - sh);
       }
-      const unsigned long long word = __ballot(ub != 0);
-      __syncthreads();
-      if (lane == 0) bw[c] = word;
+      unsigned long long ub = bw[c] ^ fbw;
+      if (c == 0) ub &= ~0x7full;
+      if (64 * c + 64 > Tn) ub &= (1ull << (Tn - 64 * c)) - 1ull;
+      bw[c] = ub;
     }
     if (lane == 0) bw[nch] = 0ull;
+    // the CRC-32 byte table moves into LDS (snaps[] is dead by now): the per-lane CRC is a chain of dependent lookups
+    uint32_t* crcT = (uint32_t*)snaps;
+    for (int i = lane; i < 256; i += 64) crcT[i] = T->crc32[i];
     __syncthreads();
     if (keep_bits) {
       uint8_t* uo = bits_o + Lp.bits_off;
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
           procd += padded;
           if (procd > Tn) break;
           bp += 32;
-          const uint32_t crc = wave_crc32(bw, bp, tmpLen, T);
+          const uint32_t crc = wave_crc32(bw, bp, tmpLen, T, crcT);
           if (crc != 558161692u) n_fail++;
           else {
             const uint32_t before = used;
@@ -1029,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         }
       }
     } else if (!t.ampdu) {
-      const uint32_t crc = wave_crc32(bw, 16, t.len, T);
+      const uint32_t crc = wave_crc32(bw, 16, t.len, T, crcT);
       if (crc != 558161692u) n_fail++;
       else {
         const uint32_t before = used;
