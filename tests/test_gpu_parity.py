@@ -189,6 +189,37 @@ def test_decode_limits_and_nan_llrs(eng):
             assert np.array_equal(res[k]["bits"], ub), k
 
 
+def test_trellis_length_sweep_with_ties(eng):
+    """lean decoder + block traceback at every awkward trellis length: around the 6-step groups, the 30-step survivor
+    blocks, the 64-bit words and the segment size (30 * ceil(T / 1920)); LLRs quantised to 1/4 so that exact metric
+    ties are frequent (tie rule: even predecessor).  Bits identical to the oracle for all four code rates."""
+    rng = np.random.default_rng(77)
+    Ts = list(range(1, 72)) + [89, 90, 91, 119, 120, 121, 179, 180, 181, 191, 192, 193, 959, 960, 961,
+                                 1919, 1920, 1921, 1949, 1950, 1951, 3839, 3840, 3841, 5999, 6000, 6001,
+                                 11959, 11960, 11961, 12287, 12288, 12289, 19200, 19201]
+    cases = [(T, cr) for T in Ts for cr in (abi.CR_12, abi.CR_23, abi.CR_34, abi.CR_56)]
+    tags = np.zeros(len(cases), abi.PKT_TAGS_DT)
+    llrs, off = [], 0
+    for k, (T, cr) in enumerate(cases):
+        n = 2 * T + int(rng.integers(0, 3))
+        llr = (np.round(rng.normal(0, 1.5, size=n) * 4) / 4).astype(np.float32)
+        if k % 7 == 0:
+            llr[:] = 0.0                                   # tie-only stream
+        tags[k]["status"], tags[k]["format"], tags[k]["cr"], tags[k]["trellis"] = abi.ST_OK, abi.F_L, cr, T
+        tags[k]["total"], tags[k]["len"], tags[k]["llr_off"] = n, max(1, min(4095, (T - 22) // 8)), off
+        off += n
+        llrs.append(llr)
+    allr = np.concatenate(llrs)
+    eng.decode(tags, allr)
+    res = eng.results(want_llr=False, want_bits=True)
+    o = oracle()
+    for k, (T, cr) in enumerate(cases):
+        out, pdus, sb, ub = o.decode(tags[k], allr[int(tags[k]["llr_off"]):int(tags[k]["llr_off"]) + int(tags[k]["total"])])
+        assert np.array_equal(res[k]["sbits"], sb), (T, cr)
+        assert np.array_equal(res[k]["bits"], ub), (T, cr)
+        assert res[k]["pdus"] == pdus, (T, cr)
+
+
 def test_device_resident_inputs_and_pipelined_submits(eng):
     """iq/chan handed over as device pointers (C8P_MEM_DEVICE, as bench.py does) and several batches in flight on the
     engine's rotating slots: the last submit's results are the ones read back, and they equal the host-memory run."""

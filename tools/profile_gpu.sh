@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/profile_gpu.sh <tag> — run ON the GPU box (via gpurun) from the repo root.
+# rocprofv3 kernel-trace stats of the default bench command, then one PMC pass per counter set (each its own run,
+# --kernel-trace only, as gpurun requires).  Raw output lands in gpurun_out/prof_<tag>/; summarise it afterwards with
+# tools/summarize_prof.py <tag>, which writes the tracked files under profiles/<tag>/.
+set -u
+TAG=${1:-r1x}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $PWD/bench.py --steps 10 --warmup 2 --no-cpu"
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $BENCH > $OUT/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | tr ' ' '+')
+  C8P_SLOTS=1 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o pmc --output-format csv -- python $PWD/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/pmc_$n.log 2>&1
+done
+find $OUT -name "*.csv" | head -40
