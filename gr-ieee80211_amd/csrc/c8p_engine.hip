@@ -189,6 +189,7 @@ struct c8p_ctx {
   bool own_stream = false;
   int profile = 0, keep_bits = 0;
   int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
+  unsigned lean_lds = 0;                             // dynamic LDS bytes requested by the lean kernel (occupancy shaping)
   std::string err;
   DevTables* d_tab = nullptr;
   std::vector<Slot> slots;
@@ -255,6 +256,7 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile; c->keep_bits = cfg->keep_bits;
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = getenv("C8P_LEAN_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 140000) c->lean_lds = (unsigned)atoi(e); }
   {
     // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 3) engine-owned streams.
     int nslot = 3;
@@ -379,7 +381,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
-      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), c->lean_lds, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                          d_flags, n);
     }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, c->s->stream, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
