@@ -12,9 +12,10 @@ MEM_HOST, MEM_DEVICE = 0, 1
 F_L, F_HT, F_VHT, F_VHT_CHAN = 0, 1, 2, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
-BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN = range(10)
-K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_COUNT = range(7)
-K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal"]
+BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN, \
+    BUF_DET_EVT, BUF_DET_AC, BUF_DET_TRIG, BUF_DET_CONJ = range(14)
+K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_PRESISO, K_TRIGGER, K_SYNCEVT, K_COUNT = range(10)
+K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal", "presiso", "trigger", "syncevt"]
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
 NDP_TOTAL = 1024
@@ -63,6 +64,14 @@ class SignalIn(C.Structure):
     _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64)]
 
 
+class SyncEvt(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("rad", C.c_float), ("snr", C.c_float), ("rssi", C.c_float), ("trig", C.c_uint32)]
+
+
+class DetectIn(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("keep", C.c_int32), ("raw", C.c_void_p), ("n", C.c_uint64)]
+
+
 class DecodeIn(C.Structure):
     _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("tags", C.c_void_p), ("llr", C.c_void_p),
                 ("n_llr", C.c_uint64), ("mu2x1chan", C.c_void_p)]
@@ -86,6 +95,7 @@ PKT_IN_DT = _np_dtype(PktIn)
 PKT_TAGS_DT = _np_dtype(PktTags)
 PKT_OUT_DT = _np_dtype(PktOut)
 SIG_IN_DT = _np_dtype(SigIn)
+SYNC_EVT_DT = _np_dtype(SyncEvt)
 
 TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
 

@@ -1,0 +1,356 @@
+// c8p_detect.h — packet detection front end on gfx950: examples/presiso.grc (stock GNU Radio blocks)
+// -> lib/trigger_impl.cc -> lib/sync_impl.cc, restructured as scans over the raw 20 MS/s stream.
+//
+//   k_presiso      thread = 8 consecutive samples.  p[n] = x[n-16] conj(x[n]), windows of 48 (complex) and 64 (energy)
+//                  assembled from per-thread block sums + suffix sums staged in LDS: 13 + 15 LDS reads per 8 samples,
+//                  no re-summation.  HBM-bound: 8 B read + 4 B (ac) [+ 8 B conj when kept] written per sample.
+//   k_trig_local   tile = 2048 samples: summary of the tile for the plateau state machine (whole tile above the
+//                  threshold? trailing run: start, maximum, first position of the maximum)
+//   k_trig_carry   one workgroup: exclusive scan of the tile summaries = the run that is open at every tile start
+//   k_trig_apply   per sample: "ac > 0.3" and "new maximum of this plateau" (trigger bit 0x02) by a segmented
+//                  max-scan seeded with the carry; every plateau of >= 21 samples is appended to a candidate list
+//   (host)         trigger_impl's countdown logic over the (few) candidates, sync_impl's IDLE/SYNC alternation
+//   k_sync_mark    wave = accepted trigger: last "latch conj" mark the sync block saw, and the conj value there
+//   k_sync_evt     wave = accepted trigger: LTF autocorrelation over 111 offsets with the reference's running sums in
+//                  the reference's operation order (lane 0, bit-exact given the samples), plateau centre, CFO, tags
+#pragma once
+#include "c8p_dev.h"
+
+#define C8P_DET_TILE 2048           // samples per trigger tile (256 threads x 8)
+#define C8P_AC_THR 0.3f             // trigger_impl.cc:77
+#define C8P_SYNC_BUF 240            // sync_impl.h:29
+#define C8P_SYNC_RES 111            // sync_impl.h:30
+
+struct TrigSeg {                    // summary of a stretch of samples for the plateau scan
+  int all;                          // every sample above the threshold
+  long long tstart;                 // first sample of the trailing run of above-threshold samples, -1: last sample below
+  float tmax;                       // maximum of ac over the trailing run (inside this stretch)
+  long long targ;                   // first position of that maximum
+};
+struct TrigCand {                   // a plateau of >= 21 samples: [s, e)
+  unsigned long long s, e;
+};
+
+__device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = -2; r.tmax = 0.f; r.targ = -1; return r; }   // empty stretch
+// L then R.  tstart == -2 marks the empty stretch (identity).
+__device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& R)
+{
+  if (R.tstart == -2) return L;
+  if (L.tstart == -2) return R;
+  TrigSeg o;
+  o.all = L.all && R.all;
+  if (!R.all || L.tstart < 0) { o.tstart = R.tstart; o.tmax = R.tmax; o.targ = R.targ; }
+  else {                                            // R entirely above and L ends inside a run: the run continues
+    o.tstart = L.tstart;
+    if (R.tmax > L.tmax) { o.tmax = R.tmax; o.targ = R.targ; } else { o.tmax = L.tmax; o.targ = L.targ; }
+  }
+  return o;
+}
+__device__ __forceinline__ TrigSeg seg_of_sample(float a, long long idx)
+{
+  TrigSeg r;
+  const bool ab = a > C8P_AC_THR;                   // NaN (0/0 in silence) compares false, as in the reference
+  r.all = ab; r.tstart = ab ? idx : -1; r.tmax = ab ? a : 0.f; r.targ = ab ? idx : -1;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ presiso
+// One workgroup = 256 blocks of 8 samples: blocks 0..7 only supply the 16-sample delay and the window history
+// (48 products = 6 blocks back, 64 energies = 8 blocks back), blocks 8..255 (248 blocks = 1984 samples) are written.  Global traffic is fully coalesced: samples enter
+// through LDS transposed ([sample % 8][block], row stride 264 = 8 mod 16 eight-byte banks: conflict-free both for the
+// coalesced writes and for "thread t reads row j, column t - m"), results leave the same way.
+#define C8P_PRE_HALO 8
+#define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
+#define C8P_PRE_RS 264
+__global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsigned long long n, float* __restrict__ ac,
+                                                 cf* __restrict__ conj, int keep)
+{
+  __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
+  __shared__ float sE[9 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
+  const int tid = threadIdx.x;
+  const long long blk0 = (long long)blockIdx.x * C8P_PRE_OUT_BLOCKS - C8P_PRE_HALO;   // first block of this workgroup
+  const long long base = blk0 * 8;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {             // coalesced: thread tid loads sample base + tid + 256 k
+    const int i = tid + 256 * k;
+    const long long g = base + i;
+    sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= 0 && (unsigned long long)g < n) ? x[g] : mk(0.f, 0.f);
+  }
+  __syncthreads();
+  cf p[8];
+  float e[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const cf a = sX[j * C8P_PRE_RS + tid];
+    const cf d = tid >= 2 ? sX[j * C8P_PRE_RS + tid - 2] : mk(0.f, 0.f);      // x[g - 16]: two blocks back
+    p[j] = mk(d.x * a.x + d.y * a.y, d.y * a.x - d.x * a.y);                    // x[g-16] * conj(x[g])
+    e[j] = a.x * a.x + a.y * a.y;
+  }
+  __syncthreads();
+  {
+    cf s = mk(0.f, 0.f);
+    float se = 0.f;
+    sX[8 * C8P_PRE_RS + tid] = s; sE[8 * C8P_PRE_RS + tid] = 0.f;
+#pragma unroll
+    for (int j = 7; j >= 0; j--) { s = cadd(s, p[j]); se += e[j]; sX[j * C8P_PRE_RS + tid] = s; sE[j * C8P_PRE_RS + tid] = se; }
+  }
+  __syncthreads();
+  float acv[8];
+  cf Pv[8];
+  if (tid >= C8P_PRE_HALO) {
+    cf cp = mk(0.f, 0.f);
+    float ce = 0.f;
+#pragma unroll
+    for (int m = 1; m <= 5; m++) cp = cadd(cp, sX[tid - m]);         // five whole blocks of the 48-window
+#pragma unroll
+    for (int m = 1; m <= 7; m++) ce += sE[tid - m];                  // seven whole blocks of the 64-window
+    cf pre = mk(0.f, 0.f);
+    float pe = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      pre = cadd(pre, p[j]); pe += e[j];
+      const cf P = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);   // tail of block b-6 + blocks b-5..b-1 + head of block b
+      const float E = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
+      acv[j] = sqrtf(P.x * P.x + P.y * P.y) / E;
+      Pv[j] = P;
+    }
+  }
+  __syncthreads();
+  if (tid >= C8P_PRE_HALO) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) sE[j * C8P_PRE_RS + tid] = acv[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {             // coalesced: thread tid stores sample base + tid + 256 k
+    const int i = tid + 256 * k;
+    const long long g = base + i;
+    if ((i >> 3) >= C8P_PRE_HALO && (unsigned long long)g < n && g >= 0) ac[g] = sE[(i & 7) * C8P_PRE_RS + (i >> 3)];
+  }
+  if (keep && tid >= C8P_PRE_HALO) {        // test / debug path only
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const long long g = base + tid * 8 + j; if ((unsigned long long)g < n) conj[g] = Pv[j]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ trigger scan
+// inclusive Hillis-Steele scan of 256 TrigSeg values in LDS; returns the exclusive prefix of `mine`
+__device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh /*[2][256]*/, TrigSeg& total)
+{
+  const int tid = threadIdx.x;
+  int cur = 0;
+  sh[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    TrigSeg v = sh[cur * 256 + tid];
+    if (tid >= o) v = seg_combine(sh[cur * 256 + tid - o], v);
+    sh[(cur ^ 1) * 256 + tid] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  total = sh[cur * 256 + 255];
+  TrigSeg ex = tid ? sh[cur * 256 + tid - 1] : seg_identity();
+  __syncthreads();
+  return ex;
+}
+
+__device__ __forceinline__ TrigSeg seg_of_thread(const float* __restrict__ ac, unsigned long long n, long long n0, float (&a)[8])
+{
+  TrigSeg s = seg_identity();
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const long long g = n0 + j;
+    a[j] = (unsigned long long)g < n ? ac[g] : 0.f;
+    if ((unsigned long long)g < n) s = seg_combine(s, seg_of_sample(a[j], g));
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_trig_local(const float* __restrict__ ac, unsigned long long n, TrigSeg* __restrict__ summ)
+{
+  __shared__ TrigSeg sh[2 * 256];
+  float a[8];
+  const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
+  TrigSeg total;
+  (void)seg_block_exclusive(seg_of_thread(ac, n, n0, a), sh, total);
+  if (threadIdx.x == 0) summ[blockIdx.x] = total;
+}
+
+// one workgroup of 1024 threads: carry[t] = combine(summ[0..t-1])
+__global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__ summ, TrigSeg* __restrict__ carry, int ntile)
+{
+  __shared__ TrigSeg sh[1024];
+  const int tid = threadIdx.x;
+  const int per = (ntile + 1023) / 1024;
+  const int lo = min(tid * per, ntile), hi = min(lo + per, ntile);
+  TrigSeg s = seg_identity();
+  for (int t = lo; t < hi; t++) s = seg_combine(s, summ[t]);
+  sh[tid] = s;
+  __syncthreads();
+  if (tid == 0) {                                   // 1024 chunk summaries: a short serial pass
+    TrigSeg run = seg_identity();
+    for (int k = 0; k < 1024; k++) { const TrigSeg v = sh[k]; sh[k] = run; run = seg_combine(run, v); }
+  }
+  __syncthreads();
+  s = sh[tid];
+  for (int t = lo; t < hi; t++) { carry[t] = s; s = seg_combine(s, summ[t]); }
+}
+
+__global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac, unsigned long long n, const TrigSeg* __restrict__ carry,
+                                                    uint8_t* __restrict__ trig, TrigCand* __restrict__ cand,
+                                                    unsigned int* __restrict__ n_cand, unsigned int cap)
+{
+  __shared__ TrigSeg sh[2 * 256];
+  float a[8];
+  const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
+  TrigSeg total;
+  TrigSeg ex = seg_block_exclusive(seg_of_thread(ac, n, n0, a), sh, total);
+  TrigSeg st = seg_combine(carry[blockIdx.x], ex);   // everything before this thread's first sample
+  // walk the 8 samples with the plateau state: run start and running maximum
+  long long rs = (st.tstart >= 0) ? st.tstart : -1;
+  float rmax = (st.tstart >= 0) ? st.tmax : 0.f;
+  unsigned long long packed = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const long long g = n0 + j;
+    if ((unsigned long long)g >= n) break;
+    unsigned b = 0;
+    if (a[j] > C8P_AC_THR) {
+      b = 0x04;
+      if (rs < 0) { rs = g; rmax = 0.f; }
+      if (a[j] > rmax) { rmax = a[j]; b |= 0x02; }     // trigger_impl.cc:80-85 (d_conjAc restarts at 0 with every plateau)
+    } else {
+      if (rs >= 0 && g - rs >= 21) {                   // a plateau long enough to arm the countdown ended here
+        const unsigned k = atomicAdd(n_cand, 1u);
+        if (k < cap) { cand[k].s = (unsigned long long)rs; cand[k].e = (unsigned long long)g; }
+      }
+      rs = -1; rmax = 0.f;
+    }
+    packed |= (unsigned long long)b << (8 * j);
+    if ((unsigned long long)g == n - 1 && rs >= 0 && g + 1 - rs >= 21) {   // plateau still open at the end of the stream
+      const unsigned k = atomicAdd(n_cand, 1u);
+      if (k < cap) { cand[k].s = (unsigned long long)rs; cand[k].e = n; }
+    }
+  }
+  if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = packed;
+  else for (int j = 0; j < 8 && (unsigned long long)(n0 + j) < n; j++) trig[n0 + j] = (uint8_t)(packed >> (8 * j));
+}
+
+// the host adds the trigger bits (0x01) it derived from the candidates
+__global__ void k_trig_fire(uint8_t* __restrict__ trig, const unsigned long long* __restrict__ fire, int nf)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nf) trig[fire[i]] |= 0x01;
+}
+
+// ------------------------------------------------------------------------------------------------ sync
+struct SyncJob {            // one accepted trigger
+  unsigned long long t;     // trigger item (sync_impl switches to SYNC_S_SYNC here)
+  unsigned long long seen;  // first item the IDLE state scanned before reaching t
+};
+struct SyncMark {
+  long long j;              // last item in [seen, t) with trigger bit 0x02, -1: none
+  cf conj;                  // presiso output 1 at j
+};
+
+__global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ job, const uint8_t* __restrict__ trig,
+                                                  const cf* __restrict__ x, SyncMark* __restrict__ out, int nj)
+{
+  const int k = blockIdx.x;
+  if (k >= nj) return;
+  const int lane = lane_id();
+  const SyncJob J = job[k];
+  long long j = -1;
+  for (long long hi = (long long)J.t; hi > (long long)J.seen && j < 0; hi -= 64) {   // newest 64 items first
+    const long long g = hi - 1 - lane;
+    const bool m = g >= (long long)J.seen && (trig[g] & 0x02);
+    const unsigned long long bm = __ballot(m);
+    if (bm) j = hi - 1 - (long long)__builtin_ctzll(bm);
+  }
+  cf P = mk(0.f, 0.f);
+  if (j >= 0) {
+    // conj[j] = sum_{k=j-47..j} x[k-16] conj(x[k]): 48 products, lanes 0..47, folded oldest-first by lane 0
+    __shared__ cf pr[48];
+    if (lane < 48) {
+      const long long g = j - 47 + lane;
+      cf a = mk(0.f, 0.f), d = mk(0.f, 0.f);
+      if (g >= 0) a = x[g];
+      if (g >= 16) d = x[g - 16];
+      pr[lane] = mk(d.x * a.x + d.y * a.y, d.y * a.x - d.x * a.y);
+    }
+    __syncthreads();
+    if (lane == 0) for (int i = 0; i < 48; i++) P = cadd(P, pr[i]);
+  }
+  if (lane == 0) { out[k].j = j; out[k].conj = P; }
+}
+
+__device__ __forceinline__ float habs(cf a) { return cabs_(a); }    // std::abs(std::complex<float>) == hypotf
+
+__global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job, const SyncMark* __restrict__ mark,
+                                                 const cf* __restrict__ x, c8p_sync_evt* __restrict__ evt,
+                                                 int* __restrict__ valid, int nj)
+{
+  __shared__ cf sig[C8P_SYNC_BUF];
+  __shared__ float tac[C8P_SYNC_RES], tpw[C8P_SYNC_RES];
+  __shared__ cf rot128[128];
+  const int k = blockIdx.x;
+  if (k >= nj) return;
+  const int lane = lane_id();
+  const SyncJob J = job[k];
+  for (int i = lane; i < C8P_SYNC_BUF; i += 64) sig[i] = x[J.t + i];
+  // d_conjMultiAvg: the last latch the IDLE state saw — this trigger's mark, or the one an earlier trigger left behind
+  cf cavg = mk(0.f, 0.f);
+  for (int kk = k; kk >= 0; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
+  __syncthreads();
+  int ok = 0, mIndex = 0, mx = 0;
+  if (lane == 0) {
+    // ltf_autoCorrelation sync_impl.cc:150-175, same running sums in the same order
+    cf ms = mk(0.f, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < 64; i++) {
+      ms = cadd(ms, cmul(sig[i], cconj(sig[i + 64])));
+      s1 += habs(sig[i]) * habs(sig[i]);
+      s2 += habs(sig[i + 64]) * habs(sig[i + 64]);
+    }
+    for (int i = 0; i < C8P_SYNC_RES; i++) {
+      tac[i] = habs(ms) / sqrtf(s1) / sqrtf(s2);
+      tpw[i] = s1;
+      ms = csub(ms, cmul(sig[i], cconj(sig[i + 64])));
+      s1 -= habs(sig[i]) * habs(sig[i]);
+      s2 -= habs(sig[i + 64]) * habs(sig[i + 64]);
+      ms = cadd(ms, cmul(sig[i + 64], cconj(sig[i + 128])));
+      s1 += habs(sig[i + 64]) * habs(sig[i + 64]);
+      s2 += habs(sig[i + 128]) * habs(sig[i + 128]);
+    }
+    for (int j = 1; j < C8P_SYNC_RES; j++) if (tac[j] > tac[mx]) mx = j;
+    if ((double)tac[mx] > 0.5) {                                      // sync_impl.cc:93
+      const float thr = (float)((double)tac[mx] * 0.8);
+      int l = mx, r = mx;
+      for (int j = mx; j >= 0; j--) if (tac[j] < thr) { l = j; break; }
+      for (int j = mx; j < C8P_SYNC_RES; j++) if (tac[j] < thr) { r = j; break; }
+      mIndex = (l + r) / 2;
+      ok = 1;
+    }
+  }
+  ok = __shfl(ok, 0, 64); mIndex = __shfl(mIndex, 0, 64); mx = __shfl(mx, 0, 64);
+  if (!ok) { if (lane == 0) valid[k] = 0; return; }
+  // ltf_cfo sync_impl.cc:177-192
+  const float stf = atan2f(cavg.y, cavg.x) / 16.0f;
+  for (int i = lane; i < 128; i += 64) rot128[i] = cmul(sig[mIndex + i], mk(cosf(i * stf), sinf(i * stf)));
+  __syncthreads();
+  if (lane == 0) {
+    cf sum = mk(0.f, 0.f);
+    for (int i = 0; i < 64; i++) sum = cadd(sum, cmul(rot128[i], cconj(rot128[i + 64])));
+    const cf q = cdivf(sum, 64.0f);
+    const float ltf = atan2f(q.y, q.x) / 64.0f;
+    const double d = (double)tac[mx];
+    c8p_sync_evt e;
+    e.index = J.t + (unsigned long long)mIndex;
+    e.rad = stf + ltf;
+    e.snr = (float)(10.0 * log10(d / (1.0 - d)));
+    e.rssi = tpw[mx] / 64.0f;
+    e.trig = (uint32_t)J.t;
+    evt[k] = e;
+    valid[k] = 1;
+  }
+}

@@ -12,7 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "c8p_kernels.h"
+#include "c8p_detect.h"
 
 #define HIPCHK(ctx, call)                                                                  \
   do {                                                                                     \
@@ -179,6 +182,8 @@ struct Slot {
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt;
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
+  Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_cnt, d_det_job, d_det_mark,
+      d_det_evt, d_det_valid, d_det_fire;            // detection front-end
   int n_pkt = 0;
   size_t used[C8P_BUF_COUNT] = {};
   const void* ptr[C8P_BUF_COUNT] = {};
@@ -288,7 +293,9 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt,
-                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan};
+                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig,
+                   &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
+                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
@@ -582,6 +589,133 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
   return C8P_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ detection front-end
+// presiso.grc -> trigger_impl -> sync_impl over one stream segment.  The dense work (windowed
+// autocorrelation, plateau / running-maximum scan) runs on the GPU; trigger_impl's countdown logic and sync_impl's
+// IDLE / SYNC alternation are sequential but touch only the few plateaus of >= 21 samples, so they run here on the
+// host over the compacted candidate list (trigger_impl.cc:86-109, sync_impl.cc:73-147).
+extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || (in->n > 0 && !in->raw)) { c->err = "bad detect input"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  if (in->n > (1ull << 31)) { c->err = "stream segment too long (2^31 items max)"; return C8P_ERANGE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cur = (c->cur + 1) % (int)c->slots.size();
+  c->s = &c->slots[c->cur];
+  Slot& S = *c->s;
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  drain_events(c);
+  S.n_pkt = 0;
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
+  const uint64_t n = in->n;
+  if (n == 0) return C8P_OK;
+  int rc;
+  const cf* d_raw = (const cf*)in->raw;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * n)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * n, hipMemcpyHostToDevice, S.stream));
+    d_raw = (const cf*)S.d_det_raw.p;
+  }
+  const int ntile = (int)((n + C8P_DET_TILE - 1) / C8P_DET_TILE);
+  const unsigned cap = (unsigned)(n / 22 + 16);        // a plateau needs 21 samples above and one below
+  if ((rc = ensure(c, S.d_det_ac, sizeof(float) * n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_trig, n + 8)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_conj, in->keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_summ, sizeof(TrigSeg) * (size_t)ntile)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg) * (size_t)ntile)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * (size_t)cap)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_cnt, 16)) != C8P_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(S.d_det_cnt.p, 0, 16, S.stream));
+  {
+    KTimer kt(c, C8P_K_PRESISO);
+    const uint64_t nblk = (n + 7) / 8;
+    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
+                       d_raw, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep);
+  }
+  {
+    KTimer kt(c, C8P_K_TRIGGER);
+    hipLaunchKernelGGL(k_trig_local, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n, (TrigSeg*)S.d_det_summ.p);
+    hipLaunchKernelGGL(k_trig_carry, dim3(1), dim3(1024), 0, S.stream, (const TrigSeg*)S.d_det_summ.p, (TrigSeg*)S.d_det_carry.p, ntile);
+    hipLaunchKernelGGL(k_trig_apply, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n,
+                       (const TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
+  }
+  HIPCHK(c, hipGetLastError());
+  unsigned ncand = 0;
+  HIPCHK(c, hipMemcpyAsync(&ncand, S.d_det_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
+  std::vector<TrigCand> cand(ncand);
+  if (ncand) HIPCHK(c, hipMemcpy(cand.data(), S.d_det_cand.p, sizeof(TrigCand) * ncand, hipMemcpyDeviceToHost));
+  std::sort(cand.begin(), cand.end(), [](const TrigCand& a, const TrigCand& b) { return a.s < b.s; });
+  // trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous
+  // countdown has run out if that is later and the plateau still lasts; one trigger per plateau
+  std::vector<unsigned long long> fire;
+  {
+    bool have = false;
+    unsigned long long prev_start = 0;
+    for (const TrigCand& k : cand) {
+      unsigned long long start = k.s + 20;
+      if (have && prev_start + 80 > start) start = prev_start + 80;
+      if (start < k.e) {
+        have = true; prev_start = start;
+        if (start + 79 < n) fire.push_back(start + 79);
+      }
+    }
+  }
+  // sync_impl.cc:73-147: IDLE scans up to a trigger, SYNC needs 240 items from it and consumes 111
+  std::vector<SyncJob> jobs;
+  {
+    unsigned long long pos = 0;
+    for (unsigned long long t : fire) {
+      if (t < pos) continue;                        // fell inside the 111 items a SYNC pass consumed unseen
+      if (n - t < C8P_SYNC_BUF) break;              // the block would wait for more input
+      SyncJob j; j.t = t; j.seen = pos;
+      jobs.push_back(j);
+      pos = t + C8P_SYNC_RES;
+    }
+  }
+  const int nf = (int)fire.size(), nj = (int)jobs.size();
+  std::vector<c8p_sync_evt> evts;
+  if (nf) {
+    if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * (size_t)nf)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_fire.p, fire.data(), sizeof(unsigned long long) * (size_t)nf, hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(k_trig_fire, dim3((nf + 255) / 256), dim3(256), 0, S.stream, (uint8_t*)S.d_det_trig.p,
+                       (const unsigned long long*)S.d_det_fire.p, nf);
+  }
+  if (nj) {
+    if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * (size_t)nj)) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * (size_t)nj)) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * (size_t)nj)) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_valid, sizeof(int) * (size_t)nj)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, jobs.data(), sizeof(SyncJob) * (size_t)nj, hipMemcpyHostToDevice, S.stream));
+    {
+      KTimer kt(c, C8P_K_SYNCEVT);
+      hipLaunchKernelGGL(k_sync_mark, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_raw,
+                         (SyncMark*)S.d_det_mark.p, nj);
+      hipLaunchKernelGGL(k_sync_evt, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_raw,
+                         (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, nj);
+    }
+    HIPCHK(c, hipGetLastError());
+    std::vector<c8p_sync_evt> all(nj);
+    std::vector<int> valid(nj);
+    HIPCHK(c, hipMemcpyAsync(all.data(), S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(valid.data(), S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipStreamSynchronize(S.stream));
+    for (int k = 0; k < nj; k++) if (valid[k]) evts.push_back(all[k]);
+    if (!evts.empty())      // compacted, in stream order: what the sync block's output stream carries
+      HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, evts.data(), sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  drain_events(c);
+  S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
+  S.used[C8P_BUF_DET_AC] = sizeof(float) * n; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
+  S.used[C8P_BUF_DET_TRIG] = n; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
+  S.used[C8P_BUF_DET_CONJ] = in->keep ? sizeof(cf) * n : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
+  return C8P_OK;
+}
+
 extern "C" int c8p_sync(c8p_ctx* c)
 {
   if (!c) return C8P_EINVAL;
@@ -628,7 +762,8 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
 {
   const int32_t v[] = {C8P_ABI_VERSION, (int32_t)sizeof(c8p_pkt_in), (int32_t)sizeof(c8p_pkt_tags), (int32_t)sizeof(c8p_pkt_out),
                        (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
-                       (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in)};
-  for (int i = 0; i < 9 && i < cap; i++) dst[i] = v[i];
-  return 9;
+                       (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
+                       (int32_t)sizeof(c8p_detect_in)};
+  for (int i = 0; i < 11 && i < cap; i++) dst[i] = v[i];
+  return 11;
 }

@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 
 # every entry point include/c8p_rx.h declares
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
-           "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal"]
+           "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
+           "c8p_detect"]
 
 _LIB = None
 
@@ -41,6 +42,7 @@ def load_library():
         getattr(L, f).argtypes = [C.c_void_p, C.POINTER(abi.BatchIn)]
     L.c8p_decode.argtypes = [C.c_void_p, C.POINTER(abi.DecodeIn)]
     L.c8p_signal.argtypes = [C.c_void_p, C.POINTER(abi.SignalIn)]
+    L.c8p_detect.argtypes = [C.c_void_p, C.POINTER(abi.DetectIn)]
     L.c8p_sync.argtypes = [C.c_void_p]
     L.c8p_buffer.restype = C.c_void_p
     L.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
@@ -49,10 +51,11 @@ def load_library():
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
-    sizes = np.zeros(9, np.int32)
-    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 9)
+    sizes = np.zeros(11, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 11)
     want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
-            C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn)]
+            C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn),
+            C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn)]
     if list(sizes) != want:
         raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
     _LIB = L
@@ -143,6 +146,14 @@ class Engine:
         self._keep = (evts, k1, d)
         self.n = len(evts)
         self._chk(self.L.c8p_signal(self.ctx, C.byref(d)))
+
+    def detect(self, raw, keep=False):
+        """presiso + trigger + sync over one raw stream segment (antenna 0); returns the sync events (host copy)."""
+        r_p, n_r, m, k1 = self._arena(raw, np.complex64)
+        d = abi.DetectIn(m, int(keep), r_p, n_r)
+        self._keep = (k1, d)
+        self._chk(self.L.c8p_detect(self.ctx, C.byref(d)))
+        return self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
 
     def sync(self):
         self._chk(self.L.c8p_sync(self.ctx))

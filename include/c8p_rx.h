@@ -141,6 +141,18 @@ typedef struct c8p_sig_in {
   uint8_t  rsv[3];
 } c8p_sig_in;
 
+/*
+ * One flagged item of the sync block's output stream with its tags (sync_impl.cc:111-141): what c8p_detect()
+ * produces and what, per antenna, becomes a c8p_sig_in for c8p_signal().
+ */
+typedef struct c8p_sync_evt {
+  uint64_t index;       /* item index of the sync flag in the raw stream (L-LTF start + ~16)                  */
+  float    rad;         /* tag "rad": CFO in rad / sample (STF coarse + LTF fine)                             */
+  float    snr;         /* tag "snr"                                                                          */
+  float    rssi;        /* tag "rssi"                                                                         */
+  uint32_t trig;        /* item index of the trigger that started this search (low 32 bits)                   */
+} c8p_sync_evt;
+
 typedef struct c8p_cfg {
   int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
   int32_t device;           /* HIP device ordinal                                                      */
@@ -167,6 +179,15 @@ typedef struct c8p_signal_in {
   uint64_t          n_raw;
 } c8p_signal_in;
 
+/* raw stream -> sync events: presiso.grc + trigger_impl + sync_impl over one stream segment that starts from the
+ * blocks' constructor state (antenna 0 only, as in rx.grc / rx2.grc) */
+typedef struct c8p_detect_in {
+  int32_t mem;              /* C8P_MEM_* of raw                                                        */
+  int32_t keep;             /* 1: also keep the conj stream (C8P_BUF_DET_CONJ) for tests               */
+  const c8p_c32* raw;       /* [n] raw samples of antenna 0                                            */
+  uint64_t       n;
+} c8p_detect_in;
+
 typedef struct c8p_decode_in {
   int32_t n_pkt;
   int32_t mem;              /* C8P_MEM_* of tags, llr and mu2x1chan                                    */
@@ -187,7 +208,11 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_SIG_PKT  7  /* c8p_pkt_in[n_evt]: the boundary descriptors signal produced (n_items = 0: L-SIG check failed) */
 #define C8P_BUF_SIG_IQ   8  /* CFO-corrected items, per packet at pkt.iq_off[a] (nsamp items + 320 zero pad)   */
 #define C8P_BUF_SIG_CHAN 9  /* c8p_c32[n_evt][64] legacy channel estimates (tag "chan")                        */
-#define C8P_BUF_COUNT    10
+#define C8P_BUF_DET_EVT  10 /* c8p_sync_evt[]: sync events of the last c8p_detect, in stream order                    */
+#define C8P_BUF_DET_AC   11 /* float[n]: presiso output 0 (autocorrelation magnitude / energy)                        */
+#define C8P_BUF_DET_TRIG 12 /* uint8[n]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
+#define C8P_BUF_DET_CONJ 13 /* c8p_c32[n] (keep = 1): presiso output 1                                                */
+#define C8P_BUF_COUNT    14
 
 /* kernels, for c8p_kernel_time() */
 #define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */
@@ -196,7 +221,10 @@ typedef struct c8p_decode_in {
 #define C8P_K_VITERBI  3
 #define C8P_K_FINISH   4
 #define C8P_K_SIGNAL   5
-#define C8P_K_COUNT    6
+#define C8P_K_PRESISO  6    /* windowed autocorrelation scan (HBM-bound) */
+#define C8P_K_TRIGGER  7    /* plateau / running-max scan (three passes) */
+#define C8P_K_SYNCEVT  8    /* per-trigger LTF search + CFO              */
+#define C8P_K_COUNT    9
 
 typedef struct c8p_ctx c8p_ctx;
 
@@ -209,6 +237,7 @@ int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCH
 int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
+int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
 int c8p_sync  (c8p_ctx* ctx);
 
 /* Device pointer / size in bytes of a result arena of the last submit. */
@@ -232,7 +261,7 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
 
-/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in} as compiled into the library. */
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

@@ -157,3 +157,40 @@ def signal_events(evts, raw):
         if not ok:
             pk[e]["n_items"] = 0
     return pk, iq[:-1], chan
+
+
+# ---- packet detection front end (c8p_oracle_detect.c)
+def presiso(x):
+    x = np.ascontiguousarray(x, np.complex64)
+    ac = np.zeros(len(x), np.float32)
+    cj = np.zeros(len(x), np.complex64)
+    lib().c8po_presiso(_p(x), C.c_long(len(x)), _p(ac), _p(cj))
+    return ac, cj
+
+
+def trigger(ac):
+    ac = np.ascontiguousarray(ac, np.float32)
+    t = np.zeros(len(ac), np.uint8)
+    lib().c8po_trigger(_p(ac), C.c_long(len(ac)), _p(t))
+    return t
+
+
+def sync(trig, conj, sig, cap=1 << 16):
+    a = _abi()
+    trig = np.ascontiguousarray(trig, np.uint8)
+    conj = np.ascontiguousarray(conj, np.complex64)
+    sig = np.ascontiguousarray(sig, np.complex64)
+    ev = np.zeros(cap, a.SYNC_EVT_DT)
+    sb = np.zeros(len(sig), np.uint8)
+    L = lib()
+    L.c8po_sync.restype = C.c_long
+    n = L.c8po_sync(_p(trig), _p(conj), _p(sig), C.c_long(len(sig)), _p(ev), C.c_long(cap), _p(sb))
+    return ev[:min(n, cap)].copy(), sb
+
+
+def detect(x):
+    """presiso -> trigger -> sync over one stream segment; returns (events, ac, conj, trig)."""
+    ac, cj = presiso(x)
+    t = trigger(ac)
+    ev, _ = sync(t, cj, x)
+    return ev, ac, cj, t

@@ -1,0 +1,204 @@
+"""Packet detection front end: presiso.grc -> trigger_impl -> sync_impl.
+
+CPU: the oracle (literal restatement of the two state machines + the published algorithm of the stock GNU Radio blocks
+in presiso.grc) finds every reference-TX fixture in a noisy stream with carrier offset, its events drive the signal /
+demod / decode oracle to the transmitted MPDU, and the *sparse* formulation the product uses for trigger_impl's countdown
+logic and sync_impl's IDLE/SYNC alternation is checked against the literal per-sample loops on random plateau patterns.
+GPU: c8p_detect against the oracle: ac/conj within 2e-6 (of the stream's scale) (different summation order of the moving windows; the
+reference itself is not bit-reproducible there, see oracle/c8p_oracle_detect.c), trigger bytes and event indices
+identical, rad/snr/rssi within libm tolerance; then chained on the device through c8p_signal and c8p_rx to the PDUs."""
+import numpy as np
+import pytest
+
+from c8p_cases import dewindow
+from c8p_testlib import abi, load_npz, oracle, oracle_rx, through_channel
+
+SWEEP = load_npz("packets_sweep.npz")
+NAMES = ["L_0", "L_5", "HT_3", "HT_7", "VHT_2", "VHT_8", "L_3", "VHT_5"]
+CFOS = [0.0, 37e3, -81e3, 120e3, -4e3, 66e3, -150e3, 12e3]
+
+
+def stream(names, cfos, snr=25.0, seed=3, gap=(400, 1500)):
+    """one antenna-0 stream: packets separated by noise-only gaps, each with its own carrier offset"""
+    rng = np.random.default_rng(seed)
+    parts, starts, exp = [], [], []
+    pos = 0
+    for name, cfo in zip(names, cfos):
+        d = SWEEP[name]
+        lead = int(rng.integers(*gap))
+        rx = through_channel(dewindow(d["tx"])[:1], None, snr, rng, lead=lead)[0]
+        w = 2 * np.pi * cfo / 20e6
+        rx = (rx * np.exp(1j * w * np.arange(len(rx)))).astype(np.complex64)
+        parts.append(rx)
+        starts.append(pos + lead)
+        exp.append((d, w))
+        pos += len(rx)
+    return np.concatenate(parts), starts, exp
+
+
+def sig_events(ev, n, n_ant=1):
+    s = np.zeros(len(ev), abi.SIG_IN_DT)
+    for i, e in enumerate(ev):
+        s[i]["raw_off"][0] = int(e["index"])
+        s[i]["n_avail"] = n - int(e["index"])
+        s[i]["cfo_rad"], s[i]["snr"], s[i]["rssi"] = e["rad"], e["snr"], e["rssi"]
+        s[i]["n_ant"] = n_ant
+    return s
+
+
+def consume_filter(ev, pk):
+    """signal_impl's S_TRIGGER scan (signal_impl.cc:76-111,154-160): sync flags inside a packet it is copying are never
+    seen; a failed L-SIG check skips 80 items."""
+    keep, pos = [], 0
+    for i, (e, p) in enumerate(zip(ev, pk)):
+        idx = int(e["index"])
+        if idx < pos:
+            continue
+        if p["n_items"] > 0:
+            keep.append(i)
+            pos = idx + 224 + int(p["lsig_nsamp"])
+        else:
+            pos = idx + 80
+    return keep
+
+
+def test_oracle_detect_drives_the_rx_chain():
+    x, starts, exp = stream(NAMES, CFOS)
+    o = oracle()
+    ev, ac, cj, trig = o.detect(x)
+    spk, siq, schan = o.signal_events(sig_events(ev, len(x)), x)
+    keep = consume_filter(ev, spk)
+    assert len(keep) == len(NAMES)
+    for i, s0, (d, w) in zip(keep, starts, exp):
+        ltf = s0 + 160
+        assert ltf + 6 <= int(ev[i]["index"]) <= ltf + 26          # "sync index is LTF starting index + 16" sync_impl.cc:123
+        assert abs(float(ev[i]["rad"]) + w) < 3e-4                  # tag "rad" cancels the carrier offset
+        assert 18.0 < float(ev[i]["snr"]) < 32.0
+    res = oracle_rx(spk[keep], siq, schan)
+    for r, (d, w) in zip(res, exp):
+        assert r["pdus"] == [d["pdu"].tobytes()]
+
+
+def sparse_trigger(ac):
+    """the product's formulation (c8p_engine.hip c8p_detect): plateaus [s, e) of >= 21 samples above 0.3, then
+    start = max(s + 20, previous start + 80) if the plateau still lasts, trigger at start + 79; bit 0x02 = new maximum."""
+    n = len(ac)
+    above = ac > 0.3
+    trig = np.zeros(n, np.uint8)
+    runs, s = [], None
+    for i in range(n):
+        if above[i]:
+            if s is None:
+                s, m = i, 0.0
+            if ac[i] > m:
+                m = ac[i]
+                trig[i] |= 2
+        elif s is not None:
+            runs.append((s, i)); s = None
+    if s is not None:
+        runs.append((s, n))
+    prev = None
+    for s, e in runs:
+        if e - s < 21:
+            continue
+        start = s + 20
+        if prev is not None and prev + 80 > start:
+            start = prev + 80
+        if start < e:
+            prev = start
+            if start + 79 < n:
+                trig[start + 79] |= 1
+    return trig
+
+
+def test_sparse_trigger_logic_equals_the_literal_state_machine():
+    rng = np.random.default_rng(11)
+    o = oracle()
+    for trial in range(200):
+        parts = []
+        for _ in range(int(rng.integers(1, 30))):
+            L = int(rng.choice([1, 5, 19, 20, 21, 22, 40, 79, 80, 81, 100, 160, 300, 1000]))
+            if rng.random() < 0.5:
+                parts.append(rng.uniform(0.31, 1.0, L))
+            else:
+                parts.append(rng.uniform(0.0, 0.3, L))
+            if rng.random() < 0.1:
+                parts.append(np.full(int(rng.integers(1, 4)), np.nan))
+        ac = np.concatenate(parts).astype(np.float32)
+        assert np.array_equal(o.trigger(ac), sparse_trigger(ac)), trial
+
+
+def burst_stream(seed, n_burst=60):
+    """16-periodic bursts (STF-like) of awkward lengths and gaps over a noise floor: plateaus that start, stop, merge
+    and overlap the 80-item countdown in every way, plus real packets."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for k in range(n_burst):
+        parts.append(0.01 * (rng.normal(size=int(rng.integers(3, 260))) + 1j * rng.normal(size=1)))
+        L = int(rng.choice([30, 52, 60, 61, 62, 63, 64, 70, 90, 100, 117, 118, 119, 120, 144, 160, 200, 320, 700, 2100, 4200]))
+        per = rng.normal(size=16) + 1j * rng.normal(size=16)
+        parts.append(np.tile(per, L // 16 + 1)[:L] * 0.2 + 0.01 * (rng.normal(size=L) + 1j * rng.normal(size=L)))
+        if k % 9 == 4:
+            d = SWEEP[NAMES[k % len(NAMES)]]
+            parts.append(through_channel(dewindow(d["tx"])[:1], None, 25.0, rng, lead=300)[0])
+    return np.concatenate(parts).astype(np.complex64)
+
+
+@pytest.mark.gpu
+def test_gpu_detect_matches_oracle_and_chains_into_rx():
+    from gr_ieee80211_amd import engine
+    x, starts, exp = stream(NAMES, CFOS, seed=5)
+    o = oracle()
+    ev, ac, cj, trig = o.detect(x)
+    eng = engine.Engine(device=0, profile=True)
+    gev = eng.detect(x, keep=True)
+    gac = eng.fetch(abi.BUF_DET_AC, np.float32)
+    gcj = eng.fetch(abi.BUF_DET_CONJ, np.complex64)
+    gtr = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+    fin = np.isfinite(ac)
+    assert np.array_equal(fin, np.isfinite(gac))
+    # ac is a ratio of O(1) (thresholds 0.3 / 0.5); where the 48 products nearly cancel only the absolute error is small
+    assert np.max(np.abs(gac[fin] - ac[fin]) / np.maximum(np.abs(ac[fin]), 1.0)) <= 2e-6
+    assert np.max(np.abs(gcj - cj)) <= 2e-6 * np.max(np.abs(cj))
+    assert np.array_equal(gtr & 3, trig)
+    assert np.array_equal((gtr & 4) != 0, ac > 0.3)
+    assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"]) and np.array_equal(gev["trig"], ev["trig"])
+    assert np.allclose(gev["rad"], ev["rad"], rtol=0, atol=2e-6)
+    assert np.allclose(gev["snr"], ev["snr"], rtol=1e-5) and np.allclose(gev["rssi"], ev["rssi"], rtol=1e-6)
+    # device chain: events -> c8p_signal -> (host: signal_impl's consumption rule) -> c8p_rx
+    eng2 = engine.Engine(device=0)
+    eng2.signal(sig_events(gev, len(x)), x)
+    eng2.sync()
+    gpk = eng2.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    keep = consume_filter(gev, gpk)
+    assert len(keep) == len(NAMES)
+    p_iq, b_iq = eng2.buffer(abi.BUF_SIG_IQ)
+    p_ch, b_ch = eng2.buffer(abi.BUF_SIG_CHAN)
+    eng3 = engine.Engine(device=0)
+    eng3.rx(gpk[keep], engine.DevArray(p_iq, b_iq // 8), engine.DevArray(p_ch, b_ch // 8))
+    res = eng3.results(want_llr=False)
+    for r, (d, w) in zip(res, exp):
+        assert r["pdus"] == [d["pdu"].tobytes()]
+    for e in (eng, eng2, eng3):
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gpu_trigger_and_sync_on_plateau_torture_streams(seed):
+    from gr_ieee80211_amd import engine
+    x = burst_stream(seed)
+    o = oracle()
+    ev, ac, cj, trig = o.detect(x)
+    eng = engine.Engine(device=0)
+    gev = eng.detect(x, keep=True)
+    gtr = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+    gac = eng.fetch(abi.BUF_DET_AC, np.float32)
+    eng.close()
+    # a threshold / running-maximum comparison can only differ where the two ac streams (2e-6 apart) straddle it
+    diff = np.nonzero((gtr & 3) != trig)[0]
+    print("seed %d: %d items, %d triggers, %d events, %d trigger-byte differences" % (seed, len(x), int((trig & 1).sum()), len(ev), len(diff)))
+    assert len(diff) == 0
+    assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"])
+    assert np.allclose(gev["rad"], ev["rad"], rtol=0, atol=5e-6)
+    assert (trig & 1).sum() >= 40
