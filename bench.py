@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
     ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
 
@@ -136,6 +137,8 @@ def main():
                          "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
                          "achieved_exclusive": (B_ALG * n_pkt / (kern_x[dom] * 1e-3)) / 1e9 if kern_x[dom] > 0 else 0.0},
         }
+        if not args.no_frontend:
+            out["frontend_detect"] = frontend_detect(torch, dev, local)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
@@ -165,6 +168,37 @@ def pmc_traffic(dom):
     if not k:
         return None, None
     return (k["fetch_size_kb_raw"] + k["write_size_kb"]) * 1024.0, os.path.relpath(best, ROOT)
+
+
+def frontend_detect(torch, dev, local, n_target=32 << 20):
+    """SURVEY §8f-2 stage, reported beside the headline metric: c8p_detect (presiso.grc + trigger + sync) over a raw
+    20 MS/s stream resident in HBM.  The dense kernel is k_presiso (HBM-bound scan: 8 B read + 4 B written per sample)."""
+    from c8p_cases import dewindow
+    from c8p_testlib import load_npz, through_channel
+    from gr_ieee80211_amd import engine
+    d = load_npz("packets_cfg.npz")["cfg2_VHT_mcs7_1458B_0"]
+    rng = np.random.default_rng(1)
+    unit = through_channel(dewindow(d["tx"])[:1], None, 30.0, rng, lead=600)[0]          # one packet + idle time
+    reps = max(1, n_target // len(unit))
+    x = torch.from_numpy(unit.view(np.float32)).to(dev).repeat(reps)
+    n = x.numel() // 2
+    eng = engine.Engine(device=local, profile=True)
+    arr = engine.DevArray(x.data_ptr(), n, x)
+    ev = eng.detect(arr)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        ev = eng.detect(arr)
+    dt = (time.perf_counter() - t0) / K
+    kt = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in eng.kernel_times().items()}
+    eng.close()
+    pre_s = kt["presiso"] * 1e-3
+    return {"samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
+            "x_realtime_20MSps": n / dt / 20e6, "ms_per_call": 1e3 * dt,
+            "kernel_ms": {k: round(kt[k], 4) for k in ("presiso", "trigger", "syncevt")},
+            "presiso_roofline": {"bound": "hbm", "alg_bytes_per_sample": 12, "achieved": 12.0 * n / pre_s / 1e9 if pre_s > 0 else 0.0,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (12.0 * n / pre_s / 1e9) / HBM_PEAK_GBS if pre_s > 0 else 0.0}}
 
 
 def cpu_baseline(pk, iq, chan, budget_s=12.0):

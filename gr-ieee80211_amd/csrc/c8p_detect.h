@@ -4,8 +4,8 @@
 //   k_presiso      thread = 8 consecutive samples.  p[n] = x[n-16] conj(x[n]), windows of 48 (complex) and 64 (energy)
 //                  assembled from per-thread block sums + suffix sums staged in LDS: 13 + 15 LDS reads per 8 samples,
 //                  no re-summation.  HBM-bound: 8 B read + 4 B (ac) [+ 8 B conj when kept] written per sample.
-//   k_trig_local   tile = 2048 samples: summary of the tile for the plateau state machine (whole tile above the
-//                  threshold? trailing run: start, maximum, first position of the maximum)
+//                  The same kernel reduces its 1984 ac values to the tile summary of the plateau state machine
+//                  (whole tile above the threshold? trailing run: start, maximum).
 //   k_trig_carry   one workgroup: exclusive scan of the tile summaries = the run that is open at every tile start
 //   k_trig_apply   per sample: "ac > 0.3" and "new maximum of this plateau" (trigger bit 0x02) by a segmented
 //                  max-scan seeded with the carry; every plateau of >= 21 samples is appended to a candidate list
@@ -16,42 +16,74 @@
 #pragma once
 #include "c8p_dev.h"
 
-#define C8P_DET_TILE 2048           // samples per trigger tile (256 threads x 8)
+#define C8P_DET_TILE 1984           // samples per tile (248 blocks of 8: what one k_presiso workgroup writes)
 #define C8P_AC_THR 0.3f             // trigger_impl.cc:77
 #define C8P_SYNC_BUF 240            // sync_impl.h:29
 #define C8P_SYNC_RES 111            // sync_impl.h:30
 
 struct TrigSeg {                    // summary of a stretch of samples for the plateau scan
   int all;                          // every sample above the threshold
-  long long tstart;                 // first sample of the trailing run of above-threshold samples, -1: last sample below
   float tmax;                       // maximum of ac over the trailing run (inside this stretch)
-  long long targ;                   // first position of that maximum
+  long long tstart;                 // first sample of the trailing run of above-threshold samples, -1: last sample below,
+                                    // -2: empty stretch (identity)
 };
 struct TrigCand {                   // a plateau of >= 21 samples: [s, e)
   unsigned long long s, e;
 };
 
-__device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = -2; r.tmax = 0.f; r.targ = -1; return r; }   // empty stretch
-// L then R.  tstart == -2 marks the empty stretch (identity).
-__device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& R)
+__device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = -2; r.tmax = 0.f; return r; }
+__device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& R)   // L then R
 {
   if (R.tstart == -2) return L;
   if (L.tstart == -2) return R;
   TrigSeg o;
   o.all = L.all && R.all;
-  if (!R.all || L.tstart < 0) { o.tstart = R.tstart; o.tmax = R.tmax; o.targ = R.targ; }
-  else {                                            // R entirely above and L ends inside a run: the run continues
-    o.tstart = L.tstart;
-    if (R.tmax > L.tmax) { o.tmax = R.tmax; o.targ = R.targ; } else { o.tmax = L.tmax; o.targ = L.targ; }
-  }
+  if (!R.all || L.tstart < 0) { o.tstart = R.tstart; o.tmax = R.tmax; }
+  else { o.tstart = L.tstart; o.tmax = fmaxf(L.tmax, R.tmax); }   // R entirely above and L ends inside a run: it continues
   return o;
 }
 __device__ __forceinline__ TrigSeg seg_of_sample(float a, long long idx)
 {
   TrigSeg r;
   const bool ab = a > C8P_AC_THR;                   // NaN (0/0 in silence) compares false, as in the reference
-  r.all = ab; r.tstart = ab ? idx : -1; r.tmax = ab ? a : 0.f; r.targ = ab ? idx : -1;
+  r.all = ab; r.tstart = ab ? idx : -1; r.tmax = ab ? a : 0.f;
   return r;
+}
+__device__ __forceinline__ TrigSeg seg_shfl_up(const TrigSeg& v, int d)
+{
+  TrigSeg r;
+  r.all = __shfl_up(v.all, d, 64);
+  r.tmax = __shfl_up(v.tmax, d, 64);
+  const int lo = __shfl_up((int)(unsigned)(unsigned long long)v.tstart, d, 64);
+  const int hi = __shfl_up((int)(unsigned)((unsigned long long)v.tstart >> 32), d, 64);
+  r.tstart = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  return r;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ TrigSeg seg_wave_inclusive(TrigSeg v)
+{
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const TrigSeg u = seg_shfl_up(v, d);
+    if (lane >= d) v = seg_combine(u, v);
+  }
+  return v;
+}
+// exclusive prefix of `mine` over the threads of a workgroup (blockDim.x / 64 waves <= 16); `total` = all of them
+__device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh /*[16]*/, TrigSeg& total)
+{
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const TrigSeg inc = seg_wave_inclusive(mine);
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  TrigSeg pre = seg_identity();
+  total = seg_identity();
+  for (int k = 0; k < nw; k++) { if (k == w) pre = total; total = seg_combine(total, sh[k]); }
+  TrigSeg ex = seg_shfl_up(inc, 1);
+  if (lane == 0) ex = seg_identity();
+  __syncthreads();
+  return seg_combine(pre, ex);
 }
 
 // ------------------------------------------------------------------------------------------------ presiso
@@ -63,8 +95,9 @@ __device__ __forceinline__ TrigSeg seg_of_sample(float a, long long idx)
 #define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
 #define C8P_PRE_RS 264
 __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsigned long long n, float* __restrict__ ac,
-                                                 cf* __restrict__ conj, int keep)
+                                                 cf* __restrict__ conj, int keep, TrigSeg* __restrict__ summ)
 {
+  __shared__ TrigSeg shs[16];
   __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
   __shared__ float sE[9 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
   const int tid = threadIdx.x;
@@ -115,7 +148,19 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsig
       Pv[j] = P;
     }
   }
-  __syncthreads();
+  {                                         // tile summary for the plateau scan: ordered reduction of the 1984 samples
+    TrigSeg mine = seg_identity();
+    if (tid >= C8P_PRE_HALO) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const long long g = base + tid * 8 + j;
+        if ((unsigned long long)g < n) mine = seg_combine(mine, seg_of_sample(acv[j], g));
+      }
+    }
+    TrigSeg total;
+    (void)seg_block_exclusive(mine, shs, total);     // (contains the barriers that also order the LDS reuse below)
+    if (tid == 0) summ[blockIdx.x] = total;
+  }
   if (tid >= C8P_PRE_HALO) {
 #pragma unroll
     for (int j = 0; j < 8; j++) sE[j * C8P_PRE_RS + tid] = acv[j];
@@ -134,78 +179,61 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsig
 }
 
 // ------------------------------------------------------------------------------------------------ trigger scan
-// inclusive Hillis-Steele scan of 256 TrigSeg values in LDS; returns the exclusive prefix of `mine`
-__device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh /*[2][256]*/, TrigSeg& total)
-{
-  const int tid = threadIdx.x;
-  int cur = 0;
-  sh[tid] = mine;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    TrigSeg v = sh[cur * 256 + tid];
-    if (tid >= o) v = seg_combine(sh[cur * 256 + tid - o], v);
-    sh[(cur ^ 1) * 256 + tid] = v;
-    cur ^= 1;
-    __syncthreads();
-  }
-  total = sh[cur * 256 + 255];
-  TrigSeg ex = tid ? sh[cur * 256 + tid - 1] : seg_identity();
-  __syncthreads();
-  return ex;
-}
-
-__device__ __forceinline__ TrigSeg seg_of_thread(const float* __restrict__ ac, unsigned long long n, long long n0, float (&a)[8])
-{
-  TrigSeg s = seg_identity();
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const long long g = n0 + j;
-    a[j] = (unsigned long long)g < n ? ac[g] : 0.f;
-    if ((unsigned long long)g < n) s = seg_combine(s, seg_of_sample(a[j], g));
-  }
-  return s;
-}
-
-__global__ __launch_bounds__(256) void k_trig_local(const float* __restrict__ ac, unsigned long long n, TrigSeg* __restrict__ summ)
-{
-  __shared__ TrigSeg sh[2 * 256];
-  float a[8];
-  const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
-  TrigSeg total;
-  (void)seg_block_exclusive(seg_of_thread(ac, n, n0, a), sh, total);
-  if (threadIdx.x == 0) summ[blockIdx.x] = total;
-}
-
 // one workgroup of 1024 threads: carry[t] = combine(summ[0..t-1])
 __global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__ summ, TrigSeg* __restrict__ carry, int ntile)
 {
-  __shared__ TrigSeg sh[1024];
+  __shared__ TrigSeg sh[16];
   const int tid = threadIdx.x;
   const int per = (ntile + 1023) / 1024;
   const int lo = min(tid * per, ntile), hi = min(lo + per, ntile);
   TrigSeg s = seg_identity();
   for (int t = lo; t < hi; t++) s = seg_combine(s, summ[t]);
-  sh[tid] = s;
-  __syncthreads();
-  if (tid == 0) {                                   // 1024 chunk summaries: a short serial pass
-    TrigSeg run = seg_identity();
-    for (int k = 0; k < 1024; k++) { const TrigSeg v = sh[k]; sh[k] = run; run = seg_combine(run, v); }
-  }
-  __syncthreads();
-  s = sh[tid];
+  TrigSeg total;
+  s = seg_block_exclusive(s, sh, total);
   for (int t = lo; t < hi; t++) { carry[t] = s; s = seg_combine(s, summ[t]); }
 }
 
+// tile = the 1984 samples one k_presiso workgroup wrote; thread = 8 consecutive samples (threads 248..255 idle)
 __global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac, unsigned long long n, const TrigSeg* __restrict__ carry,
                                                     uint8_t* __restrict__ trig, TrigCand* __restrict__ cand,
                                                     unsigned int* __restrict__ n_cand, unsigned int cap)
 {
-  __shared__ TrigSeg sh[2 * 256];
+  __shared__ TrigSeg sh[16];
   float a[8];
+  const bool live = threadIdx.x < C8P_DET_TILE / 8;
   const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
+  TrigSeg mine = seg_identity();
+  if (live) {
+    if ((unsigned long long)(n0 + 7) < n) {            // n0 * 4 bytes is 32-byte aligned
+      const float4 v0 = *(const float4*)(ac + n0), v1 = *(const float4*)(ac + n0 + 4);
+      a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) a[j] = (unsigned long long)(n0 + j) < n ? ac[n0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((unsigned long long)(n0 + j) < n) mine = seg_combine(mine, seg_of_sample(a[j], n0 + j));
+  }
+  const TrigSeg cin = carry[blockIdx.x];
+  {
+    // idle air: nothing in the tile is above the threshold and no plateau is open at its start -> all bytes 0, no scan
+    bool anyab = false;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) anyab = anyab || (a[j] > C8P_AC_THR);    // a[j] = 0 past the end of the stream
+    }
+    if (!__syncthreads_or(anyab) && cin.tstart < 0) {
+      if (live) {
+        if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = 0ull;
+        else for (int j = 0; j < 8 && (unsigned long long)(n0 + j) < n; j++) trig[n0 + j] = 0;
+      }
+      return;
+    }
+  }
   TrigSeg total;
-  TrigSeg ex = seg_block_exclusive(seg_of_thread(ac, n, n0, a), sh, total);
-  TrigSeg st = seg_combine(carry[blockIdx.x], ex);   // everything before this thread's first sample
+  const TrigSeg ex = seg_block_exclusive(mine, sh, total);
+  if (!live) return;
+  const TrigSeg st = seg_combine(cin, ex);                 // everything before this thread's first sample
   // walk the 8 samples with the plateau state: run start and running maximum
   long long rs = (st.tstart >= 0) ? st.tstart : -1;
   float rmax = (st.tstart >= 0) ? st.tmax : 0.f;
@@ -291,39 +319,42 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
                                                  int* __restrict__ valid, int nj)
 {
   __shared__ cf sig[C8P_SYNC_BUF];
-  __shared__ float tac[C8P_SYNC_RES], tpw[C8P_SYNC_RES];
+  __shared__ float pw[C8P_SYNC_BUF];                 // |sig[i]| * |sig[i]| as the reference forms it (hypotf squared)
+  __shared__ cf xc[C8P_SYNC_BUF - 64];               // sig[i] * conj(sig[i + 64])
+  __shared__ cf rms[C8P_SYNC_RES];                   // the three running sums before each update
+  __shared__ float rs1[C8P_SYNC_RES], rs2[C8P_SYNC_RES];
+  __shared__ float tac[C8P_SYNC_RES];
   __shared__ cf rot128[128];
   const int k = blockIdx.x;
   if (k >= nj) return;
   const int lane = lane_id();
   const SyncJob J = job[k];
-  for (int i = lane; i < C8P_SYNC_BUF; i += 64) sig[i] = x[J.t + i];
+  for (int i = lane; i < C8P_SYNC_BUF; i += 64) { const cf v = x[J.t + i]; sig[i] = v; pw[i] = habs(v) * habs(v); }
   // d_conjMultiAvg: the last latch the IDLE state saw — this trigger's mark, or the one an earlier trigger left behind
   cf cavg = mk(0.f, 0.f);
   for (int kk = k; kk >= 0; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
   __syncthreads();
-  int ok = 0, mIndex = 0, mx = 0;
+  for (int i = lane; i < C8P_SYNC_BUF - 64; i += 64) xc[i] = cmul(sig[i], cconj(sig[i + 64]));
+  __syncthreads();
   if (lane == 0) {
-    // ltf_autoCorrelation sync_impl.cc:150-175, same running sums in the same order
+    // ltf_autoCorrelation sync_impl.cc:150-175: the reference's running sums, updated in the reference's order; only
+    // these additions are sequential, the terms above and the quotients below are computed by all lanes
     cf ms = mk(0.f, 0.f);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < 64; i++) {
-      ms = cadd(ms, cmul(sig[i], cconj(sig[i + 64])));
-      s1 += habs(sig[i]) * habs(sig[i]);
-      s2 += habs(sig[i + 64]) * habs(sig[i + 64]);
-    }
+    for (int i = 0; i < 64; i++) { ms = cadd(ms, xc[i]); s1 += pw[i]; s2 += pw[i + 64]; }
     for (int i = 0; i < C8P_SYNC_RES; i++) {
-      tac[i] = habs(ms) / sqrtf(s1) / sqrtf(s2);
-      tpw[i] = s1;
-      ms = csub(ms, cmul(sig[i], cconj(sig[i + 64])));
-      s1 -= habs(sig[i]) * habs(sig[i]);
-      s2 -= habs(sig[i + 64]) * habs(sig[i + 64]);
-      ms = cadd(ms, cmul(sig[i + 64], cconj(sig[i + 128])));
-      s1 += habs(sig[i + 64]) * habs(sig[i + 64]);
-      s2 += habs(sig[i + 128]) * habs(sig[i + 128]);
+      rms[i] = ms; rs1[i] = s1; rs2[i] = s2;
+      ms = csub(ms, xc[i]); s1 -= pw[i]; s2 -= pw[i + 64];
+      ms = cadd(ms, xc[i + 64]); s1 += pw[i + 64]; s2 += pw[i + 128];
     }
-    for (int j = 1; j < C8P_SYNC_RES; j++) if (tac[j] > tac[mx]) mx = j;
-    if ((double)tac[mx] > 0.5) {                                      // sync_impl.cc:93
+  }
+  __syncthreads();
+  for (int i = lane; i < C8P_SYNC_RES; i += 64) tac[i] = habs(rms[i]) / sqrtf(rs1[i]) / sqrtf(rs2[i]);
+  __syncthreads();
+  int ok = 0, mIndex = 0, mx = 0;
+  if (lane == 0) {
+    for (int j = 1; j < C8P_SYNC_RES; j++) if (tac[j] > tac[mx]) mx = j;     // std::max_element: first maximum
+    if ((double)tac[mx] > 0.5) {                                             // sync_impl.cc:93
       const float thr = (float)((double)tac[mx] * 0.8);
       int l = mx, r = mx;
       for (int j = mx; j >= 0; j--) if (tac[j] < thr) { l = j; break; }
@@ -338,9 +369,11 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
   const float stf = atan2f(cavg.y, cavg.x) / 16.0f;
   for (int i = lane; i < 128; i += 64) rot128[i] = cmul(sig[mIndex + i], mk(cosf(i * stf), sinf(i * stf)));
   __syncthreads();
+  if (lane < 64) xc[lane] = cmul(rot128[lane], cconj(rot128[lane + 64]));
+  __syncthreads();
   if (lane == 0) {
     cf sum = mk(0.f, 0.f);
-    for (int i = 0; i < 64; i++) sum = cadd(sum, cmul(rot128[i], cconj(rot128[i + 64])));
+    for (int i = 0; i < 64; i++) sum = cadd(sum, xc[i]);
     const cf q = cdivf(sum, 64.0f);
     const float ltf = atan2f(q.y, q.x) / 64.0f;
     const double d = (double)tac[mx];
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
     e.index = J.t + (unsigned long long)mIndex;
     e.rad = stf + ltf;
     e.snr = (float)(10.0 * log10(d / (1.0 - d)));
-    e.rssi = tpw[mx] / 64.0f;
+    e.rssi = rs1[mx] / 64.0f;
     e.trig = (uint32_t)J.t;
     evt[k] = e;
     valid[k] = 1;

@@ -632,11 +632,10 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     KTimer kt(c, C8P_K_PRESISO);
     const uint64_t nblk = (n + 7) / 8;
     hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
-                       d_raw, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep);
+                       d_raw, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p);
   }
   {
     KTimer kt(c, C8P_K_TRIGGER);
-    hipLaunchKernelGGL(k_trig_local, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n, (TrigSeg*)S.d_det_summ.p);
     hipLaunchKernelGGL(k_trig_carry, dim3(1), dim3(1024), 0, S.stream, (const TrigSeg*)S.d_det_summ.p, (TrigSeg*)S.d_det_carry.p, ntile);
     hipLaunchKernelGGL(k_trig_apply, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n,
                        (const TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
