@@ -1,4 +1,4 @@
-"""ctypes driver of libc8p_blocks.so — the C++ mirror of gr::ieee80211::demod / demod2 / decode.
+"""ctypes driver of libc8p_blocks.so — the C++ mirror of gr::ieee80211::demod / demod2 / decode / signal / signal2.
 
 Feeds tagged item streams through general_work() in scheduler-sized chunks and collects the output stream,
 its tags, and the published PDUs.  Plumbing for tests and examples; a GNU Radio install uses the C++ classes
@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libc8p_blocks.so")
 ENGINE_LIB = os.path.join(_HERE, "libc8p_rx.so")
 _LIB = None
 
-DEMOD, DEMOD2, DECODE = 0, 1, 2
+DEMOD, DEMOD2, DECODE, SIGNAL, SIGNAL2 = 0, 1, 2, 3, 4
 
 
 def lib():
@@ -38,6 +38,7 @@ def lib():
             getattr(L, f).restype = C.c_long
             getattr(L, f).argtypes = [C.c_void_p]
         L.c8ph_out_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.c8ph_out1_copy.argtypes = [C.c_void_p, C.c_void_p]
         L.c8ph_tag_get.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_uint64), C.c_char_p, C.c_int, C.POINTER(C.c_long),
                                    C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.c8ph_tag_vec.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
@@ -84,12 +85,13 @@ class Block:
             raise RuntimeError(self.L.c8ph_error(self.h).decode())
         return n
 
-    def output(self):
+    def output(self, port=0):
+        """the block's output stream: float LLRs (demod), complex items (signal / signal2, port 0 or 1)"""
         n = self.L.c8ph_out_count(self.h)
         out = np.zeros(n, np.float32)
         if n:
-            self.L.c8ph_out_copy(self.h, out.ctypes.data)
-        return out
+            (self.L.c8ph_out1_copy if port == 1 else self.L.c8ph_out_copy)(self.h, out.ctypes.data)
+        return out.view(np.complex64) if self.kind in (SIGNAL, SIGNAL2) else out
 
     def tags(self):
         res = []
@@ -124,6 +126,19 @@ class Block:
             self.L.c8ph_dbg_get(self.h, i, buf, 1024)
             res.append(buf.value.decode())
         return res
+
+
+def feed_signal(blk, sync_events, raws):
+    """sync byte stream (port 0, flags tagged rad / snr / rssi as sync_impl.cc:124-141 does) + raw antenna streams"""
+    n = len(raws[0])
+    sync = np.zeros(n, np.uint8)
+    for e in sync_events:
+        i = int(e["index"])
+        sync[i] = 1
+        blk.push_tag(i, "rad", float(e["rad"])); blk.push_tag(i, "snr", float(e["snr"])); blk.push_tag(i, "rssi", float(e["rssi"]))
+    blk.push_items(0, sync)
+    for a, x in enumerate(raws):
+        blk.push_items(1 + a, np.ascontiguousarray(x, np.complex64))
 
 
 def feed_demod(blk, pk, iq, chan):

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64) void k_signal(const c8p_sig_in* __restrict__ ev
     }
     ok = b[3] && !b[4] && !((par & 1) ^ b[17]) && !(len > 4095 || len < 14);
     nsamp = ((len * 8 + 22 + ndbps - 1) / ndbps) * 80;
-    if (ok && (uint32_t)(224 + nsamp) > E.n_avail) ok = 0;            // the stream would have to wait for more items
+    if (ok && (uint32_t)(224 + nsamp) > E.n_avail) {                  // the stream would have to wait for more items
+      ok = 0;
+      P.lsig_mcs = mcs; P.lsig_len = len; P.lsig_nsamp = nsamp; P.rsv[0] = C8P_SIG_NEED_MORE;
+    }
   }
   chan_out[(size_t)e * 64 + lane] = h;
   if (ok) {

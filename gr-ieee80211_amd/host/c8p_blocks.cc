@@ -35,6 +35,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.last_error = (const char* (*)(const c8p_ctx*))sym("c8p_last_error");
   a.demod = (int (*)(c8p_ctx*, const c8p_batch_in*))sym("c8p_demod");
   a.decode = (int (*)(c8p_ctx*, const c8p_decode_in*))sym("c8p_decode");
+  a.signal = (int (*)(c8p_ctx*, const c8p_signal_in*))sym("c8p_signal");
   a.sync = (int (*)(c8p_ctx*))sym("c8p_sync");
   a.buffer = (const void* (*)(c8p_ctx*, int, uint64_t*))sym("c8p_buffer");
   a.fetch = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch");
@@ -231,6 +232,165 @@ demod2::sptr demod2::make(const c8p_api& api, const batching_cfg& cfg)
 {
   return std::shared_ptr<demod2>(new demod_front(2, 0, 0, api, cfg));
 }
+
+// ================================================================================================ signal / signal2
+// Streaming front of c8p_signal().  The reference block walks S_TRIGGER -> S_DEMOD -> S_COPY -> S_PAD per packet
+// (signal_impl.cc:76-201); which sync flags it honours depends on the L-SIG of the previous ones (flags inside a
+// packet that is being copied are never looked at; a failed L-SIG check skips 80 items).  This front buffers the raw
+// stream, hands every pending flag to the engine in one batch, and then applies that scan rule to the results in order.
+class signal_front : public signal, public signal2
+{
+public:
+  signal_front(int nant, const c8p_api& api, const batching_cfg& cfg) : d_eng(api, cfg), d_nant(nant), d_raw(nant) {}
+
+  void forecast(int noutput_items, gr_vector_int& req) override   // signal_impl.cc:57-62
+  {
+    for (auto& r : req) r = noutput_items;
+  }
+
+  int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                   gr_vector_void_star& output_items) override
+  {
+    int nproc = ninput_items[0];
+    for (int p = 1; p <= d_nant; p++) nproc = std::min(nproc, ninput_items[p]);
+    const uint8_t* sync = static_cast<const uint8_t*>(input_items[0]);
+    const uint64_t rd = d_io->nitems_read(0);
+    for (int i = 0; i < nproc; i++) {
+      if (!sync[i]) continue;
+      std::vector<tag_t> tags;
+      d_io->get_tags_in_range(tags, 0, rd + i, rd + i + 1);
+      if (tags.empty()) continue;                      // "input sync with no tag": the reference skips the item
+      evt e;
+      e.idx = rd + i; e.rad = tag_float(tags, "rad", 0.f); e.snr = tag_float(tags, "snr", 0.f); e.rssi = tag_float(tags, "rssi", 0.f);
+      d_evts.push_back(e);
+    }
+    for (int a = 0; a < d_nant; a++) {
+      const gr_complex* x = static_cast<const gr_complex*>(input_items[1 + a]);
+      d_raw[a].insert(d_raw[a].end(), x, x + nproc);
+    }
+    d_io->consume_each(nproc);
+    const bool dry = nproc == 0;
+    if (!d_evts.empty() && avail_end() != d_last_end &&
+        ((int)d_evts.size() >= d_eng.d_cfg.max_batch || (d_eng.d_cfg.flush_when_idle && dry))) {
+      d_last_end = avail_end();                      // nothing new to learn until more items arrive
+      process();
+    }
+    trim();
+    return drain(output_items, noutput_items);
+  }
+
+  void flush() override { if (!d_evts.empty()) process(); trim(); }
+
+private:
+  struct evt { uint64_t idx; float rad, snr, rssi; };
+  struct out_pkt {
+    std::vector<std::pair<std::string, tag_value>> tags;
+    std::vector<gr_complex> items[2];
+    size_t sent = 0;
+  };
+
+  uint64_t avail_end() const { return d_base + d_raw[0].size(); }
+
+  void process()
+  {
+    // every pending flag with at least 224 items behind it, against the items buffered so far
+    std::vector<c8p_sig_in> in;
+    std::vector<size_t> which;
+    std::vector<gr_complex> arena;
+    const uint64_t end = avail_end();
+    for (int a = 0; a < d_nant; a++) arena.insert(arena.end(), d_raw[a].begin(), d_raw[a].end());
+    const uint64_t per = d_raw[0].size();
+    for (size_t k = 0; k < d_evts.size(); k++) {
+      const evt& e = d_evts[k];
+      if (e.idx < d_scan || e.idx < d_base || e.idx + 224 > end) continue;
+      c8p_sig_in s;
+      memset(&s, 0, sizeof(s));
+      s.raw_off[0] = e.idx - d_base; s.raw_off[1] = d_nant == 2 ? per + (e.idx - d_base) : 0;
+      s.n_avail = (uint32_t)std::min<uint64_t>(end - e.idx, 0xffffffffull);
+      s.cfo_rad = e.rad; s.snr = e.snr; s.rssi = e.rssi; s.n_ant = (uint8_t)d_nant;
+      in.push_back(s); which.push_back(k);
+    }
+    std::vector<c8p_pkt_in> pk;
+    std::vector<gr_complex> iq, chan;
+    if (!in.empty()) {
+      c8p_signal_in b;
+      memset(&b, 0, sizeof(b));
+      b.n_evt = (int32_t)in.size(); b.mem = C8P_MEM_HOST; b.evts = in.data();
+      b.raw = reinterpret_cast<const c8p_c32*>(arena.data()); b.n_raw = arena.size();
+      d_eng.check(d_eng.d_api.signal(d_eng.d_ctx, &b));
+      d_eng.check(d_eng.d_api.sync(d_eng.d_ctx));
+      pk = d_eng.fetch_all<c8p_pkt_in>(C8P_BUF_SIG_PKT);
+      iq = d_eng.fetch_all<gr_complex>(C8P_BUF_SIG_IQ);
+      chan = d_eng.fetch_all<gr_complex>(C8P_BUF_SIG_CHAN);
+    }
+    // signal_impl's scan, in stream order
+    size_t done = 0, r = 0;
+    for (size_t k = 0; k < d_evts.size(); k++, done = k) {
+      const evt& e = d_evts[k];
+      const bool submitted = r < which.size() && which[r] == k;
+      const size_t ri = r;
+      if (submitted) r++;
+      if (e.idx < d_scan || e.idx < d_base) continue;                     // inside a packet already copied: never seen
+      if (!submitted) { done = k; break; }                               // not enough items yet: S_DEMOD waits here
+      const c8p_pkt_in& p = pk[ri];
+      if (p.n_items == 0) {
+        if (p.rsv[0] == C8P_SIG_NEED_MORE) { done = k; break; }          // S_COPY would wait for the rest of the packet
+        d_scan = e.idx + 80;                                              // signal_impl.cc:157-160
+        continue;
+      }
+      out_pkt o;
+      if (++d_seq >= 1000000000) d_seq = 0;                               // signal_impl.cc:133-134
+      o.tags.push_back({"cfo", tag_value::from_float(p.cfo)});
+      o.tags.push_back({"snr", tag_value::from_float(p.snr)});
+      o.tags.push_back({"rssi", tag_value::from_float(p.rssi)});
+      o.tags.push_back({"seq", tag_value::from_long(d_seq)});
+      o.tags.push_back({"mcs", tag_value::from_long(p.lsig_mcs)});
+      o.tags.push_back({"len", tag_value::from_long(p.lsig_len)});
+      o.tags.push_back({"nsamp", tag_value::from_long(p.lsig_nsamp)});
+      o.tags.push_back({"chan", tag_value::from_c32vector(std::vector<gr_complex>(chan.begin() + 64 * ri, chan.begin() + 64 * ri + 64))});
+      for (int a = 0; a < d_nant; a++) o.items[a].assign(iq.begin() + p.iq_off[a], iq.begin() + p.iq_off[a] + p.n_items);
+      d_outq.push_back(std::move(o));
+      d_scan = e.idx + 224 + (uint64_t)p.lsig_nsamp;                      // S_COPY consumed the packet
+    }
+    d_evts.erase(d_evts.begin(), d_evts.begin() + (std::ptrdiff_t)done);
+  }
+
+  void trim()   // raw items before the oldest pending flag are no longer needed (later flags only point forward)
+  {
+    const uint64_t keep_from = d_evts.empty() ? avail_end() : std::max(d_base, std::min(d_evts.front().idx, avail_end()));
+    const size_t drop = (size_t)(keep_from - d_base);
+    if (drop) { for (int a = 0; a < d_nant; a++) d_raw[a].erase(d_raw[a].begin(), d_raw[a].begin() + (std::ptrdiff_t)drop); d_base += drop; }
+  }
+
+  int drain(gr_vector_void_star& output_items, int noutput_items)
+  {
+    int produced = 0;
+    while (!d_outq.empty() && produced < noutput_items) {
+      out_pkt& o = d_outq.front();
+      if (o.sent == 0)
+        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
+      const size_t k = std::min(o.items[0].size() - o.sent, (size_t)(noutput_items - produced));
+      for (int a = 0; a < d_nant; a++)
+        memcpy(static_cast<gr_complex*>(output_items[a]) + produced, o.items[a].data() + o.sent, sizeof(gr_complex) * k);
+      o.sent += k; produced += (int)k;
+      if (o.sent == o.items[0].size()) d_outq.pop_front();
+    }
+    return produced;
+  }
+
+  engine_holder d_eng;
+  int d_nant;
+  std::vector<std::vector<gr_complex>> d_raw;    // buffered raw items per antenna, d_raw[a][0] = stream item d_base
+  uint64_t d_base = 0, d_scan = 0, d_last_end = ~0ull;   // d_scan: where S_TRIGGER resumes looking at sync flags
+  std::vector<evt> d_evts;                       // pending flags, in stream order
+  long d_seq = 0;
+  std::deque<out_pkt> d_outq;
+};
+
+signal::sptr signal::make() { return make(default_api(), batching_cfg()); }
+signal::sptr signal::make(const c8p_api& api, const batching_cfg& cfg) { return std::shared_ptr<signal>(new signal_front(1, api, cfg)); }
+signal2::sptr signal2::make() { return make(default_api(), batching_cfg()); }
+signal2::sptr signal2::make(const c8p_api& api, const batching_cfg& cfg) { return std::shared_ptr<signal2>(new signal_front(2, api, cfg)); }
 
 // ================================================================================================ decode
 class decode_front : public decode

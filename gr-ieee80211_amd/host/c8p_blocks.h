@@ -3,6 +3,7 @@
 //   gr::ieee80211::demod::make(int mupos, int mugid)   include/gnuradio/ieee80211/demod.h:35
 //   gr::ieee80211::demod2::make()                       include/gnuradio/ieee80211/demod2.h
 //   gr::ieee80211::decode::make(bool ifdebug)           include/gnuradio/ieee80211/decode.h
+//   gr::ieee80211::signal::make() / signal2::make()     include/gnuradio/ieee80211/signal.h, signal2.h   (§8f-1)
 //
 // Same factories, same general_work()/forecast() contract, same stream-tag keys and PDU layout as
 // lib/{demod,demod2,decode}_impl.cc, but every block is a *batching front* for the C ABI of include/c8p_rx.h:
@@ -73,6 +74,7 @@ struct c8p_api {
   const char* (*last_error)(const c8p_ctx*);
   int (*demod)(c8p_ctx*, const c8p_batch_in*);
   int (*decode)(c8p_ctx*, const c8p_decode_in*);
+  int (*signal)(c8p_ctx*, const c8p_signal_in*);
   int (*sync)(c8p_ctx*);
   const void* (*buffer)(c8p_ctx*, int, uint64_t*);
   int (*fetch)(c8p_ctx*, int, void*, uint64_t, uint64_t);
@@ -112,6 +114,24 @@ class demod2 : virtual public c8p_block
 {
 public:
   typedef std::shared_ptr<demod2> sptr;
+  static sptr make();
+  static sptr make(const c8p_api& api, const batching_cfg& cfg);
+};
+// gr::ieee80211::signal::make() / signal2::make()   include/gnuradio/ieee80211/signal.h, signal2.h
+// in: port 0 = sync bytes (flag items carry the tags "rad", "snr", "rssi"), ports 1.. = raw samples per antenna;
+// out: the CFO-corrected packet items per antenna, tags cfo/snr/rssi/seq/mcs/len/nsamp/chan on the first one
+// (lib/signal_impl.cc:68-204).  SURVEY.md §8f-1.
+class signal : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<signal> sptr;
+  static sptr make();
+  static sptr make(const c8p_api& api, const batching_cfg& cfg);
+};
+class signal2 : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<signal2> sptr;
   static sptr make();
   static sptr make(const c8p_api& api, const batching_cfg& cfg);
 };

@@ -13,13 +13,17 @@ namespace {
 
 struct harness : public block_io {
   std::shared_ptr<c8p_block> blk;
-  int nports = 1;
-  size_t item_size = sizeof(gr_complex);
+  int nports = 1, nout = 1;
+  size_t item_size = sizeof(gr_complex);        // items of the stream ports
+  size_t port0_size = 0;                        // != 0: port 0 carries items of another size (signal: sync bytes)
+  size_t out_size = sizeof(float);
+  size_t isz(int q) const { return (q == 0 && port0_size) ? port0_size : item_size; }
   std::vector<std::vector<uint8_t>> in;         // per port, remaining bytes from read position
   std::vector<tag_t> in_tags;                   // port 0, absolute offsets
   uint64_t n_read = 0, n_written = 0;
   int consumed_this_call = 0;
-  std::vector<float> out_items;
+  std::vector<float> out_items;                 // output port 0 (as floats: a complex item is two of them)
+  std::vector<float> out_items1;                // output port 1 (signal2)
   std::vector<tag_t> out_tags;
   std::vector<pdu_t> msgs;
   std::vector<std::string> dbg;
@@ -53,7 +57,9 @@ void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_bat
     batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
     if (kind == 0) { h->blk = demod::make(mupos, 0, api, cfg); h->nports = 1; }
     else if (kind == 1) { h->blk = demod2::make(api, cfg); h->nports = 2; }
-    else { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
+    else if (kind == 2) { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
+    else if (kind == 3) { h->blk = signal::make(api, cfg); h->nports = 2; h->port0_size = 1; h->out_size = sizeof(gr_complex); }
+    else { h->blk = signal2::make(api, cfg); h->nports = 3; h->port0_size = 1; h->out_size = sizeof(gr_complex); h->nout = 2; }
     h->in.resize(h->nports);
     h->blk->set_io(h);
     return h;
@@ -68,7 +74,7 @@ void c8ph_push_items(void* p, int port, const void* data, long n_items)
 {
   harness* h = static_cast<harness*>(p);
   const uint8_t* b = static_cast<const uint8_t*>(data);
-  h->in[port].insert(h->in[port].end(), b, b + (size_t)n_items * h->item_size);
+  h->in[port].insert(h->in[port].end(), b, b + (size_t)n_items * h->isz(port));
 }
 void c8ph_push_tag_long(void* p, uint64_t off, const char* key, long v)
 {
@@ -93,22 +99,25 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
   try {
     long calls = 0;
     int idle = 0;
-    std::vector<float> obuf((size_t)std::max(nout, 1));
+    const size_t fpi = h->out_size / sizeof(float);                 // floats per output item
+    std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
     while (idle < 4) {
-      size_t avail = h->in[0].size() / h->item_size;
-      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->in[q].size() / h->item_size);
+      size_t avail = h->in[0].size() / h->isz(0);
+      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->in[q].size() / h->isz(q));
       const int n = (int)std::min<size_t>(avail, (size_t)chunk);
       gr_vector_int nin(h->nports, n);
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->in[q].data();
       gr_vector_void_star outs(1, obuf.data());
+      if (h->nout == 2) outs.push_back(obuf1.data());
       h->consumed_this_call = 0;
       const int produced = h->blk->general_work(nout, nin, ins, outs);
       calls++;
       for (int q = 0; q < h->nports; q++)
-        h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->item_size);
+        h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->isz(q));
       h->n_read += h->consumed_this_call;
-      h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + produced);
+      h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
+      if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
       h->n_written += produced;
       idle = (produced == 0 && h->consumed_this_call == 0) ? idle + 1 : 0;
       if (idle == 2 && flush_at_end && avail == 0) h->blk->flush();
@@ -121,8 +130,9 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 }
 const char* c8ph_error(void* p) { return static_cast<harness*>(p)->err.c_str(); }
 
-long c8ph_out_count(void* p) { return (long)static_cast<harness*>(p)->out_items.size(); }
+long c8ph_out_count(void* p) { return (long)static_cast<harness*>(p)->out_items.size(); }     // in floats
 void c8ph_out_copy(void* p, float* dst) { harness* h = static_cast<harness*>(p); memcpy(dst, h->out_items.data(), h->out_items.size() * 4); }
+void c8ph_out1_copy(void* p, float* dst) { harness* h = static_cast<harness*>(p); memcpy(dst, h->out_items1.data(), h->out_items1.size() * 4); }
 long c8ph_tag_count(void* p) { return (long)static_cast<harness*>(p)->out_tags.size(); }
 // kind: 0 long, 1 float, 2 c32vector (vec_n = element count)
 int c8ph_tag_get(void* p, long i, uint64_t* off, char* key, int keycap, long* l, float* f, int* vec_n)

@@ -91,8 +91,10 @@ typedef struct c8p_pkt_in {
   float    rssi;        /* tag "rssi"                                                                  */
   uint8_t  n_ant;       /* 1: demod (1 port), 2: demod2 (2 ports)                                      */
   uint8_t  mupos;       /* demod::make(mupos, mugid): MU-MIMO user position 0/1                        */
-  uint8_t  rsv[2];
+  uint8_t  rsv[2];      /* rsv[0], written by c8p_signal only: C8P_SIG_NEED_MORE = the L-SIG is valid (lsig_* set) but  */
+                        /* fewer than 224 + nsamp items were available: n_items = 0, the block waits (S_COPY)           */
 } c8p_pkt_in;
+#define C8P_SIG_NEED_MORE 1
 
 /*
  * demod -> decode tags (demod_impl.cc:224-253, demod2_impl.cc:230-250) plus the descriptor

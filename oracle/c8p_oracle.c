@@ -563,7 +563,10 @@ int c8po_signal_event(const c8p_sig_in* ev, const cf* raw_arena, c8p_pkt_in* pkt
   int len = 0; for (int i = 0; i < 12; i++) len |= ((int)bits[i + 5]) << i;
   if (len > 4095 || len < 14) return 0;
   const int nsamp = ((len * 8 + 22 + ndbps - 1) / ndbps) * 80;
-  if ((uint32_t)(224 + nsamp) > ev->n_avail) return 0;        /* the stream would have to wait for more items */
+  if ((uint32_t)(224 + nsamp) > ev->n_avail) {                /* the stream would have to wait for more items */
+    pkt->lsig_mcs = mcs; pkt->lsig_len = len; pkt->lsig_nsamp = nsamp; pkt->rsv[0] = C8P_SIG_NEED_MORE;
+    return 0;
+  }
   for (int k = 0; k < nsamp; k++) {                            /* S_COPY signal_impl.cc:164-192 */
     const float th = (float)(k + 224) * ev->cfo_rad;
     out0[k] = rot(in1[224 + k], th);

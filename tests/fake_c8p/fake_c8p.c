@@ -7,13 +7,40 @@
 #include "c8p_oracle.h"
 
 struct c8p_ctx {
+  int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   int n;
   c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu;
 };
 #define PDU_STRIDE 8192
 
 c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); return (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); }
-static void drop(c8p_ctx* c) { free(c->tags); free(c->outs); free(c->llr); free(c->pdu); free(c->mu); memset(c, 0, sizeof(*c)); }
+static void drop(c8p_ctx* c)
+{
+  free(c->tags); free(c->outs); free(c->llr); free(c->pdu); free(c->mu); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
+  memset(c, 0, sizeof(*c));
+}
+
+int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as the engine: per event cap = n_avail-224+320 items per antenna */
+{
+  drop(c);
+  c->n_sig = in->n_evt;
+  c->sig_pkt = (c8p_pkt_in*)calloc((size_t)in->n_evt + 1, sizeof(c8p_pkt_in));
+  c->sig_chan = (c8p_c32*)calloc((size_t)in->n_evt * 64 + 1, sizeof(c8p_c32));
+  uint64_t tot = 0;
+  for (int e = 0; e < in->n_evt; e++) tot += ((in->evts[e].n_avail >= 224u ? in->evts[e].n_avail - 224u : 0u) + 320u) * (uint64_t)in->evts[e].n_ant;
+  c->sig_iq = (c8p_c32*)calloc(tot + 1, sizeof(c8p_c32));
+  c->n_sig_iq = tot;
+  uint64_t off = 0;
+  for (int e = 0; e < in->n_evt; e++) {
+    const c8p_sig_in* ev = &in->evts[e];
+    const uint64_t cap = (ev->n_avail >= 224u ? ev->n_avail - 224u : 0u) + 320u;
+    const int ok = c8po_signal_event(ev, in->raw, &c->sig_pkt[e], c->sig_chan + 64 * e, c->sig_iq + off, c->sig_iq + off + cap);
+    c->sig_pkt[e].iq_off[0] = off; c->sig_pkt[e].iq_off[1] = ev->n_ant == 2 ? off + cap : 0; c->sig_pkt[e].chan_off = 64u * (uint32_t)e;
+    if (!ok) c->sig_pkt[e].n_items = 0;
+    off += cap * ev->n_ant;
+  }
+  return C8P_OK;
+}
 void c8p_destroy(c8p_ctx* c) { if (c) { drop(c); free(c); } }
 const char* c8p_last_error(const c8p_ctx* c) { (void)c; return "fake backend"; }
 
@@ -61,6 +88,9 @@ const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
     case C8P_BUF_OUT: p = c->outs; b = (uint64_t)c->n * sizeof(c8p_pkt_out); break;
     case C8P_BUF_PDU: p = c->pdu; b = c->n_pdu; break;
     case C8P_BUF_MUCHAN: p = c->mu; b = (uint64_t)c->n * 128 * sizeof(c8p_c32); break;
+    case C8P_BUF_SIG_PKT: p = c->sig_pkt; b = (uint64_t)c->n_sig * sizeof(c8p_pkt_in); break;
+    case C8P_BUF_SIG_IQ: p = c->sig_iq; b = c->n_sig_iq * sizeof(c8p_c32); break;
+    case C8P_BUF_SIG_CHAN: p = c->sig_chan; b = (uint64_t)c->n_sig * 64 * sizeof(c8p_c32); break;
     default: break;
   }
   if (!p) b = 0;

@@ -103,3 +103,121 @@ def test_block_mirror_on_gpu(n_ant):
     pk, iq, chan = split(b, n_ant)
     res = chain(None, pk, iq, chan, n_ant, 1000, 4096, 16)
     assert check_against_oracle(res, pk, iq, chan) >= 10
+
+
+# ---------------------------------------------------------------------------------------------- signal / signal2 mirror
+def _signal_case(n_ant, seed=9):
+    """raw stream(s) + the sync block's flagged items (oracle detection on antenna 0), plus two flags the reference
+    would treat specially: one inside a packet that is being copied (never seen) and one on noise (L-SIG check fails,
+    80 items skipped)."""
+    from c8p_cases import dewindow
+    from c8p_testlib import H22, load_npz, oracle, through_channel
+    sw = load_npz("packets_sweep.npz")
+    names = ["L_0", "HT_3", "VHT_2", "L_5", "VHT_8"] if n_ant == 1 else ["HT2_12", "VHT2_5", "HT2_9"]
+    rng = np.random.default_rng(seed)
+    parts, exp = [], []
+    for k, name in enumerate(names):
+        d = sw[name]
+        rx = through_channel(dewindow(d["tx"]), H22 if n_ant == 2 else None, 27.0, rng, lead=int(rng.integers(500, 1200)))
+        w = 2 * np.pi * (30e3 * (k - 2)) / 20e6
+        parts.append((rx * np.exp(1j * w * np.arange(rx.shape[1]))).astype(np.complex64))
+        exp.append(d)
+    raw = np.concatenate(parts, axis=1)
+    o = oracle()
+    ev, _, _, _ = o.detect(raw[0])
+    extra = np.zeros(2, abi.SYNC_EVT_DT)
+    extra[0]["index"] = int(ev[1]["index"]) + 700          # inside the second packet's copy region
+    extra[1]["index"] = int(ev[2]["index"]) - 450          # idle air before the third packet
+    extra["snr"], extra["rssi"] = 10.0, 0.5
+    ev = np.sort(np.concatenate([ev, extra]), order="index")
+    return raw, ev, exp
+
+
+def _expected_signal_output(raw, ev, n_ant):
+    from c8p_testlib import oracle
+    from test_detect_frontend import consume_filter
+    o = oracle()
+    s = np.zeros(len(ev), abi.SIG_IN_DT)
+    n = raw.shape[1]
+    arena = np.concatenate([raw[a] for a in range(n_ant)])
+    for i, e in enumerate(ev):
+        s[i]["raw_off"][0] = int(e["index"]); s[i]["raw_off"][1] = n + int(e["index"]) if n_ant == 2 else 0
+        s[i]["n_avail"] = n - int(e["index"])
+        s[i]["cfo_rad"], s[i]["snr"], s[i]["rssi"], s[i]["n_ant"] = e["rad"], e["snr"], e["rssi"], n_ant
+    pk, iq, chan = o.signal_events(s, arena)
+    keep = consume_filter(ev, pk)
+    return pk, iq, chan, keep
+
+
+def _run_signal(engine_lib, raw, ev, n_ant, chunk, nout, max_batch):
+    sig = blocks.Block(blocks.SIGNAL if n_ant == 1 else blocks.SIGNAL2, engine_lib=engine_lib, max_batch=max_batch)
+    blocks.feed_signal(sig, ev, [raw[a] for a in range(n_ant)])
+    sig.run(chunk=chunk, nout=nout)
+    outs = [sig.output(a) for a in range(n_ant)]
+    tags = sig.tags()
+    sig.close()
+    return outs, tags
+
+
+def _check_signal(outs, tags, raw, ev, n_ant, tol):
+    pk, iq, chan, keep = _expected_signal_output(raw, ev, n_ant)
+    assert len(keep) >= 3
+    pos = 0
+    by_off = {}
+    for off, key, val in tags:
+        by_off.setdefault(off, {})[key] = val
+    starts = []
+    for seq, i in enumerate(keep, 1):
+        p = pk[i]
+        n = int(p["n_items"])
+        starts.append(pos)
+        d = by_off[pos]
+        assert d["seq"] == seq and d["mcs"] == int(p["lsig_mcs"]) and d["len"] == int(p["lsig_len"]) and d["nsamp"] == int(p["lsig_nsamp"])
+        assert abs(d["cfo"] - float(p["cfo"])) <= 1e-3 * max(1.0, abs(float(p["cfo"]))) and d["snr"] == float(p["snr"])
+        c = chan[64 * i:64 * i + 64]
+        assert np.max(np.abs(d["chan"] - c)) <= tol * max(np.max(np.abs(c)), 1e-9)
+        for a in range(n_ant):
+            want = iq[int(p["iq_off"][a]):int(p["iq_off"][a]) + n]
+            got = outs[a][pos:pos + n]
+            assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(want)), (i, a)
+        pos += n
+    assert sorted(by_off) == starts
+    assert all(len(o) == pos for o in outs)
+    return pk[keep]
+
+
+@pytest.mark.parametrize("n_ant", [1, 2])
+@pytest.mark.parametrize("chunk,nout,max_batch", [(4096, 8192, 256), (1000, 777, 2), (160, 300, 1)])
+def test_signal_mirror_with_fake_backend(n_ant, chunk, nout, max_batch):
+    raw, ev, exp = _signal_case(n_ant)
+    outs, tags = _run_signal(FAKE, raw, ev, n_ant, chunk, nout, max_batch)
+    _check_signal(outs, tags, raw, ev, n_ant, 0.0)
+
+
+def test_block_chain_raw_stream_to_pdus_with_fake_backend():
+    """signal -> demod -> decode, the rx.grc chain downstream of the sync block, on the block mirrors"""
+    raw, ev, exp = _signal_case(1)
+    sig = blocks.Block(blocks.SIGNAL, engine_lib=FAKE, max_batch=3)
+    blocks.feed_signal(sig, ev, [raw[0]])
+    sig.run(chunk=2000, nout=3000)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=2)
+    dem.push_items(0, sig.output(0))
+    for off, key, val in sig.tags():
+        dem.push_tag(off, key, val)
+    dem.run(chunk=1500, nout=4096)
+    dec = blocks.Block(blocks.DECODE, engine_lib=FAKE, max_batch=4)
+    dec.push_items(0, dem.output())
+    for off, key, val in dem.tags():
+        dec.push_tag(off, key, val)
+    dec.run(chunk=3000, nout=100)
+    assert [m[1] for m in dec.messages()] == [d["pdu"].tobytes() for d in exp]
+    for b in (sig, dem, dec):
+        b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ant", [1, 2])
+def test_signal_mirror_on_gpu(n_ant):
+    raw, ev, exp = _signal_case(n_ant, seed=10)
+    outs, tags = _run_signal(None, raw, ev, n_ant, 3000, 4096, 4)
+    _check_signal(outs, tags, raw, ev, n_ant, 2e-6)
