@@ -202,3 +202,32 @@ def test_gpu_trigger_and_sync_on_plateau_torture_streams(seed):
     assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"])
     assert np.allclose(gev["rad"], ev["rad"], rtol=0, atol=5e-6)
     assert (trig & 1).sum() >= 40
+
+
+@pytest.mark.gpu
+def test_gpu_detect_edge_lengths_and_silence():
+    """empty / shorter than one sync window / around the 1984-sample tile / exact zeros (ac = 0/0 = NaN) / a plateau that
+    is still open when the segment ends"""
+    from gr_ieee80211_amd import engine
+    o = oracle()
+    eng = engine.Engine(device=0)
+    rng = np.random.default_rng(8)
+    base, _, _ = stream(NAMES[:2], CFOS[:2], seed=12)
+    per = (rng.normal(size=16) + 1j * rng.normal(size=16)) * 0.2
+    for n in (0, 1, 7, 100, 239, 240, 1983, 1984, 1985, 3968, 3969, len(base)):
+        x = base[:n].copy()
+        if n == 3968:
+            x[1000:3000] = 0                                            # digital silence inside the segment
+        if n == 3969:
+            x[3500:] = np.tile(per, 40)[:n - 3500] + 0.01 * (rng.normal(size=n - 3500) + 1j * rng.normal(size=n - 3500))
+        ev, ac, cj, trig = o.detect(x) if n else (np.zeros(0, abi.SYNC_EVT_DT), np.zeros(0, np.float32), None, np.zeros(0, np.uint8))
+        gev = eng.detect(x if n else np.zeros(1, np.complex64)[:0], keep=True)
+        if n == 0:
+            assert len(gev) == 0
+            continue
+        gtr = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+        gac = eng.fetch(abi.BUF_DET_AC, np.float32)
+        assert np.array_equal(np.isnan(gac), np.isnan(ac)), n
+        assert np.array_equal(gtr & 3, trig), n
+        assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"]), n
+    eng.close()
