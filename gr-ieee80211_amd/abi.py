@@ -18,6 +18,7 @@ K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_PRESISO, K_TRIGG
 K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal", "presiso", "trigger", "syncevt"]
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
+DET_HIST = 80
 NDP_TOTAL = 1024
 NDP_BLOB_BYTES = 1027
 
@@ -68,8 +69,14 @@ class SyncEvt(C.Structure):
     _fields_ = [("index", C.c_uint64), ("rad", C.c_float), ("snr", C.c_float), ("rssi", C.c_float), ("trig", C.c_uint32)]
 
 
+class DetState(C.Structure):
+    _fields_ = [("run_start", C.c_int64), ("prev_start", C.c_int64), ("sync_pos", C.c_int64), ("in_run", C.c_int32),
+                ("run_fired", C.c_int32), ("have_prev", C.c_int32), ("run_max", C.c_float), ("conj_avg", C.c_float * 2)]
+
+
 class DetectIn(C.Structure):
-    _fields_ = [("mem", C.c_int32), ("keep", C.c_int32), ("raw", C.c_void_p), ("n", C.c_uint64)]
+    _fields_ = [("mem", C.c_int32), ("keep", C.c_int32), ("raw", C.c_void_p), ("n", C.c_uint64), ("n_hist", C.c_uint64),
+                ("state", C.c_void_p), ("state_out", C.c_void_p), ("commit", C.c_void_p)]
 
 
 class DecodeIn(C.Structure):

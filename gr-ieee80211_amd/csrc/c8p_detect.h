@@ -24,21 +24,24 @@
 struct TrigSeg {                    // summary of a stretch of samples for the plateau scan
   int all;                          // every sample above the threshold
   float tmax;                       // maximum of ac over the trailing run (inside this stretch)
-  long long tstart;                 // first sample of the trailing run of above-threshold samples, -1: last sample below,
-                                    // -2: empty stretch (identity)
+  long long tstart;                 // first sample of the trailing run of above-threshold samples (negative: it began
+                                    // before the commit point), C8P_SEG_NONE: last sample below, C8P_SEG_IDENT: empty stretch
 };
-struct TrigCand {                   // a plateau of >= 21 samples: [s, e)
-  unsigned long long s, e;
+#define C8P_SEG_NONE  (-0x7fffffffffffffffLL - 1)
+#define C8P_SEG_IDENT (-0x7fffffffffffffffLL)
+__device__ __host__ __forceinline__ bool seg_has_run(const TrigSeg& v) { return v.tstart > C8P_SEG_IDENT; }
+struct TrigCand {                   // a plateau of >= 21 samples: [s, e); s < 0: it began before the commit point
+  long long s, e;
 };
 
-__device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = -2; r.tmax = 0.f; return r; }
+__device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = C8P_SEG_IDENT; r.tmax = 0.f; return r; }
 __device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& R)   // L then R
 {
-  if (R.tstart == -2) return L;
-  if (L.tstart == -2) return R;
+  if (R.tstart == C8P_SEG_IDENT) return L;
+  if (L.tstart == C8P_SEG_IDENT) return R;
   TrigSeg o;
   o.all = L.all && R.all;
-  if (!R.all || L.tstart < 0) { o.tstart = R.tstart; o.tmax = R.tmax; }
+  if (!R.all || !seg_has_run(L)) { o.tstart = R.tstart; o.tmax = R.tmax; }
   else { o.tstart = L.tstart; o.tmax = fmaxf(L.tmax, R.tmax); }   // R entirely above and L ends inside a run: it continues
   return o;
 }
@@ -46,7 +49,7 @@ __device__ __forceinline__ TrigSeg seg_of_sample(float a, long long idx)
 {
   TrigSeg r;
   const bool ab = a > C8P_AC_THR;                   // NaN (0/0 in silence) compares false, as in the reference
-  r.all = ab; r.tstart = ab ? idx : -1; r.tmax = ab ? a : 0.f;
+  r.all = ab; r.tstart = ab ? idx : C8P_SEG_NONE; r.tmax = ab ? a : 0.f;
   return r;
 }
 __device__ __forceinline__ TrigSeg seg_shfl_up(const TrigSeg& v, int d)
@@ -94,7 +97,8 @@ __device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh
 #define C8P_PRE_HALO 8
 #define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
 #define C8P_PRE_RS 264
-__global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsigned long long n, float* __restrict__ ac,
+// x points at the first NEW item; items x[-hist .. -1] exist (history before the commit point), x[g] = 0 for g < -hist
+__global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long long hist, unsigned long long n, float* __restrict__ ac,
                                                  cf* __restrict__ conj, int keep, TrigSeg* __restrict__ summ)
 {
   __shared__ TrigSeg shs[16];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsig
   for (int k = 0; k < 8; k++) {             // coalesced: thread tid loads sample base + tid + 256 k
     const int i = tid + 256 * k;
     const long long g = base + i;
-    sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= 0 && (unsigned long long)g < n) ? x[g] : mk(0.f, 0.f);
+    sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= -hist && g < (long long)n) ? x[g] : mk(0.f, 0.f);
   }
   __syncthreads();
   cf p[8];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsig
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const long long g = base + tid * 8 + j;
-        if ((unsigned long long)g < n) mine = seg_combine(mine, seg_of_sample(acv[j], g));
+        if (g >= 0 && (unsigned long long)g < n) mine = seg_combine(mine, seg_of_sample(acv[j], g));
       }
     }
     TrigSeg total;
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, unsig
 }
 
 // ------------------------------------------------------------------------------------------------ trigger scan
-// one workgroup of 1024 threads: carry[t] = combine(summ[0..t-1])
-__global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__ summ, TrigSeg* __restrict__ carry, int ntile)
+// one workgroup of 1024 threads: carry[t] = combine(init, summ[0..t-1]); carry[ntile] = the state after the last tile
+__global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__ summ, TrigSeg* __restrict__ carry, int ntile, TrigSeg init)
 {
   __shared__ TrigSeg sh[16];
   const int tid = threadIdx.x;
@@ -189,8 +193,9 @@ __global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__
   TrigSeg s = seg_identity();
   for (int t = lo; t < hi; t++) s = seg_combine(s, summ[t]);
   TrigSeg total;
-  s = seg_block_exclusive(s, sh, total);
+  s = seg_combine(init, seg_block_exclusive(s, sh, total));
   for (int t = lo; t < hi; t++) { carry[t] = s; s = seg_combine(s, summ[t]); }
+  if (tid == 0) carry[ntile] = seg_combine(init, total);
 }
 
 // tile = the 1984 samples one k_presiso workgroup wrote; thread = 8 consecutive samples (threads 248..255 idle)
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac
 #pragma unroll
       for (int j = 0; j < 8; j++) anyab = anyab || (a[j] > C8P_AC_THR);    // a[j] = 0 past the end of the stream
     }
-    if (!__syncthreads_or(anyab) && cin.tstart < 0) {
+    if (!__syncthreads_or(anyab) && !seg_has_run(cin)) {
       if (live) {
         if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = 0ull;
         else for (int j = 0; j < 8 && (unsigned long long)(n0 + j) < n; j++) trig[n0 + j] = 0;
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac
   if (!live) return;
   const TrigSeg st = seg_combine(cin, ex);                 // everything before this thread's first sample
   // walk the 8 samples with the plateau state: run start and running maximum
-  long long rs = (st.tstart >= 0) ? st.tstart : -1;
-  float rmax = (st.tstart >= 0) ? st.tmax : 0.f;
+  long long rs = seg_has_run(st) ? st.tstart : C8P_SEG_NONE;
+  float rmax = seg_has_run(st) ? st.tmax : 0.f;
   unsigned long long packed = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -245,19 +250,19 @@ __global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac
     unsigned b = 0;
     if (a[j] > C8P_AC_THR) {
       b = 0x04;
-      if (rs < 0) { rs = g; rmax = 0.f; }
+      if (rs == C8P_SEG_NONE) { rs = g; rmax = 0.f; }
       if (a[j] > rmax) { rmax = a[j]; b |= 0x02; }     // trigger_impl.cc:80-85 (d_conjAc restarts at 0 with every plateau)
     } else {
-      if (rs >= 0 && g - rs >= 21) {                   // a plateau long enough to arm the countdown ended here
+      if (rs != C8P_SEG_NONE && g - rs >= 21) {        // a plateau long enough to arm the countdown ended here
         const unsigned k = atomicAdd(n_cand, 1u);
-        if (k < cap) { cand[k].s = (unsigned long long)rs; cand[k].e = (unsigned long long)g; }
+        if (k < cap) { cand[k].s = rs; cand[k].e = g; }
       }
-      rs = -1; rmax = 0.f;
+      rs = C8P_SEG_NONE; rmax = 0.f;
     }
     packed |= (unsigned long long)b << (8 * j);
-    if ((unsigned long long)g == n - 1 && rs >= 0 && g + 1 - rs >= 21) {   // plateau still open at the end of the stream
+    if ((unsigned long long)g == n - 1 && rs != C8P_SEG_NONE && g + 1 - rs >= 21) {   // plateau still open at the end of the stream
       const unsigned k = atomicAdd(n_cand, 1u);
-      if (k < cap) { cand[k].s = (unsigned long long)rs; cand[k].e = n; }
+      if (k < cap) { cand[k].s = rs; cand[k].e = (long long)n; }
     }
   }
   if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = packed;
@@ -282,7 +287,7 @@ struct SyncMark {
 };
 
 __global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ job, const uint8_t* __restrict__ trig,
-                                                  const cf* __restrict__ x, SyncMark* __restrict__ out, int nj)
+                                                  const cf* __restrict__ x, long long hist, SyncMark* __restrict__ out, int nj)
 {
   const int k = blockIdx.x;
   if (k >= nj) return;
@@ -302,8 +307,8 @@ __global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ jo
     if (lane < 48) {
       const long long g = j - 47 + lane;
       cf a = mk(0.f, 0.f), d = mk(0.f, 0.f);
-      if (g >= 0) a = x[g];
-      if (g >= 16) d = x[g - 16];
+      if (g >= -hist) a = x[g];
+      if (g - 16 >= -hist) d = x[g - 16];
       pr[lane] = mk(d.x * a.x + d.y * a.y, d.y * a.x - d.x * a.y);
     }
     __syncthreads();
@@ -316,7 +321,7 @@ __device__ __forceinline__ float habs(cf a) { return cabs_(a); }    // std::abs(
 
 __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job, const SyncMark* __restrict__ mark,
                                                  const cf* __restrict__ x, c8p_sync_evt* __restrict__ evt,
-                                                 int* __restrict__ valid, int nj)
+                                                 int* __restrict__ valid, int nj, cf conj0, unsigned long long idx_base)
 {
   __shared__ cf sig[C8P_SYNC_BUF];
   __shared__ float pw[C8P_SYNC_BUF];                 // |sig[i]| * |sig[i]| as the reference forms it (hypotf squared)
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
   const SyncJob J = job[k];
   for (int i = lane; i < C8P_SYNC_BUF; i += 64) { const cf v = x[J.t + i]; sig[i] = v; pw[i] = habs(v) * habs(v); }
   // d_conjMultiAvg: the last latch the IDLE state saw — this trigger's mark, or the one an earlier trigger left behind
-  cf cavg = mk(0.f, 0.f);
+  cf cavg = conj0;                                   // what the state at the commit point carried in
   for (int kk = k; kk >= 0; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
   __syncthreads();
   for (int i = lane; i < C8P_SYNC_BUF - 64; i += 64) xc[i] = cmul(sig[i], cconj(sig[i + 64]));
@@ -378,11 +383,11 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
     const float ltf = atan2f(q.y, q.x) / 64.0f;
     const double d = (double)tac[mx];
     c8p_sync_evt e;
-    e.index = J.t + (unsigned long long)mIndex;
+    e.index = idx_base + J.t + (unsigned long long)mIndex;
     e.rad = stf + ltf;
     e.snr = (float)(10.0 * log10(d / (1.0 - d)));
     e.rssi = rs1[mx] / 64.0f;
-    e.trig = (uint32_t)J.t;
+    e.trig = (uint32_t)(idx_base + J.t);
     evt[k] = e;
     valid[k] = 1;
   }

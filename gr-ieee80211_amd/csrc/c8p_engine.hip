@@ -598,7 +598,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
 extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
 {
   if (!c) return C8P_EINVAL;
-  if (!in || (in->n > 0 && !in->raw)) { c->err = "bad detect input"; return C8P_EINVAL; }
+  if (!in || (in->n > 0 && !in->raw) || in->n_hist > in->n) { c->err = "bad detect input"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   if (in->n > (1ull << 31)) { c->err = "stream segment too long (2^31 items max)"; return C8P_ERANGE; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -609,73 +609,102 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   drain_events(c);
   S.n_pkt = 0;
   for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
-  const uint64_t n = in->n;
+  c8p_det_state st0;
+  memset(&st0, 0, sizeof(st0));
+  if (in->state) st0 = *in->state;
+  const long long hist = (long long)in->n_hist;
+  const uint64_t n = in->n - in->n_hist;              // new items: positions below are relative to the commit point
+  if (in->commit) *in->commit = in->n_hist;
+  if (in->state_out) *in->state_out = st0;
   if (n == 0) return C8P_OK;
   int rc;
-  const cf* d_raw = (const cf*)in->raw;
+  const cf* d_all = (const cf*)in->raw;
   if (in->mem == C8P_MEM_HOST) {
-    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * n)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * n, hipMemcpyHostToDevice, S.stream));
-    d_raw = (const cf*)S.d_det_raw.p;
+    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * in->n)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * in->n, hipMemcpyHostToDevice, S.stream));
+    d_all = (const cf*)S.d_det_raw.p;
   }
+  const cf* d_raw = d_all + hist;                      // first new item
   const int ntile = (int)((n + C8P_DET_TILE - 1) / C8P_DET_TILE);
   const unsigned cap = (unsigned)(n / 22 + 16);        // a plateau needs 21 samples above and one below
   if ((rc = ensure(c, S.d_det_ac, sizeof(float) * n)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_trig, n + 8)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_conj, in->keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_summ, sizeof(TrigSeg) * (size_t)ntile)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg) * (size_t)ntile)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg) * (size_t)(ntile + 1))) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * (size_t)cap)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_cnt, 16)) != C8P_OK) return rc;
   HIPCHK(c, hipMemsetAsync(S.d_det_cnt.p, 0, 16, S.stream));
+  TrigSeg init;                                        // the plateau open at the commit point
+  init.all = 0; init.tmax = 0.f; init.tstart = C8P_SEG_NONE;
+  if (st0.in_run) { init.all = 1; init.tstart = st0.run_start; init.tmax = st0.run_max; }
   {
     KTimer kt(c, C8P_K_PRESISO);
     const uint64_t nblk = (n + 7) / 8;
     hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
-                       d_raw, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p);
+                       d_raw, hist, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p);
   }
   {
     KTimer kt(c, C8P_K_TRIGGER);
-    hipLaunchKernelGGL(k_trig_carry, dim3(1), dim3(1024), 0, S.stream, (const TrigSeg*)S.d_det_summ.p, (TrigSeg*)S.d_det_carry.p, ntile);
+    hipLaunchKernelGGL(k_trig_carry, dim3(1), dim3(1024), 0, S.stream, (const TrigSeg*)S.d_det_summ.p, (TrigSeg*)S.d_det_carry.p, ntile, init);
     hipLaunchKernelGGL(k_trig_apply, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n,
                        (const TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
   }
   HIPCHK(c, hipGetLastError());
   unsigned ncand = 0;
+  TrigSeg fin;
   HIPCHK(c, hipMemcpyAsync(&ncand, S.d_det_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(c, hipMemcpyAsync(&fin, (const TrigSeg*)S.d_det_carry.p + ntile, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
   HIPCHK(c, hipStreamSynchronize(S.stream));
   if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
   std::vector<TrigCand> cand(ncand);
   if (ncand) HIPCHK(c, hipMemcpy(cand.data(), S.d_det_cand.p, sizeof(TrigCand) * ncand, hipMemcpyDeviceToHost));
   std::sort(cand.begin(), cand.end(), [](const TrigCand& a, const TrigCand& b) { return a.s < b.s; });
+  const long long N = (long long)n;
   // trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous
-  // countdown has run out if that is later and the plateau still lasts; one trigger per plateau
+  // countdown has run out if that is later and the plateau still lasts; one trigger per plateau.
+  // sync_impl.cc:73-147: IDLE scans up to a trigger, SYNC needs 240 items from it and consumes 111.
+  // The first countdown / search window that runs past the end of the segment stops the walk: the commit point moves
+  // to the item where that countdown was armed, and the next call derives it again.
+  bool have = st0.have_prev != 0;
+  long long prev_start = st0.prev_start;
+  long long pos = st0.sync_pos;                       // first item IDLE looks at
+  long long commit = N;
+  c8p_det_state st1;
+  memset(&st1, 0, sizeof(st1));
   std::vector<unsigned long long> fire;
-  {
-    bool have = false;
-    unsigned long long prev_start = 0;
-    for (const TrigCand& k : cand) {
-      unsigned long long start = k.s + 20;
-      if (have && prev_start + 80 > start) start = prev_start + 80;
-      if (start < k.e) {
-        have = true; prev_start = start;
-        if (start + 79 < n) fire.push_back(start + 79);
-      }
-    }
-  }
-  // sync_impl.cc:73-147: IDLE scans up to a trigger, SYNC needs 240 items from it and consumes 111
   std::vector<SyncJob> jobs;
-  {
-    unsigned long long pos = 0;
-    for (unsigned long long t : fire) {
-      if (t < pos) continue;                        // fell inside the 111 items a SYNC pass consumed unseen
-      if (n - t < C8P_SYNC_BUF) break;              // the block would wait for more input
-      SyncJob j; j.t = t; j.seen = pos;
-      jobs.push_back(j);
-      pos = t + C8P_SYNC_RES;
+  bool open_fired = false;                             // the plateau that is open at the end of the segment has armed
+  bool stopped = false;
+  long long stop_run_start = 0;
+  bool stop_have = false;
+  long long stop_prev = 0;
+  for (const TrigCand& k : cand) {
+    if (st0.in_run && st0.run_fired && k.s == st0.run_start) { if (k.e == N) open_fired = true; continue; }   // armed before the commit point
+    long long start = k.s + 20;
+    if (have && prev_start + 80 > start) start = prev_start + 80;
+    if (start >= k.e) continue;                        // the plateau ended before the previous countdown ran out
+    const long long t = start + 79;
+    const bool unseen = t < pos;                       // would fall inside the 111 items a SYNC pass consumes unseen
+    if (t >= N || (!unseen && N - t < C8P_SYNC_BUF)) { // countdown or search window runs past the end: not decidable yet
+      stopped = true; commit = start; stop_run_start = k.s; stop_have = have; stop_prev = prev_start;
+      break;
     }
+    have = true; prev_start = start;
+    if (k.e == N) open_fired = true;
+    fire.push_back((unsigned long long)t);
+    if (unseen) continue;
+    SyncJob j; j.t = (unsigned long long)t; j.seen = (unsigned long long)std::max(pos, 0ll);
+    jobs.push_back(j);
+    pos = t + C8P_SYNC_RES;
   }
-  const int nf = (int)fire.size(), nj = (int)jobs.size();
+  // one more look-back job, not a trigger: what the IDLE state has latched when it reaches the commit point
+  const int nj = (int)jobs.size();
+  {
+    SyncJob j; j.t = (unsigned long long)commit; j.seen = (unsigned long long)std::min(std::max(pos, 0ll), commit);
+    jobs.push_back(j);
+  }
+  const int nf = (int)fire.size();
   std::vector<c8p_sync_evt> evts;
   if (nf) {
     if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * (size_t)nf)) != C8P_OK) return rc;
@@ -683,31 +712,63 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     hipLaunchKernelGGL(k_trig_fire, dim3((nf + 255) / 256), dim3(256), 0, S.stream, (uint8_t*)S.d_det_trig.p,
                        (const unsigned long long*)S.d_det_fire.p, nf);
   }
-  if (nj) {
-    if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * (size_t)nj)) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * (size_t)nj)) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * (size_t)nj)) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_valid, sizeof(int) * (size_t)nj)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, jobs.data(), sizeof(SyncJob) * (size_t)nj, hipMemcpyHostToDevice, S.stream));
+  std::vector<SyncMark> marks(nj + 1);
+  {
+    if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * (size_t)(nj + 1))) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * (size_t)(nj + 1))) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * (size_t)(nj + 1))) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_det_valid, sizeof(int) * (size_t)(nj + 1))) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, jobs.data(), sizeof(SyncJob) * (size_t)(nj + 1), hipMemcpyHostToDevice, S.stream));
     {
       KTimer kt(c, C8P_K_SYNCEVT);
-      hipLaunchKernelGGL(k_sync_mark, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_raw,
-                         (SyncMark*)S.d_det_mark.p, nj);
-      hipLaunchKernelGGL(k_sync_evt, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_raw,
-                         (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, nj);
+      hipLaunchKernelGGL(k_sync_mark, dim3(nj + 1), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_raw,
+                         hist, (SyncMark*)S.d_det_mark.p, nj + 1);
+      if (nj)
+        hipLaunchKernelGGL(k_sync_evt, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_raw,
+                           (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, nj, make_float2(st0.conj_avg.re, st0.conj_avg.im),
+                           (unsigned long long)in->n_hist);
     }
     HIPCHK(c, hipGetLastError());
     std::vector<c8p_sync_evt> all(nj);
     std::vector<int> valid(nj);
-    HIPCHK(c, hipMemcpyAsync(all.data(), S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
-    HIPCHK(c, hipMemcpyAsync(valid.data(), S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+    if (nj) {
+      HIPCHK(c, hipMemcpyAsync(all.data(), S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+      HIPCHK(c, hipMemcpyAsync(valid.data(), S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(marks.data(), S.d_det_mark.p, sizeof(SyncMark) * (size_t)(nj + 1), hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
     for (int k = 0; k < nj; k++) if (valid[k]) evts.push_back(all[k]);
     if (!evts.empty())      // compacted, in stream order: what the sync block's output stream carries
       HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, evts.data(), sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
   }
+  // ---- state at the new commit point
+  st1.conj_avg = st0.conj_avg;
+  for (int k = nj; k >= 0; k--) if (marks[k].j >= 0) { st1.conj_avg.re = marks[k].conj.x; st1.conj_avg.im = marks[k].conj.y; break; }
+  st1.sync_pos = pos - commit;
+  if (stopped) {
+    // the commit point is the item where the undecidable countdown is armed: its plateau is open, has not armed yet
+    st1.in_run = 1; st1.run_fired = 0; st1.run_start = stop_run_start - commit;
+    st1.have_prev = stop_have; st1.prev_start = stop_prev - commit;
+    // d_conjAc at that item: maximum of ac over the plateau so far
+    float rmax = (st0.in_run && stop_run_start == st0.run_start) ? st0.run_max : 0.f;
+    const long long lo = std::max(stop_run_start, 0ll);
+    if (commit > lo) {
+      std::vector<float> a((size_t)(commit - lo));
+      HIPCHK(c, hipMemcpy(a.data(), (const float*)S.d_det_ac.p + lo, sizeof(float) * a.size(), hipMemcpyDeviceToHost));
+      for (float v : a) if (v > rmax) rmax = v;
+    }
+    st1.run_max = rmax;
+  } else {
+    st1.in_run = seg_has_run(fin) ? 1 : 0;
+    st1.run_start = st1.in_run ? fin.tstart - commit : 0;
+    st1.run_max = st1.in_run ? fin.tmax : 0.f;
+    st1.run_fired = (st1.in_run && (open_fired || (st0.in_run && st0.run_fired && fin.tstart == st0.run_start))) ? 1 : 0;
+    st1.have_prev = have; st1.prev_start = prev_start - commit;
+  }
   HIPCHK(c, hipStreamSynchronize(S.stream));
   drain_events(c);
+  if (in->commit) *in->commit = in->n_hist + (uint64_t)commit;
+  if (in->state_out) *in->state_out = st1;
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
   S.used[C8P_BUF_DET_AC] = sizeof(float) * n; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
   S.used[C8P_BUF_DET_TRIG] = n; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
@@ -762,7 +823,7 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
   const int32_t v[] = {C8P_ABI_VERSION, (int32_t)sizeof(c8p_pkt_in), (int32_t)sizeof(c8p_pkt_tags), (int32_t)sizeof(c8p_pkt_out),
                        (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
                        (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
-                       (int32_t)sizeof(c8p_detect_in)};
-  for (int i = 0; i < 11 && i < cap; i++) dst[i] = v[i];
-  return 11;
+                       (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state)};
+  for (int i = 0; i < 12 && i < cap; i++) dst[i] = v[i];
+  return 12;
 }

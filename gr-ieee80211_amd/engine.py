@@ -51,11 +51,11 @@ def load_library():
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
-    sizes = np.zeros(11, np.int32)
-    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 11)
+    sizes = np.zeros(12, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 12)
     want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
             C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn),
-            C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn)]
+            C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn), C.sizeof(abi.DetState)]
     if list(sizes) != want:
         raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
     _LIB = L
@@ -147,13 +147,19 @@ class Engine:
         self.n = len(evts)
         self._chk(self.L.c8p_signal(self.ctx, C.byref(d)))
 
-    def detect(self, raw, keep=False):
-        """presiso + trigger + sync over one raw stream segment (antenna 0); returns the sync events (host copy)."""
+    def detect(self, raw, keep=False, n_hist=0, state=None, stream=False):
+        """presiso + trigger + sync over one raw stream segment (antenna 0); returns the sync events (host copy).
+        stream=True: also returns (state at the new commit point, commit index into raw) for the next call, which gets
+        raw[commit - DET_HIST:] + new items, n_hist = DET_HIST (or commit, if smaller) and that state."""
         r_p, n_r, m, k1 = self._arena(raw, np.complex64)
-        d = abi.DetectIn(m, int(keep), r_p, n_r)
-        self._keep = (k1, d)
+        st_out = abi.DetState()
+        commit = C.c_uint64(0)
+        d = abi.DetectIn(m, int(keep), r_p, n_r, int(n_hist), C.addressof(state) if state is not None else None,
+                         C.addressof(st_out), C.addressof(commit))
+        self._keep = (k1, d, state, st_out, commit)
         self._chk(self.L.c8p_detect(self.ctx, C.byref(d)))
-        return self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
+        ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
+        return (ev, st_out, commit.value) if stream else ev
 
     def sync(self):
         self._chk(self.L.c8p_sync(self.ctx))

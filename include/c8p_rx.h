@@ -181,13 +181,35 @@ typedef struct c8p_signal_in {
   uint64_t          n_raw;
 } c8p_signal_in;
 
-/* raw stream -> sync events: presiso.grc + trigger_impl + sync_impl over one stream segment that starts from the
- * blocks' constructor state (antenna 0 only, as in rx.grc / rx2.grc) */
+/* State of trigger_impl + sync_impl at a commit point of the stream: everything before it is final, nothing pending
+ * refers to items before it.  Item positions are relative to the commit point. */
+typedef struct c8p_det_state {
+  int64_t run_start;    /* first item of the plateau (ac > 0.3) that is open at the commit point (< 0)          */
+  int64_t prev_start;   /* item where the last 80-item countdown was armed (< 0)    trigger_impl.cc:86-91        */
+  int64_t sync_pos;     /* first item sync's IDLE state will look at (> 0 while the 111 consumed items extend past the commit point) */
+  int32_t in_run;       /* 1: a plateau is open (d_nPlateau > 0)                                                */
+  int32_t run_fired;    /* 1: that plateau already armed its countdown (d_fPlateauEnd)                          */
+  int32_t have_prev;    /* 1: prev_start is valid                                                               */
+  float   run_max;      /* d_conjAc: maximum of ac over the open plateau                                        */
+  c8p_c32 conj_avg;     /* d_conjMultiAvg: the last latched presiso output 1            sync_impl.cc:84-87       */
+} c8p_det_state;
+
+/* raw stream -> sync events: presiso.grc + trigger_impl + sync_impl (antenna 0 only, as in rx.grc / rx2.grc).
+ * One-shot: n_hist = 0, state = NULL: the segment starts from the blocks' constructor state.
+ * Streaming: raw = [n_hist items of history | new items]; the new items start at the commit point the previous call
+ * returned, `state` is the state it returned, and n_hist >= C8P_DET_HIST items before it are supplied again (fewer only
+ * at the very start of the stream).  Event indices are relative to raw[0]. */
+#define C8P_DET_HIST 80   /* presiso looks back 16 + 63 items */
 typedef struct c8p_detect_in {
   int32_t mem;              /* C8P_MEM_* of raw                                                        */
   int32_t keep;             /* 1: also keep the conj stream (C8P_BUF_DET_CONJ) for tests               */
   const c8p_c32* raw;       /* [n] raw samples of antenna 0                                            */
   uint64_t       n;
+  uint64_t       n_hist;    /* leading items of raw that lie before the commit point                   */
+  const c8p_det_state* state;   /* state at the commit point, NULL = constructor state                 */
+  c8p_det_state* state_out;     /* may be NULL; receives the state at the new commit point             */
+  uint64_t*      commit;        /* may be NULL; receives the new commit point (index into raw): triggers whose countdown or
+                                   240-item search window runs past the end of raw are re-derived by the next call        */
 } c8p_detect_in;
 
 typedef struct c8p_decode_in {
@@ -211,9 +233,9 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_SIG_IQ   8  /* CFO-corrected items, per packet at pkt.iq_off[a] (nsamp items + 320 zero pad)   */
 #define C8P_BUF_SIG_CHAN 9  /* c8p_c32[n_evt][64] legacy channel estimates (tag "chan")                        */
 #define C8P_BUF_DET_EVT  10 /* c8p_sync_evt[]: sync events of the last c8p_detect, in stream order                    */
-#define C8P_BUF_DET_AC   11 /* float[n]: presiso output 0 (autocorrelation magnitude / energy)                        */
-#define C8P_BUF_DET_TRIG 12 /* uint8[n]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
-#define C8P_BUF_DET_CONJ 13 /* c8p_c32[n] (keep = 1): presiso output 1                                                */
+#define C8P_BUF_DET_AC   11 /* float[n - n_hist]: presiso output 0 (autocorrelation magnitude / energy) of the new items  */
+#define C8P_BUF_DET_TRIG 12 /* uint8[n - n_hist]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
+#define C8P_BUF_DET_CONJ 13 /* c8p_c32[n - n_hist] (keep = 1): presiso output 1                                       */
 #define C8P_BUF_COUNT    14
 
 /* kernels, for c8p_kernel_time() */
@@ -263,7 +285,7 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
 
-/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in} as compiled into the library. */
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus
