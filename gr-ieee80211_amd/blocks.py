@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libc8p_blocks.so")
 ENGINE_LIB = os.path.join(_HERE, "libc8p_rx.so")
 _LIB = None
 
-DEMOD, DEMOD2, DECODE, SIGNAL, SIGNAL2 = 0, 1, 2, 3, 4
+DEMOD, DEMOD2, DECODE, SIGNAL, SIGNAL2, DETECT = 0, 1, 2, 3, 4, 5
 
 
 def lib():
@@ -91,6 +91,8 @@ class Block:
         out = np.zeros(n, np.float32)
         if n:
             (self.L.c8ph_out1_copy if port == 1 else self.L.c8ph_out_copy)(self.h, out.ctypes.data)
+        if self.kind == DETECT:
+            return out.astype(np.uint8)
         return out.view(np.complex64) if self.kind in (SIGNAL, SIGNAL2) else out
 
     def tags(self):

@@ -36,6 +36,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.demod = (int (*)(c8p_ctx*, const c8p_batch_in*))sym("c8p_demod");
   a.decode = (int (*)(c8p_ctx*, const c8p_decode_in*))sym("c8p_decode");
   a.signal = (int (*)(c8p_ctx*, const c8p_signal_in*))sym("c8p_signal");
+  a.detect = (int (*)(c8p_ctx*, const c8p_detect_in*))sym("c8p_detect");
   a.sync = (int (*)(c8p_ctx*))sym("c8p_sync");
   a.buffer = (const void* (*)(c8p_ctx*, int, uint64_t*))sym("c8p_buffer");
   a.fetch = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch");
@@ -391,6 +392,84 @@ signal::sptr signal::make() { return make(default_api(), batching_cfg()); }
 signal::sptr signal::make(const c8p_api& api, const batching_cfg& cfg) { return std::shared_ptr<signal>(new signal_front(1, api, cfg)); }
 signal2::sptr signal2::make() { return make(default_api(), batching_cfg()); }
 signal2::sptr signal2::make(const c8p_api& api, const batching_cfg& cfg) { return std::shared_ptr<signal2>(new signal_front(2, api, cfg)); }
+
+// ================================================================================================ detect
+// Streaming front of c8p_detect(): gathers raw items, continues from the state / commit point of the previous call with
+// C8P_DET_HIST items of history in front, and emits sync's byte stream up to the new commit point (everything before
+// it is final).  Events whose flag item lies beyond the commit point wait in a queue until the output gets there.
+class detect_front : public detect
+{
+public:
+  detect_front(const c8p_api& api, const batching_cfg& cfg) : d_eng(api, cfg) { memset(&d_state, 0, sizeof(d_state)); }
+
+  void forecast(int noutput_items, gr_vector_int& req) override { for (auto& r : req) r = noutput_items; }
+
+  int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                   gr_vector_void_star& output_items) override
+  {
+    const int nproc = ninput_items[0];
+    const gr_complex* x = static_cast<const gr_complex*>(input_items[0]);
+    d_raw.insert(d_raw.end(), x, x + nproc);
+    d_io->consume_each(nproc);
+    const uint64_t fresh = buffered_end() - d_seen_end;
+    if (fresh > 0 && ((int64_t)(buffered_end() - d_commit) >= d_eng.d_cfg.detect_items || (d_eng.d_cfg.flush_when_idle && nproc == 0))) process();
+    return drain(static_cast<uint8_t*>(output_items[0]), noutput_items);
+  }
+
+  void flush() override { if (buffered_end() > d_seen_end) process(); }
+
+private:
+  uint64_t buffered_end() const { return d_base + d_raw.size(); }
+
+  void process()
+  {
+    d_seen_end = buffered_end();
+    c8p_detect_in in;
+    memset(&in, 0, sizeof(in));
+    uint64_t commit_rel = 0;
+    c8p_det_state out;
+    in.mem = C8P_MEM_HOST; in.keep = 0;
+    in.raw = reinterpret_cast<const c8p_c32*>(d_raw.data()); in.n = d_raw.size(); in.n_hist = d_commit - d_base;
+    in.state = d_have_state ? &d_state : nullptr; in.state_out = &out; in.commit = &commit_rel;
+    d_eng.check(d_eng.d_api.detect(d_eng.d_ctx, &in));
+    std::vector<c8p_sync_evt> ev = d_eng.fetch_all<c8p_sync_evt>(C8P_BUF_DET_EVT);
+    for (c8p_sync_evt& e : ev) { e.index += d_base; d_evq.push_back(e); }
+    d_state = out; d_have_state = true;
+    d_commit = d_base + commit_rel;
+    const uint64_t keep_from = d_commit > C8P_DET_HIST ? d_commit - C8P_DET_HIST : 0;   // history for the next call
+    if (keep_from > d_base) { d_raw.erase(d_raw.begin(), d_raw.begin() + (std::ptrdiff_t)(keep_from - d_base)); d_base = keep_from; }
+  }
+
+  int drain(uint8_t* out, int noutput_items)
+  {
+    const int k = (int)std::min<uint64_t>((uint64_t)noutput_items, d_commit - d_out);
+    if (k <= 0) return 0;
+    memset(out, 0, (size_t)k);
+    while (!d_evq.empty() && d_evq.front().index < d_out + (uint64_t)k) {
+      const c8p_sync_evt& e = d_evq.front();
+      if (e.index >= d_out) {
+        out[e.index - d_out] = 0x01;                                             // sync_impl.cc:123
+        const uint64_t off = d_io->nitems_written(0) + (e.index - d_out);
+        d_io->add_item_tag(0, off, "rad", tag_value::from_float(e.rad));
+        d_io->add_item_tag(0, off, "snr", tag_value::from_float(e.snr));
+        d_io->add_item_tag(0, off, "rssi", tag_value::from_float(e.rssi));
+      }
+      d_evq.pop_front();
+    }
+    d_out += (uint64_t)k;
+    return k;
+  }
+
+  engine_holder d_eng;
+  std::vector<gr_complex> d_raw;           // d_raw[0] = stream item d_base
+  uint64_t d_base = 0, d_commit = 0, d_out = 0, d_seen_end = 0;
+  c8p_det_state d_state;
+  bool d_have_state = false;
+  std::deque<c8p_sync_evt> d_evq;          // events not yet written to the output stream (absolute indices)
+};
+
+detect::sptr detect::make() { return make(default_api(), batching_cfg()); }
+detect::sptr detect::make(const c8p_api& api, const batching_cfg& cfg) { return std::shared_ptr<detect>(new detect_front(api, cfg)); }
 
 // ================================================================================================ decode
 class decode_front : public decode

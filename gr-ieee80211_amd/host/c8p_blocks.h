@@ -75,6 +75,7 @@ struct c8p_api {
   int (*demod)(c8p_ctx*, const c8p_batch_in*);
   int (*decode)(c8p_ctx*, const c8p_decode_in*);
   int (*signal)(c8p_ctx*, const c8p_signal_in*);
+  int (*detect)(c8p_ctx*, const c8p_detect_in*);
   int (*sync)(c8p_ctx*);
   const void* (*buffer)(c8p_ctx*, int, uint64_t*);
   int (*fetch)(c8p_ctx*, int, void*, uint64_t, uint64_t);
@@ -84,6 +85,7 @@ c8p_api load_c8p_api(const std::string& so_path);
 
 struct batching_cfg {
   int max_batch = 256;          // packets per c8p_* call
+  int detect_items = 1 << 20;   // detect: raw items gathered per c8p_detect call
   bool flush_when_idle = true;  // submit a partial batch when the input runs dry (bounds latency in a live flowgraph)
   int device = 0;
 };
@@ -132,6 +134,16 @@ class signal2 : virtual public c8p_block
 {
 public:
   typedef std::shared_ptr<signal2> sptr;
+  static sptr make();
+  static sptr make(const c8p_api& api, const batching_cfg& cfg);
+};
+// The packet detector of rx.grc / rx2.grc as ONE block: the hier block presiso (examples/presiso.grc) + trigger::make()
+// + sync::make().  in: the raw samples of antenna 0; out: sync's byte stream (1 item per input item), flagged items
+// carry the tags "rad", "snr", "rssi" (lib/sync_impl.cc:111-141).  SURVEY.md §8f-2.
+class detect : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<detect> sptr;
   static sptr make();
   static sptr make(const c8p_api& api, const batching_cfg& cfg);
 };

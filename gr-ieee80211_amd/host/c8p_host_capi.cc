@@ -59,7 +59,8 @@ void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_bat
     else if (kind == 1) { h->blk = demod2::make(api, cfg); h->nports = 2; }
     else if (kind == 2) { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
     else if (kind == 3) { h->blk = signal::make(api, cfg); h->nports = 2; h->port0_size = 1; h->out_size = sizeof(gr_complex); }
-    else { h->blk = signal2::make(api, cfg); h->nports = 3; h->port0_size = 1; h->out_size = sizeof(gr_complex); h->nout = 2; }
+    else if (kind == 4) { h->blk = signal2::make(api, cfg); h->nports = 3; h->port0_size = 1; h->out_size = sizeof(gr_complex); h->nout = 2; }
+    else { cfg.detect_items = max_batch; h->blk = detect::make(api, cfg); h->nports = 1; h->out_size = 1; }   // max_batch = items per call
     h->in.resize(h->nports);
     h->blk->set_io(h);
     return h;
@@ -99,7 +100,7 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
   try {
     long calls = 0;
     int idle = 0;
-    const size_t fpi = h->out_size / sizeof(float);                 // floats per output item
+    const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);   // floats per output item (byte items: widened below)
     std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
     while (idle < 4) {
       size_t avail = h->in[0].size() / h->isz(0);
@@ -116,7 +117,11 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       for (int q = 0; q < h->nports; q++)
         h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->isz(q));
       h->n_read += h->consumed_this_call;
-      h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
+      if (h->out_size == 1) {                                       // byte stream: one float per item in the capture
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf.data());
+        for (int i = 0; i < produced; i++) h->out_items.push_back((float)b[i]);
+      } else
+        h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
       if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
       h->n_written += produced;
       idle = (produced == 0 && h->consumed_this_call == 0) ? idle + 1 : 0;

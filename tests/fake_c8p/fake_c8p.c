@@ -7,6 +7,7 @@
 #include "c8p_oracle.h"
 
 struct c8p_ctx {
+  c8p_c32* det_x; uint64_t det_n, det_commit; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   int n;
   c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu;
@@ -16,6 +17,7 @@ struct c8p_ctx {
 c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); return (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); }
 static void drop(c8p_ctx* c)
 {
+  free(c->det_x); free(c->det_evt);
   free(c->tags); free(c->outs); free(c->llr); free(c->pdu); free(c->mu); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
   memset(c, 0, sizeof(*c));
 }
@@ -77,6 +79,37 @@ int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   }
   return C8P_OK;
 }
+/* c8p_detect on the oracle: keeps every item it was ever given, re-runs the one-shot oracle over the whole stream and
+ * reports the events between the old and the new commit point (new commit = 400 items before the end: every event
+ * before it has its 240-item search window inside the stream, so later items cannot change it). */
+int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+{
+  const uint64_t n_new = in->n - in->n_hist;
+  c->det_x = (c8p_c32*)realloc(c->det_x, (size_t)(c->det_commit + n_new + 1) * sizeof(c8p_c32));
+  memcpy(c->det_x + c->det_commit, in->raw + in->n_hist, (size_t)n_new * sizeof(c8p_c32));
+  c->det_n = c->det_commit + n_new;
+  const long N = (long)c->det_n;
+  float* ac = (float*)malloc(sizeof(float) * (size_t)(N + 1));
+  c8p_c32* cj = (c8p_c32*)malloc(sizeof(c8p_c32) * (size_t)(N + 1));
+  uint8_t* tr = (uint8_t*)malloc((size_t)N + 1);
+  c8p_sync_evt* ev = (c8p_sync_evt*)malloc(sizeof(c8p_sync_evt) * (size_t)(N / 100 + 16));
+  c8po_presiso(c->det_x, N, ac, cj);
+  c8po_trigger(ac, N, tr);
+  const long nev = c8po_sync(tr, cj, c->det_x, N, ev, N / 100 + 16, NULL);
+  const uint64_t old = c->det_commit;
+  const uint64_t neu = c->det_n > 400 ? (c->det_n - 400 > old ? c->det_n - 400 : old) : old;
+  free(c->det_evt);
+  c->det_evt = (c8p_sync_evt*)calloc((size_t)nev + 1, sizeof(c8p_sync_evt));
+  c->det_nevt = 0;
+  const uint64_t origin = old - in->n_hist;            /* stream index of raw[0] */
+  for (long k = 0; k < nev; k++)
+    if (ev[k].index >= old && ev[k].index < neu) { c->det_evt[c->det_nevt] = ev[k]; c->det_evt[c->det_nevt].index -= origin; c->det_nevt++; }
+  c->det_commit = neu;
+  if (in->commit) *in->commit = neu - origin;
+  if (in->state_out) memset(in->state_out, 0, sizeof(*in->state_out));
+  free(ac); free(cj); free(tr); free(ev);
+  return C8P_OK;
+}
 int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
 
 const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
@@ -88,6 +121,7 @@ const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
     case C8P_BUF_OUT: p = c->outs; b = (uint64_t)c->n * sizeof(c8p_pkt_out); break;
     case C8P_BUF_PDU: p = c->pdu; b = c->n_pdu; break;
     case C8P_BUF_MUCHAN: p = c->mu; b = (uint64_t)c->n * 128 * sizeof(c8p_c32); break;
+    case C8P_BUF_DET_EVT: p = c->det_evt; b = (uint64_t)c->det_nevt * sizeof(c8p_sync_evt); break;
     case C8P_BUF_SIG_PKT: p = c->sig_pkt; b = (uint64_t)c->n_sig * sizeof(c8p_pkt_in); break;
     case C8P_BUF_SIG_IQ: p = c->sig_iq; b = c->n_sig_iq * sizeof(c8p_c32); break;
     case C8P_BUF_SIG_CHAN: p = c->sig_chan; b = (uint64_t)c->n_sig * 64 * sizeof(c8p_c32); break;

@@ -221,3 +221,65 @@ def test_signal_mirror_on_gpu(n_ant):
     raw, ev, exp = _signal_case(n_ant, seed=10)
     outs, tags = _run_signal(None, raw, ev, n_ant, 3000, 4096, 4)
     _check_signal(outs, tags, raw, ev, n_ant, 2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- detect mirror + whole chain
+def _rx_chain_on_mirrors(engine_lib, raw, chunk, items_per_detect):
+    """rx.grc on the block mirrors: detect (presiso + trigger + sync) -> signal -> demod -> decode"""
+    det = blocks.Block(blocks.DETECT, engine_lib=engine_lib, max_batch=items_per_detect)
+    det.push_items(0, raw)
+    det.run(chunk=chunk, nout=chunk)
+    sync_bytes, sync_tags = det.output(), det.tags()
+    sig = blocks.Block(blocks.SIGNAL, engine_lib=engine_lib, max_batch=4)
+    sig.push_items(0, sync_bytes)
+    sig.push_items(1, raw[:len(sync_bytes)])
+    for off, key, val in sync_tags:
+        sig.push_tag(off, key, val)
+    sig.run(chunk=chunk, nout=4096)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=engine_lib, max_batch=4)
+    dem.push_items(0, sig.output(0))
+    for off, key, val in sig.tags():
+        dem.push_tag(off, key, val)
+    dem.run(chunk=2048, nout=4096)
+    dec = blocks.Block(blocks.DECODE, engine_lib=engine_lib, max_batch=8)
+    dec.push_items(0, dem.output())
+    for off, key, val in dem.tags():
+        dec.push_tag(off, key, val)
+    dec.run(chunk=4096, nout=64)
+    msgs = [m[1] for m in dec.messages()]
+    for b in (det, sig, dem, dec):
+        b.close()
+    return sync_bytes, sync_tags, msgs
+
+
+def _detect_case(seed=4):
+    from test_detect_frontend import NAMES, CFOS, stream
+    x, starts, exp = stream(NAMES[:5], CFOS[:5], seed=seed)
+    return np.concatenate([x, np.zeros(600, np.complex64)]), exp      # idle tail: the last packet's windows complete
+
+
+@pytest.mark.parametrize("chunk,items", [(8192, 1 << 20), (1500, 4000), (700, 900)])
+def test_detect_mirror_and_full_chain_with_fake_backend(chunk, items):
+    from c8p_testlib import oracle
+    raw, exp = _detect_case()
+    sync_bytes, sync_tags, msgs = _rx_chain_on_mirrors(FAKE, raw, chunk, items)
+    ev, _, _, _ = oracle().detect(raw)
+    flagged = np.nonzero(sync_bytes)[0]
+    assert list(flagged) == [int(e["index"]) for e in ev if int(e["index"]) < len(sync_bytes)]
+    by_off = {}
+    for off, key, val in sync_tags:
+        by_off.setdefault(off, {})[key] = val
+    assert sorted(by_off) == list(flagged)
+    for e in ev[:len(flagged)]:
+        d = by_off[int(e["index"])]
+        assert d["rad"] == float(e["rad"]) and d["snr"] == float(e["snr"]) and d["rssi"] == float(e["rssi"])
+    assert msgs == [d["pdu"].tobytes() for d, w in exp]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk,items", [(8192, 1 << 20), (1500, 4000)])
+def test_full_chain_on_gpu_mirrors(chunk, items):
+    """raw IQ -> detect -> signal -> demod -> decode -> PDUs, every block a front of the HIP engine"""
+    raw, exp = _detect_case(seed=6)
+    sync_bytes, sync_tags, msgs = _rx_chain_on_mirrors(None, raw, chunk, items)
+    assert msgs == [d["pdu"].tobytes() for d, w in exp]
