@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -69,7 +69,7 @@ def main():
 
     # engine-owned streams: consecutive batches are software-pipelined across C8P_SLOTS slots (upload / classify /
     # symbol demod of batch i+1 overlap the decoder of batch i); eng.sync() joins all of them
-    eng = engine.Engine(device=local, profile=True)
+    eng = engine.Engine(device=local, profile=not os.environ.get("C8P_BENCH_NOPROFILE"))
 
     def barrier():
         eng.sync()
