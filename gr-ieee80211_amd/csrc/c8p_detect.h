@@ -99,7 +99,7 @@ __device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh
 #define C8P_PRE_RS 264
 // x points at the first NEW item; items x[-hist .. -1] exist (history before the commit point), x[g] = 0 for g < -hist
 __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long long hist, unsigned long long n, float* __restrict__ ac,
-                                                 cf* __restrict__ conj, int keep, TrigSeg* __restrict__ summ)
+                                                 cf* __restrict__ conj, int keep, TrigSeg* __restrict__ summ, int x_aligned16)
 {
   __shared__ TrigSeg shs[16];
   __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
@@ -107,11 +107,23 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
   const int tid = threadIdx.x;
   const long long blk0 = (long long)blockIdx.x * C8P_PRE_OUT_BLOCKS - C8P_PRE_HALO;   // first block of this workgroup
   const long long base = blk0 * 8;
+  if (x_aligned16 && base >= -hist && base + 2048 <= (long long)n) {
+    // interior workgroup: 16-byte loads, thread tid takes samples base + 2 tid + 512 k and the next one (base is a
+    // multiple of 8, so these are 16-byte aligned whenever x is: the host passes that in)
 #pragma unroll
-  for (int k = 0; k < 8; k++) {             // coalesced: thread tid loads sample base + tid + 256 k
-    const int i = tid + 256 * k;
-    const long long g = base + i;
-    sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= -hist && g < (long long)n) ? x[g] : mk(0.f, 0.f);
+    for (int k = 0; k < 4; k++) {
+      const int i = 2 * tid + 512 * k;
+      const float4 v = *(const float4*)(x + base + i);
+      sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = mk(v.x, v.y);
+      sX[((i + 1) & 7) * C8P_PRE_RS + ((i + 1) >> 3)] = mk(v.z, v.w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {           // coalesced: thread tid loads sample base + tid + 256 k
+      const int i = tid + 256 * k;
+      const long long g = base + i;
+      sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= -hist && g < (long long)n) ? x[g] : mk(0.f, 0.f);
+    }
   }
   __syncthreads();
   cf p[8];
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
       pre = cadd(pre, p[j]); pe += e[j];
       const cf P = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);   // tail of block b-6 + blocks b-5..b-1 + head of block b
       const float E = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
-      acv[j] = sqrtf(P.x * P.x + P.y * P.y) / E;
+      // hardware sqrt / reciprocal (1 ulp each): ac is compared at 2e-6, the correctly rounded forms cost ~25 instructions
+      acv[j] = __builtin_amdgcn_sqrtf(P.x * P.x + P.y * P.y) * __builtin_amdgcn_rcpf(E);
       Pv[j] = P;
     }
   }
@@ -170,11 +183,25 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
     for (int j = 0; j < 8; j++) sE[j * C8P_PRE_RS + tid] = acv[j];
   }
   __syncthreads();
+  if (base >= 0 && base + 2048 <= (long long)n) {
+    // interior workgroup: 16-byte stores, thread tid stores samples base + 4 tid + 1024 k .. +3 (base is a multiple of 8)
 #pragma unroll
-  for (int k = 0; k < 8; k++) {             // coalesced: thread tid stores sample base + tid + 256 k
-    const int i = tid + 256 * k;
-    const long long g = base + i;
-    if ((i >> 3) >= C8P_PRE_HALO && (unsigned long long)g < n && g >= 0) ac[g] = sE[(i & 7) * C8P_PRE_RS + (i >> 3)];
+    for (int k = 0; k < 2; k++) {
+      const int i = 4 * tid + 1024 * k;
+      if ((i >> 3) >= C8P_PRE_HALO) {
+        const int r = (i >> 3);
+        const float4 v = make_float4(sE[(i & 7) * C8P_PRE_RS + r], sE[((i + 1) & 7) * C8P_PRE_RS + r],
+                                     sE[((i + 2) & 7) * C8P_PRE_RS + r], sE[((i + 3) & 7) * C8P_PRE_RS + r]);
+        *(float4*)(ac + base + i) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {           // coalesced: thread tid stores sample base + tid + 256 k
+      const int i = tid + 256 * k;
+      const long long g = base + i;
+      if ((i >> 3) >= C8P_PRE_HALO && (unsigned long long)g < n && g >= 0) ac[g] = sE[(i & 7) * C8P_PRE_RS + (i >> 3)];
+    }
   }
   if (keep && tid >= C8P_PRE_HALO) {        // test / debug path only
 #pragma unroll

@@ -687,8 +687,10 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   {
     KTimer kt(c, C8P_K_PRESISO);
     const uint64_t nblk = (n + 7) / 8;
-    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
-                       d_raw, hist, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p);
+    static const unsigned pre_lds = getenv("C8P_PRE_LDS") ? (unsigned)atoi(getenv("C8P_PRE_LDS")) : 0u;   // occupancy experiment
+    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), pre_lds, S.stream,
+                       d_raw, hist, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p,
+                       (int)(((uintptr_t)d_raw & 15u) == 0));
   }
   {
     KTimer kt(c, C8P_K_TRIGGER);
