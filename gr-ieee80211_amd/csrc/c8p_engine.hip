@@ -13,6 +13,7 @@
 #include <vector>
 
 #include <algorithm>
+#include <chrono>
 
 #include "c8p_kernels.h"
 #include "c8p_detect.h"
@@ -659,6 +660,14 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   memset(&st0, 0, sizeof(st0));
   if (in->state) st0 = *in->state;
   const long long hist = (long long)in->n_hist;
+  static const bool tlog = getenv("C8P_DET_TLOG") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!tlog) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[c8p_detect] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count());
+    T0 = t;
+  };
   const uint64_t n = in->n - in->n_hist;              // new items: positions below are relative to the commit point
   if (in->commit) *in->commit = in->n_hist;
   if (in->state_out) *in->state_out = st0;
@@ -699,15 +708,41 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
                        (const TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
   }
   HIPCHK(c, hipGetLastError());
-  unsigned ncand = 0;
-  TrigSeg fin;
-  HIPCHK(c, hipMemcpyAsync(&ncand, S.d_det_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(c, hipMemcpyAsync(&fin, (const TrigSeg*)S.d_det_carry.p + ntile, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
+  // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a
+  // synchronous staging hop each): [count | final seg | first C8P_DET_SPEC candidates] come back with one sync
+  constexpr unsigned C8P_DET_SPEC = 32768;
+  const unsigned spec = std::min(cap, C8P_DET_SPEC);
+  const size_t o_cnt = 0, o_fin = 64, o_cand = 128;
+  if ((rc = ensure_host(c, o_cand + sizeof(TrigCand) * (size_t)spec)) != C8P_OK) return rc;
+  char* hp = (char*)S.h_stage;
+  HIPCHK(c, hipMemcpyAsync(hp + o_cnt, S.d_det_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(c, hipMemcpyAsync(hp + o_fin, (const TrigSeg*)S.d_det_carry.p + ntile, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(c, hipMemcpyAsync(hp + o_cand, S.d_det_cand.p, sizeof(TrigCand) * (size_t)spec, hipMemcpyDeviceToHost, S.stream));
   HIPCHK(c, hipStreamSynchronize(S.stream));
+  lap("scan kernels + first sync");
+  const unsigned ncand = *(const unsigned*)(hp + o_cnt);
+  const TrigSeg fin = *(const TrigSeg*)(hp + o_fin);
   if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
-  std::vector<TrigCand> cand(ncand);
-  if (ncand) HIPCHK(c, hipMemcpy(cand.data(), S.d_det_cand.p, sizeof(TrigCand) * ncand, hipMemcpyDeviceToHost));
-  std::sort(cand.begin(), cand.end(), [](const TrigCand& a, const TrigCand& b) { return a.s < b.s; });
+  std::vector<TrigCand> cand((const TrigCand*)(hp + o_cand), (const TrigCand*)(hp + o_cand) + std::min(ncand, spec));
+  if (ncand > spec) {
+    cand.resize(ncand);
+    HIPCHK(c, hipMemcpy(cand.data() + spec, (const TrigCand*)S.d_det_cand.p + spec, sizeof(TrigCand) * (size_t)(ncand - spec), hipMemcpyDeviceToHost));
+  }
+  {
+    // stream order: the list comes back in atomic-append order; bucket by the tile a plateau ENDS in (one or two per
+    // tile at most in practice), then order inside the buckets — O(n + tiles) instead of a comparison sort
+    std::vector<unsigned> head((size_t)ntile + 2, 0);
+    auto bucket = [&](const TrigCand& k) { const long long e = std::max(k.e - 1, 0ll); return (size_t)std::min<long long>(e / C8P_DET_TILE, ntile); };
+    for (const TrigCand& k : cand) head[bucket(k) + 1]++;
+    for (size_t t = 1; t < head.size(); t++) head[t] += head[t - 1];
+    std::vector<TrigCand> tmp(cand.size());
+    std::vector<unsigned> fill(head.begin(), head.end() - 1);
+    for (const TrigCand& k : cand) tmp[fill[bucket(k)]++] = k;
+    for (size_t t = 0; t + 1 < head.size(); t++)
+      if (head[t + 1] - head[t] > 1)
+        std::sort(tmp.begin() + head[t], tmp.begin() + head[t + 1], [](const TrigCand& a, const TrigCand& b) { return a.s < b.s; });
+    cand.swap(tmp);
+  }
   const long long N = (long long)n;
   // trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous
   // countdown has run out if that is later and the plateau still lasts; one trigger per plateau.
@@ -722,6 +757,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   memset(&st1, 0, sizeof(st1));
   std::vector<unsigned long long> fire;
   std::vector<SyncJob> jobs;
+  fire.reserve(cand.size() + 1); jobs.reserve(cand.size() + 2);
   bool open_fired = false;                             // the plateau that is open at the end of the segment has armed
   bool stopped = false;
   long long stop_run_start = 0;
@@ -746,6 +782,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     jobs.push_back(j);
     pos = t + C8P_SYNC_RES;
   }
+  lap("sort + state machines");
   // one more look-back job, not a trigger: what the IDLE state has latched when it reaches the commit point
   const int nj = (int)jobs.size();
   {
@@ -754,19 +791,27 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   }
   const int nf = (int)fire.size();
   std::vector<c8p_sync_evt> evts;
+  // pinned layout for the second exchange: [fires | jobs] up, [marks | events | valid] down, [compacted events] up
+  const size_t o_fire = 0, o_job = o_fire + sizeof(unsigned long long) * (size_t)(nf + 1);
+  const size_t o_mark = o_job + sizeof(SyncJob) * (size_t)(nj + 1), o_evt = o_mark + sizeof(SyncMark) * (size_t)(nj + 1);
+  const size_t o_val = o_evt + sizeof(c8p_sync_evt) * (size_t)(nj + 1), o_out = (o_val + sizeof(int) * (size_t)(nj + 1) + 63) & ~(size_t)63;
+  if ((rc = ensure_host(c, o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1) + 64)) != C8P_OK) return rc;   // (phase-1 data is consumed)
+  hp = (char*)S.h_stage;
   if (nf) {
     if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * (size_t)nf)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(S.d_det_fire.p, fire.data(), sizeof(unsigned long long) * (size_t)nf, hipMemcpyHostToDevice, S.stream));
+    memcpy(hp + o_fire, fire.data(), sizeof(unsigned long long) * (size_t)nf);
+    HIPCHK(c, hipMemcpyAsync(S.d_det_fire.p, hp + o_fire, sizeof(unsigned long long) * (size_t)nf, hipMemcpyHostToDevice, S.stream));
     hipLaunchKernelGGL(k_trig_fire, dim3((nf + 255) / 256), dim3(256), 0, S.stream, (uint8_t*)S.d_det_trig.p,
                        (const unsigned long long*)S.d_det_fire.p, nf);
   }
-  std::vector<SyncMark> marks(nj + 1);
+  const SyncMark* marks = (const SyncMark*)(hp + o_mark);
   {
     if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * (size_t)(nj + 1))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * (size_t)(nj + 1))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * (size_t)(nj + 1))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_det_valid, sizeof(int) * (size_t)(nj + 1))) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, jobs.data(), sizeof(SyncJob) * (size_t)(nj + 1), hipMemcpyHostToDevice, S.stream));
+    memcpy(hp + o_job, jobs.data(), sizeof(SyncJob) * (size_t)(nj + 1));
+    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, hp + o_job, sizeof(SyncJob) * (size_t)(nj + 1), hipMemcpyHostToDevice, S.stream));
     {
       KTimer kt(c, C8P_K_SYNCEVT);
       hipLaunchKernelGGL(k_sync_mark, dim3(nj + 1), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_raw,
@@ -777,17 +822,20 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
                            (unsigned long long)in->n_hist);
     }
     HIPCHK(c, hipGetLastError());
-    std::vector<c8p_sync_evt> all(nj);
-    std::vector<int> valid(nj);
     if (nj) {
-      HIPCHK(c, hipMemcpyAsync(all.data(), S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
-      HIPCHK(c, hipMemcpyAsync(valid.data(), S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+      HIPCHK(c, hipMemcpyAsync(hp + o_evt, S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
+      HIPCHK(c, hipMemcpyAsync(hp + o_val, S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
     }
-    HIPCHK(c, hipMemcpyAsync(marks.data(), S.d_det_mark.p, sizeof(SyncMark) * (size_t)(nj + 1), hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_mark, S.d_det_mark.p, sizeof(SyncMark) * (size_t)(nj + 1), hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
+    lap("sync kernels + second sync");
+    const c8p_sync_evt* all = (const c8p_sync_evt*)(hp + o_evt);
+    const int* valid = (const int*)(hp + o_val);
     for (int k = 0; k < nj; k++) if (valid[k]) evts.push_back(all[k]);
-    if (!evts.empty())      // compacted, in stream order: what the sync block's output stream carries
-      HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, evts.data(), sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
+    if (!evts.empty()) {    // compacted, in stream order: what the sync block's output stream carries
+      memcpy(hp + o_out, evts.data(), sizeof(c8p_sync_evt) * evts.size());
+      HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, hp + o_out, sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
+    }
   }
   // ---- state at the new commit point
   st1.conj_avg = st0.conj_avg;
@@ -813,8 +861,8 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     st1.run_fired = (st1.in_run && (open_fired || (st0.in_run && st0.run_fired && fin.tstart == st0.run_start))) ? 1 : 0;
     st1.have_prev = have; st1.prev_start = prev_start - commit;
   }
-  HIPCHK(c, hipStreamSynchronize(S.stream));
-  drain_events(c);
+  lap("compaction + state");
+  drain_events(c);     // (the compacted events' upload may still be in flight: c8p_fetch / the next submit order behind it)
   if (in->commit) *in->commit = in->n_hist + (uint64_t)commit;
   if (in->state_out) *in->state_out = st1;
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
