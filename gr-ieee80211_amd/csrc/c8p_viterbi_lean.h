@@ -80,47 +80,69 @@ __device__ __forceinline__ v2f cand2(float pre, const LeanK& k, float t0, float 
   return __builtin_elementwise_fma(B, T1, P);
 }
 
-template <int Q, bool HAVE0, bool HAVE1>
-__device__ __forceinline__ float lean_step(float pre, const LeanK& k, float t0, float t1, unsigned& acc)
+// The decision of a step (compare + shift into the accumulator) does not feed the metric recurrence, so it is issued
+// one step late, in the two wait states a DPP / permlane read needs after the VALU write of its source (filled with
+// s_nop before).  PQ = exchange phase of the step whose decision is still pending (-1: none); the pending operands are
+//   PQ <= 3: (d, class mask) for v_cmp_class,   PQ >= 4: (a1, a0) for v_cmp_gt.
+struct LeanPend { unsigned x, y; };
+#define C8P_DEFER_NONE "s_nop 1\n\t"
+#define C8P_DEFER_CLS  "v_cmp_class_f32_e32 vcc, %[px], %[py]\n\tv_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+#define C8P_DEFER_GT   "v_cmp_gt_f32_e32 vcc, %[px], %[py]\n\tv_addc_co_u32_e32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+#define C8P_DPP2(NAME, DEFER, CTRL)                                                                                     \
+  asm(DEFER "v_sub_f32_dpp %[d], %[send], %[keep] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                             \
+            "v_max_f32_dpp %[nxt], %[send], %[keep] " CTRL " row_mask:0xf bank_mask:0xf"                                \
+      : [d] "=&v"(d), [nxt] "=&v"(nxt), [acc] "+v"(acc) : [send] "v"(send), [keep] "v"(keep), [px] "v"(pend.x), [py] "v"(pend.y) : "vcc")
+#define C8P_DPP3(DEFER)                                                                                                 \
+  asm(DEFER "v_mov_b32_dpp %[tq], %[send] quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"               \
+            "v_sub_f32_dpp %[d], %[tq], %[keep] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                        \
+            "v_max_f32_dpp %[nxt], %[tq], %[keep] row_half_mirror row_mask:0xf bank_mask:0xf"                          \
+      : [tq] "=&v"(tq), [d] "=&v"(d), [nxt] "=&v"(nxt), [acc] "+v"(acc)                                                \
+      : [send] "v"(send), [keep] "v"(keep), [px] "v"(pend.x), [py] "v"(pend.y) : "vcc")
+#define C8P_SWAP(DEFER, OP)                                                                                             \
+  asm(DEFER OP " %[a0], %[a1]" : [a0] "+v"(a0), [a1] "+v"(a1), [acc] "+v"(acc) : [px] "v"(pend.x), [py] "v"(pend.y) : "vcc")
+#define C8P_BY_PQ(STMT_NONE, STMT_CLS, STMT_GT) \
+  do { if constexpr (PQ < 0) { STMT_NONE; } else if constexpr (PQ <= 3) { STMT_CLS; } else { STMT_GT; } } while (0)
+
+template <int Q, int PQ, bool HAVE0, bool HAVE1>
+__device__ __forceinline__ float lean_step(float pre, const LeanK& k, float t0, float t1, unsigned& acc, LeanPend& pend)
 {
   // for q = 4,5 the constants are laid out so that `keep` is the even-predecessor candidate slot (see lean_forward)
   const v2f ks = cand2<HAVE0, HAVE1>(pre, k, t0, t1);
   const float keep = ks.x, send = ks.y;
   float nxt;
-  if (Q <= 3) {
+  if constexpr (Q <= 3) {
     float d;
-    if (Q == 0) {
-      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-          "v_max_f32_dpp %1, %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
-    } else if (Q == 1) {
-      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-          "v_max_f32_dpp %1, %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
-    } else if (Q == 2) {   // lane^3 inside the quad, then mirror inside 8 lanes (lane^7): together lane^4
+    if constexpr (Q == 0) {
+      C8P_BY_PQ(C8P_DPP2(0, C8P_DEFER_NONE, "quad_perm:[1,0,3,2]"), C8P_DPP2(0, C8P_DEFER_CLS, "quad_perm:[1,0,3,2]"), C8P_DPP2(0, C8P_DEFER_GT, "quad_perm:[1,0,3,2]"));
+    } else if constexpr (Q == 1) {
+      C8P_BY_PQ(C8P_DPP2(1, C8P_DEFER_NONE, "quad_perm:[2,3,0,1]"), C8P_DPP2(1, C8P_DEFER_CLS, "quad_perm:[2,3,0,1]"), C8P_DPP2(1, C8P_DEFER_GT, "quad_perm:[2,3,0,1]"));
+    } else if constexpr (Q == 2) {   // lane^3 inside the quad, then mirror inside 8 lanes (lane^7): together lane^4
       float tq;
-      asm("s_nop 1\n\tv_mov_b32_dpp %0, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-          "v_sub_f32_dpp %1, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-          "v_max_f32_dpp %2, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
-          : "=&v"(tq), "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+      C8P_BY_PQ(C8P_DPP3(C8P_DEFER_NONE), C8P_DPP3(C8P_DEFER_CLS), C8P_DPP3(C8P_DEFER_GT));
     } else {
-      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-          "v_max_f32_dpp %1, %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(d), "=&v"(nxt) : "v"(send), "v"(keep));
+      C8P_BY_PQ(C8P_DPP2(3, C8P_DEFER_NONE, "row_ror:8"), C8P_DPP2(3, C8P_DEFER_CLS, "row_ror:8"), C8P_DPP2(3, C8P_DEFER_GT, "row_ror:8"));
     }
-    asm("v_cmp_class_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(d), "v"(k.cls) : "vcc");
+    pend.x = __float_as_uint(d); pend.y = (unsigned)k.cls;
   } else {
     // `keep`/`send` are here the candidates this lane computes for the a0-register / a1-register respectively;
-    // the swap moves each to the lane that needs it: afterwards r[0] = a0 and r[1] = a1 in every lane.
-    float a0, a1;
-    if (Q == 4) {
-      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(keep), __float_as_uint(send), false, false);
-      a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+    // the swap moves each to the lane that needs it: afterwards a0 / a1 hold those candidates in every lane.
+    float a0 = keep, a1 = send;
+    if constexpr (Q == 4) {
+      C8P_BY_PQ(C8P_SWAP(C8P_DEFER_NONE, "v_permlane16_swap_b32"), C8P_SWAP(C8P_DEFER_CLS, "v_permlane16_swap_b32"), C8P_SWAP(C8P_DEFER_GT, "v_permlane16_swap_b32"));
     } else {
-      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(keep), __float_as_uint(send), false, false);
-      a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+      C8P_BY_PQ(C8P_SWAP(C8P_DEFER_NONE, "v_permlane32_swap_b32"), C8P_SWAP(C8P_DEFER_CLS, "v_permlane32_swap_b32"), C8P_SWAP(C8P_DEFER_GT, "v_permlane32_swap_b32"));
     }
-    asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a1), "v"(a0) : "vcc");
     asm("v_max_f32 %0, %1, %2" : "=v"(nxt) : "v"(a0), "v"(a1));
+    pend.x = __float_as_uint(a1); pend.y = __float_as_uint(a0);
   }
   return nxt;
+}
+// the decision still pending after the last step of a block
+template <int PQ> __device__ __forceinline__ void lean_flush(unsigned& acc, const LeanPend& pend)
+{
+  if constexpr (PQ < 0) return;
+  else if constexpr (PQ <= 3) asm("v_cmp_class_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(pend.x), "v"(pend.y) : "vcc");
+  else asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(pend.x), "v"(pend.y) : "vcc");
 }
 
 // range check applied where LLRs are produced (k_demod_sym) or handed in (k_llr_check), one flag per packet
@@ -151,15 +173,19 @@ template <int CR> __device__ __forceinline__ constexpr int idx1(int j)
 
 #define C8P_SV_BLK 30      // trellis steps per survivor block (lcm of the exchange period 6 and the r=5/6 puncture period 5)
 
-template <int CR, int J, bool GUARD>
-__device__ __forceinline__ void lean_steps(float& pre, const LeanK (&K)[6], const float (&x)[RateInfo<CR>::NL], unsigned& acc, int rem)
+// J-th step of a super-iteration.  FIRST: no decision is pending when step 0 starts (first super-iteration of a block).
+// GUARD (partial last block): every step settles its own decision at once.
+template <int CR, int J, bool GUARD, bool FIRST>
+__device__ __forceinline__ void lean_steps(float& pre, const LeanK (&K)[6], const float (&x)[RateInfo<CR>::NL], unsigned& acc, LeanPend& pend, int rem)
 {
   if constexpr (J < RateInfo<CR>::PER) {
     if (!GUARD || J < rem) {
       constexpr int i0 = idx0<CR>(J), i1 = idx1<CR>(J);
-      pre = lean_step<J % 6, (i0 >= 0), (i1 >= 0)>(pre, K[J % 6], i0 >= 0 ? x[i0 >= 0 ? i0 : 0] : 0.0f,
-                                                    i1 >= 0 ? x[i1 >= 0 ? i1 : 0] : 0.0f, acc);
-      lean_steps<CR, J + 1, GUARD>(pre, K, x, acc, rem);
+      constexpr int PQ = GUARD ? -1 : (J == 0 ? (FIRST ? -1 : (RateInfo<CR>::PER - 1) % 6) : (J - 1) % 6);
+      pre = lean_step<J % 6, PQ, (i0 >= 0), (i1 >= 0)>(pre, K[J % 6], i0 >= 0 ? x[i0 >= 0 ? i0 : 0] : 0.0f,
+                                                        i1 >= 0 ? x[i1 >= 0 ? i1 : 0] : 0.0f, acc, pend);
+      if constexpr (GUARD) lean_flush<J % 6>(acc, pend);
+      lean_steps<CR, J + 1, GUARD, FIRST>(pre, K, x, acc, pend, rem);
     }
   }
 }
@@ -189,6 +215,7 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
   c4float* L = (c4float*)Lg;
   float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;      // state 0 sits in lane 0 under every rotation
   unsigned acc = 0;
+  LeanPend pend = {0u, 0u};
   int tb = 0, lb = 0;
   float x[NL];
   unsigned* out = sv + lane;
@@ -218,8 +245,10 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
                        "s_load_dword %3, %4, %7"
                        : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3) : "s"(nx), "s"(x[0]), "s"(x[NL - 1]), "n"(NLB * 4 - 4));
       }
-      lean_steps<CR, 0, false>(pre, K, x, acc, PER);
+      if (r == 0) lean_steps<CR, 0, false, true>(pre, K, x, acc, pend, PER);
+      else lean_steps<CR, 0, false, false>(pre, K, x, acc, pend, PER);
     }
+    lean_flush<(PER - 1) % 6>(acc, pend);
     *out = acc;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4));   // last touches land before anything reuses the registers
@@ -230,7 +259,7 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
       if (r * PER < rem) {
 #pragma unroll
         for (int i = 0; i < NL; i++) { const int li = lb + i; x[i] = li < n_llr ? L[li] : 0.0f; }
-        lean_steps<CR, 0, true>(pre, K, x, acc, rem - r * PER);
+        lean_steps<CR, 0, true, true>(pre, K, x, acc, pend, rem - r * PER);
       }
     }
     *out = acc << (C8P_SV_BLK - rem);
