@@ -155,6 +155,18 @@ typedef struct c8p_sync_evt {
   uint32_t trig;        /* item index of the trigger that started this search (low 32 bits)                   */
 } c8p_sync_evt;
 
+/* Geometry of one transmitted packet (1 spatial stream, 20 MHz, long GI): the values the reference's modulation
+ * descriptor holds after formatToModSu / procPktLenAggre (cloud80211phy.cc:2487-2524, tools/phy80211header.py:427-506). */
+typedef struct c8p_tx_plan {
+  int32_t nb, cr, ndbps, ncbps, nsd;  /* bits per subcarrier, C8P_CR_*, data / coded bits per symbol, data subcarriers */
+  int32_t nsym;                       /* data symbols                                                               */
+  int32_t psdu_len;                   /* PSDU bytes after VHT padding (= len for legacy / HT)                       */
+  int32_t npad_eof, npad_octet;       /* VHT: EOF delimiters and zero octets appended to the A-MPDU                  */
+  int32_t legacy_len;                 /* L-SIG LENGTH                                                               */
+  int32_t n_pre;                      /* 80-sample symbols between L-SIG and the first data symbol                  */
+  int32_t n_samp;                     /* samples of the packet                                                      */
+} c8p_tx_plan;
+
 typedef struct c8p_cfg {
   int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
   int32_t device;           /* HIP device ordinal                                                      */

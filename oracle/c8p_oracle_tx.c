@@ -1,0 +1,302 @@
+/*
+ * c8p_oracle_tx.c — CPU restatement of the reference's transmit chain for one spatial stream at 20 MHz, long GI
+ * ("TX-lite"): what tools/phy80211.py genFromMpdu / genFromAmpdu + genFinalSig produce, which is also
+ * what lib/encode_impl.cc + lib/modulation_impl.cc + cloud80211phy.cc:2594-3180 produce in the flowgraph.
+ *
+ * TEST INFRASTRUCTURE ONLY (see c8p_oracle.h).  Pinned by the committed fixtures: tests/golden/packets_*.npz hold the
+ * toolbox's own IQ ("tx") and punctured coded bits ("coded") for legacy MCS 0-7, HT MCS 0-7 and VHT MCS 0-8.
+ *
+ * Restated from tools/phy80211.py (line numbers of that file):
+ *   __genLegacyTraining :223-235, __genLegacySignal :237-282, __genHtSignal :284-350, __genVhtSignalA :352-455,
+ *   __genNonLegacyTraining :459-510, __genVhtSignalB :512-569, __genDataBits :639-682, __genCodedBits :684-710,
+ *   __genInterleaveDataBits :736-746, __genConstellation :748-761, __genOfdmSignal :788-819, genFinalSig :1018-1035
+ * and tools/phy80211header.py: procPktLenNonAggre :427-459, procPktLenAggre :461-506, procBcc :763-798,
+ * procScramble :800-806, procInterleaveSigL :808-819, procConcat2Symbol :894-901, procPilotInsert :914-925,
+ * procDcInsert :927-937, procNonDataSC :940-948, procFftMod :958-964, procToneScaling :966-967, procGi :969-977.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "c8p_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct { double re, im; } cd;
+
+static const signed char LTF_L53[53] = {1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                                        1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1};
+static const signed char STF_SIGN[12] = {1, -1, 1, -1, -1, 1, -1, -1, 1, 1, 1, 1};   /* subcarriers -24,-20,...,-4, 4,...,24 */
+
+typedef struct { int nb, cr, ndbps, ncbps, nsd; } rate_t;
+
+static int rate_of(int format, int mcs, rate_t* r)
+{
+  static const int nbL[8] = {1, 1, 2, 2, 4, 4, 6, 6}, crL[8] = {0, 2, 0, 2, 0, 2, 1, 2};
+  static const int nbN[10] = {1, 2, 2, 4, 4, 6, 6, 6, 8, 8}, crN[10] = {0, 0, 2, 0, 2, 1, 2, 3, 2, 3};
+  if (format == 0) { if (mcs < 0 || mcs > 7) return 0; r->nb = nbL[mcs]; r->cr = crL[mcs]; r->nsd = 48; }
+  else { if (mcs < 0 || mcs > (format == 1 ? 7 : 8)) return 0; r->nb = nbN[mcs]; r->cr = crN[mcs]; r->nsd = 52; }
+  r->ncbps = r->nsd * r->nb;
+  r->ndbps = r->cr == 0 ? r->ncbps / 2 : r->cr == 1 ? r->ncbps * 2 / 3 : r->cr == 2 ? r->ncbps * 3 / 4 : r->ncbps * 5 / 6;
+  return 1;
+}
+
+int c8po_tx_plan(int format, int mcs, int len, c8p_tx_plan* p)
+{
+  rate_t r;
+  memset(p, 0, sizeof(*p));
+  if (!rate_of(format, mcs, &r) || len <= 0 || len > 4095) return 0;
+  p->nb = r.nb; p->cr = r.cr; p->ndbps = r.ndbps; p->ncbps = r.ncbps; p->nsd = r.nsd;
+  if (format == 2) {                                 /* procPktLenAggre :480-494 (len = A-MPDU bytes) */
+    p->nsym = (8 * len + 16 + 6 + r.ndbps - 1) / r.ndbps;
+    p->psdu_len = (p->nsym * r.ndbps - 16 - 6) / 8;
+    p->npad_eof = (p->psdu_len - len) / 4;
+    p->npad_octet = p->psdu_len - len - p->npad_eof * 4;
+    p->legacy_len = ((20 + 8 + 4 + 4 + 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
+    p->n_pre = 5;                                    /* SIG-A x2, VHT-STF, VHT-LTF, SIG-B */
+  } else {                                           /* procPktLenNonAggre :431-456 */
+    p->nsym = (8 * len + 16 + 6 + r.ndbps - 1) / r.ndbps;
+    p->psdu_len = len;
+    p->legacy_len = format == 0 ? len : ((20 + 8 + 4 + 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
+    p->n_pre = format == 0 ? 0 : 4;                  /* HT-SIG x2, HT-STF, HT-LTF */
+  }
+  p->n_samp = 320 + 80 * (1 + p->n_pre + p->nsym);
+  return 1;
+}
+
+static void bcc(const uint8_t* in, int n, uint8_t* out2n)      /* procBcc :766-771, rate 1/2: A (0155) then B (0117) */
+{
+  unsigned st = 0;
+  for (int j = 0; j < n; j++) {
+    st = ((st << 1) & 0x7e) | in[j];
+    out2n[2 * j] = (uint8_t)(__builtin_popcount(st & 0155) & 1);
+    out2n[2 * j + 1] = (uint8_t)(__builtin_popcount(st & 0117) & 1);
+  }
+}
+static int puncture(const uint8_t* c, int n2, int cr, uint8_t* out)   /* procBcc :772-795 */
+{
+  int k = 0;
+  for (int i = 0; i < n2; i++) {
+    int keep = 1;
+    if (cr == 1) keep = (i % 4) != 3;
+    else if (cr == 2) keep = !((i % 6) == 3 || (i % 6) == 4);
+    else if (cr == 3) { const int m = i % 10; keep = !(m == 3 || m == 4 || m == 7 || m == 8); }
+    if (keep) out[k++] = c[i];
+  }
+  return k;
+}
+static void crc8_bits(const uint8_t* b, int n, uint8_t* out8)  /* genBitBitCrc8: x^8+x^2+x+1, init ones, complemented, MSB first */
+{
+  unsigned c = 0xff;
+  for (int i = 0; i < n; i++) {
+    const unsigned fb = ((c >> 7) & 1u) ^ b[i];
+    c = (c << 1) & 0xffu;
+    if (fb) c ^= 0x07u;
+  }
+  c ^= 0xffu;
+  for (int i = 0; i < 8; i++) out8[i] = (uint8_t)((c >> (7 - i)) & 1u);
+}
+static void interleave_sig48(const uint8_t* in, uint8_t* out)  /* procInterleaveSigL :808-816 */
+{
+  for (int k = 0; k < 48; k++) out[3 * (k % 16) + k / 16] = in[k];
+}
+
+/* one OFDM symbol: X[64] in "shifted" order (index i = subcarrier i - 32), scale 1/sqrt(ntf), 64-point IDFT with 1/64,
+ * written as cp + 64 samples at dst */
+static void ofdm(const cd* X, double ntf, int cp, cd* dst)
+{
+  cd t[64];
+  for (int n = 0; n < 64; n++) {
+    double sr = 0, si = 0;
+    for (int i = 0; i < 64; i++) {
+      const int k = i - 32;                            /* subcarrier */
+      const double a = 2.0 * M_PI * (double)k * (double)n / 64.0;
+      sr += X[i].re * cos(a) - X[i].im * sin(a);
+      si += X[i].re * sin(a) + X[i].im * cos(a);
+    }
+    t[n].re = sr / 64.0 / sqrt(ntf); t[n].im = si / 64.0 / sqrt(ntf);
+  }
+  for (int n = 0; n < cp; n++) dst[n] = t[64 - cp + n];
+  for (int n = 0; n < 64; n++) dst[cp + n] = t[n];
+}
+/* data / SIG symbol from nsd constellation points (ascending subcarrier, pilots and DC not included) */
+static void place(const cd* q, int nsd, const double pil[4], cd* X)
+{
+  memset(X, 0, sizeof(cd) * 64);
+  const int lim = nsd == 48 ? 26 : 28;
+  int j = 0;
+  for (int k = -lim; k <= lim; k++) {
+    if (k == 0) continue;
+    if (k == -21 || k == -7 || k == 7 || k == 21) { const int pi = k == -21 ? 0 : k == -7 ? 1 : k == 7 ? 2 : 3; X[k + 32].re = pil[pi]; continue; }
+    X[k + 32] = q[j++];
+  }
+}
+static cd qam_point(const uint8_t* bits, int nb)      /* C_QAM_MODU_TAB: chip = sum b_j 2^j, Gray levels, I from the low half */
+{
+  cd r = {0, 0};
+  if (nb == 1) { r.re = bits[0] ? 1.0 : -1.0; return r; }
+  const int h = nb / 2;
+  const double A = h == 1 ? 0 : (double)(1 << (h - 1));
+  double ax[2];
+  for (int a = 0; a < 2; a++) {
+    const uint8_t* b = bits + a * h;
+    double v = b[h - 1] ? 1.0 : -1.0;
+    for (int k = h - 1; k >= 1; k--) { const double T = A / (double)(1 << (k - 1)); v = (b[k - 1] ? 1.0 : -1.0) * (T - v); }
+    ax[a] = v;
+  }
+  const double sc = nb == 2 ? sqrt(2.0) : nb == 4 ? sqrt(10.0) : nb == 6 ? sqrt(42.0) : sqrt(170.0);
+  r.re = ax[0] / sc; r.im = ax[1] / sc;
+  return r;
+}
+
+static int PS127[127];
+static void init_ps(void)
+{
+  static int done = 0;
+  if (done) return;
+  int st = 0x7f;
+  for (int n = 0; n < 127; n++) { const int fb = ((st >> 6) & 1) ^ ((st >> 3) & 1); PS127[n] = fb ? -1 : 1; st = ((st << 1) & 0x7e) | fb; }
+  done = 1;
+}
+
+int c8po_tx_packet(int format, int mcs, const uint8_t* psdu, int len, int scr_seed, float mult, c8p_c32* out, int cap,
+                   uint8_t* coded_out, int* n_coded)
+{
+  c8p_tx_plan P;
+  c8po_init();
+  init_ps();
+  if (!c8po_tx_plan(format, mcs, len, &P) || P.n_samp > cap) return -1;
+  cd* sig = (cd*)calloc((size_t)P.n_samp, sizeof(cd));
+  cd X[64];
+  int pos = 0;
+  const double pil0[4] = {1, 1, 1, -1};
+  /* ---- L-STF, L-LTF (:223-235) */
+  memset(X, 0, sizeof(X));
+  for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+  { cd t[80]; ofdm(X, 12.0, 0, t); for (int n = 0; n < 32; n++) sig[n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[32 + 64 * r + n] = t[n]; }
+  memset(X, 0, sizeof(X));
+  for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
+  { cd t[80]; ofdm(X, 52.0, 0, t); for (int n = 0; n < 32; n++) sig[160 + n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[192 + 64 * r + n] = t[n]; }
+  pos = 320;
+  /* ---- L-SIG (:237-282) */
+  {
+    static const uint8_t RATE[8][4] = {{1, 1, 0, 1}, {1, 1, 1, 1}, {0, 1, 0, 1}, {0, 1, 1, 1}, {1, 0, 0, 1}, {1, 0, 1, 1}, {0, 0, 0, 1}, {0, 0, 1, 1}};
+    uint8_t b[24], c[48], it[48];
+    memset(b, 0, sizeof(b));
+    memcpy(b, RATE[format == 0 ? mcs : 0], 4);
+    for (int i = 0; i < 12; i++) b[5 + i] = (uint8_t)((P.legacy_len >> i) & 1);
+    int par = 0; for (int i = 0; i < 17; i++) par += b[i];
+    b[17] = (uint8_t)(par & 1);
+    bcc(b, 24, c); interleave_sig48(c, it);
+    cd q[48]; for (int i = 0; i < 48; i++) { q[i].re = it[i] ? 1.0 : -1.0; q[i].im = 0; }
+    place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
+  }
+  uint8_t sigb_crc[8] = {0};
+  if (format == 1) {
+    /* ---- HT-SIG (:284-350): both symbols QBPSK */
+    uint8_t b[48], c[96], it[96];
+    memset(b, 0, sizeof(b));
+    for (int i = 0; i < 7; i++) b[i] = (uint8_t)((mcs >> i) & 1);
+    for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((P.psdu_len >> i) & 1);
+    b[24] = 1; b[25] = 1; b[26] = 1; b[27] = 0 /* not aggregated (genFromMpdu) */;
+    crc8_bits(b, 34, b + 34);
+    bcc(b, 48, c); interleave_sig48(c, it); interleave_sig48(c + 48, it + 48);
+    for (int s = 0; s < 2; s++) {
+      cd q[48]; for (int i = 0; i < 48; i++) { q[i].re = 0; q[i].im = it[48 * s + i] ? 1.0 : -1.0; }
+      place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
+    }
+  } else if (format == 2) {
+    /* ---- VHT-SIG-A (:352-455): BPSK then QBPSK; single user, group id 0, partial AID 0 */
+    uint8_t b[48], c[96], it[96];
+    memset(b, 0, sizeof(b));
+    b[2] = 1;                                          /* bw 0,0; reserved 1; STBC 0; gid 0; nSTS-1 = 0; partial AID 0; txop 0 */
+    b[23] = 1;
+    for (int i = 0; i < 4; i++) b[24 + 4 + i] = (uint8_t)((mcs >> i) & 1);
+    b[24 + 9] = 1;
+    crc8_bits(b, 34, b + 34);
+    bcc(b, 48, c); interleave_sig48(c, it); interleave_sig48(c + 48, it + 48);
+    for (int s = 0; s < 2; s++) {
+      cd q[48];
+      for (int i = 0; i < 48; i++) { const double v = it[48 * s + i] ? 1.0 : -1.0; q[i].re = s ? 0 : v; q[i].im = s ? v : 0; }
+      place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
+    }
+  }
+  if (format != 0) {
+    /* ---- HT / VHT STF + one LTF (:459-510), nSS = 1: P and R factors are +1 */
+    memset(X, 0, sizeof(X));
+    for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+    ofdm(X, 12.0, 16, sig + pos); pos += 80;
+    memset(X, 0, sizeof(X));
+    for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
+    X[-28 + 32].re = 1; X[-27 + 32].re = 1; X[27 + 32].re = -1; X[28 + 32].re = -1;
+    ofdm(X, 56.0, 16, sig + pos); pos += 80;
+  }
+  if (format == 2) {
+    /* ---- VHT-SIG-B (:512-569) */
+    uint8_t b[26], c[52], it[52];
+    memset(b, 0, sizeof(b));
+    const int l4 = (len + 3) / 4;
+    for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
+    b[17] = b[18] = b[19] = 1;
+    crc8_bits(b, 20, sigb_crc);
+    bcc(b, 26, c);
+    int32_t map[64];
+    c8po_table(4 /* C8P_TAB_DEINT_SIGB */, 0, map, 64);
+    for (int r = 0; r < 52; r++) it[r] = c[map[r]];
+    cd q[52]; for (int i = 0; i < 52; i++) { q[i].re = it[i] ? 1.0 : -1.0; q[i].im = 0; }
+    place(q, 52, pil0, X); ofdm(X, 56.0, 16, sig + pos); pos += 80;
+  }
+  /* ---- data bits (:639-682), scrambling and coding (:684-710) */
+  const int nbits = P.nsym * P.ndbps;
+  uint8_t* d = (uint8_t*)calloc((size_t)nbits + 8, 1);
+  uint8_t* c2 = (uint8_t*)calloc((size_t)nbits * 2 + 16, 1);
+  uint8_t* cp = (uint8_t*)calloc((size_t)P.nsym * P.ncbps + 16, 1);
+  int w = 16;
+  if (format == 2) memcpy(d + 8, sigb_crc, 8);
+  for (int i = 0; i < len; i++) for (int k = 0; k < 8; k++) d[w++] = (uint8_t)((psdu[i] >> k) & 1);
+  if (format == 2) {
+    static const uint8_t EOF32[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0};
+    for (int e = 0; e < P.npad_eof; e++) { memcpy(d + w, EOF32, 32); w += 32; }
+  }
+  {
+    unsigned st = (unsigned)scr_seed;                  /* procScramble :800-806 */
+    for (int i = 0; i < nbits; i++) {
+      const unsigned fb = ((st >> 6) & 1u) ^ ((st >> 3) & 1u);
+      d[i] ^= (uint8_t)fb;
+      st = ((st << 1) & 0x7e) | fb;
+    }
+  }
+  if (format == 2) { for (int i = nbits - 6; i < nbits; i++) d[i] = 0; }     /* tail after scrambling (:692-696) */
+  else { for (int i = 0; i < 6; i++) d[16 + 8 * P.psdu_len + i] = 0; }       /* tail reset (:700-702) */
+  bcc(d, nbits, c2);
+  const int ncoded = puncture(c2, 2 * nbits, P.cr, cp);
+  if (n_coded) *n_coded = ncoded;
+  if (coded_out) memcpy(coded_out, cp, (size_t)ncoded);
+  /* ---- interleave, map, OFDM (:736-819) */
+  int32_t map[512];
+  const int mi = P.nb == 1 ? 0 : P.nb == 2 ? 1 : P.nb == 4 ? 2 : P.nb == 6 ? 3 : 4;
+  c8po_table(format == 0 ? 0 : 1, mi, map, 512);
+  double pil[4] = {1, 1, 1, -1};
+  int pidx = format == 0 ? 1 : format == 1 ? 3 : 4;
+  for (int s = 0; s < P.nsym; s++) {
+    cd q[52];
+    uint8_t bits[8];
+    for (int j = 0; j < P.nsd; j++) {
+      for (int k = 0; k < P.nb; k++) bits[k] = cp[s * P.ncbps + map[j * P.nb + k]];
+      q[j] = qam_point(bits, P.nb);
+    }
+    double pp[4]; for (int k = 0; k < 4; k++) pp[k] = pil[k] * PS127[pidx];
+    place(q, P.nsd, pp, X);
+    ofdm(X, format == 0 ? 52.0 : 56.0, 16, sig + pos); pos += 80;
+    pidx = (pidx + 1) % 127;
+    if (format != 0) { const double t = pil[0]; pil[0] = pil[1]; pil[1] = pil[2]; pil[2] = pil[3]; pil[3] = t; }
+  }
+  /* ---- procConcat2Symbol at every junction (:894-901), amplitude (:839) */
+  for (int b = 160; b < P.n_samp; b += (b < 320 ? 160 : 80)) { sig[b - 1].re *= 0.5; sig[b - 1].im *= 0.5; sig[b].re *= 0.5; sig[b].im *= 0.5; }
+  for (int n = 0; n < P.n_samp; n++) { out[n].re = (float)(sig[n].re * (double)mult); out[n].im = (float)(sig[n].im * (double)mult); }
+  free(sig); free(d); free(c2); free(cp);
+  return P.n_samp;
+}

@@ -194,3 +194,16 @@ def detect(x):
     t = trigger(ac)
     ev, _ = sync(t, cj, x)
     return ev, ac, cj, t
+
+
+# ---- transmit chain (c8p_oracle_tx.c)
+def tx_packet(fmt, mcs, psdu, scr_seed=93, mult=12.0):
+    """fmt 0/1/2 = legacy / HT / VHT; psdu = MPDU bytes (legacy, HT) or A-MPDU bytes (VHT).  Returns (iq complex64, coded bits)."""
+    psdu = np.frombuffer(bytes(psdu), np.uint8).copy()
+    out = np.zeros(400 + 80 * (8 + (8 * len(psdu) + 22) // 24 + 2), np.complex64)
+    coded = np.zeros(2 * (8 * len(psdu) + 22) + 4096, np.uint8)
+    nc = C.c_int(0)
+    n = lib().c8po_tx_packet(int(fmt), int(mcs), _p(psdu), len(psdu), int(scr_seed), C.c_float(mult), _p(out), len(out), _p(coded), C.byref(nc))
+    if n < 0:
+        raise ValueError("c8po_tx_packet rejected (fmt %d mcs %d len %d)" % (fmt, mcs, len(psdu)))
+    return out[:n].copy(), coded[:nc.value].copy()
