@@ -13,9 +13,9 @@ F_L, F_HT, F_VHT, F_VHT_CHAN = 0, 1, 2, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
 BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN, \
-    BUF_DET_EVT, BUF_DET_AC, BUF_DET_TRIG, BUF_DET_CONJ = range(14)
-K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_PRESISO, K_TRIGGER, K_SYNCEVT, K_COUNT = range(10)
-K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal", "presiso", "trigger", "syncevt"]
+    BUF_DET_EVT, BUF_DET_AC, BUF_DET_TRIG, BUF_DET_CONJ, BUF_TX_IQ, BUF_TX_DESC, BUF_TX_CODED = range(17)
+K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_PRESISO, K_TRIGGER, K_SYNCEVT, K_TXBITS, K_TXSYM, K_COUNT = range(12)
+K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal", "presiso", "trigger", "syncevt", "txbits", "txsym"]
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
 DET_HIST = 80
@@ -79,6 +79,25 @@ class DetectIn(C.Structure):
                 ("state", C.c_void_p), ("state_out", C.c_void_p), ("commit", C.c_void_p)]
 
 
+class TxPkt(C.Structure):
+    _fields_ = [("psdu_off", C.c_uint64), ("len", C.c_uint32), ("format", C.c_uint8), ("mcs", C.c_uint8), ("scr_seed", C.c_uint8),
+                ("rsv", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32)]
+
+
+class TxDesc(C.Structure):
+    _fields_ = [("iq_off", C.c_uint64), ("coded_off", C.c_uint64), ("n_samp", C.c_uint32), ("n_coded", C.c_uint32)]
+
+
+class TxIn(C.Structure):
+    _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("pkts", C.c_void_p), ("psdu", C.c_void_p), ("n_psdu", C.c_uint64),
+                ("tail_gap", C.c_uint32), ("rsv", C.c_uint32)]
+
+
+class TxPlan(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("nb", "cr", "ndbps", "ncbps", "nsd", "nsym", "psdu_len", "npad_eof", "npad_octet",
+                                         "legacy_len", "n_pre", "n_samp")]
+
+
 class DecodeIn(C.Structure):
     _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("tags", C.c_void_p), ("llr", C.c_void_p),
                 ("n_llr", C.c_uint64), ("mu2x1chan", C.c_void_p)]
@@ -103,6 +122,8 @@ PKT_TAGS_DT = _np_dtype(PktTags)
 PKT_OUT_DT = _np_dtype(PktOut)
 SIG_IN_DT = _np_dtype(SigIn)
 SYNC_EVT_DT = _np_dtype(SyncEvt)
+TX_PKT_DT = _np_dtype(TxPkt)
+TX_DESC_DT = _np_dtype(TxDesc)
 
 TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
 

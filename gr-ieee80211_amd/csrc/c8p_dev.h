@@ -110,10 +110,9 @@ __device__ __forceinline__ double shfl_d(double v, int src)
   lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T)
+__device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T)
 {
   const int lane = lane_id();
-  double xr = xin.x, xi = xin.y;
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const int half = 32 >> s;
@@ -129,7 +128,18 @@ __device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T
     }
   }
   const int src = T->bitrev6[lane];
-  return mk((float)shfl_d(xr, src), (float)shfl_d(xi, src));
+  return make_double2(shfl_d(xr, src), shfl_d(xi, src));
+}
+__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T)
+{
+  const double2 r = wave_fft64_d((double)xin.x, (double)xin.y, T);
+  return mk((float)r.x, (float)r.y);
+}
+// inverse DFT with the 1/64 of numpy.fft.ifft: ifft(X) = conj(fft(conj(X))) / 64, in double
+__device__ __forceinline__ double2 wave_ifft64_d(double xr, double xi, const DevTables* __restrict__ T)
+{
+  const double2 r = wave_fft64_d(xr, -xi, T);
+  return make_double2(r.x / 64.0, -r.y / 64.0);
 }
 
 __device__ __forceinline__ bool is_null_nl(int i) { return i == 0 || (i >= 29 && i <= 35); }

@@ -17,6 +17,7 @@
 
 #include "c8p_kernels.h"
 #include "c8p_detect.h"
+#include "c8p_tx.h"
 
 #define HIPCHK(ctx, call)                                                                  \
   do {                                                                                     \
@@ -187,6 +188,7 @@ struct Slot {
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
   Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_cnt, d_det_job, d_det_mark,
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
+  Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc;   // transmit chain
   int n_pkt = 0;
   size_t used[C8P_BUF_COUNT] = {};
   const void* ptr[C8P_BUF_COUNT] = {};
@@ -323,7 +325,8 @@ extern "C" void c8p_destroy(c8p_ctx* c)
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt,
                    &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig,
                    &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
-                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire};
+                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_coded, &sl.d_tx_sig,
+                   &sl.d_tx_u2p, &sl.d_tx_iq, &sl.d_tx_desc};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
@@ -872,6 +875,87 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   return C8P_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ transmit chain
+extern "C" int c8p_tx_plan_of(int format, int mcs, int len, c8p_tx_plan* plan)
+{
+  c8p_tx_plan p;
+  const int ok = tx_plan_of(format, mcs, len, p);
+  if (plan) *plan = p;
+  return ok;
+}
+
+// pktgen / encode / modulation for one spatial stream: PSDUs in, one sample stream out (packets
+// separated by the requested gaps of zeros), plus encode's punctured coded bits for parity tests.
+extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->pkts || !in->psdu))) { c->err = "bad tx input"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cur = (c->cur + 1) % (int)c->slots.size();
+  c->s = &c->slots[c->cur];
+  Slot& S = *c->s;
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  drain_events(c);
+  S.n_pkt = in->n_pkt;
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
+  const int n = in->n_pkt;
+  if (n == 0) return C8P_OK;
+  std::vector<TxPlan> plans(n);
+  std::vector<c8p_tx_desc> desc(n);
+  uint64_t iq = 0, coded = 0;
+  uint32_t units = 0;
+  for (int p = 0; p < n; p++) {
+    const c8p_tx_pkt& k = in->pkts[p];
+    TxPlan& P = plans[p];
+    if (!tx_plan_of(k.format, k.mcs, (int)k.len, P.p)) { c->err = "unsupported tx format / mcs / length"; return C8P_EINVAL; }
+    if (k.psdu_off + k.len > in->n_psdu) { c->err = "psdu outside the arena"; return C8P_ERANGE; }
+    if (k.scr_seed == 0 || k.scr_seed > 127) { c->err = "scrambler seed must be 1..127"; return C8P_EINVAL; }
+    iq += k.gap;
+    P.iq_off = iq; P.coded_off = coded; P.psdu_off = k.psdu_off; P.len = k.len;
+    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.mult = k.mult; P.unit_base = units;
+    desc[p].iq_off = iq; desc[p].coded_off = coded; desc[p].n_samp = (uint32_t)P.p.n_samp; desc[p].n_coded = (uint32_t)(P.p.nsym * P.p.ncbps);
+    iq += (uint64_t)P.p.n_samp; coded += ((uint64_t)desc[p].n_coded + 15u) & ~(uint64_t)15u; units += (uint32_t)P.p.n_samp / 80u;
+  }
+  iq += in->tail_gap;
+  int rc;
+  const size_t plan_bytes = align256(sizeof(TxPlan) * (size_t)n), desc_bytes = align256(sizeof(c8p_tx_desc) * (size_t)n);
+  if ((rc = ensure_host(c, plan_bytes + desc_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_plan, plan_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_desc, desc_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_coded, coded + 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_sig, (size_t)C8P_TX_SIGBITS * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_u2p, sizeof(unsigned) * (size_t)(units + 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_iq, sizeof(cf) * (size_t)(iq + 1))) != C8P_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  memcpy(S.h_stage, plans.data(), sizeof(TxPlan) * (size_t)n);
+  memcpy((char*)S.h_stage + plan_bytes, desc.data(), sizeof(c8p_tx_desc) * (size_t)n);
+  HIPCHK(c, hipMemcpyAsync(S.d_tx_plan.p, S.h_stage, sizeof(TxPlan) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+  HIPCHK(c, hipMemcpyAsync(S.d_tx_desc.p, (char*)S.h_stage + plan_bytes, sizeof(c8p_tx_desc) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+  const uint8_t* d_psdu = in->psdu;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, S.d_tx_psdu, in->n_psdu + 16)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_tx_psdu.p, in->psdu, in->n_psdu, hipMemcpyHostToDevice, S.stream));
+    d_psdu = (const uint8_t*)S.d_tx_psdu.p;
+  }
+  HIPCHK(c, hipMemsetAsync(S.d_tx_iq.p, 0, sizeof(cf) * (size_t)iq, S.stream));      // the gaps
+  {
+    KTimer kt(c, C8P_K_TXBITS);
+    hipLaunchKernelGGL(k_tx_bits, dim3(n), dim3(64), 0, S.stream, (const TxPlan*)S.d_tx_plan.p, d_psdu, (const DevTables*)c->d_tab,
+                       (uint8_t*)S.d_tx_coded.p, (uint8_t*)S.d_tx_sig.p, (unsigned*)S.d_tx_u2p.p, n);
+  }
+  {
+    KTimer kt(c, C8P_K_TXSYM);
+    hipLaunchKernelGGL(k_tx_sym, dim3((units + 3) / 4), dim3(256), 0, S.stream, (const TxPlan*)S.d_tx_plan.p, (const unsigned*)S.d_tx_u2p.p,
+                       (const uint8_t*)S.d_tx_coded.p, (const uint8_t*)S.d_tx_sig.p, (const DevTables*)c->d_tab, (cf*)S.d_tx_iq.p, units);
+  }
+  HIPCHK(c, hipGetLastError());
+  S.used[C8P_BUF_TX_IQ] = sizeof(cf) * (size_t)iq; S.ptr[C8P_BUF_TX_IQ] = S.d_tx_iq.p;
+  S.used[C8P_BUF_TX_DESC] = sizeof(c8p_tx_desc) * (size_t)n; S.ptr[C8P_BUF_TX_DESC] = S.d_tx_desc.p;
+  S.used[C8P_BUF_TX_CODED] = coded; S.ptr[C8P_BUF_TX_CODED] = S.d_tx_coded.p;
+  return C8P_OK;
+}
+
 extern "C" int c8p_sync(c8p_ctx* c)
 {
   if (!c) return C8P_EINVAL;
@@ -919,7 +1003,8 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
   const int32_t v[] = {C8P_ABI_VERSION, (int32_t)sizeof(c8p_pkt_in), (int32_t)sizeof(c8p_pkt_tags), (int32_t)sizeof(c8p_pkt_out),
                        (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
                        (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
-                       (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state)};
-  for (int i = 0; i < 12 && i < cap; i++) dst[i] = v[i];
-  return 12;
+                       (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state), (int32_t)sizeof(c8p_tx_pkt),
+                       (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan)};
+  for (int i = 0; i < 16 && i < cap; i++) dst[i] = v[i];
+  return 16;
 }

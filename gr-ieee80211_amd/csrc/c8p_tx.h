@@ -1,0 +1,286 @@
+// c8p_tx.h — transmit chain for one spatial stream at 20 MHz, long GI, on gfx950 (SURVEY.md §8f-4 "TX-lite"):
+// what lib/encode_impl.cc + lib/modulation_impl.cc (cloud80211phy.cc:2594-3180) / tools/phy80211.py produce.
+//
+//   k_tx_bits   wave = packet.  SIG fields (L-SIG, HT-SIG, VHT-SIG-A/B: rate-1/2 BCC + interleave, lane 0), then the data
+//               field: service + PSDU (+ VHT EOF / zero padding) assembled 64 bits per lane-word, scrambled with the
+//               packed doubled LFSR sequence, tail zeroed, and BCC + puncturing evaluated per OUTPUT bit (every coded
+//               bit is a parity over a 7-bit window of the packed data bits) — nothing is sequential.
+//   k_tx_sym    wave = 80 output samples, lane = subcarrier.  Field by field: training sequences, BPSK / QBPSK SIG
+//               symbols, data symbols (interleaver map -> constellation point from the Gray recursion, pilots with the
+//               127-periodic polarity and the HT/VHT rotation), 64-point inverse FFT across the wave in fp64, GI,
+//               half-amplitude samples at every field junction (procConcat2Symbol), amplitude.
+#pragma once
+#include "c8p_dev.h"
+
+struct TxPlan {            // c8p_tx_plan + where the packet's outputs go
+  c8p_tx_plan p;
+  unsigned long long iq_off, coded_off, psdu_off;
+  unsigned int len;
+  int format, mcs, seed;
+  float mult;
+  unsigned int unit_base;  // first 80-sample unit of this packet in k_tx_sym's grid
+};
+#define C8P_TX_SIGBITS 256  // per packet: L-SIG 48 | SIG-1 48 | SIG-2 48 | SIG-B 52 interleaved coded bits
+
+__host__ __device__ __forceinline__ int tx_rate(int format, int mcs, c8p_tx_plan& r)
+{
+  const int nbL[8] = {1, 1, 2, 2, 4, 4, 6, 6}, crL[8] = {0, 2, 0, 2, 0, 2, 1, 2};
+  const int nbN[10] = {1, 2, 2, 4, 4, 6, 6, 6, 8, 8}, crN[10] = {0, 0, 2, 0, 2, 1, 2, 3, 2, 3};
+  if (format == C8P_F_L) { if (mcs < 0 || mcs > 7) return 0; r.nb = nbL[mcs]; r.cr = crL[mcs]; r.nsd = 48; }
+  else if (format == C8P_F_HT || format == C8P_F_VHT) { if (mcs < 0 || mcs > (format == C8P_F_HT ? 7 : 8)) return 0; r.nb = nbN[mcs]; r.cr = crN[mcs]; r.nsd = 52; }
+  else return 0;
+  r.ncbps = r.nsd * r.nb;
+  r.ndbps = r.cr == 0 ? r.ncbps / 2 : r.cr == 1 ? r.ncbps * 2 / 3 : r.cr == 2 ? r.ncbps * 3 / 4 : r.ncbps * 5 / 6;
+  return 1;
+}
+// tools/phy80211header.py procPktLenNonAggre :427-459 / procPktLenAggre :461-506 (cloud80211phy.cc:2487-2524)
+__host__ __device__ __forceinline__ int tx_plan_of(int format, int mcs, int len, c8p_tx_plan& p)
+{
+  p = c8p_tx_plan{};
+  if (!tx_rate(format, mcs, p) || len <= 0 || len > 4095) return 0;
+  p.nsym = (8 * len + 16 + 6 + p.ndbps - 1) / p.ndbps;
+  if (format == C8P_F_VHT) {
+    p.psdu_len = (p.nsym * p.ndbps - 16 - 6) / 8;
+    p.npad_eof = (p.psdu_len - len) / 4;
+    p.npad_octet = p.psdu_len - len - p.npad_eof * 4;
+    p.legacy_len = ((20 + 8 + 4 + 4 + 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
+    p.n_pre = 5;
+  } else {
+    p.psdu_len = len;
+    p.legacy_len = format == C8P_F_L ? len : ((20 + 8 + 4 + 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
+    p.n_pre = format == C8P_F_L ? 0 : 4;
+  }
+  p.n_samp = 320 + 80 * (1 + p.n_pre + p.nsym);
+  return 1;
+}
+
+__device__ __forceinline__ void tx_bcc_sig(const uint8_t* b, int n, uint8_t* c)   // rate 1/2: A (0155), B (0117) on st = {.., in[j-1], in[j]}
+{
+  unsigned st = 0;
+  for (int j = 0; j < n; j++) {
+    st = ((st << 1) & 0x7e) | b[j];
+    c[2 * j] = (uint8_t)(__popc(st & 0155) & 1);
+    c[2 * j + 1] = (uint8_t)(__popc(st & 0117) & 1);
+  }
+}
+__device__ __forceinline__ void tx_crc8(const uint8_t* b, int n, uint8_t* out8)
+{
+  unsigned c = 0xff;
+  for (int i = 0; i < n; i++) {
+    const unsigned fb = ((c >> 7) & 1u) ^ b[i];
+    c = (c << 1) & 0xffu;
+    if (fb) c ^= 0x07u;
+  }
+  c ^= 0xffu;
+  for (int i = 0; i < 8; i++) out8[i] = (uint8_t)((c >> (7 - i)) & 1u);
+}
+// byte b of the padded PSDU: the caller's bytes, then (VHT) EOF delimiters {01 00 79 4e}, then zero octets
+__device__ __forceinline__ unsigned tx_psdu_byte(const uint8_t* __restrict__ psdu, int b, int len, int npad_eof)
+{
+  if (b < 0) return 0u;
+  if (b < len) return psdu[b];
+  const int e = b - len;
+  if (e < 4 * npad_eof) { const int k = e & 3; return k == 0 ? 0x01u : k == 1 ? 0x00u : k == 2 ? 0x79u : 0x4eu; }
+  return 0u;
+}
+
+__global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans, const uint8_t* __restrict__ psdu_arena,
+                                                const DevTables* __restrict__ T, uint8_t* __restrict__ coded,
+                                                uint8_t* __restrict__ sigbits, unsigned int* __restrict__ unit2pkt, int n)
+{
+  __shared__ unsigned long long dw[(C8P_DECODE_T_MAX + 63) / 64 + 2];   // scrambled data bits, 64 per word
+  __shared__ uint8_t s_crc[8];
+  const int p = blockIdx.x;
+  if (p >= n) return;
+  const int lane = lane_id();
+  const TxPlan P = plans[p];
+  const c8p_tx_plan& m = P.p;
+  uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
+  for (unsigned i = lane; i < (unsigned)m.n_samp / 80u; i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
+  if (lane == 0) {
+    uint8_t b[48], c[96];
+    // ---- L-SIG  tools/phy80211.py:237-282
+    for (int i = 0; i < 24; i++) b[i] = 0;
+    const int rate = P.format == C8P_F_L ? P.mcs : 0;
+    const unsigned rb = rate == 0 ? 0xBu : rate == 1 ? 0xFu : rate == 2 ? 0xAu : rate == 3 ? 0xEu : rate == 4 ? 0x9u : rate == 5 ? 0xDu : rate == 6 ? 0x8u : 0xCu;
+    for (int i = 0; i < 4; i++) b[i] = (uint8_t)((rb >> i) & 1u);                 // C_LEGACY_RATE_BIT
+    for (int i = 0; i < 12; i++) b[5 + i] = (uint8_t)((m.legacy_len >> i) & 1);
+    int par = 0; for (int i = 0; i < 17; i++) par += b[i];
+    b[17] = (uint8_t)(par & 1);
+    tx_bcc_sig(b, 24, c);
+    for (int k = 0; k < 48; k++) sb[3 * (k % 16) + k / 16] = c[k];                 // procInterleaveSigL
+    for (int i = 0; i < 8; i++) s_crc[i] = 0;
+    if (P.format != C8P_F_L) {
+      for (int i = 0; i < 48; i++) b[i] = 0;
+      if (P.format == C8P_F_HT) {                                                   // :284-350
+        for (int i = 0; i < 7; i++) b[i] = (uint8_t)((P.mcs >> i) & 1);
+        for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((m.psdu_len >> i) & 1);
+        b[24] = 1; b[25] = 1; b[26] = 1;
+      } else {                                                                      // :352-455, SU, group id 0, partial AID 0
+        b[2] = 1; b[23] = 1;
+        for (int i = 0; i < 4; i++) b[28 + i] = (uint8_t)((P.mcs >> i) & 1);
+        b[33] = 1;
+      }
+      tx_crc8(b, 34, b + 34);
+      tx_bcc_sig(b, 48, c);
+      for (int h = 0; h < 2; h++) for (int k = 0; k < 48; k++) sb[48 + 48 * h + 3 * (k % 16) + k / 16] = c[48 * h + k];
+    }
+    if (P.format == C8P_F_VHT) {                                                    // :512-569
+      for (int i = 0; i < 26; i++) b[i] = 0;
+      const int l4 = ((int)P.len + 3) / 4;
+      for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
+      b[17] = b[18] = b[19] = 1;
+      tx_crc8(b, 20, s_crc);
+      tx_bcc_sig(b, 26, c);
+      for (int r = 0; r < 52; r++) sb[144 + r] = c[T->deintSigB[r]];
+    }
+  }
+  __syncthreads();
+  // ---- data bits, 64 per word: bit i = service (16) | PSDU bits LSB first | zeros     :639-682
+  const int nbits = m.nsym * m.ndbps;
+  const int nw = (nbits + 63) >> 6;
+  const uint8_t* psdu = psdu_arena + P.psdu_off;
+  const int ph = T->scrPhase[P.seed & 127];
+  for (int c = lane; c < nw; c += 64) {
+    unsigned long long w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w |= (unsigned long long)tx_psdu_byte(psdu, 8 * c - 2 + k, (int)P.len, m.npad_eof) << (8 * k);
+    if (c == 0 && P.format == C8P_F_VHT)
+      for (int i = 0; i < 8; i++) w |= (unsigned long long)s_crc[i] << (8 + i);    // service bits 8..15 = SIG-B CRC
+    // scramble: output bit of data bit i = seq[(ph + i) mod 127]                       procScramble :800-806
+    const int o = (ph + 64 * c) % 127, wi = o >> 6, sh = o & 63;
+    unsigned long long sq = T->scrW[wi] >> sh;
+    if (sh) sq |= T->scrW[wi + 1] << (64 - sh);
+    w ^= sq;
+    if (64 * c + 64 > nbits) w &= (1ull << (nbits - 64 * c)) - 1ull;
+    dw[c] = w;
+  }
+  if (lane == 0) dw[nw] = 0ull;
+  __syncthreads();
+  if (lane == 0) {        // tail bits are zero AFTER scrambling (:692-702)
+    const int t0 = P.format == C8P_F_VHT ? nbits - 6 : 16 + 8 * m.psdu_len;
+    for (int i = t0; i < t0 + 6; i++) dw[i >> 6] &= ~(1ull << (i & 63));
+  }
+  __syncthreads();
+  // ---- BCC + puncturing, one coded bit per lane and pass                               procBcc :763-798
+  const int ncoded = m.nsym * m.ncbps;
+  uint8_t* out = coded + P.coded_off;
+  for (int q = lane; q < ncoded; q += 64) {
+    int j, second;                                     // input bit index, 0: output A (g0 = 133), 1: output B (g1 = 171)
+    if (m.cr == C8P_CR_12) { j = q >> 1; second = q & 1; }
+    else if (m.cr == C8P_CR_23) { const int g = q / 3, r = q - 3 * g; j = 2 * g + (r == 2); second = r == 1; }
+    else if (m.cr == C8P_CR_34) { const int g = q >> 2, r = q & 3; j = 3 * g + (r >= 2 ? r - 1 : 0); second = (r == 1 || r == 3); }
+    else { const int g = q / 6, r = q - 6 * g; j = 5 * g + (r <= 1 ? 0 : r - 1); second = (r == 1 || r == 3 || r == 5); }
+    // window: bit k of `win` = data bit j - 6 + k (zero before the start)
+    const int lo = j - 6;
+    unsigned win;
+    if (lo >= 0) {
+      const int wi2 = lo >> 6, sh2 = lo & 63;
+      unsigned long long v = dw[wi2] >> sh2;
+      if (sh2 > 57) v |= dw[wi2 + 1] << (64 - sh2);
+      win = (unsigned)v & 0x7fu;
+    } else win = ((unsigned)dw[0] << (-lo)) & 0x7fu;
+    out[q] = (uint8_t)(__popc(win & (second ? 0171u : 0133u)) & 1);
+  }
+}
+
+// Gray recursion of C_QAM_MODU_TAB: h bits per axis, least significant chip bit first, level from the LLR recursion run backwards
+__device__ __forceinline__ double tx_axis(const uint8_t* b, int h)
+{
+  const double A = h == 1 ? 0.0 : (double)(1 << (h - 1));
+  double v = b[h - 1] ? 1.0 : -1.0;
+  for (int k = h - 1; k >= 1; k--) { const double Tk = A / (double)(1 << (k - 1)); v = (b[k - 1] ? 1.0 : -1.0) * (Tk - v); }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans, const unsigned int* __restrict__ unit2pkt,
+                                                const uint8_t* __restrict__ coded, const uint8_t* __restrict__ sigbits,
+                                                const DevTables* __restrict__ T, cf* __restrict__ iq, unsigned int total_units)
+{
+  __shared__ double2 st[4][64];
+  const unsigned int u = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (u >= total_units) return;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int p = (int)unit2pkt[u];
+  const TxPlan P = plans[p];
+  const c8p_tx_plan& m = P.p;
+  const int unit = (int)(u - P.unit_base);            // 80-sample unit inside the packet: 0,1 L-STF  2,3 L-LTF  4 L-SIG  5.. pre  then data
+  const int k = lane < 32 ? lane : lane - 64;         // subcarrier of this lane's bin
+  const int ak = k < 0 ? -k : k;
+  double xr = 0.0, xi = 0.0, ntf = 52.0;
+  const uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
+  const bool pilot_bin = ak == 7 || ak == 21;
+  const int pil_i = k == -21 ? 0 : k == -7 ? 1 : k == 7 ? 2 : 3;
+  const bool vht = P.format == C8P_F_VHT;
+  enum { F_STF, F_LLTF, F_NLLTF, F_SIG, F_SIGB, F_DATA } kind;
+  int sig_off = 0, sig_q = 0, dsym = 0;
+  if (unit < 2) kind = F_STF;
+  else if (unit < 4) kind = F_LLTF;
+  else if (unit == 4) { kind = F_SIG; sig_off = 0; }
+  else {
+    const int q = unit - 5;                           // index among the pre symbols
+    if (q < m.n_pre) {
+      if (q < 2) { kind = F_SIG; sig_off = 48 + 48 * q; sig_q = (P.format == C8P_F_HT || q == 1) ? 1 : 0; }   // HT-SIG: QBPSK x2, VHT-SIG-A: BPSK, QBPSK
+      else if (q == 2) kind = F_STF;
+      else if (q == 3) kind = F_NLLTF;
+      else kind = F_SIGB;
+    } else { kind = F_DATA; dsym = q - m.n_pre; }
+  }
+  if (kind == F_STF) {                                // C_STF_L / C_STF_HT / C_STF_VHT: +-(1+j)/sqrt(2) on every 4th subcarrier
+    ntf = 12.0;
+    if (ak >= 4 && ak <= 24 && (ak & 3) == 0) {
+      const int mi = k < 0 ? (k + 24) / 4 : 6 + (k - 4) / 4;
+      const int sgn = (0xF25u >> mi) & 1u ? 1 : -1;   // {1,-1,1,-1,-1,1, -1,-1,1,1,1,1}
+      xr = xi = sgn * 0.70710678118654757;
+    }
+  } else if (kind == F_LLTF) { ntf = 52.0; xr = (double)T->ltfL[lane]; }
+  else if (kind == F_NLLTF) { ntf = 56.0; xr = (double)T->ltfNL[lane]; }
+  else if (kind == F_SIG) {
+    ntf = 52.0;
+    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
+    else if (ak >= 1 && ak <= 26) { const double v = sb[sig_off + qidx_l(lane)] ? 1.0 : -1.0; if (sig_q) xi = v; else xr = v; }
+  } else if (kind == F_SIGB) {
+    ntf = 56.0;
+    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
+    else if (ak >= 1 && ak <= 28) xr = sb[144 + qidx_nl(lane)] ? 1.0 : -1.0;
+  } else {
+    const bool leg = P.format == C8P_F_L;
+    ntf = leg ? 52.0 : 56.0;
+    const int lim = leg ? 26 : 28;
+    const int p0 = leg ? 1 : (vht ? 4 : 3);
+    const float pol = T->pilotP[(p0 + dsym) % 127];
+    if (pilot_bin) {                                  // base {1,1,1,-1}, rotated left by one per symbol for HT / VHT (:811-818)
+      const int idx = leg ? pil_i : ((pil_i + dsym) & 3);
+      xr = (double)((idx == 3 ? -1.0f : 1.0f) * pol);
+    } else if (ak >= 1 && ak <= lim) {
+      const int j = leg ? qidx_l(lane) : qidx_nl(lane);
+      const int mi = nbpsc_index(m.nb);
+      const int16_t* map = leg ? T->deintL[mi] : T->deintNL[mi];
+      const uint8_t* cb = coded + P.coded_off + (size_t)dsym * m.ncbps;
+      uint8_t bits[8];
+      for (int b = 0; b < m.nb; b++) bits[b] = cb[map[j * m.nb + b]];
+      if (m.nb == 1) xr = bits[0] ? 1.0 : -1.0;
+      else {
+        const int h = m.nb >> 1;
+        const double sc = m.nb == 2 ? 1.4142135623730951 : m.nb == 4 ? 3.1622776601683795 : m.nb == 6 ? 6.4807406984078604 : 13.038404810405298;
+        xr = tx_axis(bits, h) / sc; xi = tx_axis(bits + h, h) / sc;
+      }
+    }
+  }
+  const double2 t = wave_ifft64_d(xr, xi, T);
+  const double sc = 1.0 / sqrt(ntf);
+  st[wv][lane] = make_double2(t.x * sc, t.y * sc);
+  __syncthreads();
+  // ---- 80 output samples: GI (or the 160-sample training field layout), junction halving, amplitude
+  const int n_samp = m.n_samp;
+  for (int mm = lane; mm < 80; mm += 64) {
+    int src;
+    if (unit < 4) { const int f = (unit & 1) * 80 + mm; src = f < 32 ? 32 + f : (f - 32) & 63; }   // t[32:] + t + t
+    else src = mm < 16 ? 48 + mm : mm - 16;
+    const int g = unit * 80 + mm;
+    double2 v = st[wv][src];
+    const bool junction = (g == 159 || g == 160) || (g >= 319 && ((g + 1) % 80 == 0) && g + 1 < n_samp) || (g >= 320 && (g % 80 == 0));
+    const double a = (double)P.mult * (junction ? 0.5 : 1.0);
+    iq[P.iq_off + (unsigned long long)g] = mk((float)(v.x * a), (float)(v.y * a));
+  }
+}

@@ -167,6 +167,36 @@ typedef struct c8p_tx_plan {
   int32_t n_samp;                     /* samples of the packet                                                      */
 } c8p_tx_plan;
 
+/* One packet to transmit (1 spatial stream, 20 MHz, long GI): what pktgen -> encode -> modulation take from the
+ * "packet" PDU (lib/pktgen_impl.cc, lib/encode_impl.cc:110-160), or tools/phy80211.py genFromMpdu / genFromAmpdu. */
+typedef struct c8p_tx_pkt {
+  uint64_t psdu_off;    /* byte offset of the PSDU inside the psdu arena: the MPDU (legacy, HT) or the A-MPDU (VHT)  */
+  uint32_t len;         /* its length in bytes                                                                       */
+  uint8_t  format;      /* C8P_F_L / C8P_F_HT / C8P_F_VHT                                                            */
+  uint8_t  mcs;         /* legacy 0-7, HT 0-7, VHT 0-8                                                               */
+  uint8_t  scr_seed;    /* initial scrambler state, 1..127 (the reference toolbox uses 93)                           */
+  uint8_t  rsv;
+  float    mult;        /* amplitude multiplier (genFinalSig; tools/pktGenExample.py uses 12.0)                      */
+  uint32_t gap;         /* zero items inserted in the output stream before this packet                               */
+} c8p_tx_pkt;
+
+typedef struct c8p_tx_desc {  /* per packet, in C8P_BUF_TX_DESC */
+  uint64_t iq_off;      /* item offset of the packet's first sample inside C8P_BUF_TX_IQ (after its gap)             */
+  uint64_t coded_off;   /* byte offset of its punctured coded bits (1 bit per byte) inside C8P_BUF_TX_CODED          */
+  uint32_t n_samp;      /* samples                                                                                   */
+  uint32_t n_coded;     /* coded bits = nsym * ncbps                                                                 */
+} c8p_tx_desc;
+
+typedef struct c8p_tx_in {
+  int32_t n_pkt;
+  int32_t mem;              /* C8P_MEM_* of psdu                                                         */
+  const c8p_tx_pkt* pkts;   /* [n_pkt], host memory                                                      */
+  const uint8_t* psdu;      /* PSDU byte arena                                                           */
+  uint64_t n_psdu;
+  uint32_t tail_gap;        /* zero items appended after the last packet                                 */
+  uint32_t rsv;
+} c8p_tx_in;
+
 typedef struct c8p_cfg {
   int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
   int32_t device;           /* HIP device ordinal                                                      */
@@ -248,7 +278,10 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_DET_AC   11 /* float[n - n_hist]: presiso output 0 (autocorrelation magnitude / energy) of the new items  */
 #define C8P_BUF_DET_TRIG 12 /* uint8[n - n_hist]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
 #define C8P_BUF_DET_CONJ 13 /* c8p_c32[n - n_hist] (keep = 1): presiso output 1                                       */
-#define C8P_BUF_COUNT    14
+#define C8P_BUF_TX_IQ    14 /* c8p_c32[]: the transmitted stream, packets at tx_desc[p].iq_off, gaps are zeros                     */
+#define C8P_BUF_TX_DESC  15 /* c8p_tx_desc[n_pkt]                                                                              */
+#define C8P_BUF_TX_CODED 16 /* uint8[]: punctured coded bits (encode's output), 1 bit per byte                                 */
+#define C8P_BUF_COUNT    17
 
 /* kernels, for c8p_kernel_time() */
 #define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */
@@ -260,7 +293,9 @@ typedef struct c8p_decode_in {
 #define C8P_K_PRESISO  6    /* windowed autocorrelation scan (HBM-bound) */
 #define C8P_K_TRIGGER  7    /* plateau / running-max scan (three passes) */
 #define C8P_K_SYNCEVT  8    /* per-trigger LTF search + CFO              */
-#define C8P_K_COUNT    9
+#define C8P_K_TXBITS   9    /* scramble + BCC + puncture + SIG fields   */
+#define C8P_K_TXSYM    10   /* interleave + map + pilots + IFFT + GI    */
+#define C8P_K_COUNT    11
 
 typedef struct c8p_ctx c8p_ctx;
 
@@ -274,6 +309,8 @@ int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS,
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
 int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
+int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */
+int c8p_tx_plan_of(int format, int mcs, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
 int c8p_sync  (c8p_ctx* ctx);
 
 /* Device pointer / size in bytes of a result arena of the last submit. */
@@ -297,7 +334,7 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
 
-/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state} as compiled into the library. */
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc, tx_in, tx_plan} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

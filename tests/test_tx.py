@@ -1,0 +1,175 @@
+"""Transmit chain, one spatial stream (SURVEY.md §8f-4 "TX-lite").
+
+CPU: the oracle's restatement of the reference TX reproduces the reference toolbox's own output — IQ and punctured coded
+bits of all 31 single-stream fixtures (legacy MCS 0-7, HT MCS 0-7, VHT MCS 0-8, BASELINE cfg 1 / 2 / 4) — and closes the
+loop through the detect / signal / demod / decode oracle.
+GPU: c8p_tx against that oracle (coded bits identical, IQ within 1e-6 of the packet's peak: the IFFT runs in fp64 on both
+sides, only the summation order differs), then a device-resident loopback c8p_tx -> AWGN -> c8p_detect -> c8p_signal ->
+c8p_rx whose PDUs must be the transmitted MPDUs."""
+import zlib
+
+import numpy as np
+import pytest
+
+from c8p_testlib import abi, load_npz, oracle, oracle_rx
+
+FIX = {}
+for _fn in ("packets_sweep.npz", "packets_cfg.npz"):
+    for _name, _d in load_npz(_fn).items():
+        if int(_d["nss"]) == 1 and len(_d["mpdu"]):
+            FIX[_name] = _d
+
+
+def ampdu_vht(mpdu):
+    """mac80211.genAmpduVHT([mpdu]) (tools/mac80211.py:333-360): delimiter {EOF, reserved, len[12:14], len[0:12], CRC-8,
+    signature 0x4e} + MPDU, padded to a multiple of 4 bytes"""
+    n = len(mpdu)
+    lb = [(n >> i) & 1 for i in range(14)]
+    bits = [1, 0] + lb[12:14] + lb[0:12]
+    c = [1] * 8
+    for b in bits:
+        c = [b ^ c[7], b ^ c[7] ^ c[0], b ^ c[7] ^ c[1]] + c[2:7]
+    bits = bits + [1 - b for b in c[::-1]] + [(0x4E >> i) & 1 for i in range(8)]
+    d = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(4))
+    pkt = d + bytes(mpdu)
+    return pkt + b"\x00" * ((-len(pkt)) % 4)
+
+
+def psdu_of(fmt, mpdu):
+    return ampdu_vht(mpdu) if fmt == abi.F_VHT else bytes(mpdu)
+
+
+def mpdu_with_fcs(rng, n):
+    body = bytes(rng.integers(0, 256, size=n - 4, dtype=np.uint8))
+    return body + zlib.crc32(body).to_bytes(4, "little")
+
+
+@pytest.mark.parametrize("name", sorted(FIX))
+def test_oracle_tx_reproduces_the_reference_toolbox(name):
+    d = FIX[name]
+    fmt, mcs = int(d["fmt"]), int(d["mcs"])
+    ps = psdu_of(fmt, d["mpdu"].tobytes())
+    if fmt == abi.F_VHT:
+        assert len(ps) == int(d["psdu_len"])
+    iq, coded = oracle().tx_packet(fmt, mcs, ps)           # seed 93, multiplier 12: tools/phy80211.py:40, pktGenExample.py:187
+    tx = d["tx"][0]
+    assert len(iq) == len(tx)
+    assert np.array_equal(coded, d["coded"])
+    assert np.max(np.abs(iq - tx)) <= 1e-6 * np.max(np.abs(tx))
+
+
+def random_packets(rng, n, lens=(14, 1600)):
+    specs = []
+    for _ in range(n):
+        fmt = int(rng.integers(0, 3))
+        mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+        ln = int(rng.integers(*lens))
+        mpdu = mpdu_with_fcs(rng, ln)
+        specs.append((fmt, mcs, mpdu, psdu_of(fmt, mpdu)))
+    return specs
+
+
+def tx_batch(specs, gap=700, seed=93, mult=12.0):
+    pk = np.zeros(len(specs), abi.TX_PKT_DT)
+    arena, off = [], 0
+    for i, (fmt, mcs, mpdu, ps) in enumerate(specs):
+        pk[i]["psdu_off"], pk[i]["len"], pk[i]["format"], pk[i]["mcs"] = off, len(ps), fmt, mcs
+        pk[i]["scr_seed"], pk[i]["mult"], pk[i]["gap"] = seed, mult, gap
+        arena.append(np.frombuffer(ps, np.uint8))
+        off += len(ps)
+    return pk, np.concatenate(arena)
+
+
+def test_oracle_loopback_tx_to_pdus():
+    from test_detect_frontend import consume_filter, sig_events
+    rng = np.random.default_rng(21)
+    o = oracle()
+    specs = random_packets(rng, 10, lens=(20, 400))
+    parts = []
+    for fmt, mcs, mpdu, ps in specs:
+        iq, _ = o.tx_packet(fmt, mcs, ps, mult=0.3)
+        parts += [np.zeros(600, np.complex64), iq]
+    x = np.concatenate(parts + [np.zeros(600, np.complex64)])
+    sigma = 0.3 * 0.0156 / 10 ** (30 / 20)                 # ~30 dB below the packet power (|x|^2 ~ mult^2 / 64^2 per tone set)
+    x = (x + sigma * (rng.normal(size=len(x)) + 1j * rng.normal(size=len(x)))).astype(np.complex64)
+    ev, _, _, _ = o.detect(x)
+    spk, siq, schan = o.signal_events(sig_events(ev, len(x)), x)
+    keep = consume_filter(ev, spk)
+    assert len(keep) == len(specs)
+    res = oracle_rx(spk[keep], siq, schan)
+    for r, (fmt, mcs, mpdu, ps) in zip(res, specs):
+        assert r["pdus"] == [bytes([fmt, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs])]
+
+
+@pytest.mark.gpu
+def test_gpu_tx_matches_oracle():
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(5)
+    specs = [(int(d["fmt"]), int(d["mcs"]), d["mpdu"].tobytes(), psdu_of(int(d["fmt"]), d["mpdu"].tobytes())) for d in FIX.values()]
+    for fmt in range(3):                                   # awkward lengths: minimum, odd, block edges, maximum
+        for mcs in (0, 7, 8 if fmt == 2 else 5):
+            for ln in (1, 2, 3, 4, 5, 13, 14, 15, 63, 64, 65, 1023, 4092, 4095):
+                if fmt == 2:
+                    ln = min(ln + (-ln) % 4, 4092)         # an A-MPDU is a multiple of 4 bytes
+                specs.append((fmt, mcs, b"", bytes(rng.integers(0, 256, size=ln, dtype=np.uint8))))
+    pk, arena = tx_batch(specs, gap=0)
+    pk["scr_seed"] = [93 if i < len(FIX) else int(rng.integers(1, 128)) for i in range(len(pk))]
+    eng = engine.Engine(device=0)
+    eng.tx(pk, arena)
+    eng.sync()
+    iq = eng.fetch(abi.BUF_TX_IQ, np.complex64)
+    coded = eng.fetch(abi.BUF_TX_CODED, np.uint8)
+    desc = eng.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)
+    eng.close()
+    o = oracle()
+    for i, (fmt, mcs, mpdu, ps) in enumerate(specs):
+        oiq, ocoded = o.tx_packet(fmt, mcs, ps, scr_seed=int(pk[i]["scr_seed"]))
+        d = desc[i]
+        assert int(d["n_samp"]) == len(oiq) and int(d["n_coded"]) == len(ocoded), (i, fmt, mcs, len(ps))
+        got = iq[int(d["iq_off"]):int(d["iq_off"]) + len(oiq)]
+        assert np.array_equal(coded[int(d["coded_off"]):int(d["coded_off"]) + len(ocoded)], ocoded), (i, fmt, mcs, len(ps))
+        assert np.max(np.abs(got - oiq)) <= 1e-6 * np.max(np.abs(oiq)), (i, fmt, mcs, len(ps))
+    for name, d, i in zip(FIX, FIX.values(), range(len(FIX))):      # and the toolbox's own output, directly
+        got = iq[int(desc[i]["iq_off"]):int(desc[i]["iq_off"]) + int(desc[i]["n_samp"])]
+        assert np.max(np.abs(got - d["tx"][0])) <= 1e-6 * np.max(np.abs(d["tx"][0])), name
+
+
+@pytest.mark.gpu
+def test_gpu_loopback_tx_noise_detect_signal_rx():
+    """everything on the device: c8p_tx -> AWGN (torch) -> c8p_detect -> c8p_signal -> c8p_rx; PDUs = transmitted MPDUs"""
+    import torch
+    from gr_ieee80211_amd import engine
+    from test_detect_frontend import consume_filter, sig_events
+    rng = np.random.default_rng(33)
+    specs = random_packets(rng, 200, lens=(30, 1500))
+    pk, arena = tx_batch(specs, gap=500, mult=0.3)
+    eng = engine.Engine(device=0)
+    eng.tx(pk, arena, tail_gap=600)
+    eng.sync()
+    p_iq, nbytes = eng.buffer(abi.BUF_TX_IQ)
+    n = nbytes // 8
+    clean = torch.from_numpy(eng.fetch(abi.BUF_TX_IQ, np.complex64).view(np.float32)).cuda()
+    torch.manual_seed(1)
+    noisy = clean + 1.0e-4 * torch.randn_like(clean)      # ~33 dB SNR
+    x = engine.DevArray(noisy.data_ptr(), n, noisy)
+    e2 = engine.Engine(device=0)
+    ev = e2.detect(x)
+    e3 = engine.Engine(device=0)
+    e3.signal(sig_events(ev, n), x)
+    e3.sync()
+    gpk = e3.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    keep = consume_filter(ev, gpk)
+    assert len(keep) == len(specs)
+    pi, bi = e3.buffer(abi.BUF_SIG_IQ)
+    pc, bc = e3.buffer(abi.BUF_SIG_CHAN)
+    e4 = engine.Engine(device=0)
+    e4.rx(gpk[keep], engine.DevArray(pi, bi // 8), engine.DevArray(pc, bc // 8))
+    res = e4.results(want_llr=False)
+    ok = 0
+    for r, (fmt, mcs, mpdu, ps) in zip(res, specs):
+        want = bytes([fmt, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs])
+        assert r["pdus"] in ([], [want])
+        ok += r["pdus"] == [want]
+    assert ok >= 0.97 * len(specs), ok
+    for e in (eng, e2, e3, e4):
+        e.close()
