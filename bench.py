@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fixture-workload", action="store_true", help="replicate the 4 committed reference-TX frames (host-generated) "
+                    "instead of generating 4096 distinct packets on the device with c8p_tx")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
     ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
@@ -52,19 +54,27 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from c8p_cases import cfg2_batch
+    from c8p_cases import cfg2_batch, cfg2_workload_on_device
     from c8p_testlib import abi
     from gr_ieee80211_amd import engine
 
-    # ---- synthetic workload (host), then resident in HBM
+    # ---- synthetic workload, resident in HBM before anything is timed
     t_gen = time.time()
-    b, expected = cfg2_batch(args.batch, snr_db=args.snr, seed=8021200 + 100000 * rank)
-    pk, iq, chan = b.arrays()
+    if args.fixture_workload:
+        b, expected = cfg2_batch(args.batch, snr_db=args.snr, seed=8021200 + 100000 * rank)
+        pk, iq, chan = b.arrays()
+        iq_d = torch.from_numpy(iq.view(np.float32)).to(dev)
+        chan_d = torch.from_numpy(chan.view(np.float32)).to(dev)
+        iq_dev = engine.DevArray(iq_d.data_ptr(), iq.size, iq_d)
+        chan_dev = engine.DevArray(chan_d.data_ptr(), chan.size, chan_d)
+        data_note = "synthetic"
+    else:
+        # 4096 distinct MPDUs, generated on the box by the build's own transmitter (c8p_tx), per-packet
+        # flat-channel phase + AWGN on the device, c8p_signal to the signal -> demod boundary
+        pk, iq_dev, chan_dev, expected, _keep = cfg2_workload_on_device(args.batch, args.snr, 100000 * rank, torch, dev, local)
+        iq, chan = None, None
+        data_note = "synthetic (c8p_tx, distinct payloads)"
     n_pkt = len(pk)
-    iq_d = torch.from_numpy(iq.view(np.float32)).to(dev)
-    chan_d = torch.from_numpy(chan.view(np.float32)).to(dev)
-    iq_dev = engine.DevArray(iq_d.data_ptr(), iq.size, iq_d)
-    chan_dev = engine.DevArray(chan_d.data_ptr(), chan.size, chan_d)
     t_gen = time.time() - t_gen
 
     # engine-owned streams: consecutive batches are software-pipelined across C8P_SLOTS slots (upload / classify /
@@ -124,7 +134,7 @@ def main():
             "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": value, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.no_check else "INVALID (--no-check experiment)",
+            "vs_baseline": None, "dtype": "f32", "data": data_note if not args.no_check else "INVALID (--no-check experiment)",
             "config": {"workload": "BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU, %d packets/GPU/step, "
                                    "AWGN %.0f dB, random-phase flat channel" % (n_pkt, args.snr),
                        "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1),
@@ -140,6 +150,13 @@ def main():
         if not args.no_frontend:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
         if not args.no_cpu:
+            if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
+                iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
+                torch.cuda.synchronize(dev)
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipMemcpy(ctypes.c_void_p(iq.ctypes.data), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(iq.nbytes), ctypes.c_int(2))
+                hip.hipMemcpy(ctypes.c_void_p(chan.ctypes.data), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(chan.nbytes), ctypes.c_int(2))
             out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
@@ -218,27 +235,31 @@ def cpu_baseline(pk, iq, chan, budget_s=12.0):
             "sample": "first %d packets of the same batch, oracle demod+decode, 1 thread, %.1f s, %d PDUs" % (n, dt, npdu)}
 
 
-def cpu_baseline_all_cores(pk, iq, chan, per_core_rate, budget_s=8.0):
+def cpu_baseline_all_cores(pk, iq, chan, per_core_rate, budget_s=6.0):
     """one independent packet stream per host core (the oracle is re-entrant C, ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from c8p_testlib import oracle
     o = oracle()
     cores = os.cpu_count() or 1
-    per = int(max(8, min(len(pk) // cores, budget_s * per_core_rate)))
+    per = int(max(4, min(len(pk) // cores, 16)))                 # packets per pass and thread: short passes, checked against a deadline
     slices = [pk[i * per:(i + 1) * per] for i in range(cores) if len(pk[i * per:(i + 1) * per])]
-    reps = int(max(1, budget_s * per_core_rate / per))          # every thread decodes its slice `reps` times
+    t = time.perf_counter()
+    deadline = t + budget_s
 
     def work(s):
-        return sum(o.rx_batch(s, iq, chan)[3] for _ in range(reps))
+        done = pdus = 0
+        while time.perf_counter() < deadline:
+            pdus += o.rx_batch(s, iq, chan)[3]
+            done += len(s)
+        return done, pdus
 
-    t = time.perf_counter()
     with ThreadPoolExecutor(len(slices)) as ex:
         res = list(ex.map(work, slices))
     dt = time.perf_counter() - t
-    n = sum(len(s) for s in slices) * reps
+    n = sum(r[0] for r in res)
     return {"value": n / dt, "unit": "packets/s", "cores": len(slices), "kind": "port",
-            "sample": "%d packets (%d of the same batch per thread x %d passes), oracle demod+decode, %.1f s, %d PDUs"
-                      % (n, per, reps, dt, sum(res))}
+            "sample": "%d packets (passes of %d of the same batch per thread until %.0f s), oracle demod+decode, %.1f s, %d PDUs"
+                      % (n, per, budget_s, dt, sum(r[1] for r in res))}
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal",
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
 DET_HIST = 80
+TX_NO_WINDOW = 1
 NDP_TOTAL = 1024
 NDP_BLOB_BYTES = 1027
 
@@ -81,7 +82,7 @@ class DetectIn(C.Structure):
 
 class TxPkt(C.Structure):
     _fields_ = [("psdu_off", C.c_uint64), ("len", C.c_uint32), ("format", C.c_uint8), ("mcs", C.c_uint8), ("scr_seed", C.c_uint8),
-                ("rsv", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32)]
+                ("flags", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32)]
 
 
 class TxDesc(C.Structure):

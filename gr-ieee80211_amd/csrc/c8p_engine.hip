@@ -913,7 +913,7 @@ extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
     if (k.scr_seed == 0 || k.scr_seed > 127) { c->err = "scrambler seed must be 1..127"; return C8P_EINVAL; }
     iq += k.gap;
     P.iq_off = iq; P.coded_off = coded; P.psdu_off = k.psdu_off; P.len = k.len;
-    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.mult = k.mult; P.unit_base = units;
+    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.flags = k.flags; P.mult = k.mult; P.unit_base = units;
     desc[p].iq_off = iq; desc[p].coded_off = coded; desc[p].n_samp = (uint32_t)P.p.n_samp; desc[p].n_coded = (uint32_t)(P.p.nsym * P.p.ncbps);
     iq += (uint64_t)P.p.n_samp; coded += ((uint64_t)desc[p].n_coded + 15u) & ~(uint64_t)15u; units += (uint32_t)P.p.n_samp / 80u;
   }

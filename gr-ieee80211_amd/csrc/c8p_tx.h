@@ -16,7 +16,7 @@ struct TxPlan {            // c8p_tx_plan + where the packet's outputs go
   c8p_tx_plan p;
   unsigned long long iq_off, coded_off, psdu_off;
   unsigned int len;
-  int format, mcs, seed;
+  int format, mcs, seed, flags;
   float mult;
   unsigned int unit_base;  // first 80-sample unit of this packet in k_tx_sym's grid
 };
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
     else src = mm < 16 ? 48 + mm : mm - 16;
     const int g = unit * 80 + mm;
     double2 v = st[wv][src];
-    const bool junction = (g == 159 || g == 160) || (g >= 319 && ((g + 1) % 80 == 0) && g + 1 < n_samp) || (g >= 320 && (g % 80 == 0));
+    const bool junction = !(P.flags & C8P_TX_NO_WINDOW) && ((g == 159 || g == 160) || (g >= 319 && ((g + 1) % 80 == 0) && g + 1 < n_samp) || (g >= 320 && (g % 80 == 0)));
     const double a = (double)P.mult * (junction ? 0.5 : 1.0);
     iq[P.iq_off + (unsigned long long)g] = mk((float)(v.x * a), (float)(v.y * a));
   }

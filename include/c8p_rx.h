@@ -175,10 +175,13 @@ typedef struct c8p_tx_pkt {
   uint8_t  format;      /* C8P_F_L / C8P_F_HT / C8P_F_VHT                                                            */
   uint8_t  mcs;         /* legacy 0-7, HT 0-7, VHT 0-8                                                               */
   uint8_t  scr_seed;    /* initial scrambler state, 1..127 (the reference toolbox uses 93)                           */
-  uint8_t  rsv;
+  uint8_t  flags;       /* C8P_TX_NO_WINDOW: do not halve the two samples at every field junction (the toolbox's
+                           procConcat2Symbol does; the C++ chain only touches the legacy preamble, pad_impl.cc:68-71)   */
   float    mult;        /* amplitude multiplier (genFinalSig; tools/pktGenExample.py uses 12.0)                      */
   uint32_t gap;         /* zero items inserted in the output stream before this packet                               */
 } c8p_tx_pkt;
+
+#define C8P_TX_NO_WINDOW 1
 
 typedef struct c8p_tx_desc {  /* per packet, in C8P_BUF_TX_DESC */
   uint64_t iq_off;      /* item offset of the packet's first sample inside C8P_BUF_TX_IQ (after its gap)             */

@@ -74,3 +74,82 @@ def replicated_batch(frame, n, n_ant, snr_db=30.0, seed=0, H=None, mupos=0):
         rx = through_channel(tx, Hp.astype(np.complex64), snr_db, rng)
         assert b.add_rx(rx, n_ant=n_ant, mupos=mupos) >= 0
     return b
+
+
+def ampdu_vht(mpdu):
+    """mac80211.genAmpduVHT([mpdu]) (tools/mac80211.py:333-360): delimiter {EOF, reserved, len[12:14], len[0:12], CRC-8,
+    signature 0x4e} + MPDU, padded to a multiple of 4 bytes"""
+    n = len(mpdu)
+    lb = [(n >> i) & 1 for i in range(14)]
+    bits = [1, 0] + lb[12:14] + lb[0:12]
+    c = [1] * 8
+    for b in bits:
+        c = [b ^ c[7], b ^ c[7] ^ c[0], b ^ c[7] ^ c[1]] + c[2:7]
+    bits = bits + [1 - b for b in c[::-1]] + [(0x4E >> i) & 1 for i in range(8)]
+    d = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(4))
+    pkt = d + bytes(mpdu)
+    return pkt + b"\x00" * ((-len(pkt)) % 4)
+
+
+def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0):
+    """BASELINE configs[1] as SURVEY.md §8d-2 specifies it, generated on the box by the build's own transmitter:
+    packet p carries its own MPDU (1454 bytes from numpy.random.default_rng(8021100 + p) + CRC-32, inside a VHT A-MPDU),
+    VHT MCS7, amplitude as tools/pktGenExample.py (multiplier 12), a flat channel e^{j theta_p} and AWGN at snr_db
+    (sigma per tools/performance/perf_siso.py:92).  c8p_tx -> channel (torch, on the device) -> c8p_signal at the nominal
+    sync item (L-LTF + 24, CFO 0) gives the packets at the signal -> demod boundary, all resident in HBM.
+    Returns (descriptors [host], iq DevArray, chan DevArray, expected PDUs, keep-alive objects)."""
+    import zlib
+    from c8p_testlib import abi
+    from gr_ieee80211_amd import engine
+    GAP = 120
+    pk = np.zeros(n, abi.TX_PKT_DT)
+    arena, exp = [], []
+    off = 0
+    for p in range(n):
+        rng = np.random.default_rng(8021100 + seed + p)
+        body = bytes(rng.integers(0, 256, size=1454, dtype=np.uint8))
+        mpdu = body + zlib.crc32(body).to_bytes(4, "little")
+        ps = ampdu_vht(mpdu)
+        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = off, len(ps), abi.F_VHT, 7
+        pk[p]["scr_seed"], pk[p]["mult"], pk[p]["gap"] = 93, 12.0, GAP
+        pk[p]["flags"] = abi.TX_NO_WINDOW                   # clean OFDM symbols, as `dewindow` makes the fixture frames
+        arena.append(np.frombuffer(ps, np.uint8))
+        off += len(ps)
+        exp.append(bytes([abi.F_VHT, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([7]))
+    e_tx = engine.Engine(device=local)
+    e_tx.tx(pk, np.concatenate(arena), tail_gap=400)
+    e_tx.sync()
+    desc = e_tx.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)
+    p_iq, nbytes = e_tx.buffer(abi.BUF_TX_IQ)
+    ntot = nbytes // 8
+    # channel on the device: per-packet phase, then noise
+    clean = torch.empty(ntot * 2, dtype=torch.float32, device=dev)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(clean.data_ptr()), ctypes.c_void_p(p_iq), ctypes.c_size_t(nbytes), ctypes.c_int(3))   # device to device
+    z = torch.view_as_complex(clean.view(-1, 2))
+    g = torch.Generator(device=dev); g.manual_seed(8021200 + seed)
+    theta = torch.rand(n, generator=g, device=dev, dtype=torch.float32) * (2 * np.pi)
+    starts = torch.from_numpy(desc["iq_off"].astype(np.int64)).to(dev)
+    idx = torch.searchsorted(starts, torch.arange(ntot, device=dev), right=True) - 1
+    z = z * torch.polar(torch.ones(n, device=dev), theta)[idx.clamp(min=0)]
+    sigma = float(np.sqrt(0.1875 ** 2 / (10 ** (snr_db / 10.0))))
+    noise = torch.randn(ntot, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))
+    noisy = (torch.view_as_real(z) + noise).contiguous()
+    x = engine.DevArray(noisy.data_ptr(), ntot, noisy)
+    ev = np.zeros(n, abi.SIG_IN_DT)
+    ev["raw_off"][:, 0] = desc["iq_off"] + 184             # L-LTF start + 24 (signal_impl's sync item)
+    ev["n_avail"] = desc["n_samp"] - 184 + GAP             # up to the next packet (the output slot is sized by this)
+    ev["snr"], ev["rssi"], ev["n_ant"] = snr_db, 1.0, 1
+    e_sig = engine.Engine(device=local)
+    e_sig.signal(ev, x)
+    e_sig.sync()
+    spk = e_sig.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    ok = spk["n_items"] > 0
+    spk = spk[ok].copy()
+    spk["seq"] = np.arange(1, len(spk) + 1)
+    exp = [e for e, k in zip(exp, ok) if k]
+    p_i, b_i = e_sig.buffer(abi.BUF_SIG_IQ)
+    p_c, b_c = e_sig.buffer(abi.BUF_SIG_CHAN)
+    e_tx.close()
+    return spk, engine.DevArray(p_i, b_i // 8, e_sig), engine.DevArray(p_c, b_c // 8, e_sig), exp, (e_sig, noisy)

@@ -11,6 +11,7 @@ import zlib
 import numpy as np
 import pytest
 
+from c8p_cases import ampdu_vht
 from c8p_testlib import abi, load_npz, oracle, oracle_rx
 
 FIX = {}
@@ -18,21 +19,6 @@ for _fn in ("packets_sweep.npz", "packets_cfg.npz"):
     for _name, _d in load_npz(_fn).items():
         if int(_d["nss"]) == 1 and len(_d["mpdu"]):
             FIX[_name] = _d
-
-
-def ampdu_vht(mpdu):
-    """mac80211.genAmpduVHT([mpdu]) (tools/mac80211.py:333-360): delimiter {EOF, reserved, len[12:14], len[0:12], CRC-8,
-    signature 0x4e} + MPDU, padded to a multiple of 4 bytes"""
-    n = len(mpdu)
-    lb = [(n >> i) & 1 for i in range(14)]
-    bits = [1, 0] + lb[12:14] + lb[0:12]
-    c = [1] * 8
-    for b in bits:
-        c = [b ^ c[7], b ^ c[7] ^ c[0], b ^ c[7] ^ c[1]] + c[2:7]
-    bits = bits + [1 - b for b in c[::-1]] + [(0x4E >> i) & 1 for i in range(8)]
-    d = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(4))
-    pkt = d + bytes(mpdu)
-    return pkt + b"\x00" * ((-len(pkt)) % 4)
 
 
 def psdu_of(fmt, mpdu):
