@@ -159,3 +159,41 @@ def test_gpu_loopback_tx_noise_detect_signal_rx():
     assert ok >= 0.97 * len(specs), ok
     for e in (eng, e2, e3, e4):
         e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_new_entry_points_reject_bad_input():
+    """c8p_tx / c8p_detect / c8p_signal: negative return code + message, and the ctx stays usable"""
+    from gr_ieee80211_amd import engine
+    eng = engine.Engine(device=0)
+    rng = np.random.default_rng(2)
+    pk, arena = tx_batch(random_packets(rng, 3, lens=(20, 60)))
+    bad = pk.copy(); bad["mcs"][1] = 9
+    with pytest.raises(RuntimeError, match="unsupported tx"):
+        eng.tx(bad, arena)
+    bad = pk.copy(); bad["format"][0] = 7
+    with pytest.raises(RuntimeError, match="unsupported tx"):
+        eng.tx(bad, arena)
+    bad = pk.copy(); bad["scr_seed"][2] = 0
+    with pytest.raises(RuntimeError, match="seed"):
+        eng.tx(bad, arena)
+    bad = pk.copy(); bad["psdu_off"][2] = len(arena)
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.tx(bad, arena)
+    bad = pk.copy(); bad["len"][0] = 4096
+    with pytest.raises(RuntimeError, match="unsupported tx"):
+        eng.tx(bad, arena)
+    eng.tx(pk, arena)                                     # still usable
+    eng.sync()
+    assert len(eng.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)) == 3
+    x = np.zeros(1000, np.complex64)
+    with pytest.raises(RuntimeError, match="bad detect"):
+        eng.detect(x, n_hist=2000)
+    ev = np.zeros(1, abi.SIG_IN_DT); ev["n_ant"] = 1; ev["raw_off"][0, 0] = 900; ev["n_avail"] = 500
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.signal(ev, x)
+    ev["n_ant"] = 3; ev["n_avail"] = 50
+    with pytest.raises(RuntimeError, match="n_ant"):
+        eng.signal(ev, x)
+    assert len(eng.detect(x)) == 0
+    eng.close()
