@@ -44,28 +44,35 @@ static int rate_of(int format, int mcs, rate_t* r)
   return 1;
 }
 
-int c8po_tx_plan(int format, int mcs, int len, c8p_tx_plan* p)
+/* nss = 1 or 2 spatial streams (HT: mcs 0-7 with nss 1, mcs 8-15 with nss 2 — pass mcs % 8 and nss).  len = 0 with VHT: NDP. */
+int c8po_tx_plan2(int format, int mcs, int nss, int len, c8p_tx_plan* p)
 {
   rate_t r;
   memset(p, 0, sizeof(*p));
-  if (!rate_of(format, mcs, &r) || len <= 0 || len > 4095) return 0;
+  if (!rate_of(format, mcs, &r) || len < 0 || len > 4095 || nss < 1 || nss > 2 || (format == 0 && nss != 1)) return 0;
+  if (len == 0 && format != 2) return 0;
+  r.ncbps *= nss; r.ndbps *= nss;
   p->nb = r.nb; p->cr = r.cr; p->ndbps = r.ndbps; p->ncbps = r.ncbps; p->nsd = r.nsd;
-  if (format == 2) {                                 /* procPktLenAggre :480-494 (len = A-MPDU bytes) */
-    p->nsym = (8 * len + 16 + 6 + r.ndbps - 1) / r.ndbps;
-    p->psdu_len = (p->nsym * r.ndbps - 16 - 6) / 8;
-    p->npad_eof = (p->psdu_len - len) / 4;
-    p->npad_octet = p->psdu_len - len - p->npad_eof * 4;
-    p->legacy_len = ((20 + 8 + 4 + 4 + 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
-    p->n_pre = 5;                                    /* SIG-A x2, VHT-STF, VHT-LTF, SIG-B */
+  const int nltf = nss;
+  if (format == 2) {                                 /* procPktLenAggre :480-504 (len = A-MPDU bytes) */
+    if (len > 0) {
+      p->nsym = (8 * len + 16 + 6 + r.ndbps - 1) / r.ndbps;
+      p->psdu_len = (p->nsym * r.ndbps - 16 - 6) / 8;
+      p->npad_eof = (p->psdu_len - len) / 4;
+      p->npad_octet = p->psdu_len - len - p->npad_eof * 4;
+    }
+    p->legacy_len = ((20 + 8 + 4 + nltf * 4 + 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
+    p->n_pre = 2 + 1 + nltf + 1;                     /* SIG-A x2, VHT-STF, VHT-LTFs, SIG-B */
   } else {                                           /* procPktLenNonAggre :431-456 */
     p->nsym = (8 * len + 16 + 6 + r.ndbps - 1) / r.ndbps;
     p->psdu_len = len;
-    p->legacy_len = format == 0 ? len : ((20 + 8 + 4 + 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
-    p->n_pre = format == 0 ? 0 : 4;                  /* HT-SIG x2, HT-STF, HT-LTF */
+    p->legacy_len = format == 0 ? len : ((20 + 8 + 4 + nltf * 4 + p->nsym * 4 - 20) / 4) * 3 - 3;
+    p->n_pre = format == 0 ? 0 : 2 + 1 + nltf;       /* HT-SIG x2, HT-STF, HT-LTFs */
   }
   p->n_samp = 320 + 80 * (1 + p->n_pre + p->nsym);
   return 1;
 }
+int c8po_tx_plan(int format, int mcs, int len, c8p_tx_plan* p) { return len > 0 ? c8po_tx_plan2(format, mcs, 1, len, p) : 0; }
 
 static void bcc(const uint8_t* in, int n, uint8_t* out2n)      /* procBcc :766-771, rate 1/2: A (0155) then B (0117) */
 {
@@ -106,9 +113,16 @@ static void interleave_sig48(const uint8_t* in, uint8_t* out)  /* procInterleave
 
 /* one OFDM symbol: X[64] in "shifted" order (index i = subcarrier i - 32), scale 1/sqrt(ntf), 64-point IDFT with 1/64,
  * written as cp + 64 samples at dst */
-static void ofdm(const cd* X, double ntf, int cp, cd* dst)
+/* procLegacyCSD / procCSD (phy80211header.py:950-956): X[k] *= exp(-j 2 pi shift k / 64), shift = cyclic shift in samples
+ * (shift_ns * 20 MHz * 0.001: -200 ns = -4, -400 ns = -8) */
+void c8po_ofdm_csd(const cd* X0, double ntf, int cp, double shift, cd* dst)
 {
-  cd t[64];
+  cd t[64], X[64];
+  for (int i = 0; i < 64; i++) {
+    const double ph = -2.0 * M_PI * shift * (double)(i - 32) / 64.0;
+    X[i].re = X0[i].re * cos(ph) - X0[i].im * sin(ph);
+    X[i].im = X0[i].re * sin(ph) + X0[i].im * cos(ph);
+  }
   for (int n = 0; n < 64; n++) {
     double sr = 0, si = 0;
     for (int i = 0; i < 64; i++) {
@@ -162,141 +176,172 @@ static void init_ps(void)
   done = 1;
 }
 
-int c8po_tx_packet(int format, int mcs, const uint8_t* psdu, int len, int scr_seed, float mult, c8p_c32* out, int cap,
-                   uint8_t* coded_out, int* n_coded)
+/* one packet on nss transmit chains (no spatial mapping matrix: stream i = chain i, as genFromMpdu / genFromAmpdu).
+ * out0 / out1: cap samples each (out1 may be NULL when nss == 1).  HT: mcs = 0..7 is the per-stream rate, the HT-SIG MCS
+ * field carries mcs + 8 (nss - 1).  VHT with len == 0: NDP.  Returns the samples per chain, or -1. */
+int c8po_tx_packet2(int format, int mcs, int nss, const uint8_t* psdu, int len, int scr_seed, float mult,
+                    c8p_c32* out0, c8p_c32* out1, int cap, uint8_t* coded_out, int* n_coded)
 {
   c8p_tx_plan P;
   c8po_init();
   init_ps();
-  if (!c8po_tx_plan(format, mcs, len, &P) || P.n_samp > cap) return -1;
-  cd* sig = (cd*)calloc((size_t)P.n_samp, sizeof(cd));
-  cd X[64];
-  int pos = 0;
+  if (!c8po_tx_plan2(format, mcs, nss, len, &P) || P.n_samp > cap || (nss == 2 && !out1)) return -1;
+  const double csdL[2] = {0.0, -4.0}, csdN[2] = {0.0, -8.0};       /* C_CYCLIC_SHIFT_L / _NL for 2 streams, in samples */
   const double pil0[4] = {1, 1, 1, -1};
-  /* ---- L-STF, L-LTF (:223-235) */
-  memset(X, 0, sizeof(X));
-  for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
-  { cd t[80]; ofdm(X, 12.0, 0, t); for (int n = 0; n < 32; n++) sig[n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[32 + 64 * r + n] = t[n]; }
-  memset(X, 0, sizeof(X));
-  for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
-  { cd t[80]; ofdm(X, 52.0, 0, t); for (int n = 0; n < 32; n++) sig[160 + n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[192 + 64 * r + n] = t[n]; }
-  pos = 320;
-  /* ---- L-SIG (:237-282) */
+  /* ---- bit level, shared by the chains */
+  uint8_t lsig[48], sig12[96], sigb[52], sigb_crc[8] = {0};
   {
     static const uint8_t RATE[8][4] = {{1, 1, 0, 1}, {1, 1, 1, 1}, {0, 1, 0, 1}, {0, 1, 1, 1}, {1, 0, 0, 1}, {1, 0, 1, 1}, {0, 0, 0, 1}, {0, 0, 1, 1}};
-    uint8_t b[24], c[48], it[48];
-    memset(b, 0, sizeof(b));
+    uint8_t b[48], c[96];
+    memset(b, 0, sizeof(b));                           /* L-SIG :237-282 */
     memcpy(b, RATE[format == 0 ? mcs : 0], 4);
     for (int i = 0; i < 12; i++) b[5 + i] = (uint8_t)((P.legacy_len >> i) & 1);
     int par = 0; for (int i = 0; i < 17; i++) par += b[i];
     b[17] = (uint8_t)(par & 1);
-    bcc(b, 24, c); interleave_sig48(c, it);
-    cd q[48]; for (int i = 0; i < 48; i++) { q[i].re = it[i] ? 1.0 : -1.0; q[i].im = 0; }
-    place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
-  }
-  uint8_t sigb_crc[8] = {0};
-  if (format == 1) {
-    /* ---- HT-SIG (:284-350): both symbols QBPSK */
-    uint8_t b[48], c[96], it[96];
-    memset(b, 0, sizeof(b));
-    for (int i = 0; i < 7; i++) b[i] = (uint8_t)((mcs >> i) & 1);
-    for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((P.psdu_len >> i) & 1);
-    b[24] = 1; b[25] = 1; b[26] = 1; b[27] = 0 /* not aggregated (genFromMpdu) */;
-    crc8_bits(b, 34, b + 34);
-    bcc(b, 48, c); interleave_sig48(c, it); interleave_sig48(c + 48, it + 48);
-    for (int s = 0; s < 2; s++) {
-      cd q[48]; for (int i = 0; i < 48; i++) { q[i].re = 0; q[i].im = it[48 * s + i] ? 1.0 : -1.0; }
-      place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
+    bcc(b, 24, c); interleave_sig48(c, lsig);
+    if (format == 1) {                                 /* HT-SIG :284-350 */
+      memset(b, 0, sizeof(b));
+      const int m = mcs + 8 * (nss - 1);
+      for (int i = 0; i < 7; i++) b[i] = (uint8_t)((m >> i) & 1);
+      for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((P.psdu_len >> i) & 1);
+      b[24] = 1; b[25] = 1; b[26] = 1;
+      crc8_bits(b, 34, b + 34);
+      bcc(b, 48, c); interleave_sig48(c, sig12); interleave_sig48(c + 48, sig12 + 48);
+    } else if (format == 2) {                          /* VHT-SIG-A :352-455, SU, group id 0, partial AID 0 */
+      memset(b, 0, sizeof(b));
+      b[2] = 1;
+      for (int i = 0; i < 3; i++) b[10 + i] = (uint8_t)(((nss - 1) >> i) & 1);
+      b[23] = 1;
+      for (int i = 0; i < 4; i++) b[28 + i] = (uint8_t)((mcs >> i) & 1);
+      b[33] = 1;
+      crc8_bits(b, 34, b + 34);
+      bcc(b, 48, c); interleave_sig48(c, sig12); interleave_sig48(c + 48, sig12 + 48);
+      memset(b, 0, sizeof(b));                         /* VHT-SIG-B :512-569 */
+      if (len > 0) {
+        const int l4 = (len + 3) / 4;
+        for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
+        b[17] = b[18] = b[19] = 1;
+        crc8_bits(b, 20, sigb_crc);
+      } else {
+        static const uint8_t NDP20[20] = {0, 0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        memcpy(b, NDP20, 20);
+      }
+      bcc(b, 26, c);
+      int32_t map[64];
+      c8po_table(4 /* C8P_TAB_DEINT_SIGB */, 0, map, 64);
+      for (int r = 0; r < 52; r++) sigb[r] = c[map[r]];
     }
-  } else if (format == 2) {
-    /* ---- VHT-SIG-A (:352-455): BPSK then QBPSK; single user, group id 0, partial AID 0 */
-    uint8_t b[48], c[96], it[96];
-    memset(b, 0, sizeof(b));
-    b[2] = 1;                                          /* bw 0,0; reserved 1; STBC 0; gid 0; nSTS-1 = 0; partial AID 0; txop 0 */
-    b[23] = 1;
-    for (int i = 0; i < 4; i++) b[24 + 4 + i] = (uint8_t)((mcs >> i) & 1);
-    b[24 + 9] = 1;
-    crc8_bits(b, 34, b + 34);
-    bcc(b, 48, c); interleave_sig48(c, it); interleave_sig48(c + 48, it + 48);
-    for (int s = 0; s < 2; s++) {
-      cd q[48];
-      for (int i = 0; i < 48; i++) { const double v = it[48 * s + i] ? 1.0 : -1.0; q[i].re = s ? 0 : v; q[i].im = s ? v : 0; }
-      place(q, 48, pil0, X); ofdm(X, 52.0, 16, sig + pos); pos += 80;
-    }
-  }
-  if (format != 0) {
-    /* ---- HT / VHT STF + one LTF (:459-510), nSS = 1: P and R factors are +1 */
-    memset(X, 0, sizeof(X));
-    for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
-    ofdm(X, 12.0, 16, sig + pos); pos += 80;
-    memset(X, 0, sizeof(X));
-    for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
-    X[-28 + 32].re = 1; X[-27 + 32].re = 1; X[27 + 32].re = -1; X[28 + 32].re = -1;
-    ofdm(X, 56.0, 16, sig + pos); pos += 80;
-  }
-  if (format == 2) {
-    /* ---- VHT-SIG-B (:512-569) */
-    uint8_t b[26], c[52], it[52];
-    memset(b, 0, sizeof(b));
-    const int l4 = (len + 3) / 4;
-    for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
-    b[17] = b[18] = b[19] = 1;
-    crc8_bits(b, 20, sigb_crc);
-    bcc(b, 26, c);
-    int32_t map[64];
-    c8po_table(4 /* C8P_TAB_DEINT_SIGB */, 0, map, 64);
-    for (int r = 0; r < 52; r++) it[r] = c[map[r]];
-    cd q[52]; for (int i = 0; i < 52; i++) { q[i].re = it[i] ? 1.0 : -1.0; q[i].im = 0; }
-    place(q, 52, pil0, X); ofdm(X, 56.0, 16, sig + pos); pos += 80;
   }
   /* ---- data bits (:639-682), scrambling and coding (:684-710) */
   const int nbits = P.nsym * P.ndbps;
   uint8_t* d = (uint8_t*)calloc((size_t)nbits + 8, 1);
   uint8_t* c2 = (uint8_t*)calloc((size_t)nbits * 2 + 16, 1);
   uint8_t* cp = (uint8_t*)calloc((size_t)P.nsym * P.ncbps + 16, 1);
-  int w = 16;
-  if (format == 2) memcpy(d + 8, sigb_crc, 8);
-  for (int i = 0; i < len; i++) for (int k = 0; k < 8; k++) d[w++] = (uint8_t)((psdu[i] >> k) & 1);
-  if (format == 2) {
-    static const uint8_t EOF32[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0};
-    for (int e = 0; e < P.npad_eof; e++) { memcpy(d + w, EOF32, 32); w += 32; }
-  }
-  {
+  int ncoded = 0;
+  if (nbits > 0) {
+    int w = 16;
+    if (format == 2) memcpy(d + 8, sigb_crc, 8);
+    for (int i = 0; i < len; i++) for (int k = 0; k < 8; k++) d[w++] = (uint8_t)((psdu[i] >> k) & 1);
+    if (format == 2) {
+      static const uint8_t EOF32[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0};
+      for (int e = 0; e < P.npad_eof; e++) { memcpy(d + w, EOF32, 32); w += 32; }
+    }
     unsigned st = (unsigned)scr_seed;                  /* procScramble :800-806 */
     for (int i = 0; i < nbits; i++) {
       const unsigned fb = ((st >> 6) & 1u) ^ ((st >> 3) & 1u);
       d[i] ^= (uint8_t)fb;
       st = ((st << 1) & 0x7e) | fb;
     }
+    if (format == 2) { for (int i = nbits - 6; i < nbits; i++) d[i] = 0; }     /* tail after scrambling (:692-696) */
+    else { for (int i = 0; i < 6; i++) d[16 + 8 * P.psdu_len + i] = 0; }       /* tail reset (:700-702) */
+    bcc(d, nbits, c2);
+    ncoded = puncture(c2, 2 * nbits, P.cr, cp);
   }
-  if (format == 2) { for (int i = nbits - 6; i < nbits; i++) d[i] = 0; }     /* tail after scrambling (:692-696) */
-  else { for (int i = 0; i < 6; i++) d[16 + 8 * P.psdu_len + i] = 0; }       /* tail reset (:700-702) */
-  bcc(d, nbits, c2);
-  const int ncoded = puncture(c2, 2 * nbits, P.cr, cp);
   if (n_coded) *n_coded = ncoded;
   if (coded_out) memcpy(coded_out, cp, (size_t)ncoded);
-  /* ---- interleave, map, OFDM (:736-819) */
-  int32_t map[512];
+  /* ---- per transmit chain */
   const int mi = P.nb == 1 ? 0 : P.nb == 2 ? 1 : P.nb == 4 ? 2 : P.nb == 6 ? 3 : 4;
-  c8po_table(format == 0 ? 0 : 1, mi, map, 512);
-  double pil[4] = {1, 1, 1, -1};
-  int pidx = format == 0 ? 1 : format == 1 ? 3 : 4;
-  for (int s = 0; s < P.nsym; s++) {
-    cd q[52];
-    uint8_t bits[8];
-    for (int j = 0; j < P.nsd; j++) {
-      for (int k = 0; k < P.nb; k++) bits[k] = cp[s * P.ncbps + map[j * P.nb + k]];
-      q[j] = qam_point(bits, P.nb);
+  int32_t map1[512], map2[512];
+  c8po_table(format == 0 ? 0 : 1, mi, map1, 512);
+  c8po_table(2 /* C8P_TAB_DEINT_NL2 */, mi, map2, 512);
+  const int ncbpss = P.nsd * P.nb, sblk = P.nb / 2 > 1 ? P.nb / 2 : 1;
+  cd* sig = (cd*)calloc((size_t)P.n_samp, sizeof(cd));
+  for (int ss = 0; ss < nss; ss++) {
+    cd X[64];
+    int pos = 0;
+    const double sL = csdL[nss == 2 ? ss : 0], sN = csdN[nss == 2 ? ss : 0], dn = (double)nss;
+    /* L-STF, L-LTF (:223-235) */
+    memset(X, 0, sizeof(X));
+    for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+    { cd t[80]; c8po_ofdm_csd(X, 12.0 * dn, 0, sL, t); for (int n = 0; n < 32; n++) sig[n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[32 + 64 * r + n] = t[n]; }
+    memset(X, 0, sizeof(X));
+    for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
+    { cd t[80]; c8po_ofdm_csd(X, 52.0 * dn, 0, sL, t); for (int n = 0; n < 32; n++) sig[160 + n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[192 + 64 * r + n] = t[n]; }
+    pos = 320;
+    { cd q[48]; for (int i = 0; i < 48; i++) { q[i].re = lsig[i] ? 1.0 : -1.0; q[i].im = 0; }
+      place(q, 48, pil0, X); c8po_ofdm_csd(X, 52.0 * dn, 16, sL, sig + pos); pos += 80; }
+    if (format != 0) {
+      for (int s2 = 0; s2 < 2; s2++) {                 /* HT-SIG: QBPSK x2; VHT-SIG-A: BPSK then QBPSK */
+        cd q[48];
+        const int quad = format == 1 || s2 == 1;
+        for (int i = 0; i < 48; i++) { const double v = sig12[48 * s2 + i] ? 1.0 : -1.0; q[i].re = quad ? 0 : v; q[i].im = quad ? v : 0; }
+        place(q, 48, pil0, X); c8po_ofdm_csd(X, 52.0 * dn, 16, sL, sig + pos); pos += 80;
+      }
+      /* HT / VHT STF + nss LTFs (:459-510) */
+      memset(X, 0, sizeof(X));
+      for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+      c8po_ofdm_csd(X, 12.0 * dn, 16, sN, sig + pos); pos += 80;
+      static const int PM[2][2] = {{1, -1}, {1, 1}}, RM[2] = {1, -1};           /* C_P_LTF_VHT_4, C_R_LTF_VHT_4 */
+      for (int l = 0; l < nss; l++) {
+        memset(X, 0, sizeof(X));
+        for (int k = -28; k <= 28; k++) {
+          if (k == 0) continue;
+          double v = (k >= -26 && k <= 26) ? (double)LTF_L53[k + 26] : (k < 0 ? 1.0 : -1.0);
+          const int pilot = k == -21 || k == -7 || k == 7 || k == 21;
+          v *= (format == 2 && pilot) ? RM[l] : PM[ss][l];
+          X[k + 32].re = v;
+        }
+        c8po_ofdm_csd(X, 56.0 * dn, 16, sN, sig + pos); pos += 80;
+      }
     }
-    double pp[4]; for (int k = 0; k < 4; k++) pp[k] = pil[k] * PS127[pidx];
-    place(q, P.nsd, pp, X);
-    ofdm(X, format == 0 ? 52.0 : 56.0, 16, sig + pos); pos += 80;
-    pidx = (pidx + 1) % 127;
-    if (format != 0) { const double t = pil[0]; pil[0] = pil[1]; pil[1] = pil[2]; pil[2] = pil[3]; pil[3] = t; }
+    if (format == 2) {
+      cd q[52]; for (int i = 0; i < 52; i++) { q[i].re = sigb[i] ? 1.0 : -1.0; q[i].im = 0; }
+      place(q, 52, pil0, X); c8po_ofdm_csd(X, 56.0 * dn, 16, sN, sig + pos); pos += 80;
+    }
+    /* data symbols: stream parse + interleave (:712-746), map (:748-761), pilots + OFDM (:788-819) */
+    double pil[4] = {1, 1, 1, -1};
+    if (format == 1 && nss == 2) { if (ss == 0) { pil[2] = -1; } else { pil[1] = -1; pil[2] = -1; pil[3] = 1; } }   /* C_PILOT_HT 2 streams */
+    int pidx = format == 0 ? 1 : format == 1 ? 3 : 4;
+    for (int s3 = 0; s3 < P.nsym; s3++) {
+      cd q[52];
+      uint8_t bits[8];
+      for (int j = 0; j < P.nsd; j++) {
+        for (int k = 0; k < P.nb; k++) {
+          const int r = j * P.nb + k;
+          int ci = ss == 0 ? map1[r] : map2[r];        /* position inside the stream after de-interleaving */
+          if (nss == 2) ci = ((ci / sblk) * 2 + ss) * sblk + ci % sblk;      /* stream parser */
+          bits[k] = cp[s3 * P.ncbps + ci];
+        }
+        q[j] = qam_point(bits, P.nb);
+      }
+      (void)ncbpss;
+      double pp[4]; for (int k = 0; k < 4; k++) pp[k] = pil[k] * PS127[pidx];
+      place(q, P.nsd, pp, X);
+      c8po_ofdm_csd(X, (format == 0 ? 52.0 : 56.0) * dn, 16, format == 0 ? sL : sN, sig + pos); pos += 80;
+      pidx = (pidx + 1) % 127;
+      if (format != 0) { const double t = pil[0]; pil[0] = pil[1]; pil[1] = pil[2]; pil[2] = pil[3]; pil[3] = t; }
+    }
+    /* procConcat2Symbol at every junction (:894-901), amplitude (:839) */
+    for (int b = 160; b < P.n_samp; b += (b < 320 ? 160 : 80)) { sig[b - 1].re *= 0.5; sig[b - 1].im *= 0.5; sig[b].re *= 0.5; sig[b].im *= 0.5; }
+    c8p_c32* out = ss == 0 ? out0 : out1;
+    for (int n = 0; n < P.n_samp; n++) { out[n].re = (float)(sig[n].re * (double)mult); out[n].im = (float)(sig[n].im * (double)mult); }
   }
-  /* ---- procConcat2Symbol at every junction (:894-901), amplitude (:839) */
-  for (int b = 160; b < P.n_samp; b += (b < 320 ? 160 : 80)) { sig[b - 1].re *= 0.5; sig[b - 1].im *= 0.5; sig[b].re *= 0.5; sig[b].im *= 0.5; }
-  for (int n = 0; n < P.n_samp; n++) { out[n].re = (float)(sig[n].re * (double)mult); out[n].im = (float)(sig[n].im * (double)mult); }
   free(sig); free(d); free(c2); free(cp);
   return P.n_samp;
+}
+
+int c8po_tx_packet(int format, int mcs, const uint8_t* psdu, int len, int scr_seed, float mult, c8p_c32* out, int cap,
+                   uint8_t* coded_out, int* n_coded)
+{
+  return len > 0 ? c8po_tx_packet2(format, mcs, 1, psdu, len, scr_seed, mult, out, NULL, cap, coded_out, n_coded) : -1;
 }

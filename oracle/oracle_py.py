@@ -207,3 +207,18 @@ def tx_packet(fmt, mcs, psdu, scr_seed=93, mult=12.0):
     if n < 0:
         raise ValueError("c8po_tx_packet rejected (fmt %d mcs %d len %d)" % (fmt, mcs, len(psdu)))
     return out[:n].copy(), coded[:nc.value].copy()
+
+
+def tx_packet2(fmt, mcs, nss, psdu, scr_seed=93, mult=12.0):
+    """one or two transmit chains; HT: mcs = per-stream rate 0..7; VHT with empty psdu = NDP.  Returns (iq [nss][n], coded bits)."""
+    n_in = len(psdu)
+    buf = np.frombuffer(bytes(psdu), np.uint8).copy() if n_in else np.zeros(1, np.uint8)
+    cap = 400 + 80 * (10 + (8 * n_in + 22) // 24 + 2)
+    out = np.zeros((2, cap), np.complex64)
+    coded = np.zeros(2 * (8 * n_in + 22) + 4096, np.uint8)
+    nc = C.c_int(0)
+    n = lib().c8po_tx_packet2(int(fmt), int(mcs), int(nss), _p(buf), n_in, int(scr_seed), C.c_float(mult), _p(out[0]), _p(out[1]), cap,
+                              _p(coded), C.byref(nc))
+    if n < 0:
+        raise ValueError("c8po_tx_packet2 rejected (fmt %d mcs %d nss %d len %d)" % (fmt, mcs, nss, n_in))
+    return out[:nss, :n].copy(), coded[:nc.value].copy()
