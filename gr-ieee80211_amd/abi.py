@@ -82,7 +82,7 @@ class DetectIn(C.Structure):
 
 class TxPkt(C.Structure):
     _fields_ = [("psdu_off", C.c_uint64), ("len", C.c_uint32), ("format", C.c_uint8), ("mcs", C.c_uint8), ("scr_seed", C.c_uint8),
-                ("flags", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32)]
+                ("flags", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32), ("nss", C.c_uint8), ("rsv", C.c_uint8 * 3)]
 
 
 class TxDesc(C.Structure):

@@ -876,10 +876,10 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
 }
 
 // ------------------------------------------------------------------------------------------------ transmit chain
-extern "C" int c8p_tx_plan_of(int format, int mcs, int len, c8p_tx_plan* plan)
+extern "C" int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan)
 {
   c8p_tx_plan p;
-  const int ok = tx_plan_of(format, mcs, len, p);
+  const int ok = tx_plan_of(format, mcs, nss < 1 ? 1 : nss, len, p);
   if (plan) *plan = p;
   return ok;
 }
@@ -905,19 +905,25 @@ extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
   std::vector<c8p_tx_desc> desc(n);
   uint64_t iq = 0, coded = 0;
   uint32_t units = 0;
+  int max_nss = 1;
   for (int p = 0; p < n; p++) {
     const c8p_tx_pkt& k = in->pkts[p];
     TxPlan& P = plans[p];
-    if (!tx_plan_of(k.format, k.mcs, (int)k.len, P.p)) { c->err = "unsupported tx format / mcs / length"; return C8P_EINVAL; }
+    const int nss = k.nss < 1 ? 1 : k.nss;
+    max_nss = std::max(max_nss, nss);
+    if (!tx_plan_of(k.format, k.mcs, nss, (int)k.len, P.p)) { c->err = "unsupported tx format / mcs / streams / length"; return C8P_EINVAL; }
     if (k.psdu_off + k.len > in->n_psdu) { c->err = "psdu outside the arena"; return C8P_ERANGE; }
     if (k.scr_seed == 0 || k.scr_seed > 127) { c->err = "scrambler seed must be 1..127"; return C8P_EINVAL; }
     iq += k.gap;
     P.iq_off = iq; P.coded_off = coded; P.psdu_off = k.psdu_off; P.len = k.len;
-    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.flags = k.flags; P.mult = k.mult; P.unit_base = units;
+    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.flags = k.flags; P.mult = k.mult; P.unit_base = units; P.nss = nss;
     desc[p].iq_off = iq; desc[p].coded_off = coded; desc[p].n_samp = (uint32_t)P.p.n_samp; desc[p].n_coded = (uint32_t)(P.p.nsym * P.p.ncbps);
-    iq += (uint64_t)P.p.n_samp; coded += ((uint64_t)desc[p].n_coded + 15u) & ~(uint64_t)15u; units += (uint32_t)P.p.n_samp / 80u;
+    iq += (uint64_t)P.p.n_samp; coded += ((uint64_t)desc[p].n_coded + 15u) & ~(uint64_t)15u; units += (uint32_t)(P.p.n_samp / 80 * nss);
   }
   iq += in->tail_gap;
+  const uint64_t stream_len = iq;                      // items per chain
+  for (TxPlan& P : plans) P.stride = stream_len;
+  iq *= (uint64_t)max_nss;
   int rc;
   const size_t plan_bytes = align256(sizeof(TxPlan) * (size_t)n), desc_bytes = align256(sizeof(c8p_tx_desc) * (size_t)n);
   if ((rc = ensure_host(c, plan_bytes + desc_bytes)) != C8P_OK) return rc;

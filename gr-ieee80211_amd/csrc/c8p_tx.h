@@ -16,7 +16,8 @@ struct TxPlan {            // c8p_tx_plan + where the packet's outputs go
   c8p_tx_plan p;
   unsigned long long iq_off, coded_off, psdu_off;
   unsigned int len;
-  int format, mcs, seed, flags;
+  int format, mcs, seed, flags, nss;
+  unsigned long long stride;   // chain 1 starts this many items after chain 0
   float mult;
   unsigned int unit_base;  // first 80-sample unit of this packet in k_tx_sym's grid
 };
@@ -34,21 +35,27 @@ __host__ __device__ __forceinline__ int tx_rate(int format, int mcs, c8p_tx_plan
   return 1;
 }
 // tools/phy80211header.py procPktLenNonAggre :427-459 / procPktLenAggre :461-506 (cloud80211phy.cc:2487-2524)
-__host__ __device__ __forceinline__ int tx_plan_of(int format, int mcs, int len, c8p_tx_plan& p)
+__host__ __device__ __forceinline__ int tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan& p)
 {
   p = c8p_tx_plan{};
-  if (!tx_rate(format, mcs, p) || len <= 0 || len > 4095) return 0;
-  p.nsym = (8 * len + 16 + 6 + p.ndbps - 1) / p.ndbps;
+  if (!tx_rate(format, mcs, p) || len < 0 || len > 4095 || nss < 1 || nss > 2 || (format == C8P_F_L && nss != 1)) return 0;
+  if (len == 0 && format != C8P_F_VHT) return 0;
+  p.ncbps *= nss; p.ndbps *= nss;
+  const int nltf = nss;
   if (format == C8P_F_VHT) {
-    p.psdu_len = (p.nsym * p.ndbps - 16 - 6) / 8;
-    p.npad_eof = (p.psdu_len - len) / 4;
-    p.npad_octet = p.psdu_len - len - p.npad_eof * 4;
-    p.legacy_len = ((20 + 8 + 4 + 4 + 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
-    p.n_pre = 5;
+    if (len > 0) {
+      p.nsym = (8 * len + 16 + 6 + p.ndbps - 1) / p.ndbps;
+      p.psdu_len = (p.nsym * p.ndbps - 16 - 6) / 8;
+      p.npad_eof = (p.psdu_len - len) / 4;
+      p.npad_octet = p.psdu_len - len - p.npad_eof * 4;
+    }
+    p.legacy_len = ((20 + 8 + 4 + nltf * 4 + 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
+    p.n_pre = 2 + 1 + nltf + 1;
   } else {
+    p.nsym = (8 * len + 16 + 6 + p.ndbps - 1) / p.ndbps;
     p.psdu_len = len;
-    p.legacy_len = format == C8P_F_L ? len : ((20 + 8 + 4 + 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
-    p.n_pre = format == C8P_F_L ? 0 : 4;
+    p.legacy_len = format == C8P_F_L ? len : ((20 + 8 + 4 + nltf * 4 + p.nsym * 4 - 20) / 4) * 3 - 3;
+    p.n_pre = format == C8P_F_L ? 0 : 2 + 1 + nltf;
   }
   p.n_samp = 320 + 80 * (1 + p.n_pre + p.nsym);
   return 1;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
   const TxPlan P = plans[p];
   const c8p_tx_plan& m = P.p;
   uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
-  for (unsigned i = lane; i < (unsigned)m.n_samp / 80u; i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
+  for (unsigned i = lane; i < (unsigned)(m.n_samp / 80 * P.nss); i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
   if (lane == 0) {
     uint8_t b[48], c[96];
     // ---- L-SIG  tools/phy80211.py:237-282
@@ -113,11 +120,13 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
     if (P.format != C8P_F_L) {
       for (int i = 0; i < 48; i++) b[i] = 0;
       if (P.format == C8P_F_HT) {                                                   // :284-350
-        for (int i = 0; i < 7; i++) b[i] = (uint8_t)((P.mcs >> i) & 1);
+        const int mf = P.mcs + 8 * (P.nss - 1);
+        for (int i = 0; i < 7; i++) b[i] = (uint8_t)((mf >> i) & 1);
         for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((m.psdu_len >> i) & 1);
         b[24] = 1; b[25] = 1; b[26] = 1;
       } else {                                                                      // :352-455, SU, group id 0, partial AID 0
         b[2] = 1; b[23] = 1;
+        for (int i = 0; i < 3; i++) b[10 + i] = (uint8_t)(((P.nss - 1) >> i) & 1);
         for (int i = 0; i < 4; i++) b[28 + i] = (uint8_t)((P.mcs >> i) & 1);
         b[33] = 1;
       }
@@ -127,10 +136,15 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
     }
     if (P.format == C8P_F_VHT) {                                                    // :512-569
       for (int i = 0; i < 26; i++) b[i] = 0;
-      const int l4 = ((int)P.len + 3) / 4;
-      for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
-      b[17] = b[18] = b[19] = 1;
-      tx_crc8(b, 20, s_crc);
+      if (P.len > 0) {
+        const int l4 = ((int)P.len + 3) / 4;
+        for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
+        b[17] = b[18] = b[19] = 1;
+        tx_crc8(b, 20, s_crc);
+      } else {                                          // NDP: C_NDP_SIG_B_20 = 00000111010001000010
+        const unsigned ndp = 0x422E0u;
+        for (int i = 0; i < 20; i++) b[i] = (uint8_t)((ndp >> i) & 1u);
+      }
       tx_bcc_sig(b, 26, c);
       for (int r = 0; r < 52; r++) sb[144 + r] = c[T->deintSigB[r]];
     }
@@ -204,7 +218,11 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
   const int p = (int)unit2pkt[u];
   const TxPlan P = plans[p];
   const c8p_tx_plan& m = P.p;
-  const int unit = (int)(u - P.unit_base);            // 80-sample unit inside the packet: 0,1 L-STF  2,3 L-LTF  4 L-SIG  5.. pre  then data
+  const int upp = m.n_samp / 80;                      // units per chain
+  const int ss = (int)(u - P.unit_base) / upp;        // transmit chain
+  const int unit = (int)(u - P.unit_base) - ss * upp; // 80-sample unit inside the packet: 0,1 L-STF  2,3 L-LTF  4 L-SIG  5.. pre  then data
+  const int nss = P.nss;
+  int shift = 0;                                      // cyclic shift of this field on this chain, in samples (C_CYCLIC_SHIFT_L / _NL)
   const int k = lane < 32 ? lane : lane - 64;         // subcarrier of this lane's bin
   const int ak = k < 0 ? -k : k;
   double xr = 0.0, xi = 0.0, ntf = 52.0;
@@ -213,18 +231,19 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
   const int pil_i = k == -21 ? 0 : k == -7 ? 1 : k == 7 ? 2 : 3;
   const bool vht = P.format == C8P_F_VHT;
   enum { F_STF, F_LLTF, F_NLLTF, F_SIG, F_SIGB, F_DATA } kind;
-  int sig_off = 0, sig_q = 0, dsym = 0;
-  if (unit < 2) kind = F_STF;
-  else if (unit < 4) kind = F_LLTF;
-  else if (unit == 4) { kind = F_SIG; sig_off = 0; }
+  int sig_off = 0, sig_q = 0, dsym = 0, ltf_i = 0;
+  const int shL = ss ? -4 : 0, shN = ss ? -8 : 0;     // -200 ns / -400 ns on the second chain
+  if (unit < 2) { kind = F_STF; shift = shL; }
+  else if (unit < 4) { kind = F_LLTF; shift = shL; }
+  else if (unit == 4) { kind = F_SIG; sig_off = 0; shift = shL; }
   else {
     const int q = unit - 5;                           // index among the pre symbols
     if (q < m.n_pre) {
-      if (q < 2) { kind = F_SIG; sig_off = 48 + 48 * q; sig_q = (P.format == C8P_F_HT || q == 1) ? 1 : 0; }   // HT-SIG: QBPSK x2, VHT-SIG-A: BPSK, QBPSK
-      else if (q == 2) kind = F_STF;
-      else if (q == 3) kind = F_NLLTF;
-      else kind = F_SIGB;
-    } else { kind = F_DATA; dsym = q - m.n_pre; }
+      if (q < 2) { kind = F_SIG; sig_off = 48 + 48 * q; sig_q = (P.format == C8P_F_HT || q == 1) ? 1 : 0; shift = shL; }   // HT-SIG: QBPSK x2, VHT-SIG-A: BPSK, QBPSK
+      else if (q == 2) { kind = F_STF; shift = shN; }
+      else if (q < 3 + nss) { kind = F_NLLTF; ltf_i = q - 3; shift = shN; }
+      else { kind = F_SIGB; shift = shN; }
+    } else { kind = F_DATA; dsym = q - m.n_pre; shift = P.format == C8P_F_L ? shL : shN; }
   }
   if (kind == F_STF) {                                // C_STF_L / C_STF_HT / C_STF_VHT: +-(1+j)/sqrt(2) on every 4th subcarrier
     ntf = 12.0;
@@ -234,7 +253,11 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
       xr = xi = sgn * 0.70710678118654757;
     }
   } else if (kind == F_LLTF) { ntf = 52.0; xr = (double)T->ltfL[lane]; }
-  else if (kind == F_NLLTF) { ntf = 56.0; xr = (double)T->ltfNL[lane]; }
+  else if (kind == F_NLLTF) {                         // C_P_LTF_VHT_4 rows {1,-1},{1,1}; VHT pilots follow C_R_LTF_VHT_4 = {1,-1}
+    ntf = 56.0;
+    const double pm = (ss == 0 && ltf_i == 1) ? -1.0 : 1.0, rm = ltf_i == 1 ? -1.0 : 1.0;
+    xr = (double)T->ltfNL[lane] * ((vht && pilot_bin) ? rm : pm);
+  }
   else if (kind == F_SIG) {
     ntf = 52.0;
     if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
@@ -249,13 +272,16 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
     const int lim = leg ? 26 : 28;
     const int p0 = leg ? 1 : (vht ? 4 : 3);
     const float pol = T->pilotP[(p0 + dsym) % 127];
-    if (pilot_bin) {                                  // base {1,1,1,-1}, rotated left by one per symbol for HT / VHT (:811-818)
+    if (pilot_bin) {                                  // base pattern rotated left by one per symbol for HT / VHT (:811-818)
       const int idx = leg ? pil_i : ((pil_i + dsym) & 3);
-      xr = (double)((idx == 3 ? -1.0f : 1.0f) * pol);
+      float base = idx == 3 ? -1.0f : 1.0f;                                       // {1,1,1,-1}
+      if (P.format == C8P_F_HT && nss == 2) base = ss == 0 ? (idx >= 2 ? -1.0f : 1.0f)      // {1,1,-1,-1}
+                                                           : ((idx == 1 || idx == 2) ? -1.0f : 1.0f);   // {1,-1,-1,1}
+      xr = (double)(base * pol);
     } else if (ak >= 1 && ak <= lim) {
       const int j = leg ? qidx_l(lane) : qidx_nl(lane);
       const int mi = nbpsc_index(m.nb);
-      const int16_t* map = leg ? T->deintL[mi] : T->deintNL[mi];
+      const int16_t* map = leg ? T->deintL[mi] : (nss == 2 ? T->deint2ss[ss][mi] : T->deintNL[mi]);   // (2 chains: de-interleave fused with the stream parser)
       const uint8_t* cb = coded + P.coded_off + (size_t)dsym * m.ncbps;
       uint8_t bits[8];
       for (int b = 0; b < m.nb; b++) bits[b] = cb[map[j * m.nb + b]];
@@ -267,8 +293,15 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
       }
     }
   }
+  if (shift) {                                        // procLegacyCSD / procCSD: X[k] *= exp(-j 2 pi shift k / 64)
+    const int mm = (shift * k) & 63;                   // e^{-j 2 pi mm / 64} from the twiddle table
+    const double2 w = T->tw[mm & 31];
+    const double wr = mm < 32 ? w.x : -w.x, wi = mm < 32 ? w.y : -w.y;
+    const double ar = xr * wr - xi * wi, ai = xr * wi + xi * wr;
+    xr = ar; xi = ai;
+  }
   const double2 t = wave_ifft64_d(xr, xi, T);
-  const double sc = 1.0 / sqrt(ntf);
+  const double sc = 1.0 / sqrt(ntf * (double)nss);
   st[wv][lane] = make_double2(t.x * sc, t.y * sc);
   __syncthreads();
   // ---- 80 output samples: GI (or the 160-sample training field layout), junction halving, amplitude
@@ -281,6 +314,6 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
     double2 v = st[wv][src];
     const bool junction = !(P.flags & C8P_TX_NO_WINDOW) && ((g == 159 || g == 160) || (g >= 319 && ((g + 1) % 80 == 0) && g + 1 < n_samp) || (g >= 320 && (g % 80 == 0)));
     const double a = (double)P.mult * (junction ? 0.5 : 1.0);
-    iq[P.iq_off + (unsigned long long)g] = mk((float)(v.x * a), (float)(v.y * a));
+    iq[P.iq_off + (unsigned long long)ss * P.stride + (unsigned long long)g] = mk((float)(v.x * a), (float)(v.y * a));
   }
 }

@@ -44,7 +44,7 @@ def load_library():
     L.c8p_signal.argtypes = [C.c_void_p, C.POINTER(abi.SignalIn)]
     L.c8p_detect.argtypes = [C.c_void_p, C.POINTER(abi.DetectIn)]
     L.c8p_tx.argtypes = [C.c_void_p, C.POINTER(abi.TxIn)]
-    L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
+    L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_sync.argtypes = [C.c_void_p]
     L.c8p_buffer.restype = C.c_void_p
     L.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]

@@ -177,8 +177,11 @@ typedef struct c8p_tx_pkt {
   uint8_t  scr_seed;    /* initial scrambler state, 1..127 (the reference toolbox uses 93)                           */
   uint8_t  flags;       /* C8P_TX_NO_WINDOW: do not halve the two samples at every field junction (the toolbox's
                            procConcat2Symbol does; the C++ chain only touches the legacy preamble, pad_impl.cc:68-71)   */
-  float    mult;        /* amplitude multiplier (genFinalSig; tools/pktGenExample.py uses 12.0)                      */
+  float    mult;        /* amplitude multiplier (genFinalSig; tools/pktGenExample.py uses 12.0, x sqrt(2) for 2 streams) */
   uint32_t gap;         /* zero items inserted in the output stream before this packet                               */
+  uint8_t  nss;         /* transmit chains / spatial streams: 0 or 1 = one, 2 = two (HT: mcs stays the per-stream rate 0-7,
+                           the HT-SIG field carries mcs + 8; VHT with len = 0 and nss = 2: the NDP sounding packet)     */
+  uint8_t  rsv[3];
 } c8p_tx_pkt;
 
 #define C8P_TX_NO_WINDOW 1
@@ -281,7 +284,8 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_DET_AC   11 /* float[n - n_hist]: presiso output 0 (autocorrelation magnitude / energy) of the new items  */
 #define C8P_BUF_DET_TRIG 12 /* uint8[n - n_hist]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
 #define C8P_BUF_DET_CONJ 13 /* c8p_c32[n - n_hist] (keep = 1): presiso output 1                                       */
-#define C8P_BUF_TX_IQ    14 /* c8p_c32[]: the transmitted stream, packets at tx_desc[p].iq_off, gaps are zeros                     */
+#define C8P_BUF_TX_IQ    14 /* c8p_c32[]: the transmitted stream(s), packets at tx_desc[p].iq_off, gaps are zeros; when any packet
+                               has two chains the buffer holds chain 0 then chain 1 (each half = the whole stream length)       */
 #define C8P_BUF_TX_DESC  15 /* c8p_tx_desc[n_pkt]                                                                              */
 #define C8P_BUF_TX_CODED 16 /* uint8[]: punctured coded bits (encode's output), 1 bit per byte                                 */
 #define C8P_BUF_COUNT    17
@@ -313,7 +317,7 @@ int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLR
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
 int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
 int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */
-int c8p_tx_plan_of(int format, int mcs, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
+int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
 int c8p_sync  (c8p_ctx* ctx);
 
 /* Device pointer / size in bytes of a result arena of the last submit. */

@@ -14,11 +14,13 @@ import pytest
 from c8p_cases import ampdu_vht
 from c8p_testlib import abi, load_npz, oracle, oracle_rx
 
-FIX = {}
+FIX, FIX2 = {}, {}
 for _fn in ("packets_sweep.npz", "packets_cfg.npz"):
     for _name, _d in load_npz(_fn).items():
         if int(_d["nss"]) == 1 and len(_d["mpdu"]):
             FIX[_name] = _d
+        elif int(_d["nss"]) == 2:
+            FIX2[_name] = _d                   # HT MCS 8-15, VHT 2 streams MCS 0-8, the VHT NDP, BASELINE cfg 3
 
 
 def psdu_of(fmt, mpdu):
@@ -44,6 +46,18 @@ def test_oracle_tx_reproduces_the_reference_toolbox(name):
     assert np.max(np.abs(iq - tx)) <= 1e-6 * np.max(np.abs(tx))
 
 
+@pytest.mark.parametrize("name", sorted(FIX2))
+def test_oracle_tx_two_streams_reproduces_the_reference_toolbox(name):
+    d = FIX2[name]
+    fmt, mcs = int(d["fmt"]), int(d["mcs"])
+    mp = d["mpdu"].tobytes()
+    ps = (ampdu_vht(mp) if len(mp) else b"") if fmt == abi.F_VHT else mp
+    iq, coded = oracle().tx_packet2(fmt, mcs % 8 if fmt == abi.F_HT else mcs, 2, ps, mult=12.0 * np.sqrt(2))   # gen_golden.py: MULT * sqrt(2)
+    assert iq.shape == d["tx"].shape
+    assert np.array_equal(coded, d["coded"])
+    assert np.max(np.abs(iq - d["tx"])) <= 1e-6 * np.max(np.abs(d["tx"]))
+
+
 def random_packets(rng, n, lens=(14, 1600)):
     specs = []
     for _ in range(n):
@@ -55,12 +69,12 @@ def random_packets(rng, n, lens=(14, 1600)):
     return specs
 
 
-def tx_batch(specs, gap=700, seed=93, mult=12.0):
+def tx_batch(specs, gap=700, seed=93, mult=12.0, nss=1):
     pk = np.zeros(len(specs), abi.TX_PKT_DT)
-    arena, off = [], 0
+    arena, off = [np.zeros(4, np.uint8)], 4
     for i, (fmt, mcs, mpdu, ps) in enumerate(specs):
         pk[i]["psdu_off"], pk[i]["len"], pk[i]["format"], pk[i]["mcs"] = off, len(ps), fmt, mcs
-        pk[i]["scr_seed"], pk[i]["mult"], pk[i]["gap"] = seed, mult, gap
+        pk[i]["scr_seed"], pk[i]["mult"], pk[i]["gap"], pk[i]["nss"] = seed, mult, gap, nss
         arena.append(np.frombuffer(ps, np.uint8))
         off += len(ps)
     return pk, np.concatenate(arena)
@@ -197,3 +211,94 @@ def test_gpu_new_entry_points_reject_bad_input():
         eng.signal(ev, x)
     assert len(eng.detect(x)) == 0
     eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tx_two_streams_matches_oracle_and_toolbox():
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(9)
+    specs = []
+    for d in FIX2.values():
+        fmt, mcs, mp = int(d["fmt"]), int(d["mcs"]), d["mpdu"].tobytes()
+        specs.append((fmt, mcs % 8 if fmt == abi.F_HT else mcs, mp, (ampdu_vht(mp) if len(mp) else b"") if fmt == abi.F_VHT else mp))
+    for fmt in (1, 2):
+        for mcs in (0, 3, 7):
+            for ln in (4, 20, 61, 1000, 4092):
+                specs.append((fmt, mcs, b"", bytes(rng.integers(0, 256, size=ln + ((-ln) % 4 if fmt == 2 else 0), dtype=np.uint8))))
+    mult = np.float32(12.0 * np.sqrt(2))
+    pk, arena = tx_batch(specs, gap=0, mult=mult, nss=2)
+    eng = engine.Engine(device=0)
+    eng.tx(pk, arena)
+    eng.sync()
+    iq = eng.fetch(abi.BUF_TX_IQ, np.complex64)
+    coded = eng.fetch(abi.BUF_TX_CODED, np.uint8)
+    desc = eng.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)
+    eng.close()
+    half = len(iq) // 2
+    o = oracle()
+    for i, (fmt, mcs, mpdu, ps) in enumerate(specs):
+        oiq, ocoded = o.tx_packet2(fmt, mcs, 2, ps, mult=float(mult))
+        d = desc[i]
+        assert int(d["n_samp"]) == oiq.shape[1] and int(d["n_coded"]) == len(ocoded), (i, fmt, mcs, len(ps))
+        assert np.array_equal(coded[int(d["coded_off"]):int(d["coded_off"]) + len(ocoded)], ocoded), (i, fmt, mcs, len(ps))
+        for a in range(2):
+            got = iq[a * half + int(d["iq_off"]):a * half + int(d["iq_off"]) + oiq.shape[1]]
+            assert np.max(np.abs(got - oiq[a])) <= 1e-6 * np.max(np.abs(oiq)), (i, a, fmt, mcs, len(ps))
+    for (name, d), i in zip(FIX2.items(), range(len(FIX2))):
+        for a in range(2):
+            got = iq[a * half + int(desc[i]["iq_off"]):a * half + int(desc[i]["iq_off"]) + int(desc[i]["n_samp"])]
+            assert np.max(np.abs(got - d["tx"][a])) <= 1e-6 * np.max(np.abs(d["tx"])), (name, a)
+
+
+@pytest.mark.gpu
+def test_gpu_loopback_two_streams_through_a_2x2_channel():
+    """c8p_tx (2 chains) -> flat 2x2 channel + AWGN (torch) -> c8p_detect on antenna 0 -> c8p_signal (2 antennas) -> c8p_rx"""
+    import torch
+    from c8p_testlib import H22
+    from gr_ieee80211_amd import engine
+    from test_detect_frontend import consume_filter
+    rng = np.random.default_rng(44)
+    specs = []
+    for _ in range(60):
+        fmt = int(rng.integers(1, 3))
+        mcs = int(rng.integers(0, 8 if fmt == 1 else 9))
+        mpdu = mpdu_with_fcs(rng, int(rng.integers(30, 1500)))
+        specs.append((fmt, mcs, mpdu, psdu_of(fmt, mpdu)))
+    pk, arena = tx_batch(specs, gap=500, mult=0.3 * np.sqrt(2), nss=2)
+    pk["flags"] = abi.TX_NO_WINDOW
+    eng = engine.Engine(device=0)
+    eng.tx(pk, arena, tail_gap=600)
+    eng.sync()
+    tx = torch.from_numpy(eng.fetch(abi.BUF_TX_IQ, np.complex64)).cuda()
+    n = tx.numel() // 2
+    t0, t1 = tx[:n], tx[n:]
+    H = torch.tensor(H22).cuda()
+    torch.manual_seed(3)
+    rx = torch.stack([H[0, 0] * t0 + H[0, 1] * t1, H[1, 0] * t0 + H[1, 1] * t1])
+    rx = (torch.view_as_real(rx) + 8.0e-5 * torch.randn(2, n, 2, device="cuda")).contiguous()     # antenna 0 | antenna 1
+    x = engine.DevArray(rx.data_ptr(), 2 * n, rx)
+    e2 = engine.Engine(device=0)
+    ev = e2.detect(engine.DevArray(rx.data_ptr(), n, rx))
+    s = np.zeros(len(ev), abi.SIG_IN_DT)
+    s["raw_off"][:, 0] = ev["index"]; s["raw_off"][:, 1] = n + ev["index"]
+    s["n_avail"] = n - ev["index"]
+    s["cfo_rad"], s["snr"], s["rssi"], s["n_ant"] = ev["rad"], ev["snr"], ev["rssi"], 2
+    e3 = engine.Engine(device=0)
+    e3.signal(s, x)
+    e3.sync()
+    gpk = e3.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    keep = consume_filter(ev, gpk)
+    assert len(keep) == len(specs)
+    pi, bi = e3.buffer(abi.BUF_SIG_IQ)
+    pc, bc = e3.buffer(abi.BUF_SIG_CHAN)
+    e4 = engine.Engine(device=0)
+    e4.rx(gpk[keep], engine.DevArray(pi, bi // 8), engine.DevArray(pc, bc // 8))
+    res = e4.results(want_llr=False)
+    ok = 0
+    for r, (fmt, mcs, mpdu, ps) in zip(res, specs):
+        want = bytes([fmt, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs + 8 if fmt == 1 else mcs])
+        assert r["pdus"] in ([], [want])
+        ok += r["pdus"] == [want]
+    assert ok >= 0.9 * len(specs), ok
+    for e in (eng, e2, e3, e4):
+        e.close()
