@@ -213,11 +213,35 @@ def frontend_detect(torch, dev, local, n_target=32 << 20):
     kt = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in eng.kernel_times().items()}
     eng.close()
     pre_s = kt["presiso"] * 1e-3
-    return {"samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
+    tx = tx_rate(engine, local)
+    return {"tx_packets_per_s": tx, "samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
             "x_realtime_20MSps": n / dt / 20e6, "ms_per_call": 1e3 * dt,
             "kernel_ms": {k: round(kt[k], 4) for k in ("presiso", "trigger", "syncevt")},
             "presiso_roofline": {"bound": "hbm", "alg_bytes_per_sample": 12, "achieved": 12.0 * n / pre_s / 1e9 if pre_s > 0 else 0.0,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (12.0 * n / pre_s / 1e9) / HBM_PEAK_GBS if pre_s > 0 else 0.0}}
+
+
+def tx_rate(engine, local, n=4096):
+    """SURVEY §8f-4 stage: c8p_tx packets/s for the cfg-2 packet shape (4096 x VHT MCS7, 1464-byte A-MPDU), PSDUs resident
+    on the host (0.15 MB upload per call inside the timing)."""
+    from c8p_testlib import abi
+    rng = np.random.default_rng(3)
+    pk = np.zeros(n, abi.TX_PKT_DT)
+    pk["psdu_off"] = 1464 * np.arange(n); pk["len"] = 1464; pk["format"] = abi.F_VHT; pk["mcs"] = 7
+    pk["scr_seed"] = 93; pk["mult"] = 12.0; pk["gap"] = 100; pk["nss"] = 1
+    arena = rng.integers(0, 256, size=1464 * n, dtype=np.uint8)
+    eng = engine.Engine(device=local)
+    for _ in range(3):
+        eng.tx(pk, arena)
+    eng.sync()
+    t0 = time.perf_counter()
+    K = 10
+    for _ in range(K):
+        eng.tx(pk, arena)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / K
+    eng.close()
+    return n / dt
 
 
 def cpu_baseline(pk, iq, chan, budget_s=12.0):

@@ -1,7 +1,8 @@
 // c8p_tx.h — transmit chain for one spatial stream at 20 MHz, long GI, on gfx950 (SURVEY.md §8f-4 "TX-lite"):
 // what lib/encode_impl.cc + lib/modulation_impl.cc (cloud80211phy.cc:2594-3180) / tools/phy80211.py produce.
 //
-//   k_tx_bits   wave = packet.  SIG fields (L-SIG, HT-SIG, VHT-SIG-A/B: rate-1/2 BCC + interleave, lane 0), then the data
+//   k_tx_bits   wave = packet.  SIG fields (L-SIG, HT-SIG, VHT-SIG-A/B: field bits in one 64-bit word, every lane its own
+//               coded bits, CRC-8 on the word), then the data
 //               field: service + PSDU (+ VHT EOF / zero padding) assembled 64 bits per lane-word, scrambled with the
 //               packed doubled LFSR sequence, tail zeroed, and BCC + puncturing evaluated per OUTPUT bit (every coded
 //               bit is a parity over a 7-bit window of the packed data bits) — nothing is sequential.
@@ -61,25 +62,26 @@ __host__ __device__ __forceinline__ int tx_plan_of(int format, int mcs, int nss,
   return 1;
 }
 
-__device__ __forceinline__ void tx_bcc_sig(const uint8_t* b, int n, uint8_t* c)   // rate 1/2: A (0155), B (0117) on st = {.., in[j-1], in[j]}
+// coded bit q (A at even, B at odd positions) of the rate-1/2 encoder run over the field bits in `w` (bit i = i-th input)
+__device__ __forceinline__ uint8_t tx_bcc_bit(unsigned long long w, int q)
 {
-  unsigned st = 0;
-  for (int j = 0; j < n; j++) {
-    st = ((st << 1) & 0x7e) | b[j];
-    c[2 * j] = (uint8_t)(__popc(st & 0155) & 1);
-    c[2 * j + 1] = (uint8_t)(__popc(st & 0117) & 1);
-  }
+  const int j = q >> 1, lo = j - 6;
+  const unsigned win = (unsigned)(lo >= 0 ? (w >> lo) : (w << (-lo))) & 0x7fu;     // bit k = input bit j - 6 + k
+  return (uint8_t)(__popc(win & ((q & 1) ? 0171u : 0133u)) & 1);
 }
-__device__ __forceinline__ void tx_crc8(const uint8_t* b, int n, uint8_t* out8)
+// genBitBitCrc8 over the first n bits of w; returns the 8 CRC bits, bit i = i-th bit in transmission order
+__device__ __forceinline__ unsigned long long tx_crc8_word(unsigned long long w, int n)
 {
   unsigned c = 0xff;
   for (int i = 0; i < n; i++) {
-    const unsigned fb = ((c >> 7) & 1u) ^ b[i];
+    const unsigned fb = ((c >> 7) & 1u) ^ (unsigned)((w >> i) & 1ull);
     c = (c << 1) & 0xffu;
     if (fb) c ^= 0x07u;
   }
   c ^= 0xffu;
-  for (int i = 0; i < 8; i++) out8[i] = (uint8_t)((c >> (7 - i)) & 1u);
+  unsigned long long r = 0;
+  for (int i = 0; i < 8; i++) r |= (unsigned long long)((c >> (7 - i)) & 1u) << i;
+  return r;
 }
 // byte b of the padded PSDU: the caller's bytes, then (VHT) EOF delimiters {01 00 79 4e}, then zero octets
 __device__ __forceinline__ unsigned tx_psdu_byte(const uint8_t* __restrict__ psdu, int b, int len, int npad_eof)
@@ -96,7 +98,6 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
                                                 uint8_t* __restrict__ sigbits, unsigned int* __restrict__ unit2pkt, int n)
 {
   __shared__ unsigned long long dw[(C8P_DECODE_T_MAX + 63) / 64 + 2];   // scrambled data bits, 64 per word
-  __shared__ uint8_t s_crc[8];
   const int p = blockIdx.x;
   if (p >= n) return;
   const int lane = lane_id();
@@ -104,49 +105,35 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
   const c8p_tx_plan& m = P.p;
   uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
   for (unsigned i = lane; i < (unsigned)(m.n_samp / 80 * P.nss); i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
-  if (lane == 0) {
-    uint8_t b[48], c[96];
-    // ---- L-SIG  tools/phy80211.py:237-282
-    for (int i = 0; i < 24; i++) b[i] = 0;
+  // ---- SIG fields.  The field bits live in a 64-bit word (uniform); every lane produces coded bits on its own: the
+  // rate-1/2 encoder output 2j / 2j+1 is the parity of the 7-bit window ending at input bit j under 133 / 171.
+  unsigned long long crcb = 0;                        // VHT-SIG-B CRC (service bits 8..15), bit i = i-th CRC bit
+  {
+    // L-SIG  tools/phy80211.py:237-282
     const int rate = P.format == C8P_F_L ? P.mcs : 0;
     const unsigned rb = rate == 0 ? 0xBu : rate == 1 ? 0xFu : rate == 2 ? 0xAu : rate == 3 ? 0xEu : rate == 4 ? 0x9u : rate == 5 ? 0xDu : rate == 6 ? 0x8u : 0xCu;
-    for (int i = 0; i < 4; i++) b[i] = (uint8_t)((rb >> i) & 1u);                 // C_LEGACY_RATE_BIT
-    for (int i = 0; i < 12; i++) b[5 + i] = (uint8_t)((m.legacy_len >> i) & 1);
-    int par = 0; for (int i = 0; i < 17; i++) par += b[i];
-    b[17] = (uint8_t)(par & 1);
-    tx_bcc_sig(b, 24, c);
-    for (int k = 0; k < 48; k++) sb[3 * (k % 16) + k / 16] = c[k];                 // procInterleaveSigL
-    for (int i = 0; i < 8; i++) s_crc[i] = 0;
+    unsigned long long w = (unsigned long long)rb | ((unsigned long long)(m.legacy_len & 0xfff) << 5);     // C_LEGACY_RATE_BIT, LENGTH
+    w |= (unsigned long long)(__popcll(w & 0x1ffffull) & 1) << 17;                                         // even parity
+    if (lane < 48) sb[3 * (lane % 16) + lane / 16] = tx_bcc_bit(w, lane);                                  // procInterleaveSigL
     if (P.format != C8P_F_L) {
-      for (int i = 0; i < 48; i++) b[i] = 0;
       if (P.format == C8P_F_HT) {                                                   // :284-350
         const int mf = P.mcs + 8 * (P.nss - 1);
-        for (int i = 0; i < 7; i++) b[i] = (uint8_t)((mf >> i) & 1);
-        for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((m.psdu_len >> i) & 1);
-        b[24] = 1; b[25] = 1; b[26] = 1;
+        w = (unsigned long long)(mf & 0x7f) | ((unsigned long long)(m.psdu_len & 0xffff) << 8) | (7ull << 24);
       } else {                                                                      // :352-455, SU, group id 0, partial AID 0
-        b[2] = 1; b[23] = 1;
-        for (int i = 0; i < 3; i++) b[10 + i] = (uint8_t)(((P.nss - 1) >> i) & 1);
-        for (int i = 0; i < 4; i++) b[28 + i] = (uint8_t)((P.mcs >> i) & 1);
-        b[33] = 1;
+        w = (1ull << 2) | ((unsigned long long)((P.nss - 1) & 7) << 10) | (1ull << 23) | ((unsigned long long)(P.mcs & 15) << 28) | (1ull << 33);
       }
-      tx_crc8(b, 34, b + 34);
-      tx_bcc_sig(b, 48, c);
-      for (int h = 0; h < 2; h++) for (int k = 0; k < 48; k++) sb[48 + 48 * h + 3 * (k % 16) + k / 16] = c[48 * h + k];
+      w |= tx_crc8_word(w, 34) << 34;
+      for (int q = lane; q < 96; q += 64) { const int h = q / 48, k = q - 48 * h; sb[48 + 48 * h + 3 * (k % 16) + k / 16] = tx_bcc_bit(w, q); }
     }
     if (P.format == C8P_F_VHT) {                                                    // :512-569
-      for (int i = 0; i < 26; i++) b[i] = 0;
       if (P.len > 0) {
-        const int l4 = ((int)P.len + 3) / 4;
-        for (int i = 0; i < 17; i++) b[i] = (uint8_t)((l4 >> i) & 1);
-        b[17] = b[18] = b[19] = 1;
-        tx_crc8(b, 20, s_crc);
-      } else {                                          // NDP: C_NDP_SIG_B_20 = 00000111010001000010
-        const unsigned ndp = 0x422E0u;
-        for (int i = 0; i < 20; i++) b[i] = (uint8_t)((ndp >> i) & 1u);
-      }
-      tx_bcc_sig(b, 26, c);
-      for (int r = 0; r < 52; r++) sb[144 + r] = c[T->deintSigB[r]];
+        w = (unsigned long long)((((int)P.len + 3) / 4) & 0x1ffff) | (7ull << 17);
+        crcb = tx_crc8_word(w, 20);
+      } else w = 0x422E0ull;                                                        // NDP: C_NDP_SIG_B_20
+      __shared__ uint8_t s_c52[64];
+      if (lane < 52) s_c52[lane] = tx_bcc_bit(w, lane);
+      __syncthreads();
+      if (lane < 52) sb[144 + lane] = s_c52[T->deintSigB[lane]];
     }
   }
   __syncthreads();
@@ -159,8 +146,7 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
     unsigned long long w = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) w |= (unsigned long long)tx_psdu_byte(psdu, 8 * c - 2 + k, (int)P.len, m.npad_eof) << (8 * k);
-    if (c == 0 && P.format == C8P_F_VHT)
-      for (int i = 0; i < 8; i++) w |= (unsigned long long)s_crc[i] << (8 + i);    // service bits 8..15 = SIG-B CRC
+    if (c == 0 && P.format == C8P_F_VHT) w |= crcb << 8;                            // service bits 8..15 = SIG-B CRC
     // scramble: output bit of data bit i = seq[(ph + i) mod 127]                       procScramble :800-806
     const int o = (ph + 64 * c) % 127, wi = o >> 6, sh = o & 63;
     unsigned long long sq = T->scrW[wi] >> sh;
