@@ -45,7 +45,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # any torch.distributed.run launch
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
@@ -84,7 +85,7 @@ def main():
     def barrier():
         eng.sync()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -107,7 +108,7 @@ def main():
     eng.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -162,7 +163,7 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
