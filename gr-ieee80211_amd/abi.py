@@ -9,7 +9,7 @@ import numpy as np
 
 ABI_VERSION = 1
 MEM_HOST, MEM_DEVICE = 0, 1
-F_L, F_HT, F_VHT, F_VHT_CHAN = 0, 1, 2, 20
+F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
 BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN, \
@@ -85,13 +85,19 @@ class TxPkt(C.Structure):
                 ("flags", C.c_uint8), ("mult", C.c_float), ("gap", C.c_uint32), ("nss", C.c_uint8), ("rsv", C.c_uint8 * 3)]
 
 
+class TxMu(C.Structure):
+    _fields_ = [("psdu_off", C.c_uint64), ("len", C.c_uint32), ("mcs", C.c_uint8), ("group_id", C.c_uint8), ("rsv", C.c_uint8 * 2),
+                ("q_off", C.c_uint64)]
+
+
 class TxDesc(C.Structure):
-    _fields_ = [("iq_off", C.c_uint64), ("coded_off", C.c_uint64), ("n_samp", C.c_uint32), ("n_coded", C.c_uint32)]
+    _fields_ = [("iq_off", C.c_uint64), ("coded_off", C.c_uint64), ("n_samp", C.c_uint32), ("n_coded", C.c_uint32),
+                ("coded_off1", C.c_uint64), ("n_coded1", C.c_uint32), ("rsv", C.c_uint32)]
 
 
 class TxIn(C.Structure):
     _fields_ = [("n_pkt", C.c_int32), ("mem", C.c_int32), ("pkts", C.c_void_p), ("psdu", C.c_void_p), ("n_psdu", C.c_uint64),
-                ("tail_gap", C.c_uint32), ("rsv", C.c_uint32)]
+                ("tail_gap", C.c_uint32), ("n_mu", C.c_uint32), ("mu", C.c_void_p), ("bfq", C.c_void_p), ("n_bfq", C.c_uint64)]
 
 
 class TxPlan(C.Structure):
@@ -125,6 +131,7 @@ SIG_IN_DT = _np_dtype(SigIn)
 SYNC_EVT_DT = _np_dtype(SyncEvt)
 TX_PKT_DT = _np_dtype(TxPkt)
 TX_DESC_DT = _np_dtype(TxDesc)
+TX_MU_DT = _np_dtype(TxMu)
 
 TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
 

@@ -188,7 +188,7 @@ struct Slot {
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
   Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_cnt, d_det_job, d_det_mark,
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
-  Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc;   // transmit chain
+  Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc, d_tx_bfq;   // transmit chain
   int n_pkt = 0;
   size_t used[C8P_BUF_COUNT] = {};
   const void* ptr[C8P_BUF_COUNT] = {};
@@ -325,7 +325,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt,
                    &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig,
                    &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
-                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_coded, &sl.d_tx_sig,
+                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
                    &sl.d_tx_u2p, &sl.d_tx_iq, &sl.d_tx_desc};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
@@ -876,6 +876,13 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
 }
 
 // ------------------------------------------------------------------------------------------------ transmit chain
+extern "C" int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2)
+{
+  c8p_tx_plan a, b;
+  const int ok = tx_plan_mu(mcs0, len0, mcs1, len1, a, b);
+  if (plan2) { plan2[0] = a; plan2[1] = b; }
+  return ok;
+}
 extern "C" int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan)
 {
   c8p_tx_plan p;
@@ -901,42 +908,63 @@ extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
   for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
   const int n = in->n_pkt;
   if (n == 0) return C8P_OK;
-  std::vector<TxPlan> plans(n);
+  std::vector<TxPlan> plans;                           // one per bit job: a packet, or each user of an MU-MIMO packet
+  plans.reserve((size_t)n + in->n_mu);
   std::vector<c8p_tx_desc> desc(n);
   uint64_t iq = 0, coded = 0;
-  uint32_t units = 0;
+  uint32_t units = 0, mu_used = 0;
   int max_nss = 1;
   for (int p = 0; p < n; p++) {
     const c8p_tx_pkt& k = in->pkts[p];
-    TxPlan& P = plans[p];
-    const int nss = k.nss < 1 ? 1 : k.nss;
+    TxPlan P = TxPlan{}, P1 = TxPlan{};
+    const bool mu = k.format == C8P_F_VHT_MU;
+    const int nss = mu ? 2 : (k.nss < 1 ? 1 : k.nss);
     max_nss = std::max(max_nss, nss);
-    if (!tx_plan_of(k.format, k.mcs, nss, (int)k.len, P.p)) { c->err = "unsupported tx format / mcs / streams / length"; return C8P_EINVAL; }
+    if (mu) {
+      if (!in->mu || mu_used >= in->n_mu || !in->bfq) { c->err = "MU-MIMO packet without its c8p_tx_mu entry / steering matrices"; return C8P_EINVAL; }
+      const c8p_tx_mu& k1 = in->mu[mu_used++];
+      if (!tx_plan_mu(k.mcs, (int)k.len, k1.mcs, (int)k1.len, P.p, P1.p)) { c->err = "unsupported MU-MIMO mcs / length"; return C8P_EINVAL; }
+      if (k1.psdu_off + k1.len > in->n_psdu) { c->err = "psdu outside the arena"; return C8P_ERANGE; }
+      if (k1.q_off + 256 > in->n_bfq) { c->err = "steering matrix outside the arena"; return C8P_ERANGE; }
+      if (k1.group_id < 1 || k1.group_id > 62) { c->err = "MU-MIMO group id must be 1..62"; return C8P_EINVAL; }
+      P.mu = 1; P1.mu = 2; P.gid = P1.gid = k1.group_id; P.q_off = P1.q_off = k1.q_off;
+      P1.psdu_off = k1.psdu_off; P1.len = k1.len; P1.mcs = k1.mcs;
+    } else if (!tx_plan_of(k.format, k.mcs, nss, (int)k.len, P.p)) { c->err = "unsupported tx format / mcs / streams / length"; return C8P_EINVAL; }
     if (k.psdu_off + k.len > in->n_psdu) { c->err = "psdu outside the arena"; return C8P_ERANGE; }
     if (k.scr_seed == 0 || k.scr_seed > 127) { c->err = "scrambler seed must be 1..127"; return C8P_EINVAL; }
     iq += k.gap;
     P.iq_off = iq; P.coded_off = coded; P.psdu_off = k.psdu_off; P.len = k.len;
-    P.format = k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.flags = k.flags; P.mult = k.mult; P.unit_base = units; P.nss = nss;
+    P.format = mu ? C8P_F_VHT : k.format; P.mcs = k.mcs; P.seed = k.scr_seed; P.flags = k.flags; P.mult = k.mult; P.unit_base = units; P.nss = nss;
+    desc[p] = c8p_tx_desc{};
     desc[p].iq_off = iq; desc[p].coded_off = coded; desc[p].n_samp = (uint32_t)P.p.n_samp; desc[p].n_coded = (uint32_t)(P.p.nsym * P.p.ncbps);
     iq += (uint64_t)P.p.n_samp; coded += ((uint64_t)desc[p].n_coded + 15u) & ~(uint64_t)15u; units += (uint32_t)(P.p.n_samp / 80 * nss);
+    plans.push_back(P);
+    if (mu) {
+      P1.iq_off = P.iq_off; P1.coded_off = coded; P1.format = C8P_F_VHT; P1.seed = P.seed; P1.flags = P.flags; P1.mult = P.mult;
+      P1.unit_base = P.unit_base; P1.nss = 2;
+      desc[p].coded_off1 = coded; desc[p].n_coded1 = (uint32_t)(P1.p.nsym * P1.p.ncbps);
+      coded += ((uint64_t)desc[p].n_coded1 + 15u) & ~(uint64_t)15u;
+      plans.push_back(P1);
+    }
   }
+  const int nj = (int)plans.size();
   iq += in->tail_gap;
   const uint64_t stream_len = iq;                      // items per chain
   for (TxPlan& P : plans) P.stride = stream_len;
   iq *= (uint64_t)max_nss;
   int rc;
-  const size_t plan_bytes = align256(sizeof(TxPlan) * (size_t)n), desc_bytes = align256(sizeof(c8p_tx_desc) * (size_t)n);
+  const size_t plan_bytes = align256(sizeof(TxPlan) * (size_t)nj), desc_bytes = align256(sizeof(c8p_tx_desc) * (size_t)n);
   if ((rc = ensure_host(c, plan_bytes + desc_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_tx_plan, plan_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_tx_desc, desc_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_tx_coded, coded + 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_tx_sig, (size_t)C8P_TX_SIGBITS * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_tx_sig, (size_t)C8P_TX_SIGBITS * (size_t)nj)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_tx_u2p, sizeof(unsigned) * (size_t)(units + 1))) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_tx_iq, sizeof(cf) * (size_t)(iq + 1))) != C8P_OK) return rc;
   HIPCHK(c, hipStreamSynchronize(S.stream));
-  memcpy(S.h_stage, plans.data(), sizeof(TxPlan) * (size_t)n);
+  memcpy(S.h_stage, plans.data(), sizeof(TxPlan) * (size_t)nj);
   memcpy((char*)S.h_stage + plan_bytes, desc.data(), sizeof(c8p_tx_desc) * (size_t)n);
-  HIPCHK(c, hipMemcpyAsync(S.d_tx_plan.p, S.h_stage, sizeof(TxPlan) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+  HIPCHK(c, hipMemcpyAsync(S.d_tx_plan.p, S.h_stage, sizeof(TxPlan) * (size_t)nj, hipMemcpyHostToDevice, S.stream));
   HIPCHK(c, hipMemcpyAsync(S.d_tx_desc.p, (char*)S.h_stage + plan_bytes, sizeof(c8p_tx_desc) * (size_t)n, hipMemcpyHostToDevice, S.stream));
   const uint8_t* d_psdu = in->psdu;
   if (in->mem == C8P_MEM_HOST) {
@@ -944,16 +972,22 @@ extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
     HIPCHK(c, hipMemcpyAsync(S.d_tx_psdu.p, in->psdu, in->n_psdu, hipMemcpyHostToDevice, S.stream));
     d_psdu = (const uint8_t*)S.d_tx_psdu.p;
   }
+  const cf* d_bfq = (const cf*)in->bfq;
+  if (in->mem == C8P_MEM_HOST && mu_used) {
+    if ((rc = ensure(c, S.d_tx_bfq, sizeof(cf) * in->n_bfq + 16)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_tx_bfq.p, in->bfq, sizeof(cf) * in->n_bfq, hipMemcpyHostToDevice, S.stream));
+    d_bfq = (const cf*)S.d_tx_bfq.p;
+  }
   HIPCHK(c, hipMemsetAsync(S.d_tx_iq.p, 0, sizeof(cf) * (size_t)iq, S.stream));      // the gaps
   {
     KTimer kt(c, C8P_K_TXBITS);
-    hipLaunchKernelGGL(k_tx_bits, dim3(n), dim3(64), 0, S.stream, (const TxPlan*)S.d_tx_plan.p, d_psdu, (const DevTables*)c->d_tab,
-                       (uint8_t*)S.d_tx_coded.p, (uint8_t*)S.d_tx_sig.p, (unsigned*)S.d_tx_u2p.p, n);
+    hipLaunchKernelGGL(k_tx_bits, dim3(nj), dim3(64), 0, S.stream, (const TxPlan*)S.d_tx_plan.p, d_psdu, (const DevTables*)c->d_tab,
+                       (uint8_t*)S.d_tx_coded.p, (uint8_t*)S.d_tx_sig.p, (unsigned*)S.d_tx_u2p.p, nj);
   }
   {
     KTimer kt(c, C8P_K_TXSYM);
     hipLaunchKernelGGL(k_tx_sym, dim3((units + 3) / 4), dim3(256), 0, S.stream, (const TxPlan*)S.d_tx_plan.p, (const unsigned*)S.d_tx_u2p.p,
-                       (const uint8_t*)S.d_tx_coded.p, (const uint8_t*)S.d_tx_sig.p, (const DevTables*)c->d_tab, (cf*)S.d_tx_iq.p, units);
+                       (const uint8_t*)S.d_tx_coded.p, (const uint8_t*)S.d_tx_sig.p, d_bfq, (const DevTables*)c->d_tab, (cf*)S.d_tx_iq.p, units);
   }
   HIPCHK(c, hipGetLastError());
   S.used[C8P_BUF_TX_IQ] = sizeof(cf) * (size_t)iq; S.ptr[C8P_BUF_TX_IQ] = S.d_tx_iq.p;
@@ -1010,7 +1044,7 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
                        (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
                        (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
                        (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state), (int32_t)sizeof(c8p_tx_pkt),
-                       (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan)};
-  for (int i = 0; i < 16 && i < cap; i++) dst[i] = v[i];
-  return 16;
+                       (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan), (int32_t)sizeof(c8p_tx_mu)};
+  for (int i = 0; i < 17 && i < cap; i++) dst[i] = v[i];
+  return 17;
 }

@@ -21,6 +21,9 @@ struct TxPlan {            // c8p_tx_plan + where the packet's outputs go
   unsigned long long stride;   // chain 1 starts this many items after chain 0
   float mult;
   unsigned int unit_base;  // first 80-sample unit of this packet in k_tx_sym's grid
+  int mu;                  // 0: single user; 1 / 2: user 0 / user 1 of a 2-user MU-MIMO packet (user 1's plan follows user 0's)
+  int gid;                 // MU group id (VHT-SIG-A bits 4-9)
+  unsigned long long q_off;   // MU: first item of the packet's steering matrix in the bfq arena ([64 bins, FFT order][q00 q01 q10 q11])
 };
 #define C8P_TX_SIGBITS 256  // per packet: L-SIG 48 | SIG-1 48 | SIG-2 48 | SIG-B 52 interleaved coded bits
 
@@ -59,6 +62,29 @@ __host__ __device__ __forceinline__ int tx_plan_of(int format, int mcs, int nss,
     p.n_pre = format == C8P_F_L ? 0 : 2 + 1 + nltf;
   }
   p.n_samp = 320 + 80 * (1 + p.n_pre + p.nsym);
+  return 1;
+}
+
+// 2-user MU-MIMO, one stream per user: formatToModMu (cloud80211phy.cc:2558-2585) / procPktLenAggreMu (phy80211header.py:509-525)
+__host__ __device__ __forceinline__ int tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan& p0, c8p_tx_plan& p1)
+{
+  if (len0 <= 0 || len1 <= 0 || !tx_plan_of(C8P_F_VHT, mcs0, 1, len0, p0) || !tx_plan_of(C8P_F_VHT, mcs1, 1, len1, p1)) return 0;
+  const int nsym = p0.nsym > p1.nsym ? p0.nsym : p1.nsym;
+  // both users are padded to the longer one's symbols: the padded data field must still fit the decoder's trellis limit
+  // (decode_impl.cc:93, 32782 steps) — encode2's d_bitsCoded[65728] (encode2_impl.h:74) holds two bits per data bit
+  if (nsym * p0.ndbps > C8P_DECODE_T_MAX || nsym * p1.ndbps > C8P_DECODE_T_MAX) return 0;
+  c8p_tx_plan* P[2] = {&p0, &p1};
+  const int len[2] = {len0, len1};
+  for (int u = 0; u < 2; u++) {
+    c8p_tx_plan& p = *P[u];
+    p.nsym = nsym;
+    p.psdu_len = (nsym * p.ndbps - 16 - 6) / 8;
+    p.npad_eof = (p.psdu_len - len[u]) / 4;
+    p.npad_octet = p.psdu_len - len[u] - 4 * p.npad_eof;
+    p.legacy_len = ((20 + 8 + 4 + 2 * 4 + 4 + nsym * 4 - 20) / 4) * 3 - 3;
+    p.n_pre = 2 + 1 + 2 + 1;
+    p.n_samp = 320 + 80 * (1 + p.n_pre + nsym);
+  }
   return 1;
 }
 
@@ -103,8 +129,8 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
   const int lane = lane_id();
   const TxPlan P = plans[p];
   const c8p_tx_plan& m = P.p;
-  uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
-  for (unsigned i = lane; i < (unsigned)(m.n_samp / 80 * P.nss); i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
+  uint8_t* sb = sigbits + (size_t)(P.mu == 2 ? p - 1 : p) * C8P_TX_SIGBITS;      // MU: both users share user 0's row
+  if (P.mu != 2) for (unsigned i = lane; i < (unsigned)(m.n_samp / 80 * P.nss); i += 64) unit2pkt[P.unit_base + i] = (unsigned)p;   // k_tx_sym's grid
   // ---- SIG fields.  The field bits live in a 64-bit word (uniform); every lane produces coded bits on its own: the
   // rate-1/2 encoder output 2j / 2j+1 is the parity of the 7-bit window ending at input bit j under 133 / 171.
   unsigned long long crcb = 0;                        // VHT-SIG-B CRC (service bits 8..15), bit i = i-th CRC bit
@@ -114,11 +140,13 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
     const unsigned rb = rate == 0 ? 0xBu : rate == 1 ? 0xFu : rate == 2 ? 0xAu : rate == 3 ? 0xEu : rate == 4 ? 0x9u : rate == 5 ? 0xDu : rate == 6 ? 0x8u : 0xCu;
     unsigned long long w = (unsigned long long)rb | ((unsigned long long)(m.legacy_len & 0xfff) << 5);     // C_LEGACY_RATE_BIT, LENGTH
     w |= (unsigned long long)(__popcll(w & 0x1ffffull) & 1) << 17;                                         // even parity
-    if (lane < 48) sb[3 * (lane % 16) + lane / 16] = tx_bcc_bit(w, lane);                                  // procInterleaveSigL
-    if (P.format != C8P_F_L) {
+    if (lane < 48 && P.mu != 2) sb[3 * (lane % 16) + lane / 16] = tx_bcc_bit(w, lane);                     // procInterleaveSigL
+    if (P.format != C8P_F_L && P.mu != 2) {
       if (P.format == C8P_F_HT) {                                                   // :284-350
         const int mf = P.mcs + 8 * (P.nss - 1);
         w = (unsigned long long)(mf & 0x7f) | ((unsigned long long)(m.psdu_len & 0xffff) << 8) | (7ull << 24);
+      } else if (P.mu) {                                                            // :366-416 MU: group id, nSTS 1 + 1, reserved ones
+        w = (1ull << 2) | ((unsigned long long)(P.gid & 63) << 4) | (1ull << 10) | (1ull << 13) | (1ull << 23) | (0x1full << 29);
       } else {                                                                      // :352-455, SU, group id 0, partial AID 0
         w = (1ull << 2) | ((unsigned long long)((P.nss - 1) & 7) << 10) | (1ull << 23) | ((unsigned long long)(P.mcs & 15) << 28) | (1ull << 33);
       }
@@ -126,14 +154,17 @@ __global__ __launch_bounds__(64) void k_tx_bits(const TxPlan* __restrict__ plans
       for (int q = lane; q < 96; q += 64) { const int h = q / 48, k = q - 48 * h; sb[48 + 48 * h + 3 * (k % 16) + k / 16] = tx_bcc_bit(w, q); }
     }
     if (P.format == C8P_F_VHT) {                                                    // :512-569
-      if (P.len > 0) {
+      if (P.mu) {                                                                   // :571-598 MU: length / 4 (16 bits), MCS (4 bits)
+        w = (unsigned long long)(((int)P.len / 4) & 0xffff) | ((unsigned long long)(P.mcs & 15) << 16);
+        crcb = tx_crc8_word(w, 20);
+      } else if (P.len > 0) {
         w = (unsigned long long)((((int)P.len + 3) / 4) & 0x1ffff) | (7ull << 17);
         crcb = tx_crc8_word(w, 20);
       } else w = 0x422E0ull;                                                        // NDP: C_NDP_SIG_B_20
       __shared__ uint8_t s_c52[64];
       if (lane < 52) s_c52[lane] = tx_bcc_bit(w, lane);
       __syncthreads();
-      if (lane < 52) sb[144 + lane] = s_c52[T->deintSigB[lane]];
+      if (lane < 52) sb[144 + (P.mu == 2 ? 52 : 0) + lane] = s_c52[T->deintSigB[lane]];
     }
   }
   __syncthreads();
@@ -193,9 +224,89 @@ __device__ __forceinline__ double tx_axis(const uint8_t* b, int h)
   return v;
 }
 
+enum { TXF_STF, TXF_LLTF, TXF_NLLTF, TXF_SIG, TXF_SIGB, TXF_DATA };
+struct TxField { int kind, sig_off, sig_q, dsym, ltf_i; };
+
+// frequency-domain value of this lane's bin for one field of one spatial stream (before the cyclic shift); returns ntf
+// U = the plan that owns the stream's bits (the packet's, or the user's for MU-MIMO); ss / nss = stream index / streams
+// that share U's coded bits (MU: every user is a single stream, nss = 1, ss only selects the P-matrix row)
+__device__ __forceinline__ double tx_field_x(const TxPlan& U, const TxField& f, int ss, int nss, const uint8_t* __restrict__ sb, int sigb_off,
+                                             const uint8_t* __restrict__ coded, const DevTables* __restrict__ T, int lane, double& xr, double& xi)
+{
+  const c8p_tx_plan& m = U.p;
+  const int k = lane < 32 ? lane : lane - 64;         // subcarrier of this lane's bin
+  const int ak = k < 0 ? -k : k;
+  const bool pilot_bin = ak == 7 || ak == 21;
+  const int pil_i = k == -21 ? 0 : k == -7 ? 1 : k == 7 ? 2 : 3;
+  const bool vht = U.format == C8P_F_VHT;
+  double ntf = 52.0;
+  xr = 0.0; xi = 0.0;
+  if (f.kind == TXF_STF) {                            // C_STF_L / C_STF_HT / C_STF_VHT: +-(1+j)/sqrt(2) on every 4th subcarrier
+    ntf = 12.0;
+    if (ak >= 4 && ak <= 24 && (ak & 3) == 0) {
+      const int mi = k < 0 ? (k + 24) / 4 : 6 + (k - 4) / 4;
+      const int sgn = (0xF25u >> mi) & 1u ? 1 : -1;   // {1,-1,1,-1,-1,1, -1,-1,1,1,1,1}
+      xr = xi = sgn * 0.70710678118654757;
+    }
+  } else if (f.kind == TXF_LLTF) { ntf = 52.0; xr = (double)T->ltfL[lane]; }
+  else if (f.kind == TXF_NLLTF) {                     // C_P_LTF_VHT_4 rows {1,-1},{1,1}; VHT pilots follow C_R_LTF_VHT_4 = {1,-1}
+    ntf = 56.0;
+    const double pm = (ss == 0 && f.ltf_i == 1) ? -1.0 : 1.0, rm = f.ltf_i == 1 ? -1.0 : 1.0;
+    xr = (double)T->ltfNL[lane] * ((vht && pilot_bin) ? rm : pm);
+  }
+  else if (f.kind == TXF_SIG) {
+    ntf = 52.0;
+    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
+    else if (ak >= 1 && ak <= 26) { const double v = sb[f.sig_off + qidx_l(lane)] ? 1.0 : -1.0; if (f.sig_q) xi = v; else xr = v; }
+  } else if (f.kind == TXF_SIGB) {
+    ntf = 56.0;
+    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
+    else if (ak >= 1 && ak <= 28) xr = sb[sigb_off + qidx_nl(lane)] ? 1.0 : -1.0;
+  } else {
+    const bool leg = U.format == C8P_F_L;
+    ntf = leg ? 52.0 : 56.0;
+    const int lim = leg ? 26 : 28;
+    const int p0 = leg ? 1 : (vht ? 4 : 3);
+    const float pol = T->pilotP[(p0 + f.dsym) % 127];
+    if (pilot_bin) {                                  // base pattern rotated left by one per symbol for HT / VHT (:811-818)
+      const int idx = leg ? pil_i : ((pil_i + f.dsym) & 3);
+      float base = idx == 3 ? -1.0f : 1.0f;                                       // {1,1,1,-1}
+      if (U.format == C8P_F_HT && nss == 2) base = ss == 0 ? (idx >= 2 ? -1.0f : 1.0f)      // {1,1,-1,-1}
+                                                           : ((idx == 1 || idx == 2) ? -1.0f : 1.0f);   // {1,-1,-1,1}
+      xr = (double)(base * pol);
+    } else if (ak >= 1 && ak <= lim) {
+      const int j = leg ? qidx_l(lane) : qidx_nl(lane);
+      const int mi = nbpsc_index(m.nb);
+      const int16_t* map = leg ? T->deintL[mi] : (nss == 2 ? T->deint2ss[ss][mi] : T->deintNL[mi]);   // (2 chains: de-interleave fused with the stream parser)
+      const uint8_t* cb = coded + U.coded_off + (size_t)f.dsym * m.ncbps;
+      uint8_t bits[8];
+      for (int b = 0; b < m.nb; b++) bits[b] = cb[map[j * m.nb + b]];
+      if (m.nb == 1) xr = bits[0] ? 1.0 : -1.0;
+      else {
+        const int h = m.nb >> 1;
+        const double sc = m.nb == 2 ? 1.4142135623730951 : m.nb == 4 ? 3.1622776601683795 : m.nb == 6 ? 6.4807406984078604 : 13.038404810405298;
+        xr = tx_axis(bits, h) / sc; xi = tx_axis(bits + h, h) / sc;
+      }
+    }
+  }
+  return ntf;
+}
+// procLegacyCSD / procCSD: X[k] *= exp(-j 2 pi shift k / 64), shift in samples
+__device__ __forceinline__ void tx_csd(int shift, int lane, const DevTables* __restrict__ T, double& xr, double& xi)
+{
+  if (!shift) return;
+  const int k = lane < 32 ? lane : lane - 64;
+  const int mm = (shift * k) & 63;                     // e^{-j 2 pi mm / 64} from the twiddle table
+  const double2 w = T->tw[mm & 31];
+  const double wr = mm < 32 ? w.x : -w.x, wi = mm < 32 ? w.y : -w.y;
+  const double ar = xr * wr - xi * wi, ai = xr * wi + xi * wr;
+  xr = ar; xi = ai;
+}
+
 __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans, const unsigned int* __restrict__ unit2pkt,
                                                 const uint8_t* __restrict__ coded, const uint8_t* __restrict__ sigbits,
-                                                const DevTables* __restrict__ T, cf* __restrict__ iq, unsigned int total_units)
+                                                const cf* __restrict__ bfq, const DevTables* __restrict__ T, cf* __restrict__ iq,
+                                                unsigned int total_units)
 {
   __shared__ double2 st[4][64];
   const unsigned int u = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -209,82 +320,37 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
   const int unit = (int)(u - P.unit_base) - ss * upp; // 80-sample unit inside the packet: 0,1 L-STF  2,3 L-LTF  4 L-SIG  5.. pre  then data
   const int nss = P.nss;
   int shift = 0;                                      // cyclic shift of this field on this chain, in samples (C_CYCLIC_SHIFT_L / _NL)
-  const int k = lane < 32 ? lane : lane - 64;         // subcarrier of this lane's bin
-  const int ak = k < 0 ? -k : k;
-  double xr = 0.0, xi = 0.0, ntf = 52.0;
   const uint8_t* sb = sigbits + (size_t)p * C8P_TX_SIGBITS;
-  const bool pilot_bin = ak == 7 || ak == 21;
-  const int pil_i = k == -21 ? 0 : k == -7 ? 1 : k == 7 ? 2 : 3;
-  const bool vht = P.format == C8P_F_VHT;
-  enum { F_STF, F_LLTF, F_NLLTF, F_SIG, F_SIGB, F_DATA } kind;
-  int sig_off = 0, sig_q = 0, dsym = 0, ltf_i = 0;
+  TxField f = {TXF_STF, 0, 0, 0, 0};
+  bool steered = false;                               // MU-MIMO: fields from the VHT-STF on go through the steering matrix
   const int shL = ss ? -4 : 0, shN = ss ? -8 : 0;     // -200 ns / -400 ns on the second chain
-  if (unit < 2) { kind = F_STF; shift = shL; }
-  else if (unit < 4) { kind = F_LLTF; shift = shL; }
-  else if (unit == 4) { kind = F_SIG; sig_off = 0; shift = shL; }
+  if (unit < 2) { f.kind = TXF_STF; shift = shL; }
+  else if (unit < 4) { f.kind = TXF_LLTF; shift = shL; }
+  else if (unit == 4) { f.kind = TXF_SIG; f.sig_off = 0; shift = shL; }
   else {
     const int q = unit - 5;                           // index among the pre symbols
     if (q < m.n_pre) {
-      if (q < 2) { kind = F_SIG; sig_off = 48 + 48 * q; sig_q = (P.format == C8P_F_HT || q == 1) ? 1 : 0; shift = shL; }   // HT-SIG: QBPSK x2, VHT-SIG-A: BPSK, QBPSK
-      else if (q == 2) { kind = F_STF; shift = shN; }
-      else if (q < 3 + nss) { kind = F_NLLTF; ltf_i = q - 3; shift = shN; }
-      else { kind = F_SIGB; shift = shN; }
-    } else { kind = F_DATA; dsym = q - m.n_pre; shift = P.format == C8P_F_L ? shL : shN; }
+      if (q < 2) { f.kind = TXF_SIG; f.sig_off = 48 + 48 * q; f.sig_q = (P.format == C8P_F_HT || q == 1) ? 1 : 0; shift = shL; }   // HT-SIG: QBPSK x2, VHT-SIG-A: BPSK, QBPSK
+      else if (q == 2) { f.kind = TXF_STF; shift = shN; steered = true; }
+      else if (q < 3 + nss) { f.kind = TXF_NLLTF; f.ltf_i = q - 3; shift = shN; steered = true; }
+      else { f.kind = TXF_SIGB; shift = shN; steered = true; }
+    } else { f.kind = TXF_DATA; f.dsym = q - m.n_pre; shift = P.format == C8P_F_L ? shL : shN; steered = true; }
   }
-  if (kind == F_STF) {                                // C_STF_L / C_STF_HT / C_STF_VHT: +-(1+j)/sqrt(2) on every 4th subcarrier
-    ntf = 12.0;
-    if (ak >= 4 && ak <= 24 && (ak & 3) == 0) {
-      const int mi = k < 0 ? (k + 24) / 4 : 6 + (k - 4) / 4;
-      const int sgn = (0xF25u >> mi) & 1u ? 1 : -1;   // {1,-1,1,-1,-1,1, -1,-1,1,1,1,1}
-      xr = xi = sgn * 0.70710678118654757;
-    }
-  } else if (kind == F_LLTF) { ntf = 52.0; xr = (double)T->ltfL[lane]; }
-  else if (kind == F_NLLTF) {                         // C_P_LTF_VHT_4 rows {1,-1},{1,1}; VHT pilots follow C_R_LTF_VHT_4 = {1,-1}
-    ntf = 56.0;
-    const double pm = (ss == 0 && ltf_i == 1) ? -1.0 : 1.0, rm = ltf_i == 1 ? -1.0 : 1.0;
-    xr = (double)T->ltfNL[lane] * ((vht && pilot_bin) ? rm : pm);
-  }
-  else if (kind == F_SIG) {
-    ntf = 52.0;
-    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
-    else if (ak >= 1 && ak <= 26) { const double v = sb[sig_off + qidx_l(lane)] ? 1.0 : -1.0; if (sig_q) xi = v; else xr = v; }
-  } else if (kind == F_SIGB) {
-    ntf = 56.0;
-    if (pilot_bin) xr = pil_i == 3 ? -1.0 : 1.0;
-    else if (ak >= 1 && ak <= 28) xr = sb[144 + qidx_nl(lane)] ? 1.0 : -1.0;
+  double xr, xi, ntf;
+  if (P.mu && steered) {
+    // chain ss = Q[ss][0] X_0 + Q[ss][1] X_1 per subcarrier (procSpatialMapping / procNss2SymBfQ); stream s carries user s,
+    // the second stream with the VHT cyclic shift
+    const TxPlan U1 = plans[p + 1];
+    double x0r, x0i, x1r, x1i;
+    ntf = tx_field_x(P, f, 0, 1, sb, 144, coded, T, lane, x0r, x0i);
+    tx_field_x(U1, f, 1, 1, sb, 196, coded, T, lane, x1r, x1i);
+    tx_csd(-8, lane, T, x1r, x1i);
+    const cf qa = bfq[P.q_off + 4u * (unsigned)lane + 2u * (unsigned)ss], qb = bfq[P.q_off + 4u * (unsigned)lane + 2u * (unsigned)ss + 1u];
+    xr = (double)qa.x * x0r - (double)qa.y * x0i + (double)qb.x * x1r - (double)qb.y * x1i;
+    xi = (double)qa.x * x0i + (double)qa.y * x0r + (double)qb.x * x1i + (double)qb.y * x1r;
   } else {
-    const bool leg = P.format == C8P_F_L;
-    ntf = leg ? 52.0 : 56.0;
-    const int lim = leg ? 26 : 28;
-    const int p0 = leg ? 1 : (vht ? 4 : 3);
-    const float pol = T->pilotP[(p0 + dsym) % 127];
-    if (pilot_bin) {                                  // base pattern rotated left by one per symbol for HT / VHT (:811-818)
-      const int idx = leg ? pil_i : ((pil_i + dsym) & 3);
-      float base = idx == 3 ? -1.0f : 1.0f;                                       // {1,1,1,-1}
-      if (P.format == C8P_F_HT && nss == 2) base = ss == 0 ? (idx >= 2 ? -1.0f : 1.0f)      // {1,1,-1,-1}
-                                                           : ((idx == 1 || idx == 2) ? -1.0f : 1.0f);   // {1,-1,-1,1}
-      xr = (double)(base * pol);
-    } else if (ak >= 1 && ak <= lim) {
-      const int j = leg ? qidx_l(lane) : qidx_nl(lane);
-      const int mi = nbpsc_index(m.nb);
-      const int16_t* map = leg ? T->deintL[mi] : (nss == 2 ? T->deint2ss[ss][mi] : T->deintNL[mi]);   // (2 chains: de-interleave fused with the stream parser)
-      const uint8_t* cb = coded + P.coded_off + (size_t)dsym * m.ncbps;
-      uint8_t bits[8];
-      for (int b = 0; b < m.nb; b++) bits[b] = cb[map[j * m.nb + b]];
-      if (m.nb == 1) xr = bits[0] ? 1.0 : -1.0;
-      else {
-        const int h = m.nb >> 1;
-        const double sc = m.nb == 2 ? 1.4142135623730951 : m.nb == 4 ? 3.1622776601683795 : m.nb == 6 ? 6.4807406984078604 : 13.038404810405298;
-        xr = tx_axis(bits, h) / sc; xi = tx_axis(bits + h, h) / sc;
-      }
-    }
-  }
-  if (shift) {                                        // procLegacyCSD / procCSD: X[k] *= exp(-j 2 pi shift k / 64)
-    const int mm = (shift * k) & 63;                   // e^{-j 2 pi mm / 64} from the twiddle table
-    const double2 w = T->tw[mm & 31];
-    const double wr = mm < 32 ? w.x : -w.x, wi = mm < 32 ? w.y : -w.y;
-    const double ar = xr * wr - xi * wi, ai = xr * wi + xi * wr;
-    xr = ar; xi = ai;
+    ntf = tx_field_x(P, f, ss, nss, sb, 144, coded, T, lane, xr, xi);
+    tx_csd(shift, lane, T, xr, xi);
   }
   const double2 t = wave_ifft64_d(xr, xi, T);
   const double sc = 1.0 / sqrt(ntf * (double)nss);
@@ -294,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
   const int n_samp = m.n_samp;
   for (int mm = lane; mm < 80; mm += 64) {
     int src;
-    if (unit < 4) { const int f = (unit & 1) * 80 + mm; src = f < 32 ? 32 + f : (f - 32) & 63; }   // t[32:] + t + t
+    if (unit < 4) { const int f2 = (unit & 1) * 80 + mm; src = f2 < 32 ? 32 + f2 : (f2 - 32) & 63; }   // t[32:] + t + t
     else src = mm < 16 ? 48 + mm : mm - 16;
     const int g = unit * 80 + mm;
     double2 v = st[wv][src];

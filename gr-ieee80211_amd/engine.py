@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 # every entry point include/c8p_rx.h declares
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
-           "c8p_detect", "c8p_tx", "c8p_tx_plan_of"]
+           "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu"]
 
 _LIB = None
 
@@ -45,6 +45,7 @@ def load_library():
     L.c8p_detect.argtypes = [C.c_void_p, C.POINTER(abi.DetectIn)]
     L.c8p_tx.argtypes = [C.c_void_p, C.POINTER(abi.TxIn)]
     L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
+    L.c8p_tx_plan_mu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_sync.argtypes = [C.c_void_p]
     L.c8p_buffer.restype = C.c_void_p
     L.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
@@ -53,12 +54,12 @@ def load_library():
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
-    sizes = np.zeros(16, np.int32)
-    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 16)
+    sizes = np.zeros(17, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 17)
     want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
             C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn),
             C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn), C.sizeof(abi.DetState), C.sizeof(abi.TxPkt), C.sizeof(abi.TxDesc),
-            C.sizeof(abi.TxIn), C.sizeof(abi.TxPlan)]
+            C.sizeof(abi.TxIn), C.sizeof(abi.TxPlan), C.sizeof(abi.TxMu)]
     if list(sizes) != want:
         raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
     _LIB = L
@@ -164,12 +165,21 @@ class Engine:
         ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
         return (ev, st_out, commit.value) if stream else ev
 
-    def tx(self, pkts, psdu, tail_gap=0):
-        """transmit chain (1 spatial stream): pkts = TX_PKT_DT records, psdu = byte arena (host array or DevArray)"""
+    def tx(self, pkts, psdu, tail_gap=0, mu=None, bfq=None):
+        """transmit chain: pkts = TX_PKT_DT records, psdu = byte arena (host array or DevArray); MU-MIMO packets
+        (format F_VHT_MU) take their second user from mu (TX_MU_DT records, in order) and their steering matrices from
+        bfq (complex64 arena of the same memory kind as psdu, 256 items per matrix)"""
         pkts = np.ascontiguousarray(pkts, abi.TX_PKT_DT)
         p_p, n_p, m, k1 = self._arena(psdu, np.uint8)
-        d = abi.TxIn(len(pkts), m, pkts.ctypes.data, p_p, n_p, int(tail_gap), 0)
-        self._keep = (pkts, k1, d)
+        mu_p, n_mu, q_p, n_q, k2 = None, 0, None, 0, None
+        if mu is not None and len(mu):
+            mu = np.ascontiguousarray(mu, abi.TX_MU_DT)
+            mu_p, n_mu = mu.ctypes.data, len(mu)
+            q_p, n_q, m2, k2 = self._arena(bfq, np.complex64)
+            if m2 != m:
+                raise ValueError("psdu and bfq must be of the same memory kind")
+        d = abi.TxIn(len(pkts), m, pkts.ctypes.data, p_p, n_p, int(tail_gap), n_mu, mu_p, q_p, n_q)
+        self._keep = (pkts, k1, d, mu, k2)
         self._chk(self.L.c8p_tx(self.ctx, C.byref(d)))
 
     def sync(self):

@@ -172,7 +172,8 @@ typedef struct c8p_tx_plan {
 typedef struct c8p_tx_pkt {
   uint64_t psdu_off;    /* byte offset of the PSDU inside the psdu arena: the MPDU (legacy, HT) or the A-MPDU (VHT)  */
   uint32_t len;         /* its length in bytes                                                                       */
-  uint8_t  format;      /* C8P_F_L / C8P_F_HT / C8P_F_VHT                                                            */
+  uint8_t  format;      /* C8P_F_L / C8P_F_HT / C8P_F_VHT, or C8P_F_VHT_MU: 2-user MU-MIMO — this struct describes user 0
+                           and the next unused entry of c8p_tx_in.mu describes user 1 and the steering matrix            */
   uint8_t  mcs;         /* legacy 0-7, HT 0-7, VHT 0-8                                                               */
   uint8_t  scr_seed;    /* initial scrambler state, 1..127 (the reference toolbox uses 93)                           */
   uint8_t  flags;       /* C8P_TX_NO_WINDOW: do not halve the two samples at every field junction (the toolbox's
@@ -185,12 +186,30 @@ typedef struct c8p_tx_pkt {
 } c8p_tx_pkt;
 
 #define C8P_TX_NO_WINDOW 1
+#define C8P_F_VHT_MU 3       /* c8p_tx only (C8P_F_VHT_MU of cloud80211phy.h:38): VHT MU-MIMO, 2 users x 1 stream, 2 chains */
+
+/* Second user and steering of a C8P_F_VHT_MU packet: what encode2 / modulation2 take from the "mcs1", "len1", "gid" tags
+ * and the C8P_F_VHT_BFQ message (lib/encode2_impl.cc:92-100, lib/modulation2_impl.cc:117-125), or genAmpduMu's
+ * ampdu1 / mod1 / groupId / bfQ arguments (tools/phy80211.py:180). */
+typedef struct c8p_tx_mu {
+  uint64_t psdu_off;    /* user 1's A-MPDU inside the psdu arena                                                     */
+  uint32_t len;         /* its length in bytes                                                                       */
+  uint8_t  mcs;         /* user 1's VHT MCS 0-8 (user 0's is c8p_tx_pkt.mcs)                                         */
+  uint8_t  group_id;    /* VHT-SIG-A group id, 1..62                                                                 */
+  uint8_t  rsv[2];
+  uint64_t q_off;       /* item offset of the packet's steering matrix inside c8p_tx_in.bfq: 256 complex64 =
+                           [64 FFT bins, bin 0 = DC][q00 q01 q10 q11]; chain c sends q_c0 * user 0 + q_c1 * user 1
+                           (the layout of d_vhtMuBfQ, cloud80211phy.cc:2932-2942)                                     */
+} c8p_tx_mu;
 
 typedef struct c8p_tx_desc {  /* per packet, in C8P_BUF_TX_DESC */
   uint64_t iq_off;      /* item offset of the packet's first sample inside C8P_BUF_TX_IQ (after its gap)             */
   uint64_t coded_off;   /* byte offset of its punctured coded bits (1 bit per byte) inside C8P_BUF_TX_CODED          */
   uint32_t n_samp;      /* samples                                                                                   */
   uint32_t n_coded;     /* coded bits = nsym * ncbps                                                                 */
+  uint64_t coded_off1;  /* C8P_F_VHT_MU: user 1's coded bits                                                         */
+  uint32_t n_coded1;
+  uint32_t rsv;
 } c8p_tx_desc;
 
 typedef struct c8p_tx_in {
@@ -200,7 +219,10 @@ typedef struct c8p_tx_in {
   const uint8_t* psdu;      /* PSDU byte arena                                                           */
   uint64_t n_psdu;
   uint32_t tail_gap;        /* zero items appended after the last packet                                 */
-  uint32_t rsv;
+  uint32_t n_mu;            /* entries of mu (= number of C8P_F_VHT_MU packets in pkts)                  */
+  const c8p_tx_mu* mu;      /* host memory; the j-th C8P_F_VHT_MU packet of pkts takes mu[j]             */
+  const c8p_c32* bfq;       /* steering matrices, same memory kind as psdu                               */
+  uint64_t n_bfq;           /* items                                                                     */
 } c8p_tx_in;
 
 typedef struct c8p_cfg {
@@ -318,6 +340,7 @@ int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ
 int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
 int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */
 int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
+int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2); /* C8P_F_VHT_MU: plan2[0], plan2[1] = the users */
 int c8p_sync  (c8p_ctx* ctx);
 
 /* Device pointer / size in bytes of a result arena of the last submit. */

@@ -345,3 +345,190 @@ int c8po_tx_packet(int format, int mcs, const uint8_t* psdu, int len, int scr_se
 {
   return len > 0 ? c8po_tx_packet2(format, mcs, 1, psdu, len, scr_seed, mult, out, NULL, cap, coded_out, n_coded) : -1;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * 2-user VHT MU-MIMO packet, one spatial stream per user, steering matrix Q per subcarrier:
+ * tools/phy80211.py genAmpduMu :180-221 (__genVhtSignalA MU branch :366-416, __genNonLegacyTraining :459-510 with
+ * procSpatialMapping, __genVhtSignalBMu :571-637, __genOfdmSignalMu :763-786; phy80211header.py procPktLenAggreMu
+ * :509-525, procSpatialMapping :1364-1378) = lib/encode2_impl.cc:129-215 + lib/modulation2_impl.cc:176-205,356-364
+ * (formatToModMu cloud80211phy.cc:2558, vhtSigB20BitsGenMU :3084, procNss2SymBfQ :2932).
+ * Pinned by tests/golden/packets_mu_tx.npz (the toolbox's own IQ on both chains and both users' coded bits). */
+int c8po_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* p0, c8p_tx_plan* p1)
+{
+  c8p_tx_plan* P[2] = {p0, p1};
+  const int mcs[2] = {mcs0, mcs1}, len[2] = {len0, len1};
+  int nsym = 0;
+  for (int u = 0; u < 2; u++) {
+    if (len[u] <= 0 || !c8po_tx_plan2(2, mcs[u], 1, len[u], P[u])) return 0;       /* procPktLenAggre per user */
+    if (P[u]->nsym > nsym) nsym = P[u]->nsym;
+  }
+  for (int u = 0; u < 2; u++) if (nsym * P[u]->ndbps > 32782) return 0;            /* decode_impl.cc:93 / encode2_impl.h:74 */
+  for (int u = 0; u < 2; u++) {                                                    /* procPktLenAggreMu */
+    c8p_tx_plan* p = P[u];
+    p->nsym = nsym;
+    p->psdu_len = (nsym * p->ndbps - 16 - 6) / 8;
+    p->npad_eof = (p->psdu_len - len[u]) / 4;
+    p->npad_octet = p->psdu_len - len[u] - 4 * p->npad_eof;
+    p->legacy_len = ((20 + 8 + 4 + 2 * 4 + 4 + nsym * 4 - 20) / 4) * 3 - 3;
+    p->n_pre = 2 + 1 + 2 + 1;
+    p->n_samp = 320 + 80 * (1 + p->n_pre + nsym);
+  }
+  return 1;
+}
+
+static void sig_symbol_bits(const uint8_t* b, int nbits, uint8_t* out)             /* rate 1/2 + procInterleaveSigL per 48 */
+{
+  uint8_t c[96];
+  bcc(b, nbits, c);
+  for (int h = 0; h < 2 * nbits / 48; h++) interleave_sig48(c + 48 * h, out + 48 * h);
+}
+
+int c8po_tx_packet_mu(int mcs0, const uint8_t* psdu0, int len0, int mcs1, const uint8_t* psdu1, int len1, int group_id,
+                      const c8p_c32* bfq, int scr_seed, float mult, c8p_c32* out0, c8p_c32* out1, int cap,
+                      uint8_t* coded0, uint8_t* coded1, int* n_coded /* [2] */)
+{
+  c8p_tx_plan P[2];
+  c8po_init();
+  init_ps();
+  if (!c8po_tx_plan_mu(mcs0, len0, mcs1, len1, &P[0], &P[1]) || P[0].n_samp > cap) return -1;
+  const int mcs[2] = {mcs0, mcs1}, len[2] = {len0, len1};
+  const uint8_t* psdu[2] = {psdu0, psdu1};
+  uint8_t* coded_out[2] = {coded0, coded1};
+  const int nsym = P[0].nsym, n_samp = P[0].n_samp;
+  const double pil0[4] = {1, 1, 1, -1};
+  uint8_t lsig[48], siga[96], sigb[2][52], sigb_crc[2][8];
+  {
+    uint8_t b[48];
+    memset(b, 0, sizeof(b));                            /* L-SIG, rate 6 Mb/s */
+    b[0] = 1; b[1] = 1; b[3] = 1;
+    for (int i = 0; i < 12; i++) b[5 + i] = (uint8_t)((P[0].legacy_len >> i) & 1);
+    int par = 0; for (int i = 0; i < 17; i++) par += b[i];
+    b[17] = (uint8_t)(par & 1);
+    sig_symbol_bits(b, 24, lsig);
+    memset(b, 0, sizeof(b));                            /* VHT-SIG-A, MU */
+    b[2] = 1;
+    for (int i = 0; i < 6; i++) b[4 + i] = (uint8_t)((group_id >> i) & 1);
+    b[10] = 1; b[13] = 1;                               /* nSTS of user 0 / 1 = 1, users 2, 3 absent */
+    b[23] = 1;
+    b[29] = b[30] = b[31] = b[32] = b[33] = 1;          /* b28 = user-1 BCC; reserved ones */
+    crc8_bits(b, 34, b + 34);
+    sig_symbol_bits(b, 48, siga);
+    int32_t map[64];
+    c8po_table(4 /* C8P_TAB_DEINT_SIGB */, 0, map, 64);
+    for (int u = 0; u < 2; u++) {                       /* VHT-SIG-B per user: len/4 (16 bits), mcs (4), tail */
+      uint8_t c[52];
+      memset(b, 0, sizeof(b));
+      for (int i = 0; i < 16; i++) b[i] = (uint8_t)(((len[u] / 4) >> i) & 1);
+      for (int i = 0; i < 4; i++) b[16 + i] = (uint8_t)((mcs[u] >> i) & 1);
+      crc8_bits(b, 20, sigb_crc[u]);
+      bcc(b, 26, c);
+      for (int r = 0; r < 52; r++) sigb[u][r] = c[map[r]];
+    }
+  }
+  /* per-user data field: service (SIG-B CRC) + A-MPDU + EOF delimiters + zero octets + pad, scramble, tail, BCC, puncture */
+  uint8_t* cp[2];
+  for (int u = 0; u < 2; u++) {
+    const int nbits = nsym * P[u].ndbps;
+    uint8_t* d = (uint8_t*)calloc((size_t)nbits + 8, 1);
+    uint8_t* c2 = (uint8_t*)calloc((size_t)nbits * 2 + 16, 1);
+    cp[u] = (uint8_t*)calloc((size_t)nsym * P[u].ncbps + 16, 1);
+    static const uint8_t EOF32[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1, 0};
+    int w = 16;
+    memcpy(d + 8, sigb_crc[u], 8);
+    for (int i = 0; i < len[u]; i++) for (int k = 0; k < 8; k++) d[w++] = (uint8_t)((psdu[u][i] >> k) & 1);
+    for (int e = 0; e < P[u].npad_eof; e++) { memcpy(d + w, EOF32, 32); w += 32; }
+    unsigned st = (unsigned)scr_seed;
+    for (int i = 0; i < nbits; i++) { const unsigned fb = ((st >> 6) & 1u) ^ ((st >> 3) & 1u); d[i] ^= (uint8_t)fb; st = ((st << 1) & 0x7e) | fb; }
+    for (int i = nbits - 6; i < nbits; i++) d[i] = 0;
+    bcc(d, nbits, c2);
+    const int nc = puncture(c2, 2 * nbits, P[u].cr, cp[u]);
+    if (n_coded) n_coded[u] = nc;
+    if (coded_out[u]) memcpy(coded_out[u], cp[u], (size_t)nc);
+    free(d); free(c2);
+  }
+  /* ---- frequency-domain fields per stream, spatial mapping, OFDM per chain */
+  cd* sig[2];
+  for (int c = 0; c < 2; c++) sig[c] = (cd*)calloc((size_t)n_samp, sizeof(cd));
+  const double csdL[2] = {0.0, -4.0}, csdN[2] = {0.0, -8.0};
+  cd X[64], Z[64];
+  memset(Z, 0, sizeof(Z));
+  /* legacy part and SIG-A: the same symbol on both chains, legacy cyclic shift on the second (no Q) */
+  for (int c = 0; c < 2; c++) {
+    memset(X, 0, sizeof(X));
+    for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+    { cd t[80]; c8po_ofdm_csd(X, 24.0, 0, csdL[c], t); for (int n = 0; n < 32; n++) sig[c][n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[c][32 + 64 * r + n] = t[n]; }
+    memset(X, 0, sizeof(X));
+    for (int k = -26; k <= 26; k++) X[k + 32].re = LTF_L53[k + 26];
+    { cd t[80]; c8po_ofdm_csd(X, 104.0, 0, csdL[c], t); for (int n = 0; n < 32; n++) sig[c][160 + n] = t[32 + n]; for (int r = 0; r < 2; r++) for (int n = 0; n < 64; n++) sig[c][192 + 64 * r + n] = t[n]; }
+    cd q[48];
+    for (int i = 0; i < 48; i++) { q[i].re = lsig[i] ? 1.0 : -1.0; q[i].im = 0; }
+    place(q, 48, pil0, X); c8po_ofdm_csd(X, 104.0, 16, csdL[c], sig[c] + 320);
+    for (int s2 = 0; s2 < 2; s2++) {
+      for (int i = 0; i < 48; i++) { const double v = siga[48 * s2 + i] ? 1.0 : -1.0; q[i].re = s2 ? 0 : v; q[i].im = s2 ? v : 0; }
+      place(q, 48, pil0, X); c8po_ofdm_csd(X, 104.0, 16, csdL[c], sig[c] + 400 + 80 * s2);
+    }
+  }
+  /* steered fields: per stream X_s (with the VHT cyclic shift applied in the frequency domain), chain c = sum_s Q[c][s] X_s */
+  const int n_steer = 1 + 2 + 1 + nsym;                 /* VHT-STF, 2 LTFs, SIG-B, data */
+  double pil[4] = {1, 1, 1, -1};
+  int pidx = 4;
+  int32_t map1[512];
+  for (int f = 0; f < n_steer; f++) {
+    cd Xs[2][64];
+    double ntf = 56.0;
+    for (int s = 0; s < 2; s++) {
+      memset(X, 0, sizeof(X));
+      if (f == 0) {
+        ntf = 12.0;
+        for (int m = 0; m < 12; m++) { const int k = (m < 6 ? -24 + 4 * m : 4 + 4 * (m - 6)); const double v = STF_SIGN[m] * sqrt(0.5); X[k + 32].re = v; X[k + 32].im = v; }
+      } else if (f <= 2) {
+        static const int PM[2][2] = {{1, -1}, {1, 1}}, RM[2] = {1, -1};
+        const int l = f - 1;
+        for (int k = -28; k <= 28; k++) {
+          if (k == 0) continue;
+          double v = (k >= -26 && k <= 26) ? (double)LTF_L53[k + 26] : (k < 0 ? 1.0 : -1.0);
+          const int pilot = k == -21 || k == -7 || k == 7 || k == 21;
+          X[k + 32].re = v * (pilot ? RM[l] : PM[s][l]);
+        }
+      } else if (f == 3) {
+        cd q[52]; for (int i = 0; i < 52; i++) { q[i].re = sigb[s][i] ? 1.0 : -1.0; q[i].im = 0; }
+        place(q, 52, pil0, X);
+      } else {
+        const int s3 = f - 4;
+        const int mi = P[s].nb == 1 ? 0 : P[s].nb == 2 ? 1 : P[s].nb == 4 ? 2 : P[s].nb == 6 ? 3 : 4;
+        c8po_table(1 /* C8P_TAB_DEINT_NL */, mi, map1, 512);                      /* both users: the first stream's interleaver */
+        cd q[52];
+        uint8_t bits[8];
+        for (int j = 0; j < 52; j++) {
+          for (int k = 0; k < P[s].nb; k++) bits[k] = cp[s][s3 * P[s].ncbps + map1[j * P[s].nb + k]];
+          q[j] = qam_point(bits, P[s].nb);
+        }
+        double pp[4]; for (int k = 0; k < 4; k++) pp[k] = pil[k] * PS127[pidx];
+        place(q, 52, pp, X);
+      }
+      for (int i = 0; i < 64; i++) {                    /* procCSD in the frequency domain */
+        const double ph = -2.0 * M_PI * csdN[s] * (double)(i - 32) / 64.0;
+        Xs[s][i].re = X[i].re * cos(ph) - X[i].im * sin(ph);
+        Xs[s][i].im = X[i].re * sin(ph) + X[i].im * cos(ph);
+      }
+    }
+    if (f >= 4) { pidx = (pidx + 1) % 127; const double t = pil[0]; pil[0] = pil[1]; pil[1] = pil[2]; pil[2] = pil[3]; pil[3] = t; }
+    for (int c = 0; c < 2; c++) {
+      for (int i = 0; i < 64; i++) {
+        const int bin = (i - 32) & 63;                  /* bfq is in FFT order */
+        const c8p_c32 qa = bfq[4 * bin + 2 * c], qb = bfq[4 * bin + 2 * c + 1];
+        X[i].re = (double)qa.re * Xs[0][i].re - (double)qa.im * Xs[0][i].im + (double)qb.re * Xs[1][i].re - (double)qb.im * Xs[1][i].im;
+        X[i].im = (double)qa.re * Xs[0][i].im + (double)qa.im * Xs[0][i].re + (double)qb.re * Xs[1][i].im + (double)qb.im * Xs[1][i].re;
+      }
+      c8po_ofdm_csd(X, ntf * 2.0, 16, 0.0, sig[c] + 560 + 80 * f);
+    }
+  }
+  for (int c = 0; c < 2; c++) {
+    for (int b = 160; b < n_samp; b += (b < 320 ? 160 : 80)) { sig[c][b - 1].re *= 0.5; sig[c][b - 1].im *= 0.5; sig[c][b].re *= 0.5; sig[c][b].im *= 0.5; }
+    c8p_c32* out = c == 0 ? out0 : out1;
+    for (int n = 0; n < n_samp; n++) { out[n].re = (float)(sig[c][n].re * (double)mult); out[n].im = (float)(sig[c][n].im * (double)mult); }
+    free(sig[c]);
+  }
+  free(cp[0]); free(cp[1]);
+  return n_samp;
+}

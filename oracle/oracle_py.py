@@ -222,3 +222,19 @@ def tx_packet2(fmt, mcs, nss, psdu, scr_seed=93, mult=12.0):
     if n < 0:
         raise ValueError("c8po_tx_packet2 rejected (fmt %d mcs %d nss %d len %d)" % (fmt, mcs, nss, n_in))
     return out[:nss, :n].copy(), coded[:nc.value].copy()
+
+
+def tx_packet_mu(mcs, ampdus, gid, bfq, scr_seed=93, mult=12.0 * np.sqrt(2.0)):
+    """2-user MU-MIMO: mcs = (mcs0, mcs1), ampdus = (bytes, bytes), bfq complex64 [64][4] in FFT order.
+    Returns (iq [2][n], coded0, coded1)."""
+    a = [np.frombuffer(bytes(x), np.uint8).copy() for x in ampdus]
+    q = np.ascontiguousarray(bfq, np.complex64).reshape(64, 4)
+    cap = 400 + 80 * (12 + max((8 * len(x) + 22) // 26 for x in a) + 2)
+    out = np.zeros((2, cap), np.complex64)
+    coded = [np.zeros(cap * 8, np.uint8) for _ in range(2)]
+    nc = (C.c_int * 2)()
+    n = lib().c8po_tx_packet_mu(int(mcs[0]), _p(a[0]), len(a[0]), int(mcs[1]), _p(a[1]), len(a[1]), int(gid), _p(q), int(scr_seed),
+                                C.c_float(mult), _p(out[0]), _p(out[1]), cap, _p(coded[0]), _p(coded[1]), nc)
+    if n < 0:
+        raise ValueError("c8po_tx_packet_mu rejected")
+    return out[:, :n].copy(), coded[0][:nc[0]].copy(), coded[1][:nc[1]].copy()

@@ -196,11 +196,51 @@ def gen_mu(rng):
             "lsig_len": np.int32(ins.m.legacyLen)}
 
 
+
+def gen_mu_tx():
+    """2-user MU-MIMO transmit vectors (genAmpduMu) with a full-rank random steering matrix per subcarrier, so that
+    every term of the spatial mapping is pinned: both chains' IQ, both users' punctured coded bits, the Q matrices in
+    FFT order (bin 0 = DC, as lib/modulation2_impl.cc:120 stores d_vhtMuBfQ), A-MPDUs, geometry."""
+    out = {}
+    cases = [(3, 3, 100, 60, 2), (0, 7, 40, 300, 5), (8, 1, 500, 32, 62), (5, 4, 64, 64, 1)]
+    for ci, (mcs0, mcs1, n0, n1, gid) in enumerate(cases):
+        rng = np.random.default_rng(8021500 + ci)
+        q = (rng.normal(size=(56, 2, 2)) + 1j * rng.normal(size=(56, 2, 2))) / 2.0
+        one = np.ones((2, 2), np.complex128)
+        bfq = [one] * 4 + [q[i] for i in range(28)] + [one] + [q[28 + i] for i in range(28)] + [one] * 3   # -32 .. 31
+        m0, m1 = mpdu_bytes(rng, n0), mpdu_bytes(rng, n1)
+        a0, a1 = mac80211.genAmpduVHT([m0]), mac80211.genAmpduVHT([m1])
+        ins = phy80211.phy80211(ifDebug=False)
+        coded = []
+        orig = ins._phy80211__genCodedBits
+
+        def spy():
+            orig()
+            coded.append(np.array(ins.esCodedBits[0], np.uint8))
+        ins._phy80211__genCodedBits = spy
+        ins.genAmpduMu(nUser=2, bfQ=bfq, groupId=gid,
+                       ampdu0=a0, mod0=p8h.modulation(p8h.F.VHT, mcs0, p8h.BW.BW20, 1, False),
+                       ampdu1=a1, mod1=p8h.modulation(p8h.F.VHT, mcs1, p8h.BW.BW20, 1, False))
+        sig = ins.genFinalSig(multiplier=MULT * np.sqrt(2), cfoHz=0.0, num=1, gap=False, gapLen=0)
+        assert len(coded) == 2
+        fftq = np.array([bfq[(b + 32) % 64] for b in range(64)], np.complex64).reshape(64, 4)     # bin b <- subcarrier b (b<32) / b-64
+        out.update(flat("mu%d" % ci, {
+            "tx": np.array(sig, np.complex64), "bfq": fftq, "ampdu0": np.frombuffer(a0, np.uint8),
+            "ampdu1": np.frombuffer(a1, np.uint8), "mpdu0": np.frombuffer(m0, np.uint8), "mpdu1": np.frombuffer(m1, np.uint8),
+            "coded0": coded[0], "coded1": coded[1], "mcs": np.array([mcs0, mcs1], np.int32), "gid": np.int32(gid),
+            "nsym": np.int32(ins.m.nSym), "lsig_len": np.int32(ins.m.legacyLen)}))
+    return out
+
+
 def flat(prefix, d):
     return {prefix + "/" + k: v for k, v in d.items()}
 
 
 def main():
+    if "--mu-tx" in sys.argv:       # added later than the other files; own seeds, leaves them untouched
+        np.savez_compressed(os.path.join(OUT, "packets_mu_tx.npz"), **gen_mu_tx())
+        print("packets_mu_tx.npz written")
+        return
     rng = np.random.default_rng(80211)
     json.dump(table_digests(), open(os.path.join(OUT, "table_digests.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **small_vectors(rng))
