@@ -260,12 +260,31 @@ def cpu_baseline(pk, iq, chan, budget_s=12.0):
             "sample": "first %d packets of the same batch, oracle demod+decode, 1 thread, %.1f s, %d PDUs" % (n, dt, npdu)}
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max /
+    v1 cfs quota) — the GPU box shows 256 logical CPUs but grants a 16-CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline_all_cores(pk, iq, chan, per_core_rate, budget_s=6.0):
     """one independent packet stream per host core (the oracle is re-entrant C, ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from c8p_testlib import oracle
     o = oracle()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     per = int(max(4, min(len(pk) // cores, 16)))                 # packets per pass and thread: short passes, checked against a deadline
     slices = [pk[i * per:(i + 1) * per] for i in range(cores) if len(pk[i * per:(i + 1) * per])]
     t = time.perf_counter()
