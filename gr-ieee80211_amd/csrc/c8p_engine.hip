@@ -179,8 +179,6 @@ struct Buf {
 // decoder of batch i on the same GPU.
 struct Slot {
   hipStream_t stream = nullptr;
-  hipStream_t fin_stream = nullptr;                  // split mode: k_finish of this slot
-  hipEvent_t ev_pre = nullptr, ev_dec = nullptr, ev_fin = nullptr;
   void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
@@ -199,15 +197,6 @@ struct c8p_ctx {
   bool own_stream = false;
   int profile = 0, keep_bits = 0;
   int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
-  unsigned lean_lds = 0;                             // dynamic LDS bytes requested by the lean kernel (occupancy shaping)
-  // split mode (C8P_SPLIT=1, experiment): every slot's forward Viterbi pass goes to ONE shared in-order stream, so
-  // that the VALU-bound decoders of consecutive batches run back to back instead of two of them sharing the SIMDs,
-  // while the latency-bound kernels of the other batches (classify / symbol demod on the slot streams, k_finish on
-  // the slots' finish streams) fill the issue slots a single decoder leaves idle.  Measured on MI355X: 2.8-3.5 M
-  // packets/s against 4.4 M with plain per-slot streams — the three cross-stream event hops per batch cost more
-  // than the better co-scheduling gains — so it is off by default.
-  int split = 0;
-  hipStream_t dec_stream = nullptr;
   std::string err;
   DevTables* d_tab = nullptr;
   std::vector<Slot> slots;
@@ -277,7 +266,6 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile; c->keep_bits = cfg->keep_bits;
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
-  { const char* e = getenv("C8P_LEAN_LDS"); if (e && atoi(e) >= 0 && atoi(e) <= 140000) c->lean_lds = (unsigned)atoi(e); }
   {
     // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 3) engine-owned streams.
     int nslot = 3;
@@ -292,20 +280,6 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
     }
     c->s = &c->slots[0];
     c->cur = 0;
-    const char* sp = getenv("C8P_SPLIT");
-    c->split = (c->own_stream && nslot > 1 && sp && sp[0] == '1') ? 1 : 0;     // opt-in: measured slower (see below)
-    if (c->split) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&c->dec_stream, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return nullptr; }
-      for (int i = 0; i < nslot; i++) {
-        Slot& sl = c->slots[i];
-        if (hipStreamCreateWithFlags(&sl.fin_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-        if (hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.ev_dec, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.ev_fin, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
-      }
-    }
   }
   if (hipMalloc((void**)&c->d_tab, sizeof(DevTables)) != hipSuccess) { delete c; return nullptr; }
   const DevTables& T = host_tables();
@@ -330,12 +304,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
-    if (sl.fin_stream) (void)hipStreamDestroy(sl.fin_stream);
-    if (sl.ev_pre) (void)hipEventDestroy(sl.ev_pre);
-    if (sl.ev_dec) (void)hipEventDestroy(sl.ev_dec);
-    if (sl.ev_fin) (void)hipEventDestroy(sl.ev_fin);
   }
-  if (c->dec_stream) (void)hipStreamDestroy(c->dec_stream);
   if (c->d_tab) (void)hipFree(c->d_tab);
   delete c;
 }
@@ -419,35 +388,22 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
   const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->s->d_flags.p;
   hipStream_t dst = c->s->stream, fst = c->s->stream;
-  if (c->split) {
-    dst = c->dec_stream; fst = c->s->fin_stream;
-    HIPCHK(c, hipEventRecord(c->s->ev_pre, c->s->stream));      // everything the decoder reads has been enqueued
-    HIPCHK(c, hipStreamWaitEvent(dst, c->s->ev_pre, 0));
-  }
   {
     // forward pass: lean kernel for every packet whose LLRs passed the range check, clamp-exact kernel for the rest
     KTimer kt(c, C8P_K_VITERBI, dst);
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
-      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), c->lean_lds, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                          d_flags, n);
     }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
-  }
-  if (c->split) {
-    HIPCHK(c, hipEventRecord(c->s->ev_dec, dst));
-    HIPCHK(c, hipStreamWaitEvent(fst, c->s->ev_dec, 0));
   }
   {
     KTimer kt(c, C8P_K_FINISH, fst);
     hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, fst, d_tags, d_lay, (const ulonglong2*)c->s->d_surv.p, d_mu,
                        (const DevTables*)c->d_tab, (c8p_pkt_out*)c->s->d_outs.p, (uint8_t*)c->s->d_pdu.p, (uint8_t*)c->s->d_bits.p,
                        (uint8_t*)c->s->d_sbits.p, d_flags, c->keep_bits, n);
-  }
-  if (c->split) {                                               // the slot stream is "done" only when its k_finish is
-    HIPCHK(c, hipEventRecord(c->s->ev_fin, fst));
-    HIPCHK(c, hipStreamWaitEvent(c->s->stream, c->s->ev_fin, 0));
   }
   HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->s->ptr[C8P_BUF_OUT] = c->s->d_outs.p;
@@ -699,8 +655,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   {
     KTimer kt(c, C8P_K_PRESISO);
     const uint64_t nblk = (n + 7) / 8;
-    static const unsigned pre_lds = getenv("C8P_PRE_LDS") ? (unsigned)atoi(getenv("C8P_PRE_LDS")) : 0u;   // occupancy experiment
-    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), pre_lds, S.stream,
+    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
                        d_raw, hist, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p,
                        (int)(((uintptr_t)d_raw & 15u) == 0));
   }

@@ -901,32 +901,16 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         bool act = redo;
         unsigned long long am = __ballot(act && 0 < nblk);
         C8P_PREFETCH(0, am);                              // idle rows re-read block 0
-#ifdef C8P_EXP_FIXED
-        if (it >= 2) break;
-        act = have; am = __ballot(act);
-        for (int i = 0; i < (it == 0 ? ntile : 3); i++) {
-#else
         for (int i = 0; i < ntile && am; i++) {
-#endif
           __syncthreads();
           C8P_ROWS16(C8P_STAGE)
           __syncthreads();
-#ifndef C8P_EXP_NOLOAD
           C8P_PREFETCH(i + 1, __ballot(act && i + 1 < nblk));   // in flight during the walk below
-#endif
-#ifdef C8P_EXP_NOWALK
-          if (false) {
-#else
           if (act && i < nblk) {
-#endif
             const int blk = btop - i, b0 = blk * C8P_SV_BLK;
             const int hi = min(tend, b0 + C8P_SV_BLK) - 1 - b0, lo = max(tbeg, b0) - b0;   // active steps k in [lo, hi]
             const int gtop = blk * 5 + hi / 6;                                             // group of the first step walked
-#ifdef C8P_EXP_FIXED
-            if (false) {
-#else
             if (it > 0 && snaps[gtop] == (uint8_t)D) {
-#endif
               act = false;                                 // met the previous path
               D = Dbeg;
             } else {
@@ -937,7 +921,6 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                 if (A & (63u << (6 * g))) snaps[blk * 5 + g] = (uint8_t)D;
 #pragma unroll
                 for (int q = 5; q >= 0; q--) {
-                  constexpr int dummy = 0; (void)dummy;
                   const int k = 6 * g + q;                 // step b0 + k moves lane bit q  ((b0 + k) % 6 == q)
                   const uint32_t w = row[D];
                   const uint32_t sel = ((A >> k) & 1u) << q;             // 0 for steps outside [lo, hi]
@@ -948,9 +931,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
               }
             }
           }
-#ifndef C8P_EXP_FIXED
           am = __ballot(act && i + 1 < nblk);
-#endif
         }
         if (redo) Dbeg = D;
         int nd = __shfl_down(Dbeg, 1, 64);
@@ -959,10 +940,6 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         Dend = nd;
         if (!__any(redo)) break;
       }
-#if defined(C8P_EXP_FIN_STOP) && C8P_EXP_FIN_STOP == 1
-      if (lane == 0) outs[p].n_pdu = Dbeg;
-      return;
-#endif
       // ---- decoded bits: word c = times 64c .. 64c+63, gathered from the 6-bit group snapshots
       __syncthreads();
       const int ngrp = (Tn + 5) / 6;                       // (the tile is dead from here on: its memory becomes bw[])
@@ -1031,10 +1008,6 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       uint8_t* uo = bits_o + Lp.bits_off;
       for (int i = lane; i < Tn; i += 64) uo[i] = (uint8_t)((bw[i >> 6] >> (i & 63)) & 1ull);
     }
-#if defined(C8P_EXP_FIN_STOP) && C8P_EXP_FIN_STOP == 2
-    if (lane == 0) outs[p].n_pdu = (int)bw[1];
-    return;
-#endif
     // ---- packetAssemble (decode_impl.cc:325-520)
     if (t.format == C8P_F_VHT) {
       int procd = 16;
