@@ -110,21 +110,33 @@ __device__ __forceinline__ double shfl_d(double v, int src)
   lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double neg_if(double v, bool c)      // sign-bit flip: exact, one 32-bit op
+{
+  return __hiloint2double(__double2hiint(v) ^ (c ? (int)0x80000000 : 0), __double2loint(v));
+}
+// Decimation in frequency, lane = point, branch-free: the upper lane of a pair negates its own value before the exchange
+// (p - x = p + (-x)), so both lanes do ONE add, and the lower lane's twiddle is 1.  The last two stages only see the
+// twiddles 1 and -j (a swap), so they have no multiplication at all; the others use 2 mul + 2 fma.  (fp64 runs at half
+// the fp32 rate on gfx950 and this kernel competes with the decoder for VALU issue: 28 fp64 ops per transform
+// instead of 60.)
 __device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T)
 {
   const int lane = lane_id();
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const int half = 32 >> s;
-    const double pr = shfl_xor_d(xr, half), pi = shfl_xor_d(xi, half);
     const bool up = (lane & half) != 0;
-    if (!up) {
-      xr = xr + pr; xi = xi + pi;
+    const double pr = shfl_xor_d(xr, half), pi = shfl_xor_d(xi, half);
+    const double yr = pr + neg_if(xr, up), yi = pi + neg_if(xi, up);
+    if (s == 5) { xr = yr; xi = yi; }
+    else if (s == 4) {                                  // twiddle index (lane & 1) << 4: 1 or -j;  (a + jb)(-j) = b - ja
+      const bool rot = up && (lane & 1);
+      xr = rot ? yi : yr;
+      xi = rot ? -yr : yi;
     } else {
-      const double dr = pr - xr, di = pi - xi;
-      const double2 w = T->tw[(lane & (half - 1)) << s];
-      xr = dr * w.x - di * w.y;
-      xi = dr * w.y + di * w.x;
+      const double2 w = T->tw[up ? ((lane & (half - 1)) << s) : 0];
+      xr = __builtin_fma(yr, w.x, -(yi * w.y));
+      xi = __builtin_fma(yr, w.y, yi * w.x);
     }
   }
   const int src = T->bitrev6[lane];

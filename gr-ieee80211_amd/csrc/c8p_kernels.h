@@ -304,7 +304,7 @@ __device__ __forceinline__ void zf_2x2(cf y1, cf y2, const cf H[4], const cf INV
   s2 = cadd(cmul(t1, INV[1]), cmul(t2, INV[3]));
 }
 
-__global__ __launch_bounds__(64) void k_classify(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_classify(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                  const cf* __restrict__ chan, const PktLayout* __restrict__ lay,
                                                  const DevTables* __restrict__ T, c8p_pkt_tags* __restrict__ tags,
                                                  cf* __restrict__ Hout, Mimo* __restrict__ mimo, cf* __restrict__ muchan,
@@ -545,7 +545,7 @@ __device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_
   }
 }
 
-__global__ __launch_bounds__(256) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                    const cf* __restrict__ chan, const uint32_t* __restrict__ sym2pkt,
                                                    const PktLayout* __restrict__ lay, const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
                                                    const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
