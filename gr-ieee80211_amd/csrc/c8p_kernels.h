@@ -1032,6 +1032,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
             const uint32_t before = used;
             emit_pdu(area, Lp.pdu_cap, used, bw, bp, tmpLen, t.format, t.mcs);
             if (used != before) n_pdu++;
+            tmpLen += 4;       // decode_impl.cc:414 reuses the variable for the PDU length; the next delimiter is OR-ed into it (:346-351)
           }
           bp += padded;
           if (eof) break;

@@ -1025,7 +1025,8 @@ int c8po_decode(const c8p_pkt_tags* tg, const float* llr, const cf* mu2x1chan,
           if (c8po_crc32(pkt + 3, tmpLen) != 558161692u) out->n_crc_fail++;
           else {
             pkt[tmpLen + 3] = (uint8_t)tg->mcs;
-            if (pdu_put(pdu, pdu_cap, &used, pkt, tmpLen + 4)) out->n_pdu++;
+            tmpLen += 4;                                 /* :414 — and the next delimiter's length is OR-ed into THIS value (:346-351) */
+            if (pdu_put(pdu, pdu_cap, &used, pkt, tmpLen)) out->n_pdu++;
           }
           if (eof) break;
         }

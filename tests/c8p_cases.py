@@ -76,6 +76,22 @@ def replicated_batch(frame, n, n_ant, snr_db=30.0, seed=0, H=None, mupos=0):
     return b
 
 
+def ampdu_vht_multi(mpdus):
+    """mac80211.genAmpduVHT(list) for any number of subframes: EOF is set only when there is a single one (:339-341)"""
+    out = b""
+    for mpdu in mpdus:
+        n = len(mpdu)
+        lb = [(n >> i) & 1 for i in range(14)]
+        bits = [1 if len(mpdus) == 1 else 0, 0] + lb[12:14] + lb[0:12]
+        c = [1] * 8
+        for b in bits:
+            c = [b ^ c[7], b ^ c[7] ^ c[0], b ^ c[7] ^ c[1]] + c[2:7]
+        bits = bits + [1 - b for b in c[::-1]] + [(0x4E >> i) & 1 for i in range(8)]
+        pkt = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(4)) + bytes(mpdu)
+        out += pkt + b"\x00" * ((-len(pkt)) % 4)
+    return out
+
+
 def ampdu_vht(mpdu):
     """mac80211.genAmpduVHT([mpdu]) (tools/mac80211.py:333-360): delimiter {EOF, reserved, len[12:14], len[0:12], CRC-8,
     signature 0x4e} + MPDU, padded to a multiple of 4 bytes"""
