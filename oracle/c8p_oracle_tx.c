@@ -176,6 +176,12 @@ static void init_ps(void)
   done = 1;
 }
 
+/* Test hook: bits XOR-ed into HT-SIG / VHT-SIG-A bits 0..33 before their CRC-8 is computed, so that tests can transmit
+ * packets whose (valid, CRC-correct) signal field announces things the transmitter does not do — short GI, aggregation,
+ * LDPC, STBC, 40 MHz, other stream counts, MU group ids — and compare how receivers take them. */
+static unsigned long long g_sig_xor = 0;
+void c8po_tx_test_sig_xor(unsigned long long mask) { g_sig_xor = mask & 0x3ffffffffull; }
+
 /* one packet on nss transmit chains (no spatial mapping matrix: stream i = chain i, as genFromMpdu / genFromAmpdu).
  * out0 / out1: cap samples each (out1 may be NULL when nss == 1).  HT: mcs = 0..7 is the per-stream rate, the HT-SIG MCS
  * field carries mcs + 8 (nss - 1).  VHT with len == 0: NDP.  Returns the samples per chain, or -1. */
@@ -205,6 +211,7 @@ int c8po_tx_packet2(int format, int mcs, int nss, const uint8_t* psdu, int len, 
       for (int i = 0; i < 7; i++) b[i] = (uint8_t)((m >> i) & 1);
       for (int i = 0; i < 16; i++) b[8 + i] = (uint8_t)((P.psdu_len >> i) & 1);
       b[24] = 1; b[25] = 1; b[26] = 1;
+      for (int i = 0; i < 34; i++) b[i] ^= (uint8_t)((g_sig_xor >> i) & 1);
       crc8_bits(b, 34, b + 34);
       bcc(b, 48, c); interleave_sig48(c, sig12); interleave_sig48(c + 48, sig12 + 48);
     } else if (format == 2) {                          /* VHT-SIG-A :352-455, SU, group id 0, partial AID 0 */
@@ -214,6 +221,7 @@ int c8po_tx_packet2(int format, int mcs, int nss, const uint8_t* psdu, int len, 
       b[23] = 1;
       for (int i = 0; i < 4; i++) b[28 + i] = (uint8_t)((mcs >> i) & 1);
       b[33] = 1;
+      for (int i = 0; i < 34; i++) b[i] ^= (uint8_t)((g_sig_xor >> i) & 1);
       crc8_bits(b, 34, b + 34);
       bcc(b, 48, c); interleave_sig48(c, sig12); interleave_sig48(c + 48, sig12 + 48);
       memset(b, 0, sizeof(b));                         /* VHT-SIG-B :512-569 */

@@ -238,3 +238,8 @@ def tx_packet_mu(mcs, ampdus, gid, bfq, scr_seed=93, mult=12.0 * np.sqrt(2.0)):
     if n < 0:
         raise ValueError("c8po_tx_packet_mu rejected")
     return out[:, :n].copy(), coded[0][:nc[0]].copy(), coded[1][:nc[1]].copy()
+
+
+def tx_sig_xor(mask):
+    """test hook: bits flipped in HT-SIG / VHT-SIG-A (bits 0..33, CRC recomputed) by the following tx_packet* calls; 0 = off"""
+    lib().c8po_tx_test_sig_xor(C.c_ulonglong(int(mask)))

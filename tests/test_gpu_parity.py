@@ -1,7 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the oracle.
 
 Tolerances: integers / bytes / indices bit-exact; LLR |delta| <= 1e-5 (BASELINE.json north_star); the only float
-difference between the two sides is the FFT (exact DFT rounded to float in the oracle, float32 radix-2 on the GPU).
+difference between the two sides is the FFT (exact DFT accumulated in double in the oracle, fp64 radix-2 butterflies across
+the wave on the GPU, both rounded to float once).
 """
 import os
 

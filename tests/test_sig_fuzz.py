@@ -1,0 +1,120 @@
+"""Signal-field fuzz: packets whose HT-SIG / VHT-SIG-A is valid (CRC-8 correct) but announces something the transmitter did
+not do — short GI, aggregation, LDPC, STBC, 40 MHz, other MCS / stream counts / lengths, MU group ids, beamforming.
+The receivers must take every such field exactly as demod_impl.cc / demod2_impl.cc do (signalCheckHt / signalCheckVhtA
+only reject some of them; the rest is parsed and demodulated with whatever geometry the field claims).
+CPU: known consequences of single bits in the oracle.  GPU: engine == oracle on every single-bit flip and on random masks."""
+import zlib
+
+import numpy as np
+import pytest
+
+from c8p_cases import ampdu_vht
+from c8p_testlib import H22, Batch, abi, oracle, oracle_rx, through_channel
+
+
+def mpdu(rng, n):
+    body = bytes(rng.integers(0, 256, size=n - 4, dtype=np.uint8))
+    return body + zlib.crc32(body).to_bytes(4, "little")
+
+
+def fuzzed(fmt, mcs, nss, mask, rng, n=120, snr=None, mupos=0):
+    """one packet with `mask` XOR-ed into its signal field, at the signal -> demod boundary (Batch of 1); None if the
+    legacy front end does not even deliver it"""
+    o = oracle()
+    m = mpdu(rng, n)
+    ps = ampdu_vht(m) if fmt == abi.F_VHT else m
+    o.tx_sig_xor(mask)
+    try:
+        iq, _ = o.tx_packet2(fmt, mcs, nss, ps, mult=12.0 * (np.sqrt(2.0) if nss == 2 else 1.0))
+    finally:
+        o.tx_sig_xor(0)
+    b = Batch()
+    rx = through_channel(iq, H22 if nss == 2 else None, snr_db=snr, rng=rng)
+    return (b if b.add_rx(rx, n_ant=nss, mupos=mupos) == 0 else None), m
+
+
+def test_oracle_takes_the_announced_geometry():
+    rng = np.random.default_rng(1)
+    # HT bit 31: short GI -> 72-sample symbol stride (signalParserHt), the frame is lost but still demodulated
+    b, m = fuzzed(abi.F_HT, 3, 1, 1 << 31, rng)
+    r = oracle_rx(*b.arrays())[0]
+    assert r["tags"]["status"] == abi.ST_OK and r["tags"]["nsymsamp"] == 72 and r["pdus"] == []
+    # HT bit 27: aggregation -> decode publishes nothing for an HT A-MPDU (decode_impl.cc:432-435), FCS not even checked
+    b, m = fuzzed(abi.F_HT, 3, 1, 1 << 27, rng)
+    r = oracle_rx(*b.arrays())[0]
+    assert r["tags"]["status"] == abi.ST_OK and r["tags"]["ampdu"] == 1 and r["pdus"] == [] and r["out"]["n_crc_fail"] == 0
+    # HT bit 7 (40 MHz), 28 / 29 (STBC), 30 (LDPC), 32 / 33 (extension streams): signalCheckHt fails -> the packet falls to legacy
+    for bit in (7, 28, 29, 30, 32, 33):
+        b, m = fuzzed(abi.F_HT, 3, 1, 1 << bit, rng)
+        r = oracle_rx(*b.arrays())[0]
+        assert r["tags"]["format"] == abi.F_L, bit
+    # HT bits 24 / 25 (smoothing, not sounding) are ignored: the MPDU still comes out
+    for bit in (24, 25):
+        b, m = fuzzed(abi.F_HT, 3, 1, 1 << bit, rng)
+        r = oracle_rx(*b.arrays())[0]
+        assert r["pdus"] == [bytes([1, len(m) % 256, len(m) // 256]) + m + bytes([3])], bit
+    # VHT bit 24: short GI; bits 3 (STBC), 22 (TXOP PS), 25, 26 (LDPC), 27, 32 (beamformed), 13-21 (partial AID): parsed, not acted on
+    b, m = fuzzed(abi.F_VHT, 2, 1, 1 << 24, rng)
+    r = oracle_rx(*b.arrays())[0]
+    assert r["tags"]["status"] == abi.ST_OK and r["tags"]["nsymsamp"] == 72 and r["pdus"] == []
+    for bit in (3, 22, 25, 26, 27, 32, 13, 17, 21):
+        b, m = fuzzed(abi.F_VHT, 2, 1, 1 << bit, rng)
+        r = oracle_rx(*b.arrays())[0]
+        assert r["pdus"] == [bytes([2, len(m) % 256, len(m) // 256]) + m + bytes([2])], bit
+    # VHT bits 0 / 1 (bandwidth) and the reserved ones: signalCheckVhtA fails, HT check fails too -> legacy
+    for bit in (0, 1, 2, 23, 33):
+        b, m = fuzzed(abi.F_VHT, 2, 1, 1 << bit, rng)
+        r = oracle_rx(*b.arrays())[0]
+        assert r["tags"]["format"] == abi.F_L, bit
+    # a group id other than 0 / 63 makes it an MU packet: two LTFs expected, MCS and length from SIG-B
+    b, m = fuzzed(abi.F_VHT, 2, 1, 5 << 4, rng)
+    r = oracle_rx(*b.arrays())[0]
+    assert r["tags"]["status"] != abi.ST_OK or r["tags"]["sumu"] == 1
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.shape != b.shape:
+        return False
+    fin = np.isfinite(a) & np.isfinite(b)
+    same_special = np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~fin & ~np.isnan(a)], b[~fin & ~np.isnan(b)])
+    return same_special and bool(np.all(np.abs(a[fin] - b[fin]) <= tol * np.maximum(1.0, np.abs(b[fin]))))
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_on_every_fuzzed_signal_field():
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(2)
+    batch = Batch()
+    masks = [1 << i for i in range(34)] + [int(rng.integers(1, 1 << 34)) for _ in range(60)]
+    cases = [(abi.F_HT, 3, 1, 0), (abi.F_VHT, 4, 1, 0), (abi.F_VHT, 1, 1, 1), (abi.F_HT, 2, 2, 0), (abi.F_VHT, 3, 2, 0)]
+    n_in = 0
+    for fmt, mcs, nss, mupos in cases:
+        for mk in masks:
+            b, _ = fuzzed(fmt, mcs, nss, mk, rng, n=int(rng.integers(40, 200)), snr=35.0, mupos=mupos)
+            if b is None:
+                continue
+            pk, iq, chan = b.arrays()
+            ports = [iq[int(pk[0]["iq_off"][a]):int(pk[0]["iq_off"][a]) + int(pk[0]["n_items"])] for a in range(nss)]
+            batch.add_boundary(ports, chan[:64], int(pk[0]["lsig_mcs"]), int(pk[0]["lsig_len"]), int(pk[0]["lsig_nsamp"]), mupos=mupos, seq=n_in)
+            n_in += 1
+    pk, iq, chan = batch.arrays()
+    ref = oracle_rx(pk, iq, chan)
+    eng = engine.Engine(device=0, keep_bits=True)
+    eng.rx(pk, iq, chan)
+    got = eng.results(want_bits=True)
+    eng.close()
+    kinds = {}
+    for p, (g, o) in enumerate(zip(got, ref)):
+        assert g["tags"]["status"] == o["tags"]["status"], p
+        kinds[int(o["tags"]["status"])] = kinds.get(int(o["tags"]["status"]), 0) + 1
+        if o["tags"]["status"] != abi.ST_OK:
+            continue
+        for k in abi.TAG_KEYS + ("nsym", "nss", "nltf", "ncbps", "ndbps", "nsymsamp", "sumu", "is_ndp", "data_off"):
+            assert g["tags"][k] == o["tags"][k], (p, k)
+        assert close([g["tags"]["sssnr0"], g["tags"]["sssnr1"]], [o["tags"]["sssnr0"], o["tags"]["sssnr1"]], 1e-4), p
+        assert close(g["llr"], o["llr"]), p
+        assert g["pdus"] == o["pdus"] and g["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], p
+        if len(o["pdus"]):
+            assert np.array_equal(g["bits"], o["bits"]), p
+    assert n_in >= 400 and kinds.get(abi.ST_OK, 0) >= 200 and len(kinds) >= 2, kinds
