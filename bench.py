@@ -148,9 +148,9 @@ def main():
                          "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
                          "achieved_exclusive": (B_ALG * n_pkt / (kern_x[dom] * 1e-3)) / 1e9 if kern_x[dom] > 0 else 0.0},
         }
-        if not args.no_frontend:
+        if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
                 iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
                 torch.cuda.synchronize(dev)
