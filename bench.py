@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 B_ALG = 8 * 4400 + 512 + 32 + 1462       # algorithmic bytes per packet, SURVEY.md §8(d) = 37 206
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PROFILE_EVERY = 4                        # c8p_cfg.profile: sample the per-kernel HIP events on every 4th submit
 
 
 def main():
@@ -80,7 +81,8 @@ def main():
 
     # engine-owned streams: consecutive batches are software-pipelined across C8P_SLOTS slots (upload / classify /
     # symbol demod of batch i+1 overlap the decoder of batch i); eng.sync() joins all of them
-    eng = engine.Engine(device=local, profile=not os.environ.get("C8P_BENCH_NOPROFILE"))
+    # HIP events bracket each kernel on every 4th submit of the timed region (bracketing every launch costs ~5 % of the step)
+    eng = engine.Engine(device=local, profile=0 if os.environ.get("C8P_BENCH_NOPROFILE") else PROFILE_EVERY)
 
     def barrier():
         eng.sync()
@@ -89,16 +91,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        eng.rx(pk, iq_dev, chan_dev)
+    # correctness gate (outside the timed region, before the warm-up so that the GPU does not idle between warm-up and timing):
+    # every published PDU is the transmitted MPDU
+    eng.rx(pk, iq_dev, chan_dev)
     eng.sync()
-    # correctness gate (outside the timed region): every published PDU is the transmitted MPDU
     res = eng.results(want_llr=False)
     n_ok = 0
     for r, e in zip(res, expected):
         if r["pdus"] and not args.no_check:
             assert r["pdus"] == [e], "PDU mismatch"
             n_ok += 1
+    for _ in range(args.warmup):
+        eng.rx(pk, iq_dev, chan_dev)
+    eng.sync()
     eng.profile_reset()
 
     barrier()
@@ -114,12 +119,16 @@ def main():
         elapsed = float(t.item())
     kt = eng.kernel_times()
 
-    # exclusive per-kernel durations: the same batch once more with a sync after every step (no overlap between slots)
-    eng.profile_reset()
-    for _ in range(3):
-        eng.rx(pk, iq_dev, chan_dev)
-        eng.sync()
-    kt_excl = eng.kernel_times()
+    # exclusive per-kernel durations: the same batch once more with a sync after every step (no overlap between slots),
+    # every launch bracketed
+    eng_x = engine.Engine(device=local, profile=1)
+    for i in range(4):
+        eng_x.rx(pk, iq_dev, chan_dev)
+        eng_x.sync()
+        if i == 0:
+            eng_x.profile_reset()
+    kt_excl = eng_x.kernel_times()
+    eng_x.close()
 
     out = None
     if rank == 0:
@@ -144,7 +153,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_packet": B_ALG, "packets_per_launch": n_pkt,
                          "avg_launch_ms": {k: round(v, 4) for k, v in kern.items()},
-                         "note": "durations in the timed region overlap across pipeline slots; exclusive = same launches, one batch at a time",
+                         "note": "avg_launch_ms: HIP events on every %d-th launch of each kernel inside the timed region (launches of consecutive batches overlap across pipeline slots); exclusive = every launch, one batch at a time" % PROFILE_EVERY,
                          "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
                          "achieved_exclusive": (B_ALG * n_pkt / (kern_x[dom] * 1e-3)) / 1e9 if kern_x[dom] > 0 else 0.0},
         }

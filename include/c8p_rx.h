@@ -228,7 +228,8 @@ typedef struct c8p_tx_in {
 typedef struct c8p_cfg {
   int32_t abi_version;      /* C8P_ABI_VERSION                                                         */
   int32_t device;           /* HIP device ordinal                                                      */
-  int32_t profile;          /* 1: bracket every kernel with HIP events (c8p_kernel_time)               */
+  int32_t profile;          /* 1: bracket every kernel launch with HIP events (c8p_kernel_time);
+                               N > 1: only on every N-th submit (staggered per kernel) — sampling             */
   int32_t keep_bits;        /* 1: also store descrambled bits (v_unCodedBits) and v_scramBits          */
   void*   stream;           /* hipStream_t to launch on; NULL = engine-owned stream                    */
 } c8p_cfg;
