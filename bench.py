@@ -157,6 +157,9 @@ def main():
                          "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
                          "achieved_exclusive": (B_ALG * n_pkt / (kern_x[dom] * 1e-3)) / 1e9 if kern_x[dom] > 0 else 0.0},
         }
+        rv = valu_roofline(kern_x)
+        if rv:
+            out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
         if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
@@ -177,6 +180,25 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def valu_roofline(kern_x):
+    """The resource that actually binds the decoder: VALU issue.  Wave-instructions per launch from the committed PMC pass
+    (SQ_INSTS_VALU, profiles/*/pmc_hbm.json) over the exclusive launch duration measured in this run, against
+    256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
+    import glob
+    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"]["k_viterbi_lean"]
+            if "sq_insts_valu" in k and kern_x.get("viterbi_fwd", 0) > 0:
+                ach = k["sq_insts_valu"] / (kern_x["viterbi_fwd"] * 1e-3) / 1e9
+                return {"bound": "valu issue", "kernel": "viterbi_fwd (k_viterbi_lean)", "achieved": ach, "peak": peak,
+                        "unit": "G wave-instr/s", "frac": ach / peak, "instr_per_launch": k["sq_insts_valu"],
+                        "source": os.path.relpath(f, ROOT) + " (SQ_INSTS_VALU) / exclusive launch duration of this run"}
+        except Exception:
+            continue
+    return None
 
 
 def pmc_traffic(dom):

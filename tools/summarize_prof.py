@@ -45,6 +45,9 @@ for k in sorted(counters):
         continue
     fk, wk = avg(c["FETCH_SIZE"]), avg(c.get("WRITE_SIZE", []))
     hbm["kernels"][k] = {"fetch_size_kb_raw": fk, "write_size_kb": wk}
+    for extra_c in ("SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+        if extra_c in c:
+            hbm["kernels"][k][extra_c.lower()] = avg(c[extra_c])
     lines.append("%s, %d, %.1f, %d, %.1f, %d, %d, %d" % (k, len(c["FETCH_SIZE"]), fk, fk * 2048, wk, wk * 1024, fk * 2048 + wk * 1024, avg(durs.get(k, []))))
 lines += ["", "SQ / GRBM counters, average per launch (SQ_*_CYCLES, SQ_ACTIVE_*, SQ_WAIT_* are in quad-cycles summed over waves / SIMDs)"]
 for k in sorted(counters):
