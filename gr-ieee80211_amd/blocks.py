@@ -32,6 +32,7 @@ def lib():
         L.c8ph_push_tag_c32.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_void_p, C.c_int]
         L.c8ph_run.restype = C.c_long
         L.c8ph_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.c8ph_set_jitter.argtypes = [C.c_void_p, C.c_ulonglong]
         L.c8ph_error.restype = C.c_char_p
         L.c8ph_error.argtypes = [C.c_void_p]
         for f in ("c8ph_out_count", "c8ph_tag_count", "c8ph_msg_count", "c8ph_dbg_count"):
@@ -78,6 +79,10 @@ class Block:
         else:
             v = np.ascontiguousarray(value, np.complex64)
             self.L.c8ph_push_tag_c32(self.h, offset, k, v.ctypes.data, len(v))
+
+    def set_jitter(self, seed):
+        """random item counts per general_work call from now on (0 = off): what a busy scheduler hands a block"""
+        self.L.c8ph_set_jitter(self.h, int(seed))
 
     def run(self, chunk=4096, nout=8192, flush_at_end=True):
         n = self.L.c8ph_run(self.h, chunk, nout, int(flush_at_end))

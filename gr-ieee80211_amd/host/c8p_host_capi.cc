@@ -28,6 +28,8 @@ struct harness : public block_io {
   std::vector<pdu_t> msgs;
   std::vector<std::string> dbg;
   std::string err;
+  uint64_t jitter = 0;                          // != 0: xorshift state; every call gets random item counts (scheduler-like)
+  uint32_t rnd() { jitter ^= jitter << 13; jitter ^= jitter >> 7; jitter ^= jitter << 17; return (uint32_t)(jitter >> 11); }
 
   uint64_t nitems_read(unsigned) override { return n_read; }
   uint64_t nitems_written(unsigned) override { return n_written; }
@@ -94,25 +96,40 @@ void c8ph_push_tag_c32(void* p, uint64_t off, const char* key, const float* reim
 
 // Run until the input is exhausted; `chunk` = max items offered per call, `nout` = noutput_items per call.
 // Returns the number of general_work calls, or -1 on error (c8ph_error()).
+// from now on c8ph_run() hands general_work a random number of input items (1..chunk, sometimes more on one port than on the
+// others, sometimes none) and a random output space (1..nout) on every call, the way a busy scheduler does
+void c8ph_set_jitter(void* p, unsigned long long seed) { static_cast<harness*>(p)->jitter = seed ? seed : 0; }
+
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 {
   harness* h = static_cast<harness*>(p);
   try {
     long calls = 0;
-    int idle = 0;
+    int idle = 0, starved = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);   // floats per output item (byte items: widened below)
     std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
     while (idle < 4) {
       size_t avail = h->in[0].size() / h->isz(0);
       for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->in[q].size() / h->isz(q));
-      const int n = (int)std::min<size_t>(avail, (size_t)chunk);
+      int n = (int)std::min<size_t>(avail, (size_t)chunk);
+      int nout_call = nout;
+      const bool full = !h->jitter || starved > 32;                 // after a run of fruitless small calls: one full-size call
+      if (!full) {
+        if (n > 0) n = (h->rnd() % 16 == 0) ? 0 : 1 + (int)(h->rnd() % (uint32_t)n);
+        nout_call = 1 + (int)(h->rnd() % (uint32_t)std::max(nout, 1));
+      }
       gr_vector_int nin(h->nports, n);
+      if (!full && h->nports > 1) {                                 // ports rarely hold the same number of items
+        const int q = (int)(h->rnd() % (uint32_t)h->nports);
+        const size_t aq = h->in[q].size() / h->isz(q);
+        nin[q] = (int)std::min<size_t>(aq, (size_t)n + h->rnd() % 97);
+      }
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->in[q].data();
       gr_vector_void_star outs(1, obuf.data());
       if (h->nout == 2) outs.push_back(obuf1.data());
       h->consumed_this_call = 0;
-      const int produced = h->blk->general_work(nout, nin, ins, outs);
+      const int produced = h->blk->general_work(nout_call, nin, ins, outs);
       calls++;
       for (int q = 0; q < h->nports; q++)
         h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->isz(q));
@@ -124,6 +141,11 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
         h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
       if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
       h->n_written += produced;
+      if (!full) {                                                  // a starved call that got nowhere proves nothing
+        if (produced || h->consumed_this_call) { idle = 0; starved = 0; } else starved++;
+        continue;
+      }
+      starved = 0;
       idle = (produced == 0 && h->consumed_this_call == 0) ? idle + 1 : 0;
       if (idle == 2 && flush_at_end && avail == 0) h->blk->flush();
     }

@@ -283,3 +283,56 @@ def test_full_chain_on_gpu_mirrors(chunk, items):
     raw, exp = _detect_case(seed=6)
     sync_bytes, sync_tags, msgs = _rx_chain_on_mirrors(None, raw, chunk, items)
     assert msgs == [d["pdu"].tobytes() for d, w in exp]
+
+
+# ---------------------------------------------------------------------------------------------- scheduler jitter
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_blocks_under_random_scheduler_chunks_with_fake_backend(seed):
+    """every general_work() call gets a random number of input items (sometimes none, sometimes more on one port) and a
+    random output space, as a loaded scheduler hands them out: the item streams, tags and PDUs must not depend on it"""
+    rng = np.random.default_rng(seed)
+    n_ant = 1 + seed % 2
+    # demod(2) -> decode
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)))
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.set_jitter(1000 + seed)
+    dem.run(chunk=int(rng.integers(100, 3000)), nout=int(rng.integers(50, 5000)))
+    llr, tags = dem.output(), dem.tags()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)))
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.set_jitter(2000 + seed)
+    dec.run(chunk=int(rng.integers(200, 4000)), nout=int(rng.integers(1, 300)))
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert check_against_oracle(res, pk, iq, chan) >= 10
+    # signal(2)
+    raw, ev, exp = _signal_case(n_ant)
+    sig = blocks.Block(blocks.SIGNAL if n_ant == 1 else blocks.SIGNAL2, engine_lib=FAKE, max_batch=int(rng.integers(1, 5)))
+    blocks.feed_signal(sig, ev, [raw[a] for a in range(n_ant)])
+    sig.set_jitter(3000 + seed)
+    sig.run(chunk=int(rng.integers(100, 3000)), nout=int(rng.integers(100, 3000)))
+    outs, stags = [sig.output(a) for a in range(n_ant)], sig.tags()
+    sig.close()
+    _check_signal(outs, stags, raw, ev, n_ant, 0.0)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_detect_mirror_under_random_scheduler_chunks_with_fake_backend(seed):
+    raw, exp = _detect_case()
+    ref_bytes, ref_tags, ref_msgs = _rx_chain_on_mirrors(FAKE, raw, 8192, 1 << 20)
+    rng = np.random.default_rng(seed)
+    det = blocks.Block(blocks.DETECT, engine_lib=FAKE, max_batch=int(rng.integers(700, 5000)))
+    det.push_items(0, raw)
+    det.set_jitter(seed)
+    c = int(rng.integers(300, 3000))
+    det.run(chunk=c, nout=c)
+    got_bytes, got_tags = det.output(), det.tags()
+    det.close()
+    assert np.array_equal(got_bytes, ref_bytes)
+    assert [(o, k) for o, k, v in got_tags] == [(o, k) for o, k, v in ref_tags]
+    for (o, k, v), (o2, k2, v2) in zip(got_tags, ref_tags):
+        assert abs(v - v2) <= 1e-6 * max(1.0, abs(v2)), (o, k)
