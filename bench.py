@@ -118,6 +118,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kt = eng.kernel_times()
+    eng.close()                              # its arenas (4 slots, sized for the worst case per packet) are not needed any more
 
     # exclusive per-kernel durations: the same batch once more with a sync after every step (no overlap between slots),
     # every launch bracketed
@@ -174,7 +175,6 @@ def main():
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
-    eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
