@@ -188,6 +188,7 @@ struct Slot {
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
   Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc, d_tx_bfq;   // transmit chain
   int n_pkt = 0;
+  unsigned ticket = 0;                               // c8p_ticket() of the submit that filled this slot (0: never used)
   size_t used[C8P_BUF_COUNT] = {};
   const void* ptr[C8P_BUF_COUNT] = {};
 };
@@ -424,7 +425,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   // next slot; its previous batch (submitted slots.size() submits ago) must be done before its arenas are reused
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++;
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
@@ -499,7 +500,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
   // next slot; its previous batch (submitted slots.size() submits ago) must be done before its arenas are reused
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++;
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
@@ -550,7 +551,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
   if (!in || in->n_evt < 0 || (in->n_evt > 0 && (!in->evts || !in->raw))) { c->err = "bad batch"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++;
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
@@ -612,7 +613,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   if (in->n > (1ull << 31)) { c->err = "stream segment too long (2^31 items max)"; return C8P_ERANGE; }
   HIPCHK(c, hipSetDevice(c->device));
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++;
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   Slot& S = *c->s;
   HIPCHK(c, hipStreamSynchronize(S.stream));
@@ -858,7 +859,7 @@ extern "C" int c8p_tx(c8p_ctx* c, const c8p_tx_in* in)
   if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->pkts || !in->psdu))) { c->err = "bad tx input"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
   HIPCHK(c, hipSetDevice(c->device));
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++;
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   Slot& S = *c->s;
   HIPCHK(c, hipStreamSynchronize(S.stream));
@@ -962,6 +963,19 @@ extern "C" int c8p_sync(c8p_ctx* c)
   for (Slot& sl : c->slots) HIPCHK(c, hipStreamSynchronize(sl.stream));
   drain_events(c);
   return C8P_OK;
+}
+
+// Tickets: consecutive submits rotate through the slots, so the result arenas of the last slots.size() submits are all
+// resident; c8p_select() points c8p_buffer / c8p_fetch at an earlier one (a caller that overlaps the upload of batch i+1
+// with the download of batch i).  The next submit makes its own slot current again.
+extern "C" int c8p_ticket(c8p_ctx* c) { return c ? (int)(c->seq & 0x7fffffffu) : C8P_EINVAL; }
+extern "C" int c8p_select(c8p_ctx* c, int ticket)
+{
+  if (!c) return C8P_EINVAL;
+  for (Slot& sl : c->slots)
+    if (sl.ticket != 0 && (int)(sl.ticket & 0x7fffffffu) == ticket) { c->s = &sl; return C8P_OK; }
+  c->err = "ticket is not resident any more (its slot has been reused) or was never issued";
+  return C8P_ERANGE;
 }
 
 extern "C" const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 # every entry point include/c8p_rx.h declares
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
-           "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu"]
+           "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select"]
 
 _LIB = None
 
@@ -47,6 +47,8 @@ def load_library():
     L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_tx_plan_mu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_sync.argtypes = [C.c_void_p]
+    L.c8p_ticket.argtypes = [C.c_void_p]
+    L.c8p_select.argtypes = [C.c_void_p, C.c_int]
     L.c8p_buffer.restype = C.c_void_p
     L.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.c8p_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -184,6 +186,13 @@ class Engine:
 
     def sync(self):
         self._chk(self.L.c8p_sync(self.ctx))
+
+    def ticket(self):
+        """id of the latest submit; select(ticket) points buffer() / fetch() at it for as long as its slot is not reused"""
+        return self.L.c8p_ticket(self.ctx)
+
+    def select(self, ticket):
+        self._chk(self.L.c8p_select(self.ctx, int(ticket)))
 
     def buffer(self, which):
         nbytes = C.c_uint64(0)

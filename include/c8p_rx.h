@@ -344,7 +344,14 @@ int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   
 int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2); /* C8P_F_VHT_MU: plan2[0], plan2[1] = the users */
 int c8p_sync  (c8p_ctx* ctx);
 
-/* Device pointer / size in bytes of a result arena of the last submit. */
+/* Submits rotate through C8P_SLOTS (default 4) sets of arenas, so the results of the last few submits stay resident.
+ * c8p_ticket: id of the latest submit (> 0).  c8p_select: make c8p_buffer / c8p_fetch refer to that earlier submit
+ * (C8P_ERANGE once its slot has been reused); the next submit selects itself.  Lets a caller upload batch i+1 while it
+ * downloads batch i.  One slot only when the ctx runs on a caller-provided stream. */
+int c8p_ticket(c8p_ctx* ctx);
+int c8p_select(c8p_ctx* ctx, int ticket);
+
+/* Device pointer / size in bytes of a result arena of the selected (by default: the last) submit. */
 const void* c8p_buffer(c8p_ctx* ctx, int which, uint64_t* bytes);
 /* Copy [offset, offset+bytes) of a result arena to host memory (synchronises the stream). */
 int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);

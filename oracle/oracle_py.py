@@ -84,6 +84,7 @@ def descramble(sbits):
 def demod(pkts, iq, chan, p):
     """Run the demod oracle on packet p of a batch. Returns (tags record, llr[total], mu2x1chan[128])."""
     from_abi = _abi()
+    assert pkts.flags.c_contiguous and pkts.dtype == from_abi.PKT_IN_DT, "packet records must be a contiguous PKT_IN_DT array"
     tags = np.zeros(1, from_abi.PKT_TAGS_DT)
     n_items = int(pkts[p]["n_items"])
     llr = np.zeros((n_items // 72 + 1) * 832 + 1024, np.float32)

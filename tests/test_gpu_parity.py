@@ -316,3 +316,39 @@ def test_baseline_configs_at_full_size(eng):
         ok = sum(1 for r in res if r["pdus"] == [want])
         assert all(r["pdus"] in ([], [want]) for r in res)
         assert ok >= 0.97 * 1024, (u, ok)
+
+
+def test_tickets_keep_earlier_submits_fetchable():
+    """c8p_ticket / c8p_select: the arenas of the last C8P_SLOTS submits stay resident and can be fetched out of order"""
+    e = engine.Engine(device=0)
+    batches = []
+    for seed, snr in ((3, None), (4, 20.0), (5, 12.0)):
+        b, _ = sweep_batch(snr_db=snr, seed=seed)
+        pk, iq, chan = b.arrays()
+        sel = np.ascontiguousarray(pk[::(seed - 1)])                 # different packet counts per submit
+        batches.append((sel, iq, chan))
+    tickets = []
+    for pk, iq, chan in batches:                                  # three submits back to back, nothing fetched in between
+        e.rx(pk, iq, chan)
+        tickets.append(e.ticket())
+    assert len(set(tickets)) == 3 and all(t > 0 for t in tickets)
+    for k in (1, 0, 2, 0):                                        # out of order, and twice
+        pk, iq, chan = batches[k]
+        e.select(tickets[k])
+        outs, tags = e.outs(), e.tags()
+        assert len(outs) == len(pk) == len(tags)
+        ref = oracle_rx(pk, iq, chan)
+        area = e.fetch(abi.BUF_PDU, np.uint8).tobytes()
+        for p, r in enumerate(ref):
+            assert tags[p]["status"] == r["tags"]["status"] and outs[p]["n_pdu"] == r["out"]["n_pdu"], (k, p)
+            o = int(outs[p]["pdu_off"])
+            assert abi.split_pdus(area[o:o + int(outs[p]["pdu_bytes"])], int(outs[p]["n_pdu"])) == r["pdus"], (k, p)
+    with pytest.raises(RuntimeError, match="ticket"):
+        e.select(tickets[2] + 1000)
+    for _ in range(4):                                            # four more submits: every slot has been reused
+        e.rx(*batches[0])
+    with pytest.raises(RuntimeError, match="ticket"):
+        e.select(tickets[0])
+    e.select(e.ticket())
+    assert len(e.outs()) == len(batches[0][0])
+    e.close()

@@ -33,6 +33,21 @@ for name, (a, c) in cases.items():
         pdu = eng.fetch(abi.BUF_PDU, np.uint8)             # PDU arena to the host
     dt = time.perf_counter() - t
     ok = int((outs["n_pdu"] == 1).sum())
-    print({"input": name, "packets_per_s": round(4096 * steps / dt), "ms_per_step": round(1e3 * dt / steps, 3),
+    print({"input": name, "mode": "fetch after every submit", "packets_per_s": round(4096 * steps / dt), "ms_per_step": round(1e3 * dt / steps, 3),
            "MB_in_per_step": round((a.nbytes + c.nbytes) / 1e6, 1), "MB_out_per_step": round((pdu.nbytes + outs.nbytes) / 1e6, 1), "pdus": ok})
+    # pipelined with tickets: submit batch i+1, then download batch i (c8p_select)
+    t = time.perf_counter()
+    prev = None
+    for i in range(steps + 1):
+        if i < steps:
+            eng.rx(pk, a, c)
+            cur = eng.ticket()
+        if prev is not None:
+            eng.select(prev)
+            outs = eng.outs()
+            pdu = eng.fetch(abi.BUF_PDU, np.uint8)
+        prev = cur
+    dt = time.perf_counter() - t
+    print({"input": name, "mode": "submit i+1, then fetch i (tickets)", "packets_per_s": round(4096 * steps / dt),
+           "ms_per_step": round(1e3 * dt / steps, 3), "pdus": int((outs["n_pdu"] == 1).sum())})
     eng.close()
