@@ -30,6 +30,7 @@ struct Mimo {               // demod2_impl.h:95-105
   cf pil1[4], pil2[4];
 };
 
+#define C8P_X8N 4104
 struct DevTables {
   int16_t deintL[4][288];         // mapDeintLegacy*      cloud80211phy.cc:1413-1500
   int16_t deintNL[5][416];        // mapDeintNonlegacy*   :1711-1831
@@ -48,6 +49,7 @@ struct DevTables {
   uint64_t scrW[4];               // scrSeq repeated, packed: bit i = scrSeq[i % 127], i = 0..255
   uint32_t crc32[256];
   uint32_t x2n[32];               // x^(2^n) mod P, reflected CRC-32 domain
+  uint32_t x8n[C8P_X8N];          // x^(8 n) mod P for every byte distance a frame can have (wave_crc32's segment shifts)
 };
 
 // ---------------------------------------------------------------------------------------------- complex helpers

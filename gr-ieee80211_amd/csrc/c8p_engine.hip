@@ -131,6 +131,8 @@ static const DevTables& host_tables()
     uint32_t p = 1u << 30;
     T.x2n[0] = p;
     for (int n = 1; n < 32; n++) T.x2n[n] = p = h_multmodp(p, p);
+    T.x8n[0] = 1u << 31;                                   // the polynomial 1
+    for (int n = 1; n < C8P_X8N; n++) T.x8n[n] = h_multmodp(T.x8n[n - 1], T.x2n[3]);      // times x^8
   }
   init = true;
   return T;
