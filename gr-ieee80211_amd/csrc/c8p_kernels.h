@@ -890,12 +890,16 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       __syncthreads();
       // rows this lane fetches: instruction j covers rows 4j .. 4j+3, 16 lanes x 16 bytes per row
       const int frow = lane >> 4, fcol = (lane & 15) * 4;
+      const uint32_t fcol4 = (uint32_t)fcol * 4u;
       // 16 in-flight 16-byte loads per lane, kept in named registers (an indexed array ends up in scratch)
 #define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define C8P_DECL(j) const int fb##j = s_btop[j * 4 + frow]; uint4 pf##j;
       C8P_ROWS16(C8P_DECL)
-#define C8P_LOAD(j) pf##j = *(const uint4*)(SW + (((rows_ >> (j * 4 + frow)) & 1ull) ? (size_t)(fb##j - i_) * 64 + fcol : (size_t)fcol));
-#define C8P_PREFETCH(i, rows) do { const int i_ = (i); const unsigned long long rows_ = (rows); C8P_ROWS16(C8P_LOAD) } while (0)
+      // byte offset inside the packet's survivor area (32 bits, uniform base): block (fb_j - i) of an active row, block 0 of an
+      // idle one.  mine_ = this lane's 16 row-activity bits, one per nibble
+#define C8P_LOAD(j) pf##j = *(const uint4*)((const char*)SW + ((((uint32_t)(fb##j - i_) << 8) & (uint32_t)__builtin_amdgcn_sbfe((int)(j < 8 ? mlo_ : mhi_), ((j & 7) * 4), 1)) + fcol4));
+#define C8P_PREFETCH(i, rows) do { const int i_ = (i); const unsigned long long m_ = (rows) >> frow; \
+    const uint32_t mlo_ = (uint32_t)m_, mhi_ = (uint32_t)(m_ >> 32); C8P_ROWS16(C8P_LOAD) } while (0)
 #define C8P_STAGE(j) *(uint4*)(&tile[(j * 4 + frow) * TS + fcol]) = pf##j;
       for (int it = 0; it < 66; it++) {
         int D = Dend;
