@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include <algorithm>
@@ -55,11 +56,16 @@ static uint32_t h_multmodp(uint32_t a, uint32_t b)
   return p;
 }
 
-static const DevTables& host_tables()
+static void build_host_tables(DevTables& T);
+static const DevTables& host_tables()      // built once; contexts may be created from several threads (one per GNU Radio block)
 {
   static DevTables T;
-  static bool init = false;
-  if (init) return T;
+  static std::once_flag once;
+  std::call_once(once, [] { build_host_tables(T); });
+  return T;
+}
+static void build_host_tables(DevTables& T)
+{
   memset(&T, 0, sizeof(T));
   static const int nbL[4] = {1, 2, 4, 6}, nbNL[5] = {1, 2, 4, 6, 8};
   for (int m = 0; m < 4; m++) build_deint(T.deintL[m], 48 * nbL[m], nbL[m], 16, false);
@@ -134,8 +140,6 @@ static const DevTables& host_tables()
     T.x8n[0] = 1u << 31;                                   // the polynomial 1
     for (int n = 1; n < C8P_X8N; n++) T.x8n[n] = h_multmodp(T.x8n[n - 1], T.x2n[3]);      // times x^8
   }
-  init = true;
-  return T;
 }
 
 extern "C" int c8p_table(int which, int sub, int32_t* dst, int cap)

@@ -352,3 +352,34 @@ def test_tickets_keep_earlier_submits_fetchable():
     e.select(e.ticket())
     assert len(e.outs()) == len(batches[0][0])
     e.close()
+
+
+def test_contexts_on_concurrent_host_threads():
+    """one ctx per block instance, each driven from its own thread (GNU Radio runs every block on its own thread): four
+    threads create a context and push different batches through it at the same time; every result equals the oracle's"""
+    import threading
+    jobs = []
+    for seed, snr in ((21, None), (22, 18.0), (23, 12.0), (24, 25.0)):
+        b, _ = sweep_batch(snr_db=snr, seed=seed)
+        pk, iq, chan = b.arrays()
+        jobs.append((pk, iq, chan, oracle_rx(pk, iq, chan)))
+    errs = []
+
+    def work(k):
+        try:
+            pk, iq, chan, ref = jobs[k]
+            e = engine.Engine(device=0)
+            for _ in range(6):
+                e.rx(pk, iq, chan)
+                res = e.results(want_llr=False)
+                for p, (g, o) in enumerate(zip(res, ref)):
+                    assert g["tags"]["status"] == o["tags"]["status"] and g["pdus"] == o["pdus"], (k, p)
+            e.close()
+        except Exception as ex:                                     # surfaced in the main thread
+            errs.append((k, repr(ex)))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
