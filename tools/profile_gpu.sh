@@ -8,7 +8,7 @@ TAG=${1:-r1x}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 10 --warmup 2 --no-cpu"
+BENCH="python $PWD/bench.py --no-cpu"     # the default bench command (60 timed steps) without the CPU leg
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $BENCH > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
