@@ -383,3 +383,24 @@ def test_contexts_on_concurrent_host_threads():
     for t in th:
         t.join()
     assert not errs, errs
+
+
+def test_every_entry_point_takes_an_empty_batch():
+    e = engine.Engine(device=0)
+    one = np.zeros(64, np.complex64)
+    e.rx(np.zeros(0, abi.PKT_IN_DT), one, one); e.sync()
+    assert len(e.outs()) == 0 and len(e.tags()) == 0
+    e.demod(np.zeros(0, abi.PKT_IN_DT), one, one); e.sync()
+    assert len(e.tags()) == 0 and len(e.fetch(abi.BUF_LLR, np.float32)) == 0
+    e.decode(np.zeros(0, abi.PKT_TAGS_DT), np.zeros(4, np.float32)); e.sync()
+    assert len(e.outs()) == 0 and len(e.fetch(abi.BUF_PDU, np.uint8)) == 0
+    e.signal(np.zeros(0, abi.SIG_IN_DT), one); e.sync()
+    assert len(e.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)) == 0
+    e.tx(np.zeros(0, abi.TX_PKT_DT), np.zeros(4, np.uint8)); e.sync()
+    assert len(e.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)) == 0 and len(e.fetch(abi.BUF_TX_IQ, np.complex64)) == 0
+    assert len(e.detect(one[:0])) == 0
+    b, _ = sweep_batch(snr_db=None, seed=2)                    # and the context still works
+    pk, iq, chan = b.arrays()
+    e.rx(pk, iq, chan)
+    assert sum(len(r["pdus"]) for r in e.results(want_llr=False)) >= 40
+    e.close()
