@@ -552,7 +552,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    float* __restrict__ llr, uint32_t* __restrict__ flags, int n,
                                                    uint32_t total_syms)
 {
-  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  // (the wave index is uniform, but the compiler cannot see that through threadIdx: without the readfirstlane the packet's
+  // tags and descriptor — 170 bytes — are fetched per lane into VGPRs instead of once into SGPRs)
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
   if (w >= total_syms) return;
   const int lane = lane_id();
   const int p = (int)sym2pkt[w];                   // written by k_classify
