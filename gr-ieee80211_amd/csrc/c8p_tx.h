@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void k_tx_sym(const TxPlan* __restrict__ plans
                                                 unsigned int total_units)
 {
   __shared__ double2 st[4][64];
-  const unsigned int u = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const unsigned int u = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // uniform: the plan comes through scalar loads
   if (u >= total_units) return;
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int p = (int)unit2pkt[u];
   const TxPlan P = plans[p];
   const c8p_tx_plan& m = P.p;
