@@ -17,30 +17,38 @@ struct ModD {
   int format, sumu, ampdu, nSym, nSymSamp, nSS, nLTF, mcs, len, cr, nBPSCS, nDBPS, nCBPS, nCBPSS, valid;
 };
 
-__device__ __forceinline__ bool crc8_check(const uint8_t* b, int len, const uint8_t* crc)   // checkBitCrc8 :1367-1403
+// The decoded SIG bits are handed around as ONE wave-uniform 64-bit word (bit i = i-th bit): checks and field extraction
+// then run on the scalar unit instead of 64 lanes each redoing them on bytes from LDS.
+__device__ __forceinline__ unsigned long long sig_word(const uint8_t* b, int L)          // b in LDS, L <= 64
+{
+  const int lane = lane_id();
+  return __ballot(lane < L && b[lane] != 0);
+}
+__device__ __forceinline__ bool crc8_check(unsigned long long w)   // checkBitCrc8 :1367-1403 over bits 0..33 against bits 34..41
 {
   unsigned c = 0xff;
-  for (int i = 0; i < len; i++) {
+  for (int i = 0; i < 34; i++) {
     unsigned fb = (c >> 7) & 1u;
     c = (c << 1) & 0xffu;
     if (fb) c ^= 0x07u;
-    if (b[i]) c ^= 0x07u;
+    if ((w >> i) & 1ull) c ^= 0x07u;
   }
-  for (int i = 0; i < 8; i++) if (crc[i]) c ^= (1u << (7 - i));
+  for (int i = 0; i < 8; i++) if ((w >> (34 + i)) & 1ull) c ^= (1u << (7 - i));
   return (c & 0xffu) == 0xffu;
 }
-__device__ __forceinline__ bool check_vht_a(const uint8_t* b)   // signalCheckVhtA :753-771
+__device__ __forceinline__ bool check_vht_a(unsigned long long w)   // signalCheckVhtA :753-771
 {
-  if ((b[2] != 1) || (b[23] != 1) || (b[33] != 1)) return false;
-  if (!crc8_check(b, 34, &b[34])) return false;
-  if (b[0] + b[1]) return false;
+  const unsigned long long ones = (1ull << 2) | (1ull << 23) | (1ull << 33);
+  if ((w & ones) != ones) return false;
+  if (!crc8_check(w)) return false;
+  if (w & 3ull) return false;
   return true;
 }
-__device__ __forceinline__ bool check_ht(const uint8_t* b)      // signalCheckHt :730-751
+__device__ __forceinline__ bool check_ht(unsigned long long w)      // signalCheckHt :730-751
 {
-  if (b[26] != 1) return false;
-  if (!crc8_check(b, 34, &b[34])) return false;
-  if (b[5] + b[6] + b[7] + b[28] + b[29] + b[30] + b[32] + b[33]) return false;
+  if (!((w >> 26) & 1ull)) return false;
+  if (!crc8_check(w)) return false;
+  if (w & ((7ull << 5) | (7ull << 28) | (3ull << 32))) return false;       // bits 5-7, 28-30, 32-33
   return true;
 }
 __device__ __forceinline__ void set_rate(ModD& m)               // :1294-1322
@@ -72,15 +80,13 @@ __device__ __forceinline__ void parse_legacy(int mcs, int len, ModD& m)   // sig
   m.len = len; m.nSS = 1; m.sumu = 0; m.nLTF = 0; m.format = C8P_F_L; m.nSymSamp = 80; m.ampdu = 0;
   m.nSym = (len * 8 + 22) / ndbps + (((len * 8 + 22) % ndbps) != 0);
 }
-__device__ __forceinline__ void parse_ht(const uint8_t* b, ModD& m)       // signalParserHt :852-998
+__device__ __forceinline__ void parse_ht(unsigned long long w, ModD& m)    // signalParserHt :852-998
 {
   m = ModD{};
-  int mcs = 0, len = 0;
-  for (int i = 0; i < 7; i++) mcs |= ((int)b[i]) << i;
-  for (int i = 0; i < 16; i++) len |= ((int)b[i + 8]) << i;
+  const int mcs = (int)(w & 0x7full), len = (int)((w >> 8) & 0xffffull);
   m.valid = 1; m.format = C8P_F_HT; m.sumu = 0;
-  m.nSymSamp = b[31] ? 72 : 80;
-  m.ampdu = b[27] ? 1 : 0;
+  m.nSymSamp = ((w >> 31) & 1ull) ? 72 : 80;
+  m.ampdu = (int)((w >> 27) & 1ull);
   m.mcs = mcs;
   const int k = mcs & 7;
   m.nBPSCS = k == 0 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : 6;
@@ -89,19 +95,16 @@ __device__ __forceinline__ void parse_ht(const uint8_t* b, ModD& m)       // sig
   set_rate(m);
   m.nSym = (len * 8 + 22) / m.nDBPS + (((len * 8 + 22) % m.nDBPS) != 0);
 }
-__device__ __forceinline__ void parse_vht_a(const uint8_t* b, ModD& m)    // signalParserVhtA :1090-1178
+__device__ __forceinline__ void parse_vht_a(unsigned long long w, ModD& m) // signalParserVhtA :1090-1178
 {
   m = ModD{};
   m.valid = 1;
-  int gid = 0;
-  for (int i = 0; i < 6; i++) gid |= ((int)b[i + 4]) << i;
+  const int gid = (int)((w >> 4) & 63ull);
   m.format = C8P_F_VHT;
-  m.nSymSamp = b[24] ? 72 : 80;
+  m.nSymSamp = ((w >> 24) & 1ull) ? 72 : 80;
   m.ampdu = 1;
   if (gid == 0 || gid == 63) {
-    int nsts = 0, mcs = 0;
-    for (int i = 0; i < 3; i++) nsts |= ((int)b[i + 10]) << i;
-    for (int i = 0; i < 4; i++) mcs |= ((int)b[i + 28]) << i;
+    const int nsts = (int)((w >> 10) & 7ull), mcs = (int)((w >> 28) & 15ull);
     m.sumu = 0; m.nSS = nsts + 1;
     if (m.nSS > 4) m.valid = 0;
     mod_vht(mcs, m);
@@ -109,25 +112,20 @@ __device__ __forceinline__ void parse_vht_a(const uint8_t* b, ModD& m)    // sig
     m.sumu = 1; m.nLTF = 2; m.nSS = 1;
   }
 }
-__device__ __forceinline__ void parse_vht_b(const uint8_t* b, ModD& m)    // signalParserVhtB :1180-1223
+__device__ __forceinline__ void parse_vht_b(unsigned long long w, ModD& m) // signalParserVhtB :1180-1223
 {
-  int len = 0, mcs = 0;
   if (m.sumu) {
-    for (int i = 0; i < 16; i++) len |= ((int)b[i]) << i;
-    for (int i = 0; i < 4; i++) mcs |= ((int)b[i + 16]) << i;
+    const int len = (int)(w & 0xffffull), mcs = (int)((w >> 16) & 15ull);
     if (!mod_vht(mcs, m)) return;
     m.len = len * 4;
     m.nSym = (m.len * 8 + 16 + 6) / m.nDBPS + (((m.len * 8 + 16 + 6) % m.nDBPS) != 0);
     m.nLTF = 2;
   } else {
-    if ((b[17] + b[18] + b[19]) == 3) {
-      for (int i = 0; i < 17; i++) len |= ((int)b[i]) << i;
-      m.len = len * 4;
+    if (((w >> 17) & 7ull) == 7ull) {
+      m.len = (int)(w & 0x1ffffull) * 4;
       m.nSym = (m.len * 8 + 16 + 6) / m.nDBPS + (((m.len * 8 + 16 + 6) % m.nDBPS) != 0);
     } else {
-      uint32_t pat = 0;
-      for (int i = 0; i < 20; i++) pat |= ((uint32_t)b[i]) << i;
-      if (pat == 0x422E0u) { m.len = 0; m.nSym = 0; } else { m.len = -1; m.nSym = -1; }
+      if ((w & 0xfffffull) == 0x422E0ull) { m.len = 0; m.nSym = 0; } else { m.len = -1; m.nSym = -1; }
     }
   }
 }
@@ -356,11 +354,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
       }
       __syncthreads();
       wave_sig_viterbi(S.llr_vht, S.bits, 48, S.w1, S.w0);
-      if (check_vht_a(S.bits)) { parse_vht_a(S.bits, m); fmt = C8P_F_VHT; }
+      const unsigned long long wa = sig_word(S.bits, 48);
+      if (check_vht_a(wa)) { parse_vht_a(wa, m); fmt = C8P_F_VHT; }
       else {
         __syncthreads();
         wave_sig_viterbi(S.llr_ht, S.bits, 48, S.w1, S.w0);
-        if (check_ht(S.bits)) { parse_ht(S.bits, m); fmt = C8P_F_HT; }
+        const unsigned long long wh = sig_word(S.bits, 48);
+        if (check_ht(wh)) { parse_ht(wh, m); fmt = C8P_F_HT; }
       }
     }
   }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
       __syncthreads();
       sigb_finish(S, T, nss_eff);
       sssnr0 = S.sssnr[0]; sssnr1 = S.sssnr[1];
-      parse_vht_b(S.bbits, m);
+      parse_vht_b(sig_word(S.bbits, 26), m);
       const int nSymL = (P.lsig_len * 8 + 22 + 23) / 24;
       const bool len_ok = two ? (m.len > 0) : (m.len >= 0);
       if (!m.valid) { status = C8P_ST_REJ_UNSUP; done = true; }
