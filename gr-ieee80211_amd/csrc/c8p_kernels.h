@@ -531,7 +531,7 @@ template <int NB> __device__ __forceinline__ bool llr_scatter(cf q, int j, const
   qam_to_llr<NB>(q, o);
   bool bad = false;
 #pragma unroll
-  for (int b = 0; b < NB; b++) { out[map[j * NB + b]] = o[b]; bad = bad || bad_llr(o[b]); }
+  for (int b = 0; b < NB; b++) { out[(uint32_t)(uint16_t)map[j * NB + b]] = o[b]; bad = bad || bad_llr(o[b]); }   // unsigned 32-bit offsets from a uniform base: no 64-bit address per store
   return bad;
 }
 __device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out)
