@@ -205,8 +205,15 @@ __device__ __forceinline__ float acs_step(float pre, int src0, int cA, int cB, f
 
 // Short rate-1/2 decoder of the SIG fields (svSigDecoder::decode cloud80211phy.cc:2001-2088), L <= 48.
 // llr in LDS (2L floats), bits out to LDS; w1/w0: 49-entry scratch in LDS.
-__device__ __forceinline__ void wave_sig_viterbi(const float* llr, uint8_t* bits, int L,
-                                                 unsigned long long* w1, unsigned long long* w0)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)      // the same value in every lane -> SGPR pair
+{
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// Returns the decoded bits as a wave-uniform word (bit t = bit t) and leaves them in bits[] as bytes.
+__device__ __forceinline__ unsigned long long wave_sig_viterbi(const float* llr, uint8_t* bits, int L,
+                                                               unsigned long long* w1, unsigned long long* w0)
 {
   const int lane = lane_id();
   const int m = lane & 31, b = lane >> 5;
@@ -219,13 +226,16 @@ __device__ __forceinline__ void wave_sig_viterbi(const float* llr, uint8_t* bits
     if (lane == 0) { w1[t] = b1; w0[t] = b0; }
   }
   __syncthreads();
-  if (lane == 0) {
-    int st = 0;
-    for (int t = L - 1; t >= 0; t--) {
-      int prev = ((w0[t] >> st) & 1ull) ? 0 : (2 * (st & 31) + (int)((w1[t] >> st) & 1ull));
-      bits[t] = (st == ((prev >> 1) | 32)) ? 1 : 0;
-      st = prev;
-    }
+  // traceback from state 0 on the scalar unit: the survivor words come back through readfirstlane, the state is uniform
+  int st = 0;
+  unsigned long long word = 0;
+  for (int t = L - 1; t >= 0; t--) {
+    const unsigned long long a1 = uniform_u64(w1[t]), a0 = uniform_u64(w0[t]);
+    const int prev = ((a0 >> st) & 1ull) ? 0 : (2 * (st & 31) + (int)((a1 >> st) & 1ull));
+    if (st == ((prev >> 1) | 32)) word |= 1ull << t;
+    st = prev;
   }
+  if (lane < L) bits[lane] = (uint8_t)((word >> lane) & 1ull);
   __syncthreads();
+  return word;
 }

@@ -353,13 +353,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         S.llr_vht[idx] = m1.x; S.llr_vht[idx + 48] = m2.y;
       }
       __syncthreads();
-      wave_sig_viterbi(S.llr_vht, S.bits, 48, S.w1, S.w0);
-      const unsigned long long wa = sig_word(S.bits, 48);
+      const unsigned long long wa = wave_sig_viterbi(S.llr_vht, S.bits, 48, S.w1, S.w0);
       if (check_vht_a(wa)) { parse_vht_a(wa, m); fmt = C8P_F_VHT; }
       else {
         __syncthreads();
-        wave_sig_viterbi(S.llr_ht, S.bits, 48, S.w1, S.w0);
-        const unsigned long long wh = sig_word(S.bits, 48);
+        const unsigned long long wh = wave_sig_viterbi(S.llr_ht, S.bits, 48, S.w1, S.w0);
         if (check_ht(wh)) { parse_ht(wh, m); fmt = C8P_F_HT; }
       }
     }
