@@ -1,0 +1,45 @@
+"""Register / LDS budgets of the hot kernels, from the compiler's own resource remarks (hipcc cross-compiles without a GPU).
+
+The pipelined step keeps the launches of four batches resident at once, and its throughput follows how many decoder waves fit
+next to the side kernels: measured on MI355X, a decoder build with 66 instead of 64 VGPRs (7 instead of 8 waves per SIMD) is
+4-8 % slower per step although the kernel alone is faster, and 18 KB of LDS per decoder workgroup (the compiler's alloca
+promotion) cost up to 6.5 %.  These budgets are therefore part of the design and guarded here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gr-ieee80211_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def usage():
+    r = subprocess.run(["make", "-s", "-C", CSRC, "asm"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res, cur = {}, None
+    for line in (r.stdout + r.stderr).splitlines():
+        m = re.search(r"Function Name: _Z(\d+)(\w+)", line)
+        if m:
+            cur = res.setdefault(m.group(2)[:int(m.group(1))], {})       # Itanium mangling: <length><name>
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return res
+
+
+def test_decoder_and_symbol_kernels_keep_eight_waves_per_simd(usage):
+    lean, demod = usage["k_viterbi_lean"], usage["k_demod_sym"]
+    assert lean["VGPRs"] <= 64 and lean["AGPRs"] == 0 and lean["Occupancy"] == 8, lean
+    assert lean["LDS Size"] == 0, lean                      # no alloca promoted into LDS (-disable-promote-alloca-to-lds)
+    assert lean["VGPRs Spill"] == 0 and lean["SGPRs Spill"] == 0, lean
+    assert demod["VGPRs"] <= 64 and demod["Occupancy"] == 8 and demod["LDS Size"] == 0, demod
+    assert demod["ScratchSize"] == 0 and demod["VGPRs Spill"] == 0, demod
+
+
+def test_side_kernels_stay_inside_their_budgets(usage):
+    assert usage["k_classify"]["VGPRs"] <= 72, usage["k_classify"]
+    assert usage["k_finish"]["LDS Size"] <= 24 * 1024 and usage["k_finish"]["ScratchSize"] == 0, usage["k_finish"]
+    assert usage["k_presiso"]["ScratchSize"] == 0 and usage["k_tx_sym"]["ScratchSize"] <= 16
