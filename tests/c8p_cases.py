@@ -46,6 +46,26 @@ def sweep_batch(snr_db=None, seed=1, dewin=False):
     return b, meta
 
 
+def multipath_batch(snr_db=None, seed=3):
+    """every single-user fixture packet through a 3-path channel (echoes at 2 and 5 samples, inside the 16-sample guard
+    interval); the 2-stream ones through a 2x2 channel with different echoes on every antenna pair"""
+    from c8p_testlib import through_multipath
+    rng = np.random.default_rng(seed)
+    b, meta = Batch(), []
+    t1 = [[[(0, 1.0), (2, 0.35 * np.exp(0.7j)), (5, 0.2 * np.exp(-2.1j))]]]
+    t2 = [[[(0, 1.0), (3, 0.3 * np.exp(1.1j))], [(0, 0.3j), (1, 0.25)]],
+          [[(0, 0.2), (4, 0.2 * np.exp(2.0j))], [(0, 0.9), (2, 0.3 * np.exp(-0.4j)), (6, 0.15)]]]
+    for fn in ("packets_sweep.npz", "packets_cfg.npz"):
+        for name, d in load_npz(fn).items():
+            nss = int(d["nss"])
+            if name == "VHT_NDP":
+                continue
+            rx = through_multipath(dewindow(d["tx"]), t2 if nss == 2 else t1, snr_db, rng)
+            if b.add_rx(rx, n_ant=nss) >= 0:
+                meta.append((name, d))
+    return b, meta
+
+
 def cfg2_batch(n, snr_db=30.0, seed=8021200, dewin=True):
     """n VHT MCS7 1458-byte packets (BASELINE.json configs[1]): the 4 reference-TX fixture frames, each sent
     through a per-packet random-phase flat channel plus AWGN."""

@@ -56,6 +56,23 @@ def through_channel(tx, H=None, snr_db=None, rng=None, lead=0, sig_amp=0.1875):
     return rx.astype(np.complex64)
 
 
+def through_multipath(tx, taps, snr_db=None, rng=None, sig_amp=0.1875):
+    """tx: [nss][N] -> rx [n_rx][N + PAD + 160]; taps[r][s] = list of (delay in samples, complex gain): a frequency-selective
+    channel whose echoes stay inside the guard interval, so every subcarrier sees its own H[k]."""
+    tx = np.atleast_2d(tx)
+    nss, n = tx.shape
+    n_rx = len(taps)
+    rx = np.zeros((n_rx, n + PAD + 160), np.complex64)
+    for r in range(n_rx):
+        for s_ in range(nss):
+            for d, g in taps[r][s_]:
+                rx[r, d:d + n] += (np.complex64(g) * tx[s_]).astype(np.complex64)
+    if snr_db is not None:
+        sigma = np.sqrt(sig_amp ** 2 / (10 ** (snr_db / 10.0)))
+        rx = rx + awgn(rx.shape, sigma, rng)
+    return rx.astype(np.complex64)
+
+
 class Batch:
     """Accumulates packets at the signal->demod boundary into the arenas of c8p_batch_in."""
 

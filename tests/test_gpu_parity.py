@@ -404,3 +404,18 @@ def test_every_entry_point_takes_an_empty_batch():
     e.rx(pk, iq, chan)
     assert sum(len(r["pdus"]) for r in e.results(want_llr=False)) >= 40
     e.close()
+
+
+@pytest.mark.parametrize("snr", [None, 35.0, 15.0])
+def test_frequency_selective_channels_match_oracle(eng, snr):
+    from c8p_cases import multipath_batch
+    b, meta = multipath_batch(snr_db=snr, seed=6)
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    res = eng.results(want_bits=True)
+    ref = oracle_rx(pk, iq, chan)
+    n_pdu = compare(res, ref, LLR_TOL)
+    for g, o in zip(res, ref):
+        if o["out"]["n_pdu"] > 0:
+            assert np.array_equal(g["bits"], o["bits"])
+    assert n_pdu >= (40 if snr != 15.0 else 5)
