@@ -1,6 +1,7 @@
 // c8p_host_capi.cc — C entry points around the block mirror, used by the Python tests and by INTEGRATION examples:
 // an in-memory block_io (tagged item streams in, items/tags/messages out) plus a tiny run loop that calls
 // general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -18,7 +19,16 @@ struct harness : public block_io {
   size_t port0_size = 0;                        // != 0: port 0 carries items of another size (signal: sync bytes)
   size_t out_size = sizeof(float);
   size_t isz(int q) const { return (q == 0 && port0_size) ? port0_size : item_size; }
-  std::vector<std::vector<uint8_t>> in;         // per port, remaining bytes from read position
+  std::vector<std::vector<uint8_t>> in;         // per port; the unread part starts at in_pos[port] bytes (compacted now and then)
+  std::vector<size_t> in_pos;
+  size_t avail(int q) const { return (in[q].size() - in_pos[q]) / isz(q); }
+  const uint8_t* rd(int q) const { return in[q].data() + in_pos[q]; }
+  void advance(int q, size_t items)
+  {
+    in_pos[q] += items * isz(q);
+    if (in_pos[q] > (1u << 22) && in_pos[q] * 2 > in[q].size()) { in[q].erase(in[q].begin(), in[q].begin() + (long)in_pos[q]); in_pos[q] = 0; }
+  }
+  bool tags_sorted = true;
   std::vector<tag_t> in_tags;                   // port 0, absolute offsets
   uint64_t n_read = 0, n_written = 0;
   int consumed_this_call = 0;
@@ -36,8 +46,11 @@ struct harness : public block_io {
   void get_tags_in_range(std::vector<tag_t>& v, unsigned, uint64_t a, uint64_t b) override
   {
     v.clear();
-    for (const auto& t : in_tags) if (t.offset >= a && t.offset < b) v.push_back(t);
+    if (!tags_sorted) { std::stable_sort(in_tags.begin(), in_tags.end(), [](const tag_t& x, const tag_t& y) { return x.offset < y.offset; }); tags_sorted = true; }
+    auto it = std::lower_bound(in_tags.begin(), in_tags.end(), a, [](const tag_t& t, uint64_t off) { return t.offset < off; });
+    for (; it != in_tags.end() && it->offset < b; ++it) v.push_back(*it);
   }
+  void push_tag(const tag_t& t) { if (!in_tags.empty() && t.offset < in_tags.back().offset) tags_sorted = false; in_tags.push_back(t); }
   void add_item_tag(unsigned, uint64_t off, const std::string& key, const tag_value& val) override
   {
     tag_t t; t.offset = off; t.key = key; t.value = val; out_tags.push_back(t);
@@ -64,6 +77,7 @@ void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_bat
     else if (kind == 4) { h->blk = signal2::make(api, cfg); h->nports = 3; h->port0_size = 1; h->out_size = sizeof(gr_complex); h->nout = 2; }
     else { cfg.detect_items = max_batch; h->blk = detect::make(api, cfg); h->nports = 1; h->out_size = 1; }   // max_batch = items per call
     h->in.resize(h->nports);
+    h->in_pos.assign(h->nports, 0);
     h->blk->set_io(h);
     return h;
   } catch (const std::exception& e) {
@@ -81,17 +95,17 @@ void c8ph_push_items(void* p, int port, const void* data, long n_items)
 }
 void c8ph_push_tag_long(void* p, uint64_t off, const char* key, long v)
 {
-  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_long(v); static_cast<harness*>(p)->in_tags.push_back(t);
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_long(v); static_cast<harness*>(p)->push_tag(t);
 }
 void c8ph_push_tag_float(void* p, uint64_t off, const char* key, float v)
 {
-  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_float(v); static_cast<harness*>(p)->in_tags.push_back(t);
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_float(v); static_cast<harness*>(p)->push_tag(t);
 }
 void c8ph_push_tag_c32(void* p, uint64_t off, const char* key, const float* reim, int n)
 {
   std::vector<gr_complex> v(n);
   for (int i = 0; i < n; i++) v[i] = gr_complex(reim[2 * i], reim[2 * i + 1]);
-  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_c32vector(v); static_cast<harness*>(p)->in_tags.push_back(t);
+  tag_t t; t.offset = off; t.key = key; t.value = tag_value::from_c32vector(v); static_cast<harness*>(p)->push_tag(t);
 }
 
 // Run until the input is exhausted; `chunk` = max items offered per call, `nout` = noutput_items per call.
@@ -109,8 +123,8 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);   // floats per output item (byte items: widened below)
     std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
     while (idle < 4) {
-      size_t avail = h->in[0].size() / h->isz(0);
-      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->in[q].size() / h->isz(q));
+      size_t avail = h->avail(0);
+      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->avail(q));
       int n = (int)std::min<size_t>(avail, (size_t)chunk);
       int nout_call = nout;
       const bool full = !h->jitter || starved > 32;                 // after a run of fruitless small calls: one full-size call
@@ -121,18 +135,17 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       gr_vector_int nin(h->nports, n);
       if (!full && h->nports > 1) {                                 // ports rarely hold the same number of items
         const int q = (int)(h->rnd() % (uint32_t)h->nports);
-        const size_t aq = h->in[q].size() / h->isz(q);
+        const size_t aq = h->avail(q);
         nin[q] = (int)std::min<size_t>(aq, (size_t)n + h->rnd() % 97);
       }
       gr_vector_const_void_star ins(h->nports);
-      for (int q = 0; q < h->nports; q++) ins[q] = h->in[q].data();
+      for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
       gr_vector_void_star outs(1, obuf.data());
       if (h->nout == 2) outs.push_back(obuf1.data());
       h->consumed_this_call = 0;
       const int produced = h->blk->general_work(nout_call, nin, ins, outs);
       calls++;
-      for (int q = 0; q < h->nports; q++)
-        h->in[q].erase(h->in[q].begin(), h->in[q].begin() + (size_t)h->consumed_this_call * h->isz(q));
+      for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
       h->n_read += h->consumed_this_call;
       if (h->out_size == 1) {                                       // byte stream: one float per item in the capture
         const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf.data());
