@@ -77,10 +77,17 @@ def table(which, sub=0):
 
 
 class DevArray:
-    """A caller-owned device buffer (e.g. torch tensor storage): raw pointer + item count."""
+    """A caller-owned device buffer (e.g. torch tensor storage): raw pointer + item count.
+
+    The engine works on its OWN streams (unless Engine(stream=...) hands it the caller's), so the buffer's contents must be
+    complete before an engine call reads them.  If `keepalive` is a CUDA torch tensor, its producer stream is synchronised
+    here, when the DevArray is made — i.e. make the DevArray after the operations that fill the tensor have been issued."""
 
     def __init__(self, ptr, n, keepalive=None):
         self.ptr, self.n, self.keepalive = int(ptr), int(n), keepalive
+        if getattr(keepalive, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(keepalive.device).synchronize()
 
 
 class Engine:

@@ -333,7 +333,9 @@ c8p_ctx* c8p_create(const c8p_cfg* cfg);
 void     c8p_destroy(c8p_ctx* ctx);
 const char* c8p_last_error(const c8p_ctx* ctx);
 
-/* Enqueue on the ctx stream; return before the GPU work is done. */
+/* Enqueue on the ctx stream; return before the GPU work is done.  C8P_MEM_DEVICE inputs are read on the engine's streams:
+ * unless the ctx was created on the caller's stream (c8p_cfg.stream), the caller must have completed the work that fills
+ * them (stream / event synchronisation) before the call. */
 int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCHAN              */
 int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */

@@ -6,6 +6,7 @@ loop through the detect / signal / demod / decode oracle.
 GPU: c8p_tx against that oracle (coded bits identical, IQ within 1e-6 of the packet's peak: the IFFT runs in fp64 on both
 sides, only the summation order differs), then a device-resident loopback c8p_tx -> AWGN -> c8p_detect -> c8p_signal ->
 c8p_rx whose PDUs must be the transmitted MPDUs."""
+import os
 import zlib
 
 import numpy as np
@@ -509,3 +510,22 @@ def test_gpu_loopback_mu_mimo_two_stations():
         assert ok >= 0.9 * len(specs), (u, ok)
     for e in engs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_delivery_ratio_against_snr_has_the_waterfall_shape():
+    """tools/perf_pdr.py (the reference's tools/performance/perf_siso.py on the engine): per MCS the delivered count rises
+    with the SNR, nothing comes through at 0 dB, everything at 30 dB, and a denser constellation never beats a sparser one
+    by more than noise"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import perf_pdr
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    snrs = [0, 6, 12, 18, 24, 30]
+    for fmt, n_mcs in ((abi.F_L, 8), (abi.F_HT, 8), (abi.F_VHT, 9)):
+        rows = np.array(perf_pdr.run(fmt, n_mcs, 25, snrs, torch, dev))
+        assert rows[0].sum() == 0 and (rows[-1] >= 24).all(), (fmt, rows)
+        assert (np.diff(rows, axis=0) >= -2).all(), (fmt, rows)              # rising in SNR
+        assert (rows[:, :-1] - rows[:, 1:] >= -3).all(), (fmt, rows)         # falling in MCS
