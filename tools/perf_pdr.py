@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(fmt, n_mcs, packets, snrs, torch, dev, window=True, seed=1):
+def run(fmt, n_mcs, packets, snrs, torch, dev, window=True, seed=1, nss=1):
     from c8p_cases import ampdu_vht
     from c8p_testlib import abi
     from gr_ieee80211_amd import engine
@@ -32,31 +32,41 @@ def run(fmt, n_mcs, packets, snrs, torch, dev, window=True, seed=1):
     ps = ampdu_vht(mpdu) if fmt == abi.F_VHT else mpdu
     n = n_mcs * packets
     pk = np.zeros(n, abi.TX_PKT_DT)
-    pk["psdu_off"], pk["len"], pk["format"], pk["scr_seed"], pk["mult"], pk["gap"] = 0, len(ps), fmt, 93, 12.0, 1200
+    pk["psdu_off"], pk["len"], pk["format"], pk["scr_seed"], pk["gap"], pk["nss"] = 0, len(ps), fmt, 93, 1200, nss
+    pk["mult"] = 12.0 * (np.sqrt(2.0) if nss == 2 else 1.0)        # tools/pktGenExample.py:187,210
     pk["mcs"] = np.repeat(np.arange(n_mcs), packets)
     pk["flags"] = 0 if window else abi.TX_NO_WINDOW
     e_tx = engine.Engine(device=0)
     e_tx.tx(pk, np.frombuffer(ps, np.uint8), tail_gap=1200)
     e_tx.sync()
-    clean = torch.from_numpy(e_tx.fetch(abi.BUF_TX_IQ, np.complex64).view(np.float32).reshape(-1, 2)).to(dev)
+    tx = torch.from_numpy(e_tx.fetch(abi.BUF_TX_IQ, np.complex64)).to(dev)
     e_tx.close()
-    ntot = clean.shape[0]
+    if nss == 2:                                                   # flat 2x2 channel (SURVEY.md §8d cfg 3), antenna streams back to back
+        from c8p_testlib import H22
+        h = torch.tensor(H22, device=dev)
+        half = tx.numel() // 2
+        t0_, t1_ = tx[:half], tx[half:]
+        tx = torch.cat([h[0, 0] * t0_ + h[0, 1] * t1_, h[1, 0] * t0_ + h[1, 1] * t1_])
+    clean = torch.view_as_real(tx).contiguous()
+    ntot = clean.shape[0] // nss                                   # items per antenna
     want = bytes([fmt, len(mpdu) % 256, len(mpdu) // 256]) + mpdu
+    mcs_tag = 8 if (fmt == abi.F_HT and nss == 2) else 0           # HT two-stream rates are MCS 8-15
     g = torch.Generator(device=dev)
     g.manual_seed(13579)
     rows = []
     e_det, e_sig, e_rx = engine.Engine(device=0), engine.Engine(device=0), engine.Engine(device=0)
     for snr in snrs:
         sigma = float(np.sqrt(0.1875 ** 2 / (10.0 ** (snr / 10.0))))
-        noisy = (clean + torch.randn(ntot, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))).contiguous()
-        x = engine.DevArray(noisy.data_ptr(), ntot, noisy)
-        ev = e_det.detect(x)
+        noisy = (clean + torch.randn(ntot * nss, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))).contiguous()
+        x = engine.DevArray(noisy.data_ptr(), ntot * nss, noisy)
+        ev = e_det.detect(engine.DevArray(noisy.data_ptr(), ntot, noisy))     # the detector listens on antenna 0
         counts = [0] * n_mcs
         if len(ev):
             s = np.zeros(len(ev), abi.SIG_IN_DT)
             s["raw_off"][:, 0] = ev["index"]
+            s["raw_off"][:, 1] = ntot + ev["index"]
             s["n_avail"] = ntot - ev["index"]
-            s["cfo_rad"], s["snr"], s["rssi"], s["n_ant"] = ev["rad"], ev["snr"], ev["rssi"], 1
+            s["cfo_rad"], s["snr"], s["rssi"], s["n_ant"] = ev["rad"], ev["snr"], ev["rssi"], nss
             e_sig.signal(s, x)
             e_sig.sync()
             gpk = e_sig.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
@@ -67,8 +77,8 @@ def run(fmt, n_mcs, packets, snrs, torch, dev, window=True, seed=1):
                 e_rx.rx(gpk[keep], engine.DevArray(pi, bi // 8), engine.DevArray(pc, bc // 8))
                 for r in e_rx.results(want_llr=False):
                     for p in r["pdus"]:
-                        if p[:-1] == want and p[-1] < n_mcs:
-                            counts[p[-1]] += 1
+                        if p[:-1] == want and 0 <= p[-1] - mcs_tag < n_mcs:
+                            counts[p[-1] - mcs_tag] += 1
         rows.append(counts)
     for e in (e_det, e_sig, e_rx):
         e.close()
@@ -79,6 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--packets", type=int, default=100)
     ap.add_argument("--snr", type=int, nargs=3, default=[0, 31, 1])
+    ap.add_argument("--nss", type=int, default=1, help="2: two spatial streams through a flat 2x2 channel into signal2 / demod2 (perf_sumimo.py)")
     ap.add_argument("--no-window", action="store_true", help="clean OFDM symbols instead of the toolbox's half-amplitude junction samples")
     a = ap.parse_args()
     import torch
@@ -88,7 +99,9 @@ def main():
     snrs = list(range(*a.snr))
     t0 = time.time()
     for name, fmt, n_mcs in (("legacy", abi.F_L, 8), ("ht", abi.F_HT, 8), ("vht", abi.F_VHT, 9)):
-        rows = run(fmt, n_mcs, a.packets, snrs, torch, dev, window=not a.no_window)
+        if a.nss == 2 and fmt == abi.F_L:
+            continue
+        rows = run(fmt, n_mcs, a.packets, snrs, torch, dev, window=not a.no_window, nss=a.nss)
         print("%s: delivered of %d per MCS 0..%d" % (name, a.packets, n_mcs - 1))
         for snr, r in zip(snrs, rows):
             print("  %2d dB  %s" % (snr, " ".join("%3d" % c for c in r)))
