@@ -419,3 +419,23 @@ def test_frequency_selective_channels_match_oracle(eng, snr):
         if o["out"]["n_pdu"] > 0:
             assert np.array_equal(g["bits"], o["bits"])
     assert n_pdu >= (40 if snr != 15.0 else 5)
+
+
+def test_pdu_gather_over_rccl_world_of_one(eng):
+    """shard.gather_pdus with backend nccl (= RCCL) and device tensors: the collectives of the multi-GPU path on the one GPU
+    a test box has (the 2-rank logic runs under gloo in tests/test_shard_gloo.py)"""
+    import torch
+    import torch.distributed as dist
+    from gr_ieee80211_amd import shard
+    b, _ = sweep_batch(snr_db=None, seed=9)
+    pk, iq, chan = b.arrays()
+    lo, hi = shard.partition(len(pk), 1, 0)
+    eng.rx(shard.slice_batch(pk, lo, hi), iq, chan)
+    pdus = [r["pdus"] for r in eng.results(want_llr=False)]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        got = shard.gather_pdus(pdus, lo, device=torch.device("cuda", 0))
+    finally:
+        dist.destroy_process_group()
+    want = [(p, x) for p, lst in enumerate(pdus) for x in lst]
+    assert got == want and len(got) >= 40
