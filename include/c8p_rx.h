@@ -18,7 +18,8 @@
  * Conventions
  *   - plain C types only, no torch / GNU Radio / HIP types in signatures;
  *   - every pointer is caller-owned; the engine never frees or keeps caller memory past
- *     c8p_sync(); engine-owned result arenas stay valid until the next submit on that ctx;
+ *     c8p_sync(); engine-owned result arenas stay valid until their slot is reused — with the default 4 slots that is the
+ *     4th submit after theirs (c8p_ticket / c8p_select), with a caller-provided stream the next submit;
  *   - errors are negative return codes, never exceptions or abort();
  *   - one ctx per block instance / per thread; a ctx is not internally locked;
  *   - there is no CPU fallback: c8p_create() fails if no HIP device is usable.
