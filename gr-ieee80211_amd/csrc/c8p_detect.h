@@ -6,7 +6,7 @@
 //                  no re-summation.  HBM-bound: 8 B read + 4 B (ac) [+ 8 B conj when kept] written per sample.
 //                  The same kernel reduces its 1984 ac values to the tile summary of the plateau state machine
 //                  (whole tile above the threshold? trailing run: start, maximum).
-//   k_trig_carry   one workgroup: exclusive scan of the tile summaries = the run that is open at every tile start
+//   (tile carry)   every k_trig_apply workgroup looks back over the tile summaries for the run open at its tile start
 //   k_trig_apply   per sample: "ac > 0.3" and "new maximum of this plateau" (trigger bit 0x02) by a segmented
 //                  max-scan seeded with the carry; every plateau of >= 21 samples is appended to a candidate list
 //   (host)         trigger_impl's countdown logic over the (few) candidates, sync_impl's IDLE/SYNC alternation
@@ -211,26 +211,41 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
 
 // ------------------------------------------------------------------------------------------------ trigger scan
 // one workgroup of 1024 threads: carry[t] = combine(init, summ[0..t-1]); carry[ntile] = the state after the last tile
-__global__ __launch_bounds__(1024) void k_trig_carry(const TrigSeg* __restrict__ summ, TrigSeg* __restrict__ carry, int ntile, TrigSeg init)
+__device__ __forceinline__ TrigSeg seg_bcast(const TrigSeg& v, int src)
 {
-  __shared__ TrigSeg sh[16];
-  const int tid = threadIdx.x;
-  const int per = (ntile + 1023) / 1024;
-  const int lo = min(tid * per, ntile), hi = min(lo + per, ntile);
-  TrigSeg s = seg_identity();
-  for (int t = lo; t < hi; t++) s = seg_combine(s, summ[t]);
-  TrigSeg total;
-  s = seg_combine(init, seg_block_exclusive(s, sh, total));
-  for (int t = lo; t < hi; t++) { carry[t] = s; s = seg_combine(s, summ[t]); }
-  if (tid == 0) carry[ntile] = seg_combine(init, total);
+  TrigSeg r;
+  r.all = __shfl(v.all, src, 64);
+  r.tmax = __shfl(v.tmax, src, 64);
+  const int lo = __shfl((int)(unsigned)(unsigned long long)v.tstart, src, 64);
+  const int hi = __shfl((int)(unsigned)((unsigned long long)v.tstart >> 32), src, 64);
+  r.tstart = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  return r;
+}
+// tile = the 1984 samples one k_presiso workgroup wrote; thread = 8 consecutive samples (threads 248..255 idle)
+// The plateau state at the start of a tile = the combination of everything before it.  A tile that is not entirely above the
+// threshold fixes that state by itself, so instead of a global scan kernel every workgroup looks BACK over the tile
+// summaries k_presiso wrote: 64 tiles per step (lane = tile, coalesced), until a chunk contains such a tile or the start of
+// the segment (`init`) is reached.  Plateaus are a few hundred samples long: one step in practice.
+__device__ __forceinline__ TrigSeg trig_lookback(const TrigSeg* __restrict__ summ, long long tile, const TrigSeg& init)
+{
+  const int lane = lane_id();
+  TrigSeg acc = seg_identity();                       // tiles [base, tile)
+  for (long long base = tile; ; base -= 64) {
+    if (base <= 0) return seg_combine(init, acc);
+    const long long t = base - 64 + lane;
+    const TrigSeg chunk = seg_bcast(seg_wave_inclusive(t >= 0 ? summ[t] : seg_identity()), 63);
+    acc = seg_combine(chunk, acc);
+    if (!chunk.all) return acc;                        // independent of anything earlier (seg_combine with R.all == 0)
+  }
 }
 
-// tile = the 1984 samples one k_presiso workgroup wrote; thread = 8 consecutive samples (threads 248..255 idle)
-__global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac, unsigned long long n, const TrigSeg* __restrict__ carry,
+__global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac, unsigned long long n, const TrigSeg* __restrict__ summ,
+                                                    TrigSeg init, TrigSeg* __restrict__ fin,
                                                     uint8_t* __restrict__ trig, TrigCand* __restrict__ cand,
                                                     unsigned int* __restrict__ n_cand, unsigned int cap)
 {
   __shared__ TrigSeg sh[16];
+  __shared__ TrigSeg s_cin;
   float a[8];
   const bool live = threadIdx.x < C8P_DET_TILE / 8;
   const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
@@ -246,7 +261,15 @@ __global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac
 #pragma unroll
     for (int j = 0; j < 8; j++) if ((unsigned long long)(n0 + j) < n) mine = seg_combine(mine, seg_of_sample(a[j], n0 + j));
   }
-  const TrigSeg cin = carry[blockIdx.x];
+  if (threadIdx.x < 64) {
+    const TrigSeg c0 = trig_lookback(summ, (long long)blockIdx.x, init);
+    if (threadIdx.x == 0) {
+      s_cin = c0;
+      if (blockIdx.x == gridDim.x - 1) *fin = seg_combine(c0, summ[blockIdx.x]);      // the state at the end of the segment
+    }
+  }
+  __syncthreads();
+  const TrigSeg cin = s_cin;
   {
     // idle air: nothing in the tile is above the threshold and no plateau is open at its start -> all bytes 0, no scan
     bool anyab = false;

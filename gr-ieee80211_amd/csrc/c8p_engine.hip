@@ -672,9 +672,9 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   }
   {
     KTimer kt(c, C8P_K_TRIGGER);
-    hipLaunchKernelGGL(k_trig_carry, dim3(1), dim3(1024), 0, S.stream, (const TrigSeg*)S.d_det_summ.p, (TrigSeg*)S.d_det_carry.p, ntile, init);
     hipLaunchKernelGGL(k_trig_apply, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n,
-                       (const TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
+                       (const TrigSeg*)S.d_det_summ.p, init, (TrigSeg*)S.d_det_carry.p + ntile,
+                       (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
   }
   HIPCHK(c, hipGetLastError());
   // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a

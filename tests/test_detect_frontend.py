@@ -281,3 +281,35 @@ def test_gpu_detect_streaming_equals_one_shot(seed, chunks):
     bad = np.nonzero((gtrig[:commit] & 2) != (trig[:commit] & 2))[0]
     assert len(bad) <= 3 and all(near_tie(ac, i) for i in bad), (bad[:10], commits)   # latch marks: identical up to float near-ties
     assert commit >= len(x) - 400
+
+
+@pytest.mark.gpu
+def test_gpu_detect_plateaus_spanning_hundreds_of_tiles():
+    """a carrier that repeats every 16 samples keeps the autocorrelation above the threshold for 400 000 samples (200 tiles):
+    the per-tile look-back of k_trig_apply walks several 64-tile chunks of entirely-above tiles, then reaches the start of
+    the segment (`init`); a second, shorter plateau and ordinary packets follow.  Marks, triggers and events equal the oracle's,
+    one-shot and cut into segments."""
+    from gr_ieee80211_amd import engine
+    o = oracle()
+    rng = np.random.default_rng(3)
+    per = (rng.normal(size=16) + 1j * rng.normal(size=16)) * 0.2
+    base, _, _ = stream(NAMES[:3], CFOS[:3], seed=5)
+    noise = lambda k: 0.004 * (rng.normal(size=k) + 1j * rng.normal(size=k))
+    x = np.concatenate([np.tile(per, 25000) + noise(400000), noise(3000), np.tile(per, 9000) + noise(144000), noise(2000), base]).astype(np.complex64)
+    ev, ac, cj, trig = o.detect(x)
+    assert (ac[100:399000] > 0.3).all()
+    eng = engine.Engine(device=0)
+    gev = eng.detect(x, keep=True)
+    gtr = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+    assert np.array_equal(gtr & 2, trig & 2) and np.array_equal(gtr & 1, trig & 1)
+    assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"]) and len(ev) >= 3
+    # the same stream in three segments, the first cut deep inside the long plateau
+    end, commit, state, got = 0, 0, None, []
+    for cut in (250000, 470000, len(x)):
+        lo = max(commit - abi.DET_HIST, 0)
+        e2, state, c2 = eng.detect(x[lo:cut], n_hist=commit - lo, state=state, stream=True)
+        for e in e2:
+            got.append(int(e["index"]) + lo)
+        commit = lo + c2
+    assert got == [int(i) for i in ev["index"]]
+    eng.close()
