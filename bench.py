@@ -47,14 +47,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # any torch.distributed.run launch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)                         # before the process group: RCCL binds the communicator to the current device
+    dev = torch.device("cuda", local)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dist.init_process_group(backend="nccl")
 
     from c8p_cases import cfg2_batch, cfg2_workload_on_device
     from c8p_testlib import abi
