@@ -101,6 +101,11 @@ def main():
         if r["pdus"] and not args.no_check:
             assert r["pdus"] == [e], "PDU mismatch"
             n_ok += 1
+    # clock pre-roll (untimed, independent of --warmup): the PDU check above leaves the GPU idle for ~50 ms and its shader clock
+    # needs some tens of ms of load to come back up; a short --steps run would otherwise measure the ramp
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.15:
+        eng.rx(pk, iq_dev, chan_dev)
     for _ in range(args.warmup):
         eng.rx(pk, iq_dev, chan_dev)
     eng.sync()
