@@ -200,6 +200,11 @@ void c8po_bcc_encode(const uint8_t* in, uint8_t* out, int len)
   }
 }
 
+#ifndef C8PO_BUILD_FLAGS
+#define C8PO_BUILD_FLAGS "unknown"
+#endif
+const char* c8po_build_flags(void) { return C8PO_BUILD_FLAGS; }
+
 uint32_t c8po_crc32(const uint8_t* p, int n)
 {
   c8po_init();

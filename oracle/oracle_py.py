@@ -27,8 +27,13 @@ def lib():
         L.c8po_cabsf.restype = C.c_float
         L.c8po_crc32.restype = C.c_uint32
         L.c8po_rx_batch.restype = C.c_long
+        L.c8po_build_flags.restype = C.c_char_p
         _LIB = L
     return _LIB
+
+
+def build_flags():
+    return lib().c8po_build_flags().decode()
 
 
 def _p(a):
