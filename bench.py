@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--fixture-workload", action="store_true", help="replicate the 4 committed reference-TX frames (host-generated) "
                     "instead of generating 4096 distinct packets on the device with c8p_tx")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the PCIe-inclusive and block-chain legs (extra keys in the JSON line)")
     ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
 
@@ -194,6 +195,22 @@ def main():
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
+        if not args.no_host_legs and world == 1:
+            # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
+            out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("bench_blocks", os.path.join(ROOT, "tools", "bench_blocks.py"))
+            bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
+            r = bb.run(2048, batches=(256,), quiet=True)
+            out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
+            out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
+            out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
+            out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
+            out["host_legs_note"] = ("pcie_inclusive: c8p_rx from pinned host arenas, PDUs + results fetched back, batch i+1 submitted "
+                                     "before batch i is fetched (c8p_ticket / c8p_select); block_chain: the gr::ieee80211::demod -> decode "
+                                     "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
+                                     "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
+                                     "over 2048 packets, max_batch 256, %d of 2048 PDUs correct in the worst leg" % r["pdus_ok_min"])
         if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
                 iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
@@ -276,6 +293,40 @@ def pmc_traffic(dom):
     per = {n: hbm(n) for n in names.values()}
     whole = sum(v for v in per.values() if v) if all(per.values()) else None
     return per[names[dom]], os.path.relpath(best, ROOT), whole
+
+
+def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
+    """PCIe-inclusive rate of the same batch (tools/pcie_rate.py's pipelined case): IQ + chan in pinned host memory, c8p_rx
+    copies them in, per-packet results and the PDU arena are fetched back; submit i+1, then fetch i."""
+    import ctypes
+    from c8p_testlib import abi
+    from gr_ieee80211_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    iq_pin = torch.empty(2 * iq_dev.n, dtype=torch.float32).pin_memory()
+    ch_pin = torch.empty(2 * chan_dev.n, dtype=torch.float32).pin_memory()
+    torch.cuda.synchronize(dev)
+    hip.hipMemcpy(ctypes.c_void_p(iq_pin.data_ptr()), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(8 * iq_dev.n), ctypes.c_int(2))
+    hip.hipMemcpy(ctypes.c_void_p(ch_pin.data_ptr()), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(8 * chan_dev.n), ctypes.c_int(2))
+    a, c = iq_pin.numpy().view(np.complex64), ch_pin.numpy().view(np.complex64)
+    eng = engine.Engine(device=local)
+    for _ in range(3):
+        eng.rx(pk, a, c); eng.sync()
+    t = time.perf_counter()
+    prev = cur = None
+    outs = None
+    for i in range(steps + 1):
+        if i < steps:
+            eng.rx(pk, a, c)
+            cur = eng.ticket()
+        if prev is not None:
+            eng.select(prev)
+            outs = eng.outs()
+            eng.fetch(abi.BUF_PDU, np.uint8)
+        prev = cur
+    dt = time.perf_counter() - t
+    eng.close()
+    assert int((outs["n_pdu"] == 1).sum()) >= 0.99 * len(pk)
+    return len(pk) * steps / dt
 
 
 def frontend_detect(torch, dev, local, n_target=32 << 20):

@@ -25,6 +25,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.c8ph_create.restype = C.c_void_p
         L.c8ph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.c8ph_create_ex.restype = C.c_void_p
+        L.c8ph_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.c8ph_run_chain.restype = C.c_long
+        L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
         L.c8ph_push_items.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
         L.c8ph_push_tag_long.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_long]
@@ -33,6 +37,7 @@ def lib():
         L.c8ph_run.restype = C.c_long
         L.c8ph_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.c8ph_set_jitter.argtypes = [C.c_void_p, C.c_ulonglong]
+        L.c8ph_set_capture.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_error.restype = C.c_char_p
         L.c8ph_error.argtypes = [C.c_void_p]
         for f in ("c8ph_out_count", "c8ph_tag_count", "c8ph_msg_count", "c8ph_dbg_count"):
@@ -52,11 +57,12 @@ def lib():
 
 
 class Block:
-    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True):
+    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None):
+        """fused: batching_cfg::fused (None = its default, the environment variable C8P_FUSED)"""
         self.L = lib()
         err = C.create_string_buffer(512)
-        self.h = self.L.c8ph_create(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
-                                    int(flush_when_idle), err, 512)
+        self.h = self.L.c8ph_create_ex(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
+                                       int(flush_when_idle), -1 if fused is None else int(fused), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
         self.kind = kind
@@ -79,6 +85,10 @@ class Block:
         else:
             v = np.ascontiguousarray(value, np.complex64)
             self.L.c8ph_push_tag_c32(self.h, offset, k, v.ctypes.data, len(v))
+
+    def set_capture(self, on):
+        """off: run() counts the produced items instead of keeping them (throughput measurements)"""
+        self.L.c8ph_set_capture(self.h, int(on))
 
     def set_jitter(self, seed):
         """random item counts per general_work call from now on (0 = off): what a busy scheduler hands a block"""
@@ -135,6 +145,14 @@ class Block:
         return res
 
 
+def run_chain(a, b, chunk=1 << 16, nout=1 << 16):
+    """a -> b with each block on its own thread, as the GNU Radio scheduler runs a flowgraph (a's items are not captured)"""
+    n = a.L.c8ph_run_chain(a.h, b.h, chunk, nout)
+    if n < 0:
+        raise RuntimeError((a.L.c8ph_error(a.h) or b"").decode() + " | " + (b.L.c8ph_error(b.h) or b"").decode())
+    return n
+
+
 def feed_signal(blk, sync_events, raws):
     """sync byte stream (port 0, flags tagged rad / snr / rssi as sync_impl.cc:124-141 does) + raw antenna streams"""
     n = len(raws[0])
@@ -148,9 +166,10 @@ def feed_signal(blk, sync_events, raws):
         blk.push_items(1 + a, np.ascontiguousarray(x, np.complex64))
 
 
-def feed_demod(blk, pk, iq, chan):
-    """Lay a batch out as the tagged stream signal/signal2 would produce: packets back to back."""
-    pos = 0
+def feed_demod(blk, pk, iq, chan, base=0):
+    """Lay a batch out as the tagged stream signal/signal2 would produce: packets back to back.  base = items already pushed
+    into the block (a second pass over the same block).  Returns the number of items pushed per port."""
+    pos = base
     for p in pk:
         n = int(p["n_items"])
         for a in range(int(p["n_ant"])):
@@ -159,3 +178,4 @@ def feed_demod(blk, pk, iq, chan):
         blk.push_tag(pos, "seq", int(p["seq"])); blk.push_tag(pos, "mcs", int(p["lsig_mcs"])); blk.push_tag(pos, "len", int(p["lsig_len"]))
         blk.push_tag(pos, "nsamp", int(p["lsig_nsamp"])); blk.push_tag(pos, "chan", chan[int(p["chan_off"]):int(p["chan_off"]) + 64])
         pos += n
+    return pos - base

@@ -334,9 +334,12 @@ struct Plan {
 // 256-byte block per 30 steps (8.5 bytes per step + the partial last block)
 static uint32_t surv_slots(uint32_t tcap) { return tcap + 17u; }
 
+// PDU area of one packet.  A published (sub)frame of len bytes costs a record of len + 6 bytes ({u16 len}{format, len_lo, len_hi,
+// MPDU, mcs}) and consumed at least len + 4 bytes of the decoded stream (delimiter + MPDU padded to 4), at least 8 of them: the
+// records of an A-MPDU made of many tiny subframes exceed the stream by 2 bytes per subframe, at most tcap / 64 subframes.
 static uint32_t pdu_cap_for(uint32_t tcap)
 {
-  uint32_t pcap = tcap / 8u + 16u;
+  uint32_t pcap = tcap / 8u + tcap / 32u + 16u;
   if (pcap < C8P_NDP_BLOB_BYTES + 5u) pcap = C8P_NDP_BLOB_BYTES + 5u;
   return (pcap + 15u) & ~15u;
 }
@@ -1001,6 +1004,44 @@ extern "C" int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint
   drain_events(c);
   return C8P_OK;
 }
+
+// c8p_fetch without the stream synchronisation: the copy is only enqueued behind the selected submit's kernels; dst should be
+// pinned (c8p_host_alloc), otherwise the runtime stages the copy and the call blocks anyway.  Complete after c8p_wait(ticket)
+// of that submit or c8p_sync().
+extern "C" int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
+{
+  if (!c || which < 0 || which >= C8P_BUF_COUNT || !dst) return C8P_EINVAL;
+  if (offset + bytes > c->s->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->s->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->s->stream));
+  return C8P_OK;
+}
+
+// Wait for ONE submit: its uploads, kernels and the c8p_fetch_async copies enqueued behind it (c8p_sync waits for all slots).
+extern "C" int c8p_wait(c8p_ctx* c, int ticket)
+{
+  if (!c) return C8P_EINVAL;
+  for (Slot& sl : c->slots)
+    if (sl.ticket != 0 && (int)(sl.ticket & 0x7fffffffu) == ticket) {
+      HIPCHK(c, hipSetDevice(c->device));
+      HIPCHK(c, hipStreamSynchronize(sl.stream));
+      drain_events(c);
+      return C8P_OK;
+    }
+  c->err = "ticket is not resident any more (its slot has been reused) or was never issued";
+  return C8P_ERANGE;
+}
+
+// Pinned host memory for the caller's staging arenas: a C8P_MEM_HOST submit reads them with asynchronous copies (they must stay
+// untouched until c8p_wait / c8p_sync), c8p_fetch_async writes into them.  Plain malloc memory works everywhere too, at
+// pageable-copy speed and without overlap.
+extern "C" void* c8p_host_alloc(uint64_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void c8p_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int c8p_kernel_time(c8p_ctx* c, int kernel, double* total_ms, int64_t* launches)
 {

@@ -8,13 +8,21 @@
 //     one (an NDP: 1024 zero items + "mu2x1chan"); rejected packets emit nothing;
 //   * decode publishes pmt::cons(dict{"len"}, blob) on port "out" per FCS-correct (sub)frame and prints the
 //     reference's debug lines when ifdebug (decode_impl.cc:377-411, 456-509 — scraped by tools/performance).
-// What differs is *when*: packets are processed a batch at a time, so outputs trail inputs by up to one batch.
+// What differs is *when*: packets are processed a batch at a time, so outputs trail inputs by up to one batch (two while
+// full batches follow each other back to back: batch i+1 is submitted before batch i is collected, so that its upload and
+// kernels overlap the download of batch i; a partial batch submitted because the input ran dry is collected at once).
+// Staging arenas are pinned (c8p_host_alloc): the scheduler's buffers are pageable and only valid during general_work.
 #include "c8p_blocks.h"
 
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 
 namespace gr {
@@ -40,6 +48,13 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.sync = (int (*)(c8p_ctx*))sym("c8p_sync");
   a.buffer = (const void* (*)(c8p_ctx*, int, uint64_t*))sym("c8p_buffer");
   a.fetch = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch");
+  a.rx = (int (*)(c8p_ctx*, const c8p_batch_in*))sym("c8p_rx");
+  a.ticket = (int (*)(c8p_ctx*))sym("c8p_ticket");
+  a.select = (int (*)(c8p_ctx*, int))sym("c8p_select");
+  a.wait = (int (*)(c8p_ctx*, int))sym("c8p_wait");
+  a.fetch_async = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch_async");
+  a.host_alloc = (void* (*)(uint64_t))sym("c8p_host_alloc");
+  a.host_free = (void (*)(void*))sym("c8p_host_free");
   return a;
 }
 
@@ -48,6 +63,54 @@ static c8p_api default_api()
   const char* e = getenv("C8P_RX_LIB");
   return load_c8p_api(e ? e : "libc8p_rx.so");
 }
+
+bool batching_cfg::default_fused()
+{
+  const char* e = getenv("C8P_FUSED");
+  return e && e[0] == '1';
+}
+
+// Fused mode hand-over (batching_cfg::fused): what `demod` learned about a packet from c8p_rx, parked until `decode` meets
+// the "c8p_fused" tag that names it.  Both mirrors live in the flowgraph's process; the tag travels through the scheduler.
+struct fused_pkt {
+  std::vector<pdu_t> pdus;
+  int n_crc_fail = 0;
+};
+static std::mutex g_fused_mu;
+static std::map<long, fused_pkt> g_fused;
+static std::atomic<long> g_fused_next{1};
+
+// growable array in pinned host memory (uninitialised growth: no zero fill of tens of megabytes per batch)
+template <typename T> class pinned_vec
+{
+public:
+  explicit pinned_vec(const c8p_api* a) : d_a(a) {}
+  pinned_vec(const pinned_vec&) = delete;
+  pinned_vec& operator=(const pinned_vec&) = delete;
+  ~pinned_vec() { if (d_p) d_a->host_free(d_p); }
+  T* data() { return d_p; }
+  const T* data() const { return d_p; }
+  size_t size() const { return d_n; }
+  bool empty() const { return d_n == 0; }
+  void clear() { d_n = 0; }
+  void reserve(size_t want)
+  {
+    if (want <= d_cap) return;
+    const size_t nc = std::max<size_t>(std::max(want, d_cap * 2), 1u << 14);
+    T* q = static_cast<T*>(d_a->host_alloc(nc * sizeof(T)));
+    if (!q) throw std::runtime_error("c8p_host_alloc failed");
+    if (d_n) memcpy(static_cast<void*>(q), static_cast<const void*>(d_p), d_n * sizeof(T));
+    if (d_p) d_a->host_free(d_p);
+    d_p = q; d_cap = nc;
+  }
+  T* grow(size_t extra) { reserve(d_n + extra); T* r = d_p + d_n; d_n += extra; return r; }
+  void resize_uninit(size_t n) { reserve(n); d_n = n; }
+
+private:
+  const c8p_api* d_a;
+  T* d_p = nullptr;
+  size_t d_n = 0, d_cap = 0;
+};
 
 static const tag_value* find_tag(const std::vector<tag_t>& tags, const char* key)
 {
@@ -65,6 +128,10 @@ static float tag_float(const std::vector<tag_t>& tags, const char* key, float df
   return v ? (v->kind == tag_value::LONG ? (float)v->l : v->f) : dflt;
 }
 
+typedef std::chrono::steady_clock::time_point tick_t;
+static tick_t now_tick() { return std::chrono::steady_clock::now(); }
+static long us_since(tick_t t) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(now_tick() - t).count(); }
+
 class engine_holder
 {
 public:
@@ -77,9 +144,9 @@ public:
     if (!d_ctx) throw std::runtime_error("c8p_create failed: no usable HIP device (there is no CPU fallback)");
   }
   ~engine_holder() { if (d_ctx) d_api.destroy(d_ctx); }
-  void check(int rc)
+  void check(int rc, const char* what = "")
   {
-    if (rc != C8P_OK) throw std::runtime_error(std::string("c8p error: ") + d_api.last_error(d_ctx));
+    if (rc != C8P_OK) throw std::runtime_error(std::string("c8p error ") + std::to_string(rc) + " " + what + ": " + d_api.last_error(d_ctx));
   }
   template <typename T> std::vector<T> fetch_all(int which)
   {
@@ -99,7 +166,7 @@ class demod_front : public demod, public demod2
 {
 public:
   demod_front(int nports, int mupos, int mugid, const c8p_api& api, const batching_cfg& cfg)
-      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid)
+      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)}
   {
   }
 
@@ -115,6 +182,7 @@ public:
     for (int p = 1; p < d_nports; p++) nproc = std::min(nproc, ninput_items[p]);
     int used = 0;
     while (used < nproc) {
+      stage& st = d_st[d_fill];
       if (d_state == S_RDTAG) {
         std::vector<tag_t> tags;
         const uint64_t pos = d_io->nitems_read(0) + used;
@@ -128,56 +196,149 @@ public:
         d_cur.lsig_nsamp = (int32_t)tag_long(tags, "nsamp", -1);
         d_cur.n_ant = (uint8_t)d_nports; d_cur.mupos = (uint8_t)(d_mupos ? 1 : 0);
         d_cur.n_items = (uint32_t)std::max(d_cur.lsig_nsamp, 0) + 320u;     // demod_impl.cc:92
-        d_cur.chan_off = (uint32_t)d_chan.size();
+        d_cur.chan_off = (uint32_t)st.chan.size();
         const tag_value* ch = find_tag(tags, "chan");
-        for (int i = 0; i < 64; i++) d_chan.push_back(ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f));
+        gr_complex* c = st.chan.grow(64);
+        for (int i = 0; i < 64; i++) c[i] = ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f);
         for (int p = 0; p < d_nports; p++) {
-          d_cur.iq_off[p] = d_iq.size();
-          d_iq.resize(d_iq.size() + d_cur.n_items);
+          d_cur.iq_off[p] = st.iq.size();
+          st.iq.grow(d_cur.n_items);
         }
         d_have = 0;
         d_state = S_COLLECT;
       }
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.n_items - d_have);
       for (int p = 0; p < d_nports; p++)
-        memcpy(&d_iq[d_cur.iq_off[p] + d_have], static_cast<const gr_complex*>(input_items[p]) + used, sizeof(gr_complex) * (size_t)take);
+        memcpy(static_cast<void*>(st.iq.data() + d_cur.iq_off[p] + d_have), static_cast<const gr_complex*>(input_items[p]) + used,
+               sizeof(gr_complex) * (size_t)take);
       d_have += take; used += take;
       if (d_have == (int)d_cur.n_items) {
-        d_pk.push_back(d_cur);
+        if (st.pk.empty()) st.t_first = now_tick();
+        st.pk.push_back(d_cur);
         d_state = S_RDTAG;
-        if ((int)d_pk.size() >= d_eng.d_cfg.max_batch) submit();
+        if ((int)st.pk.size() >= d_eng.d_cfg.max_batch) submit(false);
       }
     }
-    if (d_eng.d_cfg.flush_when_idle && d_state == S_RDTAG && !d_pk.empty()) submit();
+    if (d_eng.d_cfg.flush_when_idle) age_check();
     d_io->consume_each(used);
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
-  void flush() override
+  void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    if (!d_pk.empty()) submit();
+    if (!d_st[d_fill].pk.empty()) submit(true);
+    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+  }
+
+  // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us (asynchronously: its
+  // predecessor is collected, it stays in flight); a batch in flight is collected once it is that old
+  void age_check()
+  {
+    const long w = d_eng.d_cfg.max_wait_us;
+    if (!d_st[d_fill].pk.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
+    stage& fl = d_st[d_fill ^ 1];
+    if (fl.ticket && us_since(fl.t_submit) >= w) collect(fl);
   }
 
 private:
+  struct result {             // downloaded arenas of one batch, shared by its packets until they have been drained
+    explicit result(const c8p_api* a) : llr(a) {}
+    pinned_vec<float> llr;
+  };
+  struct stage {              // one batch being gathered / in flight: its arenas must stay untouched until the submit has completed
+    explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a) {}
+    pinned_vec<gr_complex> iq, chan;
+    std::vector<c8p_pkt_in> pk;
+    int ticket = 0;
+    tick_t t_first, t_submit;   // when the first packet was complete / when the batch was submitted
+    pinned_vec<c8p_pkt_tags> tags;      // downloads enqueued at submit time, right behind the kernels: they run while the
+    std::shared_ptr<result> res;        // next batch is being gathered; collect() only waits
+  };
   struct out_pkt {
     std::vector<std::pair<std::string, tag_value>> tags;
-    std::vector<float> llr;
-    size_t sent = 0;
+    std::shared_ptr<result> res;
+    const float* llr = nullptr;   // null (fused mode): the items are produced, their values are not written
+    size_t n = 0, sent = 0;
   };
 
-  void submit()
+  std::shared_ptr<result> acquire()
   {
+    for (auto& r : d_pool) if (r.use_count() == 1) return r;
+    d_pool.push_back(std::make_shared<result>(&d_eng.d_api));
+    return d_pool.back();
+  }
+
+  // submit the batch being gathered; while full batches follow each other (last = false) the previous one is collected
+  // only now, after its successor has been enqueued
+  void submit(bool last)
+  {
+    stage& st = d_st[d_fill];
+    // a packet that is still being received lives at the end of this stage's arenas: it moves to the next stage
+    std::vector<gr_complex> part_iq[2], part_chan;
+    if (d_state == S_COLLECT) {
+      for (int p = 0; p < d_nports; p++) part_iq[p].assign(st.iq.data() + d_cur.iq_off[p], st.iq.data() + d_cur.iq_off[p] + d_have);
+      part_chan.assign(st.chan.data() + d_cur.chan_off, st.chan.data() + d_cur.chan_off + 64);
+    }
     c8p_batch_in b;
     memset(&b, 0, sizeof(b));
-    b.n_pkt = (int32_t)d_pk.size(); b.mem = C8P_MEM_HOST; b.pkts = d_pk.data();
-    b.iq = reinterpret_cast<const c8p_c32*>(d_iq.data()); b.n_iq = d_iq.size();
-    b.chan = reinterpret_cast<const c8p_c32*>(d_chan.data()); b.n_chan = d_chan.size();
-    d_eng.check(d_eng.d_api.demod(d_eng.d_ctx, &b));
-    d_eng.check(d_eng.d_api.sync(d_eng.d_ctx));
-    std::vector<c8p_pkt_tags> tags = d_eng.fetch_all<c8p_pkt_tags>(C8P_BUF_TAGS);
-    std::vector<float> llr = d_eng.fetch_all<float>(C8P_BUF_LLR);
-    std::vector<gr_complex> mu = d_eng.fetch_all<gr_complex>(C8P_BUF_MUCHAN);
-    for (size_t p = 0; p < d_pk.size(); p++) {
+    b.n_pkt = (int32_t)st.pk.size(); b.mem = C8P_MEM_HOST; b.pkts = st.pk.data();
+    b.iq = reinterpret_cast<const c8p_c32*>(st.iq.data()); b.n_iq = st.iq.size();
+    b.chan = reinterpret_cast<const c8p_c32*>(st.chan.data()); b.n_chan = st.chan.size();
+    d_eng.check(d_eng.d_cfg.fused ? d_eng.d_api.rx(d_eng.d_ctx, &b) : d_eng.d_api.demod(d_eng.d_ctx, &b));
+    st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
+    st.t_submit = now_tick();
+    {
+      const c8p_api& A = d_eng.d_api;
+      st.tags.resize_uninit(st.pk.size());
+      d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_TAGS, st.tags.data(), 0, st.pk.size() * sizeof(c8p_pkt_tags)), "tags");
+      st.res = acquire();
+      st.res->llr.clear();
+      if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use)
+        uint64_t bytes = 0;
+        A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
+        st.res->llr.resize_uninit(bytes / sizeof(float));
+        if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, st.res->llr.data(), 0, bytes), "llr");
+      }
+    }
+    stage& prev = d_st[d_fill ^ 1];
+    if (prev.ticket) collect(prev);
+    if (last) collect(st);
+    else d_fill ^= 1;
+    if (d_state == S_COLLECT) {
+      stage& nx = d_st[d_fill];
+      d_cur.chan_off = (uint32_t)nx.chan.size();
+      memcpy(static_cast<void*>(nx.chan.grow(64)), part_chan.data(), 64 * sizeof(gr_complex));
+      for (int p = 0; p < d_nports; p++) {
+        d_cur.iq_off[p] = nx.iq.size();
+        gr_complex* dst = nx.iq.grow(d_cur.n_items);
+        if (d_have) memcpy(static_cast<void*>(dst), part_iq[p].data(), sizeof(gr_complex) * (size_t)d_have);
+      }
+    }
+  }
+
+  void collect(stage& st)
+  {
+    const c8p_api& A = d_eng.d_api;
+    c8p_ctx* ctx = d_eng.d_ctx;
+    const size_t n = st.pk.size();
+    d_eng.check(A.wait(ctx, st.ticket), "wait");                 // kernels + the downloads enqueued behind them
+    d_eng.check(A.select(ctx, st.ticket), "select");
+    const c8p_pkt_tags* tags = st.tags.data();
+    const bool fused = d_eng.d_cfg.fused;
+    std::shared_ptr<result> res = st.res;
+    st.res.reset();
+    std::vector<c8p_pkt_out> outs;
+    std::vector<uint8_t> pdu;
+    uint64_t pdu_base = 0;
+    if (fused) {
+      outs.resize(n);
+      d_eng.check(A.fetch(ctx, C8P_BUF_OUT, outs.data(), 0, n * sizeof(c8p_pkt_out)));
+      uint64_t lo = ~0ull, hi = 0;
+      for (const c8p_pkt_out& o : outs)
+        if (o.n_pdu > 0) { lo = std::min<uint64_t>(lo, o.pdu_off); hi = std::max<uint64_t>(hi, o.pdu_off + o.pdu_bytes); }
+      if (hi > lo) { pdu.resize(hi - lo); pdu_base = lo; d_eng.check(A.fetch(ctx, C8P_BUF_PDU, pdu.data(), lo, hi - lo)); }
+    }
+    for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = tags[p];
       if (t.status != C8P_ST_OK) continue;          // DEMOD_S_CLEAN without tags: nothing reaches decode
       out_pkt o;
@@ -188,14 +349,33 @@ private:
       F("rssi", t.rssi);
       L("format", t.format); L("mcs", t.mcs); L("len", t.len); L("cr", t.cr); L("ampdu", t.ampdu); L("trellis", t.trellis);
       if (t.is_ndp) {
-        std::vector<gr_complex> c(mu.begin() + 128 * p, mu.begin() + 128 * p + 128);
+        std::vector<gr_complex> c(128);
+        d_eng.check(A.fetch(ctx, C8P_BUF_MUCHAN, c.data(), 128 * p * sizeof(gr_complex), 128 * sizeof(gr_complex)));
         o.tags.push_back({"mu2x1chan", tag_value::from_c32vector(c)});
       }
       L("total", t.total);
-      o.llr.assign(llr.begin() + t.llr_off, llr.begin() + t.llr_off + t.total);
+      o.n = (size_t)std::max(t.total, 0);
+      if (!fused) { o.res = res; o.llr = res->llr.data() + t.llr_off; }
+      else {
+        fused_pkt f;
+        const c8p_pkt_out& po = outs[p];
+        size_t off = (size_t)(po.pdu_off - pdu_base);
+        for (int k = 0; k < po.n_pdu; k++) {
+          const int len = pdu[off] | (pdu[off + 1] << 8);
+          pdu_t m;
+          m.len = len;
+          m.blob.assign(pdu.begin() + (std::ptrdiff_t)off + 2, pdu.begin() + (std::ptrdiff_t)off + 2 + len);
+          off += 2 + (size_t)len;
+          f.pdus.push_back(std::move(m));
+        }
+        f.n_crc_fail = po.n_crc_fail;
+        const long id = g_fused_next.fetch_add(1);
+        { std::lock_guard<std::mutex> g(g_fused_mu); g_fused[id] = std::move(f); }
+        L("c8p_fused", id);
+      }
       d_outq.push_back(std::move(o));
     }
-    d_pk.clear(); d_iq.clear(); d_chan.clear();
+    st.pk.clear(); st.iq.clear(); st.chan.clear(); st.ticket = 0;
   }
 
   int drain(float* out, int noutput_items)
@@ -205,10 +385,10 @@ private:
       out_pkt& o = d_outq.front();
       if (o.sent == 0)
         for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
-      const size_t k = std::min(o.llr.size() - o.sent, (size_t)(noutput_items - produced));
-      memcpy(out + produced, o.llr.data() + o.sent, sizeof(float) * k);
+      const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
+      if (o.llr) memcpy(out + produced, o.llr + o.sent, sizeof(float) * k);
       o.sent += k; produced += (int)k;
-      if (o.sent == o.llr.size()) d_outq.pop_front();
+      if (o.sent == o.n) d_outq.pop_front();
     }
     return produced;
   }
@@ -218,8 +398,9 @@ private:
   int d_nports, d_mupos, d_mugid;
   c8p_pkt_in d_cur;
   int d_have = 0;
-  std::vector<c8p_pkt_in> d_pk;
-  std::vector<gr_complex> d_iq, d_chan;
+  stage d_st[2];
+  int d_fill = 0;                                  // the stage being gathered; the other one may be in flight
+  std::vector<std::shared_ptr<result>> d_pool;
   std::deque<out_pkt> d_outq;
 };
 
@@ -270,9 +451,12 @@ public:
       d_raw[a].insert(d_raw[a].end(), x, x + nproc);
     }
     d_io->consume_each(nproc);
-    const bool dry = nproc == 0;
+    // Process at the end of every call in which a pending flag can make progress (the scheduler never calls a block with zero
+    // input items, so waiting for a dry call would park detected packets until max_batch flags have piled up, with every raw
+    // sample since the oldest of them buffered): the first pending flag needs 224 items behind it, or — once its L-SIG is
+    // known and the packet was incomplete (C8P_SIG_NEED_MORE) — the rest of its packet.
     if (!d_evts.empty() && avail_end() != d_last_end &&
-        ((int)d_evts.size() >= d_eng.d_cfg.max_batch || (d_eng.d_cfg.flush_when_idle && dry))) {
+        ((int)d_evts.size() >= d_eng.d_cfg.max_batch || (d_eng.d_cfg.flush_when_idle && avail_end() >= d_need_end))) {
       d_last_end = avail_end();                      // nothing new to learn until more items arrive
       process();
     }
@@ -332,10 +516,13 @@ private:
       const size_t ri = r;
       if (submitted) r++;
       if (e.idx < d_scan || e.idx < d_base) continue;                     // inside a packet already copied: never seen
-      if (!submitted) { done = k; break; }                               // not enough items yet: S_DEMOD waits here
+      if (!submitted) { d_need_end = e.idx + 224; done = k; break; }     // not enough items yet: S_DEMOD waits here
       const c8p_pkt_in& p = pk[ri];
       if (p.n_items == 0) {
-        if (p.rsv[0] == C8P_SIG_NEED_MORE) { done = k; break; }          // S_COPY would wait for the rest of the packet
+        if (p.rsv[0] == C8P_SIG_NEED_MORE) {                              // S_COPY would wait for the rest of the packet
+          d_need_end = e.idx + 224 + (uint64_t)std::max(p.lsig_nsamp, 0);
+          done = k; break;
+        }
         d_scan = e.idx + 80;                                              // signal_impl.cc:157-160
         continue;
       }
@@ -354,6 +541,7 @@ private:
       d_scan = e.idx + 224 + (uint64_t)p.lsig_nsamp;                      // S_COPY consumed the packet
     }
     d_evts.erase(d_evts.begin(), d_evts.begin() + (std::ptrdiff_t)done);
+    if (d_evts.empty()) d_need_end = 0;
   }
 
   void trim()   // raw items before the oldest pending flag are no longer needed (later flags only point forward)
@@ -383,6 +571,7 @@ private:
   int d_nant;
   std::vector<std::vector<gr_complex>> d_raw;    // buffered raw items per antenna, d_raw[a][0] = stream item d_base
   uint64_t d_base = 0, d_scan = 0, d_last_end = ~0ull;   // d_scan: where S_TRIGGER resumes looking at sync flags
+  uint64_t d_need_end = 0;                       // stream position the first pending flag waits for (0: unknown, try at once)
   std::vector<evt> d_evts;                       // pending flags, in stream order
   long d_seq = 0;
   std::deque<out_pkt> d_outq;
@@ -475,7 +664,8 @@ detect::sptr detect::make(const c8p_api& api, const batching_cfg& cfg) { return 
 class decode_front : public decode
 {
 public:
-  decode_front(bool ifdebug, const c8p_api& api, const batching_cfg& cfg) : d_eng(api, cfg), d_debug(ifdebug)
+  decode_front(bool ifdebug, const c8p_api& api, const batching_cfg& cfg)
+      : d_eng(api, cfg), d_debug(ifdebug), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)}
   {
     memset(d_vhtMcsCount, 0, sizeof(d_vhtMcsCount));
     memset(d_legacyMcsCount, 0, sizeof(d_legacyMcsCount));
@@ -494,6 +684,7 @@ public:
     const int nproc = ninput_items[0];
     int used = 0;
     while (used < nproc) {
+      stage& st = d_st[d_fill];
       if (d_state == S_IDLE) {
         std::vector<tag_t> tags;
         const uint64_t pos = d_io->nitems_read(0) + used;
@@ -508,61 +699,141 @@ public:
         d_cur.cfo = tag_float(tags, "cfo", 0.f); d_cur.snr = tag_float(tags, "snr", 0.f); d_cur.rssi = tag_float(tags, "rssi", 0.f);
         d_cur.sssnr0 = tag_float(tags, "sssnr0", 0.f); d_cur.sssnr1 = tag_float(tags, "sssnr1", 0.f);
         d_cur.is_ndp = d_cur.trellis == 0;
-        d_cur.llr_off = d_llr.size();
-        const tag_value* mu = find_tag(tags, "mu2x1chan");
-        for (int i = 0; i < 128; i++) d_mu.push_back(mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f));
-        d_llr.resize(d_llr.size() + (size_t)std::max(d_cur.total, 0));
+        d_cur_fused = tag_long(tags, "c8p_fused", -1);
+        if (d_cur_fused < 0) {
+          d_cur.llr_off = st.llr.size();
+          const tag_value* mu = find_tag(tags, "mu2x1chan");
+          for (int i = 0; i < 128; i++) st.mu.push_back(mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f));
+          st.llr.grow((size_t)std::max(d_cur.total, 0));
+        }
         d_have = 0;
         d_state = S_COLLECT;
       }
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.total - d_have);
-      if (take > 0) memcpy(&d_llr[d_cur.llr_off + d_have], in + used, sizeof(float) * (size_t)take);
+      if (take > 0 && d_cur_fused < 0) memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
       d_have += std::max(take, 0); used += std::max(take, 0);
       if (d_have >= d_cur.total) {
-        d_tags.push_back(d_cur);
         d_state = S_IDLE;
-        if ((int)d_tags.size() >= d_eng.d_cfg.max_batch) submit();
+        if (d_cur.total <= 0) used++;        // a tag set announcing no items: step over its item (the reference livelocks here)
+        if (d_cur_fused >= 0) publish_fused();
+        else {
+          if (st.tags.empty()) st.t_first = now_tick();
+          st.tags.push_back(d_cur);
+          if ((int)st.tags.size() >= d_eng.d_cfg.max_batch) submit(false);
+        }
       }
     }
-    if (d_eng.d_cfg.flush_when_idle && d_state == S_IDLE && !d_tags.empty()) submit();
-    d_io->consume_each(used);
+    if (d_eng.d_cfg.flush_when_idle) age_check();
+    d_io->consume_each(std::min(used, nproc));
     return 0;
   }
 
-  void flush() override
+  void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    if (!d_tags.empty()) submit();
+    if (!d_st[d_fill].tags.empty()) submit(true);
+    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+  }
+
+  void age_check()           // see demod_front::age_check
+  {
+    const long w = d_eng.d_cfg.max_wait_us;
+    if (!d_st[d_fill].tags.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
+    stage& fl = d_st[d_fill ^ 1];
+    if (fl.ticket && us_since(fl.t_submit) >= w) collect(fl);
   }
 
 private:
-  void submit()
+  struct stage {
+    explicit stage(const c8p_api* a) : llr(a) {}
+    pinned_vec<float> llr;
+    std::vector<c8p_pkt_tags> tags;
+    std::vector<gr_complex> mu;
+    int ticket = 0;
+    tick_t t_first, t_submit;
+  };
+
+  void submit(bool last)
   {
+    stage& st = d_st[d_fill];
+    const bool part = d_state == S_COLLECT && d_cur_fused < 0;      // a packet still being received moves to the next stage
+    std::vector<float> part_llr;
+    std::vector<gr_complex> part_mu;
+    if (part) {
+      part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
+      part_mu.assign(st.mu.end() - 128, st.mu.end());
+    }
     c8p_decode_in b;
     memset(&b, 0, sizeof(b));
-    b.n_pkt = (int32_t)d_tags.size(); b.mem = C8P_MEM_HOST; b.tags = d_tags.data();
-    if (d_llr.empty()) d_llr.push_back(0.f);
-    b.llr = d_llr.data(); b.n_llr = d_llr.size();
-    b.mu2x1chan = reinterpret_cast<const c8p_c32*>(d_mu.data());
-    d_eng.check(d_eng.d_api.decode(d_eng.d_ctx, &b));
-    d_eng.check(d_eng.d_api.sync(d_eng.d_ctx));
-    std::vector<c8p_pkt_out> outs = d_eng.fetch_all<c8p_pkt_out>(C8P_BUF_OUT);
-    std::vector<uint8_t> pdu = d_eng.fetch_all<uint8_t>(C8P_BUF_PDU);
-    for (size_t p = 0; p < d_tags.size(); p++) {
-      const c8p_pkt_tags& t = d_tags[p];
+    b.n_pkt = (int32_t)st.tags.size(); b.mem = C8P_MEM_HOST; b.tags = st.tags.data();
+    if (st.llr.empty()) *st.llr.grow(1) = 0.f;
+    b.llr = st.llr.data(); b.n_llr = st.llr.size();
+    b.mu2x1chan = reinterpret_cast<const c8p_c32*>(st.mu.data());
+    d_eng.check(d_eng.d_api.decode(d_eng.d_ctx, &b), "decode");
+    st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
+    st.t_submit = now_tick();
+    stage& prev = d_st[d_fill ^ 1];
+    if (prev.ticket) collect(prev);
+    if (last) collect(st);
+    else d_fill ^= 1;
+    if (part) {
+      stage& nx = d_st[d_fill];
+      d_cur.llr_off = nx.llr.size();
+      float* dst = nx.llr.grow((size_t)std::max(d_cur.total, 0));
+      if (d_have) memcpy(dst, part_llr.data(), sizeof(float) * (size_t)d_have);
+      nx.mu.insert(nx.mu.end(), part_mu.begin(), part_mu.end());
+    }
+  }
+
+  void collect(stage& st)
+  {
+    const c8p_api& A = d_eng.d_api;
+    c8p_ctx* ctx = d_eng.d_ctx;
+    const size_t n = st.tags.size();
+    d_eng.check(A.select(ctx, st.ticket), "select");
+    std::vector<c8p_pkt_out> outs(n);
+    d_eng.check(A.fetch(ctx, C8P_BUF_OUT, outs.data(), 0, n * sizeof(c8p_pkt_out)), "fetch out");          // waits for the batch
+    uint64_t lo = ~0ull, hi = 0;
+    for (const c8p_pkt_out& o : outs)
+      if (o.n_pdu > 0) { lo = std::min<uint64_t>(lo, o.pdu_off); hi = std::max<uint64_t>(hi, o.pdu_off + o.pdu_bytes); }
+    std::vector<uint8_t> pdu;
+    if (hi > lo) { pdu.resize(hi - lo); d_eng.check(A.fetch(ctx, C8P_BUF_PDU, pdu.data(), lo, hi - lo), "fetch pdu"); }
+    for (size_t p = 0; p < n; p++) {
+      const c8p_pkt_tags& t = st.tags[p];
       const c8p_pkt_out& o = outs[p];
-      size_t off = o.pdu_off;
+      size_t off = o.n_pdu > 0 ? (size_t)(o.pdu_off - lo) : 0;
       for (int k = 0; k < o.n_pdu; k++) {
-        const int n = pdu[off] | (pdu[off + 1] << 8);
+        const int len = pdu[off] | (pdu[off + 1] << 8);
         pdu_t m;
-        m.len = n;
-        m.blob.assign(pdu.begin() + off + 2, pdu.begin() + off + 2 + n);
-        off += 2 + (size_t)n;
+        m.len = len;
+        m.blob.assign(pdu.begin() + (std::ptrdiff_t)off + 2, pdu.begin() + (std::ptrdiff_t)off + 2 + len);
+        off += 2 + (size_t)len;
         if (t.trellis != 0) debug_line(t, true);
         d_io->message_port_pub("out", m);
       }
       for (int k = 0; k < o.n_crc_fail; k++) debug_line(t, false);
     }
-    d_tags.clear(); d_llr.clear(); d_mu.clear();
+    st.tags.clear(); st.llr.clear(); st.mu.clear(); st.ticket = 0;
+  }
+
+  // fused mode: the packet was decoded on the device when `demod` ran c8p_rx; its results wait behind the handle.
+  // Everything gathered before it is published first, so the message order stays the arrival order.
+  void publish_fused()
+  {
+    if (!d_st[d_fill].tags.empty()) submit(true);
+    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+    fused_pkt f;
+    {
+      std::lock_guard<std::mutex> g(g_fused_mu);
+      auto it = g_fused.find(d_cur_fused);
+      if (it == g_fused.end()) return;            // a handle from another process / a replayed capture: nothing to publish
+      f = std::move(it->second);
+      g_fused.erase(it);
+    }
+    for (const pdu_t& m : f.pdus) {
+      if (d_cur.trellis != 0) debug_line(d_cur, true);
+      d_io->message_port_pub("out", m);
+    }
+    for (int k = 0; k < f.n_crc_fail; k++) debug_line(d_cur, false);
   }
 
   // decode_impl.cc:375-411 (vht) and :454-509 (legacy / ht)
@@ -592,9 +863,9 @@ private:
   bool d_debug;
   c8p_pkt_tags d_cur;
   int d_have = 0;
-  std::vector<c8p_pkt_tags> d_tags;
-  std::vector<float> d_llr;
-  std::vector<gr_complex> d_mu;
+  long d_cur_fused = -1;
+  stage d_st[2];
+  int d_fill = 0;
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
 };
 

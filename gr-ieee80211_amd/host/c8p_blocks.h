@@ -79,6 +79,14 @@ struct c8p_api {
   int (*sync)(c8p_ctx*);
   const void* (*buffer)(c8p_ctx*, int, uint64_t*);
   int (*fetch)(c8p_ctx*, int, void*, uint64_t, uint64_t);
+  // pipelining: submit batch i+1, then collect batch i (pinned staging, asynchronous copies, per-submit wait)
+  int (*rx)(c8p_ctx*, const c8p_batch_in*);
+  int (*ticket)(c8p_ctx*);
+  int (*select)(c8p_ctx*, int);
+  int (*wait)(c8p_ctx*, int);
+  int (*fetch_async)(c8p_ctx*, int, void*, uint64_t, uint64_t);
+  void* (*host_alloc)(uint64_t);
+  void (*host_free)(void*);
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);
@@ -86,8 +94,17 @@ c8p_api load_c8p_api(const std::string& so_path);
 struct batching_cfg {
   int max_batch = 256;          // packets per c8p_* call
   int detect_items = 1 << 20;   // detect: raw items gathered per c8p_detect call
-  bool flush_when_idle = true;  // submit a partial batch when the input runs dry (bounds latency in a live flowgraph)
+  bool flush_when_idle = true;  // submit a partial batch once its oldest packet has waited max_wait_us (bounds latency in a live
+                                // flowgraph; a saturated one fills whole batches between two checks and is never cut short)
+  int max_wait_us = 1000;       // checked at the end of every general_work call (the scheduler calls as long as items arrive)
   int device = 0;
+  // Fused demod -> decode (default: environment C8P_FUSED=1).  When both mirrors sit in one flowgraph the float LLR stream
+  // between them only exists to carry packets from one block to the next; in fused mode `demod` runs c8p_rx (demod + decode on
+  // the device, the LLRs never leave HBM), emits the reference's tags plus "c8p_fused" (a handle) on the first of `total`
+  // items whose VALUES ARE NOT WRITTEN, and `decode` publishes the PDUs behind the handle instead of decoding the items.
+  // Tags, item counts, PDU bytes and debug lines are unchanged; anything else that reads the LLR items must not use it.
+  bool fused = default_fused();
+  static bool default_fused();
 };
 
 class c8p_block

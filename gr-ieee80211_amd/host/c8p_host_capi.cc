@@ -2,9 +2,12 @@
 // an in-memory block_io (tagged item streams in, items/tags/messages out) plus a tiny run loop that calls
 // general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "c8p_blocks.h"
 
@@ -38,6 +41,7 @@ struct harness : public block_io {
   std::vector<pdu_t> msgs;
   std::vector<std::string> dbg;
   std::string err;
+  bool capture = true;                          // false: produced items are counted, not kept (throughput runs)
   uint64_t jitter = 0;                          // != 0: xorshift state; every call gets random item counts (scheduler-like)
   uint32_t rnd() { jitter ^= jitter << 13; jitter ^= jitter >> 7; jitter ^= jitter << 17; return (uint32_t)(jitter >> 11); }
 
@@ -64,12 +68,14 @@ struct harness : public block_io {
 
 extern "C" {
 
-void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, char* errbuf, int errcap)
+// fused: 0 / 1 = batching_cfg::fused, -1 = its default (environment C8P_FUSED)
+void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, int fused, char* errbuf, int errcap)
 {
   try {
     harness* h = new harness();
     c8p_api api = load_c8p_api(lib);
     batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
+    if (fused >= 0) cfg.fused = fused != 0;
     if (kind == 0) { h->blk = demod::make(mupos, 0, api, cfg); h->nports = 1; }
     else if (kind == 1) { h->blk = demod2::make(api, cfg); h->nports = 2; }
     else if (kind == 2) { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
@@ -84,6 +90,10 @@ void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_bat
     if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
     return nullptr;
   }
+}
+void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, char* errbuf, int errcap)
+{
+  return c8ph_create_ex(kind, mupos, ifdebug, lib, max_batch, flush_idle, -1, errbuf, errcap);
 }
 void c8ph_destroy(void* p) { delete static_cast<harness*>(p); }
 
@@ -112,6 +122,7 @@ void c8ph_push_tag_c32(void* p, uint64_t off, const char* key, const float* reim
 // Returns the number of general_work calls, or -1 on error (c8ph_error()).
 // from now on c8ph_run() hands general_work a random number of input items (1..chunk, sometimes more on one port than on the
 // others, sometimes none) and a random output space (1..nout) on every call, the way a busy scheduler does
+void c8ph_set_capture(void* p, int on) { static_cast<harness*>(p)->capture = on != 0; }
 void c8ph_set_jitter(void* p, unsigned long long seed) { static_cast<harness*>(p)->jitter = seed ? seed : 0; }
 
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
@@ -147,12 +158,13 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       calls++;
       for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
       h->n_read += h->consumed_this_call;
-      if (h->out_size == 1) {                                       // byte stream: one float per item in the capture
+      if (!h->capture) {
+      } else if (h->out_size == 1) {                                // byte stream: one float per item in the capture
         const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf.data());
         for (int i = 0; i < produced; i++) h->out_items.push_back((float)b[i]);
       } else
         h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
-      if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
+      if (h->nout == 2 && h->capture) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
       h->n_written += produced;
       if (!full) {                                                  // a starved call that got nowhere proves nothing
         if (produced || h->consumed_this_call) { idle = 0; starved = 0; } else starved++;
@@ -168,6 +180,92 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     return -1;
   }
 }
+// Two blocks the way a flowgraph runs them: each on its own thread (GNU Radio's thread-per-block scheduler), A's output
+// port 0 (items + tags) feeding B's input port 0 through a queue.  A's items are not captured (c8ph_out_count stays 0), B's
+// messages / debug lines are.  Returns the number of general_work calls of both, -1 on error (c8ph_error of either).
+long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
+{
+  harness* A = static_cast<harness*>(pa);
+  harness* B = static_cast<harness*>(pb);
+  struct piece { std::vector<float> items; std::vector<tag_t> tags; };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<piece> q;
+  bool a_done = false, failed = false;
+  long calls_a = 0, calls_b = 0;
+  const size_t fpi = std::max<size_t>(A->out_size / sizeof(float), 1);
+  std::thread ta([&] {
+    try {
+      std::vector<float> obuf((size_t)std::max(nout, 1) * fpi);
+      int idle = 0;
+      while (idle < 4) {
+        size_t avail = A->avail(0);
+        for (int qq = 1; qq < A->nports; qq++) avail = std::min(avail, A->avail(qq));
+        const int n = (int)std::min<size_t>(avail, (size_t)chunk);
+        gr_vector_int nin(A->nports, n);
+        gr_vector_const_void_star ins(A->nports);
+        for (int qq = 0; qq < A->nports; qq++) ins[qq] = A->rd(qq);
+        gr_vector_void_star outs(1, obuf.data());
+        A->consumed_this_call = 0;
+        const size_t tags_before = A->out_tags.size();
+        const int produced = A->blk->general_work(nout, nin, ins, outs);
+        calls_a++;
+        for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
+        A->n_read += A->consumed_this_call;
+        A->n_written += produced;
+        if (produced > 0) {
+          piece pc;
+          pc.items.assign(obuf.begin(), obuf.begin() + (size_t)produced * fpi);
+          pc.tags.assign(A->out_tags.begin() + (std::ptrdiff_t)tags_before, A->out_tags.end());
+          A->out_tags.resize(tags_before);
+          { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(pc)); }
+          cv.notify_one();
+        }
+        idle = (produced == 0 && A->consumed_this_call == 0) ? idle + 1 : 0;
+        if (idle == 2 && avail == 0) A->blk->flush();
+      }
+    } catch (const std::exception& e) { A->err = e.what(); failed = true; }
+    { std::lock_guard<std::mutex> g(mu); a_done = true; }
+    cv.notify_one();
+  });
+  try {
+    int idle = 0;
+    while (idle < 4) {
+      bool fin;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (B->avail(0) == 0) cv.wait(lk, [&] { return !q.empty() || a_done; });
+        while (!q.empty()) {
+          piece& pc = q.front();
+          const uint8_t* b = reinterpret_cast<const uint8_t*>(pc.items.data());
+          B->in[0].insert(B->in[0].end(), b, b + pc.items.size() * sizeof(float));
+          for (const tag_t& t : pc.tags) B->push_tag(t);
+          q.pop_front();
+        }
+        fin = a_done;
+      }
+      const size_t avail = B->avail(0);
+      const int n = (int)std::min<size_t>(avail, (size_t)chunk);
+      if (n == 0 && !fin) continue;
+      gr_vector_int nin(1, n);
+      gr_vector_const_void_star ins(1, B->rd(0));
+      std::vector<float> dummy(16);
+      gr_vector_void_star outs(1, dummy.data());
+      B->consumed_this_call = 0;
+      B->blk->general_work(0, nin, ins, outs);
+      calls_b++;
+      B->advance(0, (size_t)B->consumed_this_call);
+      B->n_read += B->consumed_this_call;
+      if (fin) {
+        idle = (B->consumed_this_call == 0) ? idle + 1 : 0;
+        if (idle == 2 && avail == 0) B->blk->flush();
+      }
+    }
+  } catch (const std::exception& e) { B->err = e.what(); failed = true; }
+  ta.join();
+  return failed ? -1 : calls_a + calls_b;
+}
+
 const char* c8ph_error(void* p) { return static_cast<harness*>(p)->err.c_str(); }
 
 long c8ph_out_count(void* p) { return (long)static_cast<harness*>(p)->out_items.size(); }     // in floats

@@ -237,8 +237,9 @@ typedef struct c8p_cfg {
 
 typedef struct c8p_batch_in {
   int32_t n_pkt;
-  int32_t mem;              /* C8P_MEM_* of pkts, iq and chan (all three the same)                     */
-  const c8p_pkt_in* pkts;   /* [n_pkt]                                                                 */
+  int32_t mem;              /* C8P_MEM_* of the iq and chan arenas (both the same)                     */
+  const c8p_pkt_in* pkts;   /* [n_pkt], ALWAYS host memory (the engine plans the arena layout from it on the host); to chain
+                               device-resident C8P_BUF_SIG_PKT descriptors, c8p_fetch them first (48 bytes per packet)  */
   const c8p_c32*    iq;     /* iq arena                                                                */
   uint64_t          n_iq;   /* items in the iq arena                                                   */
   const c8p_c32*    chan;   /* chan arena                                                              */
@@ -286,8 +287,9 @@ typedef struct c8p_detect_in {
 
 typedef struct c8p_decode_in {
   int32_t n_pkt;
-  int32_t mem;              /* C8P_MEM_* of tags, llr and mu2x1chan                                    */
-  const c8p_pkt_tags* tags; /* [n_pkt]  llr_off locates each packet's `total` items                    */
+  int32_t mem;              /* C8P_MEM_* of llr and mu2x1chan                                          */
+  const c8p_pkt_tags* tags; /* [n_pkt], ALWAYS host memory (sizes are planned on the host); llr_off locates each packet's
+                               `total` items                                                            */
   const float*   llr;       /* LLR arena (reference demod output stream layout)                        */
   uint64_t       n_llr;
   const c8p_c32* mu2x1chan; /* [n_pkt][128] tag "mu2x1chan" (only read for NDP packets); may be NULL   */
@@ -358,6 +360,16 @@ int c8p_select(c8p_ctx* ctx, int ticket);
 const void* c8p_buffer(c8p_ctx* ctx, int which, uint64_t* bytes);
 /* Copy [offset, offset+bytes) of a result arena to host memory (synchronises the stream). */
 int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
+
+/* c8p_fetch without the synchronisation: enqueues the copy behind the selected submit; complete after c8p_wait(ticket) of that
+ * submit or c8p_sync().  dst should come from c8p_host_alloc (pinned), otherwise the call may block like c8p_fetch. */
+int c8p_fetch_async(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
+/* Wait for one submit (uploads, kernels, the c8p_fetch_async copies behind it); C8P_ERANGE once its slot has been reused. */
+int c8p_wait(c8p_ctx* ctx, int ticket);
+/* Pinned host memory for staging arenas (what the block fronts use: lib/demod_impl.cc's scheduler buffers are pageable and
+ * only valid during general_work, so the fronts copy packets into these).  NULL on failure. */
+void* c8p_host_alloc(uint64_t bytes);
+void  c8p_host_free(void* p);
 
 /* profile=1: accumulated HIP-event time and launch count of one kernel since the last reset. */
 int c8p_kernel_time(c8p_ctx* ctx, int kernel, double* total_ms, int64_t* launches);

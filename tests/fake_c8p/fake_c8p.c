@@ -6,20 +6,25 @@
 #include "c8p_rx.h"
 #include "c8p_oracle.h"
 
+#define SLOTS 4     /* like the engine: the results of the last 4 demod / decode / rx submits stay resident (c8p_ticket / c8p_select) */
+struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
 struct c8p_ctx {
   c8p_c32* det_x; uint64_t det_n, det_commit; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
-  int n;
-  c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu;
+  struct res r[SLOTS];
+  int cur, seq;
+  struct res* s;      /* selected submit */
 };
 #define PDU_STRIDE 8192
 
-c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); return (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); }
+c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); c8p_ctx* c = (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); c->s = &c->r[0]; return c; }
+static void drop_res(struct res* r) { free(r->tags); free(r->outs); free(r->llr); free(r->pdu); free(r->mu); memset(r, 0, sizeof(*r)); }
+static void next_slot(c8p_ctx* c) { c->cur = (c->cur + 1) % SLOTS; c->s = &c->r[c->cur]; drop_res(c->s); c->s->ticket = ++c->seq; }
 static void drop(c8p_ctx* c)
 {
-  free(c->det_x); free(c->det_evt);
-  free(c->tags); free(c->outs); free(c->llr); free(c->pdu); free(c->mu); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
-  memset(c, 0, sizeof(*c));
+  free(c->det_x); free(c->det_evt); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
+  c->det_x = NULL; c->det_evt = NULL; c->sig_pkt = NULL; c->sig_iq = NULL; c->sig_chan = NULL;
+  c->det_n = c->det_commit = 0; c->det_nevt = 0; c->n_sig = 0; c->n_sig_iq = 0;
 }
 
 int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as the engine: per event cap = n_avail-224+320 items per antenna */
@@ -43,42 +48,43 @@ int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as
   }
   return C8P_OK;
 }
-void c8p_destroy(c8p_ctx* c) { if (c) { drop(c); free(c); } }
+void c8p_destroy(c8p_ctx* c) { if (c) { drop(c); for (int i = 0; i < SLOTS; i++) drop_res(&c->r[i]); free(c); } }
 const char* c8p_last_error(const c8p_ctx* c) { (void)c; return "fake backend"; }
 
 int c8p_demod(c8p_ctx* c, const c8p_batch_in* in)
 {
-  drop(c);
-  c->n = in->n_pkt;
-  c->tags = (c8p_pkt_tags*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_tags));
-  c->mu = (c8p_c32*)calloc((size_t)in->n_pkt * 128 + 1, sizeof(c8p_c32));
+  next_slot(c);
+  c->s->n = in->n_pkt;
+  c->s->tags = (c8p_pkt_tags*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_tags));
+  c->s->mu = (c8p_c32*)calloc((size_t)in->n_pkt * 128 + 1, sizeof(c8p_c32));
   uint64_t cap = 0;
   for (int p = 0; p < in->n_pkt; p++) cap += (uint64_t)(in->pkts[p].n_items / 72 + 1) * 832 + 1024;
-  c->llr = (float*)calloc(cap + 1, sizeof(float));
+  c->s->llr = (float*)calloc(cap + 1, sizeof(float));
   uint64_t off = 0;
   for (int p = 0; p < in->n_pkt; p++) {
-    c8po_demod(&in->pkts[p], in->iq, in->chan, &c->tags[p], c->llr + off, c->mu + 128 * p);
-    c->tags[p].llr_off = off;
+    c8po_demod(&in->pkts[p], in->iq, in->chan, &c->s->tags[p], c->s->llr + off, c->s->mu + 128 * p);
+    c->s->tags[p].llr_off = off;
     off += (uint64_t)(in->pkts[p].n_items / 72 + 1) * 832 + 1024;
   }
-  c->n_llr = cap;
+  c->s->n_llr = cap;
   return C8P_OK;
 }
 
-int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
+static int decode_into(c8p_ctx* c, const c8p_decode_in* in)
 {
-  free(c->outs); free(c->pdu);
-  c->outs = (c8p_pkt_out*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_out));
-  c->pdu = (uint8_t*)calloc((size_t)in->n_pkt * PDU_STRIDE + 1, 1);
-  c->n_pdu = (uint64_t)in->n_pkt * PDU_STRIDE;
-  c->n = in->n_pkt;
+  free(c->s->outs); free(c->s->pdu);
+  c->s->outs = (c8p_pkt_out*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_out));
+  c->s->pdu = (uint8_t*)calloc((size_t)in->n_pkt * PDU_STRIDE + 1, 1);
+  c->s->n_pdu = (uint64_t)in->n_pkt * PDU_STRIDE;
+  c->s->n = in->n_pkt;
   for (int p = 0; p < in->n_pkt; p++) {
     c8po_decode(&in->tags[p], in->llr + in->tags[p].llr_off, in->mu2x1chan ? in->mu2x1chan + 128 * p : NULL, NULL, NULL,
-                c->pdu + (size_t)p * PDU_STRIDE, PDU_STRIDE, &c->outs[p]);
-    c->outs[p].pdu_off = (uint64_t)p * PDU_STRIDE;
+                c->s->pdu + (size_t)p * PDU_STRIDE, PDU_STRIDE, &c->s->outs[p]);
+    c->s->outs[p].pdu_off = (uint64_t)p * PDU_STRIDE;
   }
   return C8P_OK;
 }
+int c8p_decode(c8p_ctx* c, const c8p_decode_in* in) { next_slot(c); return decode_into(c, in); }
 /* c8p_detect on the oracle: keeps every item it was ever given, re-runs the one-shot oracle over the whole stream and
  * reports the events between the old and the new commit point (new commit = 400 items before the end: every event
  * before it has its 240-item search window inside the stream, so later items cannot change it). */
@@ -116,11 +122,11 @@ const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
 {
   const void* p = NULL; uint64_t b = 0;
   switch (which) {
-    case C8P_BUF_TAGS: p = c->tags; b = (uint64_t)c->n * sizeof(c8p_pkt_tags); break;
-    case C8P_BUF_LLR: p = c->llr; b = c->n_llr * sizeof(float); break;
-    case C8P_BUF_OUT: p = c->outs; b = (uint64_t)c->n * sizeof(c8p_pkt_out); break;
-    case C8P_BUF_PDU: p = c->pdu; b = c->n_pdu; break;
-    case C8P_BUF_MUCHAN: p = c->mu; b = (uint64_t)c->n * 128 * sizeof(c8p_c32); break;
+    case C8P_BUF_TAGS: p = c->s->tags; b = (uint64_t)c->s->n * sizeof(c8p_pkt_tags); break;
+    case C8P_BUF_LLR: p = c->s->llr; b = c->s->n_llr * sizeof(float); break;
+    case C8P_BUF_OUT: p = c->s->outs; b = (uint64_t)c->s->n * sizeof(c8p_pkt_out); break;
+    case C8P_BUF_PDU: p = c->s->pdu; b = c->s->n_pdu; break;
+    case C8P_BUF_MUCHAN: p = c->s->mu; b = (uint64_t)c->s->n * 128 * sizeof(c8p_c32); break;
     case C8P_BUF_DET_EVT: p = c->det_evt; b = (uint64_t)c->det_nevt * sizeof(c8p_sync_evt); break;
     case C8P_BUF_SIG_PKT: p = c->sig_pkt; b = (uint64_t)c->n_sig * sizeof(c8p_pkt_in); break;
     case C8P_BUF_SIG_IQ: p = c->sig_iq; b = c->n_sig_iq * sizeof(c8p_c32); break;
@@ -138,3 +144,24 @@ int c8p_fetch(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes)
   memcpy(dst, (const char*)p + offset, bytes);
   return C8P_OK;
 }
+
+/* the asynchronous / pipelining entry points: everything is synchronous here, one resident submit */
+int c8p_rx(c8p_ctx* c, const c8p_batch_in* in)
+{
+  int rc = c8p_demod(c, in);
+  if (rc != C8P_OK) return rc;
+  c8p_decode_in d;
+  memset(&d, 0, sizeof(d));
+  d.n_pkt = in->n_pkt; d.mem = C8P_MEM_HOST; d.tags = c->s->tags; d.llr = c->s->llr; d.n_llr = c->s->n_llr; d.mu2x1chan = c->s->mu;
+  return decode_into(c, &d);
+}
+int c8p_ticket(c8p_ctx* c) { return c->seq; }
+int c8p_select(c8p_ctx* c, int ticket)
+{
+  for (int i = 0; i < SLOTS; i++) if (c->r[i].ticket == ticket && ticket != 0) { c->s = &c->r[i]; return C8P_OK; }
+  return C8P_ERANGE;
+}
+int c8p_wait(c8p_ctx* c, int ticket) { (void)c; (void)ticket; return C8P_OK; }
+int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes) { return c8p_fetch(c, which, dst, offset, bytes); }
+void* c8p_host_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
+void c8p_host_free(void* p) { free(p); }

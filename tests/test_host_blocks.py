@@ -336,3 +336,70 @@ def test_detect_mirror_under_random_scheduler_chunks_with_fake_backend(seed):
     assert [(o, k) for o, k, v in got_tags] == [(o, k) for o, k, v in ref_tags]
     for (o, k, v), (o2, k2, v2) in zip(got_tags, ref_tags):
         assert abs(v - v2) <= 1e-6 * max(1.0, abs(v2)), (o, k)
+
+
+# ---------------------------------------------------------------------------------------------- fused mode, threaded chain
+def _chain_threads(engine_lib, pk, iq, chan, n_ant, max_batch, fused):
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=engine_lib, max_batch=max_batch, fused=fused)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=engine_lib, max_batch=max_batch, fused=fused)
+    blocks.feed_demod(dem, pk, iq, chan)
+    blocks.run_chain(dem, dec, chunk=3000, nout=5000)
+    res = (dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    return res
+
+
+@pytest.mark.parametrize("n_ant", [1, 2])
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("max_batch", [3, 64])
+def test_chain_on_two_threads_with_fake_backend(n_ant, fused, max_batch):
+    """demod -> decode each on its own thread (the scheduler's thread-per-block), plain and fused (batching_cfg::fused: demod
+    runs c8p_rx, the LLR items are not written, decode publishes what waits behind the "c8p_fused" handle): same PDUs in the
+    same order, same debug lines as the two-pass run"""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    ref = chain(FAKE, pk, iq, chan, n_ant, 4096, 8192, 256)
+    msgs, dbg = _chain_threads(FAKE, pk, iq, chan, n_ant, max_batch, fused)
+    assert msgs == ref[2] and len(msgs) >= 10
+    assert dbg == ref[3]
+
+
+def test_fused_demod_emits_the_reference_tags_plus_a_handle():
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7, fused=True)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=4096, nout=8192)
+    llr, tags = dem.output(), dem.tags()
+    dem.close()
+    plain = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    assert len(llr) == len(plain[0])                                   # same item counts (values unwritten)
+    strip = [(o, k) for o, k, _ in tags if k != "c8p_fused"]
+    assert strip == [(o, k) for o, k, _ in plain[1]]
+    handles = [v for _, k, v in tags if k == "c8p_fused"]
+    assert len(handles) == len({o for o, _, _ in tags}) and len(set(handles)) == len(handles)
+
+
+def test_decode_steps_over_a_tag_set_that_announces_no_items():
+    """a tag set with total <= 0 must not trap general_work (the loop re-read the same tags forever)"""
+    dec = blocks.Block(blocks.DECODE, engine_lib=FAKE, max_batch=4)
+    dec.push_items(0, np.zeros(100, np.float32))
+    for k, v in (("format", 0), ("mcs", 0), ("len", 10), ("cr", 0), ("ampdu", 0), ("trellis", 102), ("total", 0)):
+        dec.push_tag(10, k, v)
+    dec.run(chunk=64, nout=64)
+    assert dec.messages() == []
+    dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_chain_on_two_threads_on_gpu(fused):
+    """the HIP engine behind both mirrors, each on its own thread; pipelined submits (max_batch 8 over ~25 packets), plain and
+    fused: PDUs and debug lines equal the oracle-checked two-pass run"""
+    b, _ = sweep_batch(snr_db=28.0, seed=6)
+    pk, iq, chan = split(b, 1)
+    ref = chain(None, pk, iq, chan, 1, 1000, 4096, 16)
+    assert check_against_oracle(ref, pk, iq, chan) >= 10
+    msgs, dbg = _chain_threads(None, pk, iq, chan, 1, 8, fused)
+    assert msgs == ref[2]
+    assert dbg == ref[3]
