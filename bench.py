@@ -40,9 +40,24 @@ def main():
     ap.add_argument("--fixture-workload", action="store_true", help="replicate the 4 committed reference-TX frames (host-generated) "
                     "instead of generating 4096 distinct packets on the device with c8p_tx")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
+                    help="cfg2: BASELINE configs[1], one 4096-packet batch per GPU and step (weak scaling; the headline). "
+                         "cfg4: BASELINE configs[3], ONE 65536-packet VHT MCS8 stream held by rank 0, scattered over the ranks, "
+                         "decoded, results gathered device-resident (strong scaling); without the flag it is reported as the extra "
+                         "object `sharded_stream` of the cfg2 line")
+    ap.add_argument("--stream-packets", type=int, default=65536)
+    ap.add_argument("--stream-steps", type=int, default=3)
+    ap.add_argument("--no-stream", action="store_true", help="skip the sharded-stream leg")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the PCIe-inclusive and block-chain legs (extra keys in the JSON line)")
     ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line and nothing else: libraries that chat on file descriptor 1 (RCCL prints a version banner when
+    # a communicator is created) are pointed at stderr; the line itself goes to a private duplicate of the original stdout
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +76,27 @@ def main():
     from c8p_cases import cfg2_batch, cfg2_workload_on_device
     from c8p_testlib import abi
     from gr_ieee80211_amd import engine
+
+    if args.workload == "cfg4":
+        st = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, max(args.steps, 1) if args.steps != 200 else 5,
+                            args.warmup if args.warmup != 5 else 1)
+        if use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            best = st["feeds"]["rccl_scatter"]
+            emit(({
+                "metric": "RX packets/s (20 MHz VHT MCS8 1458 B, one %d-packet stream sharded over the GPUs)" % st["packets"],
+                "value": best["packets_per_s"], "unit": "packets/s", "n_gpus": world, "steps": best["steps"], "warmup": best["warmup"],
+                "ms_per_step": best["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (c8p_tx, distinct payloads, seeds 8021400+p)",
+                "config": {"workload": "BASELINE configs[3] with the MCS8 substitution of SURVEY.md §7: VHT MCS8 256-QAM r=3/4 SISO, "
+                                       "1458-byte MPDU, one %d-packet stream on rank 0, contiguous blocks per rank, AWGN 30 dB" % st["packets"],
+                           "parallelism": "scatter (RCCL) -> c8p_rx per rank in sub-batches of %d -> all_gather of the fixed-stride "
+                                          "result arenas (device-resident)" % st["sub_batch"]},
+                "sharded_stream": st}))
+        return
 
     # ---- synthetic workload, resident in HBM before anything is timed
     t_gen = time.time()
@@ -147,6 +183,11 @@ def main():
     kt_excl = eng_x.kernel_times()
     eng_x.close()
 
+    # BASELINE configs[3] beside the headline: ONE stream scattered from rank 0, decoded, gathered (every rank takes part)
+    stream_res = None
+    if not args.no_stream:
+        stream_res = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, args.stream_steps, 1)
+
     out = None
     if rank == 0:
         total_pkts = n_pkt * world * args.steps
@@ -195,6 +236,8 @@ def main():
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
+        if not args.no_stream:
+            out["sharded_stream"] = stream_res
         if not args.no_host_legs and world == 1:
             # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
             out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local)
@@ -227,7 +270,145 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
+
+
+_JSON_OUT = None
+
+
+def emit(obj):
+    f = _JSON_OUT or sys.stdout
+    f.write(json.dumps(obj) + "\n")
+    f.flush()
+
+
+def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, warmup, sub=4096, snr_db=30.0):
+    """BASELINE configs[3]: rank 0 (the ingest GPU) holds ONE arrival-ordered stream of n_total VHT MCS8
+    packets; per step: scatter contiguous blocks to the ranks, c8p_rx on every rank in sub-batches (pipelined through the
+    engine's slots), all_gather of the fixed-stride c8p_pkt_out + PDU arenas, device-resident.  Two feeds are timed:
+      rccl_scatter  IQ / chan / descriptors leave rank 0's HBM through dist.scatter (grouped send/recv over xGMI)
+      direct_h2d    every rank already holds its block in pinned host memory and uploads it itself (c8p_rx with host arenas)
+    Phases are separated by device synchronisation, so they do not overlap; `ms_per_step` is the whole step."""
+    import torch.distributed as dist
+    from c8p_cases import cfg2_workload_on_device
+    from c8p_testlib import abi
+    from gr_ieee80211_amd import engine, shard
+    own_group = False
+    if not dist.is_initialized():                     # plain `python bench.py`: a world of one, still through RCCL
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        own_group = True
+    t_gen = time.time()
+    pk_all = iq_all = chan_all = expected = keep = None
+    if rank == 0:
+        pk_all, iq_d, chan_d, expected, keep = cfg2_workload_on_device(n_total, snr_db, 0, torch, dev, local, mcs=8, seed_base=8021400)
+        iq_all = shard.device_bytes(iq_d.ptr, 8 * iq_d.n, dev).view(torch.float32)
+        chan_all = shard.device_bytes(chan_d.ptr, 8 * chan_d.n, dev).view(torch.float32)
+        n_total = len(pk_all)
+    nt = torch.tensor([n_total], dtype=torch.int64, device=dev)
+    dist.broadcast(nt, src=0)
+    n_total = int(nt.item())
+    t_gen = time.time() - t_gen
+    lo, hi = shard.partition(n_total, world, rank)
+    n_local = hi - lo
+    eng = engine.Engine(device=local)
+
+    def sync_all():
+        eng.sync(); torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+
+    outs_res = torch.zeros(max(n_local, 1) * abi.PKT_OUT_DT.itemsize, dtype=torch.uint8, device=dev)
+    pdu_res = None
+    res = {"packets": n_total, "sub_batch": sub, "world": world, "generation_s": round(t_gen, 1), "feeds": {}}
+
+    def rx_block(pk, iq_arena, chan_arena):
+        """c8p_rx over this rank's block in sub-batches; every sub-batch's result arenas are copied (device to device, behind
+        its kernels on its slot's stream) into the rank's contiguous arenas before the slot is reused"""
+        nonlocal pdu_res
+        bases, base = [], 0
+        on_host = not isinstance(iq_arena, engine.DevArray)
+        for j in range(0, len(pk), sub):
+            if on_host:                               # a host arena is uploaded whole: hand over only this sub-batch's items
+                (i0, i1), (c0, c1) = shard.block_extents(pk, j, min(j + sub, len(pk)))
+                d = pk[j:j + sub].copy()
+                d["iq_off"][:, 0] -= i0; d["chan_off"] -= c0
+                eng.rx(d, iq_arena[i0:i1], chan_arena[c0:c1])
+            else:
+                eng.rx(pk[j:j + sub], iq_arena, chan_arena)
+            _, ob = eng.buffer(abi.BUF_OUT)
+            _, pb = eng.buffer(abi.BUF_PDU)
+            if pdu_res is None or pdu_res.numel() < base + pb:
+                grown = torch.zeros(max(2 * (pdu_res.numel() if pdu_res is not None else 0), (len(pk) // max(min(sub, len(pk)), 1) + 1) * pb),
+                                    dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev); eng.sync()
+                if pdu_res is not None:
+                    grown[:pdu_res.numel()] = pdu_res
+                pdu_res = grown
+                torch.cuda.synchronize(dev)
+            eng.fetch_async(abi.BUF_OUT, outs_res.data_ptr() + j * abi.PKT_OUT_DT.itemsize, 0, ob)
+            eng.fetch_async(abi.BUF_PDU, pdu_res.data_ptr() + base, 0, pb)
+            bases.append((j, min(j + sub, len(pk)), base))
+            base += pb
+        eng.sync()
+        rec = outs_res[:len(pk) * abi.PKT_OUT_DT.itemsize].view(torch.int64).view(len(pk), 4)
+        for a, b, off in bases:                      # pdu_off was relative to the sub-batch's own arena
+            if off:
+                rec[a:b, 2] += off
+        torch.cuda.synchronize(dev)
+        return base
+
+    checked = False
+    host_keep = None
+    for feed in ("rccl_scatter", "direct_h2d"):
+        host = None
+        ph = {"scatter": 0.0, "rx": 0.0, "gather": 0.0}
+        el_steps = []
+        for it in range(warmup + steps):
+            sync_all()
+            t0 = time.perf_counter()
+            if feed == "rccl_scatter":
+                pk, iq_l, ch_l = shard.scatter_stream(pk_all, iq_all, chan_all, n_total, dev)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                used = rx_block(pk, engine.DevArray(iq_l.data_ptr(), iq_l.numel() // 2, iq_l), engine.DevArray(ch_l.data_ptr(), ch_l.numel() // 2, ch_l))
+                if host is None:                      # the block in pinned host memory, for the second feed
+                    host = (pk, iq_l.cpu().pin_memory().numpy().view(np.complex64), ch_l.cpu().pin_memory().numpy().view(np.complex64))
+                    host_keep = host
+            else:
+                pk, iq_h, ch_h = host_keep
+                t1 = time.perf_counter()
+                used = rx_block(pk, iq_h, ch_h)
+            t2 = time.perf_counter()
+            counts, outs_all, pdu_all = shard.gather_results(outs_res[:n_local * abi.PKT_OUT_DT.itemsize], pdu_res[:used], n_local)
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            if not checked and rank == 0:             # once: the gathered arenas hold every transmitted MPDU, in arrival order
+                got = shard.pdus_of(counts, outs_all, pdu_all, n_total)
+                okc = sum(1 for p, b in got if b == expected[p])
+                res["pdus_gathered"], res["pdus_equal_to_transmitted"] = len(got), okc
+                assert okc >= 0.97 * n_total and okc == len(got), "sharded stream: %d PDUs, %d correct of %d packets" % (len(got), okc, n_total)
+                checked = True
+            dist.barrier()
+            t4 = time.perf_counter()
+            if it >= warmup:
+                v = torch.tensor([t1 - t0, t2 - t1, t3 - t2, t4 - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                v = v.tolist()
+                ph["scatter"] += v[0]; ph["rx"] += v[1]; ph["gather"] += v[2]
+                el_steps.append(v[3])
+        n_pdu, n_fail = shard.count_pdus(counts, outs_all)
+        el = float(np.median(el_steps))
+        res["feeds"][feed] = {"packets_per_s": n_total / el, "ms_per_step": 1e3 * el, "steps": steps, "warmup": warmup,
+                              "phase_ms": {k: round(1e3 * v / steps, 3) for k, v in ph.items()},
+                              "pdus_last_step": n_pdu, "fcs_failures_last_step": n_fail,
+                              "gathered_bytes_per_rank": int(outs_all.shape[1] + pdu_all.shape[1])}
+    res["note"] = ("unmeasured at N > 1 until the driver has an 8-GPU node; at N = 1 the scatter is a device-local copy and the "
+                   "all_gather a self-copy through RCCL") if world == 1 else "measured at world %d" % world
+    eng.close()
+    del keep
+    if own_group:
+        dist.destroy_process_group()
+    return res
 
 
 def lean_step_mix(T, cr_num=5):

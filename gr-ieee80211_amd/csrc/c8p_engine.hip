@@ -1013,7 +1013,8 @@ extern "C" int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset
   if (!c || which < 0 || which >= C8P_BUF_COUNT || !dst) return C8P_EINVAL;
   if (offset + bytes > c->s->used[which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
   HIPCHK(c, hipSetDevice(c->device));
-  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->s->ptr[which] + offset, bytes, hipMemcpyDeviceToHost, c->s->stream));
+  // hipMemcpyDefault: dst may also be device memory (a caller gathering fixed-stride result arenas on the device, shard.py)
+  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, (const char*)c->s->ptr[which] + offset, bytes, hipMemcpyDefault, c->s->stream));
   return C8P_OK;
 }
 

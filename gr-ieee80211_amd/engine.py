@@ -207,6 +207,14 @@ class Engine:
     def select(self, ticket):
         self._chk(self.L.c8p_select(self.ctx, int(ticket)))
 
+    def wait(self, ticket):
+        """wait for ONE submit (uploads, kernels, the fetch_async copies behind it)"""
+        self._chk(self.L.c8p_wait(self.ctx, int(ticket)))
+
+    def fetch_async(self, which, dst_ptr, offset_bytes, nbytes):
+        """enqueue a copy of a result arena of the selected submit behind its kernels; dst_ptr = pinned host or device memory"""
+        self._chk(self.L.c8p_fetch_async(self.ctx, which, C.c_void_p(int(dst_ptr)), int(offset_bytes), int(nbytes)))
+
     def buffer(self, which):
         nbytes = C.c_uint64(0)
         p = self.L.c8p_buffer(self.ctx, which, C.byref(nbytes))

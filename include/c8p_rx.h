@@ -362,7 +362,8 @@ const void* c8p_buffer(c8p_ctx* ctx, int which, uint64_t* bytes);
 int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
 
 /* c8p_fetch without the synchronisation: enqueues the copy behind the selected submit; complete after c8p_wait(ticket) of that
- * submit or c8p_sync().  dst should come from c8p_host_alloc (pinned), otherwise the call may block like c8p_fetch. */
+ * submit or c8p_sync().  dst should come from c8p_host_alloc (pinned), otherwise the call may block like c8p_fetch; dst may
+ * also be device memory (device-to-device: results gathered without touching the host). */
 int c8p_fetch_async(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
 /* Wait for one submit (uploads, kernels, the c8p_fetch_async copies behind it); C8P_ERANGE once its slot has been reused. */
 int c8p_wait(c8p_ctx* ctx, int ticket);

@@ -127,7 +127,7 @@ def ampdu_vht(mpdu):
     return pkt + b"\x00" * ((-len(pkt)) % 4)
 
 
-def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0):
+def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0, mcs=7, seed_base=8021100):
     """BASELINE configs[1] as SURVEY.md §8d-2 specifies it, generated on the box by the build's own transmitter:
     packet p carries its own MPDU (1454 bytes from numpy.random.default_rng(8021100 + p) + CRC-32, inside a VHT A-MPDU),
     VHT MCS7, amplitude as tools/pktGenExample.py (multiplier 12), a flat channel e^{j theta_p} and AWGN at snr_db
@@ -142,16 +142,16 @@ def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0):
     arena, exp = [], []
     off = 0
     for p in range(n):
-        rng = np.random.default_rng(8021100 + seed + p)
+        rng = np.random.default_rng(seed_base + seed + p)
         body = bytes(rng.integers(0, 256, size=1454, dtype=np.uint8))
         mpdu = body + zlib.crc32(body).to_bytes(4, "little")
         ps = ampdu_vht(mpdu)
-        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = off, len(ps), abi.F_VHT, 7
+        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = off, len(ps), abi.F_VHT, mcs
         pk[p]["scr_seed"], pk[p]["mult"], pk[p]["gap"] = 93, 12.0, GAP
         pk[p]["flags"] = abi.TX_NO_WINDOW                   # clean OFDM symbols, as `dewindow` makes the fixture frames
         arena.append(np.frombuffer(ps, np.uint8))
         off += len(ps)
-        exp.append(bytes([abi.F_VHT, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([7]))
+        exp.append(bytes([abi.F_VHT, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs]))
     e_tx = engine.Engine(device=local)
     e_tx.tx(pk, np.concatenate(arena), tail_gap=400)
     e_tx.sync()
@@ -164,7 +164,7 @@ def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0):
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMemcpy(ctypes.c_void_p(clean.data_ptr()), ctypes.c_void_p(p_iq), ctypes.c_size_t(nbytes), ctypes.c_int(3))   # device to device
     z = torch.view_as_complex(clean.view(-1, 2))
-    g = torch.Generator(device=dev); g.manual_seed(8021200 + seed)
+    g = torch.Generator(device=dev); g.manual_seed(seed_base + 100 + seed)
     theta = torch.rand(n, generator=g, device=dev, dtype=torch.float32) * (2 * np.pi)
     starts = torch.from_numpy(desc["iq_off"].astype(np.int64)).to(dev)
     idx = torch.searchsorted(starts, torch.arange(ntot, device=dev), right=True) - 1

@@ -421,21 +421,15 @@ def test_frequency_selective_channels_match_oracle(eng, snr):
     assert n_pdu >= (40 if snr != 15.0 else 5)
 
 
-def test_pdu_gather_over_rccl_world_of_one(eng):
-    """shard.gather_pdus with backend nccl (= RCCL) and device tensors: the collectives of the multi-GPU path on the one GPU
-    a test box has (the 2-rank logic runs under gloo in tests/test_shard_gloo.py)"""
+def test_sharded_stream_over_rccl_world_of_one():
+    """bench.py's BASELINE configs[3] path — scatter_stream, c8p_rx in sub-batches with device-to-device result collection,
+    gather_results — with backend nccl (= RCCL) on the one GPU a test box has (the 2- and 3-rank logic runs under gloo in
+    tests/test_shard_gloo.py).  sharded_stream() itself asserts that the gathered arenas hold every transmitted MPDU."""
     import torch
-    import torch.distributed as dist
-    from gr_ieee80211_amd import shard
-    b, _ = sweep_batch(snr_db=None, seed=9)
-    pk, iq, chan = b.arrays()
-    lo, hi = shard.partition(len(pk), 1, 0)
-    eng.rx(shard.slice_batch(pk, lo, hi), iq, chan)
-    pdus = [r["pdus"] for r in eng.results(want_llr=False)]
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
-    try:
-        got = shard.gather_pdus(pdus, lo, device=torch.device("cuda", 0))
-    finally:
-        dist.destroy_process_group()
-    want = [(p, x) for p, lst in enumerate(pdus) for x in lst]
-    assert got == want and len(got) >= 40
+    import bench
+    dev = torch.device("cuda", 0)
+    res = bench.sharded_stream(torch, dev, 0, 0, 1, False, 600, 1, 1, sub=128)
+    assert res["packets"] == 600 and res["pdus_gathered"] == res["pdus_equal_to_transmitted"] >= 590
+    for feed in ("rccl_scatter", "direct_h2d"):
+        f = res["feeds"][feed]
+        assert f["pdus_last_step"] == res["pdus_gathered"] and f["packets_per_s"] > 0

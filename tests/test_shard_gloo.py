@@ -23,6 +23,23 @@ def _free_port():
     return p
 
 
+def _arenas_from_oracle(res):
+    """fixed-stride result arenas the way the engine lays them out (c8p_pkt_out records + a PDU arena), built from oracle
+    results — the oracle stands in for the per-rank engine here (test only)"""
+    from c8p_testlib import abi
+    outs = np.zeros(len(res), abi.PKT_OUT_DT)
+    chunks, off = [], 0
+    for p, r in enumerate(res):
+        area = b"".join(len(x).to_bytes(2, "little") + x for x in r["pdus"])
+        outs[p]["n_pdu"], outs[p]["n_crc_fail"] = len(r["pdus"]), int(r["out"]["n_crc_fail"])
+        outs[p]["pdu_off"], outs[p]["pdu_bytes"] = off, len(area)
+        chunks.append(np.frombuffer(area, np.uint8))
+        off += (len(area) + 15) & ~15
+        chunks.append(np.zeros(off - sum(len(c) for c in chunks), np.uint8))
+    pdu = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    return outs, pdu
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,17 +47,29 @@ def _worker(rank, world, port, q):
         if d not in sys.path:
             sys.path.insert(0, d)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    b, _ = sweep_batch(snr_db=25.0, seed=9)
-    pk, iq, chan = b.arrays()
-    lo, hi = shard.partition(len(pk), world, rank)
-    mine = shard.slice_batch(pk, lo, hi)
-    res = oracle_rx(mine, iq, chan)
-    got = shard.gather_pdus([r["pdus"] for r in res], lo)
+    cpu = torch.device("cpu")
+    n_total, pk_all, iq_all, chan_all = 0, None, None, None
+    if rank == 0:                                           # the ingest rank holds the whole arrival-ordered stream
+        b, _ = sweep_batch(snr_db=25.0, seed=9)
+        pk_all, iq, chan = b.arrays()
+        iq_all = torch.from_numpy(iq.view(np.float32).copy())
+        chan_all = torch.from_numpy(chan.view(np.float32).copy())
+        n_total = len(pk_all)
+    nt = torch.tensor([n_total], dtype=torch.int64)
+    dist.broadcast(nt, src=0)
+    n_total = int(nt.item())
+    pk, iq_l, ch_l = shard.scatter_stream(pk_all, iq_all, chan_all, n_total, cpu)
+    lo, hi = shard.partition(n_total, world, rank)
+    assert len(pk) == hi - lo
+    res = oracle_rx(pk, iq_l.numpy().view(np.complex64), ch_l.numpy().view(np.complex64))
+    outs, pdu = _arenas_from_oracle(res)
+    counts, outs_all, pdu_all = shard.gather_results(torch.from_numpy(outs.view(np.uint8).copy()), torch.from_numpy(pdu.copy()), len(pk))
+    got = shard.pdus_of(counts, outs_all, pdu_all, n_total)
+    n_pdu, n_fail = shard.count_pdus(counts, outs_all)
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)            # bench.py's elapsed-time reduction
-    if rank == 0:
-        q.put((got, float(t.item())))
+    q.put((rank, got, float(t.item()), n_pdu, n_fail))
     dist.destroy_process_group()
 
 
@@ -54,21 +83,26 @@ def test_partition_properties():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_sharded_rx_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_stream_matches_single_process(world):
+    """scatter_stream (contiguous blocks of a mixed 1- / 2-antenna stream from the ingest rank) -> per-rank RX -> gather_results
+    (fixed-stride arenas, all-gathered): every rank ends up with the single-process PDU list in arrival order"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, tmax = q.get(timeout=300)
+    outs = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert tmax == 2.0
     b, _ = sweep_batch(snr_db=25.0, seed=9)
     pk, iq, chan = b.arrays()
     ref = oracle_rx(pk, iq, chan)
     want = [(p, x) for p, r in enumerate(ref) for x in r["pdus"]]
-    assert got == want and len(want) > 30
+    assert len(want) > 30
+    for rank, got, tmax, n_pdu, n_fail in outs:
+        assert tmax == float(world)
+        assert got == want
+        assert n_pdu == len(want) and n_fail == sum(int(r["out"]["n_crc_fail"]) for r in ref)
