@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
       pre = cadd(pre, p[j]); pe += e[j];
       const cf P = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);   // tail of block b-6 + blocks b-5..b-1 + head of block b
       const float E = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
-      // hardware sqrt / reciprocal (1 ulp each): ac is compared at 2e-6, the correctly rounded forms cost ~25 instructions
-      acv[j] = __builtin_amdgcn_sqrtf(P.x * P.x + P.y * P.y) * __builtin_amdgcn_rcpf(E);
+      // correctly rounded sqrt and quotient (-fhip-fp32-correctly-rounded-divide-sqrt), i.e. IEEE sqrtf(.) / e as VOLK + blocks_divide_ff compute it: ac feeds
+      // hard comparisons (ac > 0.3, ac > running maximum, trigger_impl.cc:77-85), so given the same window sums the trigger
+      // bytes are those of the scalar CPU restatement bit for bit (tests/test_detect_frontend.py: integer-valued torture stream straddling 0.3)
+      acv[j] = sqrtf(P.x * P.x + P.y * P.y) / E;
       Pv[j] = P;
     }
   }

@@ -1044,6 +1044,38 @@ extern "C" void* c8p_host_alloc(uint64_t bytes)
 }
 extern "C" void c8p_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// ------------------------------------------------------------------------------------------------ device self-test hooks
+// The scalar arithmetic primitives of c8p_dev.h, exposed so that a test can compare them with the CPU's libm / libgcc forms
+// on millions of operands ON the device (the kernels only exercise them on whatever the test packets contain).
+__global__ void k_selftest(int which, const float* __restrict__ in, float* __restrict__ out, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (which == C8P_SELFTEST_CABS) out[i] = cabs_(mk(in[2 * i], in[2 * i + 1]));
+  else if (which == C8P_SELFTEST_CDIV) { const cf q = cdiv(mk(in[4 * i], in[4 * i + 1]), mk(in[4 * i + 2], in[4 * i + 3])); out[2 * i] = q.x; out[2 * i + 1] = q.y; }
+  else out[i] = sqrtf(in[3 * i] * in[3 * i] + in[3 * i + 1] * in[3 * i + 1]) / in[3 * i + 2];     // k_presiso's ac
+}
+
+extern "C" int c8p_selftest(c8p_ctx* c, int which, const float* in, float* out, uint64_t n)
+{
+  if (!c || !in || !out || which < 0 || which > C8P_SELFTEST_AC) return C8P_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t fin = which == C8P_SELFTEST_CABS ? 2 : which == C8P_SELFTEST_CDIV ? 4 : 3, fout = which == C8P_SELFTEST_CDIV ? 2 : 1;
+  float *d_in = nullptr, *d_out = nullptr;
+  if (n == 0) return C8P_OK;
+  HIPCHK(c, hipMalloc((void**)&d_in, n * fin * sizeof(float)));
+  if (hipMalloc((void**)&d_out, n * fout * sizeof(float)) != hipSuccess) { (void)hipFree(d_in); c->err = "hipMalloc"; return C8P_ENOMEM; }
+  hipError_t e = hipMemcpy(d_in, in, n * fin * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->slots[0].stream, which, d_in, d_out, (size_t)n);
+    e = hipStreamSynchronize(c->slots[0].stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, n * fout * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  if (e != hipSuccess) { c->err = std::string("selftest: ") + hipGetErrorString(e); return C8P_EHIP; }
+  return C8P_OK;
+}
+
 extern "C" int c8p_kernel_time(c8p_ctx* c, int kernel, double* total_ms, int64_t* launches)
 {
   if (!c || kernel < 0 || kernel >= C8P_K_COUNT) return C8P_EINVAL;

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
            "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait",
-           "c8p_host_alloc", "c8p_host_free"]
+           "c8p_host_alloc", "c8p_host_free", "c8p_selftest"]
 
 _LIB = None
 
@@ -58,6 +58,7 @@ def load_library():
     L.c8p_host_alloc.restype = C.c_void_p
     L.c8p_host_alloc.argtypes = [C.c_uint64]
     L.c8p_host_free.argtypes = [C.c_void_p]
+    L.c8p_selftest.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
     L.c8p_kernel_time.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -206,6 +207,14 @@ class Engine:
 
     def select(self, ticket):
         self._chk(self.L.c8p_select(self.ctx, int(ticket)))
+
+    def selftest(self, which, operands):
+        """device arithmetic primitives over operand tuples (0: |z| of (n,2); 1: a/b of (n,4) -> (n,2); 2: sqrtf(x^2+y^2)/e of (n,3))"""
+        a = np.ascontiguousarray(operands, np.float32)
+        n = a.shape[0]
+        out = np.zeros((n, 2) if which == 1 else n, np.float32)
+        self._chk(self.L.c8p_selftest(self.ctx, which, a.ctypes.data, out.ctypes.data, n))
+        return out
 
     def wait(self, ticket):
         """wait for ONE submit (uploads, kernels, the fetch_async copies behind it)"""

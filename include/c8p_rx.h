@@ -388,6 +388,16 @@ int c8p_profile_reset(c8p_ctx* ctx);
 #define C8P_TAB_LTF_NL_VHT22 8
 int c8p_table(int which, int sub, int32_t* dst, int cap);
 
+/* Test hook: the device's scalar arithmetic primitives over n operand tuples (host arrays in / out), for comparison with the
+ * reference's libm / libgcc forms on operands no packet exercises.
+ *   C8P_SELFTEST_CABS  in = n x {re, im}                 out = n x |z|        std::abs(std::complex<float>) = hypotf
+ *   C8P_SELFTEST_CDIV  in = n x {a.re, a.im, b.re, b.im} out = n x {re, im}   std::complex<float> division (libgcc __divsc3)
+ *   C8P_SELFTEST_AC    in = n x {p.re, p.im, e}          out = n x ac         sqrtf(p.re^2 + p.im^2) / e  (presiso output 0) */
+#define C8P_SELFTEST_CABS 0
+#define C8P_SELFTEST_CDIV 1
+#define C8P_SELFTEST_AC   2
+int c8p_selftest(c8p_ctx* ctx, int which, const float* in, float* out, uint64_t n);
+
 /* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc, tx_in, tx_plan} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 

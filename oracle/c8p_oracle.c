@@ -35,6 +35,17 @@ cf c8po_cdiv(cf a, cf b)
 }
 #define cdiv c8po_cdiv
 float c8po_cabsf(cf a) { return hypotf(a.re, a.im); }
+/* bulk forms for the arithmetic-model tests (the device primitives are compared with these on millions of operands) */
+void c8po_cabsf_n(const cf* a, float* out, long n) { for (long i = 0; i < n; i++) out[i] = hypotf(a[i].re, a[i].im); }
+void c8po_cdiv_n(const cf* ab, cf* out, long n) { for (long i = 0; i < n; i++) out[i] = c8po_cdiv(ab[2 * i], ab[2 * i + 1]); }
+/* std::complex<float> division as the compiler emits it for the reference (libgcc __divsc3 through the _Complex operator) */
+void c8po_cdiv_libgcc_n(const cf* ab, cf* out, long n)
+{
+  for (long i = 0; i < n; i++) {
+    const float _Complex a = ab[2 * i].re + ab[2 * i].im * 1.0fi, b = ab[2 * i + 1].re + ab[2 * i + 1].im * 1.0fi, q = a / b;
+    out[i].re = __real__ q; out[i].im = __imag__ q;
+  }
+}
 #define cabsf_ c8po_cabsf
 
 /* ------------------------------------------------------------------ tables (Appendix A of SURVEY.md) */

@@ -36,6 +36,23 @@ def build_flags():
     return lib().c8po_build_flags().decode()
 
 
+def cabsf_n(xy):
+    """glibc hypotf over (n, 2) float32 operands"""
+    a = np.ascontiguousarray(xy, np.float32)
+    out = np.zeros(len(a), np.float32)
+    lib().c8po_cabsf_n(_p(a), _p(out), C.c_long(len(a)))
+    return out
+
+
+def cdiv_n(abcd, libgcc=False):
+    """complex64 division over (n, 4) float32 operands {a.re, a.im, b.re, b.im}: the oracle's restated form, or (libgcc=True)
+    the compiler's own _Complex float division = libgcc __divsc3, which is what std::complex<float> operator/ compiles to"""
+    a = np.ascontiguousarray(abcd, np.float32)
+    out = np.zeros((len(a), 2), np.float32)
+    (lib().c8po_cdiv_libgcc_n if libgcc else lib().c8po_cdiv_n)(_p(a), _p(out), C.c_long(len(a)))
+    return out
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -313,3 +313,49 @@ def test_gpu_detect_plateaus_spanning_hundreds_of_tiles():
         commit = lo + c2
     assert got == [int(i) for i in ev["index"]]
     eng.close()
+
+
+def integer_stream(n, seed):
+    """Samples with small-integer real / imaginary parts: every product x[n-16] conj(x[n]), |x|^2 and every window sum is an
+    exactly representable integer whatever the summation order, so oracle and GPU see IDENTICAL P and E and any difference in
+    the trigger bytes would come from the sqrt / quotient alone.  Bursts with period 16 and a slowly varying amplitude pattern
+    make ac = |P| / E sweep through the 0.3 threshold again and again."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros(n, np.complex64)
+    pos = 200
+    while pos + 1500 < n:
+        L = int(rng.integers(300, 1200))
+        base = rng.integers(-3, 4, size=16) + 1j * rng.integers(-3, 4, size=16)
+        rep = np.tile(base, L // 16 + 1)[:L]
+        # a correlated part (periodic, weight drifting down) plus an uncorrelated integer part (weight drifting up)
+        junk = rng.integers(-4, 5, size=L) + 1j * rng.integers(-4, 5, size=L)
+        w = (np.arange(L) * 7 // L)                                  # 0..6
+        x[pos:pos + L] = ((6 - w) // 2) * rep + (w // 2) * junk
+        pos += L + int(rng.integers(100, 400))
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gpu_trigger_bytes_on_a_stream_that_straddles_the_threshold_exactly(seed):
+    """hardware sqrt x rcp feeding `ac > 0.3` was only observed to agree.  With the correctly rounded quotient and
+    a stream whose window sums are exact, ac is bit-identical to the oracle's — including samples that sit within a few ulp of
+    0.3 and exact ties between plateau maxima — and so are the trigger bytes and events."""
+    from gr_ieee80211_amd import engine
+    x = integer_stream(1 << 20, seed)
+    o = oracle()
+    ev, ac, cj, trig = o.detect(x)
+    eng = engine.Engine(device=0)
+    gev = eng.detect(x, keep=True)
+    gac = eng.fetch(abi.BUF_DET_AC, np.float32)
+    gcj = eng.fetch(abi.BUF_DET_CONJ, np.complex64)
+    gtr = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+    eng.close()
+    assert np.array_equal(gcj.view(np.uint32), cj.view(np.uint32))                  # the window sums are exact on both sides
+    fin = np.isfinite(ac)
+    assert np.array_equal(fin, np.isfinite(gac)) and np.array_equal(gac[fin].view(np.uint32), ac[fin].view(np.uint32))
+    near = np.abs(ac[fin].astype(np.float64) - 0.3) < 4 * 2.0 ** -25                # within ~4 ulp of the threshold
+    assert near.sum() >= 10, near.sum()
+    assert np.array_equal(gtr & 3, trig)
+    assert (trig & 1).sum() >= 20
+    assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"])
