@@ -1,0 +1,19 @@
+#include "decode_impl.h"
+
+namespace gr {
+namespace ieee80211 {
+
+decode::sptr decode::make(bool ifdebug) { return gnuradio::make_block_sptr<decode_impl>(ifdebug); }
+
+decode_impl::decode_impl(bool ifdebug)
+    : gr::block("decode", gr::io_signature::make(1, 1, sizeof(float)), gr::io_signature::make(0, 0, 0)),
+      c8p_gr_block<decode>("decode", gr::io_signature::make(1, 1, sizeof(float)), gr::io_signature::make(0, 0, 0))
+{
+  message_port_register_out(pmt::mp("out"));     // decode_impl.cc:39
+  attach(c8p::decode::make(ifdebug));
+}
+
+decode_impl::~decode_impl() {}
+
+} // namespace ieee80211
+} // namespace gr

@@ -1,0 +1,18 @@
+#include "demod2_impl.h"
+
+namespace gr {
+namespace ieee80211 {
+
+demod2::sptr demod2::make() { return gnuradio::make_block_sptr<demod2_impl>(); }
+
+demod2_impl::demod2_impl()
+    : gr::block("demod2", gr::io_signature::make(2, 2, sizeof(gr_complex)), gr::io_signature::make(1, 1, sizeof(float))),
+      c8p_gr_block<demod2>("demod2", gr::io_signature::make(2, 2, sizeof(gr_complex)), gr::io_signature::make(1, 1, sizeof(float)))
+{
+  attach(c8p::demod2::make());
+}
+
+demod2_impl::~demod2_impl() {}
+
+} // namespace ieee80211
+} // namespace gr

@@ -25,8 +25,7 @@
 #include <mutex>
 #include <stdexcept>
 
-namespace gr {
-namespace ieee80211 {
+C8P_MIRROR_NS_BEGIN
 
 c8p_api load_c8p_api(const std::string& so_path)
 {
@@ -875,5 +874,4 @@ decode::sptr decode::make(bool ifdebug, const c8p_api& api, const batching_cfg& 
   return std::shared_ptr<decode>(new decode_front(ifdebug, api, cfg));
 }
 
-} // namespace ieee80211
-} // namespace gr
+C8P_MIRROR_NS_END

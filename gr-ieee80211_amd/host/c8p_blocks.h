@@ -24,13 +24,25 @@
 
 #include "c8p_rx.h"
 
+// Stand-alone (this repository, tests, plain C++ users) the mirror classes carry the reference's own names,
+// gr::ieee80211::demod ...; inside a real GNU Radio module those names belong to the public gr::block classes
+// (gnuradio/lib/*_impl.h wrap the mirrors), so that build compiles this file with -DC8P_MIRROR_NS=c8p and gets c8p::demod ...
+#ifdef C8P_MIRROR_NS
+#define C8P_MIRROR_NS_BEGIN namespace C8P_MIRROR_NS {
+#define C8P_MIRROR_NS_END }
+#define C8P_MIRROR_QUAL C8P_MIRROR_NS
+#include <gnuradio/types.h>          // gr_complex, gr_vector_*
+#else
+#define C8P_MIRROR_NS_BEGIN namespace gr { namespace ieee80211 {
+#define C8P_MIRROR_NS_END } }
+#define C8P_MIRROR_QUAL gr::ieee80211
 typedef std::complex<float> gr_complex;
 typedef std::vector<int> gr_vector_int;
 typedef std::vector<const void*> gr_vector_const_void_star;
 typedef std::vector<void*> gr_vector_void_star;
+#endif
 
-namespace gr {
-namespace ieee80211 {
+C8P_MIRROR_NS_BEGIN
 
 // value of a stream tag: the three PMT kinds the hot path uses (long, float, c32vector)
 struct tag_value {
@@ -172,5 +184,4 @@ public:
   static sptr make(bool ifdebug, const c8p_api& api, const batching_cfg& cfg);
 };
 
-} // namespace ieee80211
-} // namespace gr
+C8P_MIRROR_NS_END

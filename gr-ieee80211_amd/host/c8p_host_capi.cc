@@ -11,7 +11,7 @@
 
 #include "c8p_blocks.h"
 
-using namespace gr::ieee80211;
+using namespace C8P_MIRROR_QUAL;
 
 namespace {
 

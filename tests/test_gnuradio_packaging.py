@@ -1,0 +1,94 @@
+"""gnuradio/ (SURVEY §8 f-3): the parts of the GNU Radio packaging that can be checked without GNU Radio.
+
+* the stand-alone CMake configuration (-DC8P_STANDALONE=ON) configures and builds libc8p_blocks.so, and that library drives
+  the mirrors exactly like the Makefile build;
+* the block mirrors compile into namespace c8p (-DC8P_MIRROR_NS=c8p), which is how the GNU Radio module embeds them next to
+  the public gr::ieee80211::demod ... classes (gr_complex etc. then come from <gnuradio/types.h>, so this check stops at the
+  preprocessor);
+* the GRC files keep the ids, make lines, parameter ids and ports the reference's flowgraphs rely on, the pybind files
+  register the reference's Python names, the adapters create the reference's io signatures."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+import yaml
+
+from c8p_testlib import ROOT
+
+GR = os.path.join(ROOT, "gnuradio")
+
+
+def test_standalone_cmake_configuration_builds_the_block_mirror(tmp_path):
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    b = str(tmp_path / "build")
+    subprocess.check_call(["cmake", "-S", GR, "-B", b, "-DC8P_STANDALONE=ON", "-DC8P_BUILD_ENGINE=OFF"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", b, "-j", "4"], stdout=subprocess.DEVNULL)
+    lib = os.path.join(b, "libc8p_blocks.so")
+    assert os.path.exists(lib)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
+    for s in ("c8ph_create_ex", "c8ph_run", "c8ph_run_chain"):
+        assert s in syms
+    assert "N2gr9ieee802115demod4make" in syms                     # gr::ieee80211::demod::make: the reference's names
+
+
+def test_engine_target_of_the_cmake_build_uses_the_makefile_flags():
+    cm = open(os.path.join(GR, "CMakeLists.txt")).read()
+    mk = open(os.path.join(ROOT, "gr-ieee80211_amd", "csrc", "Makefile")).read()
+    for flag in ("-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-disable-promote-alloca-to-lds=1"):
+        assert flag in cm and flag in mk
+
+
+def test_mirror_sources_compile_into_namespace_c8p_up_to_the_gnuradio_include():
+    """-DC8P_MIRROR_NS=c8p: the only thing missing in this image is <gnuradio/types.h>"""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DC8P_MIRROR_NS=c8p", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "gr-ieee80211_amd", "host", "c8p_blocks.cc")], capture_output=True, text=True)
+    errs = [l for l in r.stderr.splitlines() if "error" in l]
+    assert len(errs) >= 1 and all("gnuradio/types.h" in e for e in errs[:1]), r.stderr[:2000]
+
+
+GRC = {
+    "ieee80211_demod.block.yml": ("ieee80211_demod", "ieee80211.demod(${mupos}, ${mugid})", ["mupos", "mugid"], [("sig", "complex")], [("llr", "float")]),
+    "ieee80211_demod2.block.yml": ("ieee80211_demod2", "ieee80211.demod2()", [], [("inSig1", "complex"), ("inSig2", "complex")], [("outLlr", "float")]),
+    "ieee80211_decode.block.yml": ("ieee80211_decode", "ieee80211.decode(${ifdebug})", ["ifdebug"], [("inLlr", "float")], None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRC))
+def test_grc_files_keep_the_reference_contract(name):
+    """ids / make lines / parameter ids / ports as grc/ieee80211_{demod,demod2,decode}.block.yml of the reference
+    (ieee80211_demod.block.yml:5-32): examples/rx.grc and rx2.grc refer to exactly these"""
+    bid, make, params, ins, outs = GRC[name]
+    y = yaml.safe_load(open(os.path.join(GR, "grc", name)))
+    assert y["id"] == bid and y["templates"]["make"] == make and y["templates"]["imports"] == "from gnuradio import ieee80211"
+    assert [p["id"] for p in y.get("parameters", [])] == params
+    assert [(i["label"], i["dtype"]) for i in y["inputs"]] == ins
+    if outs is None:
+        assert y["outputs"] == [{"domain": "message", "id": "out"}]
+    else:
+        assert [(o["label"], o["dtype"]) for o in y["outputs"]] == outs
+    assert y["file_format"] == 1
+
+
+def test_bindings_and_adapters_keep_names_and_signatures():
+    bind = {b: open(os.path.join(GR, "python", "ieee80211", "bindings", b + "_python.cc")).read() for b in ("demod", "demod2", "decode")}
+    assert 'm, "demod"' in bind["demod"] and 'py::arg("mupos"), py::arg("mugid")' in bind["demod"]
+    assert 'm, "demod2"' in bind["demod2"] and 'm, "decode"' in bind["decode"] and 'py::arg("ifdebug")' in bind["decode"]
+    mod = open(os.path.join(GR, "python", "ieee80211", "bindings", "python_bindings.cc")).read()
+    assert "PYBIND11_MODULE(ieee80211_python, m)" in mod
+    sig = {"demod": ("make(1, 1, sizeof(gr_complex))", "make(1, 1, sizeof(float))"),        # demod_impl.cc:36-37
+           "demod2": ("make(2, 2, sizeof(gr_complex))", "make(1, 1, sizeof(float))"),       # demod2_impl.cc:36-37
+           "decode": ("make(1, 1, sizeof(float))", "make(0, 0, 0)")}                        # decode_impl.cc:35-38
+    for b, (i, o) in sig.items():
+        src = open(os.path.join(GR, "lib", b + "_impl.cc")).read()
+        assert "io_signature::" + i in src and "io_signature::" + o in src
+        assert re.search(r"%s::sptr %s::make\(" % (b, b), src)
+    assert 'message_port_register_out(pmt::mp("out"))' in open(os.path.join(GR, "lib", "decode_impl.cc")).read()
+    ad = open(os.path.join(GR, "lib", "c8p_gr_adapter.h")).read()
+    assert "TPP_DONT" in ad and 'pmt::mp("len")' in ad and "pmt::make_blob" in ad
+    lib = open(os.path.join(GR, "lib", "CMakeLists.txt")).read()
+    for kept in ("trigger_impl.cc", "sync_impl.cc", "signal_impl.cc", "cloud80211phy.cc", "modulation2_impl.cc", "pad2_impl.cc"):
+        assert kept in lib
+    assert "C8P_MIRROR_NS=c8p" in lib and 'find_package(Gnuradio "3.10"' in open(os.path.join(GR, "CMakeLists.txt")).read()
