@@ -134,6 +134,9 @@ def main():
     eng.rx(pk, iq_dev, chan_dev)
     eng.sync()
     res = eng.results(want_llr=False)
+    rng_flags, flt_blocks, _ = eng.decstat()       # decoder diagnostics: packets sent to the clamp-exact kernel, float-compare blocks
+    dec_path = {"exact_kernel_packets": int(rng_flags.sum()), "float_step_block_fraction":
+                float(flt_blocks[rng_flags == 0].sum()) / max(1, int((rng_flags == 0).sum()) * (11960 // 30))}
     n_ok = 0
     for r, e in zip(res, expected):
         if r["pdus"] and not args.no_check:
@@ -216,7 +219,7 @@ def main():
                         "note": "each repeat times exactly --steps steps between barriers; value / ms_per_step are the median repeat"},
             "config": {"workload": "BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU, %d packets/GPU/step, "
                                    "AWGN %.0f dB, random-phase flat channel" % (n_pkt, args.snr),
-                       "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1),
+                       "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1), "decoder_path": dec_path,
                        "parallelism": "packet-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -188,7 +188,7 @@ struct Slot {
   void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
-  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt;
+  Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt, d_negsym;
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
   Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_cnt, d_det_job, d_det_mark,
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
@@ -307,7 +307,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
-                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt,
+                   &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt, &sl.d_negsym,
                    &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig,
                    &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
                    &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
@@ -399,7 +399,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   if ((rc = ensure(c, c->s->d_pdu, P.pdu)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
   const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->s->d_flags.p;
   hipStream_t dst = c->s->stream, fst = c->s->stream;
   {
@@ -409,7 +409,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
       hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
-                         d_flags, n);
+                         (uint32_t*)c->s->d_flags.p, flags_ready ? (const float*)c->s->d_negsym.p : nullptr, n);
     }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
   }
@@ -424,6 +424,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   c->s->used[C8P_BUF_PDU] = P.pdu; c->s->ptr[C8P_BUF_PDU] = c->s->d_pdu.p;
   c->s->used[C8P_BUF_BITS] = c->keep_bits ? P.bits : 0; c->s->ptr[C8P_BUF_BITS] = c->s->d_bits.p;
   c->s->used[C8P_BUF_SBITS] = c->keep_bits ? P.bits : 0; c->s->ptr[C8P_BUF_SBITS] = c->s->d_sbits.p;
+  c->s->used[C8P_BUF_DECSTAT] = sizeof(uint32_t) * 3 * (size_t)n; c->s->ptr[C8P_BUF_DECSTAT] = c->s->d_flags.p;
   return C8P_OK;
 }
 
@@ -476,8 +477,9 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if ((rc = ensure(c, c->s->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_sym2pkt, sizeof(uint32_t) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_negsym, sizeof(float) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
 
   {
     KTimer kt(c, C8P_K_CLASSIFY);
@@ -489,7 +491,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
     KTimer kt(c, C8P_K_DEMOD);
     hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, (const uint32_t*)c->s->d_sym2pkt.p, d_lay,
                        (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->s->d_tags.p, (const cf*)c->s->d_H.p,
-                       (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, n, P.syms);
+                       (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, (float*)c->s->d_negsym.p, n, P.syms);
   }
   HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = c->s->d_tags.p;

@@ -523,23 +523,50 @@ template <int NB> __device__ __forceinline__ void qam_to_llr(cf q, float (&o)[NB
 }
 
 // LLRs of one subcarrier scattered through a de-interleave map (procSymDeint* cloud80211phy.cc:2150-2338): out[map[j*NB+b]] = llr[b]
-template <int NB> __device__ __forceinline__ bool llr_scatter(cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out)
+// neg += sum of max(0, -LLR): the decoder's integer loop needs a bound on how far a block can pull a metric down
+template <int NB> __device__ __forceinline__ bool llr_scatter(cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out, float& neg)
 {
   float o[NB];
   qam_to_llr<NB>(q, o);
   bool bad = false;
 #pragma unroll
-  for (int b = 0; b < NB; b++) { out[(uint32_t)(uint16_t)map[j * NB + b]] = o[b]; bad = bad || bad_llr(o[b]); }   // unsigned 32-bit offsets from a uniform base: no 64-bit address per store
+  for (int b = 0; b < NB; b++) {
+    out[(uint32_t)(uint16_t)map[j * NB + b]] = o[b];   // unsigned 32-bit offsets from a uniform base: no 64-bit address per store
+    bad = bad || bad_llr(o[b]);
+    neg += fmaxf(-o[b], 0.0f);
+  }
   return bad;
 }
-__device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out)
+__device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out, float& neg)
 {
   switch (nb) {   // uniform per wave
-    case 1: return llr_scatter<1>(q, j, map, out);
-    case 2: return llr_scatter<2>(q, j, map, out);
-    case 4: return llr_scatter<4>(q, j, map, out);
-    case 6: return llr_scatter<6>(q, j, map, out);
-    default: return llr_scatter<8>(q, j, map, out);
+    case 1: return llr_scatter<1>(q, j, map, out, neg);
+    case 2: return llr_scatter<2>(q, j, map, out, neg);
+    case 4: return llr_scatter<4>(q, j, map, out, neg);
+    case 6: return llr_scatter<6>(q, j, map, out, neg);
+    default: return llr_scatter<8>(q, j, map, out, neg);
+  }
+}
+// One symbol's entry of negsym[]: an upper bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs that touch this
+// symbol (a window spans at most 2 symbols, 3 when a symbol holds fewer than C8P_NEGB_WINDOW LLRs).  The decoder takes the maximum
+// over its packet's symbols (an atomicMax per symbol here cost 0.035 ms per 4096-packet batch: 46 waves per address).
+__device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps, uint32_t* __restrict__ flags, float* __restrict__ negsym,
+                                                  uint32_t w, int p)
+{
+  // wave sum on the DPP path (six VALU adds, total in lane 63): invalid source lanes read 0 (bound_ctrl), the row broadcasts
+  // only write the rows named by their row mask
+#define C8P_DPP_ADD(CTRL, ROWS) neg += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(neg), CTRL, ROWS, 0xf, true))
+  C8P_DPP_ADD(0x111, 0xf);   // row_shr:1
+  C8P_DPP_ADD(0x112, 0xf);   // row_shr:2
+  C8P_DPP_ADD(0x114, 0xf);   // row_shr:4
+  C8P_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row's sum
+  C8P_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1, 3
+  C8P_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's sum
+#undef C8P_DPP_ADD
+  const unsigned long long anybad = __ballot(bad);
+  if (lane_id() == 63) {
+    if (anybad) atomicOr(&flags[p], 1u);
+    negsym[w] = neg * (ncbps >= C8P_NEGB_WINDOW ? 2.0f : 3.0f);
   }
 }
 
@@ -547,8 +574,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    const cf* __restrict__ chan, const uint32_t* __restrict__ sym2pkt,
                                                    const PktLayout* __restrict__ lay, const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
                                                    const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
-                                                   float* __restrict__ llr, uint32_t* __restrict__ flags, int n,
-                                                   uint32_t total_syms)
+                                                   float* __restrict__ llr, uint32_t* __restrict__ flags, float* __restrict__ negsym,
+                                                   int n, uint32_t total_syms)
 {
   // (the wave index is uniform, but the compiler cannot see that through threadIdx: without the readfirstlane the packet's
   // tags and descriptor — 170 bytes — are fetched per lane into VGPRs instead of once into SGPRs)
@@ -584,11 +611,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), 1.0f), Pp));
     cf ps = cconj(acc);
     float pa = cabs_(ps);
+    float neg = 0.0f;                     // this lane's sum of max(0, -LLR)
     if (!is_null_l(lane) && !is_pilot(lane)) {
       cf q = cdivf(cmul(sig, ps), pa);
-      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out);
+      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out, neg);
     }
-    if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
+    publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
     return;
   }
 
@@ -601,11 +629,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int kk = (k + s) & 3;
-      const float l4 = kk == 3 ? -1.0f : 1.0f;                       // {1,1,1,-1}
-      const float h21 = kk >= 2 ? -1.0f : 1.0f;                      // {1,1,-1,-1}
-      const float h22 = (kk == 1 || kk == 2) ? -1.0f : 1.0f;         // {1,-1,-1,1}
-      pa_[k] = ht2 ? h21 : l4;
-      pb_[k] = (t.format == C8P_F_VHT) ? l4 : h22;
+      // (selected as bit patterns: the values are wave-uniform and stay in SGPRs; as float selects they took 8 VGPRs)
+      const uint32_t l4 = kk == 3 ? 0xbf800000u : 0x3f800000u;               // {1,1,1,-1}
+      const uint32_t h21 = kk >= 2 ? 0xbf800000u : 0x3f800000u;              // {1,1,-1,-1}
+      const uint32_t h22 = (kk == 1 || kk == 2) ? 0xbf800000u : 0x3f800000u; // {1,-1,-1,1}
+      pa_[k] = __uint_as_float(ht2 ? h21 : l4);
+      pb_[k] = __uint_as_float((t.format == C8P_F_VHT) ? l4 : h22);
     }
   }
 
@@ -618,11 +647,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), pa_[1]), Pp));
     cf ps = cconj(acc);
     float pa = cabs_(ps);
+    float neg = 0.0f;
     if (!is_null_nl(lane) && !is_pilot(lane)) {
       cf q = cdivf(cmul(sig, ps), pa);
-      bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out);
+      bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out, neg);
     }
-    if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
+    publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
     return;
   }
 
@@ -645,14 +675,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 57), pb_[1]), Pp), M->pil2[1]));
   cf ps = cconj(acc);
   float pa = cabs_(ps);
+  float neg = 0.0f;
   if (!is_null_nl(lane) && !is_pilot(lane)) {
     cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
     const int j = qidx_nl(lane);
-    const bool b1 = llr_scatter_nb(nb, qa, j, T->deint2ss[0][mi], out);
-    const bool b2 = llr_scatter_nb(nb, qb, j, T->deint2ss[1][mi], out);
+    const bool b1 = llr_scatter_nb(nb, qa, j, T->deint2ss[0][mi], out, neg);
+    const bool b2 = llr_scatter_nb(nb, qb, j, T->deint2ss[1][mi], out, neg);
     bad = b1 || b2;
   }
-  if (__ballot(bad) && lane == 0) atomicOr(&flags[p], 1u);
+  publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
 }
 
 // ================================================================================================ Viterbi forward
@@ -722,7 +753,8 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restri
   }
 }
 
-// Range check of an LLR stream handed in by the caller (c8p_decode): flags[p] = 1 sends the packet to the exact kernel.
+// Range check of an LLR stream handed in by the caller (c8p_decode): flags[p] = 1 sends the packet to the exact kernel;
+// flags[2n + p] = bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs (c8p_viterbi_lean.h): window x the largest -LLR.
 __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict__ tags, const float* __restrict__ llr,
                                                   uint32_t* __restrict__ flags, int n)
 {
@@ -730,35 +762,57 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
   if (p >= n) return;
   const c8p_pkt_tags t = tags[p];
   bool bad = false;
+  float mneg = 0.0f;
   if (decodable(t)) {
     const float* L = llr + t.llr_off;
-    for (int i = lane_id(); i < t.total; i += 64) bad |= bad_llr(L[i]);
+    for (int i = lane_id(); i < t.total; i += 64) { const float v = L[i]; bad |= bad_llr(v); mneg = fmaxf(mneg, -v); }
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mneg = fmaxf(mneg, __shfl_xor(mneg, o, 64));
   const unsigned long long any = __ballot(bad);
-  if (lane_id() == 0) flags[p] = any ? 1u : 0u;
+  if (lane_id() == 0) { flags[p] = any ? 1u : 0u; flags[2 * n + p] = any ? 0u : __float_as_uint(mneg * (float)C8P_NEGB_WINDOW); }
 }
 
 // The fast path (c8p_viterbi_lean.h).  Packets whose LLR stream failed the range check (flags[p] != 0) are left to
 // k_viterbi_fwd, the clamp-exact recurrence.
 // 4 packets per 256-thread workgroup: the four waves of a workgroup land on the four SIMDs of one CU, which keeps the
 // 4096 equally long waves of a batch evenly spread (single-wave workgroups were observed to pile up on some SIMDs).
-__global__ __launch_bounds__(256) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
                                                       const float* __restrict__ llr, ulonglong2* __restrict__ surv,
-                                                      const uint32_t* __restrict__ flags, int n)
+                                                      uint32_t* __restrict__ flags, const float* __restrict__ negsym, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
   if (flags[p] != 0) return;
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
+  // bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs: the largest entry of the packet's symbols (c8p_rx: written
+  // by k_demod_sym) or what k_llr_check left in flags[2n + p] (c8p_decode); kept there for the tests (C8P_BUF_DECSTAT)
+  float negb;
+  if (negsym) {
+    const float* ns = negsym + lay[p].sym_base;
+    negb = 0.0f;
+    for (int s = lane_id(); s < t.nsym; s += 64) negb = fmaxf(negb, ns[s]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) negb = fmaxf(negb, __shfl_xor(negb, o, 64));
+    if (lane_id() == 0) flags[2 * n + p] = __float_as_uint(negb);
+  } else negb = __uint_as_float(flags[2 * n + p]);
   const float* L = llr + t.llr_off;
   unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
+#ifdef C8P_EXP_CLOCK   // experiment build (tools/exp_clock.py): shader cycles of this wave and where it ran, instead of the statistics
+  const unsigned long long exp_t0 = clock64();
+  unsigned exp_hw, exp_xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(exp_hw), "=s"(exp_xcc));
+#endif
   switch (t.cr) {
-    case C8P_CR_12: lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv); break;
-    case C8P_CR_23: lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv); break;
-    case C8P_CR_34: lean_forward<C8P_CR_34>(L, t.total, t.trellis, sv); break;
-    default:        lean_forward<C8P_CR_56>(L, t.total, t.trellis, sv); break;
+    case C8P_CR_12: lean_forward<C8P_CR_12>(L, t.total, t.trellis, sv, negb, &flags[n + p]); break;
+    case C8P_CR_23: lean_forward<C8P_CR_23>(L, t.total, t.trellis, sv, negb, &flags[n + p]); break;
+    case C8P_CR_34: lean_forward<C8P_CR_34>(L, t.total, t.trellis, sv, negb, &flags[n + p]); break;
+    default:        lean_forward<C8P_CR_56>(L, t.total, t.trellis, sv, negb, &flags[n + p]); break;
   }
+#ifdef C8P_EXP_CLOCK
+  if (lane_id() == 0) { flags[n + p] = (uint32_t)(clock64() - exp_t0); flags[2 * n + p] = (exp_hw & 0xffffu) | ((exp_xcc & 0xfu) << 16); }
+#endif
 }
 
 // ================================================================================================ finish

@@ -54,23 +54,22 @@ template <int Q> __device__ __forceinline__ unsigned long long lane_bit_mask()
 //
 // DPP operands sit inside inline asm, invisible to the compiler's hazard recogniser: a VGPR written by VALU needs
 // 2 wait states before a DPP read, hence the leading "s_nop 1" of every DPP block.
-struct LeanK {          // lane constants for one exchange phase q
-  float ka, kb;         // keep coefficients   tab[c]   = ka*t0 + kb*t1
-  float sa, sb;         // send coefficients   tab[3-c] = sa*t0 + sb*t1
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct LeanK {          // lane constants for one exchange phase q, as the register pairs the packed instructions read
+  v2f a;                // {ka, sa}: keep / send coefficient of t0   tab[c] = ka*t0 + kb*t1, tab[3-c] = sa*t0 + sb*t1
+  v2f b;                // {kb, sb}: keep / send coefficient of t1
   int cls;              // v_cmp_class mask for d = recv - keep (q <= 3)
 };
 
 #define C8P_CLS_POS 0x380   // +denormal | +normal | +inf
 #define C8P_CLS_NEG 0x01C   // -inf | -normal | -denormal
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 // keep and send are the same arithmetic on (ka,kb) and (sa,sb): one packed-f32 instruction does both
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are two independent IEEE operations, no cross-element effects).
 template <bool HAVE0, bool HAVE1>
 __device__ __forceinline__ v2f cand2(float pre, const LeanK& k, float t0, float t1)
 {
-  const v2f A = {k.ka, k.sa}, B = {k.kb, k.sb}, P = {pre, pre};
+  const v2f A = k.a, B = k.b, P = {pre, pre};
   if (HAVE0 && HAVE1) {
     const v2f T0 = {t0, t0}, T1 = {t1, t1};
     return P + __builtin_elementwise_fma(A, T0, B * T1);     // pre + tab[c], tab[3] = t1 + t0 rounded once
@@ -190,10 +189,42 @@ __device__ __forceinline__ void lean_steps(float& pre, const LeanK (&K)[6], cons
   }
 }
 
+
+#include "c8p_lean_asm.h"   // generated by tools/gen_lean_asm.py: lean_blocks_int<CR>, the integer-compare block loop
+
+// ---- the integer-compare fast path: when is it the same function? --------------------------------------------------
+// For POSITIVE floats the unsigned order of the bit patterns is the float order, so compare / max can be integer
+// instructions — and an integer subtract has a borrow-IN, a per-lane tie rule that the float domain cannot express in one
+// DPP instruction (tools/gen_lean_asm.py explains the step).  The loop may run a block only if every candidate metric
+// computed inside it is > 0.  Every candidate of a block is a block-start metric plus a sub-sum of the block's LLRs, each
+// addition rounded to nearest, so with   N >= sum over the block's LLRs of max(0, -LLR)   and all 64 start metrics >= b:
+//     candidate >= (b - N) (1 - 2^-24)^30 > 0      whenever b >= 1.01 N + 1e-30.
+// N comes from where the LLRs are produced: negb[p] >= the negative-part sum of ANY 60 consecutive LLRs of the packet (60 =
+// the longest block, rate 1/2): k_demod_sym takes 2 (or 3, when a symbol holds fewer than 60 LLRs) times its symbol's
+// negative-part sum, k_llr_check 60 times the largest -LLR.  Path metrics grow by about half the |LLR| mass per step
+// (scrambled data), so a few hundred steps into a packet every block qualifies; the blocks that do not (the first ones, or
+// streams that drive the metrics negative) run the float step below, which is the same function on any input.
+#define C8P_NEGB_WINDOW 60
+
+// lane constants of the integer loop: acc starts every block as `init` (bit 31-k = borrow-in of step k+1: 1 where this
+// lane will hold the even predecessor), and even-holder lanes record the complement of the decision (`flip` undoes it)
+__device__ __forceinline__ void lean_int_consts(int lane, unsigned& init, unsigned& flip)
+{
+  init = 0; flip = 0;
+#pragma unroll
+  for (int k = 0; k < C8P_SV_BLK; k++) {
+    const int qn = (k + 1) % 6, q = k % 6;
+    if (qn <= 3 && !((lane >> qn) & 1)) init |= 1u << (31 - k);
+    if (q <= 3 && !((lane >> q) & 1)) flip |= 1u << (29 - k);
+  }
+}
+
 template <int CR>
-__device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv)
+__device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv, float negb,
+                                             uint32_t* __restrict__ n_float_blocks)
 {
   constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;   // NLB: LLRs per block
+  static_assert(NLB <= C8P_NEGB_WINDOW, "negb covers windows of C8P_NEGB_WINDOW LLRs");
   const int lane = lane_id();
   LeanK K[6];
 #pragma unroll
@@ -202,28 +233,40 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
     const int m = nst & 31, b = nst >> 5;              // b == lane bit q
     const int cK = b ? sv_out(2 * m + 1, 1) : sv_out(2 * m, 0);   // class of the candidate that stays in this lane
     const int cS = 3 - cK;                                         // class of the candidate sent to the partner
-    // q <= 3: (ka,kb) = keep, (sa,sb) = send.
+    // q <= 3: a.x, b.x = keep, a.y, b.y = send.
     // q >= 4: the swap exchanges the upper halves of the first register with the lower halves of the second, so the
     //         first register must hold {bit 0: keep (= a0), bit 1: send (partner's a0)} and the second
     //         {bit 0: send (partner's a1), bit 1: keep (= a1)}.
     const int c1 = (q >= 4 && b) ? cS : cK;
     const int c2 = (q >= 4 && b) ? cK : cS;
-    K[q].ka = (c1 >> 1) ? 1.0f : 0.0f; K[q].kb = (c1 & 1) ? 1.0f : 0.0f;
-    K[q].sa = (c2 >> 1) ? 1.0f : 0.0f; K[q].sb = (c2 & 1) ? 1.0f : 0.0f;
+    K[q].a = v2f{(c1 >> 1) ? 1.0f : 0.0f, (c2 >> 1) ? 1.0f : 0.0f};
+    K[q].b = v2f{(c1 & 1) ? 1.0f : 0.0f, (c2 & 1) ? 1.0f : 0.0f};
     K[q].cls = b ? C8P_CLS_NEG : C8P_CLS_POS;
   }
+  unsigned init, flip;
+  lean_int_consts(lane, init, flip);
+  const float bound = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fmaf(negb, 1.01f, 1e-30f))));
   c4float* L = (c4float*)Lg;
   float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;      // state 0 sits in lane 0 under every rotation
   unsigned acc = 0;
   LeanPend pend = {0u, 0u};
-  int tb = 0, lb = 0;
   float x[NL];
-  unsigned* out = sv + lane;
-  // full survivor blocks: REP super-iterations of PER steps each
+  const int nfull = Tn / C8P_SV_BLK;
+  int left = nfull, nflt = 0;
+  unsigned voff = (unsigned)lane * 4u;              // byte offset of this lane's dword inside the packet's survivor area
   // touch registers: loop-carried ("+s") so that they can never share an SGPR with x[] — the touches are still in
   // flight when the next block's real loads are issued, and scalar loads may return in any order
   unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
-  for (; tb + C8P_SV_BLK <= Tn; tb += C8P_SV_BLK, out += 64) {
+  while (left > 0) {
+    // full survivor blocks, integer compare: as many as keep every metric above the bound
+#ifndef C8P_EXP_NO_INT
+    if (__ballot(pre < bound) == 0ull) {
+      lean_blocks_int<CR>(pre, acc, K, init, flip, bound, voff, Lg + (size_t)(nfull - left) * NLB, sv, left);
+      if (left == 0) break;
+    }
+#endif
+    // one full block with the float step: REP super-iterations of PER steps each
+    int lb = (nfull - left) * NLB;
 #pragma unroll
     for (int r = 0; r < REP; r++, lb += NL) {
 #pragma unroll
@@ -249,11 +292,15 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
       else lean_steps<CR, 0, false, false>(pre, K, x, acc, pend, PER);
     }
     lean_flush<(PER - 1) % 6>(acc, pend);
-    *out = acc;
+    *(unsigned*)((char*)sv + voff) = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4));   // touches land before the integer loop reuses SGPRs
+    voff += 256u; left--; nflt++;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4));   // last touches land before anything reuses the registers
+  if (lane == 0) *n_float_blocks = (uint32_t)nflt;   // diagnostic (C8P_BUF_DECSTAT): blocks that did not qualify for the integer loop
+  const int tb = nfull * C8P_SV_BLK;
   if (tb < Tn) {   // last, partial block: loads clamped to the packet's own LLRs, decisions left-aligned like a full block
     const int rem = Tn - tb;
+    int lb = nfull * NLB;
 #pragma unroll
     for (int r = 0; r < REP; r++, lb += NL) {
       if (r * PER < rem) {
@@ -262,6 +309,6 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
         lean_steps<CR, 0, true, true>(pre, K, x, acc, pend, rem - r * PER);
       }
     }
-    *out = acc << (C8P_SV_BLK - rem);
+    *(unsigned*)((char*)sv + voff) = acc << (C8P_SV_BLK - rem);
   }
 }

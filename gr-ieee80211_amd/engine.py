@@ -241,6 +241,12 @@ class Engine:
     def tags(self):
         return self.fetch(abi.BUF_TAGS, abi.PKT_TAGS_DT)
 
+    def decstat(self):
+        """(range-check flags, float-step block counts, negative-part bounds) of the last decode: C8P_BUF_DECSTAT, 3 x uint32 per packet"""
+        a = self.fetch(abi.BUF_DECSTAT, np.uint32)
+        n = len(a) // 3
+        return a[:n], a[n:2 * n], a[2 * n:].view(np.float32)
+
     def outs(self):
         return self.fetch(abi.BUF_OUT, abi.PKT_OUT_DT)
 

@@ -314,7 +314,11 @@ typedef struct c8p_decode_in {
                                has two chains the buffer holds chain 0 then chain 1 (each half = the whole stream length)       */
 #define C8P_BUF_TX_DESC  15 /* c8p_tx_desc[n_pkt]                                                                              */
 #define C8P_BUF_TX_CODED 16 /* uint8[]: punctured coded bits (encode's output), 1 bit per byte                                 */
-#define C8P_BUF_COUNT    17
+#define C8P_BUF_DECSTAT  17 /* uint32[3 n_pkt], decoder diagnostics (tests, bench): [p] = 1 if the packet's LLRs failed the range check of the fast
+                               Viterbi kernel (it was decoded by the clamp-exact kernel); [n_pkt + p] = number of 30-step trellis blocks the fast
+                               kernel ran with the float compare because their path metrics were not provably positive; [2 n_pkt + p] = float
+                               bits of the bound it was given: >= sum(max(0, -LLR)) over any 60 consecutive LLRs of the packet ([p] = 0 only) */
+#define C8P_BUF_COUNT    18
 
 /* kernels, for c8p_kernel_time() */
 #define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */

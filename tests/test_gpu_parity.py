@@ -488,3 +488,100 @@ def test_sharded_stream_over_rccl_world_of_one():
     for feed in ("rccl_scatter", "direct_h2d"):
         f = res["feeds"][feed]
         assert f["pdus_last_step"] == res["pdus_gathered"] and f["packets_per_s"] > 0
+
+
+def _decode_streams(eng, streams):
+    """decode entry on raw LLR streams [(T, cr, llr)], engine and oracle; returns the engine's float-step block counts"""
+    tags = np.zeros(len(streams), abi.PKT_TAGS_DT)
+    off = 0
+    for k, (T, cr, llr) in enumerate(streams):
+        tags[k]["status"], tags[k]["format"], tags[k]["cr"], tags[k]["trellis"] = abi.ST_OK, abi.F_L, cr, T
+        tags[k]["total"], tags[k]["len"], tags[k]["llr_off"] = len(llr), max(1, min(4095, (T - 22) // 8)), off
+        off += len(llr)
+    allr = np.concatenate([s[2] for s in streams])
+    eng.decode(tags, allr)
+    res = eng.results(want_llr=False, want_bits=True)
+    flags, nflt, _ = eng.decstat()
+    o = oracle()
+    for k, (T, cr, llr) in enumerate(streams):
+        out, pdus, sb, ub = o.decode(tags[k], llr)
+        assert np.array_equal(res[k]["sbits"], sb), (k, T, cr)
+        assert np.array_equal(res[k]["bits"], ub), (k, T, cr)
+        assert res[k]["pdus"] == pdus, (k, T, cr)
+    return flags, nflt
+
+
+def test_integer_compare_blocks_with_ties(eng):
+    """The decoder's integer-compare block loop (positive path metrics: c8p_viterbi_lean.h) against the oracle on streams that
+    keep it busy: mostly positive LLRs (the metrics climb above the bound within a few blocks), quantised to 1/4 so that exact
+    metric ties are frequent — the per-lane borrow-in IS the tie rule there.  All four code rates; the statistics buffer must
+    show that the integer loop really ran."""
+    rng = np.random.default_rng(4242)
+    streams = []
+    for cr, per in ((abi.CR_12, 2.0), (abi.CR_23, 1.5), (abi.CR_34, 4.0 / 3.0), (abi.CR_56, 1.2)):
+        for T in (600, 1801, 5999, 11960):
+            n = int(np.ceil(T * per)) + 2
+            mag = np.round(np.abs(rng.normal(0, 1.5, size=n)) * 4) / 4
+            sgn = np.where(rng.random(n) < 0.85, 1.0, -1.0)
+            llr = (mag * sgn).astype(np.float32)
+            if T == 1801:
+                llr = np.round(llr)                        # integers: even more ties
+            streams.append((T, cr, llr))
+    flags, nflt = _decode_streams(eng, streams)
+    assert not flags.any()
+    for k, (T, cr, llr) in enumerate(streams):
+        if T >= 5999:
+            assert nflt[k] < 0.5 * (T // 30), (T, cr, int(nflt[k]))   # most blocks took the integer loop
+
+
+def test_integer_compare_loop_is_left_when_metrics_fall(eng):
+    """A burst of large negative LLRs widens the spread of the path metrics: the state metrics at the bottom fall below the
+    bound the integer loop needs, the loop is left for the float step and entered again later.  Bits identical to the oracle;
+    streams whose metrics never qualify (all-negative LLRs, all-zero LLRs) run the float step throughout."""
+    rng = np.random.default_rng(99)
+    streams = []
+    for cr, per in ((abi.CR_12, 2.0), (abi.CR_34, 4.0 / 3.0), (abi.CR_56, 1.2)):
+        T = 6000
+        n = int(np.ceil(T * per)) + 2
+        llr = np.where(rng.random(n) < 0.9, 2.0, -0.25).astype(np.float32)
+        llr += (np.round(rng.normal(0, 0.5, size=n) * 4) / 4).astype(np.float32) * (llr > 0)
+        llr = np.maximum(llr, -0.25).astype(np.float32)
+        b0 = int(n * 0.75)
+        llr[b0:b0 + 48] = -150.0                           # bound = 60 x 150: reached after some thousand steps
+        llr[n - 5] = -200.0
+        streams.append((T, cr, llr))
+    T = 3000
+    streams.append((T, abi.CR_12, -np.abs(np.round(rng.normal(0, 2, size=2 * T + 2) * 4) / 4).astype(np.float32)))
+    streams.append((T, abi.CR_56, np.zeros(int(T * 1.2) + 2, np.float32)))
+    flags, nflt = _decode_streams(eng, streams)
+    assert not flags.any()
+    assert nflt[3] == T // 30 and nflt[4] == T // 30       # never positive: float step throughout
+    for k in range(3):
+        assert 0 < nflt[k] < 6000 // 30, int(nflt[k])
+
+
+def test_negative_part_bound_of_the_symbol_demodulator(eng):
+    """c8p_rx: the bound the decoder's integer loop relies on (C8P_BUF_DECSTAT[2n + p]) is at least the sum of max(0, -LLR) over any 60
+    consecutive LLRs of the packet: k_demod_sym sums per OFDM symbol on the DPP path, the decoder takes 2 (3) times the largest symbol."""
+    b, meta = sweep_batch(snr_db=20.0, seed=5)
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    eng.sync()
+    tags = eng.tags()
+    llr = eng.fetch(abi.BUF_LLR, np.float32)
+    flags, nflt, bound = eng.decstat()
+    checked = 0
+    for p in range(len(pk)):
+        t = tags[p]
+        if t["status"] != abi.ST_OK or t["is_ndp"] or flags[p] or t["trellis"] <= 0:
+            continue
+        l = llr[int(t["llr_off"]):int(t["llr_off"]) + int(t["total"])].astype(np.float64)
+        neg = np.maximum(-l, 0.0)
+        ncbps = int(t["ncbps"])
+        per_sym = neg[:int(t["nsym"]) * ncbps].reshape(-1, ncbps).sum(axis=1)
+        want = per_sym.max() * (2.0 if ncbps >= 60 else 3.0)
+        assert abs(bound[p] - want) <= 1e-4 * max(want, 1.0), (p, bound[p], want)
+        win = np.convolve(neg, np.ones(60), mode="valid").max() if len(neg) >= 60 else neg.sum()
+        assert bound[p] >= win * (1 - 1e-6)
+        checked += 1
+    assert checked > 20

@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""tools/gen_lean_asm.py — writes gr-ieee80211_amd/csrc/c8p_lean_asm.h: the full-block loop of the lean Viterbi forward pass
+(c8p_viterbi_lean.h) as ONE inline-asm statement per code rate, in two flavours.
+
+  lean_blocks_int<CR>   the production fast path.  When every path metric of a block is known to stay POSITIVE, the unsigned
+                        order of the float bit patterns is the float order, and the compare can be an integer subtract with
+                        borrow.  That buys what the float domain cannot: a per-lane carry-IN, i.e. a per-lane tie rule, in the
+                        same instruction that reads the partner lane through DPP.  A DPP step is then 4 VALU instructions
+                        (candidates, borrow, record, max) instead of 5 (candidates, difference, class test, record, max).
+  lean_blocks_asm<CR>   the float step of c8p_viterbi_lean.h, instruction for instruction (-DC8P_LEAN_ASM, experiments only).
+
+Why one asm statement: the borrow chain lives in VCC across every step of the loop, and the compiler may use VCC between two
+asm statements; DPP operands inside inline asm are also invisible to its hazard recogniser.
+
+The step (both flavours share the candidates):
+    cand  = {keep, send} = P + A(q) * t0 (+ B(q) * t1)          v_pk_fma_f32 (+ v_pk_mul_f32, v_pk_add_f32 when both LLRs exist)
+  float:
+    q <= 3:  d = recv - keep, pre = max(recv, keep)              v_sub_f32_dpp / v_max_f32_dpp   (q == 2: one v_mov_b32_dpp more)
+    q >= 4:  swap, pre = max(a0, a1)                             v_permlane{16,32}_swap_b32, v_max_f32
+    decision of the PREVIOUS step, in the two wait states a DPP read needs after the write of its source:
+             v_cmp_class_f32 (d, per-lane class mask) or v_cmp_gt_f32 (a1, a0) -> vcc -> v_addc_co_u32 acc, acc, acc
+  integer (all candidates > 0):
+    q <= 3:  pre = max_u32(recv, keep)                           v_max_u32_dpp
+    q >= 4:  swap, pre = max_u32(a0, a1)
+    decision of the PREVIOUS step:
+             q <= 3:  vcc = borrow(recv - keep - cin)            v_subb_co_u32_dpp      cin = 1 on lanes holding the EVEN predecessor
+             q >= 4:  vcc = borrow(a0 - a1)                      v_sub_co_u32
+             acc = 2 acc + vcc, vcc = old acc[31]                v_addc_co_u32
+      The reference takes the odd predecessor only on strict '>' (decode_impl.cc:231-259).  A lane holding the odd predecessor
+      (lane bit q = 1: keep = odd, recv = even) wants [keep > recv] = borrow(recv - keep).  A lane holding the even one wants
+      [recv > keep] = NOT [recv <= keep] = NOT borrow(recv - keep - 1).  So with cin = 1 on the even-holders the borrow is the
+      decision on odd-holders and its complement on even-holders, exact on ties; the complement is undone with one XOR per
+      block (lane constant `flip`).  The carry-in costs nothing: acc starts every block as a lane constant `init` whose bit
+      31 - k is the cin of step k + 1, and v_addc's carry-OUT (the bit shifted out of acc) is the next v_subb's carry-IN.
+      Before every block all lanes are checked against `bound` (c8p_viterbi_lean.h); the loop leaves at the first block whose
+      start metrics do not guarantee positive candidates, and the caller runs that block with the float step.
+
+Registers: v62 = pre (read as the pair v[62:63] with both halves taken from v62), v63 = acc, v[56:57] / v[58:59] = candidate
+pairs (alternating), v[54:55] / v[60:61] = branch-metric pairs, v52 / v53 = d (alternating; integer: v52 = unused difference),
+v51 = q=2 intermediate, v50 = byte offset of this lane's survivor dword.  SGPRs: two sets of LLR registers filled alternately
+(one load group in flight at a time), s[56:57] next block's LLRs, s[58:59] this block's, s60 blocks left, s[62:63] check mask.
+"""
+import os
+
+EXP = os.environ.get("C8P_GEN_EXP", "")      # timing experiments only (results are wrong): nowait, nostore, nocheck
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gr-ieee80211_amd", "csrc", "c8p_lean_asm.h")
+
+BLK = 30
+RATES = {"12": 0, "23": 1, "34": 2, "56": 3}   # name: C8P_CR_* value
+
+
+def idx(cr, j):
+    """positions of (t0, t1) of step j inside the block's LLRs, None = punctured (c8p_viterbi_lean.h idx0 / idx1 per period)"""
+    if cr == "12":
+        return 2 * j, 2 * j + 1
+    if cr == "23":
+        b, r = divmod(j, 2)
+        return (3 * b + (2 if r else 0)), (None if r else 3 * b + 1)
+    if cr == "34":
+        b, r = divmod(j, 3)
+        i0 = None if r == 2 else 4 * b + (2 if r == 1 else 0)
+        i1 = 4 * b + 1 if r == 0 else (4 * b + 3 if r == 2 else None)
+        return i0, i1
+    b, r = divmod(j, 5)
+    i0 = {0: 6 * b, 1: 6 * b + 2, 3: 6 * b + 4}.get(r)
+    i1 = {0: 6 * b + 1, 2: 6 * b + 3, 4: 6 * b + 5}.get(r)
+    return i0, i1
+
+
+NLB = {"12": 60, "23": 45, "34": 40, "56": 36}
+NGRP = {"12": 4, "23": 4, "34": 2, "56": 2}     # load groups per block (two register sets, used alternately)
+SETBASE = (12, 36)    # first SGPR of the two LLR register sets (multiples of 4; s32 / s33 and the top of the file are reserved)
+SETSZ = 20            # SGPRs per register set
+PTR = 56              # s[56:57] next block, s[58:59] this block, s60 blocks left, s[62:63] positivity check
+DPP = {0: "quad_perm:[1,0,3,2]", 1: "quad_perm:[2,3,0,1]", 3: "row_ror:8"}
+RM = " row_mask:0xf bank_mask:0xf"
+ADDC = "v_addc_co_u32_e32 v63, vcc, v63, v63, vcc"
+
+
+def gen_rate(cr, integer):
+    n, G = NLB[cr], NGRP[cr]
+    steps = [idx(cr, j) for j in range(BLK)]
+    # group g = the LLRs first used by steps [bounds[g], bounds[g+1]); consecutive LLR ranges
+    bounds = [round(g * BLK / G) for g in range(G + 1)]
+    gstart = []
+    for g in range(G):
+        gstart.append(min(x for j in range(bounds[g], bounds[g + 1]) for x in steps[j] if x is not None))
+    gstart.append(n)
+    for g in range(G):
+        used = [x for j in range(bounds[g], bounds[g + 1]) for x in steps[j] if x is not None]
+        assert min(used) >= gstart[g] and max(used) < gstart[g + 1] and gstart[g + 1] - gstart[g] <= SETSZ
+
+    def sreg(i):            # SGPR of LLR i of the block
+        g = max(k for k in range(G) if gstart[k] <= i)
+        return SETBASE[g % 2] + (i - gstart[g])
+
+    def sgpr_pair(i):
+        r = sreg(i)
+        return "s[%d:%d]" % (r & ~1, (r & ~1) + 1), r & 1
+
+    L = []
+    emit = L.append
+    cur, nxt, cnt, chk = "s[%d:%d]" % (PTR + 2, PTR + 3), "s[%d:%d]" % (PTR, PTR + 1), "s%d" % (PTR + 4), "s[%d:%d]" % (PTR + 6, PTR + 7)
+
+    def load_group(g, ptr):
+        """s_load instructions of group g: sizes 16/8/4/2/1, an N-dword destination starts at a multiple of min(N, 4)"""
+        i, hi = gstart[g], gstart[g + 1]
+        while i < hi:
+            for k in (16, 8, 4, 2, 1):
+                if i + k <= hi and sreg(i) % min(k, 4) == 0:
+                    sz = {1: "dword", 2: "dwordx2", 4: "dwordx4", 8: "dwordx8", 16: "dwordx16"}[k]
+                    dst = "s%d" % sreg(i) if k == 1 else "s[%d:%d]" % (sreg(i), sreg(i) + k - 1)
+                    emit("s_load_%s %s, %s, 0x%x" % (sz, dst, ptr, 4 * i))
+                    i += k
+                    break
+
+    # ---- prologue: registers, the first group of the first block
+    emit("v_mov_b32 v62, %[pre]")
+    emit("v_mov_b32 v63, %s" % ("%[init]" if integer else "%[acc]"))
+    emit("v_mov_b32 v50, %[voff]")
+    emit("s_mov_b64 %s, %%[llr]" % cur)
+    emit("s_mov_b32 %s, %%[nblk]" % cnt)
+    if integer:     # carry-in of the first step (q = 0): the lanes holding the even predecessor = lane bit 0 clear
+        emit("s_mov_b32 vcc_lo, 0x55555555")
+        emit("s_mov_b32 vcc_hi, 0x55555555")
+    load_group(0, cur)
+    emit("1:")
+    if integer and "prio" in EXP:
+        # issue priority by block parity: a wave that runs ahead of its SIMD neighbours drops to priority 0 when it enters an odd
+        # block while they are still in the even one (the arbiter otherwise serves the oldest wave first, the waves of a SIMD finish
+        # one after the other and the last one runs alone, latency-bound)
+        emit("s_bitcmp1_b32 %s, 0" % cnt)
+        emit("s_cbranch_scc1 3f")
+        emit("s_setprio 1")
+        emit("s_branch 4f")
+        emit("3:")
+        emit("s_setprio 0")
+        emit("4:")
+    # next block's pointer, clamped to the last full block (the refills of the last iteration re-read valid addresses)
+    emit("s_add_u32 s%d, s%d, %d" % (PTR, PTR + 2, 4 * n))
+    emit("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 3))
+    emit("s_cmp_gt_u32 %s, 1" % cnt)
+    emit("s_cselect_b32 s%d, s%d, s%d" % (PTR, PTR, PTR + 2))
+    emit("s_cselect_b32 s%d, s%d, s%d" % (PTR + 1, PTR + 1, PTR + 3))
+    pend = None                                              # decision pending from the previous step
+    # Steps with both LLRs need tab = A*t0 + B*t1 (one rounding) before pre is added: that pair does not depend on the path
+    # metrics, so it is computed one two-LLR step ahead (alternating v[54:55] / v[60:61]), off the pre -> pre critical path.
+    two = [j for j in range(BLK) if steps[j][0] is not None and steps[j][1] is not None]
+    tabreg = {j: (54 if k % 2 == 0 else 60) for k, j in enumerate(two)}
+
+    def emit_tab(j):
+        q, (i0, i1), t = j % 6, steps[j], tabreg[j]
+        p0, s0 = sgpr_pair(i0)
+        p1, s1 = sgpr_pair(i1)
+        emit("v_pk_mul_f32 v[%d:%d], %%[kb%d], %s op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, q, p1, s1, s1))
+        emit("v_pk_fma_f32 v[%d:%d], %%[ka%d], %s, v[%d:%d] op_sel:[0,%d,0] op_sel_hi:[1,%d,1]" % (t, t + 1, q, p0, t, t + 1, s0, s0))
+
+    def emit_pend(p):
+        if p is None:
+            emit("s_nop 1")
+        elif p[0] == "cls":                                  # float, DPP step: class test of d
+            emit("v_cmp_class_f32_e32 vcc, v%d, %%[cls%d]" % (p[1], p[2]))
+            emit(ADDC)
+        elif p[0] == "gt":                                   # float, swap step: a1 > a0
+            emit("v_cmp_gt_f32_e32 vcc, v%d, v%d" % (p[1], p[2]))
+            emit(ADDC)
+        elif p[0] == "subb":                                 # integer, DPP step: borrow(recv - keep - cin)
+            emit("v_subb_co_u32_dpp v52, vcc, v%d, v%d, vcc %s%s" % (p[1], p[2], p[3], RM))
+            emit(ADDC)
+        else:                                                # integer, swap step: borrow(a0 - a1) = [a1 > a0]
+            emit("v_sub_co_u32_e32 v52, vcc, v%d, v%d" % (p[1], p[2]))
+            emit(ADDC)
+
+    def group_of_step(j):
+        return max(g for g in range(G) if bounds[g] <= j)
+    hoisted = set()
+    vmax = "v_max_u32" if integer else "v_max_f32"
+    for j in range(BLK):
+        q = j % 6
+        i0, i1 = steps[j]
+        c = 56 if j % 2 == 0 else 58
+        d = 52 if j % 2 == 0 else 53
+        if j in bounds[:-1]:
+            # group g was requested one group ago and is the only load in flight: wait (no stall), then request the next
+            # group into the other register set (whose LLRs were used up by the previous group)
+            g = bounds.index(j)
+            if "nowait" not in EXP or j == 0:
+                emit("s_waitcnt lgkmcnt(0)")
+            if g + 1 < G:
+                load_group(g + 1, cur)
+            else:
+                load_group(0, nxt)
+        # candidates
+        if i0 is not None and i1 is not None:
+            if j not in hoisted:
+                emit_tab(j)
+            t = tabreg[j]
+            emit("v_pk_add_f32 v[%d:%d], v[62:63], v[%d:%d] op_sel:[0,0] op_sel_hi:[0,1]" % (c, c + 1, t, t + 1))
+            # the next two-LLR step's pair, if its LLRs are already here (same load group): issued now, used ~5 steps later
+            nx = [k for k in two if k > j]
+            if nx and group_of_step(nx[0]) == group_of_step(j):
+                emit_tab(nx[0])
+                hoisted.add(nx[0])
+        elif i0 is not None:
+            p0, s0 = sgpr_pair(i0)
+            emit("v_pk_fma_f32 v[%d:%d], %%[ka%d], %s, v[62:63] op_sel:[0,%d,0] op_sel_hi:[1,%d,0]" % (c, c + 1, q, p0, s0, s0))
+        else:
+            p1, s1 = sgpr_pair(i1)
+            emit("v_pk_fma_f32 v[%d:%d], %%[kb%d], %s, v[62:63] op_sel:[0,%d,0] op_sel_hi:[1,%d,0]" % (c, c + 1, q, p1, s1, s1))
+        # the previous step's decision fills the two wait states the DPP / permlane read of the candidates needs
+        emit_pend(pend)
+        if q in DPP:
+            if integer:
+                emit("%s_dpp v62, v%d, v%d %s%s" % (vmax, c + 1, c, DPP[q], RM))
+                pend = ("subb", c + 1, c, DPP[q])
+            else:
+                emit("v_sub_f32_dpp v%d, v%d, v%d %s%s" % (d, c + 1, c, DPP[q], RM))
+                emit("%s_dpp v62, v%d, v%d %s%s" % (vmax, c + 1, c, DPP[q], RM))
+                pend = ("cls", d, q)
+        elif q == 2:      # lane^3 inside the quad, then mirror inside 8 lanes (lane^7): together lane^4
+            emit("v_mov_b32_dpp v51, v%d quad_perm:[3,2,1,0]%s" % (c + 1, RM))
+            emit("s_nop 1")
+            if integer:
+                emit("%s_dpp v62, v51, v%d row_half_mirror%s" % (vmax, c, RM))
+                pend = ("subb", 51, c, "row_half_mirror")
+            else:
+                emit("v_sub_f32_dpp v%d, v51, v%d row_half_mirror%s" % (d, c, RM))
+                emit("%s_dpp v62, v51, v%d row_half_mirror%s" % (vmax, c, RM))
+                pend = ("cls", d, q)
+        else:
+            emit("v_permlane%d_swap_b32 v%d, v%d" % (16 if q == 4 else 32, c, c + 1))
+            emit("%s v62, v%d, v%d" % (vmax, c, c + 1))
+            pend = ("sub", c, c + 1) if integer else ("gt", c + 1, c)
+    # flush the last decision, store the block's survivor word of every lane, next block
+    emit_pend(pend)
+    emit("s_mov_b64 %s, %s" % (cur, nxt))
+    emit("s_sub_u32 %s, %s, 1" % (cnt, cnt))
+    if integer:
+        emit("v_xor_b32 v63, %[flip], v63")                  # even-holder lanes recorded the complement
+    if "nostore" not in EXP:
+        emit("global_store_dword v50, v63, %[sv]")
+    emit("v_add_u32 v50, 0x100, v50")
+    if integer:
+        emit("v_mov_b32 v63, %[init]")
+        emit("v_cmp_gt_f32_e64 %s, %%[bound], v62" % chk)    # a lane whose metric is below the bound: leave
+        emit("s_cmp_eq_u32 %s, 0" % cnt)
+        emit("s_cbranch_scc1 2f")
+        if "nocheck" not in EXP:
+            emit("s_cmp_eq_u64 %s, 0" % chk)
+        emit("s_cbranch_scc1 1b")
+        emit("2:")
+    else:
+        emit("s_cmp_lg_u32 %s, 0" % cnt)
+        emit("s_cbranch_scc1 1b")
+    emit("s_waitcnt lgkmcnt(0)")                             # the last refill lands before anything reuses its registers
+    if integer and "prio" in EXP:
+        emit("s_setprio 0")
+    emit("v_mov_b32 %[pre], v62")
+    emit("v_mov_b32 %[acc], v63")
+    emit("v_mov_b32 %[voff], v50")
+    emit("s_mov_b32 %%[nblk], %s" % cnt)
+    body = "\n".join('      "%s\\n\\t"' % x for x in L)
+    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(8)] + \
+           ['"s%d"' % (b + i) for b in SETBASE for i in range(SETSZ)] + ['"v%d"' % r for r in range(50, 64)]
+    ins = ['[ka%d] "v"(K[%d].a)' % (q, q) for q in range(6)] + ['[kb%d] "v"(K[%d].b)' % (q, q) for q in range(6)]
+    if integer:
+        ins += ['[init] "v"(init)', '[flip] "v"(flip)', '[bound] "s"(bound)']
+    else:
+        ins += ['[cls%d] "v"(K[%d].cls)' % (q, q) for q in range(4)]
+    ins += ['[llr] "s"(llr)', '[sv] "s"(sv)']
+    n_valu = sum(1 for x in L if x.startswith("v_") and "%[pre]" not in x and "%[acc]" not in x and "v50" not in x
+                 and "v_cmp_gt_f32_e64" not in x and "%[init]" not in x and "%[flip]" not in x)
+    name = "lean_blocks_int" if integer else "lean_blocks_asm"
+    extra = "unsigned init, unsigned flip, float bound, " if integer else ""
+    return """
+// code rate %s: %d LLRs per block in %d load groups; %d VALU instructions per 30 steps (%.2f per step)
+template <> __device__ __forceinline__ void %s<%d>(float& pre, unsigned& acc, const LeanK (&K)[6], %sunsigned& voff,
+                                                                 const float* llr, unsigned* sv, int& nblk)
+{
+  asm volatile(
+%s
+      : [pre] "+v"(pre), [acc] "+v"(acc), [voff] "+v"(voff), [nblk] "+s"(nblk)
+      : %s
+      : %s);
+}
+""" % (cr, n, G, n_valu, n_valu / 30.0, name, RATES[cr], extra, body, ", ".join(ins), ", ".join(clob)), n_valu
+
+
+def main():
+    parts, counts = [], {}
+    for integer in (True, False):
+        if not integer:
+            parts.append("\n#ifdef C8P_LEAN_ASM\n")
+        for cr in ("12", "23", "34", "56"):
+            txt, nv = gen_rate(cr, integer)
+            parts.append(txt)
+            counts[(cr, integer)] = nv
+        if not integer:
+            parts.append("#endif\n")
+    hdr = """// c8p_lean_asm.h — GENERATED by tools/gen_lean_asm.py (do not edit; edit the generator, which documents the step).
+//
+// The full-block loop of the lean Viterbi forward pass as one inline-asm statement per code rate.
+//   lean_blocks_int<CR>: integer compare with a per-lane borrow-in (all candidates positive); leaves at the first block whose
+//                        start metrics are not all >= bound.  VALU instructions per 30-step block:
+//                        rate 1/2: %d   2/3: %d   3/4: %d   5/6: %d
+//   lean_blocks_asm<CR>: the float step of c8p_viterbi_lean.h (-DC8P_LEAN_ASM, experiments):
+//                        rate 1/2: %d   2/3: %d   3/4: %d   5/6: %d
+// In / out: pre, acc, voff (byte offset of this lane's survivor dword), nblk (full blocks left; 0 when all were done).
+#pragma once
+
+template <int CR> __device__ __forceinline__ void lean_blocks_int(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned init, unsigned flip,
+                                                                   float bound, unsigned& voff, const float* llr, unsigned* sv, int& nblk);
+template <int CR> __device__ __forceinline__ void lean_blocks_asm(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned& voff,
+                                                                   const float* llr, unsigned* sv, int& nblk);
+""" % tuple(counts[(cr, i)] for i in (True, False) for cr in ("12", "23", "34", "56"))
+    open(OUT, "w").write(hdr + "".join(parts))
+    print("wrote", OUT, {("%s%s" % (k[0], "i" if k[1] else "f")): v for k, v in counts.items()})
+
+
+if __name__ == "__main__":
+    main()

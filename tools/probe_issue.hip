@@ -147,7 +147,7 @@ PROBE(p_swizzle, "ds_swizzle_b32 %[a0], %[a0] offset:0x401f\n\tds_swizzle_b32 %[
 // ---- whole trellis steps, as the lean kernel issues them (dependent through a0 = path metric) ---------------------
 // (explicit registers v[100:107]: the packed result pair is read as two 32-bit DPP operands)
 // current q=0 step with one LLR: pk_fma(keep,send) ; [decision of the previous step] ; sub_dpp ; max_dpp       = 5 VALU
-#define HARD "vcc", "s40", "s41", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"
+#define HARD "vcc", "s40", "s41", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109"
 #define PROBE_HARD(NAME, BODY)                                                                                        \
   __global__ __launch_bounds__(1024) void NAME(float* sink, Out* out, const float* seed, int iters)                  \
   {                                                                                                                   \
@@ -155,7 +155,8 @@ PROBE(p_swizzle, "ds_swizzle_b32 %[a0], %[a0] offset:0x401f\n\tds_swizzle_b32 %[
     (void)lds_pad;                                                                                                    \
     PROLOGUE                                                                                                          \
     asm volatile("v_mov_b32 v100, %0\n\tv_mov_b32 v101, %1\n\tv_mov_b32 v102, %0\n\tv_mov_b32 v103, 0\n\tv_mov_b32 v104, 0\n\t" \
-                 "v_mov_b32 v105, 0\n\tv_mov_b32 v106, 1.0\n\tv_mov_b32 v107, 0" ::"v"(a0), "v"(a1) : HARD);           \
+                 "v_mov_b32 v105, 0\n\tv_mov_b32 v106, 1.0\n\tv_mov_b32 v107, 0\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v109, %2"       \
+                 ::"v"(a0), "v"(a1), "v"(((threadIdx.x ^ 32u) & 63u) * 4u) : HARD);                                    \
     for (int i = 0; i < iters; i++) {                                                                                 \
       _Pragma("unroll") for (int r = 0; r < REP; r++) asm volatile(BODY : [u0] "+v"(u0) : [u1] "v"(u1), INS : HARD);  \
     }                                                                                                                 \
@@ -238,6 +239,41 @@ PROBE_HARD(p_step_swap_sign, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:
                              "v_sub_f32 v105, v104, v103\n\tv_alignbit_b32 %[u0], %[u0], v105, 31\n\t"
                              "v_permlane16_swap_b32 v100, v101\n\tv_max_f32 v102, v100, v101")
 
+// ---- third set: integer-compare step (all candidates positive: unsigned order of the bit patterns = float order) and LDS-pipe
+// exchanges for the lane bits 4 / 5.  v108 = d (integer difference, unused), v109 = byte address of lane ^ 32 for ds_bpermute.
+// DPP step: pk_fma ; addc (records the previous decision, its carry-out = the per-lane tie rule of this step) ; subb_dpp ; max_u32_dpp
+PROBE_HARD(p_step_int, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                       "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\ts_nop 0\n\t"
+                       "v_subb_co_u32_dpp v108, vcc, v101, v100, vcc" DPPQ "\n\tv_max_u32_dpp v102, v101, v100" DPPQ)
+// the same with v_cndmask_b32_dpp as the selector
+PROBE_HARD(p_step_int_cnd, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                           "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\ts_nop 0\n\t"
+                           "v_subb_co_u32_dpp v108, vcc, v101, v100, vcc" DPPQ "\n\tv_cndmask_b32_dpp v102, v101, v100, vcc" DPPQ)
+// lane bit 4 through ds_swizzle (LDS pipe, no VALU slot), float compare: pk_fma ; swizzle ; cmp_class ; addc ; wait ; sub ; max
+PROBE_HARD(p_step_swz, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                       "v_cmp_class_f32_e32 vcc, v104, %[u1]\n\tds_swizzle_b32 v105, v101 offset:0x401f\n\t"
+                       "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\ts_waitcnt lgkmcnt(0)\n\t"
+                       "v_sub_f32 v104, v105, v100\n\tv_max_f32 v102, v105, v100")
+// lane bit 4 through ds_swizzle, integer compare: pk_fma ; swizzle ; addc ; wait ; subb ; max_u32
+PROBE_HARD(p_step_swz_int, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                           "ds_swizzle_b32 v105, v101 offset:0x401f\n\t"
+                           "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\ts_waitcnt lgkmcnt(0)\n\t"
+                           "v_subb_co_u32_e32 v108, vcc, v105, v100, vcc\n\tv_max_u32 v102, v105, v100")
+// lane bit 5 through ds_bpermute, integer compare
+PROBE_HARD(p_step_bperm_int, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                             "ds_bpermute_b32 v105, v109, v101\n\t"
+                             "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\ts_waitcnt lgkmcnt(0)\n\t"
+                             "v_subb_co_u32_e32 v108, vcc, v105, v100, vcc\n\tv_max_u32 v102, v105, v100")
+// swap step, integer compare: pk_fma ; swap ; addc ; sub_co ; max
+PROBE_HARD(p_step_swap_int, "v_pk_fma_f32 v[100:101], v[106:107], %[sp], v[102:103] op_sel_hi:[1,0,0]\n\t"
+                            "v_addc_co_u32_e32 %[u0], vcc, %[u0], %[u0], vcc\n\t"
+                            "v_permlane16_swap_b32 v100, v101\n\tv_sub_co_u32_e32 v108, vcc, v100, v101\n\tv_max_u32 v102, v100, v101")
+PROBE(p_subb_dpp, "v_subb_co_u32_dpp %[a0], vcc, %[b0], %[b1], vcc" DPPQ "\n\tv_subb_co_u32_dpp %[a1], vcc, %[b1], %[b2], vcc" DPPQ "\n\t"
+                  "v_subb_co_u32_dpp %[a2], vcc, %[b2], %[b3], vcc" DPPQ "\n\tv_subb_co_u32_dpp %[a3], vcc, %[b3], %[b0], vcc" DPPQ "\n\t"
+                  "v_subb_co_u32_dpp %[a4], vcc, %[b0], %[b2], vcc" DPPQ "\n\tv_subb_co_u32_dpp %[a5], vcc, %[b1], %[b3], vcc" DPPQ "\n\t"
+                  "v_subb_co_u32_dpp %[a6], vcc, %[b2], %[b0], vcc" DPPQ "\n\tv_subb_co_u32_dpp %[a7], vcc, %[b3], %[b1], vcc" DPPQ)
+PROBE(p_max_u32_dpp, DPP8("v_max_u32_dpp", DPPQ))
+
 struct Probe { const char* name; void (*fn)(float*, Out*, const float*, int); int ni; const char* what; };
 #define E(NAME, NI, WHAT) {#NAME, NAME, NI, WHAT}
 static const Probe probes[] = {
@@ -301,6 +337,14 @@ static const Probe probes[] = {
   E(p_ldsbc_fma, 8, "8 v_fma_f32 + one broadcast ds_read_b128 (counted as 8)"),
   E(p_step_sign, 1, "DPP step, sign trick: pk_fma, fma, alignbit, sub_dpp, max_dpp      (cycles per STEP)"),
   E(p_step_swap_sign, 1, "swap step, sign trick: pk_fma, sub, alignbit, swap, max         (cycles per STEP)"),
+  E(p_step_int, 1, "DPP step, integer compare: pk_fma, addc, subb_dpp, max_u32_dpp            (cycles per STEP)"),
+  E(p_step_int_cnd, 1, "DPP step, integer compare: pk_fma, addc, subb_dpp, cndmask_dpp        (cycles per STEP)"),
+  E(p_step_swz, 1, "bit-4 step via ds_swizzle: pk_fma, swizzle, cmp_class, addc, sub, max      (cycles per STEP)"),
+  E(p_step_swz_int, 1, "bit-4 step via ds_swizzle, integer: pk_fma, swizzle, addc, subb, max_u32 (cycles per STEP)"),
+  E(p_step_bperm_int, 1, "bit-5 step via ds_bpermute, integer: pk_fma, bpermute, addc, subb, max_u32 (cycles per STEP)"),
+  E(p_step_swap_int, 1, "swap step, integer: pk_fma, addc, swap16, sub_co, max_u32              (cycles per STEP)"),
+  E(p_subb_dpp, 8, "v_subb_co_u32_dpp (vcc in/out)"),
+  E(p_max_u32_dpp, 8, "v_max_u32_dpp quad_perm"),
   E(p_chain_dpp, 1, "metric chain only: fma, fma, s_nop 1, max_dpp                    (cycles per STEP)"),
 };
 
