@@ -390,9 +390,13 @@ static int plan_decode(c8p_ctx* c, const c8p_decode_in* in, Plan& P)
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// c8p_rx hands over what the fused single-stream kernel needs (k_rx_1ss); c8p_decode passes nullptr
+struct RxFuse { const c8p_pkt_in* d_pk; const cf* d_iq; const cf* d_chan; bool any_2ant; };
+
 static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
-                              const cf* d_mu, const Plan& P, bool flags_ready)
+                              const cf* d_mu, const Plan& P, const RxFuse* rx)
 {
+  const bool flags_ready = rx != nullptr;
   int rc;
   if ((rc = ensure(c, c->s->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_surv, sizeof(ulonglong2) * P.surv)) != C8P_OK) return rc;
@@ -408,8 +412,14 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
-      hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
-                         (uint32_t*)c->s->d_flags.p, flags_ready ? (const float*)c->s->d_negsym.p : nullptr, n);
+      // c8p_rx: single-stream packets are demodulated AND decoded by k_rx_1ss; two-stream packets (only possible with two antennas)
+      // went through k_demod_sym and are decoded by k_viterbi_lean, as every packet of a c8p_decode batch is
+      if (rx)
+        hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
+                           d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+      if (!rx || rx->any_2ant)
+        hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+                           (uint32_t*)c->s->d_flags.p, rx ? (const float*)c->s->d_negsym.p : nullptr, rx ? rx->d_pk : nullptr, n);
     }
     hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
   }
@@ -487,18 +497,23 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
                        (c8p_pkt_tags*)c->s->d_tags.p, (cf*)c->s->d_H.p, (Mimo*)c->s->d_mimo.p, (cf*)c->s->d_muchan.p, (uint32_t*)c->s->d_flags.p,
                        (uint32_t*)c->s->d_sym2pkt.p, n);
   }
-  {
+  bool any_2ant = false;
+  for (int p = 0; p < n; p++) any_2ant |= in->pkts[p].n_ant == 2;
+  const bool fused = with_decode && !c->exact_only;      // C8P_EXACT_VITERBI: plain demodulation, the clamp-exact decoder for everything
+  if (!fused || any_2ant) {             // c8p_rx: only the two-stream packets (single-stream ones belong to k_rx_1ss)
     KTimer kt(c, C8P_K_DEMOD);
     hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, (const uint32_t*)c->s->d_sym2pkt.p, d_lay,
                        (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->s->d_tags.p, (const cf*)c->s->d_H.p,
-                       (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, (float*)c->s->d_negsym.p, n, P.syms);
+                       (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p, (uint32_t*)c->s->d_flags.p, (float*)c->s->d_negsym.p, n, P.syms,
+                       fused ? 1 : 0);
   }
   HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = c->s->d_tags.p;
   c->s->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
   c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
   if (!with_decode) return C8P_OK;
-  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, true);
+  const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant};
+  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, &rx);
 }
 
 extern "C" int c8p_demod(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, false); }
@@ -553,7 +568,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
     d_mu = (const cf*)c->s->d_mu_in.p;
   }
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = d_tags;
-  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, false);
+  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, nullptr);
 }
 
 extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)

@@ -547,14 +547,10 @@ __device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_
     default: return llr_scatter<8>(q, j, map, out, neg);
   }
 }
-// One symbol's entry of negsym[]: an upper bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs that touch this
-// symbol (a window spans at most 2 symbols, 3 when a symbol holds fewer than C8P_NEGB_WINDOW LLRs).  The decoder takes the maximum
-// over its packet's symbols (an atomicMax per symbol here cost 0.035 ms per 4096-packet batch: 46 waves per address).
-__device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps, uint32_t* __restrict__ flags, float* __restrict__ negsym,
-                                                  uint32_t w, int p)
+// wave sum on the DPP path (six VALU adds, total in lane 63): invalid source lanes read 0 (bound_ctrl), the row broadcasts
+// only write the rows named by their row mask
+__device__ __forceinline__ float wave_sum_lane63(float neg)
 {
-  // wave sum on the DPP path (six VALU adds, total in lane 63): invalid source lanes read 0 (bound_ctrl), the row broadcasts
-  // only write the rows named by their row mask
 #define C8P_DPP_ADD(CTRL, ROWS) neg += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(neg), CTRL, ROWS, 0xf, true))
   C8P_DPP_ADD(0x111, 0xf);   // row_shr:1
   C8P_DPP_ADD(0x112, 0xf);   // row_shr:2
@@ -563,6 +559,15 @@ __device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps
   C8P_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1, 3
   C8P_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's sum
 #undef C8P_DPP_ADD
+  return neg;
+}
+// One symbol's entry of negsym[]: an upper bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs that touch this
+// symbol (a window spans at most 2 symbols, 3 when a symbol holds fewer than C8P_NEGB_WINDOW LLRs).  The decoder takes the maximum
+// over its packet's symbols (an atomicMax per symbol here cost 0.035 ms per 4096-packet batch: 46 waves per address).
+__device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps, uint32_t* __restrict__ flags, float* __restrict__ negsym,
+                                                  uint32_t w, int p)
+{
+  neg = wave_sum_lane63(neg);
   const unsigned long long anybad = __ballot(bad);
   if (lane_id() == 63) {
     if (anybad) atomicOr(&flags[p], 1u);
@@ -570,12 +575,58 @@ __device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps
   }
 }
 
+// One OFDM data symbol of a single-stream packet received on antenna 0: FFT output f1 of this lane's bin, Hl = the channel of the
+// bin (tag "chan" for legacy packets, k_classify's HT / VHT estimate otherwise) -> equalise, common pilot phase, LLRs scattered
+// through the de-interleave map into out[0 .. ncbps).  legacyChanUpdate demod_impl.cc:507-539, nonLegacyChanUpdate :413-447
+// (== the nSS = 1 branches of demod2), pilotShift :549-557 (base patterns cloud80211phy.cc:170-174).
+__device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int lane, cf f1, cf Hl, const DevTables* __restrict__ T,
+                                              float* __restrict__ out, float& neg)
+{
+  const int nb = t.nbpscs, mi = nbpsc_index(nb);
+  const cf sig = cdiv(f1, Hl);
+  bool bad = false;
+  if (t.format == C8P_F_L) {
+    const float Pp = T->pilotP[(1 + s) % 127];
+    cf acc = cmulf(cmulf(shfl_c(sig, 7), 1.0f), Pp);
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), -1.0f), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), 1.0f), Pp));
+    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), 1.0f), Pp));
+    const cf ps = cconj(acc);
+    const float pa = cabs_(ps);
+    if (!is_null_l(lane) && !is_pilot(lane)) {
+      const cf q = cdivf(cmul(sig, ps), pa);
+      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out, neg);
+    }
+    return bad;
+  }
+  const int p0 = t.format == C8P_F_VHT ? 4 : 3;
+  const float Pp = T->pilotP[(p0 + s) % 127];
+  float pa_[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int kk = (k + s) & 3;
+    pa_[k] = __uint_as_float(kk == 3 ? 0xbf800000u : 0x3f800000u);         // {1,1,1,-1} rotated left by s; as a bit pattern the
+                                                                           // (wave-uniform) value stays in an SGPR
+  }
+  cf acc = cmulf(cmulf(shfl_c(sig, 7), pa_[2]), Pp);
+  acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), pa_[3]), Pp));
+  acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), pa_[0]), Pp));
+  acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), pa_[1]), Pp));
+  const cf ps = cconj(acc);
+  const float pa = cabs_(ps);
+  if (!is_null_nl(lane) && !is_pilot(lane)) {
+    const cf q = cdivf(cmul(sig, ps), pa);
+    bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out, neg);
+  }
+  return bad;
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                    const cf* __restrict__ chan, const uint32_t* __restrict__ sym2pkt,
                                                    const PktLayout* __restrict__ lay, const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
                                                    const cf* __restrict__ Hin, const Mimo* __restrict__ mimo,
                                                    float* __restrict__ llr, uint32_t* __restrict__ flags, float* __restrict__ negsym,
-                                                   int n, uint32_t total_syms)
+                                                   int n, uint32_t total_syms, int only_2x2)
 {
   // (the wave index is uniform, but the compiler cannot see that through threadIdx: without the readfirstlane the packet's
   // tags and descriptor — 170 bytes — are fetched per lane into VGPRs instead of once into SGPRs)
@@ -588,44 +639,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (t.status != C8P_ST_OK) return;
   float* out = llr + t.llr_off;
   if (t.is_ndp) {                                  // 1024 dummy items (demod_impl.cc:265-271), zero-filled
-    if (s == 0) for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
+    if (s == 0 && !only_2x2) for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
     return;
   }
   if (s >= t.nsym) return;
   const c8p_pkt_in P = pk[p];
   const bool two = P.n_ant == 2;
+  if (only_2x2 && !(two && t.nss == 2)) return;    // c8p_rx: single-stream packets belong to k_rx_1ss
   const cf* x1 = iq + P.iq_off[0] + t.data_off + s * t.nsymsamp + 8;
   out += (size_t)s * t.ncbps;
-  const int nb = t.nbpscs;
-  const int mi = nbpsc_index(nb);
   bool bad = false;                       // an LLR outside the lean decoder's exactness range (or NaN)
+  float neg = 0.0f;                       // this lane's sum of max(0, -LLR)
   cf f1 = wave_fft64(x1[lane], T);
-
-  if (t.format == C8P_F_L) {
-    // legacyChanUpdate demod_impl.cc:507-539
-    const float Pp = T->pilotP[(1 + s) % 127];
-    cf sig = cdiv(f1, chan[P.chan_off + lane]);
-    cf acc = cmulf(cmulf(shfl_c(sig, 7), 1.0f), Pp);
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), -1.0f), Pp));
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), 1.0f), Pp));
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), 1.0f), Pp));
-    cf ps = cconj(acc);
-    float pa = cabs_(ps);
-    float neg = 0.0f;                     // this lane's sum of max(0, -LLR)
-    if (!is_null_l(lane) && !is_pilot(lane)) {
-      cf q = cdivf(cmul(sig, ps), pa);
-      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out, neg);
-    }
+  if (!(two && t.nss == 2)) {
+    const cf Hl = t.format == C8P_F_L ? chan[P.chan_off + lane] : Hin[(size_t)p * 64 + lane];
+    bad = demod_sym_1ss(t, s, lane, f1, Hl, T, out, neg);
     publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
     return;
   }
 
-  const int p0 = t.format == C8P_F_VHT ? 4 : 3;
-  const float Pp = T->pilotP[(p0 + s) % 127];
+  const float Pp = T->pilotP[((t.format == C8P_F_VHT ? 4 : 3) + s) % 127];
   // pilot patterns rotated left by s (pilotShift demod_impl.cc:549-557); base patterns cloud80211phy.cc:170-174
   float pa_[4], pb_[4];
   {
-    const bool ht2 = (t.format == C8P_F_HT) && two && t.nss == 2;
+    const bool ht2 = t.format == C8P_F_HT;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int kk = (k + s) & 3;
@@ -637,24 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       pb_[k] = __uint_as_float((t.format == C8P_F_VHT) ? l4 : h22);
     }
   }
-
-  if (!(two && t.nss == 2)) {
-    // nonLegacyChanUpdate demod_impl.cc:413-447 (== demod2 nSS==1 branches)
-    cf sig = cdiv(f1, Hin[(size_t)p * 64 + lane]);
-    cf acc = cmulf(cmulf(shfl_c(sig, 7), pa_[2]), Pp);
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 21), pa_[3]), Pp));
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 43), pa_[0]), Pp));
-    acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), pa_[1]), Pp));
-    cf ps = cconj(acc);
-    float pa = cabs_(ps);
-    float neg = 0.0f;
-    if (!is_null_nl(lane) && !is_pilot(lane)) {
-      cf q = cdivf(cmul(sig, ps), pa);
-      bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out, neg);
-    }
-    publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
-    return;
-  }
+  const int nb = t.nbpscs, mi = nbpsc_index(nb);
 
   // 2x2: htChanUpdate demod2_impl.cc:471-551 / vhtChanUpdate :553-630
   const cf* x2 = iq + P.iq_off[1] + t.data_off + s * t.nsymsamp + 8;
@@ -675,7 +695,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 57), pb_[1]), Pp), M->pil2[1]));
   cf ps = cconj(acc);
   float pa = cabs_(ps);
-  float neg = 0.0f;
   if (!is_null_nl(lane) && !is_pilot(lane)) {
     cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
     const int j = qidx_nl(lane);
@@ -779,13 +798,15 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
 // 4096 equally long waves of a batch evenly spread (single-wave workgroups were observed to pile up on some SIMDs).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
                                                       const float* __restrict__ llr, ulonglong2* __restrict__ surv,
-                                                      uint32_t* __restrict__ flags, const float* __restrict__ negsym, int n)
+                                                      uint32_t* __restrict__ flags, const float* __restrict__ negsym,
+                                                      const c8p_pkt_in* __restrict__ pk_2x2_only, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
   if (flags[p] != 0) return;
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
+  if (pk_2x2_only && !(pk_2x2_only[p].n_ant == 2 && t.nss == 2)) return;   // c8p_rx: single-stream packets were decoded by k_rx_1ss
   // bound of the negative-part sum of any C8P_NEGB_WINDOW consecutive LLRs: the largest entry of the packet's symbols (c8p_rx: written
   // by k_demod_sym) or what k_llr_check left in flags[2n + p] (c8p_decode); kept there for the tests (C8P_BUF_DECSTAT)
   float negb;
@@ -813,6 +834,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_vi
 #ifdef C8P_EXP_CLOCK
   if (lane_id() == 0) { flags[n + p] = (uint32_t)(clock64() - exp_t0); flags[2 * n + p] = (exp_hw & 0xffffu) | ((exp_xcc & 0xfu) << 16); }
 #endif
+}
+
+
+// ================================================================================================ c8p_rx, single-stream packets
+// Symbol demodulation AND the lean forward pass in one wave per packet: the wave demodulates OFDM symbol s into the packet's LLR
+// area and right away runs the survivor blocks whose LLRs are complete, reading them back through the scalar cache.  k_demod_sym's
+// 46 short waves per packet (and their launch) disappear, the next symbol's samples are in flight while the current one is decoded,
+// and the decoder never waits for HBM: +3 % packets/s over the two kernels.  What it does NOT do on this part is save
+// HBM reads: tools/probe_l2rw.hip shows that a read of a line the same wave just wrote is a TCC hit and still an EA read request
+// (FETCH_SIZE counts it) — keeping the LLRs out of the memory counters would take an LDS ring and VGPR-fed LLRs.
+// (demod_impl.cc:279-314 -> decode_impl.cc:128-141, 205-281.)
+// Scalar-cache coherence: a 64-byte line is only ever read when all of it has been written (`safe` below) and waited for
+// (vmcnt(0): the vector stores are in L2); LLR areas start on 64-byte boundaries (plan_demod), so no line is shared by two packets.
+// A packet whose LLRs fail the range check, or that cannot be decoded, is demodulated to the end and left to k_viterbi_fwd.
+// Registers: the decoder's per-lane state is parked in LDS while a symbol is demodulated and its 28 lane constants travel as one
+// packed word, so the kernel needs max(demodulator, decoder) + a few registers: 80 VGPRs, 6 waves per SIMD.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
+                                                const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
+                                                const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+{
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (p >= n) return;
+  const c8p_pkt_tags t = tags[p];
+  if (t.status != C8P_ST_OK) return;
+  const c8p_pkt_in P = pk[p];
+  if (P.n_ant == 2 && t.nss == 2) return;          // two streams: k_demod_sym + k_viterbi_lean
+  const int lane = lane_id();
+  float* out = llr + t.llr_off;
+  if (t.is_ndp) {                                  // 1024 dummy items (demod_impl.cc:265-271), zero-filled
+    for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
+    return;
+  }
+  bool ok = decodable(t);                          // wave-uniform: this wave also decodes
+  const cf Hl = t.format == C8P_F_L ? chan[P.chan_off + lane] : Hin[(size_t)p * 64 + lane];
+  const cf* x1 = iq + P.iq_off[0] + t.data_off + 8 + lane;
+  unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
+  unsigned kbits;                                  // the decoder's 28 lane constants, packed while a symbol is demodulated
+  {
+    LeanK K0[6];
+    lean_k_consts(lane, K0);
+    kbits = lean_k_pack(K0);
+  }
+  unsigned init, flip;
+  lean_int_consts(lane, init, flip);
+  LeanState S;
+  lean_init(S, lane);
+  const int Tn = t.trellis, nfull = Tn / C8P_SV_BLK;
+  const int nlb = t.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                  t.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
+  const float wfac = t.ncbps >= C8P_NEGB_WINDOW ? 2.0f : 3.0f;   // symbols a window of C8P_NEGB_WINDOW LLRs can touch
+  float negb = 0.0f;                               // largest negative-part sum of the symbols so far, x wfac
+  int produced = 0;
+  cf xin = t.nsym > 0 ? x1[0] : mk(0.f, 0.f);
+  // The decoder's per-lane state is parked in LDS while a symbol is demodulated (8 dwords per lane, 8 KB per workgroup): the two
+  // phases then need max(demodulator, decoder) registers instead of their sum, which is what keeps 6 waves per SIMD resident.
+  __shared__ uint4 park[4][2][64];
+  uint4* const pk0 = &park[threadIdx.x >> 6][0][lane];
+  uint4* const pk1 = &park[threadIdx.x >> 6][1][lane];
+  for (int s = 0; s < t.nsym; s++) {
+    *pk0 = make_uint4(__float_as_uint(S.pre), S.acc, S.pend.x, S.pend.y);
+    *pk1 = make_uint4(S.voff, kbits, init, flip);
+    asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.acc), "=v"(S.pend.x), "=v"(S.pend.y), "=v"(S.voff), "=v"(kbits), "=v"(init), "=v"(flip));
+    const cf xnext = x1[(size_t)(s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp];   // next symbol's sample: in flight during this one
+    const cf f1 = wave_fft64(xin, T);
+    float neg = 0.0f;
+    int lane_s = lane;                               // opaque per symbol: the de-interleave offsets of all five constellations are
+    asm volatile("" : "+v"(lane_s));                 // otherwise hoisted out of the loop as 64-bit pairs and spilled to scratch
+    const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hl, T, out + (size_t)s * t.ncbps, neg);
+    produced += t.ncbps;
+    xin = xnext;
+    {
+      const uint4 a = *pk0, b = *pk1;
+      S.pre = __uint_as_float(a.x); S.acc = a.y; S.pend.x = a.z; S.pend.y = a.w;
+      S.voff = b.x; kbits = b.y; init = b.z; flip = b.w;
+    }
+    if (__ballot(bad)) {
+      if (ok && lane == 0) flags[p] = 1u;
+      ok = false;
+    }
+    if (!ok) continue;
+    neg = wave_sum_lane63(neg);
+    negb = fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac);
+    // survivor blocks whose LLRs lie in completely written 64-byte lines
+    const int safe = s + 1 == t.nsym ? produced : (produced & ~15);   // whole 64-byte scalar-cache lines
+    int upto = safe / nlb;
+    if (upto > nfull) upto = nfull;
+    if (upto == S.done) continue;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(kbits) :: "memory");   // this symbol's LLR stores have reached L2 (and: unpack HERE, per
+    LeanK K[6];                                                    // symbol — the constants must not stay live across the demodulation)
+    lean_k_unpack(kbits, lane, K);
+    const float bound = lean_bound(negb);
+    switch (t.cr) {
+      case C8P_CR_12: lean_blocks<C8P_CR_12>(S, K, init, flip, bound, out, safe, sv, upto); break;
+      case C8P_CR_23: lean_blocks<C8P_CR_23>(S, K, init, flip, bound, out, safe, sv, upto); break;
+      case C8P_CR_34: lean_blocks<C8P_CR_34>(S, K, init, flip, bound, out, safe, sv, upto); break;
+      default:        lean_blocks<C8P_CR_56>(S, K, init, flip, bound, out, safe, sv, upto); break;
+    }
+  }
+  if (!ok) return;
+  if (lane == 0) { flags[n + p] = (uint32_t)S.nflt; flags[2 * n + p] = __float_as_uint(negb); }   // C8P_BUF_DECSTAT
+  LeanK K[6];
+  lean_k_unpack(kbits, lane, K);
+  switch (t.cr) {
+    case C8P_CR_12: lean_tail<C8P_CR_12>(S, K, out, t.total, Tn, sv); break;
+    case C8P_CR_23: lean_tail<C8P_CR_23>(S, K, out, t.total, Tn, sv); break;
+    case C8P_CR_34: lean_tail<C8P_CR_34>(S, K, out, t.total, Tn, sv); break;
+    default:        lean_tail<C8P_CR_56>(S, K, out, t.total, Tn, sv); break;
+  }
 }
 
 // ================================================================================================ finish

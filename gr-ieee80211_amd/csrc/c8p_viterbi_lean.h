@@ -219,14 +219,9 @@ __device__ __forceinline__ void lean_int_consts(int lane, unsigned& init, unsign
   }
 }
 
-template <int CR>
-__device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv, float negb,
-                                             uint32_t* __restrict__ n_float_blocks)
+// lane constants of all six exchange phases
+__device__ __forceinline__ void lean_k_consts(int lane, LeanK (&K)[6])
 {
-  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;   // NLB: LLRs per block
-  static_assert(NLB <= C8P_NEGB_WINDOW, "negb covers windows of C8P_NEGB_WINDOW LLRs");
-  const int lane = lane_id();
-  LeanK K[6];
 #pragma unroll
   for (int q = 0; q < 6; q++) {
     const int nst = rotr6(lane, (q + 1) % 6);          // state held by this lane at time t+1, t mod 6 == q
@@ -243,30 +238,74 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
     K[q].b = v2f{(c1 & 1) ? 1.0f : 0.0f, (c2 & 1) ? 1.0f : 0.0f};
     K[q].cls = b ? C8P_CLS_NEG : C8P_CLS_POS;
   }
-  unsigned init, flip;
-  lean_int_consts(lane, init, flip);
-  const float bound = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fmaf(negb, 1.01f, 1e-30f))));
+}
+
+// The 24 coefficients (each 0.0 or 1.0) and the 4 class masks as ONE register: a kernel that does other work between two runs of
+// the block loop (k_rx_1ss demodulates a symbol) keeps `bits` and the lane index instead of 28 VGPRs and unpacks them when it resumes.
+__device__ __forceinline__ unsigned lean_k_pack(const LeanK (&K)[6])
+{
+  unsigned bits = 0;
+#pragma unroll
+  for (int q = 0; q < 6; q++)
+    bits |= (K[q].a.x != 0.0f ? 1u : 0u) << (4 * q) | (K[q].a.y != 0.0f ? 2u : 0u) << (4 * q) | (K[q].b.x != 0.0f ? 4u : 0u) << (4 * q) |
+            (K[q].b.y != 0.0f ? 8u : 0u) << (4 * q);
+  return bits;
+}
+__device__ __forceinline__ void lean_k_unpack(unsigned bits, int lane, LeanK (&K)[6])
+{
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    // 1-bit field sign-extended (0 or all ones) AND the bit pattern of 1.0f: two instructions per coefficient
+    K[q].a = v2f{__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q, 1) & 0x3f800000u),
+                 __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 1, 1) & 0x3f800000u)};
+    K[q].b = v2f{__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 2, 1) & 0x3f800000u),
+                 __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 3, 1) & 0x3f800000u)};
+    K[q].cls = ((lane >> q) & 1) ? C8P_CLS_NEG : C8P_CLS_POS;
+  }
+}
+
+// the decoder's state between two calls (everything a wave carries from one survivor block to the next)
+struct LeanState {
+  float pre;                   // this lane's path metric
+  unsigned acc;                // decision shift register
+  LeanPend pend;               // float step: operands of the decision still to be recorded
+  unsigned voff;               // byte offset of this lane's dword of the next survivor block
+  int done;                    // full blocks finished
+  int nflt;                    // of those, blocks run with the float step
+};
+__device__ __forceinline__ void lean_init(LeanState& S, int lane)
+{
+  S.pre = lane == 0 ? 0.0f : C8P_NEG_INIT;      // state 0 sits in lane 0 under every rotation
+  S.acc = 0; S.pend = LeanPend{0u, 0u}; S.voff = (unsigned)lane * 4u; S.done = 0; S.nflt = 0;
+}
+__device__ __forceinline__ float lean_bound(float negb)    // wave-uniform (SGPR) threshold of the integer loop
+{
+  return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fmaf(negb, 1.01f, 1e-30f))));
+}
+
+// full survivor blocks [S.done, upto) of a packet whose first `n_llr` LLRs (at least the ones those blocks consume) are at Lg
+template <int CR>
+__device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], unsigned init, unsigned flip, float bound,
+                                            const float* __restrict__ Lg, int n_llr, unsigned* __restrict__ sv, int upto)
+{
+  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;   // NLB: LLRs per block
+  static_assert(NLB <= C8P_NEGB_WINDOW, "negb covers windows of C8P_NEGB_WINDOW LLRs");
   c4float* L = (c4float*)Lg;
-  float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;      // state 0 sits in lane 0 under every rotation
-  unsigned acc = 0;
-  LeanPend pend = {0u, 0u};
   float x[NL];
-  const int nfull = Tn / C8P_SV_BLK;
-  int left = nfull, nflt = 0;
-  unsigned voff = (unsigned)lane * 4u;              // byte offset of this lane's dword inside the packet's survivor area
+  int left = upto - S.done;
   // touch registers: loop-carried ("+s") so that they can never share an SGPR with x[] — the touches are still in
   // flight when the next block's real loads are issued, and scalar loads may return in any order
   unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
   while (left > 0) {
-    // full survivor blocks, integer compare: as many as keep every metric above the bound
+    // integer compare: as many blocks as keep every metric above the bound
 #ifndef C8P_EXP_NO_INT
-    if (__ballot(pre < bound) == 0ull) {
-      lean_blocks_int<CR>(pre, acc, K, init, flip, bound, voff, Lg + (size_t)(nfull - left) * NLB, sv, left);
+    if (__ballot(S.pre < bound) == 0ull) {
+      lean_blocks_int<CR>(S.pre, S.acc, K, init, flip, bound, S.voff, Lg + (size_t)(upto - left) * NLB, sv, left);
       if (left == 0) break;
     }
 #endif
     // one full block with the float step: REP super-iterations of PER steps each
-    int lb = (nfull - left) * NLB;
+    int lb = (upto - left) * NLB;
 #pragma unroll
     for (int r = 0; r < REP; r++, lb += NL) {
 #pragma unroll
@@ -277,7 +316,7 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
         // this statement), touch the scalar-cache lines of the NEXT block with throw-away loads: they complete during
         // the 30 steps below, and the next block's loads hit the scalar cache instead of stalling on L2 / HBM.
         const int nb = lb + NLB;                    // first LLR of the next block
-        c4float* nx = L + (nb + NLB <= n_llr ? nb : lb);   // never touch past the packet's own LLRs (no branch: a join
+        c4float* nx = L + (nb + NLB <= n_llr ? nb : lb);   // never touch past the LLRs that exist (no branch: a join
                                                            // would make the compiler drain the touches right away)
         if (NLB * 4 > 192)
           asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
@@ -288,17 +327,26 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
                        "s_load_dword %3, %4, %7"
                        : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3) : "s"(nx), "s"(x[0]), "s"(x[NL - 1]), "n"(NLB * 4 - 4));
       }
-      if (r == 0) lean_steps<CR, 0, false, true>(pre, K, x, acc, pend, PER);
-      else lean_steps<CR, 0, false, false>(pre, K, x, acc, pend, PER);
+      if (r == 0) lean_steps<CR, 0, false, true>(S.pre, K, x, S.acc, S.pend, PER);
+      else lean_steps<CR, 0, false, false>(S.pre, K, x, S.acc, S.pend, PER);
     }
-    lean_flush<(PER - 1) % 6>(acc, pend);
-    *(unsigned*)((char*)sv + voff) = acc;
+    lean_flush<(PER - 1) % 6>(S.acc, S.pend);
+    *(unsigned*)((char*)sv + S.voff) = S.acc;
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4));   // touches land before the integer loop reuses SGPRs
-    voff += 256u; left--; nflt++;
+    S.voff += 256u; left--; S.nflt++;
   }
-  if (lane == 0) *n_float_blocks = (uint32_t)nflt;   // diagnostic (C8P_BUF_DECSTAT): blocks that did not qualify for the integer loop
-  const int tb = nfull * C8P_SV_BLK;
-  if (tb < Tn) {   // last, partial block: loads clamped to the packet's own LLRs, decisions left-aligned like a full block
+  S.done = upto;
+}
+
+// the last, partial block (steps nfull * 30 .. Tn): loads clamped to the packet's own LLRs, decisions left-aligned like a full block
+template <int CR>
+__device__ __forceinline__ void lean_tail(LeanState& S, const LeanK (&K)[6], const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv)
+{
+  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;
+  c4float* L = (c4float*)Lg;
+  const int nfull = Tn / C8P_SV_BLK, tb = nfull * C8P_SV_BLK;
+  if (tb < Tn) {
+    float x[NL];
     const int rem = Tn - tb;
     int lb = nfull * NLB;
 #pragma unroll
@@ -306,9 +354,28 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
       if (r * PER < rem) {
 #pragma unroll
         for (int i = 0; i < NL; i++) { const int li = lb + i; x[i] = li < n_llr ? L[li] : 0.0f; }
-        lean_steps<CR, 0, true, true>(pre, K, x, acc, pend, rem - r * PER);
+        lean_steps<CR, 0, true, true>(S.pre, K, x, S.acc, S.pend, rem - r * PER);
       }
     }
-    *(unsigned*)((char*)sv + voff) = acc << (C8P_SV_BLK - rem);
+    *(unsigned*)((char*)sv + S.voff) = S.acc << (C8P_SV_BLK - rem);
   }
+}
+
+template <int CR> struct LeanRate { static constexpr int NLB = RateInfo<CR>::NL * (C8P_SV_BLK / RateInfo<CR>::PER); };
+
+// the whole forward pass of one packet whose LLRs are all there (k_viterbi_lean)
+template <int CR>
+__device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n_llr, int Tn, unsigned* __restrict__ sv, float negb,
+                                             uint32_t* __restrict__ n_float_blocks)
+{
+  const int lane = lane_id();
+  LeanK K[6];
+  lean_k_consts(lane, K);
+  unsigned init, flip;
+  lean_int_consts(lane, init, flip);
+  LeanState S;
+  lean_init(S, lane);
+  lean_blocks<CR>(S, K, init, flip, lean_bound(negb), Lg, n_llr, sv, Tn / C8P_SV_BLK);
+  if (lane == 0) *n_float_blocks = (uint32_t)S.nflt;   // diagnostic (C8P_BUF_DECSTAT): blocks that did not qualify for the integer loop
+  lean_tail<CR>(S, K, Lg, n_llr, Tn, sv);
 }

@@ -39,6 +39,14 @@ def test_decoder_and_symbol_kernels_keep_eight_waves_per_simd(usage):
     assert demod["ScratchSize"] == 0 and demod["VGPRs Spill"] == 0, demod
 
 
+def test_fused_rx_kernel_keeps_six_waves_per_simd(usage):
+    """k_rx_1ss (symbol demodulation + forward pass in one wave): decoder state parked in LDS during the demodulation, lane constants packed"""
+    rx = usage["k_rx_1ss"]
+    assert rx["VGPRs"] <= 80 and rx["AGPRs"] == 0 and rx["Occupancy"] >= 6, rx
+    assert rx["LDS Size"] <= 8 * 1024, rx
+    assert rx["ScratchSize"] <= 96, rx                     # loop-invariant values around the loop, nothing inside the rate-5/6 path
+
+
 def test_side_kernels_stay_inside_their_budgets(usage):
     assert usage["k_classify"]["VGPRs"] <= 72, usage["k_classify"]
     assert usage["k_finish"]["LDS Size"] <= 24 * 1024 and usage["k_finish"]["ScratchSize"] == 0, usage["k_finish"]

@@ -127,17 +127,6 @@ def gen_rate(cr, integer):
         emit("s_mov_b32 vcc_hi, 0x55555555")
     load_group(0, cur)
     emit("1:")
-    if integer and "prio" in EXP:
-        # issue priority by block parity: a wave that runs ahead of its SIMD neighbours drops to priority 0 when it enters an odd
-        # block while they are still in the even one (the arbiter otherwise serves the oldest wave first, the waves of a SIMD finish
-        # one after the other and the last one runs alone, latency-bound)
-        emit("s_bitcmp1_b32 %s, 0" % cnt)
-        emit("s_cbranch_scc1 3f")
-        emit("s_setprio 1")
-        emit("s_branch 4f")
-        emit("3:")
-        emit("s_setprio 0")
-        emit("4:")
     # next block's pointer, clamped to the last full block (the refills of the last iteration re-read valid addresses)
     emit("s_add_u32 s%d, s%d, %d" % (PTR, PTR + 2, 4 * n))
     emit("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 3))
@@ -255,8 +244,6 @@ def gen_rate(cr, integer):
         emit("s_cmp_lg_u32 %s, 0" % cnt)
         emit("s_cbranch_scc1 1b")
     emit("s_waitcnt lgkmcnt(0)")                             # the last refill lands before anything reuses its registers
-    if integer and "prio" in EXP:
-        emit("s_setprio 0")
     emit("v_mov_b32 %[pre], v62")
     emit("v_mov_b32 %[acc], v63")
     emit("v_mov_b32 %[voff], v50")
