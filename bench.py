@@ -234,7 +234,7 @@ def main():
                                  "pipelined_avg_launch_ms = events on every %d-th launch inside the timed region, where the launches of "
                                  "%s batches overlap (not a per-launch cost)" % (PROFILE_EVERY, os.environ.get("C8P_SLOTS", "4"))},
         }
-        rv = valu_roofline(kern_x, n_pkt)
+        rv = valu_roofline(kern_x, n_pkt, dec_path["float_step_block_fraction"])
         if rv:
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
@@ -414,47 +414,69 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
     return res
 
 
-def lean_step_mix(T, cr_num=5):
-    """VALU wave-instructions of k_viterbi_lean per packet of T trellis steps at code rate 5/6, by opcode, from the kernel's
-    structure (csrc/c8p_viterbi_lean.h): every step one packed candidate fma, steps with both LLRs present (1 in 5) a packed
-    mul + add more; exchange phases q=0,1,3: sub_dpp + max_dpp, q=2: one mov_dpp more, q=4,5: permlane swap + max; the
-    decision: one compare + one carry-shift.  (Cross-check: SQ_INSTS_VALU of the PMC pass / packets = this sum.)"""
+def lean_step_mix(T, float_frac=0.0, cr_num=5):
+    """VALU wave-instructions of the lean forward pass per packet of T trellis steps at code rate 5/6, by opcode, from the kernel's
+    structure (csrc/c8p_viterbi_lean.h, tools/gen_lean_asm.py): every step one packed candidate fma, steps with both LLRs present
+    (1 in 5) a packed mul + add more.  Integer-compare blocks (path metrics provably positive): exchange phases q=0,1,3 a borrow
+    (v_subb_co_u32_dpp) and v_max_u32_dpp, q=2 one mov_dpp more, q=4,5 permlane swap + v_max_u32 + v_sub_co_u32; one carry-shift per
+    step: 147 per 30 steps.  Float blocks (the fraction `float_frac`, measured in this run): sub_dpp + max_dpp + class test: 167."""
     assert cr_num == 5
-    per30 = {"v_pk_fma_f32": 30, "v_pk_mul_f32": 6, "v_pk_add_f32": 6, "v_sub_f32_dpp": 20, "v_max_f32_dpp": 20,
-             "v_mov_b32_dpp": 5, "v_permlane16_swap_b32": 5, "v_permlane32_swap_b32": 5, "v_max_f32": 10,
-             "v_cmp_class_f32": 20, "v_cmp_gt_f32": 10, "v_addc_co_u32": 30}
-    return {k: v * T / 30.0 for k, v in per30.items()}
+    per30_int = {"v_pk_fma_f32": 30, "v_pk_mul_f32": 6, "v_pk_add_f32": 6, "v_subb_co_u32_dpp": 20, "v_max_u32_dpp": 20,
+                 "v_mov_b32_dpp": 5, "v_permlane16_swap_b32": 5, "v_permlane32_swap_b32": 5, "v_max_u32": 10,
+                 "v_sub_co_u32": 10, "v_addc_co_u32": 30, "v_xor_b32": 1}
+    per30_flt = {"v_pk_fma_f32": 30, "v_pk_mul_f32": 6, "v_pk_add_f32": 6, "v_sub_f32_dpp": 20, "v_max_f32_dpp": 20,
+                 "v_mov_b32_dpp": 5, "v_permlane16_swap_b32": 5, "v_permlane32_swap_b32": 5, "v_max_f32": 10,
+                 "v_cmp_class_f32": 20, "v_cmp_gt_f32": 10, "v_addc_co_u32": 30}
+    mix = {}
+    for d, w in ((per30_int, 1.0 - float_frac), (per30_flt, float_frac)):
+        for k, v in d.items():
+            mix[k] = mix.get(k, 0.0) + w * v * T / 30.0
+    return mix
 
 
-def valu_roofline(kern_x, n_pkt, T=11960):
-    """The resource that binds the decoder: VALU issue.  ceiling = sum over opcodes of (count per launch x measured issue
-    cost, profiles/*/opcode_costs.json from tools/probe_issue.hip) / (1024 SIMDs x 2.4 GHz); frac = ceiling / exclusive launch
-    duration of this run.  Pricing at the nominal 2.4 GHz makes the fraction a lower bound (the shader clock under this
-    load is 2.2-2.35 GHz)."""
+def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
+    """The resource that binds the dominant kernel: VALU issue.  The kernel is k_rx_1ss = symbol demodulation + the lean forward
+    pass.  ceiling = [sum over the forward pass's opcodes of (count x measured issue cost, profiles/*/opcode_costs.json from
+    tools/probe_issue.hip) + the kernel's other VALU instructions (SQ_INSTS_VALU of the newest committed PMC pass minus the forward
+    pass's count) at the 4.15-cycle slot every non-trivial opcode costs] / (1024 SIMDs x 2.4 GHz); frac = ceiling / exclusive
+    launch duration of this run.  Pricing at the nominal 2.4 GHz makes the fraction a lower bound (the shader clock under this
+    load is 2.2-2.35 GHz).  One batch alone gives every SIMD 4 decoder waves; the arbiter serves the oldest wave first, so they
+    finish one after the other and the last runs alone, latency-bound (profiles/r2b/decoder_wave_cycles.txt: 27 SIMD cycles per
+    wave-step at 4 waves, 24 at 8 waves, against 21.7 from the opcode costs) — the exclusive launch cannot reach the ceiling, the
+    pipelined step (other batches fill the tail) is what `value` measures."""
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "opcode_costs.json")))
     if not fs or kern_x.get("viterbi_fwd", 0) <= 0:
         return None
     cost = json.load(open(fs[-1]))["lean_step_opcodes"]
-    mix = lean_step_mix(T)
-    instr = sum(mix.values()) * n_pkt
+    mix = lean_step_mix(T, float_frac)
+    dec_instr = sum(mix.values()) * n_pkt
     cycles = sum(mix[k] * cost[k] for k in mix) * n_pkt            # SIMD-cycles summed over the chip
+    other, other_src = 0.0, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm.json"))):
+        k = json.load(open(f))["kernels"].get("k_rx_1ss")
+        if k and k.get("sq_insts_valu"):
+            other, other_src = max(0.0, k["sq_insts_valu"] * n_pkt / 4096.0 - dec_instr), os.path.relpath(f, ROOT)
+    cycles += other * 4.15
     n_simd, clk = 256 * 4, 2.4e9
     ceiling_ms = cycles / n_simd / clk * 1e3
     dur_ms = kern_x["viterbi_fwd"]
-    return {"bound": "valu issue", "kernel": "viterbi_fwd (k_viterbi_lean)", "unit": "ms per launch",
+    return {"bound": "valu issue", "kernel": "viterbi_fwd (k_rx_1ss: symbol demodulation + lean forward pass)", "unit": "ms per launch",
             "ceiling_ms": ceiling_ms, "achieved_ms": dur_ms, "frac": ceiling_ms / dur_ms,
-            "instr_per_launch": instr, "instr_per_step": sum(mix.values()) / T, "issue_cycles_per_step": cycles / n_pkt / T,
-            "achieved_G_wave_instr_per_s": instr / (dur_ms * 1e-3) / 1e9,
-            "source": os.path.relpath(fs[-1], ROOT) + " (measured cycles per opcode, 8 waves / SIMD) x lean_step_mix(); nominal 2.4 GHz"}
+            "forward_pass_instr_per_launch": dec_instr, "forward_pass_instr_per_step": sum(mix.values()) / T,
+            "forward_pass_issue_cycles_per_step": sum(mix[k] * cost[k] for k in mix) / T, "float_step_block_fraction": float_frac,
+            "other_instr_per_launch": other, "other_instr_source": other_src,
+            "achieved_G_wave_instr_per_s": (dec_instr + other) / (dur_ms * 1e-3) / 1e9,
+            "source": os.path.relpath(fs[-1], ROOT) + " (measured cycles per opcode) x lean_step_mix(); nominal 2.4 GHz"}
 
 
 def pmc_traffic(dom):
-    """HBM bytes per launch of the dominant kernel, and of the four RX kernels together, from the newest committed rocprofv3
-    PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/*/pmc_hbm.json).  FETCH_SIZE is doubled per
-    MI355X_MICROARCH.md for kernels that read with 16-byte vector loads and taken as reported for the scalar-cache reads of
-    the lean decoder (64-byte requests); see DESIGN.md §7."""
-    names = {"viterbi_fwd": "k_viterbi_lean", "finish": "k_finish", "demod_sym": "k_demod_sym", "classify": "k_classify"}
+    """HBM bytes per launch of the dominant kernel, and of the three RX kernels of a c8p_rx step together, from the newest committed
+    rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/*/pmc_hbm.json).  FETCH_SIZE is doubled
+    per MI355X_MICROARCH.md for kernels that read with 16-byte vector loads; the scalar-cache reads of the forward pass are 64-byte
+    requests and counted in full, so k_rx_1ss = FETCH_SIZE as reported + half of the sample bytes it reads with vector loads;
+    see DESIGN.md §7."""
+    names = {"viterbi_fwd": "k_rx_1ss", "finish": "k_finish", "classify": "k_classify"}
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -471,8 +493,9 @@ def pmc_traffic(dom):
             return None
         if "hbm_bytes" in k:
             return k["hbm_bytes"]
-        scale = 1.0 if name == "k_viterbi_lean" else 2.0
-        return (k["fetch_size_kb_raw"] * scale + k["write_size_kb"]) * 1024.0
+        if name == "k_rx_1ss":     # scalar-cache reads (64-byte requests, counted in full) + the samples, read with vector loads
+            return (k["fetch_size_kb_raw"] + k["write_size_kb"]) * 1024.0 + 0.5 * 4096 * (8 * 4400 + 512)     # (tallied at half)
+        return (k["fetch_size_kb_raw"] * 2.0 + k["write_size_kb"]) * 1024.0
 
     per = {n: hbm(n) for n in names.values()}
     whole = sum(v for v in per.values() if v) if all(per.values()) else None
