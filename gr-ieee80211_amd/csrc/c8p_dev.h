@@ -121,9 +121,8 @@ __device__ __forceinline__ double neg_if(double v, bool c)      // sign-bit flip
 // twiddles 1 and -j (a swap), so they have no multiplication at all; the others use 2 mul + 2 fma.  (fp64 runs at half
 // the fp32 rate on gfx950 and this kernel competes with the decoder for VALU issue: 28 fp64 ops per transform
 // instead of 60.)
-__device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T)
+__device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T, int lane)
 {
-  const int lane = lane_id();
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     const int half = 32 >> s;
@@ -144,11 +143,15 @@ __device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevT
   const int src = T->bitrev6[lane];
   return make_double2(shfl_d(xr, src), shfl_d(xi, src));
 }
-__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T)
+__device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T) { return wave_fft64_d(xr, xi, T, lane_id()); }
+// (lane passed in: a kernel that transforms in a loop hands over an opaque copy of its lane index, otherwise the per-lane twiddle
+// addresses of all four multiplying stages are hoisted out of the loop and held in — or spilled from — 20 VGPRs)
+__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T, int lane)
 {
-  const double2 r = wave_fft64_d((double)xin.x, (double)xin.y, T);
+  const double2 r = wave_fft64_d((double)xin.x, (double)xin.y, T, lane);
   return mk((float)r.x, (float)r.y);
 }
+__device__ __forceinline__ cf wave_fft64(cf xin, const DevTables* __restrict__ T) { return wave_fft64(xin, T, lane_id()); }
 // inverse DFT with the 1/64 of numpy.fft.ifft: ifft(X) = conj(fft(conj(X))) / 64, in double
 __device__ __forceinline__ double2 wave_ifft64_d(double xr, double xi, const DevTables* __restrict__ T)
 {

@@ -862,6 +862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   const c8p_pkt_in P = pk[p];
   if (P.n_ant == 2 && t.nss == 2) return;          // two streams: k_demod_sym + k_viterbi_lean
   const int lane = lane_id();
+  const int segn = c8p_seg_blocks(t.trellis);
   float* out = llr + t.llr_off;
   if (t.is_ndp) {                                  // 1024 dummy items (demod_impl.cc:265-271), zero-filled
     for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
@@ -898,11 +899,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     *pk1 = make_uint4(S.voff, kbits, init, flip);
     asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.acc), "=v"(S.pend.x), "=v"(S.pend.y), "=v"(S.voff), "=v"(kbits), "=v"(init), "=v"(flip));
     const cf xnext = x1[(size_t)(s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp];   // next symbol's sample: in flight during this one
-    const cf f1 = wave_fft64(xin, T);
+    // opaque per symbol: what depends only on the lane (FFT twiddle addresses, de-interleave offsets of all five constellations,
+    // the channel as doubles) is otherwise hoisted out of the loop as 64-bit pairs, stays live across the decoder and is spilled
+    // to scratch and reloaded every symbol
+    int lane_s = lane;
+    cf Hs = Hl;
+    asm volatile("" : "+v"(lane_s), "+v"(Hs.x), "+v"(Hs.y));
+    const cf f1 = wave_fft64(xin, T, lane_s);
     float neg = 0.0f;
-    int lane_s = lane;                               // opaque per symbol: the de-interleave offsets of all five constellations are
-    asm volatile("" : "+v"(lane_s));                 // otherwise hoisted out of the loop as 64-bit pairs and spilled to scratch
-    const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hl, T, out + (size_t)s * t.ncbps, neg);
+    const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, out + (size_t)s * t.ncbps, neg);
     produced += t.ncbps;
     xin = xnext;
     {
@@ -927,10 +932,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     lean_k_unpack(kbits, lane, K);
     const float bound = lean_bound(negb);
     switch (t.cr) {
-      case C8P_CR_12: lean_blocks<C8P_CR_12>(S, K, init, flip, bound, out, safe, sv, upto); break;
-      case C8P_CR_23: lean_blocks<C8P_CR_23>(S, K, init, flip, bound, out, safe, sv, upto); break;
-      case C8P_CR_34: lean_blocks<C8P_CR_34>(S, K, init, flip, bound, out, safe, sv, upto); break;
-      default:        lean_blocks<C8P_CR_56>(S, K, init, flip, bound, out, safe, sv, upto); break;
+      case C8P_CR_12: lean_blocks<C8P_CR_12>(S, K, init, flip, bound, out, safe, sv, upto, segn); break;
+      case C8P_CR_23: lean_blocks<C8P_CR_23>(S, K, init, flip, bound, out, safe, sv, upto, segn); break;
+      case C8P_CR_34: lean_blocks<C8P_CR_34>(S, K, init, flip, bound, out, safe, sv, upto, segn); break;
+      default:        lean_blocks<C8P_CR_56>(S, K, init, flip, bound, out, safe, sv, upto, segn); break;
     }
   }
   if (!ok) return;
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       //    16-byte loads while the previous tile is walked, then staged in LDS; the walk reads tile[segment][D].
       const uint32_t* SW = (const uint32_t*)SV;
       // steps per segment: whole survivor blocks (30 steps = 5 groups), so that no block is fetched by two segments
-      const int S = C8P_SV_BLK * ((Tn + 64 * C8P_SV_BLK - 1) / (64 * C8P_SV_BLK));
+      const int S = C8P_SV_BLK * c8p_seg_blocks(Tn);
       const int nseg = (Tn + S - 1) / S;
       const bool have = lane < nseg;
       const int tbeg = lane * S;
@@ -1095,6 +1100,14 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
           C8P_ROWS16(C8P_STAGE)
           __syncthreads();
           C8P_PREFETCH(i + 1, __ballot(act && i + 1 < nblk));   // in flight during the walk below
+          if (it == 0 && i == 0 && have && lane < nseg - 1) {
+            // the end lane this segment assumes: the forward pass marked the lane(s) with the largest path metric in bit 30 of
+            // the segment's last block (c8p_viterbi_lean.h); lane 0 if nothing is marked.  The last segment ends in state 0.
+            const uint32_t* row = &tile[lane * TS];
+            int h = 0;
+            for (int d = 63; d >= 0; d--) h = (row[d] & C8P_SV_HINT) ? d : h;
+            D = Dend = h;
+          }
           if (act && i < nblk) {
             const int blk = btop - i, b0 = blk * C8P_SV_BLK;
             const int hi = min(tend, b0 + C8P_SV_BLK) - 1 - b0, lo = max(tbeg, b0) - b0;   // active steps k in [lo, hi]

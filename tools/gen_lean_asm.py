@@ -228,6 +228,26 @@ def gen_rate(cr, integer):
     emit("s_sub_u32 %s, %s, 1" % (cnt, cnt))
     if integer:
         emit("v_xor_b32 v63, %[flip], v63")                  # even-holder lanes recorded the complement
+        # Traceback hint (k_finish walks segments of `segn` blocks in parallel and has to assume the lane each one ends in): in the
+        # last block of a segment, bit 30 of the survivor dword (unused: 30 decisions per block) marks the lane(s) holding the
+        # largest path metric (all positive here: unsigned max over the wave on the DPP path).  Only a hint: k_finish verifies
+        # it against the neighbouring segment and walks again where it was wrong.
+        emit("s_add_u32 %[segc], %[segc], 1")
+        emit("s_cmp_lt_u32 %[segc], %[segn]")
+        emit("s_cbranch_scc1 5f")
+        emit("s_mov_b64 s[%d:%d], vcc" % (PTR + 8, PTR + 9))   # the borrow chain survives the compare below
+        emit("v_mov_b32 v52, v62")
+        for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15 row_mask:0xa", "row_bcast:31 row_mask:0xc"):
+            emit("s_nop 1")
+            emit("v_max_u32_dpp v52, v52, v52 %s%s" % (ctrl, "" if "row_mask" in ctrl else " row_mask:0xf") + " bank_mask:0xf")
+        emit("v_mov_b32 v53, 0x40000000")
+        emit("v_readlane_b32 s%d, v52, 63" % (PTR + 10))
+        emit("s_mov_b32 %[segc], 0")
+        emit("v_cmp_eq_u32_e32 vcc, s%d, v62" % (PTR + 10))
+        emit("v_cndmask_b32_e32 v52, 0, v53, vcc")
+        emit("s_mov_b64 vcc, s[%d:%d]" % (PTR + 8, PTR + 9))
+        emit("v_or_b32 v63, v52, v63")
+        emit("5:")
     if "nostore" not in EXP:
         emit("global_store_dword v50, v63, %[sv]")
     emit("v_add_u32 v50, 0x100, v50")
@@ -249,18 +269,21 @@ def gen_rate(cr, integer):
     emit("v_mov_b32 %[voff], v50")
     emit("s_mov_b32 %%[nblk], %s" % cnt)
     body = "\n".join('      "%s\\n\\t"' % x for x in L)
-    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(8)] + \
+    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(11)] + \
            ['"s%d"' % (b + i) for b in SETBASE for i in range(SETSZ)] + ['"v%d"' % r for r in range(50, 64)]
     ins = ['[ka%d] "v"(K[%d].a)' % (q, q) for q in range(6)] + ['[kb%d] "v"(K[%d].b)' % (q, q) for q in range(6)]
     if integer:
-        ins += ['[init] "v"(init)', '[flip] "v"(flip)', '[bound] "s"(bound)']
+        ins += ['[init] "v"(init)', '[flip] "v"(flip)', '[bound] "s"(bound)', '[segn] "s"(segn)']
     else:
         ins += ['[cls%d] "v"(K[%d].cls)' % (q, q) for q in range(4)]
     ins += ['[llr] "s"(llr)', '[sv] "s"(sv)']
     n_valu = sum(1 for x in L if x.startswith("v_") and "%[pre]" not in x and "%[acc]" not in x and "v50" not in x
-                 and "v_cmp_gt_f32_e64" not in x and "%[init]" not in x and "%[flip]" not in x)
+                 and "v_cmp_gt_f32_e64" not in x and "%[init]" not in x and "%[flip]" not in x and "v52, v52" not in x and "v52, v62" not in x
+                 and "v_readlane" not in x and "v_cmp_eq_u32" not in x and "0x40000000" not in x and "v_cndmask_b32_e32 v52" not in x
+                 and x != "v_or_b32 v63, v52, v63")
     name = "lean_blocks_int" if integer else "lean_blocks_asm"
-    extra = "unsigned init, unsigned flip, float bound, " if integer else ""
+    extra = "unsigned init, unsigned flip, float bound, int& segc, int segn, " if integer else ""
+    outs2 = ', [segc] "+s"(segc)' if integer else ""
     return """
 // code rate %s: %d LLRs per block in %d load groups; %d VALU instructions per 30 steps (%.2f per step)
 template <> __device__ __forceinline__ void %s<%d>(float& pre, unsigned& acc, const LeanK (&K)[6], %sunsigned& voff,
@@ -268,11 +291,11 @@ template <> __device__ __forceinline__ void %s<%d>(float& pre, unsigned& acc, co
 {
   asm volatile(
 %s
-      : [pre] "+v"(pre), [acc] "+v"(acc), [voff] "+v"(voff), [nblk] "+s"(nblk)
+      : [pre] "+v"(pre), [acc] "+v"(acc), [voff] "+v"(voff), [nblk] "+s"(nblk)%s
       : %s
       : %s);
 }
-""" % (cr, n, G, n_valu, n_valu / 30.0, name, RATES[cr], extra, body, ", ".join(ins), ", ".join(clob)), n_valu
+""" % (cr, n, G, n_valu, n_valu / 30.0, name, RATES[cr], extra, body, outs2, ", ".join(ins), ", ".join(clob)), n_valu
 
 
 def main():
@@ -298,7 +321,7 @@ def main():
 #pragma once
 
 template <int CR> __device__ __forceinline__ void lean_blocks_int(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned init, unsigned flip,
-                                                                   float bound, unsigned& voff, const float* llr, unsigned* sv, int& nblk);
+                                                                   float bound, int& segc, int segn, unsigned& voff, const float* llr, unsigned* sv, int& nblk);
 template <int CR> __device__ __forceinline__ void lean_blocks_asm(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned& voff,
                                                                    const float* llr, unsigned* sv, int& nblk);
 """ % tuple(counts[(cr, i)] for i in (True, False) for cr in ("12", "23", "34", "56"))
