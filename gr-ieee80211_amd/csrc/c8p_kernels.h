@@ -869,6 +869,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     return;
   }
   bool ok = decodable(t);                          // wave-uniform: this wave also decodes
+#ifdef C8P_EXP_CLOCK   // experiment build (tools/exp_clock.py): shader cycles of this wave and where it ran, instead of the statistics
+  const unsigned long long exp_t0 = clock64();
+  unsigned exp_hw, exp_xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(exp_hw), "=s"(exp_xcc));
+#endif
   const cf Hl = t.format == C8P_F_L ? chan[P.chan_off + lane] : Hin[(size_t)p * 64 + lane];
   const cf* x1 = iq + P.iq_off[0] + t.data_off + 8 + lane;
   unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
@@ -948,6 +953,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     case C8P_CR_34: lean_tail<C8P_CR_34>(S, K, out, t.total, Tn, sv); break;
     default:        lean_tail<C8P_CR_56>(S, K, out, t.total, Tn, sv); break;
   }
+#ifdef C8P_EXP_CLOCK
+  if (lane == 0) { flags[n + p] = (uint32_t)(clock64() - exp_t0); flags[2 * n + p] = (exp_hw & 0xffffu) | ((exp_xcc & 0xfu) << 16); }
+#endif
 }
 
 // ================================================================================================ finish
