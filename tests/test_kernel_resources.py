@@ -51,3 +51,14 @@ def test_side_kernels_stay_inside_their_budgets(usage):
     assert usage["k_classify"]["VGPRs"] <= 72, usage["k_classify"]
     assert usage["k_finish"]["LDS Size"] <= 24 * 1024 and usage["k_finish"]["ScratchSize"] == 0, usage["k_finish"]
     assert usage["k_presiso"]["ScratchSize"] == 0 and usage["k_tx_sym"]["ScratchSize"] <= 16
+
+
+def test_generated_block_loop_is_current(tmp_path):
+    """csrc/c8p_lean_asm.h is generated (tools/gen_lean_asm.py) and committed: the committed file must be what the generator writes"""
+    import sys
+    out = tmp_path / "c8p_lean_asm.h"
+    env = dict(os.environ, C8P_GEN_OUT=str(out))
+    env.pop("C8P_GEN_EXP", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_lean_asm.py")], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text() == open(os.path.join(CSRC, "c8p_lean_asm.h")).read()

@@ -45,7 +45,7 @@ import os
 EXP = os.environ.get("C8P_GEN_EXP", "")      # timing experiments only (results are wrong): nowait, nostore, nocheck
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gr-ieee80211_amd", "csrc", "c8p_lean_asm.h")
+OUT = os.environ.get("C8P_GEN_OUT") or os.path.join(ROOT, "gr-ieee80211_amd", "csrc", "c8p_lean_asm.h")
 
 BLK = 30
 RATES = {"12": 0, "23": 1, "34": 2, "56": 3}   # name: C8P_CR_* value
