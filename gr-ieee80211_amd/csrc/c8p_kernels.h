@@ -799,11 +799,12 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
                                                       const float* __restrict__ llr, ulonglong2* __restrict__ surv,
                                                       uint32_t* __restrict__ flags, const float* __restrict__ negsym,
-                                                      const c8p_pkt_in* __restrict__ pk_2x2_only, int n)
+                                                      const c8p_pkt_in* __restrict__ pk_2x2_only, const uint8_t* __restrict__ done4, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
   if (flags[p] != 0) return;
+  if (done4 && done4[p]) return;                   // decoded by k_viterbi_lean4
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
   if (pk_2x2_only && !(pk_2x2_only[p].n_ant == 2 && t.nss == 2)) return;   // c8p_rx: single-stream packets were decoded by k_rx_1ss
@@ -836,6 +837,110 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_vi
 #endif
 }
 
+
+
+// Four packets per wave (c8p_viterbi_lean.h, bottom; tools/gen_lean4_asm.py).  Wave w takes packets 4w .. 4w+3 if all four can be
+// decoded by the lean path, share the code rate and the trellis length; it marks them in done4[] and k_viterbi_lean skips them.
+// Otherwise it leaves them to k_viterbi_lean.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_viterbi_lean4(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                       const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                       uint32_t* __restrict__ flags, uint8_t* __restrict__ done4, int n)
+{
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (4 * w + 3 >= n) return;                      // (a last, partial quad goes to k_viterbi_lean)
+  const int lane = lane_id(), row = lane >> 4, l = lane & 15;
+  const int p = 4 * w + row;
+  const c8p_pkt_tags t = tags[p];                  // per row
+  const c8p_pkt_tags t0 = tags[4 * w];             // wave-uniform copy of the first packet's tags
+  const bool good = decodable(t) && flags[p] == 0 && t.cr == t0.cr && t.trellis == t0.trellis;
+  if (__ballot(good) != ~0ull) return;
+  if (l == 0) done4[p] = 1;
+  const int Tn = __builtin_amdgcn_readfirstlane(t0.trellis), nfull = Tn / C8P_SV_BLK, segn = c8p_seg_blocks(Tn);
+  const float bound = fmaf(__uint_as_float(flags[2 * n + p]), 1.01f, 1e-30f);     // per row (lean_bound)
+  unsigned voff = (unsigned)(lay[p].surv_off * 16u) + (unsigned)l * 4u;             // byte offsets into the arenas (< 4 GB)
+  unsigned laddr = (unsigned)(t.llr_off * 4u);
+  unsigned* const svb = (unsigned*)surv;
+  __shared__ float xch_all[4][4][64];              // [wave][packet][index D]: the bridge between the two layouts
+  float (*xch)[64] = xch_all[threadIdx.x >> 6];
+  float m[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) m[r] = (l == 0 && r == 0) ? 0.0f : C8P_NEG_INIT;
+  int done = 0, segc = 0, nflt = 0;
+  while (done < nfull) {
+    // integer loop, all four packets at once, as long as every metric of every row stays above its row's bound
+    const float mn = fminf(fminf(m[0], m[1]), fminf(m[2], m[3]));
+    if (__ballot(mn < bound) == 0ull) {
+      LeanK K4[6];
+      lean4_k_consts(l, K4);
+      unsigned initx, inity, flip;
+      lean4_int_consts(l, initx, inity, flip);
+      int left = __builtin_amdgcn_readfirstlane(nfull - done), sc = __builtin_amdgcn_readfirstlane(segc);   // (asm "+s" operands)
+      switch (t0.cr) {
+        case C8P_CR_12: lean4_int<C8P_CR_12>(m, K4, initx, inity, flip, bound, sc, segn, voff, laddr, llr, svb, left); break;
+        case C8P_CR_23: lean4_int<C8P_CR_23>(m, K4, initx, inity, flip, bound, sc, segn, voff, laddr, llr, svb, left); break;
+        case C8P_CR_34: lean4_int<C8P_CR_34>(m, K4, initx, inity, flip, bound, sc, segn, voff, laddr, llr, svb, left); break;
+        default:        lean4_int<C8P_CR_56>(m, K4, initx, inity, flip, bound, sc, segn, voff, laddr, llr, svb, left); break;
+      }
+      segc = sc;
+      done = nfull - left;
+      if (done == nfull) break;
+    }
+    // one block of every packet with the lane = index code (it chooses the float or the integer step itself)
+#pragma unroll
+    for (int r = 0; r < 4; r++) xch[row][r * 16 + l] = m[r];
+    for (int pp = 0; pp < 4; pp++) {
+      const int q = __builtin_amdgcn_readfirstlane(4 * w + pp);
+      LeanK K[6];
+      lean_k_consts(lane, K);
+      unsigned init, flip;
+      lean_int_consts(lane, init, flip);
+      LeanState S;
+      lean_init(S, lane);
+      S.pre = xch[pp][lane]; S.done = done; S.segc = segc;
+      S.voff = (unsigned)lane * 4u + (unsigned)done * 256u;
+      const c8p_pkt_tags tq = tags[q];
+      const float* L = llr + tq.llr_off;
+      unsigned* sv = (unsigned*)(surv + lay[q].surv_off);
+      const float bq = lean_bound(__uint_as_float(flags[2 * n + q]));
+      switch (t0.cr) {
+        case C8P_CR_12: lean_blocks<C8P_CR_12, false>(S, K, init, flip, bq, L, tq.total, sv, done + 1, segn); break;
+        case C8P_CR_23: lean_blocks<C8P_CR_23, false>(S, K, init, flip, bq, L, tq.total, sv, done + 1, segn); break;
+        case C8P_CR_34: lean_blocks<C8P_CR_34, false>(S, K, init, flip, bq, L, tq.total, sv, done + 1, segn); break;
+        default:        lean_blocks<C8P_CR_56, false>(S, K, init, flip, bq, L, tq.total, sv, done + 1, segn); break;
+      }
+      xch[pp][lane] = S.pre;
+      if (pp == 3) segc = S.segc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) m[r] = xch[row][r * 16 + l];
+    done++; nflt++;
+    voff += 256u;
+    laddr += 4u * (unsigned)(t0.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t0.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                             t0.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB);
+  }
+  if (l == 0) flags[n + p] = (uint32_t)nflt;       // C8P_BUF_DECSTAT: blocks that went through the lane = index code
+  // the partial last block, packet by packet
+#pragma unroll
+  for (int r = 0; r < 4; r++) xch[row][r * 16 + l] = m[r];
+  for (int pp = 0; pp < 4; pp++) {
+    const int q = __builtin_amdgcn_readfirstlane(4 * w + pp);
+    LeanK K[6];
+    lean_k_consts(lane, K);
+    LeanState S;
+    lean_init(S, lane);
+    S.pre = xch[pp][lane];
+    S.voff = (unsigned)lane * 4u + (unsigned)nfull * 256u;
+    const c8p_pkt_tags tq = tags[q];
+    const float* L = llr + tq.llr_off;
+    unsigned* sv = (unsigned*)(surv + lay[q].surv_off);
+    switch (t0.cr) {
+      case C8P_CR_12: lean_tail<C8P_CR_12>(S, K, L, tq.total, Tn, sv); break;
+      case C8P_CR_23: lean_tail<C8P_CR_23>(S, K, L, tq.total, Tn, sv); break;
+      case C8P_CR_34: lean_tail<C8P_CR_34>(S, K, L, tq.total, Tn, sv); break;
+      default:        lean_tail<C8P_CR_56>(S, K, L, tq.total, Tn, sv); break;
+    }
+  }
+}
 
 // ================================================================================================ c8p_rx, single-stream packets
 // Symbol demodulation AND the lean forward pass in one wave per packet: the wave demodulates OFDM symbol s into the packet's LLR

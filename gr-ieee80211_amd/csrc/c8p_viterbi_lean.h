@@ -294,7 +294,9 @@ __device__ __forceinline__ float lean_bound(float negb)    // wave-uniform (SGPR
 #define C8P_SV_HINT 0x40000000u
 __device__ __forceinline__ int c8p_seg_blocks(int Tn) { return (Tn + 64 * C8P_SV_BLK - 1) / (64 * C8P_SV_BLK); }
 
-template <int CR>
+// TOUCH = false: no scalar-cache touches in the float step (k_viterbi_lean4 runs single blocks from inside two nested loops, where
+// the compiler cannot keep the loop-carried touch registers in SGPRs)
+template <int CR, bool TOUCH = true>
 __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], unsigned init, unsigned flip, float bound,
                                             const float* __restrict__ Lg, int n_llr, unsigned* __restrict__ sv, int upto, int segn)
 {
@@ -303,7 +305,8 @@ __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], u
   static_assert(NLB <= C8P_NEGB_WINDOW, "negb covers windows of C8P_NEGB_WINDOW LLRs");
   c4float* L = (c4float*)Lg;
   float x[NL];
-  int left = upto - S.done;
+  upto = __builtin_amdgcn_readfirstlane(upto);
+  int left = __builtin_amdgcn_readfirstlane(upto - S.done);   // (wave-uniform; an asm "+s" operand)
   // touch registers: loop-carried ("+s") so that they can never share an SGPR with x[] — the touches are still in
   // flight when the next block's real loads are issued, and scalar loads may return in any order
   unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
@@ -311,7 +314,9 @@ __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], u
     // integer compare: as many blocks as keep every metric above the bound
 #ifndef C8P_EXP_NO_INT
     if (__ballot(S.pre < bound) == 0ull) {
-      lean_blocks_int<CR>(S.pre, S.acc, K, init, flip, bound, segc, segn, S.voff, Lg + (size_t)(upto - left) * NLB, sv, left);
+      int sc = __builtin_amdgcn_readfirstlane(segc), lf = __builtin_amdgcn_readfirstlane(left);   // (asm "+s" operands: loop-carried values
+      lean_blocks_int<CR>(S.pre, S.acc, K, init, flip, bound, sc, segn, S.voff, Lg + (size_t)(upto - lf) * NLB, sv, lf);   // must not pick up a VGPR copy)
+      segc = sc; left = lf;
       if (left == 0) break;
     }
 #endif
@@ -321,7 +326,7 @@ __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], u
     for (int r = 0; r < REP; r++, lb += NL) {
 #pragma unroll
       for (int i = 0; i < NL; i++) { x[i] = L[lb + i]; }
-      if (r == 0) {
+      if (TOUCH && r == 0) {
         // Scalar loads return out of order, so the only usable wait is lgkmcnt(0): a real prefetch of the next block
         // would be drained by the wait of this one.  Instead, right after that wait (the x[] inputs force it before
         // this statement), touch the scalar-cache lines of the NEXT block with throw-away loads: they complete during
@@ -351,7 +356,7 @@ __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], u
       segc = 0;
     }
     *(unsigned*)((char*)sv + S.voff) = word;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4));   // touches land before the integer loop reuses SGPRs
+    if (TOUCH) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3), "+s"(d4));   // touches land before the integer loop reuses SGPRs
     S.voff += 256u; left--; S.nflt++;
   }
   S.done = upto; S.segc = __builtin_amdgcn_readfirstlane(segc);   // (wave-uniform: keep it out of the VGPRs)
@@ -397,4 +402,39 @@ __device__ __forceinline__ void lean_forward(const float* __restrict__ Lg, int n
   lean_blocks<CR>(S, K, init, flip, lean_bound(negb), Lg, n_llr, sv, Tn / C8P_SV_BLK, c8p_seg_blocks(Tn));
   if (lane == 0) *n_float_blocks = (uint32_t)S.nflt;   // diagnostic (C8P_BUF_DECSTAT): blocks that did not qualify for the integer loop
   lean_tail<CR>(S, K, Lg, n_llr, Tn, sv);
+}
+
+
+// ================================================================================================ four packets per wave
+// tools/gen_lean4_asm.py: a packet = one row of 16 lanes x four registers, index D = (lane & 15) + 16 r in the role of the lane index
+// above.  Only the integer-compare block loop exists in this layout (lean4_int); float-step blocks, the partial last block and
+// everything else run the code above, one packet at a time, after the metrics went through LDS into the lane = index layout.
+#include "c8p_lean4_asm.h"
+
+// lane constants of the row layout: the coefficient pairs of index D = l (register 0) without the permlane arrangement of q = 4, 5;
+// register r's classes differ by a compile-time XOR (the generator's delta(q, r))
+__device__ __forceinline__ void lean4_k_consts(int l, LeanK (&K)[6])
+{
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int nst = rotr6(l, (q + 1) % 6);
+    const int m = nst & 31, b = nst >> 5;
+    const int cK = b ? sv_out(2 * m + 1, 1) : sv_out(2 * m, 0), cS = 3 - cK;
+    K[q].a = v2f{(cK >> 1) ? 1.0f : 0.0f, (cS >> 1) ? 1.0f : 0.0f};
+    K[q].b = v2f{(cK & 1) ? 1.0f : 0.0f, (cS & 1) ? 1.0f : 0.0f};
+    K[q].cls = 0;
+  }
+}
+// decision registers of the row layout start a block as: registers 0..2 `initx` (bit 31-k = borrow-in of the NEXT register of the
+// same step k: 1 where this lane holds the even predecessor in phase k mod 6), register 3 `inity` (borrow-in of step k+1) = `init`
+// of lean_int_consts; `flip` is the same as there
+__device__ __forceinline__ void lean4_int_consts(int l, unsigned& initx, unsigned& inity, unsigned& flip)
+{
+  lean_int_consts(l, inity, flip);
+  initx = 0;
+#pragma unroll
+  for (int k = 0; k < C8P_SV_BLK; k++) {
+    const int q = k % 6;
+    if (q <= 3 && !((l >> q) & 1)) initx |= 1u << (31 - k);
+  }
 }

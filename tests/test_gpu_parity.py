@@ -585,3 +585,29 @@ def test_negative_part_bound_of_the_symbol_demodulator(eng):
         assert bound[p] >= win * (1 - 1e-6)
         checked += 1
     assert checked > 20
+
+
+def test_four_packets_per_wave_decoder(eng, monkeypatch):
+    """c8p_decode sends quads of consecutive packets with the same code rate and trellis length through k_viterbi_lean4 (16 lanes x 4
+    registers per packet: tools/gen_lean4_asm.py).  Streams with ties and positive drift (integer loop), a quad that starts with large
+    negative LLRs (leaves and re-enters the loop), a partial last block; bits identical to the oracle for all four code rates."""
+    monkeypatch.setenv("C8P_LEAN4", "1")                  # (by default only batches of >= 12288 packets take this kernel)
+    rng = np.random.default_rng(2024)
+    streams = []
+    for cr, per in ((abi.CR_12, 2.0), (abi.CR_23, 1.5), (abi.CR_34, 4.0 / 3.0), (abi.CR_56, 1.2)):
+        for T in (2417, 6000):
+            for k in range(4):
+                n = int(np.ceil(T * per)) + 2
+                mag = np.round(np.abs(rng.normal(0, 1.5, size=n)) * 4) / 4
+                sgn = np.where(rng.random(n) < 0.85, 1.0, -1.0)
+                llr = (mag * sgn).astype(np.float32)
+                if k == 1:
+                    llr = np.round(llr)
+                if k == 2 and T == 6000:
+                    llr[n // 2:n // 2 + 40] = -90.0
+                streams.append((T, cr, llr))
+    flags, nflt = _decode_streams(eng, streams)
+    assert not flags.any()
+    for k, (T, cr, llr) in enumerate(streams):
+        if T != 6000:                                      # (the quads with the burst share its large bound)
+            assert nflt[k] < 0.6 * (T // 30), (T, cr, int(nflt[k]))
