@@ -423,7 +423,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
       const char* e4 = getenv("C8P_LEAN4");
       const bool lean4 = e4 ? atoi(e4) != 0 : n >= 12288;
       const uint8_t* d_done4 = nullptr;
-      if (!rx && lean4) {
+      if (!rx && lean4 && n >= 4) {
         if ((rc = ensure(c, c->s->d_done4, (size_t)n + 4)) != C8P_OK) return rc;
         HIPCHK(c, hipMemsetAsync(c->s->d_done4.p, 0, (size_t)n, dst));
         hipLaunchKernelGGL(k_viterbi_lean4, dim3((n / 4 + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
