@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   const PktLayout Lp = lay[p];
   uint8_t* area = pdu + Lp.pdu_off;
   uint32_t used = 0;
-  int n_pdu = 0, n_fail = 0;
+  int n_pdu = 0, n_fail = 0, tb_passes = 0;
 
   if (t.status == C8P_ST_OK && t.len <= C8P_DECODE_B_MAX && t.trellis <= C8P_DECODE_T_MAX && t.trellis == 0) {
     // NDP channel report (decode_impl.cc:100-121)
@@ -1253,6 +1253,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         if (lane >= nseg - 1) nd = 0;
         redo = have && (nd != Dend);
         Dend = nd;
+        tb_passes = it + 1;
         if (!__any(redo)) break;
       }
       // ---- decoded bits: word c = times 64c .. 64c+63, gathered from the 6-bit group snapshots
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   }
   if (lane == 0) {
     c8p_pkt_out o;
-    o.n_pdu = n_pdu; o.n_crc_fail = n_fail; o.pdu_bytes = used; o.rsv = 0;
+    o.n_pdu = n_pdu; o.n_crc_fail = n_fail; o.pdu_bytes = used; o.rsv = (uint32_t)tb_passes;
     o.pdu_off = Lp.pdu_off; o.bits_off = Lp.bits_off;
     outs[p] = o;
   }

@@ -126,7 +126,8 @@ typedef struct c8p_pkt_out {
   int32_t  n_pdu;       /* PDUs published on port "out" for this packet (FCS-correct subframes / NDP report) */
   int32_t  n_crc_fail;  /* (sub)frames whose CRC-32 residue was wrong                                   */
   uint32_t pdu_bytes;   /* bytes used in this packet's PDU area: n_pdu records of {u16 len LE, len bytes} */
-  uint32_t rsv;
+  uint32_t rsv;         /* diagnostic: passes of the segment-parallel traceback over this packet (1 = every segment started from the
+                           right lane, i.e. every hint of the forward pass was right); 0 on the other decoder paths   */
   uint64_t pdu_off;     /* byte offset of the packet's PDU area inside the PDU arena                     */
   uint64_t bits_off;    /* byte offset of the packet's decoded bits (1 bit per byte) inside the bits arena */
 } c8p_pkt_out;

@@ -611,3 +611,17 @@ def test_four_packets_per_wave_decoder(eng, monkeypatch):
     for k, (T, cr, llr) in enumerate(streams):
         if T != 6000:                                      # (the quads with the burst share its large bound)
             assert nflt[k] < 0.6 * (T // 30), (T, cr, int(nflt[k]))
+
+
+def test_traceback_hints_save_the_second_walk(eng):
+    """At 30 dB nearly every traceback segment starts from the lane the forward pass marked (bit 30 of the segment's last survivor
+    block): k_finish needs one pass for most packets (c8p_pkt_out.rsv), and the PDUs are the transmitted MPDUs either way."""
+    b, expected = cfg2_batch(256, snr_db=30.0, seed=77)
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    res = eng.results(want_llr=False)
+    outs = eng.outs()
+    assert sum(r["pdus"] == [e] for r, e in zip(res, expected)) >= 250
+    passes = outs["rsv"]
+    assert (passes >= 1).all()
+    assert (passes == 1).mean() > 0.8, np.bincount(passes)
