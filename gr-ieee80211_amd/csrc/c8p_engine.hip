@@ -438,7 +438,11 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   }
   {
     KTimer kt(c, C8P_K_FINISH, fst);
-    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), 0, fst, d_tags, d_lay, (const ulonglong2*)c->s->d_surv.p, d_mu,
+    uint32_t tmax = 0;
+    for (const PktLayout& L : P.lay) tmax = L.trellis_cap > tmax ? L.trellis_cap : tmax;
+    uint32_t snap_bytes = ((tmax + 5u) / 6u + 2u + 15u) & ~15u;      // one byte per 6-step group; afterwards the 1 KB CRC table
+    if (snap_bytes < 1024u) snap_bytes = 1024u;
+    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), snap_bytes, fst, d_tags, d_lay, (const ulonglong2*)c->s->d_surv.p, d_mu,
                        (const DevTables*)c->d_tab, (c8p_pkt_out*)c->s->d_outs.p, (uint8_t*)c->s->d_pdu.p, (uint8_t*)c->s->d_bits.p,
                        (uint8_t*)c->s->d_sbits.p, d_flags, c->keep_bits, n);
   }

@@ -1132,11 +1132,13 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                int keep_bits, int n)
 {
   constexpr int TS = 68;                                  // tile row stride in dwords (16-byte aligned rows, banks shifted by 4)
-  constexpr int NSNAP = (C8P_DECODE_T_MAX + 5) / 6 + 2;
   // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
   // memory holds bw[], the decoded bits packed 64 per word.
   __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
-  __shared__ __attribute__((aligned(16))) uint8_t snaps[(NSNAP + 7) & ~7];              // lane D at the entry of every 6-step group = 6 decoded bits
+  // lane D at the entry of every 6-step group = 6 decoded bits; later the CRC-32 byte table.  Dynamic: sized by the launch for the
+  // longest trellis of the batch (c8p_finish_lds_bytes: 2 KB at cfg 2 instead of the 5.5 KB of the longest legal trellis), which lets
+  // 8 instead of 6 of these one-wave workgroups share a CU's LDS
+  extern __shared__ __attribute__((aligned(16))) uint8_t snaps[];
   __shared__ uint16_t s_btop[64];
   unsigned long long* bw = (unsigned long long*)tile;      // (C8P_DECODE_T_MAX + 63) / 64 + 2 words <= 64 * TS / 2
   static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= 64 * TS * 4, "bw must fit in the tile");
