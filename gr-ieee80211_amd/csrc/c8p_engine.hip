@@ -479,8 +479,8 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
-  // the previous submit's async copy out of the pinned buffer must have finished before we overwrite it
-  HIPCHK(c, hipStreamSynchronize(c->s->stream));
+  // (the slot's stream was synchronised when the slot was taken, and nothing has been enqueued on it since: the previous submit's
+  // asynchronous copy out of the pinned buffer has finished)
   memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
   memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
   {
@@ -558,7 +558,6 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->s->stream));
   memcpy((char*)c->s->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
   memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
   {
