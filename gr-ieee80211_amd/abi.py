@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MEM_HOST, MEM_DEVICE = 0, 1
 F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
@@ -49,7 +49,7 @@ class PktOut(C.Structure):
 
 class Cfg(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("profile", C.c_int32),
-                ("keep_bits", C.c_int32), ("stream", C.c_void_p)]
+                ("keep_bits", C.c_int32), ("stream", C.c_void_p), ("keep_llr", C.c_int32)]
 
 
 class BatchIn(C.Structure):

@@ -77,6 +77,14 @@ __device__ __forceinline__ float cabs_(cf a)
 
 // ---------------------------------------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// the lane index recomputed on the spot (two VALU instructions the compiler can neither hoist nor share): for kernels whose phases
+// must not keep ANY per-lane value alive between them — a shared lane_id() is one more register held, or spilled, across a loop
+__device__ __forceinline__ int lane_fresh()
+{
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ cf shfl_c(cf v, int src) { return mk(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); }
 __device__ __forceinline__ float readlane_f(float v, int l)

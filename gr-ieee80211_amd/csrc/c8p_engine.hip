@@ -202,7 +202,7 @@ struct Slot {
 struct c8p_ctx {
   int device = 0;
   bool own_stream = false;
-  int profile = 0, keep_bits = 0;
+  int profile = 0, keep_bits = 0, keep_llr = 0;
   unsigned seq = 0;                                  // submits so far (profile sampling)
   int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
   std::string err;
@@ -276,6 +276,7 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile < 0 ? 0 : cfg->profile; c->keep_bits = cfg->keep_bits;
+  { const char* e = getenv("C8P_RX_LLR"); c->keep_llr = e ? atoi(e) != 0 : cfg->keep_llr != 0; }   // (the env switch: A/B runs)
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
   {
     // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 4) engine-owned streams.
@@ -414,9 +415,15 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
       // c8p_rx: single-stream packets are demodulated AND decoded by k_rx_1ss; two-stream packets (only possible with two antennas)
       // went through k_demod_sym and are decoded by k_viterbi_lean, as every packet of a c8p_decode batch is
-      if (rx)
+      if (rx && c->keep_llr)
         hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
+                           d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, 0);
+      else if (rx) {     // the LLR stream stays in LDS; what the lean decoder cannot take is demodulated once more, into the arena
+        hipLaunchKernelGGL(k_rx_1ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
                            d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+        hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
+                           d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, 1);
+      }
       // c8p_decode: quads of packets with the same rate and length can go through the four-packets-per-wave kernel (17 % fewer VALU
       // instructions per packet, but 4 x fewer waves): it wins when one batch alone gives every SIMD several of its fat waves —
       // measured -12 % decode time at 16384 packets per batch, +6 % at 4096.  C8P_LEAN4 = 1 / 0 forces it on / off.
@@ -526,7 +533,8 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   }
   HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = c->s->d_tags.p;
-  c->s->used[C8P_BUF_LLR] = sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
+  // (c8p_rx without keep_llr: the fused kernel keeps the LLRs in LDS, the arena only holds what the exceptions needed)
+  c->s->used[C8P_BUF_LLR] = (fused && !c->keep_llr) ? 0 : sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
   c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
   if (!with_decode) return C8P_OK;
   const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant};

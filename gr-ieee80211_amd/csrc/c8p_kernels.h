@@ -958,10 +958,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
-                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n, int only_flagged)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
+  if (only_flagged && flags[p] == 0) return;       // after k_rx_1ss_lds: demodulate what it left to the exact decoder
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   const c8p_pkt_in P = pk[p];
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
     return;
   }
-  bool ok = decodable(t);                          // wave-uniform: this wave also decodes
+  bool ok = decodable(t) && !only_flagged;         // wave-uniform: this wave also decodes
 #ifdef C8P_EXP_CLOCK   // experiment build (tools/exp_clock.py): shader cycles of this wave and where it ran, instead of the statistics
   const unsigned long long exp_t0 = clock64();
   unsigned exp_hw, exp_xcc;
@@ -1061,6 +1062,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #ifdef C8P_EXP_CLOCK
   if (lane == 0) { flags[n + p] = (uint32_t)(clock64() - exp_t0); flags[2 * n + p] = (exp_hw & 0xffffu) | ((exp_xcc & 0xfu) << 16); }
 #endif
+}
+
+// ---- the same with the LLR stream kept on chip (c8p_rx unless c8p_cfg.keep_llr: C8P_BUF_LLR is then NOT filled) -------------------
+// The wave scatters a symbol's de-interleaved LLRs into its own LDS buffer (behind what the last round left over), runs every
+// survivor block that is complete with the LLRs as VGPR operands (lean_blocks_lds: broadcast ds_read_b128 into a rotating set of 12
+// registers that only exist inside the block loop) and moves the < 60 left-over LLRs to the front.  Neither the 235 MB of LLR
+// stores nor their read-back (an EA read even when it hits L2, tools/probe_l2rw.hip) exist any more: 1.58 -> 1.1 GB per
+// 4096-packet step.  Buffer: 59 left over + 416 of a 256-QAM symbol = 475 floats.  A packet with an LLR outside the integer
+// loop's range is rare: the wave flags it and stops, a second launch of k_rx_1ss (only_flagged) demodulates the flagged packets
+// into the LLR arena and k_viterbi_fwd decodes them.  Symbols that only carry padding behind the last trellis step are not demodulated at all.
+#define C8P_LBUF 480
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
+                                                const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
+                                                const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+{
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (p >= n) return;
+  const c8p_pkt_tags t = tags[p];
+  if (t.status != C8P_ST_OK) return;
+  const c8p_pkt_in P = pk[p];
+  if (P.n_ant == 2 && t.nss == 2) return;          // two streams: k_demod_sym + k_viterbi_lean
+  if (t.is_ndp || !decodable(t)) return;           // nothing to decode, and nobody reads the LLRs
+  const int lane = lane_id();
+  const int segn = c8p_seg_blocks(t.trellis);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ uint2 park[4][64];                    // the decoder's metric and survivor offset while a symbol is demodulated
+  __shared__ uint4 parkK[4][64];                   // its lane constants (packed coefficients, init, flip): written once, read per symbol
+  __shared__ cf parkH[4][64];                      // the channel: read back every symbol instead of living in two registers
+  __shared__ cf parkX[4][64];                      // the next symbol's sample while the blocks run
+  __shared__ __attribute__((aligned(16))) float lbuf[4][C8P_LBUF];
+  parkH[wv][lane] = t.format == C8P_F_L ? chan[P.chan_off + lane] : Hin[(size_t)p * 64 + lane];
+  const cf* x1 = iq + P.iq_off[0] + t.data_off + 8;               // wave-uniform; the lane is added per symbol
+  unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
+  unsigned kbits;
+  {
+    LeanK K0[6];
+    lean_k_consts(lane, K0);
+    kbits = lean_k_pack(K0);
+  }
+  {
+    unsigned init0, flip0;
+    lean_int_consts(lane, init0, flip0);
+    parkK[wv][lane] = make_uint4(kbits, init0, flip0, 0u);
+  }
+  LeanState S;
+  lean_init(S, lane);
+  const int Tn = t.trellis, nfull = Tn / C8P_SV_BLK;
+  const int nlb = t.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                  t.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
+  // ceil(65536 / nlb): (have * inv) >> 16 == have / nlb for have < 1499 (C8P_LBUF = 480).  Constants on purpose: a division is done by
+  // the VALU, and a wave-uniform value that comes out of the VALU drags every counter it touches into (spilled) VGPRs
+  const unsigned nlb_inv = t.cr == C8P_CR_12 ? 1093u : t.cr == C8P_CR_23 ? 1457u : t.cr == C8P_CR_34 ? 1639u : 1821u;
+  const int need_tail = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn) - nfull * nlb);       // LLRs the partial last block consumes (< nlb)
+  const float wfac = __uint_as_float(t.ncbps >= C8P_NEGB_WINDOW ? 0x40000000u : 0x40400000u);   // 2 or 3 (selected as bits: stays in an SGPR)
+  float negb = 0.0f;
+  int have = 0;                                    // LLRs in the buffer: lb[0] = first LLR of block S.done
+  cf xin = x1[lane];
+  float* const lb = lbuf[wv];
+  bool more = true;                                // false: the remaining symbols only carry padding behind the last trellis step
+  for (int s = 0; s < t.nsym && more; s++) {
+    // Nothing that depends on the lane lives across a phase: the lane index is taken afresh (opaque) in each, the decoder's state
+    // (metric, survivor offset, packed constants, the two integer-loop constants) waits in LDS while the symbol is demodulated, and
+    // the next symbol's sample waits there while the blocks run.  acc / pend are dead between blocks.
+    const int lane_s = lane_fresh();
+    park[wv][lane_s] = make_uint2(__float_as_uint(S.pre), S.voff);
+    asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.voff));
+    const cf xnext = x1[(uint32_t)((s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp + lane_s)];
+    cf Hs = parkH[wv][lane_s];
+    asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
+    const cf f1 = wave_fft64(xin, T, lane_s);
+    float neg = 0.0f;
+    const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg);
+    have += t.ncbps;
+    xin = xnext;
+    const int lane_d = lane_fresh();               // (again: the decoder's per-lane addresses and the pieces of the constant unpack must
+                                                   // not be hoisted out of the symbol loop either)
+    {
+      const uint2 a = park[wv][lane_d];
+      S.pre = __uint_as_float(a.x); S.voff = a.y;
+    }
+    if (__ballot(bad)) {                           // the exact decoder takes this packet; it wants the LLRs in memory:
+      if (lane_d == 0) flags[p] = 1u;              // k_rx_1ss (only_flagged) demodulates it once more, into the LLR arena
+      return;
+    }
+    neg = wave_sum_lane63(neg);
+    negb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(
+        fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac))));
+    const int done = S.done;
+    int nb = (int)(((unsigned)have * nlb_inv) >> 16);   // have / nlb: complete blocks in the buffer
+    if (nb > nfull - done) nb = nfull - done;
+    if (nb > 0) {
+      parkX[wv][lane_d] = xin;
+      asm volatile("; next sample parked" : "=v"(xin.x), "=v"(xin.y));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 kc = *(volatile u32x4*)&parkK[wv][lane_d];   // (volatile: read here, every time — not hoisted and kept in registers)
+      const unsigned init = kc.y, flip = kc.z;
+      LeanK K[6];
+      lean_k_unpack(kc.x, lane_d, K);
+      const float bound = lean_bound(negb);
+      const int upto = done + nb;
+      switch (t.cr) {
+        case C8P_CR_12: lean_blocks_l<C8P_CR_12>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
+        case C8P_CR_23: lean_blocks_l<C8P_CR_23>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
+        case C8P_CR_34: lean_blocks_l<C8P_CR_34>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
+        default:        lean_blocks_l<C8P_CR_56>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
+      }
+      // what is left over moves to the front (< nlb <= 60 LLRs unless the full blocks are all done; one lane each, 64 per pass)
+      const int used = nb * nlb;
+      have -= used;
+      for (int i = 0; i < have; i += 64) {
+        const float v = i + lane_d < have ? lb[used + i + lane_d] : 0.0f;
+        if (i + lane_d < have) lb[i + lane_d] = v;
+      }
+      xin = parkX[wv][lane_fresh()];
+    }
+    more = !(S.done == nfull && have >= need_tail);              // the remaining symbols only carry padding
+  }
+  const int lane_t = lane_fresh();
+  if (lane_t == 0) { flags[n + p] = (uint32_t)S.nflt; flags[2 * n + p] = __float_as_uint(negb); }   // C8P_BUF_DECSTAT
+  LeanK K[6];
+  lean_k_unpack(parkK[wv][lane_t].x, lane_t, K);
+  switch (t.cr) {
+    case C8P_CR_12: lean_tail_l<C8P_CR_12>(S, K, lb, have, lane_t, Tn, sv); break;
+    case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lb, have, lane_t, Tn, sv); break;
+    case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane_t, Tn, sv); break;
+    default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane_t, Tn, sv); break;
+  }
 }
 
 // ================================================================================================ finish

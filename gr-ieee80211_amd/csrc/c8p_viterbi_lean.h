@@ -385,6 +385,66 @@ __device__ __forceinline__ void lean_tail(LeanState& S, const LeanK (&K)[6], con
   }
 }
 
+// ---- the same two pieces with the LLRs in LDS (k_rx_1ss_lds: the wave that demodulated them decodes them, nothing goes through HBM)
+// lb: the wave's LDS buffer, lb[0] = first LLR of block S.done.  The integer loop reads it straight into VGPRs (lean_blocks_lds);
+// the float step wants its LLRs in SGPRs: one LDS read (lane i fetches LLR i of the super-iteration) and a v_readlane per LLR —
+// 5 % of the blocks at cfg 2 / 30 dB, so the extra 36 instructions per block do not show.
+template <int CR>
+__device__ __forceinline__ void lean_blocks_l(LeanState& S, const LeanK (&K)[6], unsigned init, unsigned flip, float bound,
+                                              const float* lb, int lane, unsigned* __restrict__ sv, int upto, int segn)
+{
+  int segc = S.segc;                                          // (no readfirstlane on these wave-uniform counters: the intrinsic wants its
+                                                              // operand in a VGPR, and the counters would then LIVE in — spilled — VGPRs)
+  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER, NLB = NL * REP;
+  static_assert(NLB <= C8P_NEGB_WINDOW && NL <= 64, "negb covers windows of C8P_NEGB_WINDOW LLRs; one lane per LLR of a super-iteration");
+  const unsigned la = (unsigned)(size_t)lb;                    // LDS byte address (low half of the flat address)
+  const int n0 = upto - S.done;
+  int left = n0;
+  while (left > 0) {
+    if (__ballot(S.pre < bound) == 0ull) {
+      int sc = segc, lf = left;
+      lean_blocks_lds<CR>(S.pre, S.acc, K, init, flip, bound, sc, segn, S.voff, la + (unsigned)((n0 - lf) * NLB * 4), sv, lf);
+      segc = sc; left = lf;
+      if (left == 0) break;
+    }
+    lean_block_flt_lds<CR>(S.pre, S.acc, K, la + (unsigned)((n0 - left) * NLB * 4));
+    unsigned word = S.acc & ~(C8P_SV_HINT | 0x80000000u);
+    if (++segc >= segn) {
+      float m = S.pre;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (S.pre == m) word |= C8P_SV_HINT;
+      segc = 0;
+    }
+    *(unsigned*)((char*)sv + S.voff) = word;
+    S.voff += 256u; left--; S.nflt++;
+  }
+  S.done = upto; S.segc = segc;
+}
+// lb[0] = first LLR of the partial block, n_avail of them exist (the rest read as 0.0f like the stream's end, lean_tail)
+template <int CR>
+__device__ __forceinline__ void lean_tail_l(LeanState& S, const LeanK (&K)[6], const float* lb, int n_avail, int lane, int Tn, unsigned* __restrict__ sv)
+{
+  constexpr int PER = RateInfo<CR>::PER, NL = RateInfo<CR>::NL, REP = C8P_SV_BLK / PER;
+  const int nfull = Tn / C8P_SV_BLK, tb = nfull * C8P_SV_BLK;
+  if (tb < Tn) {
+    float x[NL];
+    const int rem = Tn - tb;
+    int li = 0;
+#pragma unroll
+    for (int r = 0; r < REP; r++, li += NL) {
+      if (r * PER < rem) {
+        const int k = li + (lane < NL ? lane : 0);
+        const float v = k < n_avail ? lb[k] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < NL; i++) x[i] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), i));
+        lean_steps<CR, 0, true, true>(S.pre, K, x, S.acc, S.pend, rem - r * PER);
+      }
+    }
+    *(unsigned*)((char*)sv + S.voff) = S.acc << (C8P_SV_BLK - rem);
+  }
+}
+
 template <int CR> struct LeanRate { static constexpr int NLB = RateInfo<CR>::NL * (C8P_SV_BLK / RateInfo<CR>::PER); };
 
 // the whole forward pass of one packet whose LLRs are all there (k_viterbi_lean)

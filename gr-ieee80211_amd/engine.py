@@ -98,9 +98,9 @@ class DevArray:
 
 
 class Engine:
-    def __init__(self, device=0, profile=False, keep_bits=False, stream=None):
+    def __init__(self, device=0, profile=False, keep_bits=False, stream=None, keep_llr=False):
         self.L = load_library()
-        cfg = abi.Cfg(abi.ABI_VERSION, device, int(profile), int(keep_bits), stream)
+        cfg = abi.Cfg(abi.ABI_VERSION, device, int(profile), int(keep_bits), stream, int(keep_llr))
         self.ctx = self.L.c8p_create(C.byref(cfg))
         if not self.ctx:
             raise RuntimeError("c8p_create failed: no usable HIP device %d (there is no CPU fallback)" % device)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define C8P_ABI_VERSION 1
+#define C8P_ABI_VERSION 2
 
 /* return codes */
 #define C8P_OK          0
@@ -234,6 +234,9 @@ typedef struct c8p_cfg {
                                N > 1: only on every N-th submit (staggered per kernel) — sampling             */
   int32_t keep_bits;        /* 1: also store descrambled bits (v_unCodedBits) and v_scramBits          */
   void*   stream;           /* hipStream_t to launch on; NULL = engine-owned stream                    */
+  int32_t keep_llr;         /* c8p_rx only.  0: the LLR stream stays on chip (the wave that demodulates a packet decodes it out of
+                               LDS) and C8P_BUF_LLR is EMPTY after c8p_rx; 1: c8p_rx also leaves the LLR stream in C8P_BUF_LLR, as
+                               c8p_demod always does (costs 0.47 GB of HBM traffic per 4096 cfg-2 packets)                      */
 } c8p_cfg;
 
 typedef struct c8p_batch_in {

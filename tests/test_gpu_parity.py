@@ -19,9 +19,12 @@ pytestmark = pytest.mark.gpu
 LLR_TOL = 1e-5
 
 
-@pytest.fixture(scope="module")
-def eng():
-    e = engine.Engine(device=0, keep_bits=True, profile=True)
+# every test runs on both flavours of c8p_rx: the default (k_rx_1ss_lds: the LLR stream stays in LDS, C8P_BUF_LLR empty after c8p_rx)
+# and c8p_cfg.keep_llr (k_rx_1ss: LLRs through the arena, checked against the oracle's within LLR_TOL)
+@pytest.fixture(scope="module", params=[False, True], ids=["llr_on_chip", "llr_kept"])
+def eng(request):
+    e = engine.Engine(device=0, keep_bits=True, profile=True, keep_llr=request.param)
+    e.keep_llr = request.param
     yield e
     e.close()
 
@@ -210,7 +213,7 @@ def test_edge_cases(eng):
     for p, (g, o) in enumerate(zip(res, ref)):
         assert g["tags"]["status"] == o["tags"]["status"], p
         assert g["pdus"] == o["pdus"], p
-        if o["tags"]["status"] == abi.ST_OK and len(o["llr"]) and np.isfinite(o["llr"]).all():
+        if "llr" in g and o["tags"]["status"] == abi.ST_OK and len(o["llr"]) and np.isfinite(o["llr"]).all():
             assert np.max(np.abs(g["llr"] - o["llr"])) <= LLR_TOL
     assert sum(1 for o in ref if o["tags"]["status"] == abi.ST_REJ_SHORT) > 0
 
@@ -296,7 +299,7 @@ def test_device_resident_inputs_and_pipelined_submits(eng):
     for g, w in zip(got, want):
         assert g["pdus"] == w["pdus"]
         assert g["tags"]["status"] == w["tags"]["status"]
-        assert np.array_equal(g["llr"], w["llr"])
+        assert ("llr" in g) == eng.keep_llr and (not eng.keep_llr or np.array_equal(g["llr"], w["llr"]))
 
 
 def test_exact_kernel_agrees_with_lean_kernel(eng, monkeypatch):
@@ -565,10 +568,13 @@ def test_negative_part_bound_of_the_symbol_demodulator(eng):
     consecutive LLRs of the packet: k_demod_sym sums per OFDM symbol on the DPP path, the decoder takes 2 (3) times the largest symbol."""
     b, meta = sweep_batch(snr_db=20.0, seed=5)
     pk, iq, chan = b.arrays()
+    eng.demod(pk, iq, chan)                               # the LLR stream: from the split entry point (c8p_rx may keep it on chip)
+    eng.sync()
+    llr = eng.fetch(abi.BUF_LLR, np.float32)
     eng.rx(pk, iq, chan)
     eng.sync()
     tags = eng.tags()
-    llr = eng.fetch(abi.BUF_LLR, np.float32)
+    assert (len(eng.fetch(abi.BUF_LLR, np.float32)) > 0) == eng.keep_llr
     flags, nflt, bound = eng.decstat()
     checked = 0
     for p in range(len(pk)):
@@ -578,7 +584,15 @@ def test_negative_part_bound_of_the_symbol_demodulator(eng):
         l = llr[int(t["llr_off"]):int(t["llr_off"]) + int(t["total"])].astype(np.float64)
         neg = np.maximum(-l, 0.0)
         ncbps = int(t["ncbps"])
-        per_sym = neg[:int(t["nsym"]) * ncbps].reshape(-1, ncbps).sum(axis=1)
+        nsym = int(t["nsym"])
+        if not eng.keep_llr:      # the on-chip flavour does not demodulate symbols that only carry padding behind the last trellis step
+            T, cr = int(t["trellis"]), int(t["cr"])
+            q5, r5 = divmod(T, 5); q3, r3 = divmod(T, 3); q2, r2 = divmod(T, 2)
+            needed = {abi.CR_12: 2 * T, abi.CR_23: 3 * q2 + 2 * r2, abi.CR_34: 4 * q3 + (0, 2, 3)[r3],
+                      abi.CR_56: 6 * q5 + (0, 2, 3, 4, 5)[r5]}[cr]
+            nsym = min(nsym, -(-needed // ncbps))
+            neg = neg[:nsym * ncbps]
+        per_sym = neg[:nsym * ncbps].reshape(-1, ncbps).sum(axis=1)
         want = per_sym.max() * (2.0 if ncbps >= 60 else 3.0)
         assert abs(bound[p] - want) <= 1e-4 * max(want, 1.0), (p, bound[p], want)
         win = np.convolve(neg, np.ones(60), mode="valid").max() if len(neg) >= 60 else neg.sum()

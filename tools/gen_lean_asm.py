@@ -298,6 +298,258 @@ template <> __device__ __forceinline__ void %s<%d>(float& pre, unsigned& acc, co
 """ % (cr, n, G, n_valu, n_valu / 30.0, name, RATES[cr], extra, body, outs2, ", ".join(ins), ", ".join(clob)), n_valu
 
 
+# ---------------------------------------------------------------------------------------------- LDS-fed flavour (k_rx_1ss_lds)
+# lean_blocks_lds<CR>: the integer step above with the LLRs read from LDS instead of through the scalar cache.  The wave that
+# demodulated the symbols left them in its own LDS buffer (de-interleaved), so the LLR stream never reaches HBM.  An LLR is a
+# wave-uniform operand: every lane reads the same LDS address (a broadcast, no bank conflict) into a small rotating set of VGPRs,
+# GS LLRs per read (`ds_read_b64`; rate 2/3, whose 45 LLRs per block are not a multiple of 8 bytes: `ds_read2_b32` + `ds_read_b32`,
+# three LLRs = one puncturing period).  NSETS register sets; the read of group g + NSETS is issued right after the last instruction
+# that reads group g (same registers), LDS returns in order, so the wait before the first use of group g is an exact
+# `lgkmcnt(reads issued since)` and never drains the prefetches.  G % NSETS == 0, otherwise the next block's first groups would
+# land in registers the end of this block still reads.  The sets are small on purpose: every register the statement clobbers is
+# one the fused kernel cannot keep a long-lived value in (12-register sets made it spill five values per OFDM symbol to scratch).
+# pre / acc / voff are bound to v62 / v63 / v50 ("{v62}" constraints): no copies in or out.
+LDS_GS = {"12": 2, "23": 3, "34": 2, "56": 2}
+LDS_NSETS = {"12": 3, "23": 3, "34": 4, "56": 3}
+
+
+def gen_rate_lds(cr, integer=True):
+    """integer: the block loop (lean_blocks_lds); not integer: ONE block with the float step (lean_block_flt_lds), for the blocks
+    whose metrics are not provably positive — as asm so that its register use is as fixed as the loop's (the compiler's version of
+    the 30 unrolled float steps wanted 10 more VGPRs than the rest of k_rx_1ss_lds)"""
+    n = NLB[cr]
+    GS, NS = LDS_GS[cr], LDS_NSETS[cr]
+    SW = 2 if GS == 2 else 4      # registers per set (even, so that every LLR sits in an even-aligned pair)
+    assert n % GS == 0
+    G = n // GS
+    assert G % NS == 0
+    VB = 50 - SW * NS             # first register of the LLR sets (even)
+    VA = VB - 1                   # LDS byte address of the current block's LLRs
+    steps = [idx(cr, j) for j in range(BLK)]
+
+    def grp(i):
+        return i // GS
+
+    def vreg(i):
+        return VB + SW * (grp(i) % NS) + (i % GS)
+
+    def vpair(i):
+        r = vreg(i)
+        return "v[%d:%d]" % (r & ~1, (r & ~1) + 1), r & 1
+
+    def load_group(g, wrapped):
+        """ds reads of group g of this block (wrapped: of the next block, whose LLRs follow at + 4 n bytes)"""
+        off = 4 * GS * g + (4 * n if wrapped else 0)
+        r = VB + SW * (g % NS)
+        if GS == 2:
+            assert (4 * n) % 8 == 0
+            return ["ds_read_b64 v[%d:%d], v%d offset:%d" % (r, r + 1, VA, off)]
+        o0 = off // 4
+        assert o0 + 1 < 256
+        return ["ds_read2_b32 v[%d:%d], v%d offset0:%d offset1:%d" % (r, r + 1, VA, o0, o0 + 1),
+                "ds_read_b32 v%d, v%d offset:%d" % (r + 2, VA, off + 8)]
+
+    body = []                     # (text, groups read)
+
+    def emit(x, reads=()):
+        body.append((x, tuple(reads)))
+    cnt, chk = "s%d" % (PTR + 4), "s[%d:%d]" % (PTR + 6, PTR + 7)
+    two = [j for j in range(BLK) if steps[j][0] is not None and steps[j][1] is not None]
+    tabreg = {j: (54 if k % 2 == 0 else 60) for k, j in enumerate(two)}
+
+    def emit_tab(j):
+        q, (i0, i1), t = j % 6, steps[j], tabreg[j]
+        p0, s0 = vpair(i0)
+        p1, s1 = vpair(i1)
+        emit("v_pk_mul_f32 v[%d:%d], %%[kb%d], %s op_sel:[0,%d] op_sel_hi:[1,%d]" % (t, t + 1, q, p1, s1, s1), [grp(i1)])
+        emit("v_pk_fma_f32 v[%d:%d], %%[ka%d], %s, v[%d:%d] op_sel:[0,%d,0] op_sel_hi:[1,%d,1]" % (t, t + 1, q, p0, t, t + 1, s0, s0), [grp(i0)])
+
+    def emit_pend(p):
+        if p is None:
+            emit("s_nop 1")
+        elif p[0] == "subb":
+            emit("v_subb_co_u32_dpp v52, vcc, v%d, v%d, vcc %s%s" % (p[1], p[2], p[3], RM))
+            emit(ADDC)
+        elif p[0] == "sub":
+            emit("v_sub_co_u32_e32 v52, vcc, v%d, v%d" % (p[1], p[2]))
+            emit(ADDC)
+        elif p[0] == "cls":
+            emit("v_cmp_class_f32_e32 vcc, v%d, %%[cls%d]" % (p[1], p[2]))
+            emit(ADDC)
+        else:
+            emit("v_cmp_gt_f32_e32 vcc, v%d, v%d" % (p[1], p[2]))
+            emit(ADDC)
+    pend = None
+    hoisted = set()
+    vmax = "v_max_u32" if integer else "v_max_f32"
+    for j in range(BLK):
+        q = j % 6
+        i0, i1 = steps[j]
+        c = 56 if j % 2 == 0 else 58
+        d = 52 if j % 2 == 0 else 53
+        if i0 is not None and i1 is not None:
+            if j not in hoisted:
+                emit_tab(j)
+            t = tabreg[j]
+            emit("v_pk_add_f32 v[%d:%d], v[62:63], v[%d:%d] op_sel:[0,0] op_sel_hi:[0,1]" % (c, c + 1, t, t + 1))
+            # the next two-LLR step's pair ahead of time (off the pre -> pre chain), if its LLRs are at most one group further on
+            nx = [k for k in two if k > j]
+            if nx and grp(steps[nx[0]][1]) <= grp(i1) + 1:
+                emit_tab(nx[0])
+                hoisted.add(nx[0])
+        elif i0 is not None:
+            p0, s0 = vpair(i0)
+            emit("v_pk_fma_f32 v[%d:%d], %%[ka%d], %s, v[62:63] op_sel:[0,%d,0] op_sel_hi:[1,%d,0]" % (c, c + 1, q, p0, s0, s0), [grp(i0)])
+        else:
+            p1, s1 = vpair(i1)
+            emit("v_pk_fma_f32 v[%d:%d], %%[kb%d], %s, v[62:63] op_sel:[0,%d,0] op_sel_hi:[1,%d,0]" % (c, c + 1, q, p1, s1, s1), [grp(i1)])
+        emit_pend(pend)
+        if q in DPP:
+            if not integer:
+                emit("v_sub_f32_dpp v%d, v%d, v%d %s%s" % (d, c + 1, c, DPP[q], RM))
+            emit("%s_dpp v62, v%d, v%d %s%s" % (vmax, c + 1, c, DPP[q], RM))
+            pend = ("subb", c + 1, c, DPP[q]) if integer else ("cls", d, q)
+        elif q == 2:
+            emit("v_mov_b32_dpp v51, v%d quad_perm:[3,2,1,0]%s" % (c + 1, RM))
+            emit("s_nop 1")
+            if not integer:
+                emit("v_sub_f32_dpp v%d, v51, v%d row_half_mirror%s" % (d, c, RM))
+            emit("%s_dpp v62, v51, v%d row_half_mirror%s" % (vmax, c, RM))
+            pend = ("subb", 51, c, "row_half_mirror") if integer else ("cls", d, q)
+        else:
+            emit("v_permlane%d_swap_b32 v%d, v%d" % (16 if q == 4 else 32, c, c + 1))
+            emit("%s v62, v%d, v%d" % (vmax, c, c + 1))
+            pend = ("sub", c, c + 1) if integer else ("gt", c + 1, c)
+    emit_pend(pend)
+    # ---- loads after the last reader of a group, exact waits before the first reader
+    first, last = {}, {}
+    for k, (x, rd) in enumerate(body):
+        for g in rd:
+            first.setdefault(g, k)
+            last[g] = k
+    assert sorted(first) == list(range(G)) and all(last[g] <= last[g + 1] and first[g] <= first[g + 1] for g in range(G - 1))
+    assert all(last[g] < first[g + NS] for g in range(G - NS))      # a set is free before its next group is needed
+    after = {}
+    for g in range(G):
+        after.setdefault(last[g], []).append(g)
+    stream = []                   # one block: ("ds", text, group: g or G + g' of the next block) / ("wait", group) / ("x", text)
+    for k, (x, rd) in enumerate(body):
+        for g in sorted(set(rd)):
+            if first[g] == k:
+                stream.append(("wait", g))
+        stream.append(("x", x))
+        for g in sorted(after.get(k, [])):
+            tgt = g + NS
+            if tgt >= G and not integer:
+                continue                                     # one block only: nothing to prefetch for the next
+            for ins in load_group(tgt % G, tgt >= G):
+                stream.append(("ds", ins, tgt))
+    # simulate the prologue and two blocks: reads in flight at every wait (LDS returns in order)
+    issued = []
+    for g in range(NS):
+        issued += [g] * len(load_group(g, False))
+    waits = []
+    for blk in range(2 if integer else 1):
+        w = []
+        for it in stream:
+            if it[0] == "ds":
+                issued.append(blk * G + it[2])
+            elif it[0] == "wait":
+                gid = blk * G + it[1]
+                pos = max(k for k, v in enumerate(issued) if v == gid)
+                w.append(len(issued) - 1 - pos)
+        waits.append(w)
+    assert (not integer or waits[0] == waits[1]) and max(waits[0]) <= 15, waits
+    if not integer:
+        L = ["s_waitcnt lgkmcnt(0)", "v_mov_b32 v%d, %%[llr]" % VA]
+        for g in range(NS):
+            L.extend(load_group(g, False))
+        wi = iter(waits[0])
+        for it in stream:
+            L.append("s_waitcnt lgkmcnt(%d)" % next(wi) if it[0] == "wait" else it[1])
+        text = "\n".join('      "%s\\n\\t"' % x for x in L)
+        clob = ['"vcc"', '"memory"'] + ['"v%d"' % r for r in range(VA, 62) if r != 50]
+        ins = ['[ka%d] "v"(K[%d].a)' % (q, q) for q in range(6)] + ['[kb%d] "v"(K[%d].b)' % (q, q) for q in range(6)]
+        ins += ['[cls%d] "v"(K[%d].cls)' % (q, q) for q in range(4)] + ['[llr] "s"(llr)']
+        n_valu = sum(1 for (x, rd) in body if x.startswith("v_"))
+        return """
+// code rate %s, ONE block with the float step, LLRs from LDS (%d VALU instructions); acc: the 30 decisions in bits 29..0, older bits above
+template <> __device__ __forceinline__ void lean_block_flt_lds<%d>(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned llr)
+{
+  asm volatile(
+%s
+      : "+{v62}"(pre), "+{v63}"(acc)
+      : %s
+      : %s);
+}
+""" % (cr, n_valu, RATES[cr], text, ", ".join(ins), ", ".join(clob)), n_valu
+    L = []
+    add = L.append
+    add("s_waitcnt lgkmcnt(0)")                              # nothing of the caller's in flight: the counts below are exact
+    add("v_mov_b32 v63, %[init]")
+    add("v_mov_b32 v%d, %%[llr]" % VA)
+    add("s_mov_b32 %s, %%[nblk]" % cnt)
+    add("s_mov_b32 vcc_lo, 0x55555555")
+    add("s_mov_b32 vcc_hi, 0x55555555")
+    for g in range(NS):
+        L.extend(load_group(g, False))
+    add("1:")
+    wi = iter(waits[0])
+    for it in stream:
+        if it[0] == "wait":
+            add("s_waitcnt lgkmcnt(%d)" % next(wi))
+        else:
+            add(it[1])
+    add("s_sub_u32 %s, %s, 1" % (cnt, cnt))
+    add("v_add_u32 v%d, %d, v%d" % (VA, 4 * n, VA))
+    add("v_xor_b32 v63, %[flip], v63")
+    add("s_add_u32 %[segc], %[segc], 1")
+    add("s_cmp_lt_u32 %[segc], %[segn]")
+    add("s_cbranch_scc1 5f")
+    add("s_mov_b64 s[%d:%d], vcc" % (PTR + 8, PTR + 9))
+    add("v_mov_b32 v52, v62")
+    for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15 row_mask:0xa", "row_bcast:31 row_mask:0xc"):
+        add("s_nop 1")
+        add("v_max_u32_dpp v52, v52, v52 %s%s" % (ctrl, "" if "row_mask" in ctrl else " row_mask:0xf") + " bank_mask:0xf")
+    add("v_mov_b32 v53, 0x40000000")
+    add("v_readlane_b32 s%d, v52, 63" % (PTR + 10))
+    add("s_mov_b32 %[segc], 0")
+    add("v_cmp_eq_u32_e32 vcc, s%d, v62" % (PTR + 10))
+    add("v_cndmask_b32_e32 v52, 0, v53, vcc")
+    add("s_mov_b64 vcc, s[%d:%d]" % (PTR + 8, PTR + 9))
+    add("v_or_b32 v63, v52, v63")
+    add("5:")
+    add("global_store_dword v50, v63, %[sv]")
+    add("v_add_u32 v50, 0x100, v50")
+    add("v_mov_b32 v63, %[init]")
+    add("v_cmp_gt_f32_e64 %s, %%[bound], v62" % chk)
+    add("s_cmp_eq_u32 %s, 0" % cnt)
+    add("s_cbranch_scc1 2f")
+    add("s_cmp_eq_u64 %s, 0" % chk)
+    add("s_cbranch_scc1 1b")
+    add("2:")
+    add("s_waitcnt lgkmcnt(0)")
+    add("s_mov_b32 %%[nblk], %s" % cnt)
+    n_valu = sum(1 for (x, rd) in body if x.startswith("v_"))
+    text = "\n".join('      "%s\\n\\t"' % x for x in L)
+    fixed = (50, 62, 63)
+    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(4, 11)] + ['"v%d"' % r for r in range(VA, 64) if r not in fixed]
+    ins = ['[ka%d] "v"(K[%d].a)' % (q, q) for q in range(6)] + ['[kb%d] "v"(K[%d].b)' % (q, q) for q in range(6)]
+    ins += ['[init] "v"(init)', '[flip] "v"(flip)', '[bound] "s"(bound)', '[segn] "s"(segn)', '[llr] "s"(llr)', '[sv] "s"(sv)']
+    return """
+// code rate %s, LLRs from LDS: %d per block in %d groups of %d, %d register sets (v%d..v49), address in v%d; %d VALU instructions per 30 steps
+template <> __device__ __forceinline__ void lean_blocks_lds<%d>(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned init, unsigned flip, float bound,
+                                                                 int& segc, int segn, unsigned& voff, unsigned llr, unsigned* sv, int& nblk)
+{
+  asm volatile(
+%s
+      : "+{v62}"(pre), "={v63}"(acc), "+{v50}"(voff), [nblk] "+s"(nblk), [segc] "+s"(segc)
+      : %s
+      : %s);
+}
+""" % (cr, n, G, GS, NS, VB, VA, n_valu, RATES[cr], text, ", ".join(ins), ", ".join(clob)), n_valu
+
+
 def main():
     parts, counts = [], {}
     for integer in (True, False):
@@ -309,6 +561,14 @@ def main():
             counts[(cr, integer)] = nv
         if not integer:
             parts.append("#endif\n")
+    for cr in ("12", "23", "34", "56"):
+        txt, nv = gen_rate_lds(cr)
+        parts.append(txt)
+        counts[(cr, "lds")] = nv
+    for cr in ("12", "23", "34", "56"):
+        txt, nv = gen_rate_lds(cr, False)
+        parts.append(txt)
+        counts[(cr, "ldsf")] = nv
     hdr = """// c8p_lean_asm.h — GENERATED by tools/gen_lean_asm.py (do not edit; edit the generator, which documents the step).
 //
 // The full-block loop of the lean Viterbi forward pass as one inline-asm statement per code rate.
@@ -324,9 +584,15 @@ template <int CR> __device__ __forceinline__ void lean_blocks_int(float& pre, un
                                                                    float bound, int& segc, int segn, unsigned& voff, const float* llr, unsigned* sv, int& nblk);
 template <int CR> __device__ __forceinline__ void lean_blocks_asm(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned& voff,
                                                                    const float* llr, unsigned* sv, int& nblk);
+// lean_blocks_lds<CR>: lean_blocks_int with the LLRs read from LDS (`llr` = LDS byte address of the first block's LLRs, 16-byte aligned
+//                      except at rate 2/3) into a rotating set of VGPRs; the same instruction counts
+template <int CR> __device__ __forceinline__ void lean_blocks_lds(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned init, unsigned flip,
+                                                                   float bound, int& segc, int segn, unsigned& voff, unsigned llr, unsigned* sv, int& nblk);
+// lean_block_flt_lds<CR>: one block with the float step, LLRs from LDS (the blocks lean_blocks_lds will not take)
+template <int CR> __device__ __forceinline__ void lean_block_flt_lds(float& pre, unsigned& acc, const LeanK (&K)[6], unsigned llr);
 """ % tuple(counts[(cr, i)] for i in (True, False) for cr in ("12", "23", "34", "56"))
     open(OUT, "w").write(hdr + "".join(parts))
-    print("wrote", OUT, {("%s%s" % (k[0], "i" if k[1] else "f")): v for k, v in counts.items()})
+    print("wrote", OUT, {("%s%s" % (k[0], {"lds": "l", "ldsf": "lf", True: "i", False: "f"}[k[1]])): v for k, v in counts.items()})
 
 
 if __name__ == "__main__":
