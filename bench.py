@@ -435,8 +435,8 @@ def lean_step_mix(T, float_frac=0.0, cr_num=5):
 
 
 def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
-    """The resource that binds the dominant kernel: VALU issue.  The kernel is k_rx_1ss = symbol demodulation + the lean forward
-    pass.  ceiling = [sum over the forward pass's opcodes of (count x measured issue cost, profiles/*/opcode_costs.json from
+    """The resource that binds the dominant kernel: VALU issue.  The kernel is k_rx_1ss_lds = symbol demodulation + the lean forward
+    pass (LLRs through LDS).  ceiling = [sum over the forward pass's opcodes of (count x measured issue cost, profiles/*/opcode_costs.json from
     tools/probe_issue.hip) + the kernel's other VALU instructions (SQ_INSTS_VALU of the newest committed PMC pass minus the forward
     pass's count) at the 4.15-cycle slot every non-trivial opcode costs] / (1024 SIMDs x 2.4 GHz); frac = ceiling / exclusive
     launch duration of this run.  Pricing at the nominal 2.4 GHz makes the fraction a lower bound (the shader clock under this
@@ -454,14 +454,15 @@ def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
     cycles = sum(mix[k] * cost[k] for k in mix) * n_pkt            # SIMD-cycles summed over the chip
     other, other_src = 0.0, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm.json"))):
-        k = json.load(open(f))["kernels"].get("k_rx_1ss")
+        ks = json.load(open(f))["kernels"]
+        k = ks.get("k_rx_1ss_lds") or ks.get("k_rx_1ss")
         if k and k.get("sq_insts_valu"):
             other, other_src = max(0.0, k["sq_insts_valu"] * n_pkt / 4096.0 - dec_instr), os.path.relpath(f, ROOT)
     cycles += other * 4.15
     n_simd, clk = 256 * 4, 2.4e9
     ceiling_ms = cycles / n_simd / clk * 1e3
     dur_ms = kern_x["viterbi_fwd"]
-    return {"bound": "valu issue", "kernel": "viterbi_fwd (k_rx_1ss: symbol demodulation + lean forward pass)", "unit": "ms per launch",
+    return {"bound": "valu issue", "kernel": "viterbi_fwd (k_rx_1ss_lds: symbol demodulation + lean forward pass, LLRs through LDS)", "unit": "ms per launch",
             "ceiling_ms": ceiling_ms, "achieved_ms": dur_ms, "frac": ceiling_ms / dur_ms,
             "forward_pass_instr_per_launch": dec_instr, "forward_pass_instr_per_step": sum(mix.values()) / T,
             "forward_pass_issue_cycles_per_step": sum(mix[k] * cost[k] for k in mix) / T, "float_step_block_fraction": float_frac,
@@ -473,10 +474,11 @@ def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
 def pmc_traffic(dom):
     """HBM bytes per launch of the dominant kernel, and of the three RX kernels of a c8p_rx step together, from the newest committed
     rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/*/pmc_hbm.json).  FETCH_SIZE is doubled
-    per MI355X_MICROARCH.md for kernels that read with 16-byte vector loads; the scalar-cache reads of the forward pass are 64-byte
-    requests and counted in full, so k_rx_1ss = FETCH_SIZE as reported + half of the sample bytes it reads with vector loads;
-    see DESIGN.md §7."""
-    names = {"viterbi_fwd": "k_rx_1ss", "finish": "k_finish", "classify": "k_classify"}
+    per MI355X_MICROARCH.md (gfx950 tallies a 128-byte request as 64 bytes; every kernel here reads with wide vector loads).
+    Profiles from before the LLR stream moved into LDS hold k_rx_1ss instead of k_rx_1ss_lds: its scalar-cache reads of the LLRs were
+    64-byte requests and counted in full, so that kernel = FETCH_SIZE as reported + half of the sample bytes.  The whole step also
+    counts the second, nearly empty launch of k_rx_1ss (only_flagged) and k_viterbi_fwd.  See DESIGN.md §7."""
+    names = {"viterbi_fwd": "k_rx_1ss_lds", "finish": "k_finish", "classify": "k_classify"}
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -487,18 +489,24 @@ def pmc_traffic(dom):
         return None, None, None
     j = json.load(open(best))
 
+    old_profile = "k_rx_1ss_lds" not in j["kernels"]
+    if old_profile:
+        names["viterbi_fwd"] = "k_rx_1ss"
+
     def hbm(name):
         k = j["kernels"].get(name)
         if not k:
             return None
         if "hbm_bytes" in k:
             return k["hbm_bytes"]
-        if name == "k_rx_1ss":     # scalar-cache reads (64-byte requests, counted in full) + the samples, read with vector loads
-            return (k["fetch_size_kb_raw"] + k["write_size_kb"]) * 1024.0 + 0.5 * 4096 * (8 * 4400 + 512)     # (tallied at half)
+        if name == "k_rx_1ss" and old_profile:     # scalar-cache LLR reads (counted in full) + the samples (tallied at half)
+            return (k["fetch_size_kb_raw"] + k["write_size_kb"]) * 1024.0 + 0.5 * 4096 * (8 * 4400 + 512)
         return (k["fetch_size_kb_raw"] * 2.0 + k["write_size_kb"]) * 1024.0
 
     per = {n: hbm(n) for n in names.values()}
     whole = sum(v for v in per.values() if v) if all(per.values()) else None
+    if whole is not None and not old_profile:
+        whole += sum(hbm(n) or 0.0 for n in ("k_rx_1ss", "k_viterbi_fwd"))
     return per[names[dom]], os.path.relpath(best, ROOT), whole
 
 

@@ -7,7 +7,8 @@
  *   c8p_demod()   replaces  demod_impl::general_work   lib/demod_impl.cc:59-342
  *                 and       demod2_impl::general_work  lib/demod2_impl.cc:58-349
  *   c8p_decode()  replaces  decode_impl::general_work  lib/decode_impl.cc:60-162
- *   c8p_rx()      = c8p_demod() + c8p_decode() with the LLR stream kept in HBM
+ *   c8p_rx()      = c8p_demod() + c8p_decode() in one call; the LLR stream between them stays on chip (LDS) unless
+ *                   c8p_cfg.keep_llr asks for it in C8P_BUF_LLR
  *   c8p_signal()  replaces  signal_impl::general_work  lib/signal_impl.cc:62-206   (the producer of the boundary;
  *                 and       signal2_impl::general_work lib/signal2_impl.cc          SURVEY.md §8f-1, optional)
  *
@@ -301,7 +302,7 @@ typedef struct c8p_decode_in {
 
 /* result arenas (device memory, engine-owned) */
 #define C8P_BUF_TAGS   0    /* c8p_pkt_tags[n_pkt]                    */
-#define C8P_BUF_LLR    1    /* float, per packet at tags[p].llr_off   */
+#define C8P_BUF_LLR    1    /* float, per packet at tags[p].llr_off (c8p_demod; c8p_rx only with keep_llr) */
 #define C8P_BUF_OUT    2    /* c8p_pkt_out[n_pkt]                     */
 #define C8P_BUF_PDU    3    /* bytes, per packet at out[p].pdu_off    */
 #define C8P_BUF_BITS   4    /* bytes (keep_bits), descrambled bits    */
@@ -349,7 +350,7 @@ const char* c8p_last_error(const c8p_ctx* ctx);
  * them (stream / event synchronisation) before the call. */
 int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCHAN              */
 int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
-int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything; LLRs never leave HBM */
+int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything but C8P_BUF_LLR (empty unless c8p_cfg.keep_llr) */
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
 int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
 int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */

@@ -601,6 +601,31 @@ def test_negative_part_bound_of_the_symbol_demodulator(eng):
     assert checked > 20
 
 
+def test_rx_hands_out_of_range_packets_to_the_exact_decoder(eng):
+    """c8p_rx on packets whose LLRs leave the lean decoder's range (> 2^20: the legacy channel estimate scaled by 1e-7, so the
+    equalised symbols and the LLRs of every legacy packet are 1e7 times too large — the decisions are the same).  The fused kernel
+    flags them (C8P_BUF_DECSTAT), the on-chip flavour demodulates them once more into the LLR arena (k_rx_1ss, only_flagged), and
+    k_viterbi_fwd decodes them: PDUs, failure counts and bits as the oracle's; the other packets of the batch are not affected."""
+    b, meta = sweep_batch(snr_db=30.0, seed=31)
+    pk, iq, chan = b.arrays()
+    chan = (chan * np.float32(1e-7)).astype(np.complex64)
+    eng.rx(pk, iq, chan)
+    res = eng.results(want_bits=True)
+    flags, _, _ = eng.decstat()
+    ref = oracle_rx(pk, iq, chan)
+    n_flagged = n_pdu = 0
+    for p, (g, o) in enumerate(zip(res, ref)):
+        assert g["tags"]["status"] == o["tags"]["status"], p
+        assert g["pdus"] == o["pdus"] and g["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], p
+        if flags[p]:
+            n_flagged += 1
+            assert o["tags"]["format"] == abi.F_L and np.max(np.abs(o["llr"])) > 2.0 ** 20, p
+            n_pdu += len(o["pdus"])
+            if len(o["pdus"]):
+                assert np.array_equal(g["bits"], o["bits"]) and np.array_equal(g["sbits"], o["sbits"]), p
+    assert n_flagged >= 6 and n_pdu >= 4, (n_flagged, n_pdu)
+
+
 def test_four_packets_per_wave_decoder(eng, monkeypatch):
     """c8p_decode sends quads of consecutive packets with the same code rate and trellis length through k_viterbi_lean4 (16 lanes x 4
     registers per packet: tools/gen_lean4_asm.py).  Streams with ties and positive drift (integer loop), a quad that starts with large

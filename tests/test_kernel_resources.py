@@ -47,6 +47,16 @@ def test_fused_rx_kernel_keeps_six_waves_per_simd(usage):
     assert rx["ScratchSize"] <= 96, rx                     # loop-invariant values around the loop, nothing inside the rate-5/6 path
 
 
+def test_on_chip_llr_kernel_has_no_scratch_at_six_waves(usage):
+    """k_rx_1ss_lds (c8p_rx's default: LLRs from the demodulator to the decoder through LDS): 80 VGPRs = 6 waves per SIMD with NOTHING
+    spilled — a dword spilled around the decoder is 64 x 4 bytes per OFDM symbol and packet of scratch traffic, as much as the LLR
+    stream this kernel keeps out of HBM — and an LDS footprint that lets six workgroups share a CU (160 KB)"""
+    rx = usage["k_rx_1ss_lds"]
+    assert rx["VGPRs"] <= 80 and rx["AGPRs"] == 0 and rx["Occupancy"] >= 6, rx
+    assert rx["ScratchSize"] == 0 and rx["VGPRs Spill"] == 0 and rx["SGPRs Spill"] == 0, rx
+    assert rx["LDS Size"] <= 20 * 1024, rx
+
+
 def test_side_kernels_stay_inside_their_budgets(usage):
     assert usage["k_classify"]["VGPRs"] <= 72, usage["k_classify"]
     assert usage["k_finish"]["LDS Size"] <= 24 * 1024 and usage["k_finish"]["ScratchSize"] == 0, usage["k_finish"]
