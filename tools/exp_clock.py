@@ -9,7 +9,7 @@ from c8p_cases import cfg2_workload_on_device
 from gr_ieee80211_amd import engine
 dev = torch.device("cuda", 0)
 pk, iq_dev, chan_dev, expected, _keep = cfg2_workload_on_device(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 30.0, 0, torch, dev, 0)
-eng = engine.Engine(device=0, profile=1)
+eng = engine.Engine(device=0, profile=1, keep_llr=True)     # the C8P_EXP_CLOCK instrumentation sits in k_rx_1ss (the arena path)
 for i in range(30):
     eng.rx(pk, iq_dev, chan_dev); eng.sync()
 eng.profile_reset()
