@@ -1069,10 +1069,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // survivor block that is complete with the LLRs as VGPR operands (lean_blocks_lds: broadcast ds_read_b128 into a rotating set of 12
 // registers that only exist inside the block loop) and moves the < 60 left-over LLRs to the front.  Neither the 235 MB of LLR
 // stores nor their read-back (an EA read even when it hits L2, tools/probe_l2rw.hip) exist any more: 1.58 -> 1.1 GB per
-// 4096-packet step.  Buffer: 59 left over + 416 of a 256-QAM symbol = 475 floats.  A packet with an LLR outside the integer
+// 4096-packet step.  Buffer (C8P_LBUF floats): 59 left over + two 64-QAM symbols (one 256-QAM symbol = 416 LLRs).  A packet with an LLR outside the integer
 // loop's range is rare: the wave flags it and stops, a second launch of k_rx_1ss (only_flagged) demodulates the flagged packets
 // into the LLR arena and k_viterbi_fwd decodes them.  Symbols that only carry padding behind the last trellis step are not demodulated at all.
-#define C8P_LBUF 480
+#define C8P_LBUF 688
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
@@ -1115,41 +1115,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   // ceil(65536 / nlb): (have * inv) >> 16 == have / nlb for have < 1499 (C8P_LBUF = 480).  Constants on purpose: a division is done by
   // the VALU, and a wave-uniform value that comes out of the VALU drags every counter it touches into (spilled) VGPRs
   const unsigned nlb_inv = t.cr == C8P_CR_12 ? 1093u : t.cr == C8P_CR_23 ? 1457u : t.cr == C8P_CR_34 ? 1639u : 1821u;
-  const int need_tail = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn) - nfull * nlb);       // LLRs the partial last block consumes (< nlb)
   const float wfac = __uint_as_float(t.ncbps >= C8P_NEGB_WINDOW ? 0x40000000u : 0x40400000u);   // 2 or 3 (selected as bits: stays in an SGPR)
   float negb = 0.0f;
   int have = 0;                                    // LLRs in the buffer: lb[0] = first LLR of block S.done
   cf xin = x1[lane];
   float* const lb = lbuf[wv];
-  bool more = true;                                // false: the remaining symbols only carry padding behind the last trellis step
-  for (int s = 0; s < t.nsym && more; s++) {
+  // Rounds: as many symbols as the buffer has room for are demodulated back to back (two at 64-QAM, one at 256-QAM, up to 12 at
+  // BPSK), then their blocks run.  What a change of phase costs — parking, the constant unpack, the block loop's prologue — is paid
+  // per round, not per symbol.
+  const int needed = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn));   // LLRs the trellis consumes; symbols behind them are padding
+  int s = 0;
+  while (s < t.nsym && s * t.ncbps < needed) {
     // Nothing that depends on the lane lives across a phase: the lane index is taken afresh (opaque) in each, the decoder's state
-    // (metric, survivor offset, packed constants, the two integer-loop constants) waits in LDS while the symbol is demodulated, and
+    // (metric, survivor offset) waits in LDS while the symbols are demodulated, its lane constants were written there once, and
     // the next symbol's sample waits there while the blocks run.  acc / pend are dead between blocks.
-    const int lane_s = lane_fresh();
-    park[wv][lane_s] = make_uint2(__float_as_uint(S.pre), S.voff);
-    asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.voff));
-    const cf xnext = x1[(uint32_t)((s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp + lane_s)];
-    cf Hs = parkH[wv][lane_s];
-    asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
-    const cf f1 = wave_fft64(xin, T, lane_s);
-    float neg = 0.0f;
-    const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg);
-    have += t.ncbps;
-    xin = xnext;
+    {
+      const int lane_p = lane_fresh();
+      park[wv][lane_p] = make_uint2(__float_as_uint(S.pre), S.voff);
+      asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.voff));
+    }
+#pragma unroll 1
+    do {
+      const int lane_s = lane_fresh();
+      const cf xnext = x1[(uint32_t)((s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp + lane_s)];
+      cf Hs = parkH[wv][lane_s];
+      asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
+      const cf f1 = wave_fft64(xin, T, lane_s);
+      float neg = 0.0f;
+      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg);
+      have += t.ncbps;
+      xin = xnext;
+      s++;
+      if (__ballot(bad)) {                         // the exact decoder takes this packet; it wants the LLRs in memory:
+        if (lane_s == 0) flags[p] = 1u;            // k_rx_1ss (only_flagged) demodulates it once more, into the LLR arena
+        return;
+      }
+      neg = wave_sum_lane63(neg);
+      negb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(
+          fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac))));
+    } while (s < t.nsym && s * t.ncbps < needed && have + t.ncbps <= C8P_LBUF);
     const int lane_d = lane_fresh();               // (again: the decoder's per-lane addresses and the pieces of the constant unpack must
-                                                   // not be hoisted out of the symbol loop either)
+                                                   // not be hoisted out of the loop either)
     {
       const uint2 a = park[wv][lane_d];
       S.pre = __uint_as_float(a.x); S.voff = a.y;
     }
-    if (__ballot(bad)) {                           // the exact decoder takes this packet; it wants the LLRs in memory:
-      if (lane_d == 0) flags[p] = 1u;              // k_rx_1ss (only_flagged) demodulates it once more, into the LLR arena
-      return;
-    }
-    neg = wave_sum_lane63(neg);
-    negb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(
-        fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac))));
     const int done = S.done;
     int nb = (int)(((unsigned)have * nlb_inv) >> 16);   // have / nlb: complete blocks in the buffer
     if (nb > nfull - done) nb = nfull - done;
@@ -1178,7 +1188,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       }
       xin = parkX[wv][lane_fresh()];
     }
-    more = !(S.done == nfull && have >= need_tail);              // the remaining symbols only carry padding
   }
   const int lane_t = lane_fresh();
   if (lane_t == 0) { flags[n + p] = (uint32_t)S.nflt; flags[2 * n + p] = __float_as_uint(negb); }   // C8P_BUF_DECSTAT
