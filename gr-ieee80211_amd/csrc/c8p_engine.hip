@@ -437,7 +437,11 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
                            (uint32_t*)c->s->d_flags.p, (uint8_t*)c->s->d_done4.p, n);
         d_done4 = (const uint8_t*)c->s->d_done4.p;
       }
-      if (!rx || rx->any_2ant)
+      const char* el = getenv("C8P_DECODE_LDS");     // tests: c8p_decode through the LDS-fed block loop of k_rx_1ss_lds
+      if (!rx && el && atoi(el) != 0)
+        hipLaunchKernelGGL(k_viterbi_lean_lds, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+                           (uint32_t*)c->s->d_flags.p, n);
+      else if (!rx || rx->any_2ant)
         hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                            (uint32_t*)c->s->d_flags.p, rx ? (const float*)c->s->d_negsym.p : nullptr, rx ? rx->d_pk : nullptr, d_done4, n);
     }

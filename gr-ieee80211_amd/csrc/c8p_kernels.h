@@ -1201,6 +1201,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   }
 }
 
+// c8p_decode through the LDS-fed block loop (C8P_DECODE_LDS=1; tests): the caller's LLRs are copied into the wave's LDS buffer in
+// rounds, as k_rx_1ss_lds's demodulator would have left them, and decoded by the same lean_blocks_l / lean_tail_l.  This is how the
+// decode-entry parity tests (tie-only streams, trellis-length sweeps, bursts that leave the integer loop) reach the LDS flavours
+// of all four code rates; nothing else uses it.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_viterbi_lean_lds(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                      const float* __restrict__ llr, ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+{
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (p >= n) return;
+  if (flags[p] != 0) return;
+  const c8p_pkt_tags t = tags[p];
+  if (!decodable(t)) return;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ __attribute__((aligned(16))) float lbuf[4][C8P_LBUF];
+  float* const lb = lbuf[wv];
+  const int lane = lane_id();
+  const float negb = __uint_as_float(flags[2 * n + p]);          // k_llr_check's bound
+  const float bound = lean_bound(negb);
+  const float* L = llr + t.llr_off;
+  unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
+  const int Tn = t.trellis, nfull = Tn / C8P_SV_BLK, segn = c8p_seg_blocks(Tn);
+  const int nlb = t.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                  t.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
+  const unsigned nlb_inv = t.cr == C8P_CR_12 ? 1093u : t.cr == C8P_CR_23 ? 1457u : t.cr == C8P_CR_34 ? 1639u : 1821u;
+  const int needed = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn));
+  LeanK K[6];
+  lean_k_consts(lane, K);
+  unsigned init, flip;
+  lean_int_consts(lane, init, flip);
+  LeanState S;
+  lean_init(S, lane);
+  int have = 0, got = 0;                           // LLRs in the buffer / copied so far
+  while (got < needed) {
+    int take = C8P_LBUF - have;                    // a round: as much as fits (the left-over differs from round to round)
+    if (take > needed - got) take = needed - got;
+    for (int i = lane; i < take; i += 64) lb[have + i] = L[got + i];
+    have += take; got += take;
+    int nb = (int)(((unsigned)have * nlb_inv) >> 16);
+    if (nb > nfull - S.done) nb = nfull - S.done;
+    if (nb > 0) {
+      const int upto = S.done + nb;
+      switch (t.cr) {
+        case C8P_CR_12: lean_blocks_l<C8P_CR_12>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        case C8P_CR_23: lean_blocks_l<C8P_CR_23>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        case C8P_CR_34: lean_blocks_l<C8P_CR_34>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        default:        lean_blocks_l<C8P_CR_56>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+      }
+      const int used = nb * nlb;
+      have -= used;
+      for (int i = 0; i < have; i += 64) {
+        const float v = i + lane < have ? lb[used + i + lane] : 0.0f;
+        if (i + lane < have) lb[i + lane] = v;
+      }
+    }
+  }
+  if (lane == 0) flags[n + p] = (uint32_t)S.nflt;
+  switch (t.cr) {
+    case C8P_CR_12: lean_tail_l<C8P_CR_12>(S, K, lb, have, lane, Tn, sv); break;
+    case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lb, have, lane, Tn, sv); break;
+    case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane, Tn, sv); break;
+    default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane, Tn, sv); break;
+  }
+}
+
 // ================================================================================================ finish
 #define CRC_POLY 0xedb88320u
 __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b)   // a(x)*b(x) mod P, reflected

@@ -29,6 +29,15 @@ def eng(request):
     e.close()
 
 
+@pytest.fixture(autouse=True)
+def _decode_entry_flavour(request, monkeypatch):
+    """the decode-entry tests (reference Viterbi vectors, tie-only streams, trellis sweeps, bursts) reach the LDS-fed block loops of
+    k_rx_1ss_lds through C8P_DECODE_LDS=1 (k_viterbi_lean_lds) on the on-chip flavour of the fixture and the scalar-cache-fed loops
+    of k_viterbi_lean on the other"""
+    if "eng" in request.fixturenames and not request.getfixturevalue("eng").keep_llr:
+        monkeypatch.setenv("C8P_DECODE_LDS", "1")
+
+
 def test_viterbi_kernel_matches_python_reference_vectors(eng):
     """decode entry on the reference toolbox's Viterbi vectors (ties included): bits identical."""
     v = np.load(os.path.join(GOLD, "viterbi_vectors.npz"))
@@ -631,6 +640,7 @@ def test_four_packets_per_wave_decoder(eng, monkeypatch):
     registers per packet: tools/gen_lean4_asm.py).  Streams with ties and positive drift (integer loop), a quad that starts with large
     negative LLRs (leaves and re-enters the loop), a partial last block; bits identical to the oracle for all four code rates."""
     monkeypatch.setenv("C8P_LEAN4", "1")                  # (by default only batches of >= 12288 packets take this kernel)
+    monkeypatch.delenv("C8P_DECODE_LDS", raising=False)
     rng = np.random.default_rng(2024)
     streams = []
     for cr, per in ((abi.CR_12, 2.0), (abi.CR_23, 1.5), (abi.CR_34, 4.0 / 3.0), (abi.CR_56, 1.2)):
