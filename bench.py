@@ -186,11 +186,6 @@ def main():
     kt_excl = eng_x.kernel_times()
     eng_x.close()
 
-    # BASELINE configs[3] beside the headline: ONE stream scattered from rank 0, decoded, gathered (every rank takes part)
-    stream_res = None
-    if not args.no_stream:
-        stream_res = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, args.stream_steps, 1)
-
     out = None
     if rank == 0:
         total_pkts = n_pkt * world * args.steps
@@ -239,8 +234,23 @@ def main():
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
-        if not args.no_stream:
+    # BASELINE configs[3] beside the headline: ONE stream scattered from rank 0, decoded, gathered (every rank takes part).  The
+    # headline above is complete at this point and this leg's collectives have never run on more than one GPU: it runs under a
+    # watchdog on every rank, so that neither an exception on one rank nor a collective that never returns can cost the line.
+    if not args.no_stream:
+        guard = LegGuard(out, rank, float(os.environ.get("C8P_STREAM_LEG_TIMEOUT_S", "420")), "sharded_stream")
+        try:
+            stream_res = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, args.stream_steps, 1)
+        except Exception as e:                           # (the peers, if any, are then stuck in a collective: their guards end them)
+            stream_res = {"error": "%s: %s" % (type(e).__name__, e), "world": world}
+            if world > 1:
+                guard.fire("rank %d: %s" % (rank, stream_res["error"]))
+        if use_dist:
+            dist.barrier()                               # still guarded: a rank that failed above never arrives
+        guard.done()
+        if rank == 0:
             out["sharded_stream"] = stream_res
+    if rank == 0:
         if not args.no_host_legs and world == 1:
             # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
             out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local)
@@ -277,6 +287,39 @@ def main():
 
 
 _JSON_OUT = None
+
+
+class LegGuard:
+    """Watchdog around an optional leg that runs AFTER the headline was measured: if the leg does not finish in `timeout_s` (or
+    `fire` is called), rank 0 prints the headline line as it stands, with the leg marked as failed, and the process exits with
+    status 0 — on every rank, each by its own timer, because a rank stuck in a collective cannot be told anything."""
+
+    def __init__(self, out, rank, timeout_s, name):
+        import threading
+        self.out, self.rank, self.name, self.timeout_s = out, rank, name, timeout_s
+        self._ev = threading.Event()
+        self._th = threading.Thread(target=self._watch, daemon=True)
+        self._th.start()
+
+    def _watch(self):
+        if not self._ev.wait(self.timeout_s):
+            self.fire("no result after %.0f s" % self.timeout_s)
+
+    def fire(self, why):
+        if self._ev.is_set():
+            return
+        self._ev.set()
+        if self.rank == 0 and self.out is not None:
+            self.out[self.name] = {"error": why, "note": "the headline (`value`) was measured before this leg started and is unaffected"}
+            emit(self.out)
+        else:
+            time.sleep(5.0)                              # let rank 0 print first
+        sys.stderr.write("bench.py: leg %s abandoned on rank %d: %s\n" % (self.name, self.rank, why))
+        sys.stderr.flush()
+        os._exit(0)
+
+    def done(self):
+        self._ev.set()
 
 
 def emit(obj):
