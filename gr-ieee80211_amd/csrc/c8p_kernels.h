@@ -524,18 +524,22 @@ template <int NB> __device__ __forceinline__ void qam_to_llr(cf q, float (&o)[NB
 
 // LLRs of one subcarrier scattered through a de-interleave map (procSymDeint* cloud80211phy.cc:2150-2338): out[map[j*NB+b]] = llr[b]
 // neg += sum of max(0, -LLR): the decoder's integer loop needs a bound on how far a block can pull a metric down
+// Range check for the lean decoder (|LLR| <= 2^20, no NaN): only the two first-level values r, i are tested, against 2^20 - 8.  The
+// others follow: o[k+1] = A / 2^k - |o[k]| with A <= 8, so |o[k+1]| <= max(A, |o[k]|) <= 2^20, and they are finite when r, i are.
+// (A packet flagged a hair early takes the exact decoder, which gives the same bits.)
+#define C8P_LLR_BOUND_M8_BITS 0x497fff80u     // 2^20 - 8 as float bits
 template <int NB> __device__ __forceinline__ bool llr_scatter(cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out, float& neg)
 {
   float o[NB];
   qam_to_llr<NB>(q, o);
-  bool bad = false;
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     out[(uint32_t)(uint16_t)map[j * NB + b]] = o[b];   // unsigned 32-bit offsets from a uniform base: no 64-bit address per store
-    bad = bad || bad_llr(o[b]);
     neg += fmaxf(-o[b], 0.0f);
   }
-  return bad;
+  uint32_t m = __float_as_uint(o[0]) & 0x7fffffffu;
+  if constexpr (NB >= 2) m = max(m, __float_as_uint(o[NB / 2]) & 0x7fffffffu);
+  return m > C8P_LLR_BOUND_M8_BITS;
 }
 __device__ __forceinline__ bool llr_scatter_nb(int nb, cf q, int j, const int16_t* __restrict__ map, float* __restrict__ out, float& neg)
 {

@@ -628,7 +628,7 @@ def test_rx_hands_out_of_range_packets_to_the_exact_decoder(eng):
         assert g["pdus"] == o["pdus"] and g["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], p
         if flags[p]:
             n_flagged += 1
-            assert o["tags"]["format"] == abi.F_L and np.max(np.abs(o["llr"])) > 2.0 ** 20, p
+            assert o["tags"]["format"] == abi.F_L and np.max(np.abs(o["llr"])) > 2.0 ** 20 - 8, p
             n_pdu += len(o["pdus"])
             if len(o["pdus"]):
                 assert np.array_equal(g["bits"], o["bits"]) and np.array_equal(g["sbits"], o["sbits"]), p

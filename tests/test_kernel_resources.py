@@ -54,7 +54,7 @@ def test_on_chip_llr_kernel_has_no_scratch_at_six_waves(usage):
     rx = usage["k_rx_1ss_lds"]
     assert rx["VGPRs"] <= 80 and rx["AGPRs"] == 0 and rx["Occupancy"] >= 6, rx
     assert rx["ScratchSize"] == 0 and rx["VGPRs Spill"] == 0 and rx["SGPRs Spill"] == 0, rx
-    assert rx["LDS Size"] <= 20 * 1024, rx
+    assert rx["LDS Size"] <= 22 * 1024, rx                 # x 6 workgroups per CU = 128 KB of 160 KB
 
 
 def test_side_kernels_stay_inside_their_budgets(usage):
