@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/gen_lean_asm.py — writes gr-ieee80211_amd/csrc/c8p_lean_asm.h: the full-block loop of the lean Viterbi forward pass
-(c8p_viterbi_lean.h) as ONE inline-asm statement per code rate, in two flavours.
+(c8p_viterbi_lean.h) as ONE inline-asm statement per code rate, in four flavours (the two LDS-fed ones are described further down,
+at gen_rate_lds: lean_blocks_lds<CR> = lean_blocks_int with the LLRs as VGPR operands read from LDS, lean_block_flt_lds<CR> = one
+block of the float step, same feed; k_rx_1ss_lds uses them).
 
   lean_blocks_int<CR>   the production fast path.  When every path metric of a block is known to stay POSITIVE, the unsigned
                         order of the float bit patterns is the float order, and the compare can be an integer subtract with
