@@ -438,9 +438,18 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
         d_done4 = (const uint8_t*)c->s->d_done4.p;
       }
       const char* el = getenv("C8P_DECODE_LDS");     // tests: c8p_decode through the LDS-fed block loop of k_rx_1ss_lds
-      if (!rx && el && atoi(el) != 0)
+      if (!rx && el && atoi(el) != 0) {
+        const uint8_t* d2 = nullptr;
+        if (atoi(el) == 2 && n >= 2) {                // ... and pairs of alike packets through the two-packets-per-wave layout
+          if ((rc = ensure(c, c->s->d_done4, (size_t)n + 4)) != C8P_OK) return rc;
+          HIPCHK(c, hipMemsetAsync(c->s->d_done4.p, 0, (size_t)n, dst));
+          hipLaunchKernelGGL(k_viterbi_lean2_lds, dim3((n / 2 + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
+                             (uint32_t*)c->s->d_flags.p, (uint8_t*)c->s->d_done4.p, n);
+          d2 = (const uint8_t*)c->s->d_done4.p;
+        }
         hipLaunchKernelGGL(k_viterbi_lean_lds, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
-                           (uint32_t*)c->s->d_flags.p, n);
+                           (uint32_t*)c->s->d_flags.p, d2, n);
+      }
       else if (!rx || rx->any_2ant)
         hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                            (uint32_t*)c->s->d_flags.p, rx ? (const float*)c->s->d_negsym.p : nullptr, rx ? rx->d_pk : nullptr, d_done4, n);

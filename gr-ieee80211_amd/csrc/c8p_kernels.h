@@ -1210,11 +1210,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // decode-entry parity tests (tie-only streams, trellis-length sweeps, bursts that leave the integer loop) reach the LDS flavours
 // of all four code rates; nothing else uses it.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_viterbi_lean_lds(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                                      const float* __restrict__ llr, ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+                                                      const float* __restrict__ llr, ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags,
+                                                      const uint8_t* __restrict__ done2, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
   if (flags[p] != 0) return;
+  if (done2 && done2[p]) return;                   // decoded by k_viterbi_lean2_lds
   const c8p_pkt_tags t = tags[p];
   if (!decodable(t)) return;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1266,6 +1268,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lb, have, lane, Tn, sv); break;
     case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane, Tn, sv); break;
     default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane, Tn, sv); break;
+  }
+}
+
+// Two packets per wave (c8p_viterbi_lean.h, bottom; tools/gen_lean2_asm.py), c8p_decode entry (C8P_DECODE_LDS=2; tests and the
+// decode-only measurement of the layout).  Wave w takes packets 2w, 2w+1 if both can be decoded by the lean path and share the code
+// rate and the trellis length; it marks them in done2[] and k_viterbi_lean_lds skips them.  LLRs go through the packets' LDS
+// buffers in rounds as in k_viterbi_lean_lds; blocks whose metrics are not provably positive and the partial last block go through
+// LDS into the lane = index layout and run the one-packet code, one packet at a time.
+__global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
+                                                           const float* __restrict__ llr, ulonglong2* __restrict__ surv,
+                                                           uint32_t* __restrict__ flags, uint8_t* __restrict__ done2, int n)
+{
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (2 * w + 1 >= n) return;                      // (a last, single packet goes to k_viterbi_lean_lds)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id(), half = lane >> 5, l = lane & 31;
+  const int p = 2 * w + half;
+  const c8p_pkt_tags t = tags[p];                  // per half
+  const c8p_pkt_tags t0 = tags[2 * w];             // wave-uniform copy of the first packet's tags
+  const bool good = decodable(t) && flags[p] == 0 && t.cr == t0.cr && t.trellis == t0.trellis;
+  if (__ballot(good) != ~0ull) return;
+  if (l == 0) done2[p] = 1;
+  const int cr = __builtin_amdgcn_readfirstlane(t0.cr);
+  const int Tn = __builtin_amdgcn_readfirstlane(t0.trellis), nfull = Tn / C8P_SV_BLK, segn = c8p_seg_blocks(Tn);
+  const int nlb = cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                  cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
+  const unsigned nlb_inv = cr == C8P_CR_12 ? 1093u : cr == C8P_CR_23 ? 1457u : cr == C8P_CR_34 ? 1639u : 1821u;
+  const int needed = __builtin_amdgcn_readfirstlane(llr_needed(cr, Tn));
+  const float bound = fmaf(__uint_as_float(flags[2 * n + p]), 1.01f, 1e-30f);     // per half (lean_bound)
+  unsigned voff = (unsigned)(lay[p].surv_off * 16u) + (unsigned)l * 4u;             // byte offset into the survivor arena (< 4 GB)
+  unsigned* const svb = (unsigned*)surv;
+  __shared__ __attribute__((aligned(16))) float lbuf[4][2][C8P_LBUF];
+  __shared__ float xch_all[4][2][64];              // [wave][packet][index D]: the bridge between the two layouts
+  float (*xch)[64] = xch_all[wv];
+  float* const lbh = lbuf[wv][half];               // this half's buffer
+  const unsigned la0 = (unsigned)(size_t)lbh;
+  const float* const Lh = llr + t.llr_off;
+  float m0 = l == 0 ? 0.0f : C8P_NEG_INIT, m1 = C8P_NEG_INIT;
+  int have = 0, got = 0, done = 0, segc = 0, nflt = 0;
+  while (got < needed) {
+    int take = C8P_LBUF - have;
+    if (take > needed - got) take = needed - got;
+    for (int i = l; i < take; i += 32) lbh[have + i] = Lh[got + i];
+    have += take; got += take;
+    int nb = (int)(((unsigned)have * nlb_inv) >> 16);
+    if (nb > nfull - done) nb = nfull - done;
+    const int upto = done + nb, done_r = done;
+    unsigned laddr = la0;
+    while (done < upto) {
+      // integer loop, both packets at once, as long as every metric of both stays above its packet's bound
+      if (__ballot(fminf(m0, m1) < bound) == 0ull) {
+        LeanK K2[6];
+        lean2_k_consts(l, K2);
+        unsigned initx, inity, flip;
+        lean4_int_consts(l, initx, inity, flip);
+        int left = __builtin_amdgcn_readfirstlane(upto - done), sc = __builtin_amdgcn_readfirstlane(segc);   // (asm "+s" operands)
+        switch (cr) {
+          case C8P_CR_12: lean2_lds<C8P_CR_12>(m0, m1, K2, initx, inity, flip, bound, sc, segn, voff, laddr, svb, left); break;
+          case C8P_CR_23: lean2_lds<C8P_CR_23>(m0, m1, K2, initx, inity, flip, bound, sc, segn, voff, laddr, svb, left); break;
+          case C8P_CR_34: lean2_lds<C8P_CR_34>(m0, m1, K2, initx, inity, flip, bound, sc, segn, voff, laddr, svb, left); break;
+          default:        lean2_lds<C8P_CR_56>(m0, m1, K2, initx, inity, flip, bound, sc, segn, voff, laddr, svb, left); break;
+        }
+        segc = sc;
+        done = upto - left;
+        if (done == upto) break;
+      }
+      // one block of each packet with the float step in the lane = index layout
+      xch[half][l] = m0; xch[half][32 + l] = m1;
+      const bool seg_end = segc + 1 >= segn;
+#pragma unroll 1
+      for (int pp = 0; pp < 2; pp++) {
+        const int q = __builtin_amdgcn_readfirstlane(2 * w + pp);
+        LeanK K[6];
+        lean_k_consts(lane, K);
+        float pre = xch[pp][lane];
+        unsigned acc = 0;
+        const unsigned la = (unsigned)(size_t)lbuf[wv][pp] + (unsigned)((done - done_r) * nlb * 4);
+        switch (cr) {
+          case C8P_CR_12: lean_block_flt_lds<C8P_CR_12>(pre, acc, K, la); break;
+          case C8P_CR_23: lean_block_flt_lds<C8P_CR_23>(pre, acc, K, la); break;
+          case C8P_CR_34: lean_block_flt_lds<C8P_CR_34>(pre, acc, K, la); break;
+          default:        lean_block_flt_lds<C8P_CR_56>(pre, acc, K, la); break;
+        }
+        unsigned word = acc & ~(C8P_SV_HINT | 0x80000000u);
+        if (seg_end) {
+          float mx = pre;
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+          if (pre == mx) word |= C8P_SV_HINT;
+        }
+        unsigned* sv = (unsigned*)(surv + lay[q].surv_off);
+        sv[done * 64 + lane] = word;
+        xch[pp][lane] = pre;
+      }
+      m0 = xch[half][l]; m1 = xch[half][32 + l];
+      segc = seg_end ? 0 : segc + 1;
+      done++; nflt++;
+      voff += 256u;
+      laddr += (unsigned)(nlb * 4);
+    }
+    // what is left over moves to the front, each half its own buffer (one lane per LLR, 32 per pass; reads before writes)
+    const int used = nb * nlb;
+    have -= used;
+    if (used > 0)
+      for (int i = 0; i < have; i += 32) {
+        const float v = i + l < have ? lbh[used + i + l] : 0.0f;
+        if (i + l < have) lbh[i + l] = v;
+      }
+  }
+  if (l == 0) flags[n + p] = (uint32_t)nflt;
+  // the partial last block, packet by packet
+  xch[half][l] = m0; xch[half][32 + l] = m1;
+#pragma unroll 1
+  for (int pp = 0; pp < 2; pp++) {
+    const int q = __builtin_amdgcn_readfirstlane(2 * w + pp);
+    LeanK K[6];
+    lean_k_consts(lane, K);
+    LeanState S;
+    lean_init(S, lane);
+    S.pre = xch[pp][lane];
+    S.voff = (unsigned)lane * 4u + (unsigned)nfull * 256u;
+    unsigned* sv = (unsigned*)(surv + lay[q].surv_off);
+    switch (cr) {
+      case C8P_CR_12: lean_tail_l<C8P_CR_12>(S, K, lbuf[wv][pp], have, lane, Tn, sv); break;
+      case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lbuf[wv][pp], have, lane, Tn, sv); break;
+      case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lbuf[wv][pp], have, lane, Tn, sv); break;
+      default:        lean_tail_l<C8P_CR_56>(S, K, lbuf[wv][pp], have, lane, Tn, sv); break;
+    }
   }
 }
 

@@ -35,7 +35,7 @@ def _decode_entry_flavour(request, monkeypatch):
     k_rx_1ss_lds through C8P_DECODE_LDS=1 (k_viterbi_lean_lds) on the on-chip flavour of the fixture and the scalar-cache-fed loops
     of k_viterbi_lean on the other"""
     if "eng" in request.fixturenames and not request.getfixturevalue("eng").keep_llr:
-        monkeypatch.setenv("C8P_DECODE_LDS", "1")
+        monkeypatch.setenv("C8P_DECODE_LDS", os.environ.get("C8P_TEST_DECODE_LDS", "1"))     # 2: pairs through k_viterbi_lean2_lds
 
 
 def test_viterbi_kernel_matches_python_reference_vectors(eng):
@@ -635,12 +635,17 @@ def test_rx_hands_out_of_range_packets_to_the_exact_decoder(eng):
     assert n_flagged >= 6 and n_pdu >= 4, (n_flagged, n_pdu)
 
 
-def test_four_packets_per_wave_decoder(eng, monkeypatch):
+@pytest.mark.parametrize("layout", ["four", "two"])
+def test_several_packets_per_wave_decoders(eng, monkeypatch, layout):
     """c8p_decode sends quads of consecutive packets with the same code rate and trellis length through k_viterbi_lean4 (16 lanes x 4
-    registers per packet: tools/gen_lean4_asm.py).  Streams with ties and positive drift (integer loop), a quad that starts with large
-    negative LLRs (leaves and re-enters the loop), a partial last block; bits identical to the oracle for all four code rates."""
-    monkeypatch.setenv("C8P_LEAN4", "1")                  # (by default only batches of >= 12288 packets take this kernel)
-    monkeypatch.delenv("C8P_DECODE_LDS", raising=False)
+    registers per packet: tools/gen_lean4_asm.py), or pairs through k_viterbi_lean2_lds (32 lanes x 2 registers, LLRs from LDS:
+    tools/gen_lean2_asm.py; C8P_DECODE_LDS=2).  Streams with ties and positive drift (integer loop), packets that start with large
+    negative LLRs (leave and re-enter the loop), a partial last block; bits identical to the oracle for all four code rates."""
+    if layout == "four":
+        monkeypatch.setenv("C8P_LEAN4", "1")              # (by default only batches of >= 12288 packets take this kernel)
+        monkeypatch.delenv("C8P_DECODE_LDS", raising=False)
+    else:
+        monkeypatch.setenv("C8P_DECODE_LDS", "2")
     rng = np.random.default_rng(2024)
     streams = []
     for cr, per in ((abi.CR_12, 2.0), (abi.CR_23, 1.5), (abi.CR_34, 4.0 / 3.0), (abi.CR_56, 1.2)):
