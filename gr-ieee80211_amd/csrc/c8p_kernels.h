@@ -1285,10 +1285,8 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id(), half = lane >> 5, l = lane & 31;
   const int p = 2 * w + half;
-  const c8p_pkt_tags t = tags[p];                  // per half
-  const c8p_pkt_tags t0 = tags[2 * w];             // wave-uniform copy of the first packet's tags
-  const bool good = decodable(t) && flags[p] == 0 && t.cr == t0.cr && t.trellis == t0.trellis;
-  if (__ballot(good) != ~0ull) return;
+  const c8p_pkt_tags t0 = tags[2 * w], t1 = tags[2 * w + 1];     // wave-uniform (scalar loads)
+  if (!(decodable(t0) && decodable(t1) && flags[2 * w] == 0 && flags[2 * w + 1] == 0 && t0.cr == t1.cr && t0.trellis == t1.trellis)) return;
   if (l == 0) done2[p] = 1;
   const int cr = __builtin_amdgcn_readfirstlane(t0.cr);
   const int Tn = __builtin_amdgcn_readfirstlane(t0.trellis), nfull = Tn / C8P_SV_BLK, segn = c8p_seg_blocks(Tn);
@@ -1304,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
   float (*xch)[64] = xch_all[wv];
   float* const lbh = lbuf[wv][half];               // this half's buffer
   const unsigned la0 = (unsigned)(size_t)lbh;
-  const float* const Lh = llr + t.llr_off;
+  const float* const Lh = llr + (half ? t1.llr_off : t0.llr_off);
   float m0 = l == 0 ? 0.0f : C8P_NEG_INIT, m1 = C8P_NEG_INIT;
   int have = 0, got = 0, done = 0, segc = 0, nflt = 0;
   while (got < needed) {
@@ -1319,10 +1317,11 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
     while (done < upto) {
       // integer loop, both packets at once, as long as every metric of both stays above its packet's bound
       if (__ballot(fminf(m0, m1) < bound) == 0ull) {
+        const int l5 = lane_fresh() & 31;             // (afresh: the constants must not be hoisted and held across the other phases)
         LeanK K2[6];
-        lean2_k_consts(l, K2);
+        lean2_k_consts(l5, K2);
         unsigned initx, inity, flip;
-        lean4_int_consts(l, initx, inity, flip);
+        lean4_int_consts(l5, initx, inity, flip);
         int left = __builtin_amdgcn_readfirstlane(upto - done), sc = __builtin_amdgcn_readfirstlane(segc);   // (asm "+s" operands)
         switch (cr) {
           case C8P_CR_12: lean2_lds<C8P_CR_12>(m0, m1, K2, initx, inity, flip, bound, sc, segn, voff, laddr, svb, left); break;
@@ -1340,6 +1339,7 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
 #pragma unroll 1
       for (int pp = 0; pp < 2; pp++) {
         const int q = __builtin_amdgcn_readfirstlane(2 * w + pp);
+        const int lane = lane_fresh();
         LeanK K[6];
         lean_k_consts(lane, K);
         float pre = xch[pp][lane];
@@ -1383,6 +1383,7 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
 #pragma unroll 1
   for (int pp = 0; pp < 2; pp++) {
     const int q = __builtin_amdgcn_readfirstlane(2 * w + pp);
+    const int lane = lane_fresh();
     LeanK K[6];
     lean_k_consts(lane, K);
     LeanState S;

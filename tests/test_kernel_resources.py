@@ -77,3 +77,8 @@ def test_generated_block_loop_is_current(tmp_path):
                        env=dict(os.environ, C8P_GEN_OUT4=str(out4)), timeout=120)
     assert r.returncode == 0, r.stderr
     assert out4.read_text() == open(os.path.join(CSRC, "c8p_lean4_asm.h")).read()
+    out2 = tmp_path / "c8p_lean2_asm.h"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_lean2_asm.py")], capture_output=True, text=True,
+                       env=dict(os.environ, C8P_GEN_OUT2=str(out2)), timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_text() == open(os.path.join(CSRC, "c8p_lean2_asm.h")).read()
