@@ -175,14 +175,23 @@ def main():
     kt = eng.kernel_times()
     eng.close()                              # its arenas (4 slots, sized for the worst case per packet) are not needed any more
 
-    # exclusive per-kernel durations: the same batch once more with a sync after every step (no overlap between slots),
-    # every launch bracketed
+    # exclusive per-kernel durations: the same batch on an engine with ONE slot (one stream: every launch has the GPU to itself),
+    # every launch bracketed, 40 steps back to back after 8 untimed ones — the GPU stays busy, so the clocks are the ones of the timed
+    # region (with a sync after every step the part idles in between and the same kernel takes ~10 % longer); this is what
+    # `C8P_SLOTS=1 rocprofv3 --kernel-trace --stats` averages (profiles/*/kernel_stats_exclusive.csv)
+    slots_env = os.environ.get("C8P_SLOTS")
+    os.environ["C8P_SLOTS"] = "1"
     eng_x = engine.Engine(device=local, profile=1)
-    for i in range(4):
+    if slots_env is None:
+        del os.environ["C8P_SLOTS"]
+    else:
+        os.environ["C8P_SLOTS"] = slots_env
+    for i in range(48):
         eng_x.rx(pk, iq_dev, chan_dev)
-        eng_x.sync()
-        if i == 0:
+        if i == 7:
+            eng_x.sync()
             eng_x.profile_reset()
+    eng_x.sync()
     kt_excl = eng_x.kernel_times()
     eng_x.close()
 
@@ -225,7 +234,8 @@ def main():
                          "exclusive_avg_launch_ms": {k: round(v, 4) for k, v in kern_x.items()},
                          "pipelined_avg_launch_ms": {k: round(v, 4) for k, v in kern.items()},
                          "note": "achieved = alg_bytes_per_packet x packets_per_launch / exclusive_avg_launch_ms[kernel] (HIP events on the "
-                                 "engine's stream, every launch, one batch at a time); frac_step = the same bytes / ms_per_step; "
+                                 "engine's stream, every launch, 40 steps back to back on ONE slot: one batch at a time, the average "
+                                 "`C8P_SLOTS=1 rocprofv3 --stats` reports); frac_step = the same bytes / ms_per_step; "
                                  "pipelined_avg_launch_ms = events on every %d-th launch inside the timed region, where the launches of "
                                  "%s batches overlap (not a per-launch cost)" % (PROFILE_EVERY, os.environ.get("C8P_SLOTS", "4"))},
         }

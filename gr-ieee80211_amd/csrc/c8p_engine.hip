@@ -12,6 +12,7 @@
 #include <string>
 #include <mutex>
 #include <vector>
+#include <memory>
 
 #include <algorithm>
 #include <chrono>
@@ -409,7 +410,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   hipStream_t dst = c->s->stream, fst = c->s->stream;
   {
     // forward pass: lean kernel for every packet whose LLRs passed the range check, clamp-exact kernel for the rest
-    KTimer kt(c, C8P_K_VITERBI, dst);
+    std::unique_ptr<KTimer> kt(new KTimer(c, C8P_K_VITERBI, dst));
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
@@ -421,6 +422,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
       else if (rx) {     // the LLR stream stays in LDS; what the lean decoder cannot take is demodulated once more, into the arena
         hipLaunchKernelGGL(k_rx_1ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
                            d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+        if (!rx->any_2ant) kt.reset();   // the forward pass ends here for the events: the nearly empty launches below (2 us each) are not it
         hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
                            d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, 1);
       }

@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --no-cpu --no-host-legs"     # the default bench command without the CPU and host-fed legs
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $BENCH > $OUT/stats.log 2>&1
+# the same with ONE slot: every launch has the GPU to itself, so the per-kernel AVERAGE of this summary is the exclusive launch duration
+# that bench.py prices (roofline.exclusive_avg_launch_ms); in the 4-slot run above the launches of four batches share the GPU
+C8P_SLOTS=1 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o ${TAG}_slots1 --output-format csv -- $BENCH --no-frontend --no-stream --steps 50 --repeats 1 > $OUT/stats1.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_READ_sum TCC_WRITE_sum"; do
   n=$(echo $c | tr ' ' '+')
   C8P_SLOTS=1 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o pmc --output-format csv -- python $PWD/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu --no-frontend --no-stream --no-host-legs > $OUT/pmc_$n.log 2>&1

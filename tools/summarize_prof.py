@@ -23,6 +23,8 @@ b = open(os.path.join(src, "bench.json")).read().strip().splitlines()
 open(os.path.join(dst, "bench.json"), "w").write(b[-1] + "\n" if b else "")
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(dst, "kernel_stats.csv"), "w").write(open(f).read())
+for f in glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recursive=True):      # C8P_SLOTS=1: averages = exclusive durations
+    open(os.path.join(dst, "kernel_stats_exclusive.csv"), "w").write(open(f).read())
 
 counters = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> values
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
