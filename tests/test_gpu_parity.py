@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from c8p_cases import cfg2_batch, replicated_batch, sweep_batch
+from c8p_cases import ampdu_vht, cfg2_batch, replicated_batch, sweep_batch
 from c8p_testlib import H22, load_npz
 from c8p_smoke import compare
 from c8p_testlib import GOLD, Batch, abi, oracle, oracle_rx
@@ -679,3 +679,76 @@ def test_traceback_hints_save_the_second_walk(eng):
     passes = outs["rsv"]
     assert (passes >= 1).all()
     assert (passes == 1).mean() > 0.8, np.bincount(passes)
+
+@pytest.mark.parametrize("snr_db", [30.0, 14.0, 6.0])
+def test_both_rx_flavours_agree_on_random_formats_lengths_and_noise(snr_db):
+    """Differential test of the two product kernels behind c8p_rx (k_rx_1ss_lds: LLRs through LDS, generated lean_blocks_lds /
+    lean_block_flt_lds; k_rx_1ss: LLRs through the arena, lean_blocks_int / the C++ float step): 300 packets of random format
+    (legacy / HT / VHT), MCS and length (14 .. 3000 bytes: up to 500 OFDM symbols, rounds of 1 to 13 symbols) from c8p_tx through
+    AWGN at 30 / 14 / 6 dB — at 6 dB nearly every frame fails its FCS and the decoders run on noise.  Same demodulator arithmetic,
+    so EVERYTHING must be identical, failing frames included: tags, decoded bits before and after descrambling, failure counts,
+    PDUs.  The oracle checks a sample of the packets."""
+    import torch
+    import zlib
+    rng = np.random.default_rng(int(snr_db) * 1000 + 17)
+    n = 300
+    GAP = 160
+    pk = np.zeros(n, abi.TX_PKT_DT)
+    arena, off = [np.zeros(4, np.uint8)], 4
+    for p in range(n):
+        fmt = int(rng.integers(0, 3))
+        mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+        ln = int(rng.integers(14, 3000))
+        body = bytes(rng.integers(0, 256, size=ln, dtype=np.uint8))
+        mpdu = body + zlib.crc32(body).to_bytes(4, "little")
+        ps = ampdu_vht(mpdu) if fmt == abi.F_VHT else mpdu
+        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = off, len(ps), fmt, mcs
+        pk[p]["scr_seed"], pk[p]["mult"], pk[p]["gap"], pk[p]["flags"] = 1 + p % 127, 12.0, GAP, abi.TX_NO_WINDOW
+        arena.append(np.frombuffer(ps, np.uint8))
+        off += len(ps)
+    e_tx = engine.Engine(device=0)
+    e_tx.tx(pk, np.concatenate(arena), tail_gap=400)
+    e_tx.sync()
+    desc = e_tx.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)
+    clean = torch.from_numpy(e_tx.fetch(abi.BUF_TX_IQ, np.complex64).view(np.float32)).cuda()
+    e_tx.close()
+    g = torch.Generator(device="cuda"); g.manual_seed(int(snr_db) + 5)
+    sigma = float(np.sqrt(0.1875 ** 2 / (10 ** (snr_db / 10.0))))
+    noisy = (clean + torch.randn(clean.shape, generator=g, device="cuda", dtype=torch.float32) * (sigma / np.sqrt(2))).contiguous()
+    ntot = noisy.numel() // 2
+    ev = np.zeros(n, abi.SIG_IN_DT)
+    ev["raw_off"][:, 0] = desc["iq_off"] + 184             # L-LTF start + 24 (signal_impl's sync item)
+    ev["n_avail"] = desc["n_samp"] - 184 + GAP
+    ev["snr"], ev["rssi"], ev["n_ant"] = snr_db, 1.0, 1
+    e_sig = engine.Engine(device=0)
+    e_sig.signal(ev, engine.DevArray(noisy.data_ptr(), ntot, noisy))
+    e_sig.sync()
+    spk = e_sig.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    spk = spk[spk["n_items"] > 0].copy()
+    assert len(spk) >= (0.9 * n if snr_db >= 14 else 0.3 * n), len(spk)
+    iq = e_sig.fetch(abi.BUF_SIG_IQ, np.complex64)
+    chan = e_sig.fetch(abi.BUF_SIG_CHAN, np.complex64)
+    e_sig.close()
+    res = []
+    for keep in (False, True):
+        e = engine.Engine(device=0, keep_bits=True, keep_llr=keep)
+        e.rx(spk, iq, chan)
+        res.append(e.results(want_llr=False, want_bits=True))
+        e.close()
+    n_pdu = n_fail = 0
+    for p, (a, b) in enumerate(zip(*res)):
+        assert a["tags"].tobytes() == b["tags"].tobytes(), p
+        assert a["out"]["n_pdu"] == b["out"]["n_pdu"] and a["out"]["n_crc_fail"] == b["out"]["n_crc_fail"], p
+        assert a["pdus"] == b["pdus"], p
+        assert np.array_equal(a["sbits"], b["sbits"]) and np.array_equal(a["bits"], b["bits"]), p
+        n_pdu += len(a["pdus"]); n_fail += int(a["out"]["n_crc_fail"])
+    if snr_db >= 30:
+        assert n_pdu >= 0.95 * len(spk), (n_pdu, len(spk))
+    if snr_db <= 6:
+        assert n_fail >= 0.5 * len(spk), (n_fail, len(spk))
+    sample = np.arange(0, len(spk), 9)
+    ref = oracle_rx(spk[sample], iq, chan)
+    for k, o in zip(sample, ref):
+        assert res[0][k]["tags"]["status"] == o["tags"]["status"], k
+        assert res[0][k]["pdus"] == o["pdus"] and res[0][k]["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], k
+
