@@ -173,7 +173,7 @@ def main():
         rep_elapsed.append(el)
     elapsed = float(np.median(rep_elapsed))
     kt = eng.kernel_times()
-    eng.close()                              # its arenas (4 slots, sized for the worst case per packet) are not needed any more
+    eng.close()                              # its arenas (one set per slot, sized for the worst case per packet) are not needed any more
 
     # exclusive per-kernel durations: the same batch on an engine with ONE slot (one stream: every launch has the GPU to itself),
     # every launch bracketed, 40 steps back to back after 8 untimed ones — the GPU stays busy, so the clocks are the ones of the timed
@@ -237,7 +237,7 @@ def main():
                                  "engine's stream, every launch, 40 steps back to back on ONE slot: one batch at a time, the average "
                                  "`C8P_SLOTS=1 rocprofv3 --stats` reports); frac_step = the same bytes / ms_per_step; "
                                  "pipelined_avg_launch_ms = events on every %d-th launch inside the timed region, where the launches of "
-                                 "%s batches overlap (not a per-launch cost)" % (PROFILE_EVERY, os.environ.get("C8P_SLOTS", "4"))},
+                                 "%s batches overlap (not a per-launch cost)" % (PROFILE_EVERY, os.environ.get("C8P_SLOTS", "3"))},
         }
         rv = valu_roofline(kern_x, n_pkt, dec_path["float_step_block_fraction"])
         if rv:

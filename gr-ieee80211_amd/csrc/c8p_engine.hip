@@ -280,8 +280,11 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   { const char* e = getenv("C8P_RX_LLR"); c->keep_llr = e ? atoi(e) != 0 : cfg->keep_llr != 0; }   // (the env switch: A/B runs)
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
   {
-    // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 4) engine-owned streams.
-    int nslot = 4;                                         // measured 2 / 3 / 4 / 5 / 6 slots: 4.64 / 4.95 / 5.15 / 4.64 / 4.88 M packets/s
+    // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 3) engine-owned streams.
+    // Round 1 (three kernels per step, LLRs through HBM) measured 2 / 3 / 4 / 5 / 6 slots: 4.64 / 4.95 / 5.15 / 4.64 / 4.88 M packets/s;
+    // with the fused on-chip kernel of round 2 three batches in flight fill the machine: 2 / 3 / 4 / 6 / 8 slots = 6.47 / 6.71 / 6.62 /
+    // 6.56 / 6.69 M (3 against 4, alternated four times on one box: +1.4 % every time, profiles/r2g/ab_slots.txt)
+    int nslot = 3;
     const char* e = getenv("C8P_SLOTS");
     if (e && atoi(e) >= 1 && atoi(e) <= 8) nslot = atoi(e);
     if (cfg->stream) nslot = 1;

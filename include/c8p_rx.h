@@ -19,8 +19,8 @@
  * Conventions
  *   - plain C types only, no torch / GNU Radio / HIP types in signatures;
  *   - every pointer is caller-owned; the engine never frees or keeps caller memory past
- *     c8p_sync(); engine-owned result arenas stay valid until their slot is reused — with the default 4 slots that is the
- *     4th submit after theirs (c8p_ticket / c8p_select), with a caller-provided stream the next submit;
+ *     c8p_sync(); engine-owned result arenas stay valid until their slot is reused — with the default 3 slots that is the
+ *     3rd submit after theirs (c8p_ticket / c8p_select), with a caller-provided stream the next submit;
  *   - errors are negative return codes, never exceptions or abort();
  *   - one ctx per block instance / per thread; a ctx is not internally locked;
  *   - there is no CPU fallback: c8p_create() fails if no HIP device is usable.
@@ -358,7 +358,7 @@ int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   
 int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2); /* C8P_F_VHT_MU: plan2[0], plan2[1] = the users */
 int c8p_sync  (c8p_ctx* ctx);
 
-/* Submits rotate through C8P_SLOTS (default 4) sets of arenas, so the results of the last few submits stay resident.
+/* Submits rotate through C8P_SLOTS (default 3) sets of arenas, so the results of the last few submits stay resident.
  * c8p_ticket: id of the latest submit (> 0).  c8p_select: make c8p_buffer / c8p_fetch refer to that earlier submit
  * (C8P_ERANGE once its slot has been reused); the next submit selects itself.  Lets a caller upload batch i+1 while it
  * downloads batch i.  One slot only when the ctx runs on a caller-provided stream. */
