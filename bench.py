@@ -248,7 +248,7 @@ def main():
     # headline above is complete at this point and this leg's collectives have never run on more than one GPU: it runs under a
     # watchdog on every rank, so that neither an exception on one rank nor a collective that never returns can cost the line.
     if not args.no_stream:
-        guard = LegGuard(out, rank, float(os.environ.get("C8P_STREAM_LEG_TIMEOUT_S", "420")), "sharded_stream")
+        guard = LegGuard(out, rank, float(os.environ.get("C8P_STREAM_LEG_TIMEOUT_S", "180")), "sharded_stream")
         try:
             stream_res = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, args.stream_steps, 1)
         except Exception as e:                           # (the peers, if any, are then stuck in a collective: their guards end them)
