@@ -129,27 +129,52 @@ __device__ __forceinline__ double neg_if(double v, bool c)      // sign-bit flip
 // twiddles 1 and -j (a swap), so they have no multiplication at all; the others use 2 mul + 2 fma.  (fp64 runs at half
 // the fp32 rate on gfx950 and this kernel competes with the decoder for VALU issue: 28 fp64 ops per transform
 // instead of 60.)
+// The exchanges: lane ^ HALF for HALF <= 16 is a ds_swizzle in bit mode (and 0x1f, or 0, xor HALF: the pattern is an immediate, no
+// address register and no VALU work; it swizzles inside each half of the wave, which is all these stages need), lane ^ 32 a
+// ds_bpermute whose byte address is computed once per transform.  (__shfl_xor computes lane ^ m, clamps it to the width and shifts
+// it — three VALU instructions per stage in a kernel whose time is VALU issue slots.)
+template <int HALF> __device__ __forceinline__ double xchg_d(double v, int addr32)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (HALF == 32) {
+    lo = __builtin_amdgcn_ds_bpermute(addr32, lo); hi = __builtin_amdgcn_ds_bpermute(addr32, hi);
+  } else {
+    lo = __builtin_amdgcn_ds_swizzle(lo, (HALF << 10) | 0x1f); hi = __builtin_amdgcn_ds_swizzle(hi, (HALF << 10) | 0x1f);
+  }
+  return __hiloint2double(hi, lo);
+}
+template <int S> __device__ __forceinline__ void fft64_stage(double& xr, double& xi, const DevTables* __restrict__ T, int lane, int addr32)
+{
+  constexpr int half = 32 >> S;
+  const bool up = (lane & half) != 0;
+  const double pr = xchg_d<half>(xr, addr32), pi = xchg_d<half>(xi, addr32);
+  const double yr = pr + neg_if(xr, up), yi = pi + neg_if(xi, up);
+  if constexpr (S == 5) { xr = yr; xi = yi; }
+  else if constexpr (S == 4) {                          // twiddle index (lane & 1) << 4: 1 or -j;  (a + jb)(-j) = b - ja
+    const bool rot = up && (lane & 1);
+    xr = rot ? yi : yr;
+    xi = rot ? -yr : yi;
+  } else {
+    const double2 w = T->tw[up ? ((lane & (half - 1)) << S) : 0];
+    xr = __builtin_fma(yr, w.x, -(yi * w.y));
+    xi = __builtin_fma(yr, w.y, yi * w.x);
+  }
+}
 __device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T, int lane)
 {
-#pragma unroll
-  for (int s = 0; s < 6; s++) {
-    const int half = 32 >> s;
-    const bool up = (lane & half) != 0;
-    const double pr = shfl_xor_d(xr, half), pi = shfl_xor_d(xi, half);
-    const double yr = pr + neg_if(xr, up), yi = pi + neg_if(xi, up);
-    if (s == 5) { xr = yr; xi = yi; }
-    else if (s == 4) {                                  // twiddle index (lane & 1) << 4: 1 or -j;  (a + jb)(-j) = b - ja
-      const bool rot = up && (lane & 1);
-      xr = rot ? yi : yr;
-      xi = rot ? -yr : yi;
-    } else {
-      const double2 w = T->tw[up ? ((lane & (half - 1)) << s) : 0];
-      xr = __builtin_fma(yr, w.x, -(yi * w.y));
-      xi = __builtin_fma(yr, w.y, yi * w.x);
-    }
-  }
-  const int src = T->bitrev6[lane];
-  return make_double2(shfl_d(xr, src), shfl_d(xi, src));
+  const int addr32 = (lane ^ 32) << 2;
+  fft64_stage<0>(xr, xi, T, lane, addr32);
+  fft64_stage<1>(xr, xi, T, lane, addr32);
+  fft64_stage<2>(xr, xi, T, lane, addr32);
+  fft64_stage<3>(xr, xi, T, lane, addr32);
+  fft64_stage<4>(xr, xi, T, lane, addr32);
+  fft64_stage<5>(xr, xi, T, lane, addr32);
+  // bit reversal: X[n] sits in lane bitrev6(n) (the table T->bitrev6 holds the same numbers; two VALU instructions instead of a load)
+  const int src4 = (int)(__builtin_bitreverse32((unsigned)lane) >> 26) << 2;
+  int rl = __double2loint(xr), rh = __double2hiint(xr), il = __double2loint(xi), ih = __double2hiint(xi);
+  rl = __builtin_amdgcn_ds_bpermute(src4, rl); rh = __builtin_amdgcn_ds_bpermute(src4, rh);
+  il = __builtin_amdgcn_ds_bpermute(src4, il); ih = __builtin_amdgcn_ds_bpermute(src4, ih);
+  return make_double2(__hiloint2double(rh, rl), __hiloint2double(ih, il));
 }
 __device__ __forceinline__ double2 wave_fft64_d(double xr, double xi, const DevTables* __restrict__ T) { return wave_fft64_d(xr, xi, T, lane_id()); }
 // (lane passed in: a kernel that transforms in a loop hands over an opaque copy of its lane index, otherwise the per-lane twiddle
