@@ -583,12 +583,23 @@ __device__ __forceinline__ void publish_llr_stats(bool bad, float neg, int ncbps
 // bin (tag "chan" for legacy packets, k_classify's HT / VHT estimate otherwise) -> equalise, common pilot phase, LLRs scattered
 // through the de-interleave map into out[0 .. ncbps).  legacyChanUpdate demod_impl.cc:507-539, nonLegacyChanUpdate :413-447
 // (== the nSS = 1 branches of demod2), pilotShift :549-557 (base patterns cloud80211phy.cc:170-174).
+// position of this lane's subcarrier in the q[] order of the packet's format, -1 for the null and pilot subcarriers (a kernel that
+// demodulates many symbols of one packet computes it once: the nested range tests cost ~11 VALU instructions and a screen of scalar
+// branches per symbol)
+__device__ __forceinline__ int data_carrier_index(const c8p_pkt_tags& t, int lane)
+{
+  if (t.format == C8P_F_L) return (!is_null_l(lane) && !is_pilot(lane)) ? qidx_l(lane) : -1;
+  return (!is_null_nl(lane) && !is_pilot(lane)) ? qidx_nl(lane) : -1;
+}
+// jq: data_carrier_index() of this lane if the caller has it (>= -1), C8P_JQ_COMPUTE otherwise
+#define C8P_JQ_COMPUTE (-2)
 __device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int lane, cf f1, cf Hl, const DevTables* __restrict__ T,
-                                              float* __restrict__ out, float& neg)
+                                              float* __restrict__ out, float& neg, int jq = C8P_JQ_COMPUTE)
 {
   const int nb = t.nbpscs, mi = nbpsc_index(nb);
   const cf sig = cdiv(f1, Hl);
   bool bad = false;
+  if (jq == C8P_JQ_COMPUTE) jq = data_carrier_index(t, lane);
   if (t.format == C8P_F_L) {
     const float Pp = T->pilotP[(1 + s) % 127];
     cf acc = cmulf(cmulf(shfl_c(sig, 7), 1.0f), Pp);
@@ -597,9 +608,9 @@ __device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int 
     acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), 1.0f), Pp));
     const cf ps = cconj(acc);
     const float pa = cabs_(ps);
-    if (!is_null_l(lane) && !is_pilot(lane)) {
+    if (jq >= 0) {
       const cf q = cdivf(cmul(sig, ps), pa);
-      bad = llr_scatter_nb(nb, q, qidx_l(lane), T->deintL[mi], out, neg);
+      bad = llr_scatter_nb(nb, q, jq, T->deintL[mi], out, neg);
     }
     return bad;
   }
@@ -618,9 +629,9 @@ __device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int 
   acc = cadd(acc, cmulf(cmulf(shfl_c(sig, 57), pa_[1]), Pp));
   const cf ps = cconj(acc);
   const float pa = cabs_(ps);
-  if (!is_null_nl(lane) && !is_pilot(lane)) {
+  if (jq >= 0) {
     const cf q = cdivf(cmul(sig, ps), pa);
-    bad = llr_scatter_nb(nb, q, qidx_nl(lane), T->deintNL[mi], out, neg);
+    bad = llr_scatter_nb(nb, q, jq, T->deintNL[mi], out, neg);
   }
   return bad;
 }
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   {
     unsigned init0, flip0;
     lean_int_consts(lane, init0, flip0);
-    parkK[wv][lane] = make_uint4(kbits, init0, flip0, 0u);
+    parkK[wv][lane] = make_uint4(kbits, init0, flip0, (unsigned)data_carrier_index(t, lane));
   }
   LeanState S;
   lean_init(S, lane);
@@ -1146,7 +1157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
       const cf f1 = wave_fft64(xin, T, lane_s);
       float neg = 0.0f;
-      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg);
+      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile unsigned*)&parkK[wv][lane_s].w);
       have += t.ncbps;
       xin = xnext;
       s++;
