@@ -1157,7 +1157,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
       const cf f1 = wave_fft64(xin, T, lane_s);
       float neg = 0.0f;
-      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile unsigned*)&parkK[wv][lane_s].w);
+      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile __attribute__((address_space(3))) unsigned*)&parkK[wv][lane_s].w);   // (address space spelled out: a
+                                                                        // generic volatile pointer becomes a FLAT load)
       have += t.ncbps;
       xin = xnext;
       s++;
@@ -1182,10 +1183,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       parkX[wv][lane_d] = xin;
       asm volatile("; next sample parked" : "=v"(xin.x), "=v"(xin.y));
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 kc = *(volatile u32x4*)&parkK[wv][lane_d];   // (volatile: read here, every time — not hoisted and kept in registers)
+      const u32x4 kc = *(volatile __attribute__((address_space(3))) u32x4*)&parkK[wv][lane_d];   // (volatile: read here, every time —
+                                                                        // not hoisted and kept in registers)
       const unsigned init = kc.y, flip = kc.z;
       LeanK K[6];
-      lean_k_unpack(kc.x, lane_d, K);
+      lean_k_unpack<false>(kc.x, lane_d, K);          // (the float step's class masks are made where a float block runs)
       const float bound = lean_bound(negb);
       const int upto = done + nb;
       switch (t.cr) {

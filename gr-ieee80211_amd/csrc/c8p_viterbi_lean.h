@@ -251,6 +251,7 @@ __device__ __forceinline__ unsigned lean_k_pack(const LeanK (&K)[6])
             (K[q].b.y != 0.0f ? 8u : 0u) << (4 * q);
   return bits;
 }
+template <bool WITH_CLS = true>
 __device__ __forceinline__ void lean_k_unpack(unsigned bits, int lane, LeanK (&K)[6])
 {
 #pragma unroll
@@ -260,7 +261,7 @@ __device__ __forceinline__ void lean_k_unpack(unsigned bits, int lane, LeanK (&K
                  __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 1, 1) & 0x3f800000u)};
     K[q].b = v2f{__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 2, 1) & 0x3f800000u),
                  __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)bits, 4 * q + 3, 1) & 0x3f800000u)};
-    K[q].cls = ((lane >> q) & 1) ? C8P_CLS_NEG : C8P_CLS_POS;
+    K[q].cls = WITH_CLS ? (((lane >> q) & 1) ? C8P_CLS_NEG : C8P_CLS_POS) : 0;
   }
 }
 
@@ -407,7 +408,15 @@ __device__ __forceinline__ void lean_blocks_l(LeanState& S, const LeanK (&K)[6],
       segc = sc; left = lf;
       if (left == 0) break;
     }
-    lean_block_flt_lds<CR>(S.pre, S.acc, K, la + (unsigned)((n0 - left) * NLB * 4));
+    {
+      // the class masks of the float step (phases 0..3), made here: the caller's constants come without them (24 coefficients are
+      // unpacked every round, the masks are only needed by the ~5 % of blocks that take this path)
+      const int lf = lane_fresh();                       // (not `lane`: the masks would be hoisted back out of this branch)
+      LeanK Kf[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { Kf[q].a = K[q].a; Kf[q].b = K[q].b; Kf[q].cls = ((lf >> q) & 1) ? C8P_CLS_NEG : C8P_CLS_POS; }
+      lean_block_flt_lds<CR>(S.pre, S.acc, Kf, la + (unsigned)((n0 - left) * NLB * 4));
+    }
     unsigned word = S.acc & ~(C8P_SV_HINT | 0x80000000u);
     if (++segc >= segn) {
       float m = S.pre;
