@@ -591,15 +591,15 @@ __device__ __forceinline__ int data_carrier_index(const c8p_pkt_tags& t, int lan
   if (t.format == C8P_F_L) return (!is_null_l(lane) && !is_pilot(lane)) ? qidx_l(lane) : -1;
   return (!is_null_nl(lane) && !is_pilot(lane)) ? qidx_nl(lane) : -1;
 }
-// jq: data_carrier_index() of this lane if the caller has it (>= -1), C8P_JQ_COMPUTE otherwise
-#define C8P_JQ_COMPUTE (-2)
+// HAVE_JQ: the caller hands over data_carrier_index() of this lane in jq
+template <bool HAVE_JQ = false>
 __device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int lane, cf f1, cf Hl, const DevTables* __restrict__ T,
-                                              float* __restrict__ out, float& neg, int jq = C8P_JQ_COMPUTE)
+                                              float* __restrict__ out, float& neg, int jq = 0)
 {
   const int nb = t.nbpscs, mi = nbpsc_index(nb);
   const cf sig = cdiv(f1, Hl);
   bool bad = false;
-  if (jq == C8P_JQ_COMPUTE) jq = data_carrier_index(t, lane);
+  if (!HAVE_JQ) jq = data_carrier_index(t, lane);
   if (t.format == C8P_F_L) {
     const float Pp = T->pilotP[(1 + s) % 127];
     cf acc = cmulf(cmulf(shfl_c(sig, 7), 1.0f), Pp);
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       asm volatile("" : "+v"(Hs.x), "+v"(Hs.y));
       const cf f1 = wave_fft64(xin, T, lane_s);
       float neg = 0.0f;
-      const bool bad = demod_sym_1ss(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile __attribute__((address_space(3))) unsigned*)&parkK[wv][lane_s].w);   // (address space spelled out: a
+      const bool bad = demod_sym_1ss<true>(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile __attribute__((address_space(3))) unsigned*)&parkK[wv][lane_s].w);   // (address space spelled out: a
                                                                         // generic volatile pointer becomes a FLAT load)
       have += t.ncbps;
       xin = xnext;
