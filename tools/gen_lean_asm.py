@@ -491,6 +491,10 @@ template <> __device__ __forceinline__ void lean_block_flt_lds<%d>(float& pre, u
     add("v_mov_b32 v63, %[init]")
     add("v_mov_b32 v%d, %%[llr]" % VA)
     add("s_mov_b32 %s, %%[nblk]" % cnt)
+    # the survivor stores go through an SGPR base that the scalar unit advances by 256 bytes per block: v50 (this lane's offset)
+    # stands still inside the loop and is brought up to date once, at the end
+    add("s_mov_b64 s[%d:%d], %%[sv]" % (PTR, PTR + 1))
+    add("s_mov_b32 s%d, 0" % (PTR + 2))
     add("s_mov_b32 vcc_lo, 0x55555555")
     add("s_mov_b32 vcc_hi, 0x55555555")
     for g in range(NS):
@@ -521,8 +525,10 @@ template <> __device__ __forceinline__ void lean_block_flt_lds<%d>(float& pre, u
     add("s_mov_b64 vcc, s[%d:%d]" % (PTR + 8, PTR + 9))
     add("v_or_b32 v63, v52, v63")
     add("5:")
-    add("global_store_dword v50, v63, %[sv]")
-    add("v_add_u32 v50, 0x100, v50")
+    add("global_store_dword v50, v63, s[%d:%d]" % (PTR, PTR + 1))
+    add("s_add_u32 s%d, s%d, 0x100" % (PTR, PTR))
+    add("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
+    add("s_add_u32 s%d, s%d, 0x100" % (PTR + 2, PTR + 2))
     add("v_mov_b32 v63, %[init]")
     add("v_cmp_gt_f32_e64 %s, %%[bound], v62" % chk)
     add("s_cmp_eq_u32 %s, 0" % cnt)
@@ -531,11 +537,12 @@ template <> __device__ __forceinline__ void lean_block_flt_lds<%d>(float& pre, u
     add("s_cbranch_scc1 1b")
     add("2:")
     add("s_waitcnt lgkmcnt(0)")
+    add("v_add_u32 v50, s%d, v50" % (PTR + 2))
     add("s_mov_b32 %%[nblk], %s" % cnt)
     n_valu = sum(1 for (x, rd) in body if x.startswith("v_"))
     text = "\n".join('      "%s\\n\\t"' % x for x in L)
     fixed = (50, 62, 63)
-    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(4, 11)] + ['"v%d"' % r for r in range(VA, 64) if r not in fixed]
+    clob = ['"vcc"', '"scc"', '"memory"'] + ['"s%d"' % (PTR + i) for i in range(0, 11)] + ['"v%d"' % r for r in range(VA, 64) if r not in fixed]
     ins = ['[ka%d] "v"(K[%d].a)' % (q, q) for q in range(6)] + ['[kb%d] "v"(K[%d].b)' % (q, q) for q in range(6)]
     ins += ['[init] "v"(init)', '[flip] "v"(flip)', '[bound] "s"(bound)', '[segn] "s"(segn)', '[llr] "s"(llr)', '[sv] "s"(sv)']
     return """
