@@ -277,7 +277,8 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
   if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
   c8p_ctx* c = new c8p_ctx();
   c->device = cfg->device; c->profile = cfg->profile < 0 ? 0 : cfg->profile; c->keep_bits = cfg->keep_bits;
-  { const char* e = getenv("C8P_RX_LLR"); c->keep_llr = e ? atoi(e) != 0 : cfg->keep_llr != 0; }   // (the env switch: A/B runs)
+  c->keep_llr = cfg->keep_llr == 2 ? 2 : cfg->keep_llr != 0;
+  { const char* e = getenv("C8P_RX_LLR"); if (e && atoi(e) > 0 && !c->keep_llr) c->keep_llr = atoi(e) == 2 ? 2 : 1; }   // (A/B runs: the env switch can only turn the LLRs ON)
   { const char* e = getenv("C8P_EXACT_VITERBI"); c->exact_only = (e && e[0] == '1') ? 1 : 0; }
   {
     // a caller-provided stream means strict stream order: one slot.  Otherwise C8P_SLOTS (default 3) engine-owned streams.
@@ -397,9 +398,10 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // c8p_rx hands over what the fused single-stream kernel needs (k_rx_1ss); c8p_decode passes nullptr
 struct RxFuse { const c8p_pkt_in* d_pk; const cf* d_iq; const cf* d_chan; bool any_2ant; };
+// d_cold: the FinCold record of this submit (device memory)
 
 static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
-                              const cf* d_mu, const Plan& P, const RxFuse* rx)
+                              const cf* d_mu, const Plan& P, const RxFuse* rx, const FinCold* d_cold)
 {
   const bool flags_ready = rx != nullptr;
   int rc;
@@ -412,22 +414,23 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->s->d_flags.p;
   hipStream_t dst = c->s->stream, fst = c->s->stream;
   {
-    // forward pass: lean kernel for every packet whose LLRs passed the range check, clamp-exact kernel for the rest
-    std::unique_ptr<KTimer> kt(new KTimer(c, C8P_K_VITERBI, dst));
+    // forward pass: lean kernels for every packet whose LLRs passed the range check; the rest is left to k_finish (viterbi_fwd_exact)
+    KTimer kt(c, C8P_K_VITERBI, dst);
     if (!c->exact_only) {
       if (!flags_ready)
         hipLaunchKernelGGL(k_llr_check, dim3(n), dim3(64), 0, dst, d_tags, d_llr, (uint32_t*)c->s->d_flags.p, n);
-      // c8p_rx: single-stream packets are demodulated AND decoded by k_rx_1ss; two-stream packets (only possible with two antennas)
-      // went through k_demod_sym and are decoded by k_viterbi_lean, as every packet of a c8p_decode batch is
-      if (rx && c->keep_llr)
+      // c8p_rx: a packet is demodulated AND decoded by one wave of k_rx_1ss_lds / k_rx_2ss_lds (LLRs through LDS).  keep_llr = 1, the
+      // arena flavour: k_rx_1ss for one stream, k_demod_sym + k_viterbi_lean for two (as every packet of a c8p_decode batch)
+      if (rx && c->keep_llr == 1) {
         hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
-                           d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, 0);
-      else if (rx) {     // the LLR stream stays in LDS; what the lean decoder cannot take is demodulated once more, into the arena
-        hipLaunchKernelGGL(k_rx_1ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
                            d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
-        if (!rx->any_2ant) kt.reset();   // the forward pass ends here for the events: the nearly empty launches below (2 us each) are not it
-        hipLaunchKernelGGL(k_rx_1ss, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
-                           d_tags, (const cf*)c->s->d_H.p, (float*)c->s->d_llr.p, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, 1);
+      } else if (rx) {   // the LLR stream stays in LDS; what the lean decoder cannot take is flagged and left to k_finish
+        float* tap = c->keep_llr == 2 ? (float*)c->s->d_llr.p : nullptr;     // the parity tests' view of the on-chip LLRs
+        hipLaunchKernelGGL(k_rx_1ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
+                           d_tags, (const cf*)c->s->d_H.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+        if (rx->any_2ant)
+          hipLaunchKernelGGL(k_rx_2ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, d_lay, (const DevTables*)c->d_tab,
+                             d_tags, (const Mimo*)c->s->d_mimo.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
       }
       // c8p_decode: quads of packets with the same rate and length can go through the four-packets-per-wave kernel (17 % fewer VALU
       // instructions per packet, but 4 x fewer waves): it wins when one batch alone gives every SIMD several of its fat waves —
@@ -455,11 +458,10 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
         hipLaunchKernelGGL(k_viterbi_lean_lds, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                            (uint32_t*)c->s->d_flags.p, d2, n);
       }
-      else if (!rx || rx->any_2ant)
+      else if (!rx || (rx->any_2ant && c->keep_llr == 1))    // (c8p_rx, arena flavour: two-stream packets came through k_demod_sym)
         hipLaunchKernelGGL(k_viterbi_lean, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                            (uint32_t*)c->s->d_flags.p, rx ? (const float*)c->s->d_negsym.p : nullptr, rx ? rx->d_pk : nullptr, d_done4, n);
     }
-    hipLaunchKernelGGL(k_viterbi_fwd, dim3(n), dim3(64), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p, d_flags, n);
   }
   {
     KTimer kt(c, C8P_K_FINISH, fst);
@@ -467,9 +469,11 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
     for (const PktLayout& L : P.lay) tmax = L.trellis_cap > tmax ? L.trellis_cap : tmax;
     uint32_t snap_bytes = ((tmax + 5u) / 6u + 2u + 15u) & ~15u;      // one byte per 6-step group; afterwards the 1 KB CRC table
     if (snap_bytes < 1024u) snap_bytes = 1024u;
-    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), snap_bytes, fst, d_tags, d_lay, (const ulonglong2*)c->s->d_surv.p, d_mu,
+    hipLaunchKernelGGL(k_finish, dim3(n), dim3(64), snap_bytes, fst, d_tags, d_lay, (ulonglong2*)c->s->d_surv.p, d_mu,
                        (const DevTables*)c->d_tab, (c8p_pkt_out*)c->s->d_outs.p, (uint8_t*)c->s->d_pdu.p, (uint8_t*)c->s->d_bits.p,
-                       (uint8_t*)c->s->d_sbits.p, d_flags, c->keep_bits, n);
+                       (uint8_t*)c->s->d_sbits.p, d_flags, c->keep_bits, n,
+                       // (packets the lean kernels left: forward pass inside k_finish; the on-chip kernels of c8p_rx left them undemodulated)
+                       (rx && c->keep_llr != 1 && !c->exact_only ? C8P_FIN_REDEMOD : 0) | (rx && c->keep_llr == 2 && !c->exact_only ? C8P_FIN_TAP : 0), d_cold);
   }
   HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_OUT] = sizeof(c8p_pkt_out) * (size_t)n; c->s->ptr[C8P_BUF_OUT] = c->s->d_outs.p;
@@ -499,19 +503,11 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   int rc = plan_demod(c, in, P);
   if (rc != C8P_OK) return rc;
 
-  // descriptors + layout in one pinned staging copy
-  const size_t o_pk = 0, o_lay = align256(o_pk + sizeof(c8p_pkt_in) * (size_t)n);
-  const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  // descriptors + layout (+ the record k_finish's cold path reads) in one pinned staging copy
+  const size_t o_pk = 0, o_lay = align256(o_pk + sizeof(c8p_pkt_in) * (size_t)n), o_cold = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  const size_t stage_bytes = align256(o_cold + sizeof(FinCold));
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
-  // (the slot's stream was synchronised when the slot was taken, and nothing has been enqueued on it since: the previous submit's
-  // asynchronous copy out of the pinned buffer has finished)
-  memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
-  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
-  {
-    KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
-  }
   const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
 
@@ -532,6 +528,18 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_sym2pkt, sizeof(uint32_t) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_negsym, sizeof(float) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
+  // (the slot's stream was synchronised when the slot was taken, and nothing but the uploads above has been enqueued on it since: the
+  // previous submit's asynchronous copy out of the pinned buffer has finished)
+  memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  {
+    const FinCold fc = {d_pk, d_iq, d_chan, (const cf*)c->s->d_H.p, (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p};
+    memcpy((char*)c->s->h_stage + o_cold, &fc, sizeof(fc));
+  }
+  {
+    KTimer kt(c, C8P_K_LAYOUT);
+    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+  }
 
   {
     KTimer kt(c, C8P_K_CLASSIFY);
@@ -542,7 +550,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   bool any_2ant = false;
   for (int p = 0; p < n; p++) any_2ant |= in->pkts[p].n_ant == 2;
   const bool fused = with_decode && !c->exact_only;      // C8P_EXACT_VITERBI: plain demodulation, the clamp-exact decoder for everything
-  if (!fused || any_2ant) {             // c8p_rx: only the two-stream packets (single-stream ones belong to k_rx_1ss)
+  if (!fused || (any_2ant && c->keep_llr == 1)) {   // c8p_rx, arena flavour: only the two-stream packets (single-stream ones belong to k_rx_1ss)
     KTimer kt(c, C8P_K_DEMOD);
     hipLaunchKernelGGL(k_demod_sym, dim3((P.syms + 3) / 4), dim3(256), 0, c->s->stream, d_pk, d_iq, d_chan, (const uint32_t*)c->s->d_sym2pkt.p, d_lay,
                        (const DevTables*)c->d_tab, (const c8p_pkt_tags*)c->s->d_tags.p, (const cf*)c->s->d_H.p,
@@ -553,10 +561,12 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = c->s->d_tags.p;
   // (c8p_rx without keep_llr: the fused kernel keeps the LLRs in LDS, the arena only holds what the exceptions needed)
   c->s->used[C8P_BUF_LLR] = (fused && !c->keep_llr) ? 0 : sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
+  // (keep_llr = 2, the tap: the kernels do not write the padding between two packets' LLR areas, and the tests read only the areas)
   c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
   if (!with_decode) return C8P_OK;
   const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant};
-  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, &rx);
+  return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, &rx,
+                            (const FinCold*)((char*)c->s->d_stage.p + o_cold));
 }
 
 extern "C" int c8p_demod(c8p_ctx* c, const c8p_batch_in* in) { return submit_demod(c, in, false); }
@@ -580,16 +590,10 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   Plan P;
   int rc = plan_decode(c, in, P);
   if (rc != C8P_OK) return rc;
-  const size_t o_tg = 0, o_lay = align256(sizeof(c8p_pkt_tags) * (size_t)n);
-  const size_t stage_bytes = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  const size_t o_tg = 0, o_lay = align256(sizeof(c8p_pkt_tags) * (size_t)n), o_cold = align256(o_lay + sizeof(PktLayout) * (size_t)n);
+  const size_t stage_bytes = align256(o_cold + sizeof(FinCold));
   if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
-  memcpy((char*)c->s->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
-  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
-  {
-    KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
-  }
   const c8p_pkt_tags* d_tags = (const c8p_pkt_tags*)((char*)c->s->d_stage.p + o_tg);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
   const float* d_llr = in->llr;
@@ -609,8 +613,18 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
     HIPCHK(c, hipMemsetAsync(c->s->d_mu_in.p, 0, sizeof(cf) * 128 * (size_t)n, c->s->stream));
     d_mu = (const cf*)c->s->d_mu_in.p;
   }
+  memcpy((char*)c->s->h_stage + o_tg, in->tags, sizeof(c8p_pkt_tags) * (size_t)n);
+  memcpy((char*)c->s->h_stage + o_lay, P.lay.data(), sizeof(PktLayout) * (size_t)n);
+  {
+    const FinCold fc = {nullptr, nullptr, nullptr, nullptr, nullptr, (float*)d_llr};      // (k_finish only READS the caller's LLRs)
+    memcpy((char*)c->s->h_stage + o_cold, &fc, sizeof(fc));
+  }
+  {
+    KTimer kt(c, C8P_K_LAYOUT);
+    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+  }
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = d_tags;
-  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, nullptr);
+  return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, nullptr, (const FinCold*)((char*)c->s->d_stage.p + o_cold));
 }
 
 extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)

@@ -3,7 +3,8 @@
 //   (arena layout is computed on the host from the descriptors and uploaded with them)
 //   k_classify    wave / packet   format detection, SIG decode, channel estimate, SIG-B  (demod_impl.cc:106-219)
 //   k_demod_sym   wave / symbol   FFT -> equalise -> pilot phase -> LLR -> de-interleave  (demod_impl.cc:279-314)
-//   k_viterbi_fwd wave / packet   depuncture + 64-state ACS, lane = next state, survivors as ballot words
+//   k_rx_1ss_lds / k_rx_2ss_lds   wave / packet   c8p_rx: symbol demodulation + lean forward pass, LLRs through LDS
+//   k_viterbi_lean wave / packet  depuncture + 64-state ACS (c8p_viterbi_lean.h); viterbi_fwd_exact: the clamp-exact recurrence, inside k_finish
 //   k_finish      wave / packet   traceback, descramble, A-MPDU walk, CRC-32, PDU records (decode_impl.cc:282-520)
 //
 // Every kernel is a single-wave (64-lane) program per unit of work: lane = FFT bin in the demod kernels,
@@ -636,6 +637,54 @@ __device__ __forceinline__ bool demod_sym_1ss(const c8p_pkt_tags& t, int s, int 
   return bad;
 }
 
+// One OFDM data symbol of a two-stream packet received on two antennas: FFT outputs f1 / f2 of this lane's bin on antenna 0 / 1, the
+// bin's channel H4 and (H^H H)^-1 INV4 (k_classify's Mimo record; M also holds the LTF pilot references) -> zero-forcing, the 8-term
+// common pilot phase, both streams' LLRs scattered through the de-interleave maps fused with the stream de-parser into out[0 .. ncbps).
+// htChanUpdate demod2_impl.cc:471-551 / vhtChanUpdate :553-630, pilotShift demod_impl.cc:549-557 (base patterns cloud80211phy.cc:170-174).
+template <bool HAVE_JQ = false>
+__device__ __forceinline__ bool demod_sym_2ss(const c8p_pkt_tags& t, int s, int lane, cf f1, cf f2, const cf (&H4)[4], const cf (&INV4)[4],
+                                              const Mimo* __restrict__ M, const DevTables* __restrict__ T, float* __restrict__ out, float& neg, int jq = 0)
+{
+  const float Pp = T->pilotP[((t.format == C8P_F_VHT ? 4 : 3) + s) % 127];
+  // pilot patterns rotated left by s
+  float pa_[4], pb_[4];
+  {
+    const bool ht2 = t.format == C8P_F_HT;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int kk = (k + s) & 3;
+      // (selected as bit patterns: the values are wave-uniform and stay in SGPRs; as float selects they took 8 VGPRs)
+      const uint32_t l4 = kk == 3 ? 0xbf800000u : 0x3f800000u;               // {1,1,1,-1}
+      const uint32_t h21 = kk >= 2 ? 0xbf800000u : 0x3f800000u;              // {1,1,-1,-1}
+      const uint32_t h22 = (kk == 1 || kk == 2) ? 0xbf800000u : 0x3f800000u; // {1,-1,-1,1}
+      pa_[k] = __uint_as_float(ht2 ? h21 : l4);
+      pb_[k] = __uint_as_float((t.format == C8P_F_VHT) ? l4 : h22);
+    }
+  }
+  const int nb = t.nbpscs, mi = nbpsc_index(nb);
+  cf s1, s2;
+  zf_2x2(f1, f2, H4, INV4, s1, s2);
+  cf acc = cmul(cmulf(cmulf(shfl_c(s1, 7), pa_[2]), Pp), M->pil1[2]);
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 21), pa_[3]), Pp), M->pil1[3]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 43), pa_[0]), Pp), M->pil1[0]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 57), pa_[1]), Pp), M->pil1[1]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 7), pb_[2]), Pp), M->pil2[2]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 21), pb_[3]), Pp), M->pil2[3]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 43), pb_[0]), Pp), M->pil2[0]));
+  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 57), pb_[1]), Pp), M->pil2[1]));
+  const cf ps = cconj(acc);
+  const float pa = cabs_(ps);
+  if (!HAVE_JQ) jq = (!is_null_nl(lane) && !is_pilot(lane)) ? qidx_nl(lane) : -1;
+  bool bad = false;
+  if (jq >= 0) {
+    const cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
+    const bool b1 = llr_scatter_nb(nb, qa, jq, T->deint2ss[0][mi], out, neg);
+    const bool b2 = llr_scatter_nb(nb, qb, jq, T->deint2ss[1][mi], out, neg);
+    bad = b1 || b2;
+  }
+  return bad;
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_demod_sym(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                    const cf* __restrict__ chan, const uint32_t* __restrict__ sym2pkt,
                                                    const PktLayout* __restrict__ lay, const DevTables* __restrict__ T, const c8p_pkt_tags* __restrict__ tags,
@@ -673,24 +722,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     return;
   }
 
-  const float Pp = T->pilotP[((t.format == C8P_F_VHT ? 4 : 3) + s) % 127];
-  // pilot patterns rotated left by s (pilotShift demod_impl.cc:549-557); base patterns cloud80211phy.cc:170-174
-  float pa_[4], pb_[4];
-  {
-    const bool ht2 = t.format == C8P_F_HT;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int kk = (k + s) & 3;
-      // (selected as bit patterns: the values are wave-uniform and stay in SGPRs; as float selects they took 8 VGPRs)
-      const uint32_t l4 = kk == 3 ? 0xbf800000u : 0x3f800000u;               // {1,1,1,-1}
-      const uint32_t h21 = kk >= 2 ? 0xbf800000u : 0x3f800000u;              // {1,1,-1,-1}
-      const uint32_t h22 = (kk == 1 || kk == 2) ? 0xbf800000u : 0x3f800000u; // {1,-1,-1,1}
-      pa_[k] = __uint_as_float(ht2 ? h21 : l4);
-      pb_[k] = __uint_as_float((t.format == C8P_F_VHT) ? l4 : h22);
-    }
-  }
-  const int nb = t.nbpscs, mi = nbpsc_index(nb);
-
   // 2x2: htChanUpdate demod2_impl.cc:471-551 / vhtChanUpdate :553-630
   const cf* x2 = iq + P.iq_off[1] + t.data_off + s * t.nsymsamp + 8;
   cf f2 = wave_fft64(x2[lane], T);
@@ -698,25 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   cf H4[4], INV4[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) { H4[c] = M->H[lane][c]; INV4[c] = M->INV[lane][c]; }
-  cf s1, s2;
-  zf_2x2(f1, f2, H4, INV4, s1, s2);
-  cf acc = cmul(cmulf(cmulf(shfl_c(s1, 7), pa_[2]), Pp), M->pil1[2]);
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 21), pa_[3]), Pp), M->pil1[3]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 43), pa_[0]), Pp), M->pil1[0]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s1, 57), pa_[1]), Pp), M->pil1[1]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 7), pb_[2]), Pp), M->pil2[2]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 21), pb_[3]), Pp), M->pil2[3]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 43), pb_[0]), Pp), M->pil2[0]));
-  acc = cadd(acc, cmul(cmulf(cmulf(shfl_c(s2, 57), pb_[1]), Pp), M->pil2[1]));
-  cf ps = cconj(acc);
-  float pa = cabs_(ps);
-  if (!is_null_nl(lane) && !is_pilot(lane)) {
-    cf qa = cdivf(cmul(s1, ps), pa), qb = cdivf(cmul(s2, ps), pa);
-    const int j = qidx_nl(lane);
-    const bool b1 = llr_scatter_nb(nb, qa, j, T->deint2ss[0][mi], out, neg);
-    const bool b2 = llr_scatter_nb(nb, qb, j, T->deint2ss[1][mi], out, neg);
-    bad = b1 || b2;
-  }
+  bad = demod_sym_2ss(t, s, lane, f1, f2, H4, INV4, M, T, out, neg);
   publish_llr_stats(bad, neg, t.ncbps, flags, negsym, w, p);
 }
 
@@ -749,23 +762,16 @@ __device__ __forceinline__ bool decodable(const c8p_pkt_tags& t)   // decode_imp
          t.cr >= 0 && t.cr <= 3 && llr_needed(t.cr, t.trellis) <= t.total;
 }
 
-// One wave per packet, lane = next state.  Survivors: per step two ballot words
+// The clamp-exact recurrence, one wave per packet, lane = next state (decode_impl.cc:205-281 literally: clamp, NaN behaviour, his = 0
+// for untaken states).  Survivors: per step two ballot words
 //   .x bit n: the odd predecessor 2(n&31)+1 won            (v_state_his = 2m+1)
 //   .y bit n: neither candidate beat the -1e15 pre-fill   (v_state_his stays 0)
-__global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                                    const float* __restrict__ llr, ulonglong2* __restrict__ surv,
-                                                    const uint32_t* __restrict__ flags, int n)
+// Runs inside k_finish, for the packets the lean kernels left (range-check flag, C8P_EXACT_VITERBI=1).
+__device__ __forceinline__ void viterbi_fwd_exact(const c8p_pkt_tags& t, const float* __restrict__ L, ulonglong2* __restrict__ SV)
 {
-  const int p = blockIdx.x;
-  if (p >= n) return;
-  if (flags && flags[p] == 0) return;      // the lean kernel already produced exact survivors for this packet
-  const c8p_pkt_tags t = tags[p];
-  if (!decodable(t)) return;
   const int lane = lane_id();
   const int m = lane & 31, b = lane >> 5;
   const int cA = sv_out(2 * m, b), cB = sv_out(2 * m + 1, b);
-  const float* L = llr + t.llr_off;
-  ulonglong2* SV = surv + lay[p].surv_off;
   const int Tn = t.trellis;
   float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;
   for (int t0 = 0; t0 < Tn; t0 += 64) {
@@ -784,6 +790,38 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd(const c8p_pkt_tags* __restri
       W0 = writelane_u64(b0, l, W0);
     }
     if (ts < Tn) SV[ts] = make_ulonglong2(W1, W0);
+  }
+}
+
+// Every data symbol of one packet demodulated into its LLR area by ONE wave (what k_demod_sym spreads over a wave per symbol).  Runs
+// inside k_finish for the few packets whose LLRs are wanted in memory after all: the ones the on-chip kernels of c8p_rx flagged (an
+// LLR outside the lean decoder's range) and, with the tap (c8p_cfg.keep_llr = 2), the ones those kernels do not touch.
+__device__ __forceinline__ void redemod_packet(const c8p_pkt_in& P, const c8p_pkt_tags& t, int p, const cf* __restrict__ iq, const cf* __restrict__ chan,
+                                               const cf* __restrict__ Hin, const Mimo* __restrict__ mimo, const DevTables* __restrict__ T,
+                                               float* __restrict__ out, int s0 = 0)
+{
+  const int lane = lane_id();
+  if (t.is_ndp) {                                  // 1024 dummy items (demod_impl.cc:265-271), zero-filled
+    for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
+    return;
+  }
+  const bool two = P.n_ant == 2 && t.nss == 2;
+  const cf* x1 = iq + P.iq_off[0] + t.data_off + 8 + lane;
+  const cf* x2 = iq + P.iq_off[two ? 1 : 0] + t.data_off + 8 + lane;
+  const cf Hl = t.format == C8P_F_L ? chan[P.chan_off + lane] : Hin[(size_t)p * 64 + lane];
+  const Mimo* M = &mimo[p];
+#pragma unroll 1
+  for (int s = s0; s < t.nsym; s++) {
+    float neg = 0.0f;
+    const cf f1 = wave_fft64(x1[(size_t)s * t.nsymsamp], T);
+    if (!two) demod_sym_1ss(t, s, lane, f1, Hl, T, out + (size_t)s * t.ncbps, neg);
+    else {
+      const cf f2 = wave_fft64(x2[(size_t)s * t.nsymsamp], T);
+      cf H4[4], INV4[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { H4[c] = M->H[lane][c]; INV4[c] = M->INV[lane][c]; }
+      demod_sym_2ss(t, s, lane, f1, f2, H4, INV4, M, T, out + (size_t)s * t.ncbps, neg);
+    }
   }
 }
 
@@ -808,7 +846,7 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
 }
 
 // The fast path (c8p_viterbi_lean.h).  Packets whose LLR stream failed the range check (flags[p] != 0) are left to
-// k_viterbi_fwd, the clamp-exact recurrence.
+// viterbi_fwd_exact (inside k_finish), the clamp-exact recurrence.
 // 4 packets per 256-thread workgroup: the four waves of a workgroup land on the four SIMDs of one CU, which keeps the
 // 4096 equally long waves of a batch evenly spread (single-wave workgroups were observed to pile up on some SIMDs).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void k_viterbi_lean(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
@@ -967,17 +1005,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // (demod_impl.cc:279-314 -> decode_impl.cc:128-141, 205-281.)
 // Scalar-cache coherence: a 64-byte line is only ever read when all of it has been written (`safe` below) and waited for
 // (vmcnt(0): the vector stores are in L2); LLR areas start on 64-byte boundaries (plan_demod), so no line is shared by two packets.
-// A packet whose LLRs fail the range check, or that cannot be decoded, is demodulated to the end and left to k_viterbi_fwd.
+// A packet whose LLRs fail the range check, or that cannot be decoded, is demodulated to the end; k_finish runs the clamp-exact
+// forward pass of the flagged ones (viterbi_fwd_exact).
 // Registers: the decoder's per-lane state is parked in LDS while a symbol is demodulated and its 28 lane constants travel as one
 // packed word, so the kernel needs max(demodulator, decoder) + a few registers: 80 VGPRs, 6 waves per SIMD.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
-                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n, int only_flagged)
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
   if (p >= n) return;
-  if (only_flagged && flags[p] == 0) return;       // after k_rx_1ss_lds: demodulate what it left to the exact decoder
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   const c8p_pkt_in P = pk[p];
@@ -989,7 +1027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     for (int i = lane; i < C8P_NDP_TOTAL; i += 64) out[i] = 0.0f;
     return;
   }
-  bool ok = decodable(t) && !only_flagged;         // wave-uniform: this wave also decodes
+  bool ok = decodable(t);                          // wave-uniform: this wave also decodes
 #ifdef C8P_EXP_CLOCK   // experiment build (tools/exp_clock.py): shader cycles of this wave and where it ran, instead of the statistics
   const unsigned long long exp_t0 = clock64();
   unsigned exp_hw, exp_xcc;
@@ -1079,18 +1117,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #endif
 }
 
-// ---- the same with the LLR stream kept on chip (c8p_rx unless c8p_cfg.keep_llr: C8P_BUF_LLR is then NOT filled) -------------------
+// The tap of the on-chip kernels (c8p_cfg.keep_llr = 2; parity tests): the symbol's de-interleaved LLRs, as the wave's lanes just left
+// them in LDS, copied to the packet's LLR area before any block consumes them.  A kernel argument, not a second build of the kernel:
+// what the parity tests check (1e-5) comes out of the very code that c8p_rx runs by default.
+__device__ __forceinline__ void wave_lds_fence()   // LDS executes a wave's accesses in order; this only keeps the COMPILER from moving
+{                                                  // one lane's read above another lane's write
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_tap(float* __restrict__ dst, const float* src, int n)
+{
+  wave_lds_fence();
+  for (int i = lane_fresh(); i < n; i += 64) dst[i] = src[i];
+}
+
+// ---- the same with the LLR stream kept on chip (c8p_rx unless c8p_cfg.keep_llr == 1: C8P_BUF_LLR is then NOT filled) --------------
 // The wave scatters a symbol's de-interleaved LLRs into its own LDS buffer (behind what the last round left over), runs every
 // survivor block that is complete with the LLRs as VGPR operands (lean_blocks_lds: broadcast ds_read_b128 into a rotating set of 12
 // registers that only exist inside the block loop) and moves the < 60 left-over LLRs to the front.  Neither the 235 MB of LLR
 // stores nor their read-back (an EA read even when it hits L2, tools/probe_l2rw.hip) exist any more: 1.58 -> 1.1 GB per
 // 4096-packet step.  Buffer (C8P_LBUF floats): 59 left over + two 64-QAM symbols (one 256-QAM symbol = 416 LLRs).  A packet with an LLR outside the integer
-// loop's range is rare: the wave flags it and stops, a second launch of k_rx_1ss (only_flagged) demodulates the flagged packets
-// into the LLR arena and k_viterbi_fwd decodes them.  Symbols that only carry padding behind the last trellis step are not demodulated at all.
+// loop's range is rare: the wave flags it and stops; k_finish demodulates a flagged packet into the LLR arena (redemod_packet), runs the
+// clamp-exact forward pass and goes on with its traceback.  Symbols that only carry padding behind the last trellis step are not demodulated at all.
 #define C8P_LBUF 688
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
-                                                const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr,
+                                                const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr_tap,
                                                 ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
 {
   const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
@@ -1098,8 +1150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   const c8p_pkt_in P = pk[p];
-  if (P.n_ant == 2 && t.nss == 2) return;          // two streams: k_demod_sym + k_viterbi_lean
-  if (t.is_ndp || !decodable(t)) return;           // nothing to decode, and nobody reads the LLRs
+  if (P.n_ant == 2 && t.nss == 2) return;          // two streams: k_rx_2ss_lds
+  if (t.is_ndp || !decodable(t)) return;           // nothing to decode (with the tap, k_finish fills the LLR arena of these packets)
   const int lane = lane_id();
   const int segn = c8p_seg_blocks(t.trellis);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1159,11 +1211,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       float neg = 0.0f;
       const bool bad = demod_sym_1ss<true>(t, s, lane_s, f1, Hs, T, lb + have, neg, (int)*(volatile __attribute__((address_space(3))) unsigned*)&parkK[wv][lane_s].w);   // (address space spelled out: a
                                                                         // generic volatile pointer becomes a FLAT load)
+      if (llr_tap) lds_tap(llr_tap + t.llr_off + (uint32_t)(s * t.ncbps), lb + have, t.ncbps);   // c8p_cfg.keep_llr = 2 (parity tests)
       have += t.ncbps;
       xin = xnext;
       s++;
       if (__ballot(bad)) {                         // the exact decoder takes this packet; it wants the LLRs in memory:
-        if (lane_s == 0) flags[p] = 1u;            // k_rx_1ss (only_flagged) demodulates it once more, into the LLR arena
+        if (lane_s == 0) flags[p] = 1u;            // k_finish demodulates it once more, into the LLR arena
         return;
       }
       neg = wave_sum_lane63(neg);
@@ -1215,6 +1268,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lb, have, lane_t, Tn, sv); break;
     case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane_t, Tn, sv); break;
     default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane_t, Tn, sv); break;
+  }
+}
+
+// ---- two streams on two antennas (demod2's 2x2 path, BASELINE configs[2]) with the LLR stream kept on chip ------------------------
+// One wave per packet, as k_rx_1ss_lds: per OFDM symbol two FFTs (antenna 0 / 1), the bin's zero-forcing equaliser from k_classify's
+// Mimo record, the 8-term pilot phasor, two demaps scattered through the stream-1 / stream-2 de-interleave maps fused with the stream
+// de-parser (deint2ss) into the wave's LDS buffer, then lean_blocks_lds on the blocks that are complete.  (htChanUpdate
+// demod2_impl.cc:471-551, vhtChanUpdate :553-630, procSymDepasNL cloud80211phy.cc:2442, the loop :268-321.)  Before this kernel the
+// two-stream packets of c8p_rx went through k_demod_sym -> 114 KB of LLRs per packet through HBM and back -> k_viterbi_lean.
+// Registers and LDS: the Mimo record is 16 floats per lane — 4 KB per wave in LDS, read back with four ds_read_b128 per symbol — and
+// one 256-QAM symbol of two streams is 832 LLRs (+ up to 59 left over): 7.6 KB of LDS per wave, 30 KB per workgroup, i.e. at most
+// 5 workgroups per CU.  The kernel is therefore built for 4 waves per SIMD (128 VGPRs) and spends the registers that buys instead of
+// parking the decoder's state in LDS as the single-stream kernel has to.
+#define C8P_LBUF2 896
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rx_2ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
+                                                const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
+                                                const c8p_pkt_tags* __restrict__ tags, const Mimo* __restrict__ mimo, float* __restrict__ llr_tap,
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+{
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (p >= n) return;
+  const c8p_pkt_tags t = tags[p];
+  if (t.status != C8P_ST_OK) return;
+  const c8p_pkt_in P = pk[p];
+  if (!(P.n_ant == 2 && t.nss == 2)) return;       // one stream: k_rx_1ss_lds
+  if (t.is_ndp || !decodable(t)) return;
+  const int lane = lane_id();
+  const int segn = c8p_seg_blocks(t.trellis);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __shared__ float4 mim[4][4][64];                 // [wave][H0 H1 | H2 H3 | INV0 INV1 | INV2 INV3][lane]
+  __shared__ __attribute__((aligned(16))) float lbuf[4][C8P_LBUF2];
+  const Mimo* M = &mimo[p];
+  {
+    const float4* h = (const float4*)&M->H[lane][0];
+    const float4* v = (const float4*)&M->INV[lane][0];
+    mim[wv][0][lane] = h[0]; mim[wv][1][lane] = h[1];
+    mim[wv][2][lane] = v[0]; mim[wv][3][lane] = v[1];
+  }
+  const cf* x1 = iq + P.iq_off[0] + t.data_off + 8;               // wave-uniform; the lane is added per symbol
+  const cf* x2 = iq + P.iq_off[1] + t.data_off + 8;
+  unsigned* sv = (unsigned*)(surv + lay[p].surv_off);
+  unsigned kbits, init, flip;
+  {
+    LeanK K0[6];
+    lean_k_consts(lane, K0);
+    kbits = lean_k_pack(K0);
+    lean_int_consts(lane, init, flip);
+  }
+  const int jq = (!is_null_nl(lane) && !is_pilot(lane)) ? qidx_nl(lane) : -1;
+  LeanState S;
+  lean_init(S, lane);
+  const int Tn = t.trellis, nfull = Tn / C8P_SV_BLK;
+  const int nlb = t.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
+                  t.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
+  const unsigned nlb_inv = t.cr == C8P_CR_12 ? 1093u : t.cr == C8P_CR_23 ? 1457u : t.cr == C8P_CR_34 ? 1639u : 1821u;   // have / nlb for have < 1499
+  static_assert(C8P_LBUF2 < 1499, "nlb_inv");
+  const float wfac = __uint_as_float(t.ncbps >= C8P_NEGB_WINDOW ? 0x40000000u : 0x40400000u);   // 2 or 3
+  float negb = 0.0f;
+  int have = 0;
+  cf xa = x1[lane], xb = x2[lane];
+  float* const lb = lbuf[wv];
+  const int needed = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn));   // LLRs the trellis consumes; symbols behind them are padding
+  int s = 0;
+  while (s < t.nsym && s * t.ncbps < needed) {
+#pragma unroll 1
+    do {
+      const int lane = lane_fresh();               // (opaque per symbol: what depends only on the lane — FFT twiddle addresses, de-interleave
+                                                   // offsets of all five constellations — must not be hoisted and held across the decoder)
+      const uint32_t nx = (uint32_t)((s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp + lane);
+      const cf xna = x1[nx], xnb = x2[nx];          // the next symbol's samples: in flight during this one
+      const cf f1 = wave_fft64(xa, T, lane);
+      const cf f2 = wave_fft64(xb, T, lane_fresh());
+      cf H4[4], INV4[4];
+      {
+        const float4 a = mim[wv][0][lane], b = mim[wv][1][lane], c = mim[wv][2][lane], d = mim[wv][3][lane];
+        H4[0] = mk(a.x, a.y); H4[1] = mk(a.z, a.w); H4[2] = mk(b.x, b.y); H4[3] = mk(b.z, b.w);
+        INV4[0] = mk(c.x, c.y); INV4[1] = mk(c.z, c.w); INV4[2] = mk(d.x, d.y); INV4[3] = mk(d.z, d.w);
+      }
+      float neg = 0.0f;
+      const bool bad = demod_sym_2ss<true>(t, s, lane, f1, f2, H4, INV4, M, T, lb + have, neg, jq);
+      if (llr_tap) lds_tap(llr_tap + t.llr_off + (uint32_t)(s * t.ncbps), lb + have, t.ncbps);   // c8p_cfg.keep_llr = 2 (parity tests)
+      have += t.ncbps;
+      xa = xna; xb = xnb;
+      s++;
+      if (__ballot(bad)) {                         // an LLR outside the integer loop's range: k_finish takes the packet from the start
+        if (lane == 0) flags[p] = 1u;              // (demodulation into the LLR arena, clamp-exact forward pass)
+        return;
+      }
+      neg = wave_sum_lane63(neg);
+      negb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(
+          fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac))));
+    } while (s < t.nsym && s * t.ncbps < needed && have + t.ncbps <= C8P_LBUF2);
+    const int done = S.done;
+    int nb = (int)(((unsigned)have * nlb_inv) >> 16);   // have / nlb: complete blocks in the buffer
+    if (nb > nfull - done) nb = nfull - done;
+    if (nb > 0) {
+      wave_lds_fence();
+      LeanK K[6];
+      lean_k_unpack<false>(kbits, lane, K);
+      const float bound = lean_bound(negb);
+      const int upto = done + nb;
+      switch (t.cr) {
+        case C8P_CR_12: lean_blocks_l<C8P_CR_12>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        case C8P_CR_23: lean_blocks_l<C8P_CR_23>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        case C8P_CR_34: lean_blocks_l<C8P_CR_34>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+        default:        lean_blocks_l<C8P_CR_56>(S, K, init, flip, bound, lb, lane, sv, upto, segn); break;
+      }
+      const int used = nb * nlb;
+      have -= used;
+      for (int i = 0; i < have; i += 64) {         // what is left over moves to the front (one lane each, 64 per pass; reads before writes)
+        const float v = i + lane < have ? lb[used + i + lane] : 0.0f;
+        wave_lds_fence();
+        if (i + lane < have) lb[i + lane] = v;
+      }
+    }
+  }
+  if (lane == 0) { flags[n + p] = (uint32_t)S.nflt; flags[2 * n + p] = __float_as_uint(negb); }   // C8P_BUF_DECSTAT
+  wave_lds_fence();
+  LeanK K[6];
+  lean_k_unpack(kbits, lane, K);
+  switch (t.cr) {
+    case C8P_CR_12: lean_tail_l<C8P_CR_12>(S, K, lb, have, lane, Tn, sv); break;
+    case C8P_CR_23: lean_tail_l<C8P_CR_23>(S, K, lb, have, lane, Tn, sv); break;
+    case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane, Tn, sv); break;
+    default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane, Tn, sv); break;
   }
 }
 
@@ -1414,6 +1592,9 @@ __global__ __launch_bounds__(256) void k_viterbi_lean2_lds(const c8p_pkt_tags* _
 }
 
 // ================================================================================================ finish
+#define C8P_FIN_REDEMOD 1    // k_finish mode bits: flagged packets have no LLRs in memory yet (on-chip kernels of c8p_rx)
+#define C8P_FIN_TAP     2    //                     c8p_cfg.keep_llr = 2: also fill the LLR area of NDPs and packets that are not decoded
+struct FinCold { const c8p_pkt_in* pk; const cf* iq; const cf* chan; const cf* Hin; const Mimo* mimo; float* llr; };
 #define CRC_POLY 0xedb88320u
 __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b)   // a(x)*b(x) mod P, reflected
 {
@@ -1475,11 +1656,16 @@ __device__ __forceinline__ void emit_pdu(uint8_t* area, uint32_t cap, uint32_t& 
 }
 
 __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ tags, const PktLayout* __restrict__ lay,
-                                               const ulonglong2* __restrict__ surv, const cf* __restrict__ muchan,
+                                               ulonglong2* surv, const cf* __restrict__ muchan,
                                                const DevTables* __restrict__ T, c8p_pkt_out* __restrict__ outs,
                                                uint8_t* __restrict__ pdu, uint8_t* __restrict__ bits_o,
                                                uint8_t* __restrict__ sbits_o, const uint32_t* __restrict__ flags,
-                                               int keep_bits, int n)
+                                               int keep_bits, int n,
+                                               // the packets the lean kernels left: their forward pass runs here (viterbi_fwd_exact on the LLR area),
+                                               // after a demodulation into that area if the batch came through the on-chip kernels of c8p_rx
+                                               // (what that needs comes through a record in memory, read only on that path: as kernel
+                                               // arguments the seven values cost the traceback 25 spilled SGPRs)
+                                               int mode, const FinCold* __restrict__ cold)
 {
   constexpr int TS = 68;                                  // tile row stride in dwords (16-byte aligned rows, banks shifted by 4)
   // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
@@ -1501,6 +1687,24 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   uint32_t used = 0;
   int n_pdu = 0, n_fail = 0, tb_passes = 0;
 
+  if (mode != 0 && t.status == C8P_ST_OK) {
+    // LLRs that are wanted in memory and are not there yet: a packet the on-chip kernels flagged (C8P_FIN_REDEMOD: all of it, for the
+    // clamp-exact forward pass below) and, with the tap (C8P_FIN_TAP), what those kernels skip — NDPs, packets that are not decoded,
+    // the symbols that only carry padding behind the last trellis step
+    const bool dec = decodable(t);
+    const bool left = dec && !(flags && flags[p] == 0);
+    int s0 = -1;
+    if (left) s0 = (mode & C8P_FIN_REDEMOD) ? 0 : -1;
+    else if (mode & C8P_FIN_TAP) {
+      s0 = dec ? (llr_needed(t.cr, t.trellis) + t.ncbps - 1) / t.ncbps : 0;
+      if (dec && s0 >= t.nsym) s0 = -1;
+    }
+    if (s0 >= 0) {
+      const FinCold C = *cold;
+      redemod_packet(C.pk[p], t, p, C.iq, C.chan, C.Hin, C.mimo, T, C.llr + t.llr_off, s0);
+      __threadfence();                                     // this wave's LLR stores before its own loads through other lanes
+    }
+  }
   if (t.status == C8P_ST_OK && t.len <= C8P_DECODE_B_MAX && t.trellis <= C8P_DECODE_T_MAX && t.trellis == 0) {
     // NDP channel report (decode_impl.cc:100-121)
     const uint32_t nb = C8P_NDP_BLOB_BYTES;
@@ -1624,6 +1828,9 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         bw[c] = word;
       }
     } else {
+    // ---- a packet the lean kernels left: the clamp-exact forward pass, here
+    viterbi_fwd_exact(t, cold->llr + t.llr_off, surv + Lp.surv_off);
+    __threadfence();
     // ---- traceback from state 0 (vstb_end decode_impl.cc:282-302)
     int st = 0;
     for (int c = nch - 1; c >= 0; c--) {

@@ -99,6 +99,8 @@ class DevArray:
 
 class Engine:
     def __init__(self, device=0, profile=False, keep_bits=False, stream=None, keep_llr=False):
+        """keep_llr (c8p_rx): False / 0 = the LLR stream stays on chip, True / 1 = it goes through C8P_BUF_LLR (k_rx_1ss), 2 = on chip with a
+        copy of every symbol's LLRs written to C8P_BUF_LLR on the way (the parity tests' view of the default kernels)"""
         self.L = load_library()
         cfg = abi.Cfg(abi.ABI_VERSION, device, int(profile), int(keep_bits), stream, int(keep_llr))
         self.ctx = self.L.c8p_create(C.byref(cfg))

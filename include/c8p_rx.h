@@ -236,8 +236,10 @@ typedef struct c8p_cfg {
   int32_t keep_bits;        /* 1: also store descrambled bits (v_unCodedBits) and v_scramBits          */
   void*   stream;           /* hipStream_t to launch on; NULL = engine-owned stream                    */
   int32_t keep_llr;         /* c8p_rx only.  0: the LLR stream stays on chip (the wave that demodulates a packet decodes it out of
-                               LDS) and C8P_BUF_LLR is EMPTY after c8p_rx; 1: c8p_rx also leaves the LLR stream in C8P_BUF_LLR, as
-                               c8p_demod always does (costs 0.47 GB of HBM traffic per 4096 cfg-2 packets)                      */
+                               LDS) and C8P_BUF_LLR is EMPTY after c8p_rx; 1: the LLR stream goes through C8P_BUF_LLR, as c8p_demod
+                               always leaves it (other kernels; costs 0.47 GB of HBM traffic per 4096 cfg-2 packets); 2: the
+                               on-chip kernels of 0, which additionally copy every symbol's LLRs out of LDS into C8P_BUF_LLR
+                               before they are consumed — how the parity tests see the LLRs of the default path           */
 } c8p_cfg;
 
 typedef struct c8p_batch_in {

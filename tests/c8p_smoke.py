@@ -16,7 +16,7 @@ def compare(res, ref, llr_tol=1e-5):
             assert g["tags"][k] == o["tags"][k], (p, k)
         assert abs(float(g["tags"]["sssnr0"]) - float(o["tags"]["sssnr0"])) < 1e-4, p
         if "llr" in g:          # c8p_rx only leaves the LLR stream in memory when c8p_cfg.keep_llr is set (c8p_demod always does)
-            assert len(g["llr"]) == len(o["llr"])
+            assert len(g["llr"]) == len(o["llr"]), p
             if len(o["llr"]):
                 assert np.max(np.abs(g["llr"] - o["llr"])) <= llr_tol, (p, np.max(np.abs(g["llr"] - o["llr"])))
         assert g["pdus"] == o["pdus"], p
@@ -27,11 +27,17 @@ def compare(res, ref, llr_tol=1e-5):
 def run():
     b, meta = sweep_batch()
     pk, iq, chan = b.arrays()
-    eng = engine.Engine(device=0)
+    ref = oracle_rx(pk, iq, chan)
+    eng = engine.Engine(device=0, keep_llr=2)   # the default kernels + the tap: their LLRs against the oracle's (1e-5), tags, PDUs
     eng.rx(pk, iq, chan)
     res = eng.results()
-    ref = oracle_rx(pk, iq, chan)
+    assert all("llr" in g for g in res)
     n = compare(res, ref)
+    eng.close()
+    eng = engine.Engine(device=0)               # the default as it ships: nothing but tags and PDUs leaves the chip
+    eng.rx(pk, iq, chan)
+    res = eng.results()
+    assert not any("llr" in g for g in res) and compare(res, ref) == n
     eng.demod(pk, iq, chan)                     # the LLR stream itself: through the split entry point
     eng.sync()
     tags, llr = eng.tags(), eng.fetch(abi.BUF_LLR, np.float32)

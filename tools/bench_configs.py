@@ -26,6 +26,8 @@ def main():
     cases = [
         ("cfg1 legacy MCS0 100 B x4096", cfg["cfg1_L_mcs0_100B"], cfg["cfg1_L_mcs0_100B"]["pdu"].tobytes(), 4096, 1, None, 0, 30.0),
         ("cfg3 HT MCS15 2x2 1458 B x1024", cfg["cfg3_HT_mcs15_2x2_1458B"], cfg["cfg3_HT_mcs15_2x2_1458B"]["pdu"].tobytes(), 1024, 2, H22, 0, 30.0),
+        ("cfg3 HT MCS15 2x2 1458 B x4096", cfg["cfg3_HT_mcs15_2x2_1458B"], cfg["cfg3_HT_mcs15_2x2_1458B"]["pdu"].tobytes(), 4096, 2, H22, 0, 30.0),
+        ("cfg2 VHT MCS7 1458 B x4096 (fixture frame)", cfg["cfg2_VHT_mcs7_1458B_0"], cfg["cfg2_VHT_mcs7_1458B_0"]["pdu"].tobytes(), 4096, 1, None, 0, 30.0),
         ("cfg4 VHT MCS8 1458 B x8192", cfg["cfg4_VHT_mcs8_1458B"], cfg["cfg4_VHT_mcs8_1458B"]["pdu"].tobytes(), 8192, 1, None, 0, 36.0),
         ("cfg5 MU-MIMO station 0 (MCS3 100 B) x1024", {"tx": mu["mu_tx"]}, mu["pdu0"].tobytes(), 1024, 1, mu["h"][0:1], 0, 30.0),
         ("cfg5 MU-MIMO station 1 (MCS3 60 B) x1024", {"tx": mu["mu_tx"]}, mu["pdu1"].tobytes(), 1024, 1, mu["h"][1:2], 1, 30.0),

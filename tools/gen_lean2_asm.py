@@ -258,7 +258,7 @@ template <> __device__ __forceinline__ void lean2_lds<%d>(float& m0, float& m1, 
   unsigned a0, a1;
   asm volatile(
 %s
-      : "+{v%d}"(m0), "+{v%d}"(m1), "={v%d}"(a0), "={v%d}"(a1), "+{v%d}"(voff), "+{v%d}"(laddr), [nblk] "+s"(nblk), [segc] "+s"(segc)
+      : "+{v%d}"(m0), "+{v%d}"(m1), "=&{v%d}"(a0), "=&{v%d}"(a1), "+{v%d}"(voff), "+{v%d}"(laddr), [nblk] "+s"(nblk), [segc] "+s"(segc)
       : %s
       : %s);
 }

@@ -552,7 +552,7 @@ template <> __device__ __forceinline__ void lean_blocks_lds<%d>(float& pre, unsi
 {
   asm volatile(
 %s
-      : "+{v62}"(pre), "={v63}"(acc), "+{v50}"(voff), [nblk] "+s"(nblk), [segc] "+s"(segc)
+      : "+{v62}"(pre), "=&{v63}"(acc), "+{v50}"(voff), [nblk] "+s"(nblk), [segc] "+s"(segc)
       : %s
       : %s);
 }
