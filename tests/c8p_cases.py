@@ -127,56 +127,90 @@ def ampdu_vht(mpdu):
     return pkt + b"\x00" * ((-len(pkt)) % 4)
 
 
-def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0, mcs=7, seed_base=8021100):
-    """BASELINE configs[1] as SURVEY.md §8d-2 specifies it, generated on the box by the build's own transmitter:
-    packet p carries its own MPDU (1454 bytes from numpy.random.default_rng(8021100 + p) + CRC-32, inside a VHT A-MPDU),
-    VHT MCS7, amplitude as tools/pktGenExample.py (multiplier 12), a flat channel e^{j theta_p} and AWGN at snr_db
-    (sigma per tools/performance/perf_siso.py:92).  c8p_tx -> channel (torch, on the device) -> c8p_signal at the nominal
-    sync item (L-LTF + 24, CFO 0) gives the packets at the signal -> demod boundary, all resident in HBM.
+H_MU = np.array([[1 + 0.2j, 0.5 - 0.4j], [0.3 + 0.6j, -0.9 + 0.1j]], np.complex64)     # SURVEY.md §8d cfg 5: rows = stations
+
+
+# BASELINE.json configs as SURVEY.md §8d states them: (format, mcs [per stream], transmit chains, receive antennas, MPDU bytes,
+# flat channel [n_ant][n_chain] or None, user position, seed base, what it is)
+WORKLOADS = {
+    "cfg1": (0, 0, 1, 1, 100, None, 0, 8021000, "configs[0]: legacy 802.11a MCS0 BPSK r=1/2 SISO, 100-byte MPDU"),
+    "cfg2": (2, 7, 1, 1, 1458, None, 0, 8021100, "configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU"),
+    "cfg3": (1, 7, 2, 2, 1458, H22, 0, 8021300, "configs[2]: HT MCS15 (64-QAM r=5/6 x 2 streams) 2x2, 1458-byte MPDU, demod2's zero-forcing path"),
+    "cfg4": (2, 8, 1, 1, 1458, None, 0, 8021400, "configs[3] with the MCS8 substitution of SURVEY.md §7: VHT MCS8 256-QAM r=3/4 SISO, 1458-byte MPDU"),
+    "cfg5u0": (3, 3, 2, 1, 100, H_MU[0:1], 0, 8021500, "configs[4]: VHT 2-user MU-MIMO (MCS3 / MCS3, 100 / 60-byte MPDUs, zero-forcing Q of the cmu_v3 formula), station 0"),
+    "cfg5u1": (3, 3, 2, 1, 60, H_MU[1:2], 1, 8021500, "configs[4]: the same packets at station 1 (60-byte MPDUs)"),
+}
+
+
+def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, seed_base=None):
+    """A BASELINE.json config (WORKLOADS) as SURVEY.md §8d specifies it, generated on the box by the build's own transmitter:
+    packet p carries its own MPDU (bytes from numpy.random.default_rng(seed_base + seed + p) + CRC-32; inside an A-MPDU for VHT),
+    amplitude as tools/pktGenExample.py (multiplier 12, x sqrt(2) on two chains), clean OFDM symbols (C8P_TX_NO_WINDOW: the toolbox's
+    half-amplitude symbol edges cost 19.6 dB of self-interference at the receiver's FFT window), a flat channel
+    H e^{j theta_p} and AWGN at snr_db (sigma per tools/performance/perf_siso.py:92).  c8p_tx -> channel (torch, on the device) ->
+    c8p_signal at the nominal sync item (L-LTF + 24, CFO 0) gives the packets at the signal -> demod boundary, all resident in HBM.
     Returns (descriptors [host], iq DevArray, chan DevArray, expected PDUs, keep-alive objects)."""
     import zlib
     from c8p_testlib import abi
-    from gr_ieee80211_amd import engine
+    from gr_ieee80211_amd import engine, shard
+    fmt, mcs0, nchain, n_ant, mlen, H, mupos, sb, _ = WORKLOADS[kind]
+    mcs = mcs0 if mcs is None else mcs
+    seed_base = sb if seed_base is None else seed_base
     GAP = 120
     pk = np.zeros(n, abi.TX_PKT_DT)
+    mu = np.zeros(n if fmt == 3 else 0, abi.TX_MU_DT)
     arena, exp = [], []
     off = 0
+
+    def put(b):
+        nonlocal off
+        arena.append(np.frombuffer(b, np.uint8))
+        off += len(b)
+        return off - len(b)
     for p in range(n):
         rng = np.random.default_rng(seed_base + seed + p)
-        body = bytes(rng.integers(0, 256, size=1454, dtype=np.uint8))
-        mpdu = body + zlib.crc32(body).to_bytes(4, "little")
-        ps = ampdu_vht(mpdu)
-        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = off, len(ps), abi.F_VHT, mcs
-        pk[p]["scr_seed"], pk[p]["mult"], pk[p]["gap"] = 93, 12.0, GAP
-        pk[p]["flags"] = abi.TX_NO_WINDOW                   # clean OFDM symbols, as `dewindow` makes the fixture frames
-        arena.append(np.frombuffer(ps, np.uint8))
-        off += len(ps)
-        exp.append(bytes([abi.F_VHT, len(mpdu) % 256, len(mpdu) // 256]) + mpdu + bytes([mcs]))
+        lens = (100, 60) if fmt == 3 else (mlen,)
+        mpdus = []
+        for ln in lens:
+            body = bytes(rng.integers(0, 256, size=ln - 4, dtype=np.uint8))
+            mpdus.append(body + zlib.crc32(body).to_bytes(4, "little"))
+        ps = [ampdu_vht(m) if fmt >= 2 else m for m in mpdus]
+        pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = put(ps[0]), len(ps[0]), fmt, mcs
+        pk[p]["scr_seed"], pk[p]["gap"], pk[p]["nss"] = 93, GAP, nchain
+        pk[p]["mult"] = 12.0 * (np.sqrt(2.0) if nchain == 2 else 1.0)
+        pk[p]["flags"] = abi.TX_NO_WINDOW
+        if fmt == 3:
+            mu[p]["psdu_off"], mu[p]["len"], mu[p]["mcs"], mu[p]["group_id"], mu[p]["q_off"] = put(ps[1]), len(ps[1]), mcs, 2, 0
+        m = mpdus[mupos]
+        exp.append(bytes([min(fmt, 2), len(m) % 256, len(m) // 256]) + m + bytes([mcs + 8 if (fmt == 1 and nchain == 2) else mcs]))
+    bfq = None
+    if fmt == 3:           # zero-forcing steering (tools/cmu_v3/cmu_ap.py:182-189): nulls the other user's stream at each station
+        q = np.linalg.inv(np.asarray(H_MU, np.complex128))
+        q = q / np.linalg.norm(q, axis=0, keepdims=True)
+        bfq = np.tile(q.reshape(1, 4), (64, 1)).astype(np.complex64).reshape(256)
     e_tx = engine.Engine(device=local)
-    e_tx.tx(pk, np.concatenate(arena), tail_gap=400)
+    e_tx.tx(pk, np.concatenate(arena), tail_gap=400, mu=mu if fmt == 3 else None, bfq=bfq)
     e_tx.sync()
     desc = e_tx.fetch(abi.BUF_TX_DESC, abi.TX_DESC_DT)
     p_iq, nbytes = e_tx.buffer(abi.BUF_TX_IQ)
-    ntot = nbytes // 8
-    # channel on the device: per-packet phase, then noise
-    clean = torch.empty(ntot * 2, dtype=torch.float32, device=dev)
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemcpy(ctypes.c_void_p(clean.data_ptr()), ctypes.c_void_p(p_iq), ctypes.c_size_t(nbytes), ctypes.c_int(3))   # device to device
-    z = torch.view_as_complex(clean.view(-1, 2))
+    ntot = nbytes // 8 // nchain                               # items per transmit chain (chain 0 | chain 1)
+    z = torch.view_as_complex(shard.device_bytes(p_iq, nbytes, dev).view(torch.float32).view(nchain, ntot, 2))
     g = torch.Generator(device=dev); g.manual_seed(seed_base + 100 + seed)
     theta = torch.rand(n, generator=g, device=dev, dtype=torch.float32) * (2 * np.pi)
     starts = torch.from_numpy(desc["iq_off"].astype(np.int64)).to(dev)
-    idx = torch.searchsorted(starts, torch.arange(ntot, device=dev), right=True) - 1
-    z = z * torch.polar(torch.ones(n, device=dev), theta)[idx.clamp(min=0)]
+    idx = (torch.searchsorted(starts, torch.arange(ntot, device=dev), right=True) - 1).clamp(min=0)
+    ph = torch.polar(torch.ones(n, device=dev), theta)[idx]
+    Hm = torch.from_numpy(np.eye(1, dtype=np.complex64) if H is None else np.asarray(H, np.complex64)).to(dev)
+    rx = (Hm @ z) * ph                                         # [n_ant][ntot]
     sigma = float(np.sqrt(0.1875 ** 2 / (10 ** (snr_db / 10.0))))
-    noise = torch.randn(ntot, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))
-    noisy = (torch.view_as_real(z) + noise).contiguous()
-    x = engine.DevArray(noisy.data_ptr(), ntot, noisy)
+    noise = torch.randn(n_ant, ntot, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))
+    noisy = (torch.view_as_real(rx) + noise).contiguous()      # antenna 0 | antenna 1
+    x = engine.DevArray(noisy.data_ptr(), n_ant * ntot, noisy)
     ev = np.zeros(n, abi.SIG_IN_DT)
-    ev["raw_off"][:, 0] = desc["iq_off"] + 184             # L-LTF start + 24 (signal_impl's sync item)
-    ev["n_avail"] = desc["n_samp"] - 184 + GAP             # up to the next packet (the output slot is sized by this)
-    ev["snr"], ev["rssi"], ev["n_ant"] = snr_db, 1.0, 1
+    for a in range(n_ant):
+        ev["raw_off"][:, a] = a * ntot + desc["iq_off"] + 184  # L-LTF start + 24 (signal_impl's sync item)
+    ev["n_avail"] = desc["n_samp"] - 184 + GAP                 # up to the next packet (the output slot is sized by this)
+    ev["snr"], ev["rssi"], ev["n_ant"] = snr_db, 1.0, n_ant
     e_sig = engine.Engine(device=local)
     e_sig.signal(ev, x)
     e_sig.sync()
@@ -184,8 +218,14 @@ def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0, mcs=7, seed_ba
     ok = spk["n_items"] > 0
     spk = spk[ok].copy()
     spk["seq"] = np.arange(1, len(spk) + 1)
+    spk["mupos"] = mupos
     exp = [e for e, k in zip(exp, ok) if k]
     p_i, b_i = e_sig.buffer(abi.BUF_SIG_IQ)
     p_c, b_c = e_sig.buffer(abi.BUF_SIG_CHAN)
     e_tx.close()
     return spk, engine.DevArray(p_i, b_i // 8, e_sig), engine.DevArray(p_c, b_c // 8, e_sig), exp, (e_sig, noisy)
+
+
+def cfg2_workload_on_device(n, snr_db, seed, torch, dev, local=0, mcs=7, seed_base=8021100):
+    """BASELINE configs[1] (and, with mcs = 8 and its own seed base, configs[3]): see workload_on_device"""
+    return workload_on_device("cfg2", n, snr_db, seed, torch, dev, local, mcs=mcs, seed_base=seed_base)

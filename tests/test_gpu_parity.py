@@ -761,3 +761,83 @@ def test_both_rx_flavours_agree_on_random_formats_lengths_and_noise(snr_db):
         assert res[0][k]["tags"]["status"] == o["tags"]["status"], k
         assert res[0][k]["pdus"] == o["pdus"] and res[0][k]["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], k
 
+
+
+def _to_host(dev_arr):
+    import ctypes
+    import torch
+    torch.cuda.synchronize()
+    a = np.zeros(dev_arr.n, np.complex64)
+    ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(dev_arr.ptr), ctypes.c_size_t(a.nbytes), ctypes.c_int(2))
+    return a
+
+
+@pytest.mark.parametrize("kind,snr", [("cfg1", 30.0), ("cfg2", 30.0), ("cfg3", 30.0), ("cfg3", 17.0), ("cfg4", 30.0), ("cfg5u0", 30.0), ("cfg5u1", 7.0)])
+def test_device_generated_baseline_configs_match_oracle(eng, kind, snr):
+    """bench.py's workloads (tests/c8p_cases.py WORKLOADS: every BASELINE.json config as SURVEY.md §8d states it, generated on the box by
+    c8p_tx -> channel -> c8p_signal) at 40 packets: tags, LLRs (1e-5), bits, failure counts and PDUs equal to the oracle's on both
+    flavours of c8p_rx; at 30 dB every PDU is the transmitted MPDU.  cfg3 = the two-stream kernel (k_rx_2ss_lds) on its BASELINE
+    workload, at 17 dB with FCS-failing frames."""
+    import torch
+    from c8p_cases import workload_on_device
+    pk, A, C_, exp, keep = workload_on_device(kind, 40, snr, 7, torch, torch.device("cuda", 0), 0)
+    iq, chan = _to_host(A), _to_host(C_)
+    eng.rx(pk, A, C_)
+    res = eng.results(want_bits=True)
+    ref = oracle_rx(pk, iq, chan)
+    n_pdu = compare(res, ref, LLR_TOL)
+    for p, (g, o) in enumerate(zip(res, ref)):
+        assert g["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], p
+        assert np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"]), p
+        assert g["pdus"] in ([], [exp[p]]), p
+    if snr >= 30.0:
+        assert n_pdu >= 39, n_pdu
+    else:
+        assert sum(int(o["out"]["n_crc_fail"]) for o in ref) > 0
+
+
+def test_soak_full_size_batches_against_the_oracle_on_all_cores():
+    """Full-size batches of distinct packets through c8p_rx as it ships (the un-tapped default), EVERY packet compared with the oracle —
+    status, tags, PDU bytes, failure counts — the oracle running one slice of the batch per host core (re-entrant C behind ctypes):
+    cfg 2 at 30 / 24 / 21 dB (from all frames delivered to most frames failing) and cfg 3 (two streams) at 28 / 20 dB.
+    C8P_SOAK_N = packets per batch (default 4096 for cfg 2, half of it for cfg 3)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from bench import usable_cores
+    from c8p_cases import workload_on_device
+    n = int(os.environ.get("C8P_SOAK_N", "4096"))
+    o = oracle()
+    cores = usable_cores()
+    e = engine.Engine(device=0)
+    tot = n_ok = n_fail = 0
+    for k, (kind, snr, m) in enumerate([("cfg2", 30.0, n), ("cfg2", 24.0, n), ("cfg2", 21.0, n), ("cfg3", 28.0, n // 2), ("cfg3", 20.0, n // 2)]):
+        pk, A, C_, exp, keep = workload_on_device(kind, m, snr, 1000003 * (k + 1), torch, torch.device("cuda", 0), 0)
+        e.rx(pk, A, C_)
+        e.sync()
+        tags, outs, area = e.tags(), e.outs(), e.fetch(abi.BUF_PDU, np.uint8)
+        iq, chan = _to_host(A), _to_host(C_)
+        step = -(-len(pk) // cores)
+        with ThreadPoolExecutor(cores) as ex:
+            parts = list(ex.map(lambda a: o.rx_batch(pk[a:a + step], iq, chan), range(0, len(pk), step)))
+        p = 0
+        for t_o, o_o, pdu_o, _ in parts:
+            stride = len(pdu_o) // max(len(t_o), 1)
+            for j in range(len(t_o)):
+                assert tags[p]["status"] == t_o[j]["status"], (kind, snr, p)
+                for key in abi.TAG_KEYS + ("nsym", "nss"):
+                    assert tags[p][key] == t_o[j][key], (kind, snr, p, key)
+                assert outs[p]["n_pdu"] == o_o[j]["n_pdu"] and outs[p]["n_crc_fail"] == o_o[j]["n_crc_fail"], (kind, snr, p)
+                nb = int(o_o[j]["pdu_bytes"])
+                assert int(outs[p]["pdu_bytes"]) == nb, (kind, snr, p)
+                g0 = int(outs[p]["pdu_off"])
+                assert np.array_equal(area[g0:g0 + nb], pdu_o[j * stride:j * stride + nb]), (kind, snr, p)
+                if nb:
+                    assert area[g0 + 2:g0 + nb].tobytes() == exp[p], (kind, snr, p)
+                n_ok += int(o_o[j]["n_pdu"]); n_fail += int(o_o[j]["n_crc_fail"])
+                p += 1
+        assert p == len(pk)
+        tot += len(pk)
+        del keep
+    e.close()
+    print("soak: %d packets, %d PDUs, %d FCS failures, all equal to the oracle (%d host threads)" % (tot, n_ok, n_fail, cores))
+    assert n_ok > 0.5 * tot and n_fail > 0.05 * tot, (tot, n_ok, n_fail)

@@ -73,6 +73,77 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_pipe(rank, world, port, q, sub):
+    """the pipelined scatter (shard.StreamScatter): sub-batches posted up front, consumed in arrival order"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for d in (ROOT, os.path.join(ROOT, "tests")):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, _ = sweep_batch(snr_db=25.0, seed=9)                # every rank builds the stream, ONLY to check what arrives against it
+    pk_ref, iq_ref, chan_ref = b.arrays()
+    n_total = len(pk_ref)
+    pk_all = iq_all = chan_all = None
+    if rank == 0:
+        pk_all = pk_ref
+        iq_all = torch.from_numpy(iq_ref.view(np.float32).copy())
+        chan_all = torch.from_numpy(chan_ref.view(np.float32).copy())
+    feed = shard.StreamScatter("cpu")
+    got_all = []
+    for step in range(2):                                   # two steps through the same object: buffers are reused
+        pk = feed.begin(pk_all, iq_all, chan_all, n_total, sub)
+        lo, hi = shard.partition(n_total, world, rank)
+        assert len(pk) == hi - lo and feed.subs == shard.sub_batches(hi - lo, sub)
+        if hi - lo > sub:
+            assert len(feed.subs) >= 2 and feed.subs[-1][1] - feed.subs[-1][0] <= sub     # ragged last sub-batch
+        res = []
+        for k, (a, e) in enumerate(feed.subs):
+            feed.arrived(k)
+            # what has arrived is exactly this sub-batch of the stream, in arrival order, at the offsets its descriptors name
+            iq_l, ch_l = feed.iq.numpy().view(np.complex64), feed.chan.numpy().view(np.complex64)
+            for j in range(a, e):
+                g, w = pk[j], pk_ref[lo + j]
+                for f in ("n_items", "lsig_mcs", "lsig_len", "lsig_nsamp", "seq", "n_ant", "mupos"):
+                    assert g[f] == w[f], (rank, j, f)
+                for ant in range(int(w["n_ant"])):
+                    x = iq_l[int(g["iq_off"][ant]):int(g["iq_off"][ant]) + int(g["n_items"])]
+                    y = iq_ref[int(w["iq_off"][ant]):int(w["iq_off"][ant]) + int(w["n_items"])]
+                    assert np.array_equal(x, y), (rank, j, ant)
+                assert np.array_equal(ch_l[int(g["chan_off"]):int(g["chan_off"]) + 64], chan_ref[int(w["chan_off"]):int(w["chan_off"]) + 64])
+            res += oracle_rx(pk[a:e], iq_l, ch_l)           # (the oracle stands in for c8p_rx on the sub-batch: test only)
+        feed.finish()
+        outs, pdu = _arenas_from_oracle(res)
+        counts, outs_all, pdu_all = shard.gather_results(torch.from_numpy(outs.view(np.uint8).copy()), torch.from_numpy(pdu.copy()), len(pk))
+        got_all.append(shard.pdus_of(counts, outs_all, pdu_all, n_total))
+        dist.barrier()
+    q.put((rank, got_all))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sub", [(2, 7), (3, 5), (3, 64)])
+def test_pipelined_scatter_delivers_sub_batches_in_arrival_order(world, sub):
+    """shard.StreamScatter under gloo: exact-extent sub-batches (ragged: 53 packets in blocks of 26-27 or 17-18, sub-batches of 7 / 5;
+    sub = 64: one sub-batch per rank), 1- and 2-antenna packets mixed; each rank checks every sub-batch against the stream the moment
+    `arrived(k)` returns, decodes it, and the gathered PDU list equals the single-process run on both steps"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipe, args=(r, world, port, q, sub)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, _ = sweep_batch(snr_db=25.0, seed=9)
+    pk, iq, chan = b.arrays()
+    want = [(p, x) for p, r in enumerate(oracle_rx(pk, iq, chan)) for x in r["pdus"]]
+    assert len(want) > 30
+    for rank, got_all in outs:
+        assert got_all == [want, want], rank
+
+
 def test_partition_properties():
     for n in (0, 1, 7, 4096, 65536):
         for w in (1, 2, 3, 8):
