@@ -289,6 +289,11 @@ def main():
             out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
             out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
             out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
+            out["host_phase_us"] = {"chain": r.get("chain_host_phase_us_per_packet"), "chain_fused": r.get("chain_fused_host_phase_us_per_packet"),
+                                    "note": "host microseconds per packet inside the demod / decode block mirrors, by phase (exclusive): "
+                                            "cut_and_stage = tag reads + the copy of the items into pinned staging, submit = the c8p_* call, "
+                                            "wait = blocked on the batch, fetch = synchronous result copies, replay = tags / PDUs / debug lines, "
+                                            "drain = the LLR items into the output buffer; wall = chain time per packet (two threads)"}
             out["host_legs_note"] = ("pcie_inclusive: c8p_rx from pinned host arenas, PDUs + results fetched back, batch i+1 submitted "
                                      "before batch i is fetched (c8p_ticket / c8p_select); block_chain: the gr::ieee80211::demod -> decode "
                                      "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "

@@ -2,7 +2,7 @@
 //
 // A front (c8p::demod / demod2 / decode of ../../gr-ieee80211_amd/host/c8p_blocks.h, compiled into namespace c8p in this
 // module) cuts the tagged item stream into packets, batches them through the C ABI (libc8p_rx.so) and replays the results;
-// everything it asks of GNU Radio goes through the seven block_io methods below.  c8p_gr_block<API> is the block class:
+// everything it asks of GNU Radio goes through the eight block_io methods below.  c8p_gr_block<API> is the block class:
 // API = the public class of include/gnuradio/ieee80211/ (demod, demod2, decode), which derives from gr::block, so the
 // protected scheduler calls (get_tags_in_range, add_item_tag, ...) are made from inside the block, as in the reference's
 // own *_impl classes.  Tag values cross as the three PMT kinds the reference's blocks use: long, float, c32vector.
@@ -30,6 +30,9 @@ public:
   c8p_gr_block(const std::string& name, gr::io_signature::sptr in, gr::io_signature::sptr out) : gr::block(name, in, out)
   {
     this->set_tag_propagation_policy(gr::block::TPP_DONT);          // demod_impl.cc:44, decode_impl.cc:41
+    // wake(): a message to a port of its own is how a block gets its scheduler thread to run when no stream item arrives
+    this->message_port_register_in(pmt::mp("c8p_tick"));
+    this->set_msg_handler(pmt::mp("c8p_tick"), [](pmt::pmt_t) {});
   }
 
   // gr::block
@@ -88,6 +91,10 @@ private:
   }
 
   void debug_print(const std::string& line) override { std::cout << line << std::endl; }   // the reference's dout
+
+  // the front's latency timer collected results while no input was arriving: after the (empty) handler the scheduler thread
+  // evaluates forecast() — which asks for no input while results wait for output space — and calls general_work()
+  void wake() override { this->_post(pmt::mp("c8p_tick"), pmt::PMT_T); }
 
   std::shared_ptr<c8p::c8p_block> d_front;
 };

@@ -36,6 +36,11 @@ def lib():
         L.c8ph_push_tag_c32.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_void_p, C.c_int]
         L.c8ph_run.restype = C.c_long
         L.c8ph_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.c8ph_run_live.restype = C.c_long
+        L.c8ph_run_live.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.c8ph_host_phase_reset.argtypes = [C.c_void_p]
+        L.c8ph_host_phase_us.restype = C.c_char_p
+        L.c8ph_host_phase_us.argtypes = [C.c_void_p]
         L.c8ph_set_jitter.argtypes = [C.c_void_p, C.c_ulonglong]
         L.c8ph_set_capture.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_error.restype = C.c_char_p
@@ -99,6 +104,22 @@ class Block:
         if n < 0:
             raise RuntimeError(self.L.c8ph_error(self.h).decode())
         return n
+
+    def run_live(self, chunk=4096, nout=8192, linger_ms=50):
+        """a LIVE scheduler: general_work is only called while there is input (or the block's forecast asks for none), nothing is
+        flushed; after the input is used up the loop idles for linger_ms, woken by the block's latency timer"""
+        n = self.L.c8ph_run_live(self.h, chunk, nout, int(linger_ms))
+        if n < 0:
+            raise RuntimeError(self.L.c8ph_error(self.h).decode())
+        return n
+
+    def host_phase_reset(self):
+        self.L.c8ph_host_phase_reset(self.h)
+
+    def host_phase_us(self):
+        """{phase: microseconds} of host time inside this block since it was made (exclusive phases)"""
+        txt = self.L.c8ph_host_phase_us(self.h).decode()
+        return {k: int(v) for k, v in (kv.split("=") for kv in txt.split(";") if kv)}
 
     def output(self, port=0):
         """the block's output stream: float LLRs (demod), complex items (signal / signal2, port 0 or 1)"""

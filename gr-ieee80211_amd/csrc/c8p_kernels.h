@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   const int Tn = t.trellis, nfull = Tn / C8P_SV_BLK;
   const int nlb = t.cr == C8P_CR_12 ? LeanRate<C8P_CR_12>::NLB : t.cr == C8P_CR_23 ? LeanRate<C8P_CR_23>::NLB :
                   t.cr == C8P_CR_34 ? LeanRate<C8P_CR_34>::NLB : LeanRate<C8P_CR_56>::NLB;
-  // ceil(65536 / nlb): (have * inv) >> 16 == have / nlb for have < 1499 (C8P_LBUF = 480).  Constants on purpose: a division is done by
+  // ceil(65536 / nlb): (have * inv) >> 16 == have / nlb for have < 1499 (C8P_LBUF = 688).  Constants on purpose: a division is done by
   // the VALU, and a wave-uniform value that comes out of the VALU drags every counter it touches into (spilled) VGPRs
   const unsigned nlb_inv = t.cr == C8P_CR_12 ? 1093u : t.cr == C8P_CR_23 ? 1457u : t.cr == C8P_CR_34 ? 1639u : 1821u;
   const float wfac = __uint_as_float(t.ncbps >= C8P_NEGB_WINDOW ? 0x40000000u : 0x40400000u);   // 2 or 3 (selected as bits: stays in an SGPR)
@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     int nb = (int)(((unsigned)have * nlb_inv) >> 16);   // have / nlb: complete blocks in the buffer
     if (nb > nfull - done) nb = nfull - done;
     if (nb > 0) {
+      wave_lds_fence();                              // the demodulating lanes' LLR writes before the decoder's (other lanes') reads
       parkX[wv][lane_d] = xin;
       asm volatile("; next sample parked" : "=v"(xin.x), "=v"(xin.y));
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1254,8 +1255,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       have -= used;
       for (int i = 0; i < have; i += 64) {
         const float v = i + lane_d < have ? lb[used + i + lane_d] : 0.0f;
+        wave_lds_fence();                            // every lane has read before any lane writes
         if (i + lane_d < have) lb[i + lane_d] = v;
       }
+      wave_lds_fence();
       xin = parkX[wv][lane_fresh()];
     }
   }
@@ -1449,8 +1452,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       have -= used;
       for (int i = 0; i < have; i += 64) {
         const float v = i + lane < have ? lb[used + i + lane] : 0.0f;
+        wave_lds_fence();
         if (i + lane < have) lb[i + lane] = v;
       }
+      wave_lds_fence();
     }
   }
   if (lane == 0) flags[n + p] = (uint32_t)S.nflt;
@@ -1672,8 +1677,8 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   // memory holds bw[], the decoded bits packed 64 per word.
   __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
   // lane D at the entry of every 6-step group = 6 decoded bits; later the CRC-32 byte table.  Dynamic: sized by the launch for the
-  // longest trellis of the batch (c8p_finish_lds_bytes: 2 KB at cfg 2 instead of the 5.5 KB of the longest legal trellis), which lets
-  // 8 instead of 6 of these one-wave workgroups share a CU's LDS
+  // longest trellis of the batch (the launch passes it: 3.8 KB at cfg 2 instead of the 5.5 KB of the longest legal trellis), which lets
+  // 7 instead of 6 of these one-wave workgroups share a CU's LDS
   extern __shared__ __attribute__((aligned(16))) uint8_t snaps[];
   __shared__ uint16_t s_btop[64];
   unsigned long long* bw = (unsigned long long*)tile;      // (C8P_DECODE_T_MAX + 63) / 64 + 2 words <= 64 * TS / 2

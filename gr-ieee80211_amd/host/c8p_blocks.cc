@@ -21,9 +21,11 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
 
 C8P_MIRROR_NS_BEGIN
 
@@ -63,6 +65,12 @@ static c8p_api default_api()
   return load_c8p_api(e ? e : "libc8p_rx.so");
 }
 
+int batching_cfg::default_max_wait_us()
+{
+  const char* e = getenv("C8P_MAX_WAIT_US");
+  return e && atoi(e) > 0 ? atoi(e) : 1000;
+}
+
 bool batching_cfg::default_fused()
 {
   const char* e = getenv("C8P_FUSED");
@@ -78,6 +86,21 @@ struct fused_pkt {
 static std::mutex g_fused_mu;
 static std::map<long, fused_pkt> g_fused;
 static std::atomic<long> g_fused_next{1};
+// A handle is erased when `decode` meets its tag.  If no decode is downstream (or tags are dropped, or the flowgraph stops first)
+// nobody does: the map is therefore bounded — the oldest handles go once more than C8P_FUSED_MAX are parked — and a demod front
+// takes the handles it issued with it when it is destroyed.
+static const size_t C8P_FUSED_MAX = 1u << 16;
+static void fused_park(long id, fused_pkt&& f)
+{
+  std::lock_guard<std::mutex> g(g_fused_mu);
+  g_fused[id] = std::move(f);
+  while (g_fused.size() > C8P_FUSED_MAX) g_fused.erase(g_fused.begin());     // (ids grow: begin() is the oldest)
+}
+static void fused_purge(const std::vector<long>& ids)
+{
+  std::lock_guard<std::mutex> g(g_fused_mu);
+  for (long id : ids) g_fused.erase(id);
+}
 
 // growable array in pinned host memory (uninitialised growth: no zero fill of tens of megabytes per batch)
 template <typename T> class pinned_vec
@@ -131,6 +154,70 @@ typedef std::chrono::steady_clock::time_point tick_t;
 static tick_t now_tick() { return std::chrono::steady_clock::now(); }
 static long us_since(tick_t t) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(now_tick() - t).count(); }
 
+// host-side time per phase of a front (microseconds, accumulated, EXCLUSIVE: entering a phase stops the clock of the one around
+// it): what tools/bench_blocks.py reports as host_phase_us
+struct phase_clock {
+  enum { CUT, SUBMIT, ENQ, ALLOC, WAIT, FETCH, REPLAY, DRAIN, N };
+  double us[N] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cur = -1;
+  tick_t t_last;
+  void charge()
+  {
+    const tick_t t = now_tick();
+    if (cur >= 0) us[cur] += std::chrono::duration<double, std::micro>(t - t_last).count();
+    t_last = t;
+  }
+  struct scope {
+    phase_clock& c; int prev; bool open = true;
+    scope(phase_clock& c_, int k) : c(c_) { c.charge(); prev = c.cur; c.cur = k; }
+    void end() { if (open) { open = false; c.charge(); c.cur = prev; } }
+    ~scope() { end(); }
+  };
+  std::string str() const
+  {
+    static const char* nm[N] = {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain"};
+    std::string s;
+    for (int i = 0; i < N; i++) s += std::string(nm[i]) + "=" + std::to_string((long)us[i]) + ";";
+    return s;
+  }
+};
+typedef phase_clock::scope sub_scope;
+
+// The latency timer of a front.  general_work() only runs while items arrive; `due()` tells when the oldest gathered packet or the
+// batch in flight reaches max_wait_us, and `fire()` does what general_work's own age check would do (under the front's mutex).
+class latency_timer
+{
+public:
+  latency_timer(std::mutex& mu, std::function<bool(tick_t&)> due, std::function<void()> fire) : d_mu(mu), d_due(std::move(due)), d_fire(std::move(fire)) {}
+  ~latency_timer() { stop(); }
+  void start() { d_th = std::thread([this] { loop(); }); }
+  void stop()
+  {
+    { std::lock_guard<std::mutex> g(d_mu); d_quit = true; }
+    d_cv.notify_all();
+    if (d_th.joinable()) d_th.join();
+  }
+  void poke() { d_cv.notify_one(); }         // (the front's state changed: a deadline may have appeared; caller holds the mutex or not)
+  std::string error;                          // an engine error met on the timer thread is reported by the next general_work
+private:
+  void loop()
+  {
+    std::unique_lock<std::mutex> lk(d_mu);
+    while (!d_quit) {
+      tick_t when;
+      if (!d_due(when)) { d_cv.wait(lk); continue; }
+      if (now_tick() < when) { d_cv.wait_until(lk, when); continue; }
+      try { d_fire(); } catch (const std::exception& e) { error = e.what(); return; }
+    }
+  }
+  std::mutex& d_mu;
+  std::function<bool(tick_t&)> d_due;
+  std::function<void()> d_fire;
+  std::condition_variable d_cv;
+  std::thread d_th;
+  bool d_quit = false;
+};
+
 class engine_holder
 {
 public:
@@ -141,6 +228,10 @@ public:
     c.abi_version = C8P_ABI_VERSION; c.device = cfg.device;
     d_ctx = d_api.create(&c);
     if (!d_ctx) throw std::runtime_error("c8p_create failed: no usable HIP device (there is no CPU fallback)");
+    // The fronts submit batch i+1 before they collect batch i, which needs the result arenas of TWO submits to stay resident.
+    // The engine keeps C8P_SLOTS of them (default 3; documented values start at 1): with one slot the previous batch is collected first.
+    const char* e = getenv("C8P_SLOTS");
+    d_two_resident = !(e && atoi(e) == 1);
   }
   ~engine_holder() { if (d_ctx) d_api.destroy(d_ctx); }
   void check(int rc, const char* what = "")
@@ -158,6 +249,7 @@ public:
   c8p_api d_api;
   batching_cfg d_cfg;
   c8p_ctx* d_ctx = nullptr;
+  bool d_two_resident = true;
 };
 
 // ================================================================================================ demod / demod2
@@ -165,18 +257,33 @@ class demod_front : public demod, public demod2
 {
 public:
   demod_front(int nports, int mupos, int mugid, const c8p_api& api, const batching_cfg& cfg)
-      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)}
+      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)},
+        d_timer(d_mu, [this](tick_t& w) { return next_deadline(w); }, [this] { on_timer(); })
   {
+    if (cfg.flush_when_idle) d_timer.start();
+  }
+  ~demod_front() override
+  {
+    d_timer.stop();
+    fused_purge(d_fused_ids);                      // the handles this front parked and no decode picked up
   }
 
   void forecast(int noutput_items, gr_vector_int& req) override   // demod_impl.cc:53-57
   {
-    for (auto& r : req) r = noutput_items;
+    // results waiting for output space need no input to be handed out (the timer thread collected them while none arrived)
+    std::lock_guard<std::mutex> g(d_mu);
+    for (auto& r : req) r = d_outq.empty() ? noutput_items : 0;
   }
+
+  std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
+  void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
 
   int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& output_items) override
   {
+    std::lock_guard<std::mutex> g(d_mu);
+    if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
+    phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     int nproc = ninput_items[0];
     for (int p = 1; p < d_nports; p++) nproc = std::min(nproc, ninput_items[p]);
     int used = 0;
@@ -220,13 +327,35 @@ public:
     }
     if (d_eng.d_cfg.flush_when_idle) age_check();
     d_io->consume_each(used);
+    // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
+    const bool pending = !d_st[d_fill].pk.empty() || d_st[d_fill ^ 1].ticket != 0;
+    if (pending && !d_was_pending) d_timer.poke();
+    d_was_pending = pending;
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_st[d_fill].pk.empty()) submit(true);
     else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+  }
+
+  // the timer thread (holds d_mu): when does the oldest thing this front is sitting on reach max_wait_us?
+  bool next_deadline(tick_t& when)
+  {
+    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    bool have = false;
+    if (!d_st[d_fill].pk.empty()) { when = d_st[d_fill].t_first + w; have = true; }
+    const stage& fl = d_st[d_fill ^ 1];
+    if (fl.ticket && (!have || fl.t_submit + w < when)) { when = fl.t_submit + w; have = true; }
+    return have;
+  }
+  void on_timer()
+  {
+    const size_t before = d_outq.size();
+    age_check();
+    if (d_outq.size() > before && d_io) d_io->wake();      // no input is coming that would get general_work called: ask for a call
   }
 
   // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us (asynchronously: its
@@ -241,8 +370,10 @@ public:
 
 private:
   struct result {             // downloaded arenas of one batch, shared by its packets until they have been drained
-    explicit result(const c8p_api* a) : llr(a) {}
+    explicit result(const c8p_api* a) : llr(a), outs(a), pdu(a) {}
     pinned_vec<float> llr;
+    pinned_vec<c8p_pkt_out> outs;     // fused mode: per-packet results and the PDU arena (whole: its layout is fixed-stride)
+    pinned_vec<uint8_t> pdu;
   };
   struct stage {              // one batch being gathered / in flight: its arenas must stay untouched until the submit has completed
     explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a) {}
@@ -260,11 +391,24 @@ private:
     size_t n = 0, sent = 0;
   };
 
-  std::shared_ptr<result> acquire()
+  // A result's pinned buffers are sized for the largest batch seen so far by ANY result (d_hwm_*): batches cut short by the
+  // latency bound have all sizes, and a buffer that grows batch by batch is a hipHostMalloc + hipHostFree of tens of megabytes
+  // each time (measured: 1.5-2.9 us per packet of the chain, profiles/r3c/blocks_phases.txt)
+  std::shared_ptr<result> acquire(size_t llr_items, size_t n_pkt, size_t pdu_bytes)
   {
-    for (auto& r : d_pool) if (r.use_count() == 1) return r;
-    d_pool.push_back(std::make_shared<result>(&d_eng.d_api));
-    return d_pool.back();
+    // (scaled to a full batch at once: batch sizes are random, and a mark that creeps up record by record re-allocates every
+    // pooled buffer at each new record)
+    const size_t full = (size_t)std::max(d_eng.d_cfg.max_batch, 1), np = std::max<size_t>(n_pkt, 1);
+    d_hwm_llr = std::max(d_hwm_llr, (llr_items + np - 1) / np * full);
+    d_hwm_pkt = std::max(d_hwm_pkt, std::max(n_pkt, full));
+    d_hwm_pdu = std::max(d_hwm_pdu, (pdu_bytes + np - 1) / np * full);
+    std::shared_ptr<result> r;
+    for (auto& q : d_pool) if (q.use_count() == 1) { r = q; break; }
+    if (!r) { d_pool.push_back(std::make_shared<result>(&d_eng.d_api)); r = d_pool.back(); }
+    r->llr.clear(); r->outs.clear(); r->pdu.clear();
+    if (llr_items) r->llr.reserve(d_hwm_llr);
+    if (pdu_bytes) { r->outs.reserve(d_hwm_pkt); r->pdu.reserve(d_hwm_pdu); }
+    return r;
   }
 
   // submit the batch being gathered; while full batches follow each other (last = false) the previous one is collected
@@ -278,27 +422,39 @@ private:
       for (int p = 0; p < d_nports; p++) part_iq[p].assign(st.iq.data() + d_cur.iq_off[p], st.iq.data() + d_cur.iq_off[p] + d_have);
       part_chan.assign(st.chan.data() + d_cur.chan_off, st.chan.data() + d_cur.chan_off + 64);
     }
+    if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_batch_in b;
     memset(&b, 0, sizeof(b));
     b.n_pkt = (int32_t)st.pk.size(); b.mem = C8P_MEM_HOST; b.pkts = st.pk.data();
     b.iq = reinterpret_cast<const c8p_c32*>(st.iq.data()); b.n_iq = st.iq.size();
     b.chan = reinterpret_cast<const c8p_c32*>(st.chan.data()); b.n_chan = st.chan.size();
+    sub_scope ph(d_ph, phase_clock::SUBMIT);
     d_eng.check(d_eng.d_cfg.fused ? d_eng.d_api.rx(d_eng.d_ctx, &b) : d_eng.d_api.demod(d_eng.d_ctx, &b));
     st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
     st.t_submit = now_tick();
     {
+      sub_scope phq(d_ph, phase_clock::ENQ);
       const c8p_api& A = d_eng.d_api;
       st.tags.resize_uninit(st.pk.size());
       d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_TAGS, st.tags.data(), 0, st.pk.size() * sizeof(c8p_pkt_tags)), "tags");
-      st.res = acquire();
-      st.res->llr.clear();
-      if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use)
-        uint64_t bytes = 0;
-        A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
+      uint64_t bytes = 0, pbytes = 0;
+      {
+        sub_scope pha(d_ph, phase_clock::ALLOC);
+        if (!d_eng.d_cfg.fused) A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
+        else A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
+        st.res = acquire(bytes / sizeof(float), st.pk.size(), pbytes);
         st.res->llr.resize_uninit(bytes / sizeof(float));
+      }
+      if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use)
         if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, st.res->llr.data(), 0, bytes), "llr");
+      } else {                        // fused: the decoded results, enqueued behind the kernels like the tags (collect() only waits)
+        st.res->outs.resize_uninit(st.pk.size());
+        st.res->pdu.resize_uninit(pbytes);
+        d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.res->outs.data(), 0, st.pk.size() * sizeof(c8p_pkt_out)), "outs");
+        if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.res->pdu.data(), 0, pbytes), "pdu");
       }
     }
+    ph.end();
     stage& prev = d_st[d_fill ^ 1];
     if (prev.ticket) collect(prev);
     if (last) collect(st);
@@ -320,23 +476,19 @@ private:
     const c8p_api& A = d_eng.d_api;
     c8p_ctx* ctx = d_eng.d_ctx;
     const size_t n = st.pk.size();
-    d_eng.check(A.wait(ctx, st.ticket), "wait");                 // kernels + the downloads enqueued behind them
+    {
+      sub_scope ph(d_ph, phase_clock::WAIT);
+      d_eng.check(A.wait(ctx, st.ticket), "wait");               // kernels + the downloads enqueued behind them
+    }
+    sub_scope ph(d_ph, phase_clock::REPLAY);
     d_eng.check(A.select(ctx, st.ticket), "select");
     const c8p_pkt_tags* tags = st.tags.data();
     const bool fused = d_eng.d_cfg.fused;
     std::shared_ptr<result> res = st.res;
     st.res.reset();
-    std::vector<c8p_pkt_out> outs;
-    std::vector<uint8_t> pdu;
-    uint64_t pdu_base = 0;
-    if (fused) {
-      outs.resize(n);
-      d_eng.check(A.fetch(ctx, C8P_BUF_OUT, outs.data(), 0, n * sizeof(c8p_pkt_out)));
-      uint64_t lo = ~0ull, hi = 0;
-      for (const c8p_pkt_out& o : outs)
-        if (o.n_pdu > 0) { lo = std::min<uint64_t>(lo, o.pdu_off); hi = std::max<uint64_t>(hi, o.pdu_off + o.pdu_bytes); }
-      if (hi > lo) { pdu.resize(hi - lo); pdu_base = lo; d_eng.check(A.fetch(ctx, C8P_BUF_PDU, pdu.data(), lo, hi - lo)); }
-    }
+    const c8p_pkt_out* outs = res->outs.data();      // fused mode (downloaded behind the kernels)
+    const uint8_t* pdu = res->pdu.data();
+    const uint64_t pdu_base = 0;
     for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = tags[p];
       if (t.status != C8P_ST_OK) continue;          // DEMOD_S_CLEAN without tags: nothing reaches decode
@@ -363,13 +515,15 @@ private:
           const int len = pdu[off] | (pdu[off + 1] << 8);
           pdu_t m;
           m.len = len;
-          m.blob.assign(pdu.begin() + (std::ptrdiff_t)off + 2, pdu.begin() + (std::ptrdiff_t)off + 2 + len);
+          m.blob.assign(pdu + off + 2, pdu + off + 2 + len);
           off += 2 + (size_t)len;
           f.pdus.push_back(std::move(m));
         }
         f.n_crc_fail = po.n_crc_fail;
         const long id = g_fused_next.fetch_add(1);
-        { std::lock_guard<std::mutex> g(g_fused_mu); g_fused[id] = std::move(f); }
+        d_fused_ids.push_back(id);
+        if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
+        fused_park(id, std::move(f));
         L("c8p_fused", id);
       }
       d_outq.push_back(std::move(o));
@@ -379,6 +533,7 @@ private:
 
   int drain(float* out, int noutput_items)
   {
+    sub_scope ph(d_ph, phase_clock::DRAIN);
     int produced = 0;
     while (!d_outq.empty() && produced < noutput_items) {
       out_pkt& o = d_outq.front();
@@ -386,6 +541,7 @@ private:
         for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
       const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
       if (o.llr) memcpy(out + produced, o.llr + o.sent, sizeof(float) * k);
+      else memset(out + produced, 0, sizeof(float) * k);     // fused mode: the items exist, their values are zeros (not stale memory)
       o.sent += k; produced += (int)k;
       if (o.sent == o.n) d_outq.pop_front();
     }
@@ -393,6 +549,8 @@ private:
   }
 
   enum { S_RDTAG, S_COLLECT } d_state = S_RDTAG;
+  std::mutex d_mu;                                 // general_work / flush (scheduler thread) against the latency timer's thread
+  phase_clock d_ph;
   engine_holder d_eng;
   int d_nports, d_mupos, d_mugid;
   c8p_pkt_in d_cur;
@@ -400,7 +558,11 @@ private:
   stage d_st[2];
   int d_fill = 0;                                  // the stage being gathered; the other one may be in flight
   std::vector<std::shared_ptr<result>> d_pool;
+  size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;
   std::deque<out_pkt> d_outq;
+  std::vector<long> d_fused_ids;                   // handles this front parked in g_fused (the last 64k-128k of them)
+  bool d_was_pending = false;
+  latency_timer d_timer;                           // last member: its thread uses everything above
 };
 
 demod::sptr demod::make(int mupos, int mugid) { return make(mupos, mugid, default_api(), batching_cfg()); }
@@ -664,12 +826,18 @@ class decode_front : public decode
 {
 public:
   decode_front(bool ifdebug, const c8p_api& api, const batching_cfg& cfg)
-      : d_eng(api, cfg), d_debug(ifdebug), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)}
+      : d_eng(api, cfg), d_debug(ifdebug), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)},
+        d_timer(d_mu, [this](tick_t& w) { return next_deadline(w); }, [this] { age_check(); })
   {
     memset(d_vhtMcsCount, 0, sizeof(d_vhtMcsCount));
     memset(d_legacyMcsCount, 0, sizeof(d_legacyMcsCount));
     memset(d_htMcsCount, 0, sizeof(d_htMcsCount));
+    if (cfg.flush_when_idle) d_timer.start();       // (its results are messages: published from the timer thread, no call needed)
   }
+  ~decode_front() override { d_timer.stop(); }
+
+  std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
+  void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
 
   void forecast(int noutput_items, gr_vector_int& req) override   // decode_impl.cc:54-58
   {
@@ -679,6 +847,9 @@ public:
   int general_work(int /*noutput_items*/, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& /*output_items*/) override
   {
+    std::lock_guard<std::mutex> g(d_mu);
+    if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
+    phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     const float* in = static_cast<const float*>(input_items[0]);
     const int nproc = ninput_items[0];
     int used = 0;
@@ -724,13 +895,27 @@ public:
     }
     if (d_eng.d_cfg.flush_when_idle) age_check();
     d_io->consume_each(std::min(used, nproc));
+    const bool pending = !d_st[d_fill].tags.empty() || d_st[d_fill ^ 1].ticket != 0;
+    if (pending && !d_was_pending) d_timer.poke();
+    d_was_pending = pending;
     return 0;
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_st[d_fill].tags.empty()) submit(true);
     else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+  }
+
+  bool next_deadline(tick_t& when)     // see demod_front
+  {
+    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    bool have = false;
+    if (!d_st[d_fill].tags.empty()) { when = d_st[d_fill].t_first + w; have = true; }
+    const stage& fl = d_st[d_fill ^ 1];
+    if (fl.ticket && (!have || fl.t_submit + w < when)) { when = fl.t_submit + w; have = true; }
+    return have;
   }
 
   void age_check()           // see demod_front::age_check
@@ -743,12 +928,14 @@ public:
 
 private:
   struct stage {
-    explicit stage(const c8p_api* a) : llr(a) {}
+    explicit stage(const c8p_api* a) : llr(a), outs(a), pdu(a) {}
     pinned_vec<float> llr;
     std::vector<c8p_pkt_tags> tags;
     std::vector<gr_complex> mu;
     int ticket = 0;
     tick_t t_first, t_submit;
+    pinned_vec<c8p_pkt_out> outs;     // downloads enqueued at submit time, right behind the kernels: collect() only waits
+    pinned_vec<uint8_t> pdu;          // (the whole fixed-stride PDU arena: ~1 MB per 256 packets)
   };
 
   void submit(bool last)
@@ -761,15 +948,35 @@ private:
       part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
       part_mu.assign(st.mu.end() - 128, st.mu.end());
     }
+    if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_decode_in b;
     memset(&b, 0, sizeof(b));
     b.n_pkt = (int32_t)st.tags.size(); b.mem = C8P_MEM_HOST; b.tags = st.tags.data();
     if (st.llr.empty()) *st.llr.grow(1) = 0.f;
     b.llr = st.llr.data(); b.n_llr = st.llr.size();
     b.mu2x1chan = reinterpret_cast<const c8p_c32*>(st.mu.data());
-    d_eng.check(d_eng.d_api.decode(d_eng.d_ctx, &b), "decode");
-    st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
-    st.t_submit = now_tick();
+    {
+      sub_scope ph(d_ph, phase_clock::SUBMIT);
+      d_eng.check(d_eng.d_api.decode(d_eng.d_ctx, &b), "decode");
+      st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
+      st.t_submit = now_tick();
+    }
+    {
+      sub_scope ph(d_ph, phase_clock::ENQ);
+      const c8p_api& A = d_eng.d_api;
+      uint64_t pbytes = 0;
+      A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
+      {
+        const size_t full = (size_t)std::max(d_eng.d_cfg.max_batch, 1), np = std::max<size_t>(st.tags.size(), 1);
+        d_hwm_pdu = std::max<size_t>(d_hwm_pdu, (pbytes + np - 1) / np * full);
+      }
+      st.outs.reserve((size_t)std::max(d_eng.d_cfg.max_batch, (int)st.tags.size()));
+      st.pdu.reserve(d_hwm_pdu);
+      st.outs.resize_uninit(st.tags.size());
+      st.pdu.resize_uninit(pbytes);
+      d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.outs.data(), 0, st.tags.size() * sizeof(c8p_pkt_out)), "outs");
+      if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.pdu.data(), 0, pbytes), "pdu");
+    }
     stage& prev = d_st[d_fill ^ 1];
     if (prev.ticket) collect(prev);
     if (last) collect(st);
@@ -788,14 +995,14 @@ private:
     const c8p_api& A = d_eng.d_api;
     c8p_ctx* ctx = d_eng.d_ctx;
     const size_t n = st.tags.size();
-    d_eng.check(A.select(ctx, st.ticket), "select");
-    std::vector<c8p_pkt_out> outs(n);
-    d_eng.check(A.fetch(ctx, C8P_BUF_OUT, outs.data(), 0, n * sizeof(c8p_pkt_out)), "fetch out");          // waits for the batch
-    uint64_t lo = ~0ull, hi = 0;
-    for (const c8p_pkt_out& o : outs)
-      if (o.n_pdu > 0) { lo = std::min<uint64_t>(lo, o.pdu_off); hi = std::max<uint64_t>(hi, o.pdu_off + o.pdu_bytes); }
-    std::vector<uint8_t> pdu;
-    if (hi > lo) { pdu.resize(hi - lo); d_eng.check(A.fetch(ctx, C8P_BUF_PDU, pdu.data(), lo, hi - lo), "fetch pdu"); }
+    {
+      sub_scope ph(d_ph, phase_clock::WAIT);
+      d_eng.check(A.wait(ctx, st.ticket), "wait");
+    }
+    const c8p_pkt_out* outs = st.outs.data();
+    const uint8_t* pdu = st.pdu.data();
+    const uint64_t lo = 0;
+    sub_scope phr(d_ph, phase_clock::REPLAY);
     for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = st.tags[p];
       const c8p_pkt_out& o = outs[p];
@@ -804,7 +1011,7 @@ private:
         const int len = pdu[off] | (pdu[off + 1] << 8);
         pdu_t m;
         m.len = len;
-        m.blob.assign(pdu.begin() + (std::ptrdiff_t)off + 2, pdu.begin() + (std::ptrdiff_t)off + 2 + len);
+        m.blob.assign(pdu + off + 2, pdu + off + 2 + len);
         off += 2 + (size_t)len;
         if (t.trellis != 0) debug_line(t, true);
         d_io->message_port_pub("out", m);
@@ -858,6 +1065,8 @@ private:
   }
 
   enum { S_IDLE, S_COLLECT } d_state = S_IDLE;
+  std::mutex d_mu;                                 // general_work / flush against the latency timer's thread
+  phase_clock d_ph;
   engine_holder d_eng;
   bool d_debug;
   c8p_pkt_tags d_cur;
@@ -866,6 +1075,9 @@ private:
   stage d_st[2];
   int d_fill = 0;
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
+  size_t d_hwm_pdu = 0;
+  bool d_was_pending = false;
+  latency_timer d_timer;                           // last member: its thread uses everything above
 };
 
 decode::sptr decode::make(bool ifdebug) { return make(ifdebug, default_api(), batching_cfg()); }

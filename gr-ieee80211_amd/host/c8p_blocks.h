@@ -77,6 +77,10 @@ public:
   virtual void consume_each(int n) = 0;
   virtual void message_port_pub(const std::string& port, const pdu_t& msg) = 0;
   virtual void debug_print(const std::string& line) = 0;     // the reference's `dout` (std::cout when ifdebug)
+  // Called from the front's latency timer (another thread) when results became ready while no input was arriving: get the
+  // scheduler to call general_work() again — forecast() then asks for no input, so the call is made even though there is none.
+  // (A gr::block does it by posting a message to a port of its own, which wakes its scheduler thread.)
+  virtual void wake() {}
 };
 
 // the C ABI the blocks call; defaults to the symbols of libc8p_rx.so, tests inject another table
@@ -108,7 +112,9 @@ struct batching_cfg {
   int detect_items = 1 << 20;   // detect: raw items gathered per c8p_detect call
   bool flush_when_idle = true;  // submit a partial batch once its oldest packet has waited max_wait_us (bounds latency in a live
                                 // flowgraph; a saturated one fills whole batches between two checks and is never cut short)
-  int max_wait_us = 1000;       // checked at the end of every general_work call (the scheduler calls as long as items arrive)
+  int max_wait_us = default_max_wait_us();   // 1000, or the environment's C8P_MAX_WAIT_US; checked at the end of every general_work call AND by a timer thread of the front: the scheduler
+                                // never calls a block that has no input, and demod's input is bursty (signal emits items only
+                                // during packets), so without the timer the last packets of a burst would wait for the next one
   int device = 0;
   // Fused demod -> decode (default: environment C8P_FUSED=1).  When both mirrors sit in one flowgraph the float LLR stream
   // between them only exists to carry packets from one block to the next; in fused mode `demod` runs c8p_rx (demod + decode on
@@ -117,6 +123,7 @@ struct batching_cfg {
   // Tags, item counts, PDU bytes and debug lines are unchanged; anything else that reads the LLR items must not use it.
   bool fused = default_fused();
   static bool default_fused();
+  static int default_max_wait_us();
 };
 
 class c8p_block
@@ -128,6 +135,9 @@ public:
                            gr_vector_void_star& output_items) = 0;
   // end of stream: submit whatever is buffered (a live flowgraph never calls this)
   virtual void flush() = 0;
+  // where the host side of this block spent its time, in microseconds since it was made: "name=us;..." (tools/bench_blocks.py)
+  virtual std::string host_phase_us() { return std::string(); }
+  virtual void host_phase_reset() {}
   void set_io(block_io* io) { d_io = io; }
 
 protected:

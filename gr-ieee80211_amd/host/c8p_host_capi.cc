@@ -29,7 +29,10 @@ struct harness : public block_io {
   void advance(int q, size_t items)
   {
     in_pos[q] += items * isz(q);
-    if (in_pos[q] > (1u << 22) && in_pos[q] * 2 > in[q].size()) { in[q].erase(in[q].begin(), in[q].begin() + (long)in_pos[q]); in_pos[q] = 0; }
+    // consumed items are dropped in bulk, rarely: a scheduler's circular buffer costs nothing per item, and an erase here is a
+    // memmove of everything still unread (tens of megabytes in a throughput run: 2-3 us per packet of the chain when done at 4 MB)
+    if (in_pos[q] == in[q].size()) { in[q].clear(); in_pos[q] = 0; }
+    else if (in_pos[q] > (1u << 28) && in_pos[q] * 2 > in[q].size()) { in[q].erase(in[q].begin(), in[q].begin() + (long)in_pos[q]); in_pos[q] = 0; }
   }
   bool tags_sorted = true;
   std::vector<tag_t> in_tags;                   // port 0, absolute offsets
@@ -55,13 +58,20 @@ struct harness : public block_io {
     for (; it != in_tags.end() && it->offset < b; ++it) v.push_back(*it);
   }
   void push_tag(const tag_t& t) { if (!in_tags.empty() && t.offset < in_tags.back().offset) tags_sorted = false; in_tags.push_back(t); }
+  void push_tag(tag_t&& t) { if (!in_tags.empty() && t.offset < in_tags.back().offset) tags_sorted = false; in_tags.push_back(std::move(t)); }
   void add_item_tag(unsigned, uint64_t off, const std::string& key, const tag_value& val) override
   {
     tag_t t; t.offset = off; t.key = key; t.value = val; out_tags.push_back(t);
   }
   void consume_each(int n) override { consumed_this_call = n; }
-  void message_port_pub(const std::string&, const pdu_t& m) override { msgs.push_back(m); }
-  void debug_print(const std::string& s) override { dbg.push_back(s); }
+  void message_port_pub(const std::string&, const pdu_t& m) override { std::lock_guard<std::mutex> g(msg_mu); msgs.push_back(m); }
+  void debug_print(const std::string& s) override { std::lock_guard<std::mutex> g(msg_mu); dbg.push_back(s); }
+  // the front's latency timer asks for a call (results became ready while no input was arriving)
+  void wake() override { { std::lock_guard<std::mutex> g(wake_mu); woken = true; } wake_cv.notify_all(); }
+  std::mutex msg_mu, wake_mu;
+  std::condition_variable wake_cv;
+  bool woken = false;
+  std::string phases;
 };
 
 } // namespace
@@ -187,17 +197,20 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
 {
   harness* A = static_cast<harness*>(pa);
   harness* B = static_cast<harness*>(pb);
-  struct piece { std::vector<float> items; std::vector<tag_t> tags; };
+  // As between two GNU Radio blocks, an item crosses the edge with ONE write (A's general_work, straight into the buffer) and ONE
+  // read (B's general_work, straight out of it): buffers travel through the queue and back through a free list, nothing is copied
+  // in between.  (The first version copied every piece twice more; at 57 KB of LLRs per packet that was a third of the chain's time.)
+  struct piece { std::vector<float> items; size_t n = 0; std::vector<tag_t> tags; };
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<piece> q;
+  std::deque<std::unique_ptr<piece>> q, pool;
   bool a_done = false, failed = false;
   long calls_a = 0, calls_b = 0;
   const size_t fpi = std::max<size_t>(A->out_size / sizeof(float), 1);
   std::thread ta([&] {
     try {
-      std::vector<float> obuf((size_t)std::max(nout, 1) * fpi);
       int idle = 0;
+      std::unique_ptr<piece> cur;
       while (idle < 4) {
         size_t avail = A->avail(0);
         for (int qq = 1; qq < A->nports; qq++) avail = std::min(avail, A->avail(qq));
@@ -205,7 +218,12 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         gr_vector_int nin(A->nports, n);
         gr_vector_const_void_star ins(A->nports);
         for (int qq = 0; qq < A->nports; qq++) ins[qq] = A->rd(qq);
-        gr_vector_void_star outs(1, obuf.data());
+        if (!cur) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!pool.empty()) { cur = std::move(pool.front()); pool.pop_front(); }
+        }
+        if (!cur) { cur.reset(new piece()); cur->items.resize((size_t)std::max(nout, 1) * fpi); }
+        gr_vector_void_star outs(1, cur->items.data());
         A->consumed_this_call = 0;
         const size_t tags_before = A->out_tags.size();
         const int produced = A->blk->general_work(nout, nin, ins, outs);
@@ -214,11 +232,10 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         A->n_read += A->consumed_this_call;
         A->n_written += produced;
         if (produced > 0) {
-          piece pc;
-          pc.items.assign(obuf.begin(), obuf.begin() + (size_t)produced * fpi);
-          pc.tags.assign(A->out_tags.begin() + (std::ptrdiff_t)tags_before, A->out_tags.end());
+          cur->n = (size_t)produced * fpi;
+          cur->tags.assign(std::make_move_iterator(A->out_tags.begin() + (std::ptrdiff_t)tags_before), std::make_move_iterator(A->out_tags.end()));
           A->out_tags.resize(tags_before);
-          { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(pc)); }
+          { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(cur)); }
           cv.notify_one();
         }
         idle = (produced == 0 && A->consumed_this_call == 0) ? idle + 1 : 0;
@@ -229,42 +246,116 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
     cv.notify_one();
   });
   try {
-    int idle = 0;
-    while (idle < 4) {
+    std::vector<float> dummy(16);
+    gr_vector_void_star outs(1, dummy.data());
+    std::vector<float> carry;                      // items B left unconsumed at the end of a piece (it never does: kept for safety)
+    for (;;) {
+      std::unique_ptr<piece> pc;
       bool fin;
       {
         std::unique_lock<std::mutex> lk(mu);
-        if (B->avail(0) == 0) cv.wait(lk, [&] { return !q.empty() || a_done; });
-        while (!q.empty()) {
-          piece& pc = q.front();
-          const uint8_t* b = reinterpret_cast<const uint8_t*>(pc.items.data());
-          B->in[0].insert(B->in[0].end(), b, b + pc.items.size() * sizeof(float));
-          for (const tag_t& t : pc.tags) B->push_tag(t);
-          q.pop_front();
-        }
-        fin = a_done;
+        cv.wait(lk, [&] { return !q.empty() || a_done; });
+        if (!q.empty()) { pc = std::move(q.front()); q.pop_front(); }
+        fin = a_done && !pc;
       }
-      const size_t avail = B->avail(0);
-      const int n = (int)std::min<size_t>(avail, (size_t)chunk);
-      if (n == 0 && !fin) continue;
-      gr_vector_int nin(1, n);
-      gr_vector_const_void_star ins(1, B->rd(0));
-      std::vector<float> dummy(16);
-      gr_vector_void_star outs(1, dummy.data());
+      if (fin) break;
+      for (tag_t& t : pc->tags) B->push_tag(std::move(t));
+      pc->tags.clear();
+      const float* base = pc->items.data();
+      size_t n = pc->n;
+      if (!carry.empty()) { carry.insert(carry.end(), base, base + n); base = carry.data(); n = carry.size(); }
+      size_t pos = 0;
+      int stuck = 0;
+      while (pos < n && stuck < 2) {
+        const int k = (int)std::min<size_t>(n - pos, (size_t)chunk);
+        gr_vector_int nin(1, k);
+        gr_vector_const_void_star ins(1, base + pos);
+        B->consumed_this_call = 0;
+        B->blk->general_work(0, nin, ins, outs);
+        calls_b++;
+        pos += (size_t)B->consumed_this_call;
+        B->n_read += B->consumed_this_call;
+        stuck = B->consumed_this_call == 0 ? stuck + 1 : 0;
+      }
+      std::vector<float> rest(base + pos, base + n);
+      carry.swap(rest);
+      { std::lock_guard<std::mutex> g(mu); pool.push_back(std::move(pc)); }
+    }
+    // the producer is done and everything it made was offered: a few dry calls, then end of stream
+    for (int idle = 0; idle < 4; idle++) {
+      gr_vector_int nin(1, (int)carry.size());
+      gr_vector_const_void_star ins(1, carry.data());
       B->consumed_this_call = 0;
       B->blk->general_work(0, nin, ins, outs);
       calls_b++;
-      B->advance(0, (size_t)B->consumed_this_call);
       B->n_read += B->consumed_this_call;
-      if (fin) {
-        idle = (B->consumed_this_call == 0) ? idle + 1 : 0;
-        if (idle == 2 && avail == 0) B->blk->flush();
-      }
+      carry.erase(carry.begin(), carry.begin() + B->consumed_this_call);
+      if (idle == 1) B->blk->flush();
     }
   } catch (const std::exception& e) { B->err = e.what(); failed = true; }
   ta.join();
   return failed ? -1 : calls_a + calls_b;
 }
+
+// A LIVE scheduler: general_work is only ever called when the block's forecast() is satisfied — i.e. never with zero input items
+// unless the block itself asks for nothing (results waiting for output space) — and nothing flushes at the end.  After the input
+// is used up the loop idles like a flowgraph whose source went quiet: it sleeps until the block's wake() or `linger_ms` have passed.
+// Returns the number of general_work calls, -1 on error.
+long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
+{
+  harness* h = static_cast<harness*>(p);
+  try {
+    long calls = 0;
+    const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);
+    std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
+    const auto t_end_idle = std::chrono::milliseconds(linger_ms);
+    auto idle_since = std::chrono::steady_clock::now();
+    for (;;) {
+      size_t avail = h->avail(0);
+      for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->avail(q));
+      gr_vector_int need(h->nports, 0);
+      h->blk->forecast(nout, need);
+      int want = 0;
+      for (int q = 0; q < h->nports; q++) want = std::max(want, need[q]);
+      const int n = (int)std::min<size_t>(avail, (size_t)chunk);
+      // (forecast(noutput) asks for noutput items like the reference; the scheduler halves noutput until the request fits what
+      // the buffers hold, down to one item: the call is made as soon as there is ANY input)
+      if (want > 0 && n == 0) {
+        std::unique_lock<std::mutex> lk(h->wake_mu);
+        if (!h->woken) {
+          if (std::chrono::steady_clock::now() - idle_since >= t_end_idle) break;
+          h->wake_cv.wait_for(lk, std::chrono::milliseconds(1));
+        }
+        h->woken = false;
+        continue;
+      }
+      gr_vector_int nin(h->nports, n);
+      gr_vector_const_void_star ins(h->nports);
+      for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
+      gr_vector_void_star outs(1, obuf.data());
+      if (h->nout == 2) outs.push_back(obuf1.data());
+      h->consumed_this_call = 0;
+      const int produced = h->blk->general_work(nout, nin, ins, outs);
+      calls++;
+      for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
+      h->n_read += h->consumed_this_call;
+      if (h->capture) {
+        h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
+        if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
+      }
+      h->n_written += produced;
+      if (produced || h->consumed_this_call) idle_since = std::chrono::steady_clock::now();
+      else if (want == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (asked for a call and did nothing: do not spin)
+    }
+    return calls;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return -1;
+  }
+}
+
+void c8ph_host_phase_reset(void* p) { static_cast<harness*>(p)->blk->host_phase_reset(); }
+const char* c8ph_host_phase_us(void* p) { harness* h = static_cast<harness*>(p); h->phases = h->blk->host_phase_us(); return h->phases.c_str(); }
 
 const char* c8ph_error(void* p) { return static_cast<harness*>(p)->err.c_str(); }
 

@@ -6,7 +6,7 @@
 #include "c8p_rx.h"
 #include "c8p_oracle.h"
 
-#define SLOTS 4     /* like the engine: the results of the last 4 demod / decode / rx submits stay resident (c8p_ticket / c8p_select) */
+#define SLOTS 3     /* like the engine's default: the results of the last 3 demod / decode / rx submits stay resident (c8p_ticket / c8p_select) */
 struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
 struct c8p_ctx {
   c8p_c32* det_x; uint64_t det_n, det_commit; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */

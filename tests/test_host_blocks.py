@@ -403,3 +403,52 @@ def test_chain_on_two_threads_on_gpu(fused):
     msgs, dbg = _chain_threads(None, pk, iq, chan, 1, 8, fused)
     assert msgs == ref[2]
     assert dbg == ref[3]
+
+
+# ---------------------------------------------------------------------------------------------- a live scheduler (no dry calls, no flush)
+def test_a_burst_comes_out_without_further_input_and_without_flush():
+    """The GNU Radio scheduler never calls a block that has no input, and demod's input is bursty (signal emits items only during
+    packets).  A burst of fewer packets than max_batch must still come out — LLR items + tags from demod, PDUs from decode — within
+    a few max_wait_us, although no further item ever arrives and nobody calls flush(): the fronts' latency timer submits and
+    collects, demod asks the scheduler for a call through block_io::wake() and its forecast() then needs no input."""
+    b, _ = sweep_batch(snr_db=None, seed=2)
+    pk, iq, chan = split(b, 1)
+    pk = pk[:5]
+    ref = oracle_rx(pk, iq, chan)
+    n_llr = sum(len(r["llr"]) for r in ref if r["tags"]["status"] == 0)
+    want = [(len(x), x) for r in ref for x in r["pdus"]]
+    assert n_llr > 0 and len(want) >= 4
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=256)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run_live(chunk=1024, nout=4096, linger_ms=200)            # no dry call is ever made, nothing is flushed
+    llr, tags = dem.output(), dem.tags()
+    assert len(llr) == n_llr                                       # everything came out although max_batch was never reached
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=256)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run_live(chunk=1024, nout=4096, linger_ms=200)
+    assert dec.messages() == want
+    ph = dem.host_phase_us()
+    assert set(ph) == {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain"} and ph["cut_and_stage"] >= 0
+    dem.close(); dec.close()
+
+
+def test_live_scheduler_equals_the_flushed_run_on_a_long_stream():
+    """the same stream through run_live (calls only with input, timer-driven tail) and through run (dry calls + flush): same items, tags, PDUs"""
+    b, _ = sweep_batch(snr_db=25.0, seed=4)
+    pk, iq, chan = split(b, 1)
+    outs = []
+    for live in (False, True):
+        dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=8)
+        blocks.feed_demod(dem, pk, iq, chan)
+        (dem.run_live(chunk=3000, nout=5000, linger_ms=100) if live else dem.run(chunk=3000, nout=5000))
+        llr, tags = dem.output(), dem.tags()
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=8)
+        dec.push_items(0, llr)
+        for off, key, val in tags:
+            dec.push_tag(off, key, val)
+        (dec.run_live(chunk=3000, nout=5000, linger_ms=100) if live else dec.run(chunk=3000, nout=5000))
+        outs.append((llr, [(o, k, v if not isinstance(v, np.ndarray) else v.tobytes()) for o, k, v in tags], dec.messages()))
+        dem.close(); dec.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
