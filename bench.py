@@ -42,8 +42,10 @@ def main():
     ap.add_argument("--fixture-workload", action="store_true", help="replicate the 4 committed reference-TX frames (host-generated) "
                     "instead of generating 4096 distinct packets on the device with c8p_tx")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg4", "cfg1", "cfg3", "cfg4r", "cfg5u0", "cfg5u1"), default="cfg2",
                     help="cfg2: BASELINE configs[1], one 4096-packet batch per GPU and step (weak scaling; the headline). "
+                         "cfg1 / cfg3 / cfg4r / cfg5u0 / cfg5u1: the same measurement on another BASELINE config resident in HBM (profiling: "
+                         "tools/profile_gpu.sh takes the PMC passes of the two-stream kernel with cfg3); the line then names that config. "
                          "cfg4: BASELINE configs[3], ONE 65536-packet VHT MCS8 stream held by rank 0, scattered over the ranks, "
                          "decoded, results gathered device-resident (strong scaling); without the flag it is reported as the extra "
                          "object `sharded_stream` of the cfg2 line")
@@ -113,12 +115,18 @@ def main():
     else:
         # 4096 distinct MPDUs, generated on the box by the build's own transmitter (c8p_tx), per-packet
         # flat-channel phase + AWGN on the device, c8p_signal to the signal -> demod boundary
-        pk, iq_dev, chan_dev, expected, _keep = cfg2_workload_on_device(args.batch, args.snr, 100000 * rank, torch, dev, local)
+        from c8p_cases import WORKLOADS, workload_on_device
+        kind = {"cfg4r": "cfg4"}.get(args.workload, args.workload)
+        pk, iq_dev, chan_dev, expected, _keep = workload_on_device(kind, args.batch, args.snr, 100000 * rank, torch, dev, local)
         iq, chan = None, None
         data_note = ("synthetic (c8p_tx on the device, distinct payloads; clean OFDM symbols: the reference toolbox's half-amplitude symbol edges "
                      "are not applied — C8P_TX_NO_WINDOW, DESIGN.md §6 — AWGN + random-phase flat channel)")
     n_pkt = len(pk)
     t_gen = time.time() - t_gen
+    other = args.workload != "cfg2"        # not the headline config: algorithmic bytes from the batch itself (SURVEY §8d formula)
+    global B_ALG
+    if other:
+        B_ALG = float(np.mean(8.0 * pk["n_ant"] * pk["n_items"] + 512 + 32) + np.mean([len(e) for e in expected]))
 
     # engine-owned streams: consecutive batches are software-pipelined across C8P_SLOTS slots (upload / classify /
     # symbol demod of batch i+1 overlap the decoder of batch i); eng.sync() joins all of them
@@ -138,8 +146,9 @@ def main():
     eng.sync()
     res = eng.results(want_llr=False)
     rng_flags, flt_blocks, _ = eng.decstat()       # decoder diagnostics: packets sent to the clamp-exact kernel, float-compare blocks
+    trellis = int(np.median(eng.tags()["trellis"]))
     dec_path = {"exact_kernel_packets": int(rng_flags.sum()), "float_step_block_fraction":
-                float(flt_blocks[rng_flags == 0].sum()) / max(1, int((rng_flags == 0).sum()) * (11960 // 30))}
+                float(flt_blocks[rng_flags == 0].sum()) / max(1, int((rng_flags == 0).sum()) * (trellis // 30))}
     n_ok = 0
     for r, e in zip(res, expected):
         if r["pdus"] and not args.no_check:
@@ -225,15 +234,16 @@ def main():
         traffic, traffic_src, traffic_step = pmc_traffic(dom)
         vals = sorted(n_pkt * world * args.steps / e for e in rep_elapsed)
         out = {
-            "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": value, "unit": "packets/s",
+            "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)" if not other else "RX packets/s (NOT the headline config: %s)" % WORKLOADS[kind][8],
+            "value": value, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": data_note if not args.no_check else "INVALID (--no-check experiment)",
             "repeats": {"n": len(rep_elapsed), "value_median": value, "value_min": vals[0], "value_max": vals[-1],
                         "timed_region_ms": [round(1e3 * e, 3) for e in rep_elapsed],
                         "note": "each repeat times exactly --steps steps between barriers; value / ms_per_step are the median repeat"},
-            "config": {"workload": "BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU, %d packets/GPU/step, "
-                                   "AWGN %.0f dB, random-phase flat channel, TX without the toolbox's symbol-edge windowing" % (n_pkt, args.snr),
+            "config": {"workload": ("BASELINE configs[1]: VHT MCS7 64-QAM r=5/6 SISO, 1458-byte MPDU" if not other else "BASELINE " + WORKLOADS[kind][8]) +
+                                   ", %d packets/GPU/step, AWGN %.0f dB, random-phase flat channel, TX without the toolbox's symbol-edge windowing" % (n_pkt, args.snr),
                        "packets_per_gpu_per_step": n_pkt, "fcs_ok_fraction": n_ok / max(n_pkt, 1), "decoder_path": dec_path,
                        "parallelism": "packet-sharded x%d, no data-path collective" % world},
             # frac = the algorithmic bytes of a step / ms_per_step: the dominant kernel's EXCLUSIVE launch (one batch alone, its 4 waves per
@@ -254,7 +264,7 @@ def main():
                                  "pipelined_avg_launch_ms = events on every %d-th launch inside the timed region, where the launches of "
                                  "%s batches overlap (not a per-launch cost)" % (PROFILE_EVERY, os.environ.get("C8P_SLOTS", "3"))},
         }
-        rv = valu_roofline(kern_x, n_pkt, dec_path["float_step_block_fraction"])
+        rv = None if other else valu_roofline(kern_x, n_pkt, dec_path["float_step_block_fraction"])
         if rv:
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:

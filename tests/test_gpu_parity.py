@@ -681,9 +681,10 @@ def test_traceback_hints_save_the_second_walk(eng):
     res = eng.results(want_llr=False)
     outs = eng.outs()
     assert sum(r["pdus"] == [e] for r, e in zip(res, expected)) >= 250
-    passes = outs["rsv"]
+    passes, refetched = outs["rsv"] & 0xff, outs["rsv"] >> 8       # (k_finish's diagnostics: passes, survivor blocks fetched after the first)
     assert (passes >= 1).all()
     assert (passes == 1).mean() > 0.8, np.bincount(passes)
+    assert refetched.sum() <= 0.03 * len(outs) * (11960 // 30 + 1), (refetched.sum(), refetched.max())   # re-read: a few blocks per wrong hint
 
 @pytest.mark.parametrize("snr_db", [30.0, 14.0, 6.0])
 def test_both_rx_flavours_agree_on_random_formats_lengths_and_noise(snr_db):

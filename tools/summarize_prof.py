@@ -63,6 +63,25 @@ for k in sorted(counters):
         if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c and avg(c["SQ_WAVE_CYCLES"]) > 0:
             extra += "; VALU-busy share of a wave's lifetime = %.3f" % (avg(c["SQ_ACTIVE_INST_VALU"]) / avg(c["SQ_WAVE_CYCLES"]))
         lines.append(extra)
+# the two-stream kernel on BASELINE configs[2] (cfg3_* passes of tools/profile_gpu.sh)
+c3 = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "cfg3_pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        c3[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if c3:
+    lines += ["", "BASELINE configs[2] (HT MCS15 2x2, 4096 packets per launch, bench.py --workload cfg3, C8P_SLOTS=1): average per launch",
+              "(42 966 algorithmic bytes per packet = 176 MB per launch; the LLR stream of this config would be 14 352 x 4 B x 4096 = 235 MB each way)"]
+    hbm["cfg3_kernels"] = {}
+    for k in sorted(c3):
+        c = c3[k]
+        if not k.startswith("k_"):
+            continue
+        fk, wk = avg(c.get("FETCH_SIZE", [])), avg(c.get("WRITE_SIZE", []))
+        hbm["cfg3_kernels"][k] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, **{n.lower(): avg(v) for n, v in c.items() if n not in ("FETCH_SIZE", "WRITE_SIZE")}}
+        lines.append("%s: FETCH x2 = %.1f MB, WRITE = %.1f MB, " % (k, fk * 2048 / 1e6, wk * 1024 / 1e6) +
+                     ", ".join("%s=%d" % (n, avg(c[n])) for n in sorted(c) if n not in ("FETCH_SIZE", "WRITE_SIZE")))
+for f in glob.glob(os.path.join(src, "cfg3_stats1", "**", "*kernel_stats.csv"), recursive=True):
+    open(os.path.join(dst, "kernel_stats_exclusive_cfg3.csv"), "w").write(open(f).read())
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm.json"), "w"), indent=1)
 open(os.path.join(dst, "pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
