@@ -197,6 +197,90 @@ def gen_mu(rng):
 
 
 
+def gen_mu_recorded():
+    """BASELINE configs[4] with the reference's RECORDED NDP captures (tools/cmu_chan0.bin, cmu_chan1.bin: the two VHT-LTF windows each
+    station received from the 2-antenna AP — the only data files the reference holds on this path; read as
+    tools/cmu_v4/cmu_ap_offline.py:82-95 reads them): feedback per station with the toolbox (procFftDemod -> procRmDcNonDataSc ->
+    procToneDescaling -> procRemovePilots -> procVhtChannelFeedback, as the offline script does, without its compress / quantise round
+    trip), zero-forcing Q by the cmu_v3 formula (tools/cmu_v3/cmu_ap.py:182-189; the v4 matmul path fails on numpy 2), 2-user MU
+    packet with genAmpduMu (MCS 3 / MCS 3, 100 / 60-byte MPDUs).  What each station then receives is computed HERE, through the
+    channel the captures themselves describe: per transmit chain c and subcarrier k, G_c[k] = (capture's LTF combination) / (what the
+    clean NDP puts there), interpolated over pilots / DC / guards, applied per OFDM symbol as a circular convolution (the model the
+    receiver's own estimate assumes; the legacy training fields are periodic, so the same holds for them).  Stored: the steering
+    matrices, both received streams, the MPDUs.  (With the impulse response cut to the guard interval instead, station 0 — whose chain-0
+    path is 14 dB below its chain-1 path in the recording — sees 4 dB of residual inter-user interference and cannot decode MCS 3:
+    the recording's estimation noise is then CSI error.)"""
+    cap = [np.fromfile(os.path.join(REF, "tools", "cmu_chan%d.bin" % u), np.complex64) for u in range(2)]
+    assert all(len(c) == 128 for c in cap)
+    rng = np.random.default_rng(8021555)
+    ndp = gen_packet("VHT", 0, 2, b"", rng)["tx"]
+    base = 160 + 160 + 80 + 160 + 80                       # L-STF, L-LTF, L-SIG, VHT-SIG-A, VHT-STF
+    win = lambda x, k: np.fft.fft(x[base + 80 * k + 8: base + 80 * k + 72])
+    clean = [[win(ndp[c], 0), win(ndp[c], 1)] for c in range(2)]
+    used = np.abs(clean[0][0]) > 1e-6
+    pil = np.zeros(64, bool); pil[[7, 21, 43, 57]] = True
+    data = used & ~pil
+    sc = np.where(np.arange(64) < 32, np.arange(64), np.arange(64) - 64).astype(float)
+    # stream separation of the 2 x 2 P matrix at the data tones: one chain appears in F1 + F2, the other in F1 - F2 (the clean NDP says which)
+    plus_is_chain0 = np.abs((clean[0][0] + clean[0][1])[data]).mean() > np.abs((clean[0][0] - clean[0][1])[data]).mean()
+
+    def per_chain(F1, F2):
+        return [F1 + F2, F1 - F2] if plus_is_chain0 else [F1 - F2, F1 + F2]
+    T = [per_chain(clean[c][0], clean[c][1])[c] for c in range(2)]
+    Gk = np.zeros((2, 2, 64), complex)                      # [station][chain][bin]
+    for u in range(2):
+        S = per_chain(np.fft.fft(cap[u][:64]), np.fft.fft(cap[u][64:]))
+        for c in range(2):
+            g = S[c][data] / T[c][data]
+            xs = sc[data]; idx = np.argsort(xs)
+            Gk[u, c] = np.interp(sc, xs[idx], g.real[idx]) + 1j * np.interp(sc, xs[idx], g.imag[idx])
+    vfb = []
+    for u in range(2):
+        ltfSym = [p8h.procRemovePilots(p8h.procToneDescaling(p8h.procRmDcNonDataSc(p8h.procFftDemod([complex(x) for x in cap[u][64 * k:64 * k + 64]]), p8h.F.VHT),
+                                                             p8h.C_SCALENTF_LTF_VHT[p8h.BW.BW20.value], 2)) for k in range(2)]
+        vfb.append(p8h.procVhtChannelFeedback(ltfSym, p8h.BW.BW20, 2, 1))
+    bfQ = []
+    for k in range(len(vfb[0])):
+        H11, H21 = vfb[0][k][0][0][0], vfb[0][k][0][0][1]
+        H12, H22 = vfb[1][k][0][0][0], vfb[1][k][0][0][1]
+        d1 = np.sqrt(abs(H21) ** 2 + abs(H11) ** 2)
+        d2 = np.sqrt(abs(H22) ** 2 + abs(H12) ** 2)
+        bfQ.append(np.array([[-1 * H22 / d2, -1 * H21 / d1], [H12 / d2, H11 / d1]]))
+    one = np.ones_like(bfQ[0])
+    bfQf = [one] * 4 + bfQ[0:28] + [one] + bfQ[28:56] + [one] * 3
+    m0, m1 = mpdu_bytes(rng, 100), mpdu_bytes(rng, 60)
+    ins = phy80211.phy80211(ifDebug=False)
+    ins.genAmpduMu(nUser=2, bfQ=bfQf, groupId=2,
+                   ampdu0=mac80211.genAmpduVHT([m0]), mod0=p8h.modulation(p8h.F.VHT, 3, p8h.BW.BW20, 1, False),
+                   ampdu1=mac80211.genAmpduVHT([m1]), mod1=p8h.modulation(p8h.F.VHT, 3, p8h.BW.BW20, 1, False))
+    mu_tx = np.array(ins.genFinalSig(multiplier=MULT * np.sqrt(2), cfoHz=0.0, num=1, gap=False, gapLen=0), np.complex64)
+    # undo the toolbox's half-amplitude symbol edges (as tests/c8p_cases.dewindow does), then the channel, symbol by symbol
+    txc = np.array(mu_tx, np.complex128)
+    for b in range(160, txc.shape[1], 80):
+        if b == 160 or b >= 320:
+            txc[:, b - 1] *= 2; txc[:, b] *= 2
+    n = txc.shape[1]
+    assert n % 80 == 0
+    rx = np.zeros((2, n + 320 + 160), complex)
+    for u in range(2):
+        y = np.zeros(n, complex)
+        for c in range(2):
+            # L-STF (period 16) and L-LTF (32 + 64 + 64, period 64): one period block through the channel, then the same extension
+            stf = np.fft.ifft(Gk[u, c] * np.fft.fft(txc[c][16:80]))
+            y[0:160] += np.concatenate([stf[-16:], stf, stf, stf[:16]])
+            lt = np.fft.ifft(Gk[u, c] * np.fft.fft(txc[c][192:256]))
+            y[160:320] += np.concatenate([lt[-32:], lt, lt])
+            for b in range(320, n, 80):
+                body = np.fft.ifft(Gk[u, c] * np.fft.fft(txc[c][b + 16:b + 80]))
+                y[b:b + 80] += np.concatenate([body[-16:], body])
+        rx[u, :n] = y
+    return {"rx0": rx[0].astype(np.complex64), "rx1": rx[1].astype(np.complex64), "mu_tx": mu_tx,
+            "g": Gk.astype(np.complex64), "bfq": np.array(bfQf, np.complex64),
+            "mpdu0": np.frombuffer(m0, np.uint8), "mpdu1": np.frombuffer(m1, np.uint8),
+            "pdu0": np.frombuffer(bytes([2, 100, 0]) + m0 + bytes([3]), np.uint8),
+            "pdu1": np.frombuffer(bytes([2, 60, 0]) + m1 + bytes([3]), np.uint8)}
+
+
 def gen_mu_tx():
     """2-user MU-MIMO transmit vectors (genAmpduMu) with a full-rank random steering matrix per subcarrier, so that
     every term of the spatial mapping is pinned: both chains' IQ, both users' punctured coded bits, the Q matrices in
@@ -237,6 +321,10 @@ def flat(prefix, d):
 
 
 def main():
+    if "--mu-recorded" in sys.argv:  # cfg 5 with the reference's recorded NDP captures (round 3); own seed, leaves the others untouched
+        np.savez_compressed(os.path.join(OUT, "packets_mu_recorded.npz"), **gen_mu_recorded())
+        print("packets_mu_recorded.npz written")
+        return
     if "--mu-tx" in sys.argv:       # added later than the other files; own seeds, leaves them untouched
         np.savez_compressed(os.path.join(OUT, "packets_mu_tx.npz"), **gen_mu_tx())
         print("packets_mu_tx.npz written")

@@ -842,3 +842,28 @@ def test_soak_full_size_batches_against_the_oracle_on_all_cores():
     e.close()
     print("soak: %d packets, %d PDUs, %d FCS failures, all equal to the oracle (%d host threads)" % (tot, n_ok, n_fail, cores))
     assert n_ok > 0.5 * tot and n_fail > 0.05 * tot, (tot, n_ok, n_fail)
+
+
+@pytest.mark.parametrize("snr", [None, 26.0, 14.0])
+def test_mu_mimo_recorded_ndp_captures_match_oracle(eng, snr):
+    """cfg 5 through the channels of the reference's recorded NDP captures (tests/golden/packets_mu_recorded.npz, see
+    test_oracle_golden.py): 24 noisy copies per station in one batch, both user positions; tags, LLRs, bits and PDUs equal to the oracle"""
+    z = np.load(os.path.join(GOLD, "packets_mu_recorded.npz"))
+    rng = np.random.default_rng(5)
+    b = Batch()
+    for k in range(24):
+        for u in range(2):
+            rx = z["rx%d" % u].astype(np.complex64)
+            if snr is not None:
+                sigma = np.sqrt(0.1875 ** 2 / (10 ** (snr / 10.0)))
+                rx = rx + (rng.normal(0, sigma / np.sqrt(2), rx.shape) + 1j * rng.normal(0, sigma / np.sqrt(2), rx.shape)).astype(np.complex64)
+            assert b.add_rx(rx[None, :], n_ant=1, mupos=u) >= 0
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    res = eng.results(want_bits=True)
+    ref = oracle_rx(pk, iq, chan)
+    n_pdu = compare(res, ref, LLR_TOL)
+    for p, (g, o) in enumerate(zip(res, ref)):
+        assert np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"]), p
+        assert g["pdus"] in ([], [z["pdu%d" % (p % 2)].tobytes()]), p
+    assert n_pdu >= (48 if snr != 14.0 else 0)
