@@ -448,6 +448,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
       const char* el = getenv("C8P_DECODE_LDS");     // tests: c8p_decode through the LDS-fed block loop of k_rx_1ss_lds
       if (!rx && el && atoi(el) != 0) {
         const uint8_t* d2 = nullptr;
+#ifdef C8P_EXPERIMENTS
         if (atoi(el) == 2 && n >= 2) {                // ... and pairs of alike packets through the two-packets-per-wave layout
           if ((rc = ensure(c, c->s->d_done4, (size_t)n + 4)) != C8P_OK) return rc;
           HIPCHK(c, hipMemsetAsync(c->s->d_done4.p, 0, (size_t)n, dst));
@@ -455,6 +456,9 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
                              (uint32_t*)c->s->d_flags.p, (uint8_t*)c->s->d_done4.p, n);
           d2 = (const uint8_t*)c->s->d_done4.p;
         }
+#else
+        if (atoi(el) == 2) { c->err = "C8P_DECODE_LDS=2 (two packets per wave) needs a -DC8P_EXPERIMENTS build (make -C gr-ieee80211_amd/csrc exp)"; return C8P_EINVAL; }
+#endif
         hipLaunchKernelGGL(k_viterbi_lean_lds, dim3((n + 3) / 4), dim3(256), 0, dst, d_tags, d_lay, d_llr, (ulonglong2*)c->s->d_surv.p,
                            (uint32_t*)c->s->d_flags.p, d2, n);
       }

@@ -313,7 +313,7 @@ __device__ __forceinline__ void lean_blocks(LeanState& S, const LeanK (&K)[6], u
   unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
   while (left > 0) {
     // integer compare: as many blocks as keep every metric above the bound
-#ifndef C8P_EXP_NO_INT
+#if !(defined(C8P_EXPERIMENTS) && defined(C8P_EXP_NO_INT))
     if (__ballot(S.pre < bound) == 0ull) {
       int sc = __builtin_amdgcn_readfirstlane(segc), lf = __builtin_amdgcn_readfirstlane(left);   // (asm "+s" operands: loop-carried values
       lean_blocks_int<CR>(S.pre, S.acc, K, init, flip, bound, sc, segn, S.voff, Lg + (size_t)(upto - lf) * NLB, sv, lf);   // must not pick up a VGPR copy)
@@ -507,28 +507,3 @@ __device__ __forceinline__ void lean4_int_consts(int l, unsigned& initx, unsigne
     if (q <= 3 && !((l >> q) & 1)) initx |= 1u << (31 - k);
   }
 }
-
-
-// ================================================================================================ two packets per wave
-// tools/gen_lean2_asm.py: a packet = 32 lanes x two registers, index D = (lane & 31) + 32 r in the role of the lane index; q = 4 is
-// the permlane16 swap (lane bit 4), q = 5 a register step.  Integer-compare loop only, LLRs from LDS (lean2_lds); float-step blocks
-// and the partial last block go through LDS into the lane = index layout (lean_block_flt_lds / lean_tail_l), one packet at a time.
-#include "c8p_lean2_asm.h"
-
-// lane constants: the coefficient pairs of index D = l (register 0); q = 4 in the arrangement the permlane swap needs (as
-// lean_k_consts does for q >= 4), the others plain; register 1's classes differ by a compile-time XOR (the generator's delta(q))
-__device__ __forceinline__ void lean2_k_consts(int l, LeanK (&K)[6])
-{
-#pragma unroll
-  for (int q = 0; q < 6; q++) {
-    const int nst = rotr6(l, (q + 1) % 6);
-    const int m = nst & 31, b = nst >> 5;              // b == bit q of l
-    const int cK = b ? sv_out(2 * m + 1, 1) : sv_out(2 * m, 0), cS = 3 - cK;
-    const int c1 = (q == 4 && b) ? cS : cK;
-    const int c2 = (q == 4 && b) ? cK : cS;
-    K[q].a = v2f{(c1 >> 1) ? 1.0f : 0.0f, (c2 >> 1) ? 1.0f : 0.0f};
-    K[q].b = v2f{(c1 & 1) ? 1.0f : 0.0f, (c2 & 1) ? 1.0f : 0.0f};
-    K[q].cls = 0;
-  }
-}
-

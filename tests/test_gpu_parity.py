@@ -644,8 +644,23 @@ def test_rx_hands_out_of_range_packets_to_the_exact_decoder(eng):
 def test_several_packets_per_wave_decoders(eng, monkeypatch, layout):
     """c8p_decode sends quads of consecutive packets with the same code rate and trellis length through k_viterbi_lean4 (16 lanes x 4
     registers per packet: tools/gen_lean4_asm.py), or pairs through k_viterbi_lean2_lds (32 lanes x 2 registers, LLRs from LDS:
-    tools/gen_lean2_asm.py; C8P_DECODE_LDS=2).  Streams with ties and positive drift (integer loop), packets that start with large
-    negative LLRs (leave and re-enter the loop), a partial last block; bits identical to the oracle for all four code rates."""
+    tools/gen_lean2_asm.py; C8P_DECODE_LDS=2 — an EXPERIMENT, compiled only into libc8p_rx_exp.so (-DC8P_EXPERIMENTS), so that leg
+    runs this test in a child process that loads that library through C8P_LIB).  Streams with ties and positive drift (integer loop),
+    packets that start with large negative LLRs (leave and re-enter the loop), a partial last block; bits identical to the oracle for
+    all four code rates."""
+    if layout == "two" and os.environ.get("C8P_LIB", "").find("libc8p_rx_exp") < 0:
+        import subprocess
+        import sys
+        from c8p_testlib import ROOT
+        exp = os.path.join(ROOT, "gr-ieee80211_amd", "libc8p_rx_exp.so")
+        assert os.path.exists(exp), "libc8p_rx_exp.so is not built (make -C gr-ieee80211_amd/csrc exp; __graft_entry__.build() does)"
+        if not eng.on_chip:
+            pytest.skip("one leg (the on-chip flavour) is enough for the experiments library")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                            os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_several_packets_per_wave_decoders"],
+                           env=dict(os.environ, C8P_LIB=exp), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
     if layout == "four":
         monkeypatch.setenv("C8P_LEAN4", "1")              # (by default only batches of >= 12288 packets take this kernel)
         monkeypatch.delenv("C8P_DECODE_LDS", raising=False)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/exp_clock.py [packets] — per-wave shader-cycle account of the lean Viterbi kernel (needs a library built with -DC8P_EXP_CLOCK:
+"""tools/exp_clock.py [packets] — per-wave shader-cycle account of the lean Viterbi kernel (needs a library built with -DC8P_EXPERIMENTS -DC8P_EXP_CLOCK:
 every decoder wave then leaves its s_memtime delta and its HW_ID / XCC_ID in C8P_BUF_DECSTAT instead of the statistics; C8P_LIB=<that build>).
 Prints cycles per trellis step per wave, how the waves were spread over the SIMDs, and in which order the waves of a SIMD finish.
 Results on MI355X: profiles/r2b/decoder_wave_cycles.txt."""
