@@ -92,3 +92,19 @@ def test_bindings_and_adapters_keep_names_and_signatures():
     for kept in ("trigger_impl.cc", "sync_impl.cc", "signal_impl.cc", "cloud80211phy.cc", "modulation2_impl.cc", "pad2_impl.cc"):
         assert kept in lib
     assert "C8P_MIRROR_NS=c8p" in lib and 'find_package(Gnuradio "3.10"' in open(os.path.join(GR, "CMakeLists.txt")).read()
+
+
+def test_adapters_type_check_against_the_gnu_radio_3_10_api_declarations():
+    """gnuradio/lib/{demod,demod2,decode}_impl.cc + c8p_gr_adapter.h, and the block mirror in namespace c8p next to them, through the
+    compiler: `g++ -fsyntax-only` against tests/gr_api_decls (DECLARATIONS of the GNU Radio 3.10 members the adapters use — see its
+    README; GNU Radio itself is not in the image, gnuradio/ci/build.sh is the real build).  Catches misspelt members, wrong argument
+    types, missing overrides and access errors (the scheduler calls are protected members of gr::block) here."""
+    decls = os.path.join(ROOT, "tests", "gr_api_decls")
+    inc = ["-I" + decls, "-I" + os.path.join(GR, "include"), "-I" + os.path.join(GR, "lib"), "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "gr-ieee80211_amd", "host")]
+    srcs = [os.path.join(GR, "lib", f) for f in ("demod_impl.cc", "demod2_impl.cc", "decode_impl.cc")] + \
+           [os.path.join(ROOT, "gr-ieee80211_amd", "host", "c8p_blocks.cc")]
+    for src in srcs:
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-DC8P_MIRROR_NS=c8p",
+                            "-Dgnuradio_ieee80211_EXPORTS"] + inc + [src], capture_output=True, text=True)
+        assert r.returncode == 0, src + "\n" + r.stderr[-4000:]
