@@ -338,7 +338,10 @@ struct Plan {
 
 // survivor slots (16 bytes each) of one packet: the clamp-exact kernel writes one slot per step, the lean kernel one
 // 256-byte block per 30 steps (8.5 bytes per step + the partial last block)
-static uint32_t surv_slots(uint32_t tcap) { return tcap + 17u; }
+// Rounded up to 16 slots = 256 bytes: every packet's survivor area then starts on a 256-byte boundary (the arena does), so a
+// 256-byte survivor block is exactly two 128-byte lines.  With areas starting at any 16-byte multiple a block straddled three lines:
+// the forward pass wrote partial lines and k_finish fetched up to half as many lines again (FETCH_SIZE 1.18-1.19 x the bytes written).
+static uint32_t surv_slots(uint32_t tcap) { return (tcap + 17u + 15u) & ~15u; }
 
 // PDU area of one packet.  A published (sub)frame of len bytes costs a record of len + 6 bytes ({u16 len}{format, len_lo, len_hi,
 // MPDU, mcs}) and consumed at least len + 4 bytes of the decoded stream (delimiter + MPDU padded to 4), at least 8 of them: the

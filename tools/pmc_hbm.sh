@@ -5,7 +5,7 @@
 set -u
 TAG=${1:-x}; OUT=gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  C8P_SLOTS=1 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python $PWD/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu --no-frontend --no-stream --no-host-legs > $OUT/$c.log 2>&1
+  C8P_SLOTS=1 rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python $PWD/bench.py --steps 3 --warmup 1 --repeats 1 --min-timed-s 0 --no-cpu --no-frontend --no-stream --no-host-legs --no-configs > $OUT/$c.log 2>&1
 done
 python - $OUT <<'P'
 import csv, glob, sys, collections
