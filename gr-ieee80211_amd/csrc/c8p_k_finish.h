@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= 64 * TS * 4, "bw must fit in the tile");
   const int p = blockIdx.x;
   if (p >= n) return;
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)   // experiment build (tools/exp_finclock.py): shader cycles per phase of this wave instead of the results
+  const unsigned long long exp_t0 = clock64();
+  unsigned long long exp_t1 = exp_t0, exp_t2 = exp_t0, exp_t3 = exp_t0;
+#endif
   const int lane = lane_id();
   const c8p_pkt_tags t = tags[p];
   const PktLayout Lp = lay[p];
@@ -234,6 +238,9 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
         tb_passes = it + 1;
         if (!__any(redo)) break;
       }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)
+      exp_t1 = clock64();
+#endif
       // ---- decoded bits: word c = times 64c .. 64c+63, gathered from the 6-bit group snapshots
       __syncthreads();
       const int ngrp = (Tn + 5) / 6;                       // (the tile is dead from here on: its memory becomes bw[])
@@ -274,6 +281,9 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       uint8_t* so = sbits_o + Lp.bits_off;
       for (int i = lane; i < Tn; i += 64) so[i] = (uint8_t)((bw[i >> 6] >> (i & 63)) & 1ull);
     }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)
+    exp_t2 = clock64();
+#endif
     // ---- descramble (decode_impl.cc:304-323)
     int state = 0;
     {
@@ -305,6 +315,9 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       uint8_t* uo = bits_o + Lp.bits_off;
       for (int i = lane; i < Tn; i += 64) uo[i] = (uint8_t)((bw[i >> 6] >> (i & 63)) & 1ull);
     }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)
+    exp_t3 = clock64();
+#endif
     // ---- packetAssemble (decode_impl.cc:325-520)
     if (t.format == C8P_F_VHT) {
       int procd = 16;
@@ -345,10 +358,17 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       }
     }
   }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)
+  const unsigned long long exp_t4 = clock64();
+#endif
   if (lane == 0) {
     c8p_pkt_out o;
     o.n_pdu = n_pdu; o.n_crc_fail = n_fail; o.pdu_bytes = used; o.rsv = (uint32_t)tb_passes | ((uint32_t)n_refetch << 8);   // diagnostics
     o.pdu_off = Lp.pdu_off; o.bits_off = Lp.bits_off;
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)
+    o.n_pdu = (int32_t)(exp_t1 - exp_t0); o.n_crc_fail = (int32_t)(exp_t2 - exp_t1); o.pdu_bytes = (uint32_t)(exp_t3 - exp_t2);
+    o.rsv = (uint32_t)(exp_t4 - exp_t3); o.bits_off = exp_t0;
+#endif
     outs[p] = o;
   }
 }
