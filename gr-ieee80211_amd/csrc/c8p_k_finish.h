@@ -79,7 +79,10 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                // arguments the seven values cost the traceback 25 spilled SGPRs)
                                                int mode, const FinCold* __restrict__ cold)
 {
-  constexpr int TS = 68;                                  // tile row stride in dwords (16-byte aligned rows, banks shifted by 4)
+  constexpr int TS = 64;                                  // tile row stride in dwords.  (68 — rows shifted by 4 banks — until round 3: without
+                                                          // the 1 KB of padding, tile + snapshots of a cfg-2 batch are 20.3 KB and EIGHT
+                                                          // workgroups share a CU's LDS instead of seven: 0.135 -> 0.129 ms; the staging writes'
+                                                          // bank conflicts cost less than the eighth wave brings)
   // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
   // memory holds bw[], the decoded bits packed 64 per word.
   __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
