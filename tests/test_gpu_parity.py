@@ -815,8 +815,9 @@ def test_device_generated_baseline_configs_match_oracle(eng, kind, snr):
 def test_soak_full_size_batches_against_the_oracle_on_all_cores():
     """Full-size batches of distinct packets through c8p_rx as it ships (the un-tapped default), EVERY packet compared with the oracle —
     status, tags, PDU bytes, failure counts — the oracle running one slice of the batch per host core (re-entrant C behind ctypes):
-    cfg 2 at 30 / 24 / 21 dB (from all frames delivered to most frames failing) and cfg 3 (two streams) at 28 / 20 dB.
-    C8P_SOAK_N = packets per batch (default 4096 for cfg 2, half of it for cfg 3)."""
+    cfg 2 at 30 / 24 / 21 dB (from all frames delivered to most frames failing), cfg 3 (two streams) at 28 / 20 dB, cfg 4 (256-QAM) at
+    33 / 26 dB, cfg 1 (legacy BPSK) at 4 dB, cfg 5 (MU-MIMO, both stations) at 14 dB.
+    C8P_SOAK_N = packets per batch (default 4096 for cfg 1 / 2, half of it for cfg 3 / 4, a quarter per MU station)."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
     from bench import usable_cores
@@ -826,7 +827,8 @@ def test_soak_full_size_batches_against_the_oracle_on_all_cores():
     cores = usable_cores()
     e = engine.Engine(device=0)
     tot = n_ok = n_fail = 0
-    for k, (kind, snr, m) in enumerate([("cfg2", 30.0, n), ("cfg2", 24.0, n), ("cfg2", 21.0, n), ("cfg3", 28.0, n // 2), ("cfg3", 20.0, n // 2)]):
+    for k, (kind, snr, m) in enumerate([("cfg2", 30.0, n), ("cfg2", 24.0, n), ("cfg2", 21.0, n), ("cfg3", 28.0, n // 2), ("cfg3", 20.0, n // 2),
+                                        ("cfg4", 33.0, n // 2), ("cfg4", 26.0, n // 2), ("cfg1", 4.0, n), ("cfg5u0", 14.0, n // 4), ("cfg5u1", 14.0, n // 4)]):
         pk, A, C_, exp, keep = workload_on_device(kind, m, snr, 1000003 * (k + 1), torch, torch.device("cuda", 0), 0)
         e.rx(pk, A, C_)
         e.sync()
