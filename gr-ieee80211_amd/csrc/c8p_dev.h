@@ -239,7 +239,9 @@ __device__ __forceinline__ float acs_step(float pre, int src0, int cA, int cB, f
   return cur;
 }
 
-// Short rate-1/2 decoder of the SIG fields (svSigDecoder::decode cloud80211phy.cc:2001-2088), L <= 48.
+// Short rate-1/2 decoder of the SIG fields (svSigDecoder::decode cloud80211phy.cc:2001-2088), L <= 48: the reference's recurrence
+// literally (clamp, NaN behaviour).  The kernels call wave_sig_viterbi (c8p_viterbi_lean.h), which takes the lean step when the LLRs allow
+// it and this function otherwise.
 // llr in LDS (2L floats), bits out to LDS; w1/w0: 49-entry scratch in LDS.
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)      // the same value in every lane -> SGPR pair
 {
@@ -248,8 +250,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
   return ((unsigned long long)hi << 32) | lo;
 }
 // Returns the decoded bits as a wave-uniform word (bit t = bit t) and leaves them in bits[] as bytes.
-__device__ __forceinline__ unsigned long long wave_sig_viterbi(const float* llr, uint8_t* bits, int L,
-                                                               unsigned long long* w1, unsigned long long* w0)
+__device__ __forceinline__ unsigned long long wave_sig_viterbi_exact(const float* llr, uint8_t* bits, int L,
+                                                                     unsigned long long* w1, unsigned long long* w0)
 {
   const int lane = lane_id();
   const int m = lane & 31, b = lane >> 5;

@@ -454,6 +454,54 @@ __device__ __forceinline__ void lean_tail_l(LeanState& S, const LeanK (&K)[6], c
   }
 }
 
+// ---- the SIG fields' rate-1/2 decoder on the lean step (round 3) -----------------------------------------------------------------
+// svSigDecoder::decode (cloud80211phy.cc:2001-2088) is the data decoder's recurrence at rate 1/2 over L = 24 (L-SIG), 48 (HT-SIG,
+// VHT-SIG-A) or 26 (VHT-SIG-B) steps, traced back from state 0.  The literal form (wave_sig_viterbi_exact: two ds_bpermute gathers, a
+// three-way select per candidate, two ballots per step) costs 31 VALU instructions per step and was 60 % of k_classify's instructions;
+// the lean step costs ~8 (lane = state under the rotating map, partner through DPP / permlane swap, decision into a per-lane shift
+// register) and is the same function for finite |LLR| <= 2^20 and L >= 6 (top of this file).  The LLRs are checked first; anything
+// else takes the literal form.  Decisions: step k in bit (29 - k) of accA for k < 30 when L > 30, else in bit (L - 1 - k) of acc.
+// Traceback on the scalar unit: the lane index D at time u + 1 spells input bit u in its bit (u mod 6) (state bit k lives in lane bit
+// (k + t) mod 6), and the predecessor's lane at time u is D with that bit replaced by the decision.
+__device__ __forceinline__ unsigned long long wave_sig_viterbi(const float* llr, uint8_t* bits, int L, unsigned long long* w1, unsigned long long* w0)
+{
+  const int lane = lane_id();
+  bool bad = false;
+  for (int i = lane; i < 2 * L; i += 64) bad |= bad_llr(llr[i]);
+  if (__ballot(bad) != 0ull || L < 6 || L > 60) return wave_sig_viterbi_exact(llr, bits, L, w1, w0);
+  LeanK K[6];
+  lean_k_consts(lane, K);
+  float pre = lane == 0 ? 0.0f : C8P_NEG_INIT;
+  unsigned acc = 0, accA = 0;
+  LeanPend pend{0u, 0u};
+  const int ngrp = L / 6, rem = L - 6 * ngrp;
+  for (int g = 0; g <= ngrp; g++) {
+    const int left = g < ngrp ? 6 : rem;               // steps of this group (the last one may be partial, or empty)
+    if (left == 0) break;
+    const int k = 12 * g + (lane < 12 ? lane : 0);
+    const float v = k < 2 * L ? llr[k] : 0.0f;         // lane i holds LLR i of the group: broadcast to the scalar operands of the steps
+    float x[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) x[i] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), i));
+    lean_steps<C8P_CR_12, 0, true, true>(pre, K, x, acc, pend, left);     // (every step settles its own decision at once)
+    if (g == 4) accA = acc;                            // 30 decisions: the shift register is full
+  }
+  int D = 0;
+  unsigned long long word = 0;
+  for (int u = L - 1; u >= 0; u--) {
+    const int q = u % 6;
+    word |= (unsigned long long)((D >> q) & 1) << u;
+    const bool first = L > 30 && u < 30;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)(first ? accA : acc), D);
+    const unsigned d = (a >> (first ? 29 - u : L - 1 - u)) & 1u;
+    D = (D & ~(1 << q)) | (int)(d << q);
+  }
+  __syncthreads();
+  if (lane < L) bits[lane] = (uint8_t)((word >> lane) & 1ull);
+  __syncthreads();
+  return word;
+}
+
 template <int CR> struct LeanRate { static constexpr int NLB = RateInfo<CR>::NL * (C8P_SV_BLK / RateInfo<CR>::PER); };
 
 // the whole forward pass of one packet whose LLRs are all there (k_viterbi_lean)

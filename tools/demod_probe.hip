@@ -42,3 +42,13 @@ extern "C" __global__ void p_sym(const cf* x, float* out, const DevTables* T, co
   negout[lane] = neg + (bad ? 1.f : 0.f);
   out[lane] = lb[lane];
 }
+extern "C" __global__ void p_sigvit(const float* llr_g, uint8_t* out, int L)
+{
+  __shared__ float llr[96];
+  __shared__ uint8_t bits[48];
+  __shared__ unsigned long long w1[49], w0[49];
+  for (int i = lane_id(); i < 96; i += 64) llr[i] = llr_g[i];
+  __syncthreads();
+  const unsigned long long w = wave_sig_viterbi(llr, bits, L, w1, w0);
+  if (lane_id() == 0) out[0] = (uint8_t)w;
+}
