@@ -209,24 +209,21 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
             } else {
               const uint32_t A = (hi >= 31 ? 0xffffffffu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
               const uint32_t* row = &tile[lane * TS];
+              // (Round 3 also walked TWO steps per LDS round trip — both candidate rows of the second step fetched with one
+              // ds_read2_b32, 15 instead of 30 dependent reads per block.  Bit-exact, and not faster: the wave waits for its tile loads,
+              // not for the walk (profiles/r3e/k_finish_wave_phases.txt) — while the selects cost 890 more VALU instructions per packet
+              // (19.1 M instead of 15.4 M per launch) in a step that is bound by VALU issue.  Back to one step per read.)
 #pragma unroll
               for (int g = 4; g >= 0; g--) {
                 if (A & (63u << (6 * g))) snaps[blk * 5 + g] = (uint8_t)D;
-                // TWO steps per LDS round trip.  Step k (phase q = k mod 6) replaces lane bit q by the decision found in row[D]; the
-                // next step, k - 1, reads row[D'] where D' differs from D in bit q at most — so both candidates, row[D with bit q = 0]
-                // and row[D with bit q = 1], are fetched together (one ds_read2_b32) and the second step selects.  The walk is a chain
-                // of dependent LDS reads (~100 cycles each, one wave per workgroup, 7 workgroups per CU): 15 instead of 30 per block.
 #pragma unroll
-                for (int q = 5; q >= 1; q -= 2) {
-                  const int k = 6 * g + q;                 // steps b0 + k (phase q) and b0 + k - 1 (phase q - 1)
-                  const uint32_t i0 = (uint32_t)D & ~(1u << q);
-                  const uint32_t w0 = row[i0], w1 = row[i0 + (1u << q)];
-                  const uint32_t own1 = ((uint32_t)D >> q) & 1u, own2 = ((uint32_t)D >> (q - 1)) & 1u;
-                  uint32_t d1 = ((own1 ? w1 : w0) >> (C8P_SV_BLK - 1 - k)) & 1u;       // decision bit (29 - k)
-                  d1 = ((A >> k) & 1u) ? d1 : own1;                                     // a step outside [lo, hi] leaves D alone
-                  uint32_t d2 = ((d1 ? w1 : w0) >> (C8P_SV_BLK - k)) & 1u;             // decision bit (29 - (k - 1)) of row[D']
-                  d2 = ((A >> (k - 1)) & 1u) ? d2 : own2;
-                  D = (int)(((uint32_t)D & ~(3u << (q - 1))) | (d1 << q) | (d2 << (q - 1)));
+                for (int q = 5; q >= 0; q--) {
+                  const int k = 6 * g + q;                 // step b0 + k moves lane bit q  ((b0 + k) % 6 == q)
+                  const uint32_t w = row[D];
+                  const uint32_t sel = ((A >> k) & 1u) << q;             // 0 for steps outside [lo, hi]
+                  const int sh = (C8P_SV_BLK - 1 - k) - q;               // decision bit (29 - k) -> bit q
+                  const uint32_t wq = sh >= 0 ? (w >> sh) : (w << -sh);
+                  D = (int)((wq & sel) | ((uint32_t)D & ~sel));
                 }
               }
             }

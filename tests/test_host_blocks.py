@@ -452,3 +452,57 @@ def test_live_scheduler_equals_the_flushed_run_on_a_long_stream():
         outs.append((llr, [(o, k, v if not isinstance(v, np.ndarray) else v.tobytes()) for o, k, v in tags], dec.messages()))
         dem.close(); dec.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_chain_with_a_single_engine_slot(fused, monkeypatch):
+    """C8P_SLOTS=1 (documented; tools/profile_gpu.sh uses it): the engine then keeps ONE submit's result arenas, so a front must collect
+    batch i before it submits batch i+1 instead of after — same PDUs as with the default three slots"""
+    b, _ = sweep_batch(snr_db=None, seed=6)
+    pk, iq, chan = split(b, 1)
+    res = []
+    for slots in ("1", "3"):
+        monkeypatch.setenv("C8P_SLOTS", slots)
+        dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=4, fused=fused)
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=4, fused=fused)
+        blocks.feed_demod(dem, pk, iq, chan)
+        blocks.run_chain(dem, dec, chunk=3000, nout=8192)
+        res.append(dec.messages())
+        dem.close(); dec.close()
+    assert res[0] == res[1] and len(res[0]) >= 20
+
+
+@pytest.mark.gpu
+def test_chain_with_a_single_engine_slot_on_gpu(monkeypatch):
+    monkeypatch.setenv("C8P_SLOTS", "1")
+    b, _ = sweep_batch(snr_db=None, seed=6)
+    pk, iq, chan = split(b, 1)
+    want = [(len(x), x) for r in oracle_rx(pk, iq, chan) for x in r["pdus"]]
+    for fused in (False, True):
+        dem = blocks.Block(blocks.DEMOD, max_batch=4, fused=fused)
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, max_batch=4, fused=fused)
+        blocks.feed_demod(dem, pk, iq, chan)
+        blocks.run_chain(dem, dec, chunk=3000, nout=8192)
+        assert dec.messages() == want, fused
+        dem.close(); dec.close()
+
+
+def test_a_burst_comes_out_in_fused_mode_without_further_input():
+    """the latency timer in fused mode (demod runs c8p_rx, decode publishes behind the handle tag): a 3-packet burst, no dry call, no flush"""
+    b, _ = sweep_batch(snr_db=None, seed=2)
+    pk, iq, chan = split(b, 1)
+    pk = pk[:3]
+    want = [(len(x), x) for r in oracle_rx(pk, iq, chan) for x in r["pdus"]]
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=256, fused=True)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run_live(chunk=2048, nout=4096, linger_ms=200)
+    llr, tags = dem.output(), dem.tags()
+    assert len(llr) > 0 and not llr.any()                  # the items exist, their values are zeros
+    assert sum(1 for _, k, _ in tags if k == "c8p_fused") == sum(1 for r in oracle_rx(pk, iq, chan) if r["tags"]["status"] == 0)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=256, fused=True)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run_live(chunk=2048, nout=4096, linger_ms=100)
+    assert dec.messages() == want
+    dem.close(); dec.close()
