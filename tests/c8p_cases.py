@@ -139,6 +139,9 @@ WORKLOADS = {
     "cfg4": (2, 8, 1, 1, 1458, None, 0, 8021400, "configs[3] with the MCS8 substitution of SURVEY.md §7: VHT MCS8 256-QAM r=3/4 SISO, 1458-byte MPDU"),
     "cfg5u0": (3, 3, 2, 1, 100, H_MU[0:1], 0, 8021500, "configs[4]: VHT 2-user MU-MIMO (MCS3 / MCS3, 100 / 60-byte MPDUs, zero-forcing Q of the cmu_v3 formula), station 0"),
     "cfg5u1": (3, 3, 2, 1, 60, H_MU[1:2], 1, 8021500, "configs[4]: the same packets at station 1 (60-byte MPDUs)"),
+    # not BASELINE configs: random formats / MCS / lengths per packet (differential and soak tests)
+    "random1": (-1, 0, 1, 1, 0, None, 0, 8021700, "random legacy / HT / VHT, MCS and length (14-3000 bytes) per packet, one stream"),
+    "random2": (-2, 0, 2, 2, 0, H22, 0, 8021800, "random HT MCS 8-15 / VHT 2 x MCS 0-8 and length (14-3000 bytes) per packet, two streams on two antennas"),
 }
 
 
@@ -167,8 +170,13 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
         arena.append(np.frombuffer(b, np.uint8))
         off += len(b)
         return off - len(b)
+    fmt_cfg = fmt
     for p in range(n):
         rng = np.random.default_rng(seed_base + seed + p)
+        if fmt_cfg < 0:                                    # random1 / random2: this packet's own format, rate and length
+            fmt = int(rng.integers(0, 3)) if fmt_cfg == -1 else int(rng.integers(1, 3))
+            mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
+            mlen = int(rng.integers(14, 3000))
         lens = (100, 60) if fmt == 3 else (mlen,)
         mpdus = []
         for ln in lens:
@@ -183,6 +191,7 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
             mu[p]["psdu_off"], mu[p]["len"], mu[p]["mcs"], mu[p]["group_id"], mu[p]["q_off"] = put(ps[1]), len(ps[1]), mcs, 2, 0
         m = mpdus[mupos]
         exp.append(bytes([min(fmt, 2), len(m) % 256, len(m) // 256]) + m + bytes([mcs + 8 if (fmt == 1 and nchain == 2) else mcs]))
+    fmt = fmt_cfg
     bfq = None
     if fmt == 3:           # zero-forcing steering (tools/cmu_v3/cmu_ap.py:182-189): nulls the other user's stream at each station
         q = np.linalg.inv(np.asarray(H_MU, np.complex128))

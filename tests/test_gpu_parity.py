@@ -884,3 +884,58 @@ def test_mu_mimo_recorded_ndp_captures_match_oracle(eng, snr):
         assert np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"]), p
         assert g["pdus"] in ([], [z["pdu%d" % (p % 2)].tobytes()]), p
     assert n_pdu >= (48 if snr != 14.0 else 0)
+
+
+@pytest.mark.parametrize("kind,snr", [("random1", 24.0), ("random2", 27.0), ("random2", 15.0)])
+def test_random_packets_all_flavours_and_the_oracle(kind, snr):
+    """300 packets of random format, rate and length (14-3000 bytes) per packet — one stream (legacy / HT / VHT) or two streams on two
+    antennas (HT MCS 8-15, VHT 2 x MCS 0-8: k_rx_2ss_lds with rounds of 1 to 8 symbols, every constellation, all four code rates) —
+    through the three flavours of c8p_rx (default / arena kernels / default + tap): tags, bits, failure counts and PDUs identical,
+    tap LLRs bit-equal to the arena kernels'; the default's PDUs, tags and failure counts equal to the oracle's on EVERY packet
+    (the oracle on all host cores); every published PDU is the transmitted MPDU."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from bench import usable_cores
+    from c8p_cases import workload_on_device
+    n = int(os.environ.get("C8P_SOAK_N", "300"))
+    pk, A, C_, exp, keep = workload_on_device(kind, n, snr, 4242, torch, torch.device("cuda", 0), 0)
+    assert len(pk) >= 0.9 * n
+    res = []
+    for flavour in (0, 1, 2):
+        e = engine.Engine(device=0, keep_bits=True, keep_llr=flavour)
+        e.rx(pk, A, C_)
+        res.append(e.results(want_llr=flavour > 0, want_bits=True))
+        e.close()
+    n_pdu = n_fail = 0
+    for p, (a, b, c) in enumerate(zip(*res)):
+        for x in (b, c):
+            assert a["tags"].tobytes() == x["tags"].tobytes(), p
+            assert a["out"]["n_pdu"] == x["out"]["n_pdu"] and a["out"]["n_crc_fail"] == x["out"]["n_crc_fail"], p
+            assert a["pdus"] == x["pdus"], p
+            assert np.array_equal(a["sbits"], x["sbits"]) and np.array_equal(a["bits"], x["bits"]), p
+        assert np.array_equal(b["llr"], c["llr"]), p
+        assert a["pdus"] in ([], [exp[p]]), p
+        n_pdu += len(a["pdus"]); n_fail += int(a["out"]["n_crc_fail"])
+    iq, chan = _to_host(A), _to_host(C_)
+    o = oracle()
+    cores = usable_cores()
+    step = -(-len(pk) // cores)
+    with ThreadPoolExecutor(cores) as ex:
+        parts = list(ex.map(lambda s0: o.rx_batch(pk[s0:s0 + step], iq, chan), range(0, len(pk), step)))
+    p = 0
+    for t_o, o_o, pdu_o, _ in parts:
+        stride = len(pdu_o) // max(len(t_o), 1)
+        for j in range(len(t_o)):
+            g = res[0][p]
+            assert g["tags"]["status"] == t_o[j]["status"], p
+            for key in abi.TAG_KEYS + ("nsym", "nss"):
+                assert g["tags"][key] == t_o[j][key], (p, key)
+            assert g["out"]["n_pdu"] == o_o[j]["n_pdu"] and g["out"]["n_crc_fail"] == o_o[j]["n_crc_fail"], p
+            nb = int(o_o[j]["pdu_bytes"])
+            got = b"".join(len(x).to_bytes(2, "little") + x for x in g["pdus"])
+            assert got == pdu_o[j * stride:j * stride + nb].tobytes(), p
+            p += 1
+    assert p == len(pk)
+    print("%s at %.0f dB: %d packets, %d PDUs, %d FCS failures; three flavours identical, all equal to the oracle" % (kind, snr, len(pk), n_pdu, n_fail))
+    assert n_pdu > 0.3 * len(pk) if snr > 20 else n_fail > 0
+    del keep
