@@ -9,8 +9,8 @@ import os
 import numpy as np
 import pytest
 
-from c8p_cases import ampdu_vht, cfg2_batch, replicated_batch, sweep_batch
-from c8p_testlib import H22, load_npz
+from c8p_cases import ampdu_vht, cfg2_batch, dewindow, replicated_batch, sweep_batch
+from c8p_testlib import H22, load_npz, through_channel
 from c8p_smoke import compare
 from c8p_testlib import GOLD, Batch, abi, oracle, oracle_rx
 from gr_ieee80211_amd import engine
@@ -939,3 +939,33 @@ def test_random_packets_all_flavours_and_the_oracle(kind, snr):
     print("%s at %.0f dB: %d packets, %d PDUs, %d FCS failures; three flavours identical, all equal to the oracle" % (kind, snr, len(pk), n_pdu, n_fail))
     assert n_pdu > 0.3 * len(pk) if snr > 20 else n_fail > 0
     del keep
+
+
+@pytest.mark.parametrize("snr", [None, 24.0])
+def test_single_stream_packets_on_the_two_antenna_block(eng, snr):
+    """demod2 (rx2.grc) also receives every one-stream frame on the air — beacons, legacy and HT / VHT one-stream data: n_ant = 2, nss = 1
+    (demod2_impl's nSS = 1 branches use antenna 0).  The fused single-stream kernels take these packets (k_rx_2ss_lds only the
+    two-stream ones); in one batch with two-stream packets both kernels run.  Tags, LLRs, bits, PDUs equal to the oracle."""
+    rng = np.random.default_rng(12)
+    b = Batch()
+    n1 = n2 = 0
+    for fn in ("packets_sweep.npz", "packets_cfg.npz"):
+        for name, d in load_npz(fn).items():
+            if name == "VHT_NDP":
+                continue
+            nss = int(d["nss"])
+            Hc = H22 if nss == 2 else np.array([[1.0], [0.4 - 0.7j]], np.complex64)       # one stream seen by two antennas
+            rx = through_channel(np.atleast_2d(dewindow(d["tx"])), Hc, snr, rng)
+            if b.add_rx(rx, n_ant=2) >= 0:
+                n1 += nss == 1; n2 += nss == 2
+    assert n1 >= 25 and n2 >= 15
+    pk, iq, chan = b.arrays()
+    eng.rx(pk, iq, chan)
+    res = eng.results(want_bits=True)
+    ref = oracle_rx(pk, iq, chan)
+    n_pdu = compare(res, ref, LLR_TOL)
+    for p, (g, o) in enumerate(zip(res, ref)):
+        assert g["out"]["n_crc_fail"] == o["out"]["n_crc_fail"], p
+        if o["tags"]["status"] == abi.ST_OK and o["tags"]["trellis"] > 0:
+            assert np.array_equal(g["sbits"], o["sbits"]) and np.array_equal(g["bits"], o["bits"]), p
+    assert n_pdu >= 40
