@@ -20,6 +20,7 @@ TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_
     TAB_PILOT_P, TAB_LTF_NL, TAB_LTF_NL_VHT22 = range(9)
 DET_HIST = 80
 TX_NO_WINDOW = 1
+SIG_NEED_MORE, SIG_SKIPPED, SIG_PENDING = 1, 2, 3       # c8p_pkt_in.rsv[0] as c8p_signal writes it
 NDP_TOTAL = 1024
 NDP_BLOB_BYTES = 1027
 
@@ -63,7 +64,8 @@ class SigIn(C.Structure):
 
 
 class SignalIn(C.Structure):
-    _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64)]
+    _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64),
+                ("consume", C.c_int32), ("rsv", C.c_int32), ("pkt_host", C.c_void_p)]
 
 
 class SyncEvt(C.Structure):

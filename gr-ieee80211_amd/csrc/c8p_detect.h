@@ -1,14 +1,13 @@
 // c8p_detect.h — packet detection front end on gfx950: examples/presiso.grc (stock GNU Radio blocks)
 // -> lib/trigger_impl.cc -> lib/sync_impl.cc, restructured as scans over the raw 20 MS/s stream.
 //
-//   k_presiso      thread = 8 consecutive samples.  p[n] = x[n-16] conj(x[n]), windows of 48 (complex) and 64 (energy)
-//                  assembled from per-thread block sums + suffix sums staged in LDS: 13 + 15 LDS reads per 8 samples,
-//                  no re-summation.  HBM-bound: 8 B read + 4 B (ac) [+ 8 B conj when kept] written per sample.
-//                  The same kernel reduces its 1984 ac values to the tile summary of the plateau state machine
-//                  (whole tile above the threshold? trailing run: start, maximum).
-//   (tile carry)   every k_trig_apply workgroup looks back over the tile summaries for the run open at its tile start
-//   k_trig_apply   per sample: "ac > 0.3" and "new maximum of this plateau" (trigger bit 0x02) by a segmented
-//                  max-scan seeded with the carry; every plateau of >= 21 samples is appended to a candidate list
+//   k_detect_scan  ONE pass, thread = 8 consecutive samples.  p[n] = x[n-16] conj(x[n]), windows of 48 (complex) and 64
+//                  (energy) assembled from per-thread block sums + suffix sums staged in LDS: 13 + 15 LDS reads per 8
+//                  samples, no re-summation; per sample "ac > 0.3" and "new maximum of this plateau" (trigger bit 0x02)
+//                  by a segmented max-scan seeded with the state the earlier tiles leave behind (published tile
+//                  summaries, looked back over inside the launch); every plateau of >= 21 samples goes to the tile's
+//                  candidate list.  HBM-bound: 8 B read + 1 B written per sample; ac never leaves the chip.
+//   k_cand_offsets, k_cand_gather   the tiles' candidate lists concatenated in stream order
 //   (host)         trigger_impl's countdown logic over the (few) candidates, sync_impl's IDLE/SYNC alternation
 //   k_sync_mark    wave = accepted trigger: last "latch conj" mark the sync block saw, and the conj value there
 //   k_sync_evt     wave = accepted trigger: LTF autocorrelation over 111 offsets with the reference's running sums in
@@ -45,13 +44,6 @@ __device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& 
   else { o.tstart = L.tstart; o.tmax = fmaxf(L.tmax, R.tmax); }   // R entirely above and L ends inside a run: it continues
   return o;
 }
-__device__ __forceinline__ TrigSeg seg_of_sample(float a, long long idx)
-{
-  TrigSeg r;
-  const bool ab = a > C8P_AC_THR;                   // NaN (0/0 in silence) compares false, as in the reference
-  r.all = ab; r.tstart = ab ? idx : C8P_SEG_NONE; r.tmax = ab ? a : 0.f;
-  return r;
-}
 __device__ __forceinline__ TrigSeg seg_shfl_up(const TrigSeg& v, int d)
 {
   TrigSeg r;
@@ -73,39 +65,97 @@ __device__ __forceinline__ TrigSeg seg_wave_inclusive(TrigSeg v)
   }
   return v;
 }
-// exclusive prefix of `mine` over the threads of a workgroup (blockDim.x / 64 waves <= 16); `total` = all of them
-__device__ __forceinline__ TrigSeg seg_block_exclusive(TrigSeg mine, TrigSeg* sh /*[16]*/, TrigSeg& total)
-{
-  const int lane = lane_id(), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const TrigSeg inc = seg_wave_inclusive(mine);
-  if (lane == 63) sh[w] = inc;
-  __syncthreads();
-  TrigSeg pre = seg_identity();
-  total = seg_identity();
-  for (int k = 0; k < nw; k++) { if (k == w) pre = total; total = seg_combine(total, sh[k]); }
-  TrigSeg ex = seg_shfl_up(inc, 1);
-  if (lane == 0) ex = seg_identity();
-  __syncthreads();
-  return seg_combine(pre, ex);
-}
-
-// ------------------------------------------------------------------------------------------------ presiso
+// ------------------------------------------------------------------------------------------------ presiso + trigger scan
+// ONE pass over the raw stream: 8 B read and 1 B (trigger byte) written per sample; the autocorrelation stream `ac` that
+// presiso.grc hands to the trigger block stays in registers (it is stored only for tests, keep != 0).
+//
 // One workgroup = 256 blocks of 8 samples: blocks 0..7 only supply the 16-sample delay and the window history
-// (48 products = 6 blocks back, 64 energies = 8 blocks back), blocks 8..255 (248 blocks = 1984 samples) are written.  Global traffic is fully coalesced: samples enter
-// through LDS transposed ([sample % 8][block], row stride 264 = 8 mod 16 eight-byte banks: conflict-free both for the
-// coalesced writes and for "thread t reads row j, column t - m"), results leave the same way.
+// (48 products = 6 blocks back, 64 energies = 8 blocks back), blocks 8..255 (248 blocks = 1984 samples = one TILE) are
+// produced.  Global traffic is fully coalesced: samples enter through LDS transposed ([sample % 8][block], row stride
+// 264 = 8 mod 16 eight-byte banks: conflict-free both for the coalesced writes and for "thread t reads row j, column t - m").
+//
+// The plateau state machine of trigger_impl.cc:77-85 needs, at the start of a tile, the state everything before it leaves
+// behind.  Tiles take their number from a ticket counter (a tile's predecessors have all started), publish their own
+// summary as ONE 8-byte granule {valid, all-above, start of the trailing run inside the tile, its maximum} with an
+// agent-scope store BEFORE they look at anybody else's (no chain, no deadlock), and then read back over their
+// predecessors' granules, 64 per step, until a chunk holds a tile that is not entirely above the threshold — such a
+// tile fixes the state by itself — or the start of the segment (`init`).  Plateaus are a few hundred samples long: one
+// step, one or two granules awaited in practice; a 400 000-sample carrier walks 4 steps.
 #define C8P_PRE_HALO 8
 #define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
 #define C8P_PRE_RS 264
-// x points at the first NEW item; items x[-hist .. -1] exist (history before the commit point), x[g] = 0 for g < -hist
-__global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long long hist, unsigned long long n, float* __restrict__ ac,
-                                                 cf* __restrict__ conj, int keep, TrigSeg* __restrict__ summ, int x_aligned16)
+#define C8P_DET_TILE_CAND 96        // plateaus of >= 21 samples that can END inside one tile: ends lie >= 22 apart -> <= 91
+
+__device__ __forceinline__ unsigned long long seg_pack(const TrigSeg& v, long long tile0)
 {
-  __shared__ TrigSeg shs[16];
-  __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
-  __shared__ float sE[9 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
+  const unsigned rel = seg_has_run(v) ? (unsigned)(v.tstart - tile0) : 0xFFFu;     // a tile's own trailing run starts inside it
+  return (unsigned long long)__float_as_uint(v.tmax) | ((unsigned long long)rel << 32) | ((unsigned long long)(v.all ? 1u : 0u) << 44) | (1ull << 63);
+}
+__device__ __forceinline__ TrigSeg seg_unpack(unsigned long long g, long long tile0)
+{
+  TrigSeg r;
+  const unsigned rel = (unsigned)(g >> 32) & 0xFFFu;
+  r.all = (int)((g >> 44) & 1u);
+  r.tmax = __uint_as_float((unsigned)g);
+  r.tstart = rel == 0xFFFu ? C8P_SEG_NONE : tile0 + (long long)rel;
+  return r;
+}
+__device__ __forceinline__ TrigSeg seg_bcast(const TrigSeg& v, int src)
+{
+  TrigSeg r;
+  r.all = __shfl(v.all, src, 64);
+  r.tmax = __shfl(v.tmax, src, 64);
+  const int lo = __shfl((int)(unsigned)(unsigned long long)v.tstart, src, 64);
+  const int hi = __shfl((int)(unsigned)((unsigned long long)v.tstart >> 32), src, 64);
+  r.tstart = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  return r;
+}
+// wave 0 of a workgroup: the state at the start of `tile` (lane L of a step looks at tile base - 64 + L).
+// WAIT = false: every granule is known to be there (a later launch).  *gave_up is set when a granule did not arrive within
+// C8P_DET_SPINS polls (~tens of ms: a tile's predecessor is normally some microseconds away); the result is then meaningless
+// and the host repeats the launch with ticket numbering, under which a tile never waits for one that has not started.
+#define C8P_DET_SPINS (1 << 15)
+template <bool WAIT>
+__device__ __forceinline__ TrigSeg trig_lookback(const unsigned long long* __restrict__ summ, long long tile, const TrigSeg& init,
+                                                 unsigned int* __restrict__ gave_up)
+{
+  const int lane = lane_id();
+  TrigSeg acc = seg_identity();                       // tiles [base, tile)
+  for (long long base = tile; ; base -= 64) {
+    if (base <= 0) return seg_combine(init, acc);
+    const long long t = base - 64 + lane;
+    unsigned long long g = 0;
+    if (!WAIT) { if (t >= 0) g = summ[t]; }
+    else for (int spin = 0; ; spin++) {
+      // granules are polled with agent-scope loads (they bypass this CU's L1); a granule carries its own valid bit, so no
+      // ordering against other data is needed.  Enough = every tile from the nearest one that is not entirely above the
+      // threshold up to `tile` is there (or all 64, if this chunk has none).
+      if (t >= 0 && !(g >> 63)) g = __hip_atomic_load(summ + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long have = __ballot(t < 0 || (g >> 63));
+      const unsigned long long stop = __ballot(t >= 0 && (g >> 63) && !((g >> 44) & 1u));
+      if (have == ~0ull) break;
+      if (stop) {
+        const int j = 63 - __builtin_clzll(stop);      // nearest such tile that has published
+        if ((have >> j) == (~0ull >> j)) break;        // and everything nearer than it
+      }
+      if (spin >= C8P_DET_SPINS) { if (lane == 0) atomicOr(gave_up, 1u); return seg_identity(); }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool ok = t >= 0 && (g >> 63);               // (granules further back than the deciding tile may be missing: ignored by the combine)
+    const TrigSeg chunk = seg_bcast(seg_wave_inclusive(ok ? seg_unpack(g, t * C8P_DET_TILE) : seg_identity()), 63);
+    acc = seg_combine(chunk, acc);
+    if (!chunk.all) return acc;                        // independent of anything earlier (seg_combine with R.all == 0)
+  }
+}
+
+// x points at the first NEW item; items x[-hist .. -1] exist (history before the commit point), x[g] = 0 for g < -hist.
+// One tile's window sums: thread tid (>= C8P_PRE_HALO) gets P (48 products) and E (64 energies) of its 8 samples
+// base + 8 tid .. + 7; returns `base`.
+__device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long long hist, unsigned long long n, long long tile, int x_aligned16,
+                                                  cf* sX, float* sE, cf (&Pv)[8], float (&Ev)[8])
+{
   const int tid = threadIdx.x;
-  const long long blk0 = (long long)blockIdx.x * C8P_PRE_OUT_BLOCKS - C8P_PRE_HALO;   // first block of this workgroup
+  const long long blk0 = tile * C8P_PRE_OUT_BLOCKS - C8P_PRE_HALO;   // first block of this workgroup
   const long long base = blk0 * 8;
   if (x_aligned16 && base >= -hist && base + 2048 <= (long long)n) {
     // interior workgroup: 16-byte loads, thread tid takes samples base + 2 tid + 512 k and the next one (base is a
@@ -144,8 +194,6 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
     for (int j = 7; j >= 0; j--) { s = cadd(s, p[j]); se += e[j]; sX[j * C8P_PRE_RS + tid] = s; sE[j * C8P_PRE_RS + tid] = se; }
   }
   __syncthreads();
-  float acv[8];
-  cf Pv[8];
   if (tid >= C8P_PRE_HALO) {
     cf cp = mk(0.f, 0.f);
     float ce = 0.f;
@@ -158,32 +206,192 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       pre = cadd(pre, p[j]); pe += e[j];
-      const cf P = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);   // tail of block b-6 + blocks b-5..b-1 + head of block b
-      const float E = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
-      // correctly rounded sqrt and quotient (-fhip-fp32-correctly-rounded-divide-sqrt), i.e. IEEE sqrtf(.) / e as VOLK + blocks_divide_ff compute it: ac feeds
-      // hard comparisons (ac > 0.3, ac > running maximum, trigger_impl.cc:77-85), so given the same window sums the trigger
-      // bytes are those of the scalar CPU restatement bit for bit (tests/test_detect_frontend.py: integer-valued torture stream straddling 0.3)
-      acv[j] = sqrtf(P.x * P.x + P.y * P.y) / E;
-      Pv[j] = P;
+      Pv[j] = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);        // tail of block b-6 + blocks b-5..b-1 + head of block b
+      Ev[j] = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) { Pv[j] = mk(0.f, 0.f); Ev[j] = 0.f; }
+    if (tid == C8P_PRE_HALO - 1) {
+      // the item just before the tile, with the operations and the order in which the previous tile's last thread forms it
+      // (its j = 7: whole blocks b-1 .. b-5 resp. b-7, an empty tail, the whole own block front to back)
+      cf cp = mk(0.f, 0.f), pre = mk(0.f, 0.f);
+      float ce = 0.f, pe = 0.f;
+#pragma unroll
+      for (int m = 1; m <= 5; m++) cp = cadd(cp, sX[tid - m]);
+#pragma unroll
+      for (int m = 1; m <= 7; m++) ce += sE[tid - m];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { pre = cadd(pre, p[j]); pe += e[j]; }
+      Pv[7] = cadd(cadd(cp, mk(0.f, 0.f)), pre);
+      Ev[7] = (ce + 0.f) + pe;
     }
   }
-  {                                         // tile summary for the plateau scan: ordered reduction of the 1984 samples
-    TrigSeg mine = seg_identity();
-    if (tid >= C8P_PRE_HALO) {
+  return base;
+}
+// presiso's output 0.  Correctly rounded sqrt and quotient (-fhip-fp32-correctly-rounded-divide-sqrt), i.e. IEEE sqrtf(.) / e as
+// VOLK + blocks_divide_ff compute it: ac feeds hard comparisons (ac > 0.3, ac > running maximum, trigger_impl.cc:77-85), so given
+// the same window sums the trigger bytes are those of the scalar CPU restatement bit for bit (tests/test_detect_frontend.py:
+// integer-valued torture stream straddling 0.3)
+__device__ __forceinline__ float ac_of(const cf P, const float E) { return sqrtf(P.x * P.x + P.y * P.y) / E; }
+// "certainly not above the threshold" without the square root and the quotient: |P|^2 < 0.08 E^2 means ac < 0.283 whatever the
+// roundings; anything else (NaN, an E^2 that overflows, a borderline value) takes the exact path.  Idle air and payload symbols
+// fail this test for whole waves, which then skip the two correctly rounded operations per sample.
+__device__ __forceinline__ bool ac_surely_below(const cf P, const float E)
+{
+  const float t = 0.08f * E * E;
+  return (P.x * P.x + P.y * P.y < t) && (t < __builtin_inff());
+}
+
+// in-tile scan element over a stretch of samples: position (tile-relative) of its last sample that is NOT above the threshold
+// (-1: none), and the maximum of ac over the samples after that one
+struct RunSeg { int pos; float tmax; };
+__device__ __forceinline__ RunSeg run_combine(const RunSeg& L, const RunSeg& R)
+{
+  RunSeg o;
+  o.pos = max(L.pos, R.pos);
+  o.tmax = R.pos >= 0 ? R.tmax : fmaxf(L.tmax, R.tmax);
+  return o;
+}
+
+// `numbering`: 0 = tiles are numbered by blockIdx.x (the hardware hands workgroups out in that order: a tile's predecessors have
+// started, which is all the look-back needs — HIP does not promise it, hence the watchdog in trig_lookback), 1 = by a ticket
+// counter (a promise, at the price of 16 910 same-address atomics per 33.5 M samples: 0.09 ms)
+#define C8P_CAND_OPEN_START C8P_SEG_IDENT      // TrigCand.s of "the run that was open when this (quiet) tile began": k_cand_gather fills it in
+__global__ __launch_bounds__(256) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+                                                     unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
+                                                     TrigSeg init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
+                                                     TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
+                                                     float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering)
+{
+  __shared__ TrigSeg s_cin;
+  __shared__ RunSeg s_w[4];
+  __shared__ unsigned s_tile, s_wc[4];
+  __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
+  __shared__ float sE[9 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
+  const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+  long long tile = blockIdx.x;
+  if (numbering) {
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = (long long)s_tile;
+  }
+  const long long tile0 = tile * C8P_DET_TILE;
+  cf Pv[8];
+  float acv[8];
+  const long long base = tile_windows(x, hist, n, tile, x_aligned16, sX, sE, Pv, acv);      // acv = the energies for now
+  const bool live = tid >= C8P_PRE_HALO;
+  const long long n0 = base + tid * 8;      // this thread's first sample
+  const int r0 = (tid - C8P_PRE_HALO) * 8;  // the same, relative to the tile
+  const int nv = live ? (int)min(8ll, max(0ll, (long long)n - n0)) : 0;     // how many of the 8 exist
+  const float e_prev = acv[7];               // (halo's last thread: the energy window of the item before the tile)
+  bool maybe = false;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const long long g = base + tid * 8 + j;
-        if (g >= 0 && (unsigned long long)g < n) mine = seg_combine(mine, seg_of_sample(acv[j], g));
+  for (int j = 0; j < 8; j++) maybe = maybe || (j < nv && !ac_surely_below(Pv[j], acv[j]));
+  unsigned m = 0;                            // bit j: sample j is above the threshold
+  if (keep || __ballot(maybe)) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) { acv[j] = ac_of(Pv[j], acv[j]); if (j < nv && acv[j] > C8P_AC_THR) m |= 1u << j; }   // NaN (0/0 in silence) compares false, as in the reference
+  }
+  if (keep) {                                // test path: ac leaves through sE, once every thread has read its window sums from it
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) sE[j * C8P_PRE_RS + tid] = acv[j];
+    }
+  }
+  const int tile_any = __syncthreads_or(m != 0);
+  const int nexist = (int)min((long long)C8P_DET_TILE, (long long)n - tile0);
+  if (!tile_any) {
+    // nothing above the threshold in this tile (idle air, payload): its summary is known at once and its trigger bytes are 0.
+    // It waits for nobody: the only plateau that can end here is one that lasted up to the item before the tile — the halo's last
+    // thread has that item's ac — and where it began is filled in by k_cand_gather.
+    if (nv == 8) *(unsigned long long*)(trig + n0) = 0ull;
+    else for (int j = 0; j < nv; j++) trig[n0 + j] = 0;
+    if (tid == C8P_PRE_HALO - 1) {
+      TrigSeg total; total.all = 0; total.tstart = C8P_SEG_NONE; total.tmax = 0.f;
+      __hip_atomic_store(summ + tile, seg_pack(total, tile0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool open = tile == 0 ? seg_has_run(init) : (ac_of(Pv[7], e_prev) > C8P_AC_THR);
+      if (open) { TrigCand k; k.s = C8P_CAND_OPEN_START; k.e = tile0; tcand[tile * C8P_DET_TILE_CAND] = k; }
+      tcount[tile] = open ? 1 : 0;
+      if (tile0 + nexist >= (long long)n) *fin = total;
+    }
+  } else {
+    // per-thread element, wave scan, then across the four waves
+    RunSeg mine; mine.pos = -1; mine.tmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (j < nv) { if ((m >> j) & 1u) mine.tmax = fmaxf(mine.tmax, acv[j]); else { mine.pos = r0 + j; mine.tmax = 0.f; } }
+    }
+    RunSeg inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      RunSeg u; u.pos = __shfl_up(inc.pos, d, 64); u.tmax = __shfl_up(inc.tmax, d, 64);
+      if (lane >= d) inc = run_combine(u, inc);
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    RunSeg ex; ex.pos = __shfl_up(inc.pos, 1, 64); ex.tmax = __shfl_up(inc.tmax, 1, 64);
+    if (lane == 0) { ex.pos = -1; ex.tmax = 0.f; }
+    RunSeg pre; pre.pos = -1; pre.tmax = 0.f;
+    RunSeg tot = pre;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (k == wv) pre = tot; tot = run_combine(tot, s_w[k]); }
+    ex = run_combine(pre, ex);
+    // the tile's summary: entirely above?  its trailing run (after the last sample that is not above), if the last sample is above
+    TrigSeg total;
+    total.all = tot.pos < 0;
+    total.tstart = tot.pos + 1 < nexist ? tile0 + tot.pos + 1 : C8P_SEG_NONE;
+    total.tmax = tot.pos + 1 < nexist ? tot.tmax : 0.f;
+    if (tid == 0) __hip_atomic_store(summ + tile, seg_pack(total, tile0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+      const TrigSeg c0 = trig_lookback<true>(summ, tile, init, ticket + 2);
+      if (tid == 0) {
+        s_cin = c0;
+        if (tile0 + nexist >= (long long)n) *fin = seg_combine(c0, total);      // the state at the end of the segment
       }
     }
-    TrigSeg total;
-    (void)seg_block_exclusive(mine, shs, total);     // (contains the barriers that also order the LDS reuse below)
-    if (tid == 0) summ[blockIdx.x] = total;
-  }
-  if (tid >= C8P_PRE_HALO) {
+    __syncthreads();
+    // walk the 8 samples with the plateau state: start of the run that is open (tile-relative, negative: it began before the
+    // tile) and its running maximum (d_conjAc, which restarts at 0 with every plateau: trigger_impl.cc:80-85)
+    const TrigSeg cin = s_cin;
+    const bool from_cin = ex.pos < 0 && seg_has_run(cin);
+    int rs = from_cin ? (int)max(cin.tstart - tile0, -(1ll << 30)) : ex.pos + 1;
+    float rmax = from_cin ? fmaxf(cin.tmax, ex.tmax) : ex.tmax;
+    unsigned long long packed = 0;
+    bool hasc = false;
+    TrigCand mc; mc.s = 0; mc.e = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) sE[j * C8P_PRE_RS + tid] = acv[j];
+    for (int j = 0; j < 8; j++) {
+      if (j < nv) {
+        const int g = r0 + j;
+        unsigned b = 0;
+        if ((m >> j) & 1u) {
+          b = 0x04;
+          if (acv[j] > rmax) { rmax = acv[j]; b |= 0x02; }
+          if (n0 + j == (long long)n - 1 && g + 1 - rs >= 21) {                 // still open at the end of the stream
+            hasc = true; mc.s = rs < 0 ? cin.tstart : tile0 + rs; mc.e = (long long)n;
+          }
+        } else {
+          if (g - rs >= 21) { hasc = true; mc.s = rs < 0 ? cin.tstart : tile0 + rs; mc.e = tile0 + g; }   // a plateau long enough to arm the countdown ended here
+          rs = g + 1; rmax = 0.f;
+        }
+        packed |= (unsigned long long)b << (8 * j);
+      }
+    }
+    if (nv == 8) *(unsigned long long*)(trig + n0) = packed;
+    else for (int j = 0; j < nv; j++) trig[n0 + j] = (uint8_t)(packed >> (8 * j));
+    // the tile's candidates in stream order: ends lie >= 22 samples apart, so a thread holds at most one
+    const unsigned long long bm = __ballot(hasc);
+    if (lane == 0) s_wc[wv] = (unsigned)__builtin_popcountll(bm);
+    __syncthreads();
+    unsigned rank = (unsigned)__builtin_popcountll(bm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; w++) rank += s_wc[w];
+    if (hasc) tcand[tile * C8P_DET_TILE_CAND + rank] = mc;
+    if (tid == 0) tcount[tile] = (uint8_t)(s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]);
   }
+  if (!keep) return;
+  // test / debug path only: presiso's two output streams
   __syncthreads();
   if (base >= 0 && base + 2048 <= (long long)n) {
     // interior workgroup: 16-byte stores, thread tid stores samples base + 4 tid + 1024 k .. +3 (base is a multiple of 8)
@@ -205,120 +413,90 @@ __global__ __launch_bounds__(256) void k_presiso(const cf* __restrict__ x, long 
       if ((i >> 3) >= C8P_PRE_HALO && (unsigned long long)g < n && g >= 0) ac[g] = sE[(i & 7) * C8P_PRE_RS + (i >> 3)];
     }
   }
-  if (keep && tid >= C8P_PRE_HALO) {        // test / debug path only
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const long long g = base + tid * 8 + j; if ((unsigned long long)g < n) conj[g] = Pv[j]; }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ trigger scan
-// one workgroup of 1024 threads: carry[t] = combine(init, summ[0..t-1]); carry[ntile] = the state after the last tile
-__device__ __forceinline__ TrigSeg seg_bcast(const TrigSeg& v, int src)
-{
-  TrigSeg r;
-  r.all = __shfl(v.all, src, 64);
-  r.tmax = __shfl(v.tmax, src, 64);
-  const int lo = __shfl((int)(unsigned)(unsigned long long)v.tstart, src, 64);
-  const int hi = __shfl((int)(unsigned)((unsigned long long)v.tstart >> 32), src, 64);
-  r.tstart = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-  return r;
-}
-// tile = the 1984 samples one k_presiso workgroup wrote; thread = 8 consecutive samples (threads 248..255 idle)
-// The plateau state at the start of a tile = the combination of everything before it.  A tile that is not entirely above the
-// threshold fixes that state by itself, so instead of a global scan kernel every workgroup looks BACK over the tile
-// summaries k_presiso wrote: 64 tiles per step (lane = tile, coalesced), until a chunk contains such a tile or the start of
-// the segment (`init`) is reached.  Plateaus are a few hundred samples long: one step in practice.
-__device__ __forceinline__ TrigSeg trig_lookback(const TrigSeg* __restrict__ summ, long long tile, const TrigSeg& init)
-{
-  const int lane = lane_id();
-  TrigSeg acc = seg_identity();                       // tiles [base, tile)
-  for (long long base = tile; ; base -= 64) {
-    if (base <= 0) return seg_combine(init, acc);
-    const long long t = base - 64 + lane;
-    const TrigSeg chunk = seg_bcast(seg_wave_inclusive(t >= 0 ? summ[t] : seg_identity()), 63);
-    acc = seg_combine(chunk, acc);
-    if (!chunk.all) return acc;                        // independent of anything earlier (seg_combine with R.all == 0)
-  }
-}
-
-__global__ __launch_bounds__(256) void k_trig_apply(const float* __restrict__ ac, unsigned long long n, const TrigSeg* __restrict__ summ,
-                                                    TrigSeg init, TrigSeg* __restrict__ fin,
-                                                    uint8_t* __restrict__ trig, TrigCand* __restrict__ cand,
-                                                    unsigned int* __restrict__ n_cand, unsigned int cap)
-{
-  __shared__ TrigSeg sh[16];
-  __shared__ TrigSeg s_cin;
-  float a[8];
-  const bool live = threadIdx.x < C8P_DET_TILE / 8;
-  const long long n0 = (long long)blockIdx.x * C8P_DET_TILE + threadIdx.x * 8;
-  TrigSeg mine = seg_identity();
   if (live) {
-    if ((unsigned long long)(n0 + 7) < n) {            // n0 * 4 bytes is 32-byte aligned
-      const float4 v0 = *(const float4*)(ac + n0), v1 = *(const float4*)(ac + n0 + 4);
-      a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
-    } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) a[j] = (unsigned long long)(n0 + j) < n ? ac[n0 + j] : 0.f;
-    }
+    for (int j = 0; j < 8; j++) if (j < nv) conj[n0 + j] = Pv[j];
+  }
+}
+
+// the per-tile candidate lists, concatenated in tile (= stream) order.  k_cand_offsets: one workgroup, a thread takes a
+// contiguous range of tiles (a multiple of 16: the counts are bytes, read 16 at a time; tcount is zero beyond ntile up to the
+// next multiple of 16) and writes where each tile's list goes; k_cand_gather: thread = tile, moves the list.
+__global__ __launch_bounds__(1024) void k_cand_offsets(const uint8_t* __restrict__ tcount, int ntile, unsigned int* __restrict__ toff,
+                                                       unsigned int* __restrict__ n_out)
+{
+  __shared__ unsigned wtot[16];
+  const int tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+  const int per = (((ntile + 1023) / 1024) + 15) & ~15;
+  const int t0 = min(ntile, tid * per), t1 = min(ntile, t0 + per);
+  unsigned mine = 0;
+  for (int t = t0; t < t1; t += 16) {
+    const uint4 v = *(const uint4*)(tcount + t);
+    // bytes <= 96: the byte lanes of a word add up without carries into each other
+    const unsigned q = (v.x & 0x00ff00ffu) + ((v.x >> 8) & 0x00ff00ffu) + (v.y & 0x00ff00ffu) + ((v.y >> 8) & 0x00ff00ffu)
+                     + (v.z & 0x00ff00ffu) + ((v.z >> 8) & 0x00ff00ffu) + (v.w & 0x00ff00ffu) + ((v.w >> 8) & 0x00ff00ffu);
+    mine += (q & 0xffffu) + (q >> 16);
+  }
+  unsigned inc = mine;
 #pragma unroll
-    for (int j = 0; j < 8; j++) if ((unsigned long long)(n0 + j) < n) mine = seg_combine(mine, seg_of_sample(a[j], n0 + j));
-  }
-  if (threadIdx.x < 64) {
-    const TrigSeg c0 = trig_lookback(summ, (long long)blockIdx.x, init);
-    if (threadIdx.x == 0) {
-      s_cin = c0;
-      if (blockIdx.x == gridDim.x - 1) *fin = seg_combine(c0, summ[blockIdx.x]);      // the state at the end of the segment
-    }
-  }
+  for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+  if (lane == 63) wtot[w] = inc;
   __syncthreads();
-  const TrigSeg cin = s_cin;
-  {
-    // idle air: nothing in the tile is above the threshold and no plateau is open at its start -> all bytes 0, no scan
-    bool anyab = false;
-    if (live) {
+  unsigned off = inc - mine, all = 0;
+  for (int k = 0; k < 16; k++) { if (k < w) off += wtot[k]; all += wtot[k]; }
+  if (tid == 0) *n_out = all;
+  for (int t = t0; t < t1; t += 16) {
+    const uint4 v = *(const uint4*)(tcount + t);
+    const unsigned wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int j = 0; j < 8; j++) anyab = anyab || (a[j] > C8P_AC_THR);    // a[j] = 0 past the end of the stream
-    }
-    if (!__syncthreads_or(anyab) && !seg_has_run(cin)) {
-      if (live) {
-        if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = 0ull;
-        else for (int j = 0; j < 8 && (unsigned long long)(n0 + j) < n; j++) trig[n0 + j] = 0;
-      }
-      return;
+    for (int b = 0; b < 16; b++) {
+      if (t + b < t1) toff[t + b] = off;
+      off += (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
     }
   }
-  TrigSeg total;
-  const TrigSeg ex = seg_block_exclusive(mine, sh, total);
-  if (!live) return;
-  const TrigSeg st = seg_combine(cin, ex);                 // everything before this thread's first sample
-  // walk the 8 samples with the plateau state: run start and running maximum
-  long long rs = seg_has_run(st) ? st.tstart : C8P_SEG_NONE;
-  float rmax = seg_has_run(st) ? st.tmax : 0.f;
-  unsigned long long packed = 0;
+}
+__global__ __launch_bounds__(256) void k_cand_gather(const uint8_t* __restrict__ tcount, const unsigned int* __restrict__ toff,
+                                                     const TrigCand* __restrict__ tcand, int ntile, const unsigned long long* __restrict__ summ,
+                                                     TrigSeg init, TrigCand* __restrict__ out, unsigned int cap)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntile) return;
+  const unsigned cnt = tcount[t];
+  if (!cnt) return;
+  unsigned off = toff[t];
+  for (unsigned i = 0; i < cnt; i++, off++) {
+    TrigCand k = tcand[(size_t)t * C8P_DET_TILE_CAND + i];
+    if (k.s == C8P_CAND_OPEN_START) {
+      // a quiet tile closed the run that was open at its first item: that run's start, from the summaries before the tile
+      TrigSeg acc = seg_identity();
+      long long u = t - 1;
+      for (; u >= 0; u--) { acc = seg_combine(seg_unpack(summ[u], u * C8P_DET_TILE), acc); if (!acc.all) break; }
+      if (u < 0) acc = seg_combine(init, acc);
+      k.s = seg_has_run(acc) ? acc.tstart : k.e;     // (s = e: no plateau, the host's walk skips it)
+    }
+    if (off < cap) out[off] = k;
+  }
+}
+
+// the maximum of ac over the items [lo, hi) of one plateau (d_conjAc at a commit point that falls inside it), from the
+// same arithmetic as k_detect_scan; ac > 0.3 > 0 there, so the float order is the order of the bit patterns
+__global__ __launch_bounds__(256) void k_ac_range_max(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+                                                      long long tile_lo, long long lo, long long hi, unsigned int* __restrict__ out_bits)
+{
+  __shared__ cf sX[9 * C8P_PRE_RS];
+  __shared__ float sE[9 * C8P_PRE_RS];
+  cf Pv[8];
+  float Ev[8];
+  const long long base = tile_windows(x, hist, n, tile_lo + blockIdx.x, x_aligned16, sX, sE, Pv, Ev);
+  if (threadIdx.x < C8P_PRE_HALO) return;
+  float m = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const long long g = n0 + j;
-    if ((unsigned long long)g >= n) break;
-    unsigned b = 0;
-    if (a[j] > C8P_AC_THR) {
-      b = 0x04;
-      if (rs == C8P_SEG_NONE) { rs = g; rmax = 0.f; }
-      if (a[j] > rmax) { rmax = a[j]; b |= 0x02; }     // trigger_impl.cc:80-85 (d_conjAc restarts at 0 with every plateau)
-    } else {
-      if (rs != C8P_SEG_NONE && g - rs >= 21) {        // a plateau long enough to arm the countdown ended here
-        const unsigned k = atomicAdd(n_cand, 1u);
-        if (k < cap) { cand[k].s = rs; cand[k].e = g; }
-      }
-      rs = C8P_SEG_NONE; rmax = 0.f;
-    }
-    packed |= (unsigned long long)b << (8 * j);
-    if ((unsigned long long)g == n - 1 && rs != C8P_SEG_NONE && g + 1 - rs >= 21) {   // plateau still open at the end of the stream
-      const unsigned k = atomicAdd(n_cand, 1u);
-      if (k < cap) { cand[k].s = rs; cand[k].e = (long long)n; }
-    }
+    const long long g = base + threadIdx.x * 8 + j;
+    const float a = ac_of(Pv[j], Ev[j]);
+    if (g >= lo && g < hi && a > m) m = a;
   }
-  if ((unsigned long long)(n0 + 7) < n) *(unsigned long long*)(trig + n0) = packed;
-  else for (int j = 0; j < 8 && (unsigned long long)(n0 + j) < n; j++) trig[n0 + j] = (uint8_t)(packed >> (8 * j));
+  if (m > 0.f) atomicMax(out_bits, __float_as_uint(m));
 }
 
 // the host adds the trigger bits (0x01) it derived from the candidates

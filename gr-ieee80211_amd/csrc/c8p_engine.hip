@@ -190,10 +190,13 @@ struct Slot {
   Buf d_stage;                                       // descriptors + layout (+ sym_base)
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt, d_negsym, d_done4;
-  Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan;    // signal front-end
-  Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_cnt, d_det_job, d_det_mark,
+  Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan, d_sig_kept;    // signal front-end
+  Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_tcand, d_det_tcount, d_det_toff, d_det_cnt, d_det_job, d_det_mark,
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
   Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc, d_tx_bfq;   // transmit chain
+  std::vector<TrigCand> h_det_cand;                  // host-side work lists of c8p_detect (kept: no allocation per call)
+  std::vector<unsigned long long> h_det_fire;
+  std::vector<SyncJob> h_det_jobs;
   int n_pkt = 0;
   unsigned ticket = 0;                               // c8p_ticket() of the submit that filled this slot (0: never used)
   size_t used[C8P_BUF_COUNT] = {};
@@ -314,7 +317,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt, &sl.d_negsym, &sl.d_done4,
-                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig,
+                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_sig_kept, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig, &sl.d_det_tcand, &sl.d_det_tcount, &sl.d_det_toff,
                    &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
                    &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
                    &sl.d_tx_u2p, &sl.d_tx_iq, &sl.d_tx_desc};
@@ -674,15 +677,65 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
     d_raw = (const cf*)c->s->d_sig_raw.p;
   }
   if ((rc = ensure(c, c->s->d_sig_pkt, sizeof(c8p_pkt_in) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_sig_iq, sizeof(cf) * tot)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_sig_chan, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
-  {
+  const c8p_sig_in* d_ev = (const c8p_sig_in*)((char*)c->s->d_stage.p + o_ev);
+  if (!in->consume) {
+    if ((rc = ensure(c, c->s->d_sig_iq, sizeof(cf) * tot)) != C8P_OK) return rc;
     KTimer kt(c, C8P_K_SIGNAL);
-    hipLaunchKernelGGL(k_signal, dim3(n), dim3(64), 0, c->s->stream, (const c8p_sig_in*)((char*)c->s->d_stage.p + o_ev), d_raw,
+    hipLaunchKernelGGL(k_signal, dim3(n), dim3(64), 0, c->s->stream, d_ev, d_raw,
                        (const uint64_t*)((char*)c->s->d_stage.p + o_off), (const DevTables*)c->d_tab,
                        (c8p_pkt_in*)c->s->d_sig_pkt.p, (cf*)c->s->d_sig_iq.p, (cf*)c->s->d_sig_chan.p, n);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    // S_DEMOD of every flag, then the block's scan over the descriptors (host), then S_COPY of the packets it keeps
+    Slot& S = *c->s;
+    {
+      KTimer kt(c, C8P_K_SIGNAL);
+      hipLaunchKernelGGL(k_signal_lsig, dim3(n), dim3(64), 0, S.stream, d_ev, d_raw, (const DevTables*)c->d_tab,
+                         (c8p_pkt_in*)S.d_sig_pkt.p, (cf*)S.d_sig_chan.p, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    // (the staging upload above has been consumed once the kernel has run: the pinned buffer is reused for the way back)
+    const size_t o_pk = 0, o_kept = align256(sizeof(c8p_pkt_in) * (size_t)n);
+    if ((rc = ensure_host(c, o_kept + sizeof(int) * (size_t)n)) != C8P_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(S.stream));      // (before the pinned buffer is written again, should ensure_host have kept it)
+    c8p_pkt_in* hpk = (c8p_pkt_in*)((char*)S.h_stage + o_pk);
+    int* kept = (int*)((char*)S.h_stage + o_kept);
+    HIPCHK(c, hipMemcpyAsync(hpk, S.d_sig_pkt.p, sizeof(c8p_pkt_in) * (size_t)n, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipStreamSynchronize(S.stream));
+    uint64_t pos = 0, used = 0;
+    bool waiting = false;
+    int nk = 0;
+    for (int e = 0; e < n; e++) {
+      const c8p_sig_in& k = in->evts[e];
+      c8p_pkt_in& p = hpk[e];
+      const uint64_t idx = k.raw_off[0];
+      if (waiting) { p.n_items = 0; p.rsv[0] = C8P_SIG_PENDING; continue; }
+      if (idx < pos) { p.n_items = 0; p.rsv[0] = C8P_SIG_SKIPPED; continue; }
+      if (k.n_avail < 224u) { waiting = true; p.n_items = 0; p.rsv[0] = C8P_SIG_PENDING; continue; }     // S_DEMOD waits for 224 items
+      if (p.n_items == 0) {
+        if (p.rsv[0] == C8P_SIG_NEED_MORE) waiting = true;                                               // S_COPY waits for the rest of the packet
+        else pos = idx + 80;                                                                              // signal_impl.cc:157-160
+        continue;
+      }
+      p.iq_off[0] = used; p.iq_off[1] = k.n_ant == 2 ? used + p.n_items : 0;
+      used += (uint64_t)p.n_items * k.n_ant;
+      kept[nk++] = e;
+      pos = idx + 224 + (uint64_t)p.lsig_nsamp;                                                           // S_COPY consumed the packet
+    }
+    tot = used;
+    if ((rc = ensure(c, S.d_sig_iq, sizeof(cf) * std::max<uint64_t>(tot, 2))) != C8P_OK) return rc;
+    if ((rc = ensure(c, S.d_sig_kept, sizeof(int) * (size_t)std::max(nk, 1))) != C8P_OK) return rc;
+    if (in->pkt_host) memcpy(in->pkt_host, hpk, sizeof(c8p_pkt_in) * (size_t)n);
+    HIPCHK(c, hipMemcpyAsync(S.d_sig_pkt.p, hpk, sizeof(c8p_pkt_in) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    if (nk) {
+      HIPCHK(c, hipMemcpyAsync(S.d_sig_kept.p, kept, sizeof(int) * (size_t)nk, hipMemcpyHostToDevice, S.stream));
+      KTimer kt(c, C8P_K_SIGNAL);
+      hipLaunchKernelGGL(k_signal_copy, dim3(nk), dim3(64), 0, S.stream, d_ev, d_raw, (const c8p_pkt_in*)S.d_sig_pkt.p,
+                         (const int*)S.d_sig_kept.p, (cf*)S.d_sig_iq.p, nk);
+      HIPCHK(c, hipGetLastError());
+    }
   }
-  HIPCHK(c, hipGetLastError());
   c->s->used[C8P_BUF_SIG_PKT] = sizeof(c8p_pkt_in) * (size_t)n; c->s->ptr[C8P_BUF_SIG_PKT] = c->s->d_sig_pkt.p;
   c->s->used[C8P_BUF_SIG_IQ] = sizeof(cf) * tot; c->s->ptr[C8P_BUF_SIG_IQ] = c->s->d_sig_iq.p;
   c->s->used[C8P_BUF_SIG_CHAN] = sizeof(cf) * 64 * (size_t)n; c->s->ptr[C8P_BUF_SIG_CHAN] = c->s->d_sig_chan.p;
@@ -735,65 +788,68 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   const cf* d_raw = d_all + hist;                      // first new item
   const int ntile = (int)((n + C8P_DET_TILE - 1) / C8P_DET_TILE);
   const unsigned cap = (unsigned)(n / 22 + 16);        // a plateau needs 21 samples above and one below
-  if ((rc = ensure(c, S.d_det_ac, sizeof(float) * n)) != C8P_OK) return rc;
+  const bool keep = in->keep != 0;
+  if ((rc = ensure(c, S.d_det_ac, keep ? sizeof(float) * n : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_trig, n + 8)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_conj, in->keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_summ, sizeof(TrigSeg) * (size_t)ntile)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg) * (size_t)(ntile + 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_conj, keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_summ, sizeof(unsigned long long) * (size_t)ntile)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg))) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_tcand, sizeof(TrigCand) * (size_t)ntile * C8P_DET_TILE_CAND)) != C8P_OK) return rc;
+  const size_t tcount_bytes = ((size_t)ntile + 15) & ~(size_t)15;
+  if ((rc = ensure(c, S.d_det_tcount, tcount_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_toff, sizeof(unsigned) * (size_t)ntile)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * (size_t)cap)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_cnt, 16)) != C8P_OK) return rc;
-  HIPCHK(c, hipMemsetAsync(S.d_det_cnt.p, 0, 16, S.stream));
   TrigSeg init;                                        // the plateau open at the commit point
   init.all = 0; init.tmax = 0.f; init.tstart = C8P_SEG_NONE;
   if (st0.in_run) { init.all = 1; init.tstart = st0.run_start; init.tmax = st0.run_max; }
-  {
-    KTimer kt(c, C8P_K_PRESISO);
-    const uint64_t nblk = (n + 7) / 8;
-    hipLaunchKernelGGL(k_presiso, dim3((unsigned)((nblk + C8P_PRE_OUT_BLOCKS - 1) / C8P_PRE_OUT_BLOCKS)), dim3(256), 0, S.stream,
-                       d_raw, hist, (unsigned long long)n, (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, in->keep, (TrigSeg*)S.d_det_summ.p,
-                       (int)(((uintptr_t)d_raw & 15u) == 0));
-  }
-  {
-    KTimer kt(c, C8P_K_TRIGGER);
-    hipLaunchKernelGGL(k_trig_apply, dim3(ntile), dim3(256), 0, S.stream, (const float*)S.d_det_ac.p, (unsigned long long)n,
-                       (const TrigSeg*)S.d_det_summ.p, init, (TrigSeg*)S.d_det_carry.p + ntile,
-                       (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_cand.p, (unsigned*)S.d_det_cnt.p, cap);
-  }
-  HIPCHK(c, hipGetLastError());
+  const int x_al16 = (int)(((uintptr_t)d_raw & 15u) == 0);
   // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a
-  // synchronous staging hop each): [count | final seg | first C8P_DET_SPEC candidates] come back with one sync
-  constexpr unsigned C8P_DET_SPEC = 32768;
+  // synchronous staging hop each): [counters | final seg | first C8P_DET_SPEC candidates] come back with one sync
+  constexpr unsigned C8P_DET_SPEC = 8192;
   const unsigned spec = std::min(cap, C8P_DET_SPEC);
   const size_t o_cnt = 0, o_fin = 64, o_cand = 128;
   if ((rc = ensure_host(c, o_cand + sizeof(TrigCand) * (size_t)spec)) != C8P_OK) return rc;
   char* hp = (char*)S.h_stage;
-  HIPCHK(c, hipMemcpyAsync(hp + o_cnt, S.d_det_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(c, hipMemcpyAsync(hp + o_fin, (const TrigSeg*)S.d_det_carry.p + ntile, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(c, hipMemcpyAsync(hp + o_cand, S.d_det_cand.p, sizeof(TrigCand) * (size_t)spec, hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(c, hipStreamSynchronize(S.stream));
+  static const int force_tickets = getenv("C8P_DET_TICKETS") ? atoi(getenv("C8P_DET_TICKETS")) : 0;   // 1: always, 2: pretend the first launch gave up (tests)
+  for (int numbering = force_tickets == 1 ? 1 : 0; ; numbering = 1) {
+    HIPCHK(c, hipMemsetAsync(S.d_det_cnt.p, 0, 16, S.stream));                       // [0] candidates, [1] tile tickets, [2] k_ac_range_max, [3] a look-back gave up
+    HIPCHK(c, hipMemsetAsync(S.d_det_summ.p, 0, sizeof(unsigned long long) * (size_t)ntile, S.stream));   // no tile summary published yet
+    HIPCHK(c, hipMemsetAsync(S.d_det_tcount.p, 0, tcount_bytes, S.stream));
+    {
+      KTimer kt(c, C8P_K_PRESISO);
+      hipLaunchKernelGGL(k_detect_scan, dim3(ntile), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
+                         (unsigned long long*)S.d_det_summ.p, (unsigned*)S.d_det_cnt.p + 1, init, (TrigSeg*)S.d_det_carry.p,
+                         (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, (uint8_t*)S.d_det_tcount.p,
+                         (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
+    }
+    {
+      KTimer kt(c, C8P_K_TRIGGER);
+      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, S.stream, (const uint8_t*)S.d_det_tcount.p, ntile, (unsigned*)S.d_det_toff.p,
+                         (unsigned*)S.d_det_cnt.p);
+      hipLaunchKernelGGL(k_cand_gather, dim3((ntile + 255) / 256), dim3(256), 0, S.stream, (const uint8_t*)S.d_det_tcount.p, (const unsigned*)S.d_det_toff.p,
+                         (const TrigCand*)S.d_det_tcand.p, ntile, (const unsigned long long*)S.d_det_summ.p, init, (TrigCand*)S.d_det_cand.p, cap);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hp + o_cnt, S.d_det_cnt.p, 16, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_fin, S.d_det_carry.p, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_cand, S.d_det_cand.p, sizeof(TrigCand) * (size_t)spec, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipStreamSynchronize(S.stream));
+    const bool gave_up = ((const unsigned*)(hp + o_cnt))[3] != 0 || (force_tickets == 2 && numbering == 0);
+    if (!gave_up) break;
+    // a tile waited for a predecessor that had not started (blockIdx numbering promises nothing): once more with tickets
+    if (numbering == 1) { c->err = "detect: tile look-back timed out"; return C8P_EHIP; }
+  }
   lap("scan kernels + first sync");
   const unsigned ncand = *(const unsigned*)(hp + o_cnt);
   const TrigSeg fin = *(const TrigSeg*)(hp + o_fin);
   if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
-  std::vector<TrigCand> cand((const TrigCand*)(hp + o_cand), (const TrigCand*)(hp + o_cand) + std::min(ncand, spec));
+  // the plateaus of >= 21 samples, in stream order
+  std::vector<TrigCand>& cand = S.h_det_cand;
+  cand.assign((const TrigCand*)(hp + o_cand), (const TrigCand*)(hp + o_cand) + std::min(ncand, spec));
   if (ncand > spec) {
     cand.resize(ncand);
     HIPCHK(c, hipMemcpy(cand.data() + spec, (const TrigCand*)S.d_det_cand.p + spec, sizeof(TrigCand) * (size_t)(ncand - spec), hipMemcpyDeviceToHost));
-  }
-  {
-    // stream order: the list comes back in atomic-append order; bucket by the tile a plateau ENDS in (one or two per
-    // tile at most in practice), then order inside the buckets — O(n + tiles) instead of a comparison sort
-    std::vector<unsigned> head((size_t)ntile + 2, 0);
-    auto bucket = [&](const TrigCand& k) { const long long e = std::max(k.e - 1, 0ll); return (size_t)std::min<long long>(e / C8P_DET_TILE, ntile); };
-    for (const TrigCand& k : cand) head[bucket(k) + 1]++;
-    for (size_t t = 1; t < head.size(); t++) head[t] += head[t - 1];
-    std::vector<TrigCand> tmp(cand.size());
-    std::vector<unsigned> fill(head.begin(), head.end() - 1);
-    for (const TrigCand& k : cand) tmp[fill[bucket(k)]++] = k;
-    for (size_t t = 0; t + 1 < head.size(); t++)
-      if (head[t + 1] - head[t] > 1)
-        std::sort(tmp.begin() + head[t], tmp.begin() + head[t + 1], [](const TrigCand& a, const TrigCand& b) { return a.s < b.s; });
-    cand.swap(tmp);
   }
   const long long N = (long long)n;
   // trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous
@@ -807,8 +863,9 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   long long commit = N;
   c8p_det_state st1;
   memset(&st1, 0, sizeof(st1));
-  std::vector<unsigned long long> fire;
-  std::vector<SyncJob> jobs;
+  std::vector<unsigned long long>& fire = S.h_det_fire;
+  std::vector<SyncJob>& jobs = S.h_det_jobs;
+  fire.clear(); jobs.clear();
   fire.reserve(cand.size() + 1); jobs.reserve(cand.size() + 2);
   bool open_fired = false;                             // the plateau that is open at the end of the segment has armed
   bool stopped = false;
@@ -834,7 +891,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     jobs.push_back(j);
     pos = t + C8P_SYNC_RES;
   }
-  lap("sort + state machines");
+  lap("state machines");
   // one more look-back job, not a trigger: what the IDLE state has latched when it reaches the commit point
   const int nj = (int)jobs.size();
   {
@@ -874,6 +931,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
                            (unsigned long long)in->n_hist);
     }
     HIPCHK(c, hipGetLastError());
+    lap("second phase enqueue");
     if (nj) {
       HIPCHK(c, hipMemcpyAsync(hp + o_evt, S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
       HIPCHK(c, hipMemcpyAsync(hp + o_val, S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
@@ -900,10 +958,16 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     // d_conjAc at that item: maximum of ac over the plateau so far
     float rmax = (st0.in_run && stop_run_start == st0.run_start) ? st0.run_max : 0.f;
     const long long lo = std::max(stop_run_start, 0ll);
-    if (commit > lo) {
-      std::vector<float> a((size_t)(commit - lo));
-      HIPCHK(c, hipMemcpy(a.data(), (const float*)S.d_det_ac.p + lo, sizeof(float) * a.size(), hipMemcpyDeviceToHost));
-      for (float v : a) if (v > rmax) rmax = v;
+    if (commit > lo) {         // ac is not stored: the same arithmetic once more over the tiles this stretch of the plateau touches
+      const long long tl = lo / C8P_DET_TILE, th = (commit - 1) / C8P_DET_TILE;
+      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
+                         tl, lo, commit, (unsigned*)S.d_det_cnt.p + 2);
+      HIPCHK(c, hipGetLastError());
+      float got = 0.f;
+      HIPCHK(c, hipMemcpyAsync(hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), (unsigned*)S.d_det_cnt.p + 2, sizeof(float), hipMemcpyDeviceToHost, S.stream));
+      HIPCHK(c, hipStreamSynchronize(S.stream));
+      memcpy(&got, hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), sizeof(float));
+      if (got > rmax) rmax = got;
     }
     st1.run_max = rmax;
   } else {
@@ -918,9 +982,9 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   if (in->commit) *in->commit = in->n_hist + (uint64_t)commit;
   if (in->state_out) *in->state_out = st1;
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
-  S.used[C8P_BUF_DET_AC] = sizeof(float) * n; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
+  S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * n : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
   S.used[C8P_BUF_DET_TRIG] = n; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
-  S.used[C8P_BUF_DET_CONJ] = in->keep ? sizeof(cf) * n : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
+  S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * n : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
   return C8P_OK;
 }
 

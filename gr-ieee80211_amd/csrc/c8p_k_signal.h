@@ -8,27 +8,17 @@
 // L-SIG demod + 24-step Viterbi + signalCheckLegacy, then the de-rotated packet items.  SURVEY.md §8f-1.
 __device__ __forceinline__ cf rot(cf x, float th) { return cmul(x, mk(cosf(th), sinf(th))); }
 
-__global__ __launch_bounds__(64) void k_signal(const c8p_sig_in* __restrict__ ev, const cf* __restrict__ raw,
-                                               const uint64_t* __restrict__ out_off, const DevTables* __restrict__ T,
-                                               c8p_pkt_in* __restrict__ pk_out, cf* __restrict__ iq_out,
-                                               cf* __restrict__ chan_out, int n)
+// S_DEMOD of one sync flag (signal_impl.cc:112-160): L-LTF channel estimate, L-SIG demod + 24-step Viterbi + signalCheckLegacy.
+// Returns the boundary descriptor without its items (n_items = nsamp + 320 when the packet is complete); chan[64] is written.
+__device__ __forceinline__ c8p_pkt_in sig_lsig(const c8p_sig_in& E, int e, const cf* __restrict__ raw, const DevTables* __restrict__ T,
+                                               cf* __restrict__ chan_out, float* s_llr, uint8_t* s_bits, unsigned long long* s_w1, unsigned long long* s_w0)
 {
-  __shared__ float s_llr[48];
-  __shared__ uint8_t s_bits[24];
-  __shared__ unsigned long long s_w1[49], s_w0[49];
-  const int e = blockIdx.x;
-  if (e >= n) return;
   const int lane = lane_id();
-  const c8p_sig_in E = ev[e];
   const cf* in1 = raw + E.raw_off[0];
-  const cf* in2 = raw + E.raw_off[1];
-  const uint32_t cap = (E.n_avail >= 224u ? E.n_avail - 224u : 0u) + 320u;
-  cf* o1 = iq_out + out_off[e];
-  cf* o2 = o1 + cap;
   c8p_pkt_in P;
   memset(&P, 0, sizeof(P));
   P.n_ant = E.n_ant; P.snr = E.snr; P.rssi = E.rssi; P.cfo = E.cfo_rad * 3183098.8618379068f;   // signal_impl.cc:136
-  P.iq_off[0] = out_off[e]; P.iq_off[1] = E.n_ant == 2 ? out_off[e] + cap : 0; P.chan_off = 64u * (uint32_t)e;
+  P.chan_off = 64u * (uint32_t)e;
   cf h = mk(0.f, 0.f);
   int ok = 0, mcs = 0, len = 0, nsamp = 0;
   if (E.n_avail >= 224u) {
@@ -67,14 +57,59 @@ __global__ __launch_bounds__(64) void k_signal(const c8p_sig_in* __restrict__ ev
     }
   }
   chan_out[(size_t)e * 64 + lane] = h;
-  if (ok) {
-    for (int k = lane; k < nsamp; k += 64) {                           // S_COPY signal_impl.cc:164-192
-      const float th = (float)(k + 224) * E.cfo_rad;
-      o1[k] = rot(in1[224 + k], th);
-      if (E.n_ant == 2) o2[k] = rot(in2[224 + k], th);
-    }
-    for (int k = nsamp + lane; k < nsamp + 320; k += 64) { o1[k] = mk(0.f, 0.f); if (E.n_ant == 2) o2[k] = mk(0.f, 0.f); }
-    P.lsig_mcs = mcs; P.lsig_len = len; P.lsig_nsamp = nsamp; P.n_items = (uint32_t)nsamp + 320u;
+  if (ok) { P.lsig_mcs = mcs; P.lsig_len = len; P.lsig_nsamp = nsamp; P.n_items = (uint32_t)nsamp + 320u; }
+  return P;
+}
+// S_COPY + S_PAD (signal_impl.cc:164-192): the packet's items, de-rotated, then 320 zero items
+__device__ __forceinline__ void sig_copy(const c8p_sig_in& E, int nsamp, const cf* __restrict__ raw, cf* __restrict__ o1, cf* __restrict__ o2)
+{
+  const int lane = lane_id();
+  const cf* in1 = raw + E.raw_off[0];
+  const cf* in2 = raw + E.raw_off[1];
+  for (int k = lane; k < nsamp; k += 64) {
+    const float th = (float)(k + 224) * E.cfo_rad;
+    o1[k] = rot(in1[224 + k], th);
+    if (E.n_ant == 2) o2[k] = rot(in2[224 + k], th);
   }
-  if (lane == 0) pk_out[e] = P;
+  for (int k = nsamp + lane; k < nsamp + 320; k += 64) { o1[k] = mk(0.f, 0.f); if (E.n_ant == 2) o2[k] = mk(0.f, 0.f); }
+}
+
+// every flag on its own: the items go to a slot sized for what the flag has behind it (out_off, planned on the host from n_avail)
+__global__ __launch_bounds__(64) void k_signal(const c8p_sig_in* __restrict__ ev, const cf* __restrict__ raw,
+                                               const uint64_t* __restrict__ out_off, const DevTables* __restrict__ T,
+                                               c8p_pkt_in* __restrict__ pk_out, cf* __restrict__ iq_out,
+                                               cf* __restrict__ chan_out, int n)
+{
+  __shared__ float s_llr[48];
+  __shared__ uint8_t s_bits[24];
+  __shared__ unsigned long long s_w1[49], s_w0[49];
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const c8p_sig_in E = ev[e];
+  const uint32_t cap = (E.n_avail >= 224u ? E.n_avail - 224u : 0u) + 320u;
+  c8p_pkt_in P = sig_lsig(E, e, raw, T, chan_out, s_llr, s_bits, s_w1, s_w0);
+  P.iq_off[0] = out_off[e]; P.iq_off[1] = E.n_ant == 2 ? out_off[e] + cap : 0;
+  if (P.n_items) sig_copy(E, P.lsig_nsamp, raw, iq_out + out_off[e], iq_out + out_off[e] + cap);
+  if (lane_id() == 0) pk_out[e] = P;
+}
+// the two halves as separate launches (c8p_signal_in.consume): the host applies the block's scan rule to the descriptors in
+// between, so only the packets the block would copy are copied, back to back
+__global__ __launch_bounds__(64) void k_signal_lsig(const c8p_sig_in* __restrict__ ev, const cf* __restrict__ raw, const DevTables* __restrict__ T,
+                                                    c8p_pkt_in* __restrict__ pk_out, cf* __restrict__ chan_out, int n)
+{
+  __shared__ float s_llr[48];
+  __shared__ uint8_t s_bits[24];
+  __shared__ unsigned long long s_w1[49], s_w0[49];
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const c8p_pkt_in P = sig_lsig(ev[e], e, raw, T, chan_out, s_llr, s_bits, s_w1, s_w0);
+  if (lane_id() == 0) pk_out[e] = P;
+}
+__global__ __launch_bounds__(64) void k_signal_copy(const c8p_sig_in* __restrict__ ev, const cf* __restrict__ raw, const c8p_pkt_in* __restrict__ pk,
+                                                    const int* __restrict__ kept, cf* __restrict__ iq_out, int nk)
+{
+  if ((int)blockIdx.x >= nk) return;
+  const int e = kept[blockIdx.x];
+  const c8p_pkt_in P = pk[e];
+  sig_copy(ev[e], P.lsig_nsamp, raw, iq_out + P.iq_off[0], iq_out + P.iq_off[1]);
 }

@@ -160,14 +160,19 @@ class Engine:
         self.n = len(tags)
         self._chk(self.L.c8p_decode(self.ctx, C.byref(d)))
 
-    def signal(self, evts, raw):
-        """signal / signal2 front-end: sync events + raw samples -> boundary descriptors, de-rotated items, chan."""
+    def signal(self, evts, raw, consume=False):
+        """signal / signal2 front-end: sync events + raw samples -> boundary descriptors, de-rotated items, chan.
+        consume=True: evts are one stream's flags in order and the engine applies the block's scan rule (flags inside a
+        copied packet are never looked at, SIG_SKIPPED); the kept packets lie back to back in BUF_SIG_IQ; returns the
+        descriptors (host copy of BUF_SIG_PKT; n_items = 0 for flags that yield no packet)."""
         evts = np.ascontiguousarray(evts, abi.SIG_IN_DT)
         r_p, n_r, m, k1 = self._arena(raw, np.complex64)
-        d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r)
-        self._keep = (evts, k1, d)
+        pk = np.zeros(len(evts), abi.PKT_IN_DT) if consume else None
+        d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, int(bool(consume)), 0, pk.ctypes.data if consume and len(evts) else None)
+        self._keep = (evts, k1, d, pk)
         self.n = len(evts)
         self._chk(self.L.c8p_signal(self.ctx, C.byref(d)))
+        return pk
 
     def detect(self, raw, keep=False, n_hist=0, state=None, stream=False):
         """presiso + trigger + sync over one raw stream segment (antenna 0); returns the sync events (host copy).

@@ -97,6 +97,8 @@ typedef struct c8p_pkt_in {
                         /* fewer than 224 + nsamp items were available: n_items = 0, the block waits (S_COPY)           */
 } c8p_pkt_in;
 #define C8P_SIG_NEED_MORE 1
+#define C8P_SIG_SKIPPED   2   /* rsv[0], c8p_signal_in.consume only: n_items = 0, the block never looks at this flag            */
+#define C8P_SIG_PENDING   3   /* rsv[0], c8p_signal_in.consume only: n_items = 0, behind (or at) a flag that waits for more items */
 
 /*
  * demod -> decode tags (demod_impl.cc:224-253, demod2_impl.cc:230-250) plus the descriptor
@@ -259,6 +261,16 @@ typedef struct c8p_signal_in {
   const c8p_sig_in* evts;   /* [n_evt], host memory                                                    */
   const c8p_c32*    raw;    /* raw (not yet CFO-corrected) sample arena                                */
   uint64_t          n_raw;
+  int32_t           consume; /* 0: every flag on its own (the caller applies the block's scan rule); the call only enqueues.
+                                1: evts are the flags of ONE stream in stream order (raw_off[0] ascending) and the engine applies
+                                signal_impl's S_TRIGGER scan (signal_impl.cc:76-111,154-160) to them: a flag inside the packet an
+                                earlier flag copied, or inside the 80 items a failed L-SIG check skips, is never looked at
+                                (C8P_SIG_SKIPPED); the first flag that has to wait for more items (fewer than 224, or
+                                C8P_SIG_NEED_MORE) stops the scan, it and the flags behind it are C8P_SIG_PENDING.  Only the
+                                packets the block copies are copied, back to back in C8P_BUF_SIG_IQ.  The call blocks until the
+                                descriptors are known (the copies are only enqueued)                                          */
+  int32_t           rsv;
+  c8p_pkt_in*       pkt_host; /* consume = 1: if not NULL, receives the n_evt descriptors (what C8P_BUF_SIG_PKT holds)         */
 } c8p_signal_in;
 
 /* State of trigger_impl + sync_impl at a commit point of the stream: everything before it is final, nothing pending
@@ -282,7 +294,8 @@ typedef struct c8p_det_state {
 #define C8P_DET_HIST 80   /* presiso looks back 16 + 63 items */
 typedef struct c8p_detect_in {
   int32_t mem;              /* C8P_MEM_* of raw                                                        */
-  int32_t keep;             /* 1: also keep the conj stream (C8P_BUF_DET_CONJ) for tests               */
+  int32_t keep;             /* 1: also keep presiso's two output streams (C8P_BUF_DET_AC, C8P_BUF_DET_CONJ), for tests:
+                               the product path keeps them on the chip                                  */
   const c8p_c32* raw;       /* [n] raw samples of antenna 0                                            */
   uint64_t       n;
   uint64_t       n_hist;    /* leading items of raw that lie before the commit point                   */
@@ -314,7 +327,7 @@ typedef struct c8p_decode_in {
 #define C8P_BUF_SIG_IQ   8  /* CFO-corrected items, per packet at pkt.iq_off[a] (nsamp items + 320 zero pad)   */
 #define C8P_BUF_SIG_CHAN 9  /* c8p_c32[n_evt][64] legacy channel estimates (tag "chan")                        */
 #define C8P_BUF_DET_EVT  10 /* c8p_sync_evt[]: sync events of the last c8p_detect, in stream order                    */
-#define C8P_BUF_DET_AC   11 /* float[n - n_hist]: presiso output 0 (autocorrelation magnitude / energy) of the new items  */
+#define C8P_BUF_DET_AC   11 /* float[n - n_hist] (keep = 1): presiso output 0 (autocorrelation magnitude / energy) of the new items  */
 #define C8P_BUF_DET_TRIG 12 /* uint8[n - n_hist]: trigger output stream (bit 0x01 trigger, 0x02 latch conj; 0x04 = ac > 0.3, private) */
 #define C8P_BUF_DET_CONJ 13 /* c8p_c32[n - n_hist] (keep = 1): presiso output 1                                       */
 #define C8P_BUF_TX_IQ    14 /* c8p_c32[]: the transmitted stream(s), packets at tx_desc[p].iq_off, gaps are zeros; when any packet
@@ -334,8 +347,8 @@ typedef struct c8p_decode_in {
 #define C8P_K_VITERBI  3
 #define C8P_K_FINISH   4
 #define C8P_K_SIGNAL   5
-#define C8P_K_PRESISO  6    /* windowed autocorrelation scan (HBM-bound) */
-#define C8P_K_TRIGGER  7    /* plateau / running-max scan (three passes) */
+#define C8P_K_PRESISO  6    /* windowed autocorrelation + plateau / running-maximum scan, one pass (HBM-bound) */
+#define C8P_K_TRIGGER  7    /* candidate lists of the tiles -> one list in stream order                       */
 #define C8P_K_SYNCEVT  8    /* per-trigger LTF search + CFO              */
 #define C8P_K_TXBITS   9    /* scramble + BCC + puncture + SIG fields   */
 #define C8P_K_TXSYM    10   /* interleave + map + pilots + IFFT + GI    */
@@ -354,7 +367,7 @@ int c8p_demod (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills TAGS, LLR, MUCH
 int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS, SBITS)         */
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything but C8P_BUF_LLR (empty unless c8p_cfg.keep_llr) */
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
-int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_AC, DET_TRIG (DET_CONJ); blocks until the events are known */
+int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_TRIG (DET_AC, DET_CONJ); blocks until the events are known */
 int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */
 int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
 int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2); /* C8P_F_VHT_MU: plan2[0], plan2[1] = the users */

@@ -359,3 +359,73 @@ def test_gpu_trigger_bytes_on_a_stream_that_straddles_the_threshold_exactly(seed
     assert np.array_equal(gtr & 3, trig)
     assert (trig & 1).sum() >= 20
     assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"])
+
+
+def scan_rule(sig_in, pk):
+    """signal_impl's S_TRIGGER scan over the per-flag results (what c8p_signal_in.consume applies inside the engine):
+    returns (kept indices, rsv[0] code per flag) — signal_impl.cc:76-111,154-160 and host/c8p_blocks.cc signal_front::process"""
+    kept, code, pos, waiting = [], np.zeros(len(pk), np.uint8), 0, False
+    for i, (s, p) in enumerate(zip(sig_in, pk)):
+        idx = int(s["raw_off"][0])
+        if waiting:
+            code[i] = abi.SIG_PENDING
+        elif idx < pos:
+            code[i] = abi.SIG_SKIPPED
+        elif s["n_avail"] < 224:
+            waiting, code[i] = True, abi.SIG_PENDING
+        elif p["n_items"] == 0:
+            if p["rsv"][0] == abi.SIG_NEED_MORE:
+                waiting, code[i] = True, abi.SIG_NEED_MORE
+            else:
+                pos = idx + 80
+        else:
+            kept.append(i)
+            pos = idx + 224 + int(p["lsig_nsamp"])
+    return kept, code
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cut", [0, 0.5, 0.1, 0.97])
+def test_gpu_signal_consume_mode_equals_the_scan_rule_over_the_per_flag_results(cut):
+    """c8p_signal_in.consume = 1: the engine decodes every flag's L-SIG, applies the block's scan rule itself and copies only
+    the packets the block would copy, back to back.  Against consume = 0 (every flag on its own, the rule applied here):
+    same descriptors, same items, same chan; a stream cut inside the last packet (`cut` items before its end) leaves that flag
+    NEED_MORE or PENDING.  The burst stream (cut = 0) supplies flags inside packets, failed L-SIG checks, false L-SIGs that wait."""
+    from gr_ieee80211_amd import engine
+    x, starts, _ = stream(NAMES, CFOS, seed=6)
+    x = x[:len(x) - int(cut * (len(x) - starts[-1]))] if cut else np.concatenate([x, burst_stream(11, n_burst=40)])   # cut: that share of the last packet is missing
+    eng = engine.Engine(device=0)
+    ev = eng.detect(x)
+    assert len(ev) >= len(NAMES) - 1
+    s = sig_events(ev, len(x))
+    a, b = engine.Engine(device=0), engine.Engine(device=0)
+    a.signal(s, x)
+    a.sync()
+    pk0 = a.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT)
+    iq0 = a.fetch(abi.BUF_SIG_IQ, np.complex64)
+    ch0 = a.fetch(abi.BUF_SIG_CHAN, np.complex64)
+    kept, code = scan_rule(s, pk0)
+    pk1 = b.signal(s, x, consume=True)
+    b.sync()
+    assert np.array_equal(b.fetch(abi.BUF_SIG_PKT, abi.PKT_IN_DT), pk1)
+    iq1 = b.fetch(abi.BUF_SIG_IQ, np.complex64)
+    assert np.array_equal(b.fetch(abi.BUF_SIG_CHAN, np.complex64), ch0)
+    assert [i for i in range(len(pk1)) if pk1[i]["n_items"] > 0] == kept and len(kept) >= len(NAMES) - 1
+    assert len(set(range(len(pk1))) - set(kept)) > 0 or cut                # some flag was skipped, failed or is waiting
+    off = 0
+    for i in range(len(pk1)):
+        p0, p1 = pk0[i], pk1[i]
+        if i in kept:
+            assert p1["iq_off"][0] == off and p1["n_items"] == p0["n_items"] and p1["rsv"][0] == 0
+            for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "chan_off", "cfo", "snr", "rssi", "n_ant"):
+                assert p1[f] == p0[f], (i, f)
+            n = int(p1["n_items"])
+            assert np.array_equal(iq1[off:off + n], iq0[int(p0["iq_off"][0]):int(p0["iq_off"][0]) + n]), i
+            off += n
+        else:
+            assert p1["n_items"] == 0 and p1["rsv"][0] == code[i], (i, p1["rsv"][0], code[i])
+    assert len(iq1) == max(off, 2) or len(iq1) == off
+    if cut == 0.5:
+        assert code[-1] == abi.SIG_NEED_MORE                               # the last packet's L-SIG is there, its tail is not
+    for e in (eng, a, b):
+        e.close()

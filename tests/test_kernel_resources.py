@@ -60,7 +60,10 @@ def test_on_chip_llr_kernel_has_no_scratch_at_six_waves(usage):
 def test_side_kernels_stay_inside_their_budgets(usage):
     assert usage["k_classify"]["VGPRs"] <= 72, usage["k_classify"]
     assert usage["k_finish"]["LDS Size"] <= 24 * 1024 and usage["k_finish"]["ScratchSize"] == 0, usage["k_finish"]
-    assert usage["k_presiso"]["ScratchSize"] == 0 and usage["k_tx_sym"]["ScratchSize"] <= 16
+    assert usage["k_tx_sym"]["ScratchSize"] <= 16
+    # the one-pass detection scan: nothing spilled, and an LDS footprint that lets five workgroups share a CU
+    ds = usage["k_detect_scan"]
+    assert ds["ScratchSize"] == 0 and ds["VGPRs"] <= 96 and ds["LDS Size"] <= 30 * 1024, ds
 
 
 def test_generated_block_loop_is_current(tmp_path):
