@@ -766,8 +766,10 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
 
 
 def frontend_detect(torch, dev, local, n_target=32 << 20):
-    """SURVEY §8f-2 stage, reported beside the headline metric: c8p_detect (presiso.grc + trigger + sync) over a raw
-    20 MS/s stream resident in HBM.  The dense kernel is k_presiso (HBM-bound scan: 8 B read + 4 B written per sample)."""
+    """SURVEY §8f-2 / f-1 stages, reported beside the headline metric: c8p_detect (presiso.grc + trigger + sync) over a raw
+    20 MS/s stream resident in HBM — the dense kernel is k_detect_scan, an HBM-bound scan: 8 B read + 1 B (trigger byte)
+    written per sample, the autocorrelation stream stays on the chip — and the whole chain from that raw stream to PDUs
+    (c8p_detect -> c8p_signal -> c8p_rx) as a pipeline."""
     from c8p_cases import dewindow
     from c8p_testlib import load_npz, through_channel
     from gr_ieee80211_amd import engine
@@ -790,11 +792,33 @@ def frontend_detect(torch, dev, local, n_target=32 << 20):
     eng.close()
     pre_s = kt["presiso"] * 1e-3
     tx = tx_rate(engine, local)
+    chain = raw_stream_chain(torch, dev, local, arr, n, reps)
     return {"tx_packets_per_s": tx, "samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
             "x_realtime_20MSps": n / dt / 20e6, "ms_per_call": 1e3 * dt,
-            "kernel_ms": {k: round(kt[k], 4) for k in ("presiso", "trigger", "syncevt")},
-            "presiso_roofline": {"bound": "hbm", "alg_bytes_per_sample": 12, "achieved": 12.0 * n / pre_s / 1e9 if pre_s > 0 else 0.0,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (12.0 * n / pre_s / 1e9) / HBM_PEAK_GBS if pre_s > 0 else 0.0}}
+            "kernel_ms": {"scan": round(kt["presiso"], 4), "candidates": round(kt["trigger"], 4), "syncevt": round(kt["syncevt"], 4)},
+            "scan_roofline": {"bound": "hbm", "kernel": "k_detect_scan", "alg_bytes_per_sample": 9, "achieved": 9.0 * n / pre_s / 1e9 if pre_s > 0 else 0.0,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (9.0 * n / pre_s / 1e9) / HBM_PEAK_GBS if pre_s > 0 else 0.0},
+            "raw_stream_to_pdus": chain}
+
+
+def raw_stream_chain(torch, dev, local, arr, n, reps, segments=24):
+    """the chain from the RAW stream (rx.grc from the SDR source on) as a pipeline over `segments` copies of one resident
+    33.5 M-item segment: host/c8p_rawchain.cc — segment i+2 in c8p_detect while i+1 is in c8p_signal (consume: the block's scan
+    rule inside the engine, the kept packets back to back) and i in c8p_rx; each stage has its own engine context (own HIP
+    streams) and host thread.  Every PDU is counted from the per-packet results fetched back."""
+    from gr_ieee80211_amd import blocks
+    segs = [(arr.ptr, n)] * segments
+    try:
+        blocks.rawchain_run(segs[:4], device=local)                          # untimed: arenas, streams
+        st = blocks.rawchain_run(segs, device=local)
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    dt = st["seconds"]
+    return {"segments": st["segments"], "samples_per_segment": n, "packets_per_segment": reps, "events": st["events"], "packets": st["packets"],
+            "pdus_ok": st["pdus"], "ms_per_segment": 1e3 * dt / segments, "packets_per_s": st["pdus"] / dt, "samples_per_s": st["items"] / dt,
+            "x_realtime_20MSps": st["items"] / dt / 20e6,
+            "note": "c8p_detect -> c8p_signal (consume) -> c8p_rx through host/c8p_rawchain.cc (three host threads, everything resident in HBM, "
+                    "no state carried between segments); compare `value` (the same packets handed over at the demod boundary)"}
 
 
 def tx_rate(engine, local, n=4096):

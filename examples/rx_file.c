@@ -58,19 +58,14 @@ int main(int argc, char** argv)
   }
   c8p_signal_in sg;
   memset(&sg, 0, sizeof(sg));
-  sg.n_evt = n_evt; sg.mem = C8P_MEM_HOST; sg.evts = sin_; sg.raw = raw; sg.n_raw = n;
-  CHECK(ctx, c8p_signal(ctx, &sg));
+  /* consume = 1: the engine applies the signal block's own scan rule (signal_impl.cc:76-111,154-160: sync flags inside a packet it
+   * is copying are never seen, a failed L-SIG check skips 80 items) and copies only the packets the block would copy */
   c8p_pkt_in* pk = (c8p_pkt_in*)calloc((size_t)n_evt + 1, sizeof(c8p_pkt_in));
-  CHECK(ctx, c8p_fetch(ctx, C8P_BUF_SIG_PKT, pk, 0, (uint64_t)n_evt * sizeof(c8p_pkt_in)));
-  /* the signal block's own scan rule (signal_impl.cc:76-111,154-160): sync flags inside a packet it is copying are never seen,
-   * a failed L-SIG check skips 80 items */
+  sg.n_evt = n_evt; sg.mem = C8P_MEM_HOST; sg.evts = sin_; sg.raw = raw; sg.n_raw = n; sg.consume = 1; sg.pkt_host = pk;
+  CHECK(ctx, c8p_signal(ctx, &sg));
   int n_pkt = 0;
-  uint64_t pos = 0;
-  for (int i = 0; i < n_evt; i++) {
-    if (evts[i].index < pos) continue;
-    if (pk[i].n_items > 0) { pos = evts[i].index + 224u + (uint64_t)pk[i].lsig_nsamp; pk[n_pkt++] = pk[i]; }
-    else pos = evts[i].index + 80u;
-  }
+  for (int i = 0; i < n_evt; i++)
+    if (pk[i].n_items > 0) pk[n_pkt++] = pk[i];
   uint64_t iq_bytes = 0, ch_bytes = 0;
   const void* d_iq = c8p_buffer(ctx, C8P_BUF_SIG_IQ, &iq_bytes);        /* the packets stay on the device */
   const void* d_ch = c8p_buffer(ctx, C8P_BUF_SIG_CHAN, &ch_bytes);

@@ -30,6 +30,8 @@ def lib():
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
+        L.c8p_rawchain_run.restype = C.c_int
+        L.c8p_rawchain_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         L.c8ph_push_items.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
         L.c8ph_push_tag_long.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_long]
         L.c8ph_push_tag_float.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_float]
@@ -164,6 +166,55 @@ class Block:
             self.L.c8ph_dbg_get(self.h, i, buf, 1024)
             res.append(buf.value.decode())
         return res
+
+
+class _RawSeg(C.Structure):
+    _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64)]
+
+
+class _RawStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("segments", C.c_int64), ("items", C.c_int64), ("events", C.c_int64),
+                ("packets", C.c_int64), ("pdus", C.c_int64)]
+
+
+class _RawOut(C.Structure):
+    _fields_ = [("segment", C.c_int64), ("n_events", C.c_int32), ("n_packets", C.c_int32), ("pkts", C.c_void_p), ("outs", C.c_void_p),
+                ("rx", C.c_void_p)]
+
+
+def rawchain_run(segments, device=0, engine_lib=None, on_segment=None):
+    """host/c8p_rawchain.h: raw stream segments resident on the device -> PDUs, as a pipeline (c8p_detect -> c8p_signal with
+    the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items), ...]; on_segment(dict)
+    is called per segment in order with its descriptors / per-packet results (numpy copies) and the PDU arena bytes.
+    Returns the run's totals."""
+    from . import abi
+    L = lib()
+    segs = (_RawSeg * len(segments))(*[_RawSeg(int(p), int(n)) for p, n in segments])
+    st = _RawStats()
+    err = C.create_string_buffer(512)
+    cb_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_RawOut))
+    eng = C.CDLL(engine_lib or ENGINE_LIB)
+    eng.c8p_buffer.restype = C.c_void_p
+    eng.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    eng.c8p_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+
+    def cb(_, out):
+        o = out.contents
+        n = o.n_packets
+        pk = np.frombuffer(C.string_at(o.pkts, n * C.sizeof(abi.PktIn)), abi.PKT_IN_DT).copy() if n else np.zeros(0, abi.PKT_IN_DT)
+        outs = np.frombuffer(C.string_at(o.outs, n * C.sizeof(abi.PktOut)), abi.PKT_OUT_DT).copy() if n else np.zeros(0, abi.PKT_OUT_DT)
+        nb = C.c_uint64(0)
+        eng.c8p_buffer(o.rx, abi.BUF_PDU, C.byref(nb))
+        pdu = np.zeros(nb.value, np.uint8)
+        if nb.value:
+            eng.c8p_fetch(o.rx, abi.BUF_PDU, pdu.ctypes.data, 0, nb.value)
+        on_segment({"segment": o.segment, "n_events": o.n_events, "pkts": pk, "outs": outs, "pdu_arena": pdu})
+
+    cbp = cb_t(cb) if on_segment else None
+    rc = L.c8p_rawchain_run((engine_lib or ENGINE_LIB).encode(), device, segs, len(segments), cbp, None, C.byref(st), err, len(err))
+    if rc != 0:
+        raise RuntimeError("c8p_rawchain_run: %d %s" % (rc, err.value.decode()))
+    return {k: getattr(st, k) for k, _ in _RawStats._fields_}
 
 
 def run_chain(a, b, chunk=1 << 16, nout=1 << 16):

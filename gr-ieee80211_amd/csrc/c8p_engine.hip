@@ -191,7 +191,7 @@ struct Slot {
   Buf d_iq, d_chan, d_llr_in, d_mu_in;               // staging of caller host arenas
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt, d_negsym, d_done4;
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan, d_sig_kept;    // signal front-end
-  Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_summ, d_det_carry, d_det_cand, d_det_tcand, d_det_tcount, d_det_toff, d_det_cnt, d_det_job, d_det_mark,
+  Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_zero, d_det_carry, d_det_cand, d_det_tcand, d_det_toff, d_det_job, d_det_mark,
       d_det_evt, d_det_valid, d_det_fire;            // detection front-end
   Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc, d_tx_bfq;   // transmit chain
   std::vector<TrigCand> h_det_cand;                  // host-side work lists of c8p_detect (kept: no allocation per call)
@@ -296,7 +296,15 @@ extern "C" c8p_ctx* c8p_create(const c8p_cfg* cfg)
     c->own_stream = cfg->stream == nullptr;
     for (int i = 0; i < nslot; i++) {
       if (cfg->stream) c->slots[i].stream = (hipStream_t)cfg->stream;
-      else if (hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+      else {
+        // C8P_STREAM_PRIORITY (read at create, like C8P_SLOTS): -1 = the device's highest priority — for the contexts whose small kernels
+        // sit in front of another context's long ones (detect / signal in front of rx on one GPU)
+        const char* pe = getenv("C8P_STREAM_PRIORITY");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int pr = pe ? std::max(hi, std::min(lo, atoi(pe))) : 0;
+        if (hipStreamCreateWithPriority(&c->slots[i].stream, hipStreamNonBlocking, pr) != hipSuccess) { delete c; return nullptr; }
+      }
     }
     c->s = &c->slots[0];
     c->cur = 0;
@@ -317,8 +325,8 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   for (Slot& sl : c->slots) {
     Buf* bufs[] = {&sl.d_stage, &sl.d_iq, &sl.d_chan, &sl.d_llr_in, &sl.d_mu_in, &sl.d_tags, &sl.d_outs, &sl.d_H, &sl.d_mimo,
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt, &sl.d_negsym, &sl.d_done4,
-                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_sig_kept, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig, &sl.d_det_tcand, &sl.d_det_tcount, &sl.d_det_toff,
-                   &sl.d_det_conj, &sl.d_det_summ, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_cnt, &sl.d_det_job, &sl.d_det_mark,
+                   &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_sig_kept, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig, &sl.d_det_tcand, &sl.d_det_toff,
+                   &sl.d_det_conj, &sl.d_det_zero, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_job, &sl.d_det_mark,
                    &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
                    &sl.d_tx_u2p, &sl.d_tx_iq, &sl.d_tx_desc};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -792,14 +800,17 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   if ((rc = ensure(c, S.d_det_ac, keep ? sizeof(float) * n : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_trig, n + 8)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_conj, keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_summ, sizeof(unsigned long long) * (size_t)ntile)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg))) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_tcand, sizeof(TrigCand) * (size_t)ntile * C8P_DET_TILE_CAND)) != C8P_OK) return rc;
   const size_t tcount_bytes = ((size_t)ntile + 15) & ~(size_t)15;
-  if ((rc = ensure(c, S.d_det_tcount, tcount_bytes)) != C8P_OK) return rc;
+  // what every launch needs zeroed lies in one block (one fill): [counters 64 B | tile candidate counts | tile summaries]
+  const size_t o_zcnt = 0, o_ztc = 64, o_zsumm = (o_ztc + tcount_bytes + 63) & ~(size_t)63, zero_bytes = o_zsumm + sizeof(unsigned long long) * (size_t)ntile;
+  if ((rc = ensure(c, S.d_det_zero, zero_bytes)) != C8P_OK) return rc;
+  unsigned* d_cnt = (unsigned*)((char*)S.d_det_zero.p + o_zcnt);          // [0] candidates, [1] tile tickets, [2] k_ac_range_max, [3] a look-back gave up
+  uint8_t* d_tcount = (uint8_t*)S.d_det_zero.p + o_ztc;
+  unsigned long long* d_summ = (unsigned long long*)((char*)S.d_det_zero.p + o_zsumm);
   if ((rc = ensure(c, S.d_det_toff, sizeof(unsigned) * (size_t)ntile)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * (size_t)cap)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_cnt, 16)) != C8P_OK) return rc;
   TrigSeg init;                                        // the plateau open at the commit point
   init.all = 0; init.tmax = 0.f; init.tstart = C8P_SEG_NONE;
   if (st0.in_run) { init.all = 1; init.tstart = st0.run_start; init.tmax = st0.run_max; }
@@ -813,25 +824,22 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   char* hp = (char*)S.h_stage;
   static const int force_tickets = getenv("C8P_DET_TICKETS") ? atoi(getenv("C8P_DET_TICKETS")) : 0;   // 1: always, 2: pretend the first launch gave up (tests)
   for (int numbering = force_tickets == 1 ? 1 : 0; ; numbering = 1) {
-    HIPCHK(c, hipMemsetAsync(S.d_det_cnt.p, 0, 16, S.stream));                       // [0] candidates, [1] tile tickets, [2] k_ac_range_max, [3] a look-back gave up
-    HIPCHK(c, hipMemsetAsync(S.d_det_summ.p, 0, sizeof(unsigned long long) * (size_t)ntile, S.stream));   // no tile summary published yet
-    HIPCHK(c, hipMemsetAsync(S.d_det_tcount.p, 0, tcount_bytes, S.stream));
+    HIPCHK(c, hipMemsetAsync(S.d_det_zero.p, 0, zero_bytes, S.stream));      // no tile summary published yet, no candidates, no tickets
     {
       KTimer kt(c, C8P_K_PRESISO);
       hipLaunchKernelGGL(k_detect_scan, dim3(ntile), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
-                         (unsigned long long*)S.d_det_summ.p, (unsigned*)S.d_det_cnt.p + 1, init, (TrigSeg*)S.d_det_carry.p,
-                         (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, (uint8_t*)S.d_det_tcount.p,
+                         d_summ, d_cnt + 1, init, (TrigSeg*)S.d_det_carry.p,
+                         (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
                          (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
     }
     {
       KTimer kt(c, C8P_K_TRIGGER);
-      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, S.stream, (const uint8_t*)S.d_det_tcount.p, ntile, (unsigned*)S.d_det_toff.p,
-                         (unsigned*)S.d_det_cnt.p);
-      hipLaunchKernelGGL(k_cand_gather, dim3((ntile + 255) / 256), dim3(256), 0, S.stream, (const uint8_t*)S.d_det_tcount.p, (const unsigned*)S.d_det_toff.p,
-                         (const TrigCand*)S.d_det_tcand.p, ntile, (const unsigned long long*)S.d_det_summ.p, init, (TrigCand*)S.d_det_cand.p, cap);
+      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, S.stream, (const uint8_t*)d_tcount, ntile, (unsigned*)S.d_det_toff.p, d_cnt);
+      hipLaunchKernelGGL(k_cand_gather, dim3((ntile + 255) / 256), dim3(256), 0, S.stream, (const uint8_t*)d_tcount, (const unsigned*)S.d_det_toff.p,
+                         (const TrigCand*)S.d_det_tcand.p, ntile, (const unsigned long long*)d_summ, init, (TrigCand*)S.d_det_cand.p, cap);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hp + o_cnt, S.d_det_cnt.p, 16, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_cnt, d_cnt, 16, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipMemcpyAsync(hp + o_fin, S.d_det_carry.p, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipMemcpyAsync(hp + o_cand, S.d_det_cand.p, sizeof(TrigCand) * (size_t)spec, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
@@ -961,10 +969,10 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     if (commit > lo) {         // ac is not stored: the same arithmetic once more over the tiles this stretch of the plateau touches
       const long long tl = lo / C8P_DET_TILE, th = (commit - 1) / C8P_DET_TILE;
       hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
-                         tl, lo, commit, (unsigned*)S.d_det_cnt.p + 2);
+                         tl, lo, commit, d_cnt + 2);
       HIPCHK(c, hipGetLastError());
       float got = 0.f;
-      HIPCHK(c, hipMemcpyAsync(hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), (unsigned*)S.d_det_cnt.p + 2, sizeof(float), hipMemcpyDeviceToHost, S.stream));
+      HIPCHK(c, hipMemcpyAsync(hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), d_cnt + 2, sizeof(float), hipMemcpyDeviceToHost, S.stream));
       HIPCHK(c, hipStreamSynchronize(S.stream));
       memcpy(&got, hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), sizeof(float));
       if (got > rmax) rmax = got;

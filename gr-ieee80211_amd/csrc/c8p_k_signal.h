@@ -6,7 +6,12 @@
 // ================================================================================================ signal front-end
 // signal_impl::general_work (lib/signal_impl.cc:108-202) / signal2_impl: CFO de-rotation, L-LTF channel estimate,
 // L-SIG demod + 24-step Viterbi + signalCheckLegacy, then the de-rotated packet items.  SURVEY.md §8f-1.
-__device__ __forceinline__ cf rot(cf x, float th) { return cmul(x, mk(cosf(th), sinf(th))); }
+__device__ __forceinline__ cf rot(cf x, float th)
+{
+  float sn, cs;
+  sincosf(th, &sn, &cs);                    // cosf(th), sinf(th) with one argument reduction (signal_impl.cc:117-119,172-173)
+  return cmul(x, mk(cs, sn));
+}
 
 // S_DEMOD of one sync flag (signal_impl.cc:112-160): L-LTF channel estimate, L-SIG demod + 24-step Viterbi + signalCheckLegacy.
 // Returns the boundary descriptor without its items (n_items = nsamp + 320 when the packet is complete); chan[64] is written.

@@ -429,3 +429,50 @@ def test_gpu_signal_consume_mode_equals_the_scan_rule_over_the_per_flag_results(
         assert code[-1] == abi.SIG_NEED_MORE                               # the last packet's L-SIG is there, its tail is not
     for e in (eng, a, b):
         e.close()
+
+
+@pytest.mark.gpu
+def test_rawchain_driver_delivers_the_pdus_of_the_serial_chain_in_order():
+    """host/c8p_rawchain.cc (raw stream segments on the device -> PDUs, three segments in flight) against the same three engine
+    calls made one after the other: per segment the same events, the same kept packets, the same per-packet results and PDU
+    bytes, segments in order.  Five different segments (one of them silence, one with bursts that fail the L-SIG check)."""
+    import torch
+    from gr_ieee80211_amd import blocks, engine
+    dev = torch.device("cuda:0")
+    xs = [stream(NAMES, CFOS, seed=21)[0], stream(NAMES[::-1], CFOS, seed=22)[0],
+          (0.01 * (np.random.default_rng(3).normal(size=30000) + 1j * np.random.default_rng(4).normal(size=30000))).astype(np.complex64),
+          np.concatenate([stream(NAMES[:3], CFOS[:3], seed=23)[0], burst_stream(12, n_burst=20)]), stream(NAMES[2:], CFOS[2:], seed=24)[0]]
+    ts = [torch.from_numpy(x.view(np.float32).copy()).to(dev) for x in xs]
+    torch.cuda.synchronize()
+    got = []
+    st = blocks.rawchain_run([(t.data_ptr(), len(x)) for t, x in zip(ts, xs)], on_segment=got.append)
+    assert st["segments"] == len(xs) and [g["segment"] for g in got] == list(range(len(xs)))
+    e_det, e_sig, e_rx = engine.Engine(device=0), engine.Engine(device=0), engine.Engine(device=0)
+    tot_pdus = 0
+    for x, t, g in zip(xs, ts, got):
+        arr = engine.DevArray(t.data_ptr(), len(x), t)
+        ev = e_det.detect(arr)
+        assert g["n_events"] == len(ev)
+        s = sig_events(ev, len(x))
+        s["n_avail"] = np.minimum(s["n_avail"], 224 + 109280)
+        pk = e_sig.signal(s, arr, consume=True)
+        e_sig.sync()
+        pk = pk[pk["n_items"] > 0]
+        assert np.array_equal(g["pkts"], pk)
+        if len(pk) == 0:
+            assert len(g["outs"]) == 0
+            continue
+        pi, bi = e_sig.buffer(abi.BUF_SIG_IQ)
+        pc, bc = e_sig.buffer(abi.BUF_SIG_CHAN)
+        e_rx.rx(pk, engine.DevArray(pi, bi // 8), engine.DevArray(pc, bc // 8))
+        outs = e_rx.outs()
+        arena = e_rx.fetch(abi.BUF_PDU, np.uint8)
+        assert np.array_equal(g["outs"], outs) and len(g["pdu_arena"]) == len(arena)
+        for o in outs:                       # (the slot of a packet that failed its FCS is not written: whatever the arena held)
+            a, b = int(o["pdu_off"]), int(o["pdu_off"]) + int(o["pdu_bytes"])
+            assert np.array_equal(g["pdu_arena"][a:b], arena[a:b])
+        tot_pdus += int(outs["n_pdu"].sum())
+    assert st["pdus"] == tot_pdus and tot_pdus >= 2 * len(NAMES)
+    assert st["events"] == sum(g["n_events"] for g in got) and st["packets"] == sum(len(g["pkts"]) for g in got)
+    for e in (e_det, e_sig, e_rx):
+        e.close()
