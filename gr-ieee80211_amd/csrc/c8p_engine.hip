@@ -822,7 +822,8 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   const size_t o_cnt = 0, o_fin = 64, o_cand = 128;
   if ((rc = ensure_host(c, o_cand + sizeof(TrigCand) * (size_t)spec)) != C8P_OK) return rc;
   char* hp = (char*)S.h_stage;
-  static const int force_tickets = getenv("C8P_DET_TICKETS") ? atoi(getenv("C8P_DET_TICKETS")) : 0;   // 1: always, 2: pretend the first launch gave up (tests)
+  const char* ft_env = getenv("C8P_DET_TICKETS");
+  const int force_tickets = ft_env ? atoi(ft_env) : 0;   // 1: always, 2: pretend the first launch gave up (tests)
   for (int numbering = force_tickets == 1 ? 1 : 0; ; numbering = 1) {
     HIPCHK(c, hipMemsetAsync(S.d_det_zero.p, 0, zero_bytes, S.stream));      // no tile summary published yet, no candidates, no tickets
     {

@@ -286,7 +286,7 @@ def test_gpu_detect_streaming_equals_one_shot(seed, chunks):
 @pytest.mark.gpu
 def test_gpu_detect_plateaus_spanning_hundreds_of_tiles():
     """a carrier that repeats every 16 samples keeps the autocorrelation above the threshold for 400 000 samples (200 tiles):
-    the per-tile look-back of k_trig_apply walks several 64-tile chunks of entirely-above tiles, then reaches the start of
+    the per-tile look-back of k_detect_scan walks several 64-tile chunks of entirely-above tiles, then reaches the start of
     the segment (`init`); a second, shorter plateau and ordinary packets follow.  Marks, triggers and events equal the oracle's,
     one-shot and cut into segments."""
     from gr_ieee80211_amd import engine
@@ -475,4 +475,61 @@ def test_rawchain_driver_delivers_the_pdus_of_the_serial_chain_in_order():
     assert st["pdus"] == tot_pdus and tot_pdus >= 2 * len(NAMES)
     assert st["events"] == sum(g["n_events"] for g in got) and st["packets"] == sum(len(g["pkts"]) for g in got)
     for e in (e_det, e_sig, e_rx):
+        e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_detect_scan_hand_offs_under_load_and_plateaus_that_end_on_tile_boundaries(monkeypatch):
+    """k_detect_scan's tiles hand their summaries to their successors inside the launch (8-byte granules, agent scope).  (1) A stream
+    built so that plateaus end exactly at, one before and one after tile boundaries (tile = 1984 items) — the quiet-tile path that
+    closes the run open at its first item, whose start k_cand_gather fills in — against the oracle.  (2) The same 2 M-item stream
+    of bursts scanned 30 times while another context keeps the GPU busy with c8p_rx batches (uneven load, warm caches), tiles
+    numbered by blockIdx and by tickets: every run's trigger bytes and events identical to the first."""
+    from c8p_cases import cfg2_batch
+    from gr_ieee80211_amd import engine
+    o = oracle()
+    rng = np.random.default_rng(8)
+    per = (rng.normal(size=16) + 1j * rng.normal(size=16)) * 0.2
+    noise = lambda k: 0.004 * (rng.normal(size=k) + 1j * rng.normal(size=k))
+    parts, pos = [], 0
+    for k, off in enumerate((-1, 0, 1, 2, -2, 0, 0, 1, -1, 40, 0)):
+        L = 700 + 97 * k
+        piece = np.concatenate([np.tile(per, L // 16 + 1)[:L] + noise(L), noise(200)]).astype(np.complex64)
+        lead = noise(300).astype(np.complex64)
+        a1 = o.detect(np.concatenate([lead, piece]))[1]
+        e_local = int(np.flatnonzero(a1 > 0.3)[-1]) + 1 - 300               # first item after the plateau, relative to the piece (the
+        gap = 1984 * (3 * k + 2) + off - pos - e_local                      # items before the piece only reach 64 items into it)
+        assert gap >= 100
+        parts += [noise(gap), piece]
+        pos += gap + len(piece)
+    x = np.concatenate(parts + [noise(3000)]).astype(np.complex64)
+    ev, ac, cj, trig = o.detect(x)
+    ends = np.flatnonzero((ac[:-1] > 0.3) & ~(ac[1:] > 0.3)) + 1             # first item after each plateau
+    assert len(set(int(e) % 1984 for e in ends) & {0, 1, 1983}) >= 2, sorted(int(e) % 1984 for e in ends)
+    eng = engine.Engine(device=0)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("C8P_DET_TICKETS", mode)
+        gev = eng.detect(x)
+        assert len(gev) == len(ev) and np.array_equal(gev["index"], ev["index"]) and np.array_equal(gev["trig"], ev["trig"])
+    monkeypatch.delenv("C8P_DET_TICKETS")
+    gtr = (eng.detect(x), eng.fetch(abi.BUF_DET_TRIG, np.uint8))[1]
+    assert np.array_equal(gtr & 3, trig)
+    # (2)
+    big = np.concatenate([burst_stream(s_, n_burst=60) for s_ in range(30, 70)])
+    assert len(big) > 1_000_000
+    b, _ = cfg2_batch(512, snr_db=30.0, seed=2)
+    pk, iq, chan = b.arrays()
+    load = engine.Engine(device=0)
+    ref_ev = eng.detect(big)
+    ref_tr = eng.fetch(abi.BUF_DET_TRIG, np.uint8).copy()
+    for it in range(30):
+        if it % 3 != 2:
+            load.rx(pk, iq, chan)                                            # asynchronous: its kernels overlap the scan below
+        if it == 15:
+            monkeypatch.setenv("C8P_DET_TICKETS", "1")
+        gev = eng.detect(big)
+        assert np.array_equal(gev, ref_ev), it
+        assert np.array_equal(eng.fetch(abi.BUF_DET_TRIG, np.uint8), ref_tr), it
+    load.sync()
+    for e in (eng, load):
         e.close()
