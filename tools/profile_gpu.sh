@@ -24,4 +24,11 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_
   C8P_SLOTS=1 rocprofv3 --kernel-trace --pmc $c -d $OUT/cfg3_pmc_$n -o pmc --output-format csv -- python $PWD/bench.py --workload cfg3 --steps 3 --warmup 1 --repeats 1 --min-timed-s 0 --no-cpu --no-frontend --no-stream --no-host-legs --no-configs > $OUT/cfg3_pmc_$n.log 2>&1
 done
 C8P_SLOTS=1 rocprofv3 --kernel-trace --stats -d $OUT/cfg3_stats1 -o ${TAG}_cfg3_slots1 --output-format csv -- python $PWD/bench.py --workload cfg3 --no-cpu --no-host-legs --no-configs --no-frontend --no-stream --steps 50 --repeats 1 --min-timed-s 0 > $OUT/cfg3_stats1.log 2>&1
-find $OUT -name "*.csv" | head -60
+# the chain from the raw stream (tools/exp_rawchain.py: c8p_detect -> c8p_signal -> c8p_rx, one call after the other, 7 passes over a
+# 33.5 M-item stream of 6034 packets): exclusive durations, HBM traffic and instruction counts of the front-end kernels
+rocprofv3 --kernel-trace --stats -d $OUT/raw_stats -o ${TAG}_raw --output-format csv -- python $PWD/tools/exp_rawchain.py > $OUT/raw_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
+  n=$(echo $c | tr ' ' '+')
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/raw_pmc_$n -o pmc --output-format csv -- python $PWD/tools/exp_rawchain.py > $OUT/raw_pmc_$n.log 2>&1
+done
+find $OUT -name "*.csv" | head -80

@@ -82,6 +82,33 @@ if c3:
                      ", ".join("%s=%d" % (n, avg(c[n])) for n in sorted(c) if n not in ("FETCH_SIZE", "WRITE_SIZE")))
 for f in glob.glob(os.path.join(src, "cfg3_stats1", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(dst, "kernel_stats_exclusive_cfg3.csv"), "w").write(open(f).read())
+# the front end (raw_* passes): the chain from the raw stream, one call after the other
+cr = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "raw_pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    per = defaultdict(float)                                   # (kernel, dispatch, counter): a dispatch's rows add up
+    for r in csv.DictReader(open(f)):
+        per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, _, n), v in per.items():
+        cr[k][n].append(v)
+rd = defaultdict(list)
+for f in glob.glob(os.path.join(src, "raw_stats", "**", "*kernel_stats.csv"), recursive=True):
+    open(os.path.join(dst, "kernel_stats_raw_chain.csv"), "w").write(open(f).read())
+    for r in csv.DictReader(open(f)):
+        rd[short(r["Name"])] = float(r["AverageNs"])
+if cr:
+    lines += ["", "the chain from the RAW stream (tools/exp_rawchain.py: one 33 549 040-item stream of 6034 cfg-2 packets, c8p_detect -> c8p_signal (consume) ->",
+              "c8p_rx one call after the other, 7 passes): average per launch; avg_us from the --stats pass (kernel_stats_raw_chain.csv)",
+              "k_detect_scan's algorithmic bytes: 9 B per item (8 read + 1 trigger byte written) = 301.9 MB per launch"]
+    hbm["raw_chain_kernels"] = {}
+    for k in sorted(cr):
+        c = cr[k]
+        if not k.startswith("k_"):
+            continue
+        fk, wk = avg(c.get("FETCH_SIZE", [])), avg(c.get("WRITE_SIZE", []))
+        hbm["raw_chain_kernels"][k] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "avg_us": rd.get(k, 0.0) / 1e3,
+                                       **{n.lower(): avg(v) for n, v in c.items() if n not in ("FETCH_SIZE", "WRITE_SIZE")}}
+        lines.append("%s: %.1f us, FETCH x2 = %.1f MB, WRITE = %.1f MB, " % (k, rd.get(k, 0.0) / 1e3, fk * 2048 / 1e6, wk * 1024 / 1e6) +
+                     ", ".join("%s=%d" % (n, avg(c[n])) for n in sorted(c) if n not in ("FETCH_SIZE", "WRITE_SIZE")))
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm.json"), "w"), indent=1)
 open(os.path.join(dst, "pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
