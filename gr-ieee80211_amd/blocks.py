@@ -169,7 +169,7 @@ class Block:
 
 
 class _RawSeg(C.Structure):
-    _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64)]
+    _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64), ("ant1_off", C.c_uint64)]
 
 
 class _RawStats(C.Structure):
@@ -184,12 +184,13 @@ class _RawOut(C.Structure):
 
 def rawchain_run(segments, device=0, engine_lib=None, on_segment=None):
     """host/c8p_rawchain.h: raw stream segments resident on the device -> PDUs, as a pipeline (c8p_detect -> c8p_signal with
-    the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items), ...]; on_segment(dict)
+    the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items[, item offset of antenna 1's
+    stream inside the same allocation: rx2.grc's chain]), ...]; on_segment(dict)
     is called per segment in order with its descriptors / per-packet results (numpy copies) and the PDU arena bytes.
     Returns the run's totals."""
     from . import abi
     L = lib()
-    segs = (_RawSeg * len(segments))(*[_RawSeg(int(p), int(n)) for p, n in segments])
+    segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0) for t in segments])
     st = _RawStats()
     err = C.create_string_buffer(512)
     cb_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_RawOut))

@@ -135,6 +135,7 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
           k.raw_off[0] = ev[i].index;
           k.n_avail = (uint32_t)std::min<uint64_t>(segs[s].n - ev[i].index, 224u + 109280u);     // the longest packet: 4095 bytes at 6 Mb/s
           k.cfo_rad = ev[i].rad; k.snr = ev[i].snr; k.rssi = ev[i].rssi; k.n_ant = 1;
+          if (segs[s].ant1_off) { k.n_ant = 2; k.raw_off[1] = segs[s].ant1_off + ev[i].index; }
         }
         if (!q1.put(std::move(o))) return;
       }
@@ -151,7 +152,8 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
         c8p_signal_in b;
         memset(&b, 0, sizeof(b));
         b.n_evt = (int32_t)in.in.size(); b.mem = C8P_MEM_DEVICE; b.evts = in.in.data();
-        b.raw = segs[in.seg].raw; b.n_raw = segs[in.seg].n; b.consume = 1; b.pkt_host = all.data();
+        b.raw = segs[in.seg].raw; b.n_raw = segs[in.seg].ant1_off ? segs[in.seg].ant1_off + segs[in.seg].n : segs[in.seg].n;
+        b.consume = 1; b.pkt_host = all.data();
         sg.check(api.signal(sg.c, &b), "c8p_signal");
         sg.check(api.sync(sg.c), "c8p_sync");                     // c8p_rx reads these arenas on ITS streams
         seg_packets o;

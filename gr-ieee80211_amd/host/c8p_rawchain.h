@@ -17,6 +17,8 @@ extern "C" {
 typedef struct c8p_rawchain_seg {
   const c8p_c32* raw;      /* device memory: the segment's items (antenna 0), resident until its callback has run */
   uint64_t n;              /* items                                                                               */
+  uint64_t ant1_off;       /* 0: one antenna (signal -> demod).  Otherwise rx2.grc's chain (signal2 -> demod2): antenna 1's n items
+                              start ant1_off items after raw (the same allocation); detection listens on antenna 0             */
 } c8p_rawchain_seg;
 
 typedef struct c8p_rawchain_out {

@@ -533,3 +533,37 @@ def test_gpu_detect_scan_hand_offs_under_load_and_plateaus_that_end_on_tile_boun
     load.sync()
     for e in (eng, load):
         e.close()
+
+
+@pytest.mark.gpu
+def test_rawchain_driver_two_antennas_is_the_rx2_chain():
+    """c8p_rawchain_seg.ant1_off: the detector listens on antenna 0, signal2 / demod2 take both streams (rx2.grc).  Two-stream HT / VHT
+    packets through the 2x2 channel and one-stream packets seen by both antennas: every PDU is the transmitted one, in order."""
+    import torch
+    from c8p_testlib import H22
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    names = ["HT2_12", "L_5", "VHT2_5", "HT_7", "HT2_9", "VHT_2"]
+    parts, want = [[], []], []
+    for k, name in enumerate(names):
+        d = SWEEP[name]
+        nss = int(d["nss"])
+        Hc = H22 if nss == 2 else np.array([[1.0], [0.4 - 0.7j]], np.complex64)
+        rx = through_channel(np.atleast_2d(dewindow(d["tx"])), Hc, 27.0, rng, lead=int(rng.integers(400, 900)))
+        w = 2 * np.pi * (-60e3 + 25e3 * k) / 20e6
+        rx = (rx * np.exp(1j * w * np.arange(rx.shape[1]))).astype(np.complex64)
+        parts[0].append(rx[0]); parts[1].append(rx[1])
+        want.append(d["pdu"].tobytes())
+    a0, a1 = np.concatenate(parts[0]), np.concatenate(parts[1])
+    n = len(a0)
+    t = torch.from_numpy(np.concatenate([a0, np.zeros(37, np.complex64), a1]).view(np.float32).copy()).to(dev)     # antenna 1 starts n + 37 items in
+    torch.cuda.synchronize()
+    got = []
+    st = blocks.rawchain_run([(t.data_ptr(), n, n + 37)] * 2, on_segment=got.append)
+    assert st["segments"] == 2 and st["packets"] == 2 * len(names) and st["pdus"] == 2 * len(names)
+    for g in got:
+        assert (g["pkts"]["n_ant"] == 2).all() and (g["outs"]["n_pdu"] == 1).all()
+        for o, w in zip(g["outs"], want):
+            rec = g["pdu_arena"][int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes()
+            assert rec[2:] == w and int.from_bytes(rec[:2], "little") == len(w)
