@@ -549,74 +549,143 @@ __global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ jo
 
 __device__ __forceinline__ float habs(cf a) { return cabs_(a); }    // std::abs(std::complex<float>) == hypotf
 
+// Sequential float chains across the lanes of a wave.  The reference accumulates its running sums one item after the other, and the
+// results feed hard comparisons (> 0.5, < 0.8 max), so the order of the additions is part of the result.  A chain "value of lane l =
+// f(value of lane l - 1, operands of lane l)" is evaluated by applying f to the WHOLE wave 64 times through a one-lane DPP shift: lane 0
+// is right after the first application, lane l after l + 1, and a lane that is right stays right — one VALU instruction per link for all
+// links at once, instead of a lane-0 loop over LDS (a load, an add and a store per link, the other 63 lanes idle).
+__device__ __forceinline__ float dpp_shr1(float v)      // lane l gets v of lane l - 1, lane 0 gets 0
+{
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+// C chains side by side (their links are independent, so one chain's DPP wait states are the others' issue slots).
+// lane l: ((0 + x[0]) + x[1]) + ... + x[l]
+template <int C, int N>
+__device__ __forceinline__ void seq_prefix(const float (&x)[C], float (&a)[C])
+{
+#pragma unroll
+  for (int c = 0; c < C; c++) a[c] = 0.f;
+#pragma unroll 4
+  for (int t = 0; t < N; t++) {
+#pragma unroll
+    for (int c = 0; c < C; c++) a[c] = dpp_shr1(a[c]) + x[c];
+  }
+}
+// lane 0: T;  lane l: (value of lane l - 1  -  p[l - 1]) + q[l - 1]      (N lanes are wanted)
+template <int C, int N>
+__device__ __forceinline__ void seq_slide(const float (&T)[C], const float (&p)[C], const float (&q)[C], int lane, float (&b)[C])
+{
+  float ps[C], qs[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    ps[c] = dpp_shr1(p[c]); qs[c] = dpp_shr1(q[c]);
+    if (lane == 0) { ps[c] = -T[c]; qs[c] = 0.f; }      // (0 - (-T)) + 0 = T exactly
+    b[c] = 0.f;
+  }
+#pragma unroll 4
+  for (int t = 0; t < N; t++) {
+#pragma unroll
+    for (int c = 0; c < C; c++) b[c] = (dpp_shr1(b[c]) - ps[c]) + qs[c];
+  }
+}
+
 __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job, const SyncMark* __restrict__ mark,
                                                  const cf* __restrict__ x, c8p_sync_evt* __restrict__ evt,
                                                  int* __restrict__ valid, int nj, cf conj0, unsigned long long idx_base)
 {
-  __shared__ cf sig[C8P_SYNC_BUF];
-  __shared__ float pw[C8P_SYNC_BUF];                 // |sig[i]| * |sig[i]| as the reference forms it (hypotf squared)
-  __shared__ cf xc[C8P_SYNC_BUF - 64];               // sig[i] * conj(sig[i + 64])
-  __shared__ cf rms[C8P_SYNC_RES];                   // the three running sums before each update
-  __shared__ float rs1[C8P_SYNC_RES], rs2[C8P_SYNC_RES];
-  __shared__ float tac[C8P_SYNC_RES];
-  __shared__ cf rot128[128];
+  __shared__ cf sig[C8P_SYNC_BUF + 16];
   const int k = blockIdx.x;
   if (k >= nj) return;
   const int lane = lane_id();
   const SyncJob J = job[k];
-  for (int i = lane; i < C8P_SYNC_BUF; i += 64) { const cf v = x[J.t + i]; sig[i] = v; pw[i] = habs(v) * habs(v); }
+  // item i of the 240: lane i % 64, register i / 64 (the fourth register only in lanes 0..47)
+  cf s[4];
+  float pw[4];                                       // |sig[i]| * |sig[i]| as the reference forms it (hypotf squared)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = lane + 64 * r;
+    s[r] = i < C8P_SYNC_BUF ? x[J.t + i] : mk(0.f, 0.f);
+    pw[r] = habs(s[r]) * habs(s[r]);
+    if (i < C8P_SYNC_BUF) sig[i] = s[r];
+  }
   // d_conjMultiAvg: the last latch the IDLE state saw — this trigger's mark, or the one an earlier trigger left behind
   cf cavg = conj0;                                   // what the state at the commit point carried in
   for (int kk = k; kk >= 0; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
-  __syncthreads();
-  for (int i = lane; i < C8P_SYNC_BUF - 64; i += 64) xc[i] = cmul(sig[i], cconj(sig[i + 64]));
-  __syncthreads();
-  if (lane == 0) {
-    // ltf_autoCorrelation sync_impl.cc:150-175: the reference's running sums, updated in the reference's order; only
-    // these additions are sequential, the terms above and the quotients below are computed by all lanes
-    cf ms = mk(0.f, 0.f);
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < 64; i++) { ms = cadd(ms, xc[i]); s1 += pw[i]; s2 += pw[i + 64]; }
-    for (int i = 0; i < C8P_SYNC_RES; i++) {
-      rms[i] = ms; rs1[i] = s1; rs2[i] = s2;
-      ms = csub(ms, xc[i]); s1 -= pw[i]; s2 -= pw[i + 64];
-      ms = cadd(ms, xc[i + 64]); s1 += pw[i + 64]; s2 += pw[i + 128];
+  cf xc[3];                                          // sig[i] * conj(sig[i + 64]), i = lane + 64 r
+#pragma unroll
+  for (int r = 0; r < 3; r++) xc[r] = cmul(s[r], cconj(s[r + 1]));
+  // ltf_autoCorrelation sync_impl.cc:150-175: the three running sums in the reference's order.  Start: the sums over i = 0..63
+  float T0[4];
+  {
+    const float in4[4] = {xc[0].x, xc[0].y, pw[0], pw[1]};
+    float pre[4];
+    seq_prefix<4, 64>(in4, pre);
+#pragma unroll
+    for (int c = 0; c < 4; c++) T0[c] = readlane_f(pre[c], 63);
+  }
+  // offsets 0..63 (lane = offset): value before the update of that offset; update = - item i, + item i + 64
+  const float pA[4] = {xc[0].x, xc[0].y, pw[0], pw[1]}, qA[4] = {xc[1].x, xc[1].y, pw[1], pw[2]};
+  float A[4];
+  seq_slide<4, 64>(T0, pA, qA, lane, A);
+  // offsets 64..110 (lane = offset - 64), seeded with the value after offset 63's update
+  constexpr int NB = C8P_SYNC_RES - 64;              // 47
+  float T1[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) T1[c] = (readlane_f(A[c], 63) - readlane_f(pA[c], 63)) + readlane_f(qA[c], 63);
+  const float qB[4] = {xc[2].x, xc[2].y, pw[2], pw[3]};
+  float B[4];
+  seq_slide<4, NB>(T1, qA, qB, lane, B);
+  const float ax = A[0], ay = A[1], a1 = A[2], a2 = A[3], bx = B[0], by = B[1], b1 = B[2], b2 = B[3];
+  const float tacA = habs(mk(ax, ay)) / sqrtf(a1) / sqrtf(a2);                              // offset lane
+  const float tacB = lane < NB ? habs(mk(bx, by)) / sqrtf(b1) / sqrtf(b2) : 0.f;            // offset 64 + lane
+  // std::max_element: the first maximum; a NaN is never "greater", and nothing is greater than a NaN at offset 0
+  const float NEG = -__builtin_inff();
+  float bv = tacA != tacA ? NEG : tacA;
+  int bi = lane;
+  {
+    const float v1 = (lane < NB && tacB == tacB) ? tacB : NEG;
+    if (v1 > bv) { bv = v1; bi = 64 + lane; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float ov = __shfl_xor(bv, d, 64);
+      const int oi = __shfl_xor(bi, d, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
   }
-  __syncthreads();
-  for (int i = lane; i < C8P_SYNC_RES; i += 64) tac[i] = habs(rms[i]) / sqrtf(rs1[i]) / sqrtf(rs2[i]);
-  __syncthreads();
-  int ok = 0, mIndex = 0, mx = 0;
-  if (lane == 0) {
-    for (int j = 1; j < C8P_SYNC_RES; j++) if (tac[j] > tac[mx]) mx = j;     // std::max_element: first maximum
-    if ((double)tac[mx] > 0.5) {                                             // sync_impl.cc:93
-      const float thr = (float)((double)tac[mx] * 0.8);
-      int l = mx, r = mx;
-      for (int j = mx; j >= 0; j--) if (tac[j] < thr) { l = j; break; }
-      for (int j = mx; j < C8P_SYNC_RES; j++) if (tac[j] < thr) { r = j; break; }
-      mIndex = (l + r) / 2;
-      ok = 1;
-    }
+  const float tac0 = readlane_f(tacA, 0);
+  const int mx = tac0 != tac0 ? 0 : bi;
+  const float tmax = tac0 != tac0 ? tac0 : bv;
+  if (!((double)tmax > 0.5)) { if (lane == 0) valid[k] = 0; return; }                        // sync_impl.cc:93
+  const float thr = (float)((double)tmax * 0.8);
+  int l = mx, r = mx;
+  {
+    // plateau around the maximum: nearest offsets below 0.8 max on either side (the maximum itself if there is none)
+    const unsigned long long lo0 = __ballot(lane <= mx && tacA < thr), lo1 = __ballot(lane < NB && 64 + lane <= mx && tacB < thr);
+    const unsigned long long hi0 = __ballot(lane >= mx && tacA < thr), hi1 = __ballot(lane < NB && 64 + lane >= mx && tacB < thr);
+    if (lo1) l = 64 + 63 - __builtin_clzll(lo1); else if (lo0) l = 63 - __builtin_clzll(lo0);
+    if (hi0) r = __builtin_ctzll(hi0); else if (hi1) r = 64 + __builtin_ctzll(hi1);
   }
-  ok = __shfl(ok, 0, 64); mIndex = __shfl(mIndex, 0, 64); mx = __shfl(mx, 0, 64);
-  if (!ok) { if (lane == 0) valid[k] = 0; return; }
+  const int mIndex = (l + r) / 2;
   // ltf_cfo sync_impl.cc:177-192
   const float stf = atan2f(cavg.y, cavg.x) / 16.0f;
-  for (int i = lane; i < 128; i += 64) rot128[i] = cmul(sig[mIndex + i], mk(cosf(i * stf), sinf(i * stf)));
   __syncthreads();
-  if (lane < 64) xc[lane] = cmul(rot128[lane], cconj(rot128[lane + 64]));
-  __syncthreads();
+  const cf r0 = cmul(sig[mIndex + lane], mk(cosf(lane * stf), sinf(lane * stf)));
+  const cf r1 = cmul(sig[mIndex + lane + 64], mk(cosf((lane + 64) * stf), sinf((lane + 64) * stf)));
+  const cf xr = cmul(r0, cconj(r1));
+  const float xr2[2] = {xr.x, xr.y};
+  float sr[2];
+  seq_prefix<2, 64>(xr2, sr);
+  const cf sum = mk(readlane_f(sr[0], 63), readlane_f(sr[1], 63));
+  const float rs1mx = __shfl(mx < 64 ? a1 : b1, mx & 63, 64);
   if (lane == 0) {
-    cf sum = mk(0.f, 0.f);
-    for (int i = 0; i < 64; i++) sum = cadd(sum, xc[i]);
     const cf q = cdivf(sum, 64.0f);
     const float ltf = atan2f(q.y, q.x) / 64.0f;
-    const double d = (double)tac[mx];
+    const double d = (double)tmax;
     c8p_sync_evt e;
     e.index = idx_base + J.t + (unsigned long long)mIndex;
     e.rad = stf + ltf;
     e.snr = (float)(10.0 * log10(d / (1.0 - d)));
-    e.rssi = rs1[mx] / 64.0f;
+    e.rssi = rs1mx / 64.0f;
     e.trig = (uint32_t)(idx_base + J.t);
     evt[k] = e;
     valid[k] = 1;
