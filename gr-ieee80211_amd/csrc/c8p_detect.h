@@ -44,27 +44,36 @@ __device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& 
   else { o.tstart = L.tstart; o.tmax = fmaxf(L.tmax, R.tmax); }   // R entirely above and L ends inside a run: it continues
   return o;
 }
-__device__ __forceinline__ TrigSeg seg_shfl_up(const TrigSeg& v, int d)
+// Scans across the 64 lanes of a wave by data-parallel primitives (DPP) instead of the LDS crossbar: row_shr:1,2,4,8 inside the rows
+// of 16 lanes, then row_bcast:15 (lane 15 of a row -> the next row) and row_bcast:31; a lane with no source keeps `old` (the identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(old), __float_as_int(v))); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ TrigSeg seg_dpp(const TrigSeg& v)
 {
+  const TrigSeg id = seg_identity();
   TrigSeg r;
-  r.all = __shfl_up(v.all, d, 64);
-  r.tmax = __shfl_up(v.tmax, d, 64);
-  const int lo = __shfl_up((int)(unsigned)(unsigned long long)v.tstart, d, 64);
-  const int hi = __shfl_up((int)(unsigned)((unsigned long long)v.tstart >> 32), d, 64);
+  r.all = dpp_i<CTRL, ROW_MASK>(id.all, v.all);
+  r.tmax = dpp_f<CTRL, ROW_MASK>(id.tmax, v.tmax);
+  const int lo = dpp_i<CTRL, ROW_MASK>((int)(unsigned)(unsigned long long)id.tstart, (int)(unsigned)(unsigned long long)v.tstart);
+  const int hi = dpp_i<CTRL, ROW_MASK>((int)(unsigned)((unsigned long long)id.tstart >> 32), (int)(unsigned)((unsigned long long)v.tstart >> 32));
   r.tstart = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
   return r;
 }
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ TrigSeg seg_wave_inclusive(TrigSeg v)
 {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const TrigSeg u = seg_shfl_up(v, d);
-    if (lane >= d) v = seg_combine(u, v);
-  }
+  v = seg_combine(seg_dpp<0x111, 0xf>(v), v);
+  v = seg_combine(seg_dpp<0x112, 0xf>(v), v);
+  v = seg_combine(seg_dpp<0x114, 0xf>(v), v);
+  v = seg_combine(seg_dpp<0x118, 0xf>(v), v);
+  v = seg_combine(seg_dpp<0x142, 0xa>(v), v);
+  v = seg_combine(seg_dpp<0x143, 0xc>(v), v);
   return v;
 }
+
 // ------------------------------------------------------------------------------------------------ presiso + trigger scan
 // ONE pass over the raw stream: 8 B read and 1 B (trigger byte) written per sample; the autocorrelation stream `ac` that
 // presiso.grc hands to the trigger block stays in registers (it is stored only for tests, keep != 0).
@@ -178,10 +187,11 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
   __syncthreads();
   cf p[8];
   float e[8];
+  const int tid2 = tid >= 2 ? tid - 2 : tid;                                  // (blocks 0 and 1 have no x[g - 16] here: their products are never used)
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const cf a = sX[j * C8P_PRE_RS + tid];
-    const cf d = tid >= 2 ? sX[j * C8P_PRE_RS + tid - 2] : mk(0.f, 0.f);      // x[g - 16]: two blocks back
+    const cf d = sX[j * C8P_PRE_RS + tid2];                                    // x[g - 16]: two blocks back
     p[j] = mk(d.x * a.x + d.y * a.y, d.y * a.x - d.x * a.y);                    // x[g-16] * conj(x[g])
     e[j] = a.x * a.x + a.y * a.y;
   }
@@ -189,9 +199,8 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
   {
     cf s = mk(0.f, 0.f);
     float se = 0.f;
-    sX[8 * C8P_PRE_RS + tid] = s; sE[8 * C8P_PRE_RS + tid] = 0.f;
 #pragma unroll
-    for (int j = 7; j >= 0; j--) { s = cadd(s, p[j]); se += e[j]; sX[j * C8P_PRE_RS + tid] = s; sE[j * C8P_PRE_RS + tid] = se; }
+    for (int j = 7; j >= 0; j--) { s = cadd(s, p[j]); se += e[j]; sX[j * C8P_PRE_RS + tid] = s; sE[j * C8P_PRE_RS + tid] = se; }   // (row 8 would be zeros: not stored)
   }
   __syncthreads();
   if (tid >= C8P_PRE_HALO) {
@@ -206,8 +215,8 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       pre = cadd(pre, p[j]); pe += e[j];
-      Pv[j] = cadd(cadd(cp, sX[(j + 1) * C8P_PRE_RS + tid - 6]), pre);        // tail of block b-6 + blocks b-5..b-1 + head of block b
-      Ev[j] = (ce + sE[(j + 1) * C8P_PRE_RS + tid - 8]) + pe;
+      Pv[j] = cadd(cadd(cp, j < 7 ? sX[(j + 1) * C8P_PRE_RS + tid - 6] : mk(0.f, 0.f)), pre);   // tail of block b-6 + blocks b-5..b-1 + head of block b
+      Ev[j] = (ce + (j < 7 ? sE[(j + 1) * C8P_PRE_RS + tid - 8] : 0.f)) + pe;
     }
   } else {
 #pragma unroll
@@ -235,12 +244,12 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
 // integer-valued torture stream straddling 0.3)
 __device__ __forceinline__ float ac_of(const cf P, const float E) { return sqrtf(P.x * P.x + P.y * P.y) / E; }
 // "certainly not above the threshold" without the square root and the quotient: |P|^2 < 0.08 E^2 means ac < 0.283 whatever the
-// roundings; anything else (NaN, an E^2 that overflows, a borderline value) takes the exact path.  Idle air and payload symbols
+// roundings; anything else (NaN, a borderline value) takes the exact path.  Idle air and payload symbols
 // fail this test for whole waves, which then skip the two correctly rounded operations per sample.
 __device__ __forceinline__ bool ac_surely_below(const cf P, const float E)
 {
-  const float t = 0.08f * E * E;
-  return (P.x * P.x + P.y * P.y < t) && (t < __builtin_inff());
+  const float Ec = fminf(E, 1.0e18f);       // (keeps the square finite; a smaller E only makes the test harder to pass)
+  return P.x * P.x + P.y * P.y < 0.08f * Ec * Ec;
 }
 
 // in-tile scan element over a stretch of samples: position (tile-relative) of its last sample that is NOT above the threshold
@@ -258,7 +267,7 @@ __device__ __forceinline__ RunSeg run_combine(const RunSeg& L, const RunSeg& R)
 // started, which is all the look-back needs — HIP does not promise it, hence the watchdog in trig_lookback), 1 = by a ticket
 // counter (a promise, at the price of 16 910 same-address atomics per 33.5 M samples: 0.09 ms)
 #define C8P_CAND_OPEN_START C8P_SEG_IDENT      // TrigCand.s of "the run that was open when this (quiet) tile began": k_cand_gather fills it in
-__global__ __launch_bounds__(256) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+__global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
                                                      unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
                                                      TrigSeg init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
                                                      TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
@@ -267,8 +276,8 @@ __global__ __launch_bounds__(256) void k_detect_scan(const cf* __restrict__ x, l
   __shared__ TrigSeg s_cin;
   __shared__ RunSeg s_w[4];
   __shared__ unsigned s_tile, s_wc[4];
-  __shared__ cf sX[9 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t  ([8] = 0)
-  __shared__ float sE[9 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
+  __shared__ cf sX[8 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t
+  __shared__ float sE[8 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
   long long tile = blockIdx.x;
   if (numbering) {
@@ -285,9 +294,10 @@ __global__ __launch_bounds__(256) void k_detect_scan(const cf* __restrict__ x, l
   const int r0 = (tid - C8P_PRE_HALO) * 8;  // the same, relative to the tile
   const int nv = live ? (int)min(8ll, max(0ll, (long long)n - n0)) : 0;     // how many of the 8 exist
   const float e_prev = acv[7];               // (halo's last thread: the energy window of the item before the tile)
-  bool maybe = false;
+  unsigned sure = 0;                         // bit j: sample j is certainly not above the threshold
 #pragma unroll
-  for (int j = 0; j < 8; j++) maybe = maybe || (j < nv && !ac_surely_below(Pv[j], acv[j]));
+  for (int j = 0; j < 8; j++) sure |= (unsigned)ac_surely_below(Pv[j], acv[j]) << j;
+  const bool maybe = (~sure & ((1u << nv) - 1u)) != 0;
   unsigned m = 0;                            // bit j: sample j is above the threshold
   if (keep || __ballot(maybe)) {
 #pragma unroll
@@ -324,15 +334,13 @@ __global__ __launch_bounds__(256) void k_detect_scan(const cf* __restrict__ x, l
       if (j < nv) { if ((m >> j) & 1u) mine.tmax = fmaxf(mine.tmax, acv[j]); else { mine.pos = r0 + j; mine.tmax = 0.f; } }
     }
     RunSeg inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      RunSeg u; u.pos = __shfl_up(inc.pos, d, 64); u.tmax = __shfl_up(inc.tmax, d, 64);
-      if (lane >= d) inc = run_combine(u, inc);
-    }
+#define C8P_RUN_STEP(CTRL, ROWS) { RunSeg u; u.pos = dpp_i<CTRL, ROWS>(-1, inc.pos); u.tmax = dpp_f<CTRL, ROWS>(0.f, inc.tmax); inc = run_combine(u, inc); }
+    C8P_RUN_STEP(0x111, 0xf) C8P_RUN_STEP(0x112, 0xf) C8P_RUN_STEP(0x114, 0xf) C8P_RUN_STEP(0x118, 0xf)
+    C8P_RUN_STEP(0x142, 0xa) C8P_RUN_STEP(0x143, 0xc)
+#undef C8P_RUN_STEP
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    RunSeg ex; ex.pos = __shfl_up(inc.pos, 1, 64); ex.tmax = __shfl_up(inc.tmax, 1, 64);
-    if (lane == 0) { ex.pos = -1; ex.tmax = 0.f; }
+    RunSeg ex; ex.pos = dpp_i<0x138, 0xf>(-1, inc.pos); ex.tmax = dpp_f<0x138, 0xf>(0.f, inc.tmax);     // wave_shr:1 (lane 0: the identity)
     RunSeg pre; pre.pos = -1; pre.tmax = 0.f;
     RunSeg tot = pre;
 #pragma unroll
@@ -483,8 +491,8 @@ __global__ __launch_bounds__(256) void k_cand_gather(const uint8_t* __restrict__
 __global__ __launch_bounds__(256) void k_ac_range_max(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
                                                       long long tile_lo, long long lo, long long hi, unsigned int* __restrict__ out_bits)
 {
-  __shared__ cf sX[9 * C8P_PRE_RS];
-  __shared__ float sE[9 * C8P_PRE_RS];
+  __shared__ cf sX[8 * C8P_PRE_RS];
+  __shared__ float sE[8 * C8P_PRE_RS];
   cf Pv[8];
   float Ev[8];
   const long long base = tile_windows(x, hist, n, tile_lo + blockIdx.x, x_aligned16, sX, sE, Pv, Ev);
