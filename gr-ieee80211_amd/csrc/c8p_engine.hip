@@ -209,6 +209,7 @@ struct c8p_ctx {
   int profile = 0, keep_bits = 0, keep_llr = 0;
   unsigned seq = 0;                                  // submits so far (profile sampling)
   int exact_only = 0;                                // C8P_EXACT_VITERBI=1: skip the lean forward pass (debug / A-B)
+  unsigned det_spec = 8192;                          // c8p_detect: candidates fetched with the first sync
   std::string err;
   DevTables* d_tab = nullptr;
   std::vector<Slot> slots;
@@ -817,8 +818,8 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   const int x_al16 = (int)(((uintptr_t)d_raw & 15u) == 0);
   // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a
   // synchronous staging hop each): [counters | final seg | first C8P_DET_SPEC candidates] come back with one sync
-  constexpr unsigned C8P_DET_SPEC = 8192;
-  const unsigned spec = std::min(cap, C8P_DET_SPEC);
+  // (how many candidates come back with the first sync: a quarter more than the previous call of this context found)
+  const unsigned spec = std::min(cap, c->det_spec);
   const size_t o_cnt = 0, o_fin = 64, o_cand = 128;
   if ((rc = ensure_host(c, o_cand + sizeof(TrigCand) * (size_t)spec)) != C8P_OK) return rc;
   char* hp = (char*)S.h_stage;
@@ -853,6 +854,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   const unsigned ncand = *(const unsigned*)(hp + o_cnt);
   const TrigSeg fin = *(const TrigSeg*)(hp + o_fin);
   if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
+  c->det_spec = std::max(4096u, ncand + ncand / 4 + 64u);
   // the plateaus of >= 21 samples, in stream order
   std::vector<TrigCand>& cand = S.h_det_cand;
   cand.assign((const TrigCand*)(hp + o_cand), (const TrigCand*)(hp + o_cand) + std::min(ncand, spec));
