@@ -849,6 +849,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     if (!gave_up) break;
     // a tile waited for a predecessor that had not started (blockIdx numbering promises nothing): once more with tickets
     if (numbering == 1) { c->err = "detect: tile look-back timed out"; return C8P_EHIP; }
+    if (force_tickets != 2) fprintf(stderr, "[c8p_detect] a tile's look-back gave up waiting for its predecessor; repeating the scan with ticket numbering\n");
   }
   lap("scan kernels + first sync");
   const unsigned ncand = *(const unsigned*)(hp + o_cnt);
