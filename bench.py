@@ -321,6 +321,8 @@ def main():
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
+            if isinstance(out.get("frontend_detect"), dict) and "raw_stream_to_pdus" in out["frontend_detect"]:
+                out["frontend_detect"]["raw_stream_cpu_baseline"] = cpu_baseline_raw_stream()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -859,6 +861,44 @@ def cpu_baseline(pk, iq, chan, budget_s=12.0):
             "sample": "first %d packets of the same batch, oracle demod+decode, 1 thread, %.1f s, %d PDUs; built with '%s'; the "
                       "oracle's 64-point FFT is an O(N^2) DFT accumulated in double (51 x 4096 complex MACs per packet, ~4 %% of "
                       "its time next to the 11960-step Viterbi)" % (n, dt, npdu, o.build_flags())}
+
+
+def cpu_baseline_raw_stream(n_packets=256):
+    """the chain from the raw stream on one host core: the oracle's detect -> signal (+ the block's scan rule) -> demod + decode over
+    `n_packets` packets of the stream the raw_stream_to_pdus leg uses (same unit, same noise)"""
+    from c8p_cases import dewindow
+    from c8p_testlib import abi, load_npz, oracle, through_channel
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    o = oracle()
+    d = load_npz("packets_cfg.npz")["cfg2_VHT_mcs7_1458B_0"]
+    rng = np.random.default_rng(1)
+    unit = through_channel(dewindow(d["tx"])[:1], None, 30.0, rng, lead=600)[0]
+    x = np.tile(unit, n_packets).astype(np.complex64)
+    t0 = time.perf_counter()
+    ev = o.detect(x)[0]
+    t1 = time.perf_counter()
+    s = np.zeros(len(ev), abi.SIG_IN_DT)
+    s["raw_off"][:, 0] = ev["index"]
+    s["n_avail"] = np.minimum(len(x) - ev["index"], 8192)          # (sizes the oracle's output slots: what these packets need, not the 109 504 of the longest one)
+    s["cfo_rad"], s["snr"], s["rssi"], s["n_ant"] = ev["rad"], ev["snr"], ev["rssi"], 1
+    pk, iq, chan = o.signal_events(s, x)
+    keep, pos = [], 0
+    for i in range(len(pk)):                             # signal_impl's scan rule (signal_impl.cc:76-111,154-160)
+        idx = int(ev[i]["index"])
+        if idx < pos:
+            continue
+        if pk[i]["n_items"] > 0:
+            keep.append(i)
+            pos = idx + 224 + int(pk[i]["lsig_nsamp"])
+        else:
+            pos = idx + 80
+    t2 = time.perf_counter()
+    _, outs, _, npdu = o.rx_batch(pk[keep], iq, chan)
+    t3 = time.perf_counter()
+    dt = t3 - t0
+    return {"packets_per_s": npdu / dt, "samples_per_s": len(x) / dt, "cores": 1, "kind": "port",
+            "sample": "%d items (%d packets), %d sync events, %d PDUs, %.1f s: detect %.2f s, signal %.2f s, demod + decode %.2f s"
+                      % (len(x), n_packets, len(ev), npdu, dt, t1 - t0, t2 - t1, t3 - t2)}
 
 
 def usable_cores():
