@@ -567,3 +567,69 @@ def test_rawchain_driver_two_antennas_is_the_rx2_chain():
         for o, w in zip(g["outs"], want):
             rec = g["pdu_arena"][int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes()
             assert rec[2:] == w and int.from_bytes(rec[:2], "little") == len(w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ant", [1, 2])
+def test_rawchain_random_streams_equal_the_oracle_chain(n_ant):
+    """Three random streams of ~90 packets each — every one-stream (n_ant 1) or every fixture incl. the two-stream ones and the NDP
+    (n_ant 2) format / MCS, carrier offsets of +-150 kHz, SNRs from 6 to 35 dB so that many fail their FCS, gaps from 150 items up so
+    that some preambles are missed or merged — through host/c8p_rawchain.cc and through the oracle's detect -> signal (+ scan rule) ->
+    demod + decode: the same sync events, the same kept packets (descriptors identical), the same PDUs and FCS-failure counts."""
+    import torch
+    from c8p_testlib import H22, oracle_rx
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    o = oracle()
+    names = [k for k in SWEEP if (n_ant == 2 or int(SWEEP[k]["nss"]) == 1)]
+    segs, hosts = [], []
+    for seed in (41, 42, 43):
+        rng = np.random.default_rng(seed + 10 * n_ant)
+        parts = [[], []]
+        for k in range(90):
+            d = SWEEP[names[int(rng.integers(len(names)))]]
+            nss = int(d["nss"])
+            Hc = None if n_ant == 1 else (H22 if nss == 2 else np.array([[1.0], [0.4 - 0.7j]], np.complex64))
+            rx = through_channel(np.atleast_2d(dewindow(d["tx"]))[: (nss if n_ant == 2 else 1)], Hc, float(rng.uniform(6.0, 35.0)), rng,
+                                 lead=int(rng.choice([150, 260, 400, 900, 2500])))
+            rx = np.atleast_2d(rx)
+            w = 2 * np.pi * float(rng.uniform(-150e3, 150e3)) / 20e6
+            rx = (rx * np.exp(1j * w * np.arange(rx.shape[1]))).astype(np.complex64)
+            parts[0].append(rx[0])
+            parts[1].append(rx[1] if n_ant == 2 else rx[0])
+        a0, a1 = np.concatenate(parts[0]), np.concatenate(parts[1])
+        hosts.append((a0, a1))
+        arena = np.concatenate([a0, a1]) if n_ant == 2 else a0
+        t = torch.from_numpy(arena.view(np.float32).copy()).to(dev)
+        segs.append((t, len(a0)))
+    torch.cuda.synchronize()
+    got = []
+    blocks.rawchain_run([(t.data_ptr(), n, n if n_ant == 2 else 0) for t, n in segs], on_segment=got.append)
+    n_pdu = n_fail = n_drop = 0
+    for (a0, a1), g in zip(hosts, got):
+        n = len(a0)
+        arena = np.concatenate([a0, a1]) if n_ant == 2 else a0
+        ev = o.detect(a0)[0]
+        assert g["n_events"] == len(ev)
+        s = sig_events(ev, n, n_ant=n_ant)
+        s["n_avail"] = np.minimum(s["n_avail"], 224 + 109280)
+        if n_ant == 2:
+            s["raw_off"][:, 1] = n + s["raw_off"][:, 0]
+        pk, iq, chan = o.signal_events(s, arena)
+        kept, code = scan_rule(s, pk)
+        n_drop += len(ev) - len(kept)
+        gp = g["pkts"]
+        assert len(gp) == len(kept)
+        for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "n_items", "n_ant"):
+            assert np.array_equal(gp[f], pk[kept][f]), f
+        assert np.allclose(gp["cfo"], pk[kept]["cfo"], rtol=0, atol=0.5) and np.array_equal(gp["chan_off"], pk[kept]["chan_off"])
+        ref = oracle_rx(pk[kept], iq, chan)
+        for i, (r, oo) in enumerate(zip(ref, g["outs"])):
+            assert int(oo["n_pdu"]) == len(r["pdus"]) and int(oo["n_crc_fail"]) == int(r["out"]["n_crc_fail"]), i
+            rec = g["pdu_arena"][int(oo["pdu_off"]):int(oo["pdu_off"]) + int(oo["pdu_bytes"])].tobytes()
+            for p in r["pdus"]:
+                assert int.from_bytes(rec[:2], "little") == len(p) and rec[2:2 + len(p)] == p, i
+                rec = rec[2 + len(p):]
+            n_pdu += len(r["pdus"])
+            n_fail += int(r["out"]["n_crc_fail"])
+    assert n_pdu >= 120 and n_fail >= 20, (n_pdu, n_fail, n_drop)
