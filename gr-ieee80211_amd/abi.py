@@ -65,7 +65,7 @@ class SigIn(C.Structure):
 
 class SignalIn(C.Structure):
     _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64),
-                ("consume", C.c_int32), ("rsv", C.c_int32), ("pkt_host", C.c_void_p)]
+                ("consume", C.c_int32), ("rsv", C.c_int32), ("pkt_host", C.c_void_p), ("scan_from", C.c_uint64), ("scan_next", C.c_void_p)]
 
 
 class SyncEvt(C.Structure):

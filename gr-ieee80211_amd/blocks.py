@@ -30,6 +30,9 @@ def lib():
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
+        L.c8p_rawchain_stream.restype = C.c_int
+        L.c8p_rawchain_stream.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_char_p, C.c_int]
         L.c8p_rawchain_run.restype = C.c_int
         L.c8p_rawchain_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         L.c8ph_push_items.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
@@ -182,12 +185,13 @@ class _RawOut(C.Structure):
                 ("rx", C.c_void_p)]
 
 
-def rawchain_run(segments, device=0, engine_lib=None, on_segment=None):
+def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_items=0):
     """host/c8p_rawchain.h: raw stream segments resident on the device -> PDUs, as a pipeline (c8p_detect -> c8p_signal with
     the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items[, item offset of antenna 1's
     stream inside the same allocation: rx2.grc's chain]), ...]; on_segment(dict)
     is called per segment in order with its descriptors / per-packet results (numpy copies) and the PDU arena bytes.
-    Returns the run's totals."""
+    stream_items > 0: segments[0] is ONE capture, worked through in pieces of that many items with the detection state and the
+    signal block's scan position carried across the cuts (c8p_rawchain_stream).  Returns the run's totals."""
     from . import abi
     L = lib()
     segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0) for t in segments])
@@ -212,9 +216,14 @@ def rawchain_run(segments, device=0, engine_lib=None, on_segment=None):
         on_segment({"segment": o.segment, "n_events": o.n_events, "pkts": pk, "outs": outs, "pdu_arena": pdu})
 
     cbp = cb_t(cb) if on_segment else None
-    rc = L.c8p_rawchain_run((engine_lib or ENGINE_LIB).encode(), device, segs, len(segments), cbp, None, C.byref(st), err, len(err))
+    if stream_items:
+        (p0, n0), a1 = segments[0][:2], (segments[0][2] if len(segments[0]) > 2 else 0)
+        rc = L.c8p_rawchain_stream((engine_lib or ENGINE_LIB).encode(), device, int(p0), int(n0), int(a1), int(stream_items), cbp, None,
+                                   C.byref(st), err, len(err))
+    else:
+        rc = L.c8p_rawchain_run((engine_lib or ENGINE_LIB).encode(), device, segs, len(segments), cbp, None, C.byref(st), err, len(err))
     if rc != 0:
-        raise RuntimeError("c8p_rawchain_run: %d %s" % (rc, err.value.decode()))
+        raise RuntimeError("c8p_rawchain: %d %s" % (rc, err.value.decode()))
     return {k: getattr(st, k) for k, _ in _RawStats._fields_}
 
 

@@ -712,7 +712,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
     int* kept = (int*)((char*)S.h_stage + o_kept);
     HIPCHK(c, hipMemcpyAsync(hpk, S.d_sig_pkt.p, sizeof(c8p_pkt_in) * (size_t)n, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
-    uint64_t pos = 0, used = 0;
+    uint64_t pos = in->scan_from, used = 0;
     bool waiting = false;
     int nk = 0;
     for (int e = 0; e < n; e++) {
@@ -733,6 +733,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
       pos = idx + 224 + (uint64_t)p.lsig_nsamp;                                                           // S_COPY consumed the packet
     }
     tot = used;
+    if (in->scan_next) *in->scan_next = pos;
     if ((rc = ensure(c, S.d_sig_iq, sizeof(cf) * std::max<uint64_t>(tot, 2))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_sig_kept, sizeof(int) * (size_t)std::max(nk, 1))) != C8P_OK) return rc;
     if (in->pkt_host) memcpy(in->pkt_host, hpk, sizeof(c8p_pkt_in) * (size_t)n);

@@ -168,7 +168,7 @@ class Engine:
         evts = np.ascontiguousarray(evts, abi.SIG_IN_DT)
         r_p, n_r, m, k1 = self._arena(raw, np.complex64)
         pk = np.zeros(len(evts), abi.PKT_IN_DT) if consume else None
-        d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, int(bool(consume)), 0, pk.ctypes.data if consume and len(evts) else None)
+        d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, int(bool(consume)), 0, pk.ctypes.data if consume and len(evts) else None, 0, None)
         self._keep = (evts, k1, d, pk)
         self.n = len(evts)
         self._chk(self.L.c8p_signal(self.ctx, C.byref(d)))

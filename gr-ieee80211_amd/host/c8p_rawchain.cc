@@ -63,9 +63,9 @@ private:
   bool d_open = false;
 };
 
-struct seg_events { int64_t seg; std::vector<c8p_sig_in> in; };
+struct seg_events { int64_t seg; uint64_t new_items; std::vector<c8p_sig_in> in; };
 struct seg_packets {
-  int64_t seg; int n_events;
+  int64_t seg; int n_events; uint64_t new_items;
   std::vector<c8p_pkt_in> pk;                  // the kept packets
   const c8p_c32* iq; uint64_t n_iq; const c8p_c32* chan; uint64_t n_chan;
 };
@@ -89,8 +89,9 @@ struct ctx_holder {
 
 } // namespace
 
-extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_seg* segs, int64_t n_seg, c8p_rawchain_cb cb, void* user,
-                                c8p_rawchain_stats* stats, char* err, int errcap)
+// stream = true: segs[0] is the whole capture, cut into n_seg pieces of seg_items with the state carried across the cuts
+static int run_impl(const char* lib, int device, const c8p_rawchain_seg* segs, int64_t n_seg, bool stream, uint64_t seg_items,
+                    c8p_rawchain_cb cb, void* user, c8p_rawchain_stats* stats, char* err, int errcap)
 {
   auto fail = [&](const std::string& m, int rc) { if (err && errcap > 0) snprintf(err, (size_t)errcap, "%s", m.c_str()); return rc; };
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -118,10 +119,21 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
 
     std::thread t_detect([&] { stage([&] {
       std::vector<c8p_sync_evt> ev;
+      c8p_det_state state, state2;
+      memset(&state, 0, sizeof(state));
+      uint64_t commit = 0;                            // stream: first item the next call decides about
       for (int64_t s = 0; s < n_seg; s++) {
+        const c8p_rawchain_seg& G = stream ? segs[0] : segs[s];
         c8p_detect_in d;
         memset(&d, 0, sizeof(d));
-        d.mem = C8P_MEM_DEVICE; d.raw = segs[s].raw; d.n = segs[s].n;
+        uint64_t lo = 0, c2 = 0;                      // stream: the call sees items [lo, cut), the first n_hist of them are history
+        d.mem = C8P_MEM_DEVICE; d.raw = G.raw; d.n = G.n;
+        if (stream) {
+          const uint64_t cut = std::min<uint64_t>(G.n, (uint64_t)(s + 1) * seg_items);
+          lo = commit > C8P_DET_HIST ? commit - C8P_DET_HIST : 0;
+          d.raw = G.raw + lo; d.n = cut - lo; d.n_hist = commit - lo;
+          d.state = s ? &state : nullptr; d.state_out = &state2; d.commit = &c2;
+        }
         det.check(api.detect(det.c, &d), "c8p_detect");
         uint64_t bytes = 0;
         (void)api.buffer(det.c, C8P_BUF_DET_EVT, &bytes);
@@ -129,13 +141,15 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
         if (bytes) det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
         seg_events o;
         o.seg = s; o.in.resize(ev.size());
+        o.new_items = stream ? (lo + c2) - commit : G.n;
+        if (stream) { commit = lo + c2; state = state2; }
         for (size_t i = 0; i < ev.size(); i++) {
           c8p_sig_in& k = o.in[i];
           memset(&k, 0, sizeof(k));
-          k.raw_off[0] = ev[i].index;
-          k.n_avail = (uint32_t)std::min<uint64_t>(segs[s].n - ev[i].index, 224u + 109280u);     // the longest packet: 4095 bytes at 6 Mb/s
+          k.raw_off[0] = lo + ev[i].index;
+          k.n_avail = (uint32_t)std::min<uint64_t>(G.n - k.raw_off[0], 224u + 109280u);       // the longest packet: 4095 bytes at 6 Mb/s
           k.cfo_rad = ev[i].rad; k.snr = ev[i].snr; k.rssi = ev[i].rssi; k.n_ant = 1;
-          if (segs[s].ant1_off) { k.n_ant = 2; k.raw_off[1] = segs[s].ant1_off + ev[i].index; }
+          if (G.ant1_off) { k.n_ant = 2; k.raw_off[1] = G.ant1_off + k.raw_off[0]; }
         }
         if (!q1.put(std::move(o))) return;
       }
@@ -145,19 +159,22 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
     std::thread t_signal([&] { stage([&] {
       seg_events in;
       std::vector<c8p_pkt_in> all;
+      uint64_t scan = 0;                              // stream: where the block's S_TRIGGER scan stands
       for (int64_t k = 0; q1.get(in); k++) {
         ctx_holder& sg = *sigs[k & 1];
+        const c8p_rawchain_seg& G = stream ? segs[0] : segs[in.seg];
         sig_arenas.acquire();
         all.assign(in.in.size(), c8p_pkt_in());
         c8p_signal_in b;
         memset(&b, 0, sizeof(b));
         b.n_evt = (int32_t)in.in.size(); b.mem = C8P_MEM_DEVICE; b.evts = in.in.data();
-        b.raw = segs[in.seg].raw; b.n_raw = segs[in.seg].ant1_off ? segs[in.seg].ant1_off + segs[in.seg].n : segs[in.seg].n;
+        b.raw = G.raw; b.n_raw = G.ant1_off ? G.ant1_off + G.n : G.n;
         b.consume = 1; b.pkt_host = all.data();
+        if (stream) { b.scan_from = scan; b.scan_next = &scan; }
         sg.check(api.signal(sg.c, &b), "c8p_signal");
         sg.check(api.sync(sg.c), "c8p_sync");                     // c8p_rx reads these arenas on ITS streams
         seg_packets o;
-        o.seg = in.seg; o.n_events = (int)in.in.size();
+        o.seg = in.seg; o.n_events = (int)in.in.size(); o.new_items = in.new_items;
         for (const c8p_pkt_in& p : all) if (p.n_items) o.pk.push_back(p);
         uint64_t bi = 0, bc = 0;
         o.iq = (const c8p_c32*)api.buffer(sg.c, C8P_BUF_SIG_IQ, &bi);
@@ -177,7 +194,7 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
         rx.check(api.select(rx.c, prev_ticket), "c8p_select");
         outs.assign(prev.pk.size(), c8p_pkt_out());
         if (!outs.empty()) rx.check(api.fetch(rx.c, C8P_BUF_OUT, outs.data(), 0, sizeof(c8p_pkt_out) * outs.size()), "c8p_fetch(outs)");
-        st.segments++; st.items += (int64_t)segs[prev.seg].n; st.events += prev.n_events; st.packets += (int64_t)prev.pk.size();
+        st.segments++; st.items += (int64_t)prev.new_items; st.events += prev.n_events; st.packets += (int64_t)prev.pk.size();
         for (const c8p_pkt_out& o : outs) st.pdus += o.n_pdu;
         if (cb) {
           c8p_rawchain_out r;
@@ -211,4 +228,23 @@ extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_
   } catch (const std::exception& ex) {
     return fail(ex.what(), C8P_EHIP);
   }
+}
+
+extern "C" int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_seg* segs, int64_t n_seg, c8p_rawchain_cb cb, void* user,
+                                c8p_rawchain_stats* stats, char* err, int errcap)
+{
+  return run_impl(lib, device, segs, n_seg, false, 0, cb, user, stats, err, errcap);
+}
+
+extern "C" int c8p_rawchain_stream(const char* lib, int device, const c8p_c32* raw, uint64_t n, uint64_t ant1_off, uint64_t seg_items,
+                                   c8p_rawchain_cb cb, void* user, c8p_rawchain_stats* stats, char* err, int errcap)
+{
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (!raw || !n || seg_items < 4 * C8P_DET_HIST) {
+    if (err && errcap > 0) snprintf(err, (size_t)errcap, "bad capture or segment length");
+    return C8P_EINVAL;
+  }
+  c8p_rawchain_seg whole;
+  whole.raw = raw; whole.n = n; whole.ant1_off = ant1_off;
+  return run_impl(lib, device, &whole, (int64_t)((n + seg_items - 1) / seg_items), true, seg_items, cb, user, stats, err, errcap);
 }

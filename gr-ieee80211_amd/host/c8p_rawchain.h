@@ -43,6 +43,14 @@ typedef struct c8p_rawchain_stats {
 int c8p_rawchain_run(const char* lib, int device, const c8p_rawchain_seg* segs, int64_t n_seg, c8p_rawchain_cb cb, void* user,
                      c8p_rawchain_stats* stats, char* err, int errcap);
 
+/* ONE resident capture of n items (antenna 1, if any, ant1_off items behind antenna 0 in the same allocation), worked through in
+ * segments of seg_items: the detection state (c8p_det_state at the commit point) and the signal block's scan position are carried
+ * from one segment to the next, and a packet that straddles a cut is read from the capture wherever its items lie — the PDUs are
+ * those of one c8p_detect / c8p_signal / c8p_rx pass over the whole capture (examples/rx_file.c), delivered segment by segment
+ * while later segments are still being searched.  Flags that are still waiting for items when the capture ends yield nothing. */
+int c8p_rawchain_stream(const char* lib, int device, const c8p_c32* raw, uint64_t n, uint64_t ant1_off, uint64_t seg_items,
+                        c8p_rawchain_cb cb, void* user, c8p_rawchain_stats* stats, char* err, int errcap);
+
 #ifdef __cplusplus
 }
 #endif

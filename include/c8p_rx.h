@@ -271,6 +271,9 @@ typedef struct c8p_signal_in {
                                 descriptors are known (the copies are only enqueued)                                          */
   int32_t           rsv;
   c8p_pkt_in*       pkt_host; /* consume = 1: if not NULL, receives the n_evt descriptors (what C8P_BUF_SIG_PKT holds)         */
+  uint64_t          scan_from; /* consume = 1: where the S_TRIGGER scan stands when it meets the first flag (raw_off[0] units): flags
+                                 before it are C8P_SIG_SKIPPED — the position a previous call over the same stream left in *scan_next */
+  uint64_t*         scan_next; /* consume = 1: if not NULL, receives the scan position after the last flag that was looked at      */
 } c8p_signal_in;
 
 /* State of trigger_impl + sync_impl at a commit point of the stream: everything before it is final, nothing pending

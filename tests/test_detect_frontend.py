@@ -633,3 +633,51 @@ def test_rawchain_random_streams_equal_the_oracle_chain(n_ant):
             n_pdu += len(r["pdus"])
             n_fail += int(r["out"]["n_crc_fail"])
     assert n_pdu >= 120 and n_fail >= 20, (n_pdu, n_fail, n_drop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ant,seg_items", [(1, 20000), (1, 7777), (2, 33333), (1, 1 << 20)])
+def test_rawchain_stream_cut_anywhere_equals_one_pass_over_the_capture(n_ant, seg_items):
+    """c8p_rawchain_stream: one resident capture worked through in segments — detection state (commit points) and the signal block's
+    scan position carried across the cuts, packets that straddle a cut read from the capture wherever they lie.  Against ONE
+    c8p_detect / c8p_signal (consume) / c8p_rx pass over the whole capture: the same packets in the same order (L-SIG fields, CFO),
+    the same per-packet results and PDU bytes.  Segments far shorter than a packet, and one longer than the capture."""
+    import torch
+    from c8p_testlib import H22
+    from gr_ieee80211_amd import blocks, engine
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77 + n_ant)
+    names = [k for k in SWEEP if (n_ant == 2 or int(SWEEP[k]["nss"]) == 1)]
+    parts = [[], []]
+    for k in range(60):
+        d = SWEEP[names[int(rng.integers(len(names)))]]
+        nss = int(d["nss"])
+        Hc = None if n_ant == 1 else (H22 if nss == 2 else np.array([[1.0], [0.4 - 0.7j]], np.complex64))
+        rx = np.atleast_2d(through_channel(np.atleast_2d(dewindow(d["tx"]))[: (nss if n_ant == 2 else 1)], Hc, float(rng.uniform(10.0, 35.0)), rng,
+                                           lead=int(rng.choice([150, 400, 900, 2500]))))
+        w = 2 * np.pi * float(rng.uniform(-100e3, 100e3)) / 20e6
+        rx = (rx * np.exp(1j * w * np.arange(rx.shape[1]))).astype(np.complex64)
+        parts[0].append(rx[0]); parts[1].append(rx[1] if n_ant == 2 else rx[0])
+    a0, a1 = np.concatenate(parts[0]), np.concatenate(parts[1])
+    n = len(a0)
+    arena = np.concatenate([a0, a1]) if n_ant == 2 else a0
+    t = torch.from_numpy(arena.view(np.float32).copy()).to(dev)
+    torch.cuda.synchronize()
+    seg = (t.data_ptr(), n, n if n_ant == 2 else 0)
+    one, cut = [], []
+    blocks.rawchain_run([seg], on_segment=one.append)
+    st = blocks.rawchain_run([seg], on_segment=cut.append, stream_items=seg_items)
+    assert st["segments"] == (n + seg_items - 1) // seg_items == len(cut) and st["items"] <= n
+    ref = one[0]
+    assert len(ref["pkts"]) >= 50 and st["packets"] == len(ref["pkts"]) and st["pdus"] == int(ref["outs"]["n_pdu"].sum())
+    k = 0
+    for g in cut:
+        for i in range(len(g["pkts"])):
+            for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "n_items", "n_ant", "cfo", "snr", "rssi"):
+                assert g["pkts"][i][f] == ref["pkts"][k][f], (k, f)
+            og, orf = g["outs"][i], ref["outs"][k]
+            assert og["n_pdu"] == orf["n_pdu"] and og["n_crc_fail"] == orf["n_crc_fail"] and og["pdu_bytes"] == orf["pdu_bytes"], k
+            assert np.array_equal(g["pdu_arena"][int(og["pdu_off"]):int(og["pdu_off"]) + int(og["pdu_bytes"])],
+                                  ref["pdu_arena"][int(orf["pdu_off"]):int(orf["pdu_off"]) + int(orf["pdu_bytes"])]), k
+            k += 1
+    assert k == len(ref["pkts"])
