@@ -816,7 +816,21 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, segments=24):
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
     dt = st["seconds"]
-    return {"segments": st["segments"], "samples_per_segment": n, "packets_per_segment": reps, "events": st["events"], "packets": st["packets"],
+    # what a host-fed caller sees: the same segment in pinned host memory, crossing PCIe once per pass (inside c8p_detect)
+    pcie = None
+    try:
+        pin = torch.empty(2 * n, dtype=torch.float32).pin_memory()
+        pin.copy_(arr.keepalive)
+        torch.cuda.synchronize(dev)
+        hs = [(pin.data_ptr(), n)] * 8
+        blocks.rawchain_run(hs[:3], device=local, host=True)
+        sp = blocks.rawchain_run(hs, device=local, host=True)
+        pcie = {"segments": sp["segments"], "pdus_ok": sp["pdus"], "ms_per_segment": 1e3 * sp["seconds"] / sp["segments"],
+                "packets_per_s": sp["pdus"] / sp["seconds"], "samples_per_s": sp["items"] / sp["seconds"],
+                "GB_per_s_over_pcie": 8.0 * sp["items"] / sp["seconds"] / 1e9}
+    except Exception as e:
+        pcie = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"pcie_inclusive": pcie, "segments": st["segments"], "samples_per_segment": n, "packets_per_segment": reps, "events": st["events"], "packets": st["packets"],
             "pdus_ok": st["pdus"], "ms_per_segment": 1e3 * dt / segments, "packets_per_s": st["pdus"] / dt, "samples_per_s": st["items"] / dt,
             "x_realtime_20MSps": st["items"] / dt / 20e6,
             "note": "c8p_detect -> c8p_signal (consume) -> c8p_rx through host/c8p_rawchain.cc (three host threads, everything resident in HBM, "

@@ -13,7 +13,7 @@ F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
 BUF_TAGS, BUF_LLR, BUF_OUT, BUF_PDU, BUF_BITS, BUF_SBITS, BUF_MUCHAN, BUF_SIG_PKT, BUF_SIG_IQ, BUF_SIG_CHAN, \
-    BUF_DET_EVT, BUF_DET_AC, BUF_DET_TRIG, BUF_DET_CONJ, BUF_TX_IQ, BUF_TX_DESC, BUF_TX_CODED, BUF_DECSTAT = range(18)
+    BUF_DET_EVT, BUF_DET_AC, BUF_DET_TRIG, BUF_DET_CONJ, BUF_TX_IQ, BUF_TX_DESC, BUF_TX_CODED, BUF_DECSTAT, BUF_DET_RAW = range(19)
 K_LAYOUT, K_CLASSIFY, K_DEMOD, K_VITERBI, K_FINISH, K_SIGNAL, K_PRESISO, K_TRIGGER, K_SYNCEVT, K_TXBITS, K_TXSYM, K_COUNT = range(12)
 K_NAMES = ["layout", "classify", "demod_sym", "viterbi_fwd", "finish", "signal", "presiso", "trigger", "syncevt", "txbits", "txsym"]
 TAB_DEINT_L, TAB_DEINT_NL, TAB_DEINT_NL2, TAB_SIG_DEMAP_NL, TAB_DEINT_SIGB, TAB_SV_OUT, \

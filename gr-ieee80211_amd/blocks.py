@@ -172,7 +172,7 @@ class Block:
 
 
 class _RawSeg(C.Structure):
-    _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64), ("ant1_off", C.c_uint64)]
+    _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64), ("ant1_off", C.c_uint64), ("mem", C.c_int32), ("rsv", C.c_int32)]
 
 
 class _RawStats(C.Structure):
@@ -185,16 +185,17 @@ class _RawOut(C.Structure):
                 ("rx", C.c_void_p)]
 
 
-def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_items=0):
+def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_items=0, host=False):
     """host/c8p_rawchain.h: raw stream segments resident on the device -> PDUs, as a pipeline (c8p_detect -> c8p_signal with
     the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items[, item offset of antenna 1's
     stream inside the same allocation: rx2.grc's chain]), ...]; on_segment(dict)
     is called per segment in order with its descriptors / per-packet results (numpy copies) and the PDU arena bytes.
+    host=True: the pointers are host memory (pinned for the DMA rate), the items cross PCIe once.
     stream_items > 0: segments[0] is ONE capture, worked through in pieces of that many items with the detection state and the
     signal block's scan position carried across the cuts (c8p_rawchain_stream).  Returns the run's totals."""
     from . import abi
     L = lib()
-    segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0) for t in segments])
+    segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0, 0 if host else 1, 0) for t in segments])
     st = _RawStats()
     err = C.create_string_buffer(512)
     cb_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_RawOut))

@@ -997,6 +997,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
   S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * n : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
   S.used[C8P_BUF_DET_TRIG] = n; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
+  S.used[C8P_BUF_DET_RAW] = sizeof(cf) * in->n; S.ptr[C8P_BUF_DET_RAW] = d_all;
   S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * n : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
   return C8P_OK;
 }

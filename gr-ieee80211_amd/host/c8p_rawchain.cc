@@ -63,7 +63,7 @@ private:
   bool d_open = false;
 };
 
-struct seg_events { int64_t seg; uint64_t new_items; std::vector<c8p_sig_in> in; };
+struct seg_events { int64_t seg; uint64_t new_items; const c8p_c32* raw_dev; std::vector<c8p_sig_in> in; };
 struct seg_packets {
   int64_t seg; int n_events; uint64_t new_items;
   std::vector<c8p_pkt_in> pk;                  // the kept packets
@@ -96,6 +96,8 @@ static int run_impl(const char* lib, int device, const c8p_rawchain_seg* segs, i
   auto fail = [&](const std::string& m, int rc) { if (err && errcap > 0) snprintf(err, (size_t)errcap, "%s", m.c_str()); return rc; };
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_seg < 0 || (n_seg > 0 && !segs)) return fail("bad segment list", C8P_EINVAL);
+  for (int64_t s = 0; s < (stream ? 1 : n_seg); s++)
+    if (segs[s].mem == C8P_MEM_HOST && (stream || segs[s].ant1_off)) return fail("host segments: c8p_rawchain_run, one antenna", C8P_EINVAL);
   try {
     const char* e = getenv("C8P_RX_LIB");
     const c8p_api api = load_c8p_api(lib ? lib : (e ? e : "libc8p_rx.so"));
@@ -127,7 +129,7 @@ static int run_impl(const char* lib, int device, const c8p_rawchain_seg* segs, i
         c8p_detect_in d;
         memset(&d, 0, sizeof(d));
         uint64_t lo = 0, c2 = 0;                      // stream: the call sees items [lo, cut), the first n_hist of them are history
-        d.mem = C8P_MEM_DEVICE; d.raw = G.raw; d.n = G.n;
+        d.mem = G.mem == C8P_MEM_HOST ? C8P_MEM_HOST : C8P_MEM_DEVICE; d.raw = G.raw; d.n = G.n;
         if (stream) {
           const uint64_t cut = std::min<uint64_t>(G.n, (uint64_t)(s + 1) * seg_items);
           lo = commit > C8P_DET_HIST ? commit - C8P_DET_HIST : 0;
@@ -141,6 +143,7 @@ static int run_impl(const char* lib, int device, const c8p_rawchain_seg* segs, i
         if (bytes) det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
         seg_events o;
         o.seg = s; o.in.resize(ev.size());
+        o.raw_dev = stream ? G.raw : (const c8p_c32*)api.buffer(det.c, C8P_BUF_DET_RAW, &bytes);     // (the caller's pointer, or the engine's copy of host items)
         o.new_items = stream ? (lo + c2) - commit : G.n;
         if (stream) { commit = lo + c2; state = state2; }
         for (size_t i = 0; i < ev.size(); i++) {
@@ -168,7 +171,7 @@ static int run_impl(const char* lib, int device, const c8p_rawchain_seg* segs, i
         c8p_signal_in b;
         memset(&b, 0, sizeof(b));
         b.n_evt = (int32_t)in.in.size(); b.mem = C8P_MEM_DEVICE; b.evts = in.in.data();
-        b.raw = G.raw; b.n_raw = G.ant1_off ? G.ant1_off + G.n : G.n;
+        b.raw = in.raw_dev; b.n_raw = G.ant1_off ? G.ant1_off + G.n : G.n;
         b.consume = 1; b.pkt_host = all.data();
         if (stream) { b.scan_from = scan; b.scan_next = &scan; }
         sg.check(api.signal(sg.c, &b), "c8p_signal");
@@ -245,6 +248,7 @@ extern "C" int c8p_rawchain_stream(const char* lib, int device, const c8p_c32* r
     return C8P_EINVAL;
   }
   c8p_rawchain_seg whole;
-  whole.raw = raw; whole.n = n; whole.ant1_off = ant1_off;
+  memset(&whole, 0, sizeof(whole));
+  whole.raw = raw; whole.n = n; whole.ant1_off = ant1_off; whole.mem = C8P_MEM_DEVICE;
   return run_impl(lib, device, &whole, (int64_t)((n + seg_items - 1) / seg_items), true, seg_items, cb, user, stats, err, errcap);
 }

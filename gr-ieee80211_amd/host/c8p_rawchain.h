@@ -19,6 +19,10 @@ typedef struct c8p_rawchain_seg {
   uint64_t n;              /* items                                                                               */
   uint64_t ant1_off;       /* 0: one antenna (signal -> demod).  Otherwise rx2.grc's chain (signal2 -> demod2): antenna 1's n items
                               start ant1_off items after raw (the same allocation); detection listens on antenna 0             */
+  int32_t  mem;            /* C8P_MEM_DEVICE (1) or C8P_MEM_HOST (0; c8p_rawchain_run only, one antenna): the items come from host memory —
+                              pinned (c8p_host_alloc) for the DMA rate — and cross PCIe once, inside c8p_detect; c8p_signal reads the
+                              engine's device copy (C8P_BUF_DET_RAW)                                                             */
+  int32_t  rsv;
 } c8p_rawchain_seg;
 
 typedef struct c8p_rawchain_out {

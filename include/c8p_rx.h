@@ -341,7 +341,9 @@ typedef struct c8p_decode_in {
                                Viterbi kernel (it was decoded by the clamp-exact kernel); [n_pkt + p] = number of 30-step trellis blocks the fast
                                kernel ran with the float compare because their path metrics were not provably positive; [2 n_pkt + p] = float
                                bits of the bound it was given: >= sum(max(0, -LLR)) over any 60 consecutive LLRs of the packet ([p] = 0 only) */
-#define C8P_BUF_COUNT    18
+#define C8P_BUF_DET_RAW  18 /* c8p_c32[n]: c8p_detect's raw items on the device (history included) — the engine's copy when they came from host
+                               memory, the caller's own pointer otherwise: what a following c8p_signal can read without a second upload */
+#define C8P_BUF_COUNT    19
 
 /* kernels, for c8p_kernel_time() */
 #define C8P_K_LAYOUT   0    /* H2D upload of descriptors + arena layout (a copy, not a kernel) */

@@ -681,3 +681,27 @@ def test_rawchain_stream_cut_anywhere_equals_one_pass_over_the_capture(n_ant, se
                                   ref["pdu_arena"][int(orf["pdu_off"]):int(orf["pdu_off"]) + int(orf["pdu_bytes"])]), k
             k += 1
     assert k == len(ref["pkts"])
+
+
+@pytest.mark.gpu
+def test_rawchain_host_segments_equal_device_segments():
+    """c8p_rawchain_seg.mem = C8P_MEM_HOST: the items come from host memory (pinned here) and cross PCIe once, inside c8p_detect;
+    c8p_signal reads the engine's device copy (C8P_BUF_DET_RAW).  Same packets and PDUs as the same segments resident on the device."""
+    import torch
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    xs = [stream(NAMES, CFOS, seed=61)[0], stream(NAMES[::-1], CFOS, seed=62)[0], stream(NAMES[:5], CFOS[:5], seed=63)[0]] * 2
+    pins = [torch.from_numpy(x.view(np.float32).copy()).pin_memory() for x in xs]
+    devs = [p.to(dev) for p in pins]
+    torch.cuda.synchronize()
+    a, b = [], []
+    sa = blocks.rawchain_run([(t.data_ptr(), len(x)) for t, x in zip(devs, xs)], on_segment=a.append)
+    sb = blocks.rawchain_run([(t.data_ptr(), len(x)) for t, x in zip(pins, xs)], on_segment=b.append, host=True)
+    assert sa["pdus"] == sb["pdus"] >= 2 * (len(NAMES) * 2 + 5) - 2 and sa["packets"] == sb["packets"] and sa["events"] == sb["events"]
+    for ga, gb in zip(a, b):
+        assert np.array_equal(ga["outs"], gb["outs"])
+        for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "n_items", "cfo", "iq_off"):
+            assert np.array_equal(ga["pkts"][f], gb["pkts"][f]), f
+        for o in ga["outs"]:
+            s0, s1 = int(o["pdu_off"]), int(o["pdu_off"]) + int(o["pdu_bytes"])
+            assert np.array_equal(ga["pdu_arena"][s0:s1], gb["pdu_arena"][s0:s1])
