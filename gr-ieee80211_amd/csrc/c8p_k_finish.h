@@ -85,14 +85,15 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
                                                           // bank conflicts cost less than the eighth wave brings)
   // tile[row][lane of the forward pass]: the current survivor block of every segment.  After the traceback the same
   // memory holds bw[], the decoded bits packed 64 per word.
-  __shared__ __attribute__((aligned(16))) uint32_t tile[64 * TS];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[C8P_TB_SEGS * TS];
   // lane D at the entry of every 6-step group = 6 decoded bits; later the CRC-32 byte table.  Dynamic: sized by the launch for the
   // longest trellis of the batch (the launch passes it: 3.8 KB at cfg 2 instead of the 5.5 KB of the longest legal trellis), which lets
   // 7 instead of 6 of these one-wave workgroups share a CU's LDS
   extern __shared__ __attribute__((aligned(16))) uint8_t snaps[];
   __shared__ uint16_t s_btop[64];
   unsigned long long* bw = (unsigned long long*)tile;      // (C8P_DECODE_T_MAX + 63) / 64 + 2 words <= 64 * TS / 2
-  static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= 64 * TS * 4, "bw must fit in the tile");
+  static_assert(((C8P_DECODE_T_MAX + 63) / 64 + 2) * 8 <= C8P_TB_SEGS * TS * 4, "bw must fit in the tile");
+  static_assert(C8P_TB_SEGS % 4 == 0 && C8P_TB_SEGS <= 64, "the tile is fetched four rows per instruction");
   const int p = blockIdx.x;
   if (p >= n) return;
 #if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)   // experiment build (tools/exp_finclock.py): shader cycles per phase of this wave instead of the results
@@ -169,7 +170,21 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
       const int frow = lane >> 4, fcol = (lane & 15) * 4;
       const uint32_t fcol4 = (uint32_t)fcol * 4u;
       // 16 in-flight 16-byte loads per lane, kept in named registers (an indexed array ends up in scratch)
+#if C8P_TB_SEGS == 64
 #define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#elif C8P_TB_SEGS == 52
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#elif C8P_TB_SEGS == 56
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#elif C8P_TB_SEGS == 48
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+#elif C8P_TB_SEGS == 44
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#elif C8P_TB_SEGS == 40
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+#elif C8P_TB_SEGS == 32
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#endif
 #define C8P_DECL(j) const int fb##j = s_btop[j * 4 + frow]; uint4 pf##j;
       C8P_ROWS16(C8P_DECL)
       // byte offset inside the packet's survivor area (32 bits, uniform base): block (fb_j - i) of an active row, block 0 of an

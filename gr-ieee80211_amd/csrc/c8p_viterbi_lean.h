@@ -286,14 +286,21 @@ __device__ __forceinline__ float lean_bound(float negb)    // wave-uniform (SGPR
 }
 
 // full survivor blocks [S.done, upto) of a packet whose first `n_llr` LLRs (at least the ones those blocks consume) are at Lg
-// Traceback hints: k_finish walks segments of `segn` survivor blocks in parallel (segn = ceil(T / 1920), c8p_seg_blocks) and has to
+// Traceback hints: k_finish walks segments of `segn` survivor blocks in parallel (segn = ceil(T / (30 C8P_TB_SEGS)), c8p_seg_blocks) and has to
 // assume the lane each segment ends in.  In the last block of every segment the forward pass sets bit 30 of the survivor dword
 // (C8P_SV_HINT; a block holds 30 decisions in bits 29..0) on the lane(s) that hold the largest path metric at the block's end.
 // Only a hint: k_finish checks every assumption against the neighbouring segment and walks again where it was wrong, so the
 // decoded bits do not depend on it — but at cfg 2 / 30 dB nearly every hint is right and the survivors are read ~once instead
 // of 1.3-1.7 times.
 #define C8P_SV_HINT 0x40000000u
-__device__ __forceinline__ int c8p_seg_blocks(int Tn) { return (Tn + 64 * C8P_SV_BLK - 1) / (64 * C8P_SV_BLK); }
+#ifndef C8P_TB_SEGS
+#define C8P_TB_SEGS 40      // traceback segments per packet at most = rows of k_finish's LDS tile (a multiple of 4).  64 until late in round 3: every
+                            // lane of k_finish a segment, 16 KB of tile.  With 40 the walk takes 10 tiles instead of 7 per cfg-2 packet (more instructions in
+                            // k_finish), its exclusive time is the same (0.127 ms), and the PIPELINED step gains 1.5 % (7.10 against 6.99-7.00 M packets/s,
+                            // five builds alternated three times on one box: 64 / 48 / 44 / 40 / 32 -> 7.00 / 7.08 / 7.08 / 7.10 / 7.10): 10 KB of LDS per
+                            // k_finish workgroup leave room for one more decoder workgroup beside it on a CU
+#endif
+__device__ __forceinline__ int c8p_seg_blocks(int Tn) { return (Tn + C8P_TB_SEGS * C8P_SV_BLK - 1) / (C8P_TB_SEGS * C8P_SV_BLK); }
 
 // TOUCH = false: no scalar-cache touches in the float step (k_viterbi_lean4 runs single blocks from inside two nested loops, where
 // the compiler cannot keep the loop-carried touch registers in SGPRs)
