@@ -10,6 +10,7 @@
 struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
 struct c8p_ctx {
   c8p_c32* det_x; uint64_t det_n, det_commit; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
+  const c8p_c32* det_raw; uint64_t det_raw_n;                                           /* C8P_BUF_DET_RAW: the caller's items */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   struct res r[SLOTS];
   int cur, seq;
@@ -45,6 +46,21 @@ int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as
     c->sig_pkt[e].iq_off[0] = off; c->sig_pkt[e].iq_off[1] = ev->n_ant == 2 ? off + cap : 0; c->sig_pkt[e].chan_off = 64u * (uint32_t)e;
     if (!ok) c->sig_pkt[e].n_items = 0;
     off += cap * ev->n_ant;
+  }
+  if (in->consume) {      /* the block's scan rule over the per-flag results (c8p_rx.h); the slots stay where they are */
+    uint64_t pos = in->scan_from;
+    int waiting = 0;
+    for (int e = 0; e < in->n_evt; e++) {
+      c8p_pkt_in* p = &c->sig_pkt[e];
+      const uint64_t idx = in->evts[e].raw_off[0];
+      if (waiting) { p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
+      if (idx < pos) { p->n_items = 0; p->rsv[0] = C8P_SIG_SKIPPED; continue; }
+      if (in->evts[e].n_avail < 224u) { waiting = 1; p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
+      if (p->n_items == 0) { if (p->rsv[0] == C8P_SIG_NEED_MORE) waiting = 1; else pos = idx + 80; continue; }
+      pos = idx + 224 + (uint64_t)p->lsig_nsamp;
+    }
+    if (in->scan_next) *in->scan_next = pos;
+    if (in->pkt_host) memcpy(in->pkt_host, c->sig_pkt, sizeof(c8p_pkt_in) * (size_t)in->n_evt);
   }
   return C8P_OK;
 }
@@ -90,6 +106,9 @@ int c8p_decode(c8p_ctx* c, const c8p_decode_in* in) { next_slot(c); return decod
  * before it has its 240-item search window inside the stream, so later items cannot change it). */
 int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
 {
+  if (!in->state && in->n_hist == 0) { free(c->det_x); c->det_x = NULL; c->det_n = c->det_commit = 0; }   /* a segment from the constructor state */
+  c->det_raw = in->raw;
+  c->det_raw_n = in->n;
   const uint64_t n_new = in->n - in->n_hist;
   c->det_x = (c8p_c32*)realloc(c->det_x, (size_t)(c->det_commit + n_new + 1) * sizeof(c8p_c32));
   memcpy(c->det_x + c->det_commit, in->raw + in->n_hist, (size_t)n_new * sizeof(c8p_c32));
@@ -128,6 +147,7 @@ const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)
     case C8P_BUF_PDU: p = c->s->pdu; b = c->s->n_pdu; break;
     case C8P_BUF_MUCHAN: p = c->s->mu; b = (uint64_t)c->s->n * 128 * sizeof(c8p_c32); break;
     case C8P_BUF_DET_EVT: p = c->det_evt; b = (uint64_t)c->det_nevt * sizeof(c8p_sync_evt); break;
+    case C8P_BUF_DET_RAW: p = c->det_raw; b = c->det_raw_n * sizeof(c8p_c32); break;
     case C8P_BUF_SIG_PKT: p = c->sig_pkt; b = (uint64_t)c->n_sig * sizeof(c8p_pkt_in); break;
     case C8P_BUF_SIG_IQ: p = c->sig_iq; b = c->n_sig_iq * sizeof(c8p_c32); break;
     case C8P_BUF_SIG_CHAN: p = c->sig_chan; b = (uint64_t)c->n_sig * 64 * sizeof(c8p_c32); break;
