@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — RX packets/s of the demod+decode hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself, under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one pass of c8p_rx() over one batch of BASELINE.json configs[1]: 4096 packets of 20 MHz VHT MCS7,
@@ -21,7 +21,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 B_ALG = 8 * 4400 + 512 + 32 + 1462       # algorithmic bytes per packet, SURVEY.md §8(d) = 37 206
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -39,8 +38,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--fixture-workload", action="store_true", help="replicate the 4 committed reference-TX frames (host-generated) "
-                    "instead of generating 4096 distinct packets on the device with c8p_tx")
+    ap.add_argument("--dry-launch", action="store_true", help="no GPU: the launcher, rendezvous (gloo), barriers, max-over-ranks timing and the "
+                    "assembly of the line with a sleep standing in for the step; the line says dry_launch and carries no value")
     ap.add_argument("--no-frontend", action="store_true", help="skip the detection front-end leg (extra object in the JSON line)")
     ap.add_argument("--workload", choices=("cfg2", "cfg4", "cfg1", "cfg3", "cfg4r", "cfg5u0", "cfg5u1"), default="cfg2",
                     help="cfg2: BASELINE configs[1], one 4096-packet batch per GPU and step (weak scaling; the headline). "
@@ -55,6 +54,16 @@ def main():
     ap.add_argument("--no-host-legs", action="store_true", help="skip the PCIe-inclusive and block-chain legs (extra keys in the JSON line)")
     ap.add_argument("--no-check", action="store_true", help="kernel-variant experiments only: skip the PDU gate (line is then INVALID)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)                        # N ranks under torch.distributed.run; this process only waits for them
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a line whose n_gpus is not "
+                         "what was asked for" % (args.gpus, env_world))
+    if args.dry_launch:
+        return dry_launch(args)
 
     # stdout carries ONE JSON line and nothing else: libraries that chat on file descriptor 1 (RCCL prints a version banner when
     # a communicator is created) are pointed at stderr; the line itself goes to a private duplicate of the original stdout
@@ -70,16 +79,21 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # any torch.distributed.run launch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)                         # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the RCCL communicator has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
-    from c8p_cases import cfg2_batch, cfg2_workload_on_device
-    from c8p_testlib import abi
+    from __graft_entry__ import load_package
+    load_package()
     from gr_ieee80211_amd import engine
+    from gr_ieee80211_amd.workloads import WORKLOADS, workload_on_device
 
     if args.workload == "cfg4":
         st = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, max(args.steps, 1) if args.steps != 200 else 5,
@@ -104,23 +118,13 @@ def main():
 
     # ---- synthetic workload, resident in HBM before anything is timed
     t_gen = time.time()
-    if args.fixture_workload:
-        b, expected = cfg2_batch(args.batch, snr_db=args.snr, seed=8021200 + 100000 * rank)
-        pk, iq, chan = b.arrays()
-        iq_d = torch.from_numpy(iq.view(np.float32)).to(dev)
-        chan_d = torch.from_numpy(chan.view(np.float32)).to(dev)
-        iq_dev = engine.DevArray(iq_d.data_ptr(), iq.size, iq_d)
-        chan_dev = engine.DevArray(chan_d.data_ptr(), chan.size, chan_d)
-        data_note = "synthetic (4 reference-toolbox TX frames replicated, de-windowed: half-amplitude symbol edges undone; AWGN + random-phase flat channel)"
-    else:
-        # 4096 distinct MPDUs, generated on the box by the build's own transmitter (c8p_tx), per-packet
-        # flat-channel phase + AWGN on the device, c8p_signal to the signal -> demod boundary
-        from c8p_cases import WORKLOADS, workload_on_device
-        kind = {"cfg4r": "cfg4"}.get(args.workload, args.workload)
-        pk, iq_dev, chan_dev, expected, _keep = workload_on_device(kind, args.batch, args.snr, 100000 * rank, torch, dev, local)
-        iq, chan = None, None
-        data_note = ("synthetic (c8p_tx on the device, distinct payloads; clean OFDM symbols: the reference toolbox's half-amplitude symbol edges "
-                     "are not applied — C8P_TX_NO_WINDOW, DESIGN.md §6 — AWGN + random-phase flat channel)")
+    # 4096 distinct MPDUs, generated on the box by the build's own transmitter (c8p_tx), per-packet
+    # flat-channel phase + AWGN on the device, c8p_signal to the signal -> demod boundary
+    kind = {"cfg4r": "cfg4"}.get(args.workload, args.workload)
+    pk, iq_dev, chan_dev, expected, _keep = workload_on_device(kind, args.batch, args.snr, 100000 * rank, torch, dev, local)
+    iq, chan = None, None
+    data_note = ("synthetic (c8p_tx on the device, distinct payloads; clean OFDM symbols: the reference toolbox's half-amplitude symbol edges "
+                 "are not applied — C8P_TX_NO_WINDOW, DESIGN.md §6 — AWGN + random-phase flat channel)")
     n_pkt = len(pk)
     t_gen = time.time() - t_gen
     other = args.workload != "cfg2"        # not the headline config: algorithmic bytes from the batch itself (SURVEY §8d formula)
@@ -169,7 +173,7 @@ def main():
 
     # the timed region: EXACTLY --steps steps between two barriers (+ device syncs), max over ranks; repeated --repeats times so
     # that the headline is a median with its spread instead of one sample of a few tens of ms
-    rep_elapsed = []
+    rep_elapsed, rank_elapsed = [], []               # max over the ranks / this rank's own clock, per repeat
     n_rep = max(1, args.repeats)
     r_i = 0
     while r_i < n_rep:
@@ -181,6 +185,7 @@ def main():
         eng.sync()
         barrier()
         el = time.perf_counter() - t0
+        rank_elapsed.append(el)
         if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,6 +197,13 @@ def main():
             # the reduced first sample)
             n_rep = min(2000, max(n_rep, int(np.ceil(args.min_timed_s / max(el, 1e-6)))))
     elapsed = float(np.median(rep_elapsed))
+    # every rank's own rate (its median repeat by its own clock): the spread says whether one GPU holds the others back
+    per_rank = [n_pkt * args.steps / float(np.median(rank_elapsed))]
+    if use_dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = per_rank[0]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.tolist()]
     kt = eng.kernel_times()
     eng.close()                              # its arenas (one set per slot, sized for the worst case per packet) are not needed any more
 
@@ -216,6 +228,7 @@ def main():
     eng_x.close()
 
     out = None
+    fe_unit = None
     if rank == 0:
         total_pkts = n_pkt * world * args.steps
         value = total_pkts / elapsed
@@ -237,6 +250,8 @@ def main():
             "metric": "RX packets/s (20 MHz VHT MCS7 1458 B)" if not other else "RX packets/s (NOT the headline config: %s)" % WORKLOADS[kind][8],
             "value": value, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "per_rank_packets_per_s": {"values": per_rank, "min": min(per_rank), "max": max(per_rank),
+                                       "note": "each rank's own packets/s by its own clock (median repeat); `value` = all ranks' packets / the slowest rank's time"},
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": data_note if not args.no_check else "INVALID (--no-check experiment)",
             "repeats": {"n": len(rep_elapsed), "value_median": value, "value_min": vals[0], "value_max": vals[-1],
@@ -269,6 +284,7 @@ def main():
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
             out["frontend_detect"] = frontend_detect(torch, dev, local)
+            fe_unit = out["frontend_detect"].pop("_unit", None)
         if not args.no_configs and world == 1:
             out["configs"] = config_legs(torch, dev, local, args.snr)
     # BASELINE configs[3] beside the headline: ONE stream scattered from rank 0, decoded, gathered (every rank takes part).  The
@@ -321,13 +337,112 @@ def main():
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
-            if isinstance(out.get("frontend_detect"), dict) and "raw_stream_to_pdus" in out["frontend_detect"]:
-                out["frontend_detect"]["raw_stream_cpu_baseline"] = cpu_baseline_raw_stream()
+            if isinstance(out.get("frontend_detect"), dict) and fe_unit is not None:
+                out["frontend_detect"]["raw_stream_cpu_baseline"] = cpu_baseline_raw_stream(fe_unit)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out["legs"] = legs_summary(out)                   # last key of the line: what survives when only the tail of the line is kept
         emit(out)
+
+
+def legs_summary(out):
+    """every leg's one number (packets/s unless the name says otherwise), compact, as the LAST key of the line: the driver's record
+    keeps the contract keys and the tail of stdout, and tests/test_bench_contract.py compares these with the committed line"""
+    def g(*path):
+        v = out
+        for k in path:
+            if not isinstance(v, dict) or k not in v:
+                return None
+            v = v[k]
+        return round(float(v), 1) if isinstance(v, (int, float)) else None
+    legs = {"headline": g("value"), "cfg1": g("configs", "cfg1", "packets_per_s"), "cfg3": g("configs", "cfg3", "packets_per_s"),
+            "cfg4_share": g("configs", "cfg4_one_gpu_share", "packets_per_s"), "cfg5_sta0": g("configs", "cfg5_station0", "packets_per_s"),
+            "sharded_rccl": g("sharded_stream", "feeds", "rccl_scatter", "packets_per_s"), "pcie": g("pcie_inclusive_packets_per_s"),
+            "block_chain": g("block_chain_packets_per_s"), "block_fused": g("block_chain_fused_packets_per_s"),
+            "detect_samples_per_s": g("frontend_detect", "samples_per_s"), "tx": g("frontend_detect", "tx_packets_per_s"),
+            "raw_chain": g("frontend_detect", "raw_stream_to_pdus", "packets_per_s"),
+            "raw_chain_first_segment_ms": g("frontend_detect", "raw_stream_to_pdus", "first_segment_ms"),
+            "raw_chain_pcie": g("frontend_detect", "raw_stream_to_pdus", "pcie_inclusive", "packets_per_s"),
+            "live_streams_at_realtime": g("frontend_detect", "raw_stream_to_pdus", "live_streams", "streams_at_realtime"),
+            "cpu_1thread": g("cpu_baseline", "value")}
+    return {k: v for k, v in legs.items() if v is not None}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started by hand (no RANK in the environment): start the N ranks, one per GPU, exactly as the driver
+    does — python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>
+    — and pass their exit status on.  Rank 0 prints the line."""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible (no line is printed for a world that cannot exist)" % (args.gpus, have))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank launch failed with status %d" % (args.gpus, rc))
+
+
+def dry_launch(args):
+    """--dry-launch: everything around the measurement without a GPU — the ranks the launcher started rendezvous over gloo, the timed
+    region is bracketed by the same barriers, the elapsed time is the max over the ranks, every rank's own rate is gathered, rank 0
+    prints ONE line with n_gpus = the world that actually ran.  A sleep stands in for the step: the line carries no value."""
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")                 # (gloo chats on file descriptor 1 as RCCL does: the line goes to a private duplicate)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the communicator has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    n_pkt = args.batch
+    for _ in range(args.warmup):
+        time.sleep(1e-4)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-4 * (1 + rank))                    # (rank r is r times slower: the max-reduction and the per-rank spread have something to show)
+    mine = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    per_rank = [n_pkt * args.steps / mine]
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        v = torch.zeros(world, dtype=torch.float64)
+        v[rank] = per_rank[0]
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        per_rank = [float(x) for x in v.tolist()]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit({"metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": None, "unit": "packets/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": 1e3 * el / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "none (dry launch)", "dry_launch": True,
+              "per_rank_packets_per_s": {"values": per_rank, "min": min(per_rank), "max": max(per_rank), "note": "sleeps, not packets"},
+              "config": {"workload": "dry launch: launcher, rendezvous, barriers and reductions only; NOT a measurement",
+                         "parallelism": "packet-sharded x%d, no data-path collective" % world}})
 
 
 _JSON_OUT = None
@@ -383,9 +498,8 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
       direct_h2d    every rank already holds its block in pinned host memory and uploads it itself (c8p_rx with host arenas)
     `timeline_ms` = when, after the step's start, each stage was reached (max over ranks): stages overlap, so they do not add up."""
     import torch.distributed as dist
-    from c8p_cases import cfg2_workload_on_device
-    from c8p_testlib import abi
-    from gr_ieee80211_amd import engine, shard
+    from gr_ieee80211_amd import abi, engine, shard
+    from gr_ieee80211_amd.workloads import cfg2_workload_on_device
     own_group = False
     if not dist.is_initialized():                     # plain `python bench.py`: a world of one, still through RCCL
         import socket
@@ -592,11 +706,11 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
 
 def config_legs(torch, dev, local, snr_db=30.0, timed_s=0.35):
     """The other BASELINE.json configs beside the cfg-2 headline (all through c8p_rx, inputs resident in HBM, generated on the box by
-    c8p_tx as SURVEY.md §8d states them — tests/c8p_cases.py WORKLOADS): packets/s, ms per step, algorithmic bytes per packet
+    c8p_tx as SURVEY.md §8d states them — gr-ieee80211_amd/workloads.py WORKLOADS): packets/s, ms per step, algorithmic bytes per packet
     (8 n_ant n_items + 512 + 32 + PDU bytes) and the HBM fraction a step reaches.  Every published PDU is compared with
     the transmitted MPDU before anything is timed."""
-    from c8p_cases import WORKLOADS, workload_on_device
     from gr_ieee80211_amd import engine
+    from gr_ieee80211_amd.workloads import WORKLOADS, workload_on_device
     legs = [("cfg1", "cfg1", 4096), ("cfg3", "cfg3", 4096), ("cfg3_1024_packets", "cfg3", 1024), ("cfg4_one_gpu_share", "cfg4", 8192),
             ("cfg5_station0", "cfg5u0", 1024), ("cfg5_station1", "cfg5u1", 1024)]
     eng = engine.Engine(device=local)
@@ -737,8 +851,7 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
     """PCIe-inclusive rate of the same batch (tools/pcie_rate.py's pipelined case): IQ + chan in pinned host memory, c8p_rx
     copies them in, per-packet results and the PDU arena are fetched back; submit i+1, then fetch i."""
     import ctypes
-    from c8p_testlib import abi
-    from gr_ieee80211_amd import engine
+    from gr_ieee80211_amd import abi, engine
     hip = ctypes.CDLL("libamdhip64.so")
     iq_pin = torch.empty(2 * iq_dev.n, dtype=torch.float32).pin_memory()
     ch_pin = torch.empty(2 * chan_dev.n, dtype=torch.float32).pin_memory()
@@ -770,14 +883,11 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
 def frontend_detect(torch, dev, local, n_target=32 << 20):
     """SURVEY §8f-2 / f-1 stages, reported beside the headline metric: c8p_detect (presiso.grc + trigger + sync) over a raw
     20 MS/s stream resident in HBM — the dense kernel is k_detect_scan, an HBM-bound scan: 8 B read + 1 B (trigger byte)
-    written per sample, the autocorrelation stream stays on the chip — and the whole chain from that raw stream to PDUs
-    (c8p_detect -> c8p_signal -> c8p_rx) as a pipeline."""
-    from c8p_cases import dewindow
-    from c8p_testlib import load_npz, through_channel
+    written per sample, the autocorrelation stream stays on the chip — the whole chain from that raw stream to PDUs
+    (c8p_detect -> c8p_signal -> c8p_rx) as a pipeline, and the live ingest of many independent streams."""
     from gr_ieee80211_amd import engine
-    d = load_npz("packets_cfg.npz")["cfg2_VHT_mcs7_1458B_0"]
-    rng = np.random.default_rng(1)
-    unit = through_channel(dewindow(d["tx"])[:1], None, 30.0, rng, lead=600)[0]          # one packet + idle time
+    from gr_ieee80211_amd.workloads import raw_stream_unit
+    unit, _pdu = raw_stream_unit(local)                                                  # one cfg-2 packet + idle time, 30 dB
     reps = max(1, n_target // len(unit))
     x = torch.from_numpy(unit.view(np.float32)).to(dev).repeat(reps)
     n = x.numel() // 2
@@ -794,53 +904,140 @@ def frontend_detect(torch, dev, local, n_target=32 << 20):
     eng.close()
     pre_s = kt["presiso"] * 1e-3
     tx = tx_rate(engine, local)
-    chain = raw_stream_chain(torch, dev, local, arr, n, reps)
+    chain = raw_stream_chain(torch, dev, local, arr, n, reps, len(unit))
     return {"tx_packets_per_s": tx, "samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
             "x_realtime_20MSps": n / dt / 20e6, "ms_per_call": 1e3 * dt,
             "kernel_ms": {"scan": round(kt["presiso"], 4), "candidates": round(kt["trigger"], 4), "syncevt": round(kt["syncevt"], 4)},
             "scan_roofline": {"bound": "hbm", "kernel": "k_detect_scan", "alg_bytes_per_sample": 9, "achieved": 9.0 * n / pre_s / 1e9 if pre_s > 0 else 0.0,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (9.0 * n / pre_s / 1e9) / HBM_PEAK_GBS if pre_s > 0 else 0.0},
-            "raw_stream_to_pdus": chain}
+            "raw_stream_to_pdus": chain, "_unit": unit}
 
 
-def raw_stream_chain(torch, dev, local, arr, n, reps, segments=24):
-    """the chain from the RAW stream (rx.grc from the SDR source on) as a pipeline over `segments` copies of one resident
+def chain_report(st, tl, packets_per_segment):
+    """what a run of the raw chain says about itself: the steady-state rate (everything but the pipeline's fill), the cost of the first
+    segment beside it, every stage's host clocks, the per-stage durations from the segment marks, and the counters that would explain
+    a slow run (arena growths inside the run, look-back give-ups)"""
+    def ms(v):
+        return round(1e3 * float(v), 4)
+    stage = {}
+    if tl:
+        det = [m["det_end"] - m["det_begin"] for m in tl]
+        sig = [m["sig_end"] - m["sig_begin"] for m in tl]
+        rxd = [m["rx_done"] - m["rx_submit"] for m in tl]
+        lat = [m["rx_done"] - m["det_begin"] for m in tl]
+        for k, v in (("detect", det), ("signal", sig), ("rx_submit_to_results", rxd), ("segment_latency", lat)):
+            stage[k] = {"median_ms": ms(np.median(v)), "max_ms": ms(np.max(v)), "first_ms": ms(v[0])}
+    ss = max(st["steady_s"], 1e-9)
+    return {"segments": st["segments"], "events": st["events"], "packets": st["packets"], "pdus_ok": st["pdus"], "packets_per_segment": packets_per_segment,
+            "ms_per_segment": 1e3 * ss / max(st["steady_segments"], 1), "packets_per_s": st["steady_pdus"] / ss, "samples_per_s": st["steady_items"] / ss,
+            "x_realtime_20MSps": st["steady_items"] / ss / 20e6, "steady_segments": st["steady_segments"],
+            "first_segment_ms": ms(st["first_segment_s"]), "whole_run_ms_per_segment": 1e3 * st["seconds"] / max(st["segments"], 1),
+            "whole_run_packets_per_s": st["pdus"] / max(st["seconds"], 1e-9),
+            "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
+            "stage_ms": stage, "arena_growths_in_run": st["arena_growths"], "arena_GB": round(st["arena_bytes"] / 1e9, 3),
+            "lookback_giveups": st["det_giveups"], "ticket_scans": st["det_ticket_scans"]}
+
+
+def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
+    """the chain from the RAW stream (rx.grc from the SDR source on) as a pipeline over `segments` passes over one resident
     33.5 M-item segment: host/c8p_rawchain.cc — segment i+2 in c8p_detect while i+1 is in c8p_signal (consume: the block's scan
     rule inside the engine, the kept packets back to back) and i in c8p_rx; each stage has its own engine context (own HIP
-    streams) and host thread.  Every PDU is counted from the per-packet results fetched back."""
+    streams) and host thread.  ONE handle for everything: its arenas are reserved at create, the untimed warm-up runs through the
+    same contexts as the timed run, and the run reports where its time went (chain_report).  Every PDU is counted from the
+    per-packet results fetched back."""
     from gr_ieee80211_amd import blocks
-    segs = [(arr.ptr, n)] * segments
+    out = {"samples_per_segment": n,
+           "note": "c8p_detect -> c8p_signal (consume) -> c8p_rx through one host/c8p_rawchain handle (three host threads, four engine contexts "
+                   "that outlive the runs, arenas reserved at create), everything resident in HBM, no state carried between segments; "
+                   "packets_per_s / ms_per_segment = the steady state (the last steady_segments segments), first_segment_ms and the "
+                   "whole-run figures beside it; compare `value` (the same packets handed over at the demod boundary)"}
+    h = None
     try:
-        blocks.rawchain_run(segs[:4], device=local)                          # untimed: arenas, streams
-        st = blocks.rawchain_run(segs, device=local)
+        h = blocks.RawChain(device=local, reserve_seg_items=n, reserve_seg_events=reps + reps // 8 + 64, reserve_seg_packets=reps + 64,
+                            reserve_pkt_items=unit_len, reserve_host=True)
+        segs = [(arr.ptr, n)] * segments
+        warm = h.run(segs[:4])                                                # untimed, the same handle: streams, clocks
+        st = h.run(segs)
+        out.update(chain_report(st, h.timeline(), reps))
+        out["warmup"] = {"segments": warm["segments"], "arena_growths": warm["arena_growths"], "first_segment_ms": round(1e3 * warm["first_segment_s"], 3)}
     except Exception as e:
-        return {"error": "%s: %s" % (type(e).__name__, e)}
-    dt = st["seconds"]
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+        if h is not None:
+            h.close()
+        return out
     # what a host-fed caller sees: the same segment in pinned host memory, crossing PCIe once per pass (inside c8p_detect)
-    pcie = None
+    pin = None
     try:
         pin = torch.empty(2 * n, dtype=torch.float32).pin_memory()
         pin.copy_(arr.keepalive)
         torch.cuda.synchronize(dev)
-        hs = [(pin.data_ptr(), n)] * 8
-        blocks.rawchain_run(hs[:3], device=local, host=True)
-        sp = blocks.rawchain_run(hs, device=local, host=True)
-        pcie = {"segments": sp["segments"], "pdus_ok": sp["pdus"], "ms_per_segment": 1e3 * sp["seconds"] / sp["segments"],
-                "packets_per_s": sp["pdus"] / sp["seconds"], "samples_per_s": sp["items"] / sp["seconds"],
-                "GB_per_s_over_pcie": 8.0 * sp["items"] / sp["seconds"] / 1e9}
+        hs = [(pin.data_ptr(), n)] * 12
+        h.run(hs[:3], host=True)
+        sp = h.run(hs, host=True)
+        pc = chain_report(sp, h.timeline(), reps)
+        pc["GB_per_s_over_pcie"] = 8.0 * pc["samples_per_s"] / 1e9
+        out["pcie_inclusive"] = pc
     except Exception as e:
-        pcie = {"error": "%s: %s" % (type(e).__name__, e)}
-    return {"pcie_inclusive": pcie, "segments": st["segments"], "samples_per_segment": n, "packets_per_segment": reps, "events": st["events"], "packets": st["packets"],
-            "pdus_ok": st["pdus"], "ms_per_segment": 1e3 * dt / segments, "packets_per_s": st["pdus"] / dt, "samples_per_s": st["items"] / dt,
-            "x_realtime_20MSps": st["items"] / dt / 20e6,
-            "note": "c8p_detect -> c8p_signal (consume) -> c8p_rx through host/c8p_rawchain.cc (three host threads, everything resident in HBM, "
-                    "no state carried between segments); compare `value` (the same packets handed over at the demod boundary)"}
+        out["pcie_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    h.close()
+    try:
+        out["live_streams"] = live_streams(torch, dev, local, pin, n, unit_len)
+    except Exception as e:
+        out["live_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=16):
+    """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
+    per round (26 ms of air at 20 MS/s) out of pinned host memory — every stream a different stretch of the same packet-dense
+    capture — through the live ingest of host/c8p_rawchain: per round ONE c8p_detect_multi over all streams, one c8p_signal (scan
+    rule per stream), one c8p_rx over the packets of all streams; detection state, commit point and scan position per stream live in
+    the handle.  PCIe is in the loop (8 B per item).  x_realtime_each = air time of a round / wall time of a round: how many times
+    faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU sustains at this packet density."""
+    from gr_ieee80211_amd import blocks
+    if pin is None:
+        raise RuntimeError("no pinned capture")
+    per_round_pk = streams * (round_items // unit_len + 2)
+    h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=per_round_pk + per_round_pk // 8,
+                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len)
+    pdus = [0]
+
+    def on_round(g):
+        pdus[0] += int(g["outs"]["n_pdu"].sum())
+    h.live(on_round)
+    base = pin.data_ptr()
+    span = n - round_items * (rounds + 3)
+    off = [(s * 7919 * unit_len) % max(span, 1) for s in range(streams)]      # every stream its own stretch of the capture
+
+    def one_round(r):
+        for s in range(streams):
+            h.push(s, (base + 8 * (off[s] + r * round_items), round_items), host=True)
+        h.round()
+    for r in range(3):                                                           # untimed: the same handle
+        one_round(r)
+    t0 = time.perf_counter()
+    for r in range(3, 3 + rounds):
+        one_round(r)
+    t_push = time.perf_counter() - t0
+    st = h.drain()
+    dt = time.perf_counter() - t0
+    h.close()
+    air = round_items / 20e6
+    per_round = dt / rounds
+    return {"streams": streams, "items_per_stream_per_round": round_items, "rounds": rounds, "ms_per_round": 1e3 * per_round,
+            "x_realtime_each": air / per_round, "streams_at_realtime": streams * air / per_round,
+            "pcie_GBps": 8.0 * streams * round_items / per_round / 1e9, "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
+            "pdus_ok": st["pdus"], "push_and_round_calls_s": round(t_push, 4),
+            "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
+            "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],
+            "note": "host-fed (pinned memory, 8 B per item over PCIe), results per stream through the callback; warm-up rounds are inside the "
+                    "session, so arena_growths_in_session counts them too"}
 
 
 def tx_rate(engine, local, n=4096):
     """SURVEY §8f-4 stage: c8p_tx packets/s for the cfg-2 packet shape (4096 x VHT MCS7, 1464-byte A-MPDU), PSDUs resident
     on the host (0.15 MB upload per call inside the timing)."""
-    from c8p_testlib import abi
+    from gr_ieee80211_amd import abi
     rng = np.random.default_rng(3)
     pk = np.zeros(n, abi.TX_PKT_DT)
     pk["psdu_off"] = 1464 * np.arange(n); pk["len"] = 1464; pk["format"] = abi.F_VHT; pk["mcs"] = 7
@@ -862,8 +1059,7 @@ def tx_rate(engine, local, n=4096):
 
 def cpu_baseline(pk, iq, chan, budget_s=12.0):
     """The oracle (scalar CPU restatement, "port") timed on one host core over a bounded sample of the same batch."""
-    from c8p_testlib import oracle
-    o = oracle()
+    from oracle import oracle_py as o          # the checker, timed here as the CPU baseline ("port"): never part of the measured path
     t = time.perf_counter()
     o.rx_batch(pk[:8], iq, chan)
     per = (time.perf_counter() - t) / 8
@@ -877,16 +1073,11 @@ def cpu_baseline(pk, iq, chan, budget_s=12.0):
                       "its time next to the 11960-step Viterbi)" % (n, dt, npdu, o.build_flags())}
 
 
-def cpu_baseline_raw_stream(n_packets=256):
+def cpu_baseline_raw_stream(unit, n_packets=256):
     """the chain from the raw stream on one host core: the oracle's detect -> signal (+ the block's scan rule) -> demod + decode over
-    `n_packets` packets of the stream the raw_stream_to_pdus leg uses (same unit, same noise)"""
-    from c8p_cases import dewindow
-    from c8p_testlib import abi, load_npz, oracle, through_channel
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    o = oracle()
-    d = load_npz("packets_cfg.npz")["cfg2_VHT_mcs7_1458B_0"]
-    rng = np.random.default_rng(1)
-    unit = through_channel(dewindow(d["tx"])[:1], None, 30.0, rng, lead=600)[0]
+    `n_packets` copies of the unit the raw_stream_to_pdus leg repeats (same packet, same noise)"""
+    from gr_ieee80211_amd import abi
+    from oracle import oracle_py as o
     x = np.tile(unit, n_packets).astype(np.complex64)
     t0 = time.perf_counter()
     ev = o.detect(x)[0]
@@ -937,8 +1128,7 @@ def usable_cores():
 def cpu_baseline_all_cores(pk, iq, chan, per_core_rate, budget_s=6.0):
     """one independent packet stream per host core (the oracle is re-entrant C, ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
-    from c8p_testlib import oracle
-    o = oracle()
+    from oracle import oracle_py as o
     cores = usable_cores()
     per = int(max(4, min(len(pk) // cores, 16)))                 # packets per pass and thread: short passes, checked against a deadline
     slices = [pk[i * per:(i + 1) * per] for i in range(cores) if len(pk[i * per:(i + 1) * per])]

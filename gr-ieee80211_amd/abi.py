@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MEM_HOST, MEM_DEVICE = 0, 1
 F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
@@ -60,12 +60,13 @@ class BatchIn(C.Structure):
 
 class SigIn(C.Structure):
     _fields_ = [("raw_off", C.c_uint64 * 2), ("n_avail", C.c_uint32), ("cfo_rad", C.c_float), ("snr", C.c_float),
-                ("rssi", C.c_float), ("n_ant", C.c_uint8), ("rsv", C.c_uint8 * 3)]
+                ("rssi", C.c_float), ("n_ant", C.c_uint8), ("rsv", C.c_uint8 * 3), ("stream", C.c_uint32)]
 
 
 class SignalIn(C.Structure):
     _fields_ = [("n_evt", C.c_int32), ("mem", C.c_int32), ("evts", C.c_void_p), ("raw", C.c_void_p), ("n_raw", C.c_uint64),
-                ("consume", C.c_int32), ("rsv", C.c_int32), ("pkt_host", C.c_void_p), ("scan_from", C.c_uint64), ("scan_next", C.c_void_p)]
+                ("consume", C.c_int32), ("n_streams", C.c_int32), ("pkt_host", C.c_void_p), ("scan_from", C.c_uint64), ("scan_next", C.c_void_p),
+                ("scan_from_v", C.c_void_p)]
 
 
 class SyncEvt(C.Structure):
@@ -80,6 +81,29 @@ class DetState(C.Structure):
 class DetectIn(C.Structure):
     _fields_ = [("mem", C.c_int32), ("keep", C.c_int32), ("raw", C.c_void_p), ("n", C.c_uint64), ("n_hist", C.c_uint64),
                 ("state", C.c_void_p), ("state_out", C.c_void_p), ("commit", C.c_void_p)]
+
+
+class DetStream(C.Structure):
+    _fields_ = [("off", C.c_uint64), ("n", C.c_uint64), ("n_hist", C.c_uint64), ("commit", C.c_uint64), ("trig_off", C.c_uint64),
+                ("n_evt", C.c_uint32), ("has_state", C.c_int32), ("state", DetState)]
+
+
+class DetectMultiIn(C.Structure):
+    _fields_ = [("mem", C.c_int32), ("n_streams", C.c_int32), ("raw", C.c_void_p), ("n_raw", C.c_uint64), ("streams", C.c_void_p)]
+
+
+class ReserveIn(C.Structure):
+    _fields_ = [("rx_packets", C.c_int32), ("rx_ant", C.c_int32), ("rx_items", C.c_uint32), ("rx_host", C.c_int32),
+                ("sig_events", C.c_int32), ("sig_host", C.c_int32), ("sig_raw", C.c_uint64), ("sig_items", C.c_uint64),
+                ("det_items", C.c_uint64), ("det_host", C.c_int32), ("det_streams", C.c_int32), ("det_events", C.c_int32),
+                ("det_keep", C.c_int32)]
+
+
+class Span(C.Structure):
+    _fields_ = [("dst_off", C.c_uint64), ("src_off", C.c_uint64), ("n", C.c_uint64)]
+
+
+CNT_ARENA_GROWTHS, CNT_ARENA_BYTES, CNT_HOST_BYTES, CNT_DET_GIVEUPS, CNT_DET_TICKET_SCANS, CNT_SLOTS, CNT_SUBMITS = range(7)
 
 
 class TxPkt(C.Structure):
@@ -134,6 +158,7 @@ SYNC_EVT_DT = _np_dtype(SyncEvt)
 TX_PKT_DT = _np_dtype(TxPkt)
 TX_DESC_DT = _np_dtype(TxDesc)
 TX_MU_DT = _np_dtype(TxMu)
+SPAN_DT = _np_dtype(Span)
 
 TAG_KEYS = ("format", "mcs", "len", "cr", "ampdu", "trellis", "total")
 

@@ -30,11 +30,27 @@ def lib():
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
+        L.c8p_rawchain_create.restype = C.c_void_p
+        L.c8p_rawchain_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.c8p_rawchain_destroy.argtypes = [C.c_void_p]
         L.c8p_rawchain_stream.restype = C.c_int
-        L.c8p_rawchain_stream.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.c8p_rawchain_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_char_p, C.c_int]
         L.c8p_rawchain_run.restype = C.c_int
-        L.c8p_rawchain_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.c8p_rawchain_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.c8p_rawchain_run_once.restype = C.c_int
+        L.c8p_rawchain_run_once.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.c8p_rawchain_stream_once.restype = C.c_int
+        L.c8p_rawchain_stream_once.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_char_p, C.c_int]
+        L.c8p_rawchain_timeline.restype = C.c_int64
+        L.c8p_rawchain_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.c8p_rawchain_live.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.c8p_rawchain_push.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int32]
+        L.c8p_rawchain_round.argtypes = [C.c_void_p]
+        L.c8p_rawchain_drain.argtypes = [C.c_void_p, C.c_void_p]
+        L.c8p_rawchain_error.restype = C.c_char_p
+        L.c8p_rawchain_error.argtypes = [C.c_void_p]
         L.c8ph_push_items.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
         L.c8ph_push_tag_long.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_long]
         L.c8ph_push_tag_float.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_float]
@@ -175,31 +191,49 @@ class _RawSeg(C.Structure):
     _fields_ = [("raw", C.c_void_p), ("n", C.c_uint64), ("ant1_off", C.c_uint64), ("mem", C.c_int32), ("rsv", C.c_int32)]
 
 
+class _RawStage(C.Structure):
+    _fields_ = [("busy", C.c_double), ("wait_in", C.c_double), ("wait_out", C.c_double)]
+
+
 class _RawStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("segments", C.c_int64), ("items", C.c_int64), ("events", C.c_int64),
-                ("packets", C.c_int64), ("pdus", C.c_int64)]
+                ("packets", C.c_int64), ("pdus", C.c_int64), ("first_segment_s", C.c_double), ("steady_s", C.c_double),
+                ("steady_segments", C.c_int64), ("steady_items", C.c_int64), ("steady_packets", C.c_int64), ("steady_pdus", C.c_int64),
+                ("detect", _RawStage), ("signal", _RawStage), ("rx", _RawStage), ("arena_growths", C.c_int64), ("arena_bytes", C.c_int64),
+                ("det_giveups", C.c_int64), ("det_ticket_scans", C.c_int64)]
+
+
+class _RawMark(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("det_begin", "det_end", "sig_begin", "sig_end", "rx_submit", "rx_done")]
 
 
 class _RawOut(C.Structure):
     _fields_ = [("segment", C.c_int64), ("n_events", C.c_int32), ("n_packets", C.c_int32), ("pkts", C.c_void_p), ("outs", C.c_void_p),
-                ("rx", C.c_void_p)]
+                ("rx", C.c_void_p), ("pkt_stream", C.c_void_p), ("pkt_index", C.c_void_p)]
 
 
-def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_items=0, host=False):
-    """host/c8p_rawchain.h: raw stream segments resident on the device -> PDUs, as a pipeline (c8p_detect -> c8p_signal with
-    the block's scan rule -> c8p_rx; three segments in flight).  segments = [(device pointer, items[, item offset of antenna 1's
-    stream inside the same allocation: rx2.grc's chain]), ...]; on_segment(dict)
-    is called per segment in order with its descriptors / per-packet results (numpy copies) and the PDU arena bytes.
-    host=True: the pointers are host memory (pinned for the DMA rate), the items cross PCIe once.
-    stream_items > 0: segments[0] is ONE capture, worked through in pieces of that many items with the detection state and the
-    signal block's scan position carried across the cuts (c8p_rawchain_stream).  Returns the run's totals."""
+class _RawCfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("lib", C.c_char_p), ("reserve_seg_items", C.c_uint64),
+                ("reserve_seg_events", C.c_uint32), ("reserve_seg_packets", C.c_uint32), ("reserve_pkt_items", C.c_uint32),
+                ("reserve_host", C.c_int32), ("reserve_ant", C.c_int32), ("streams", C.c_uint32), ("rsv", C.c_uint32),
+                ("stream_round_items", C.c_uint64)]
+
+
+def _stats_dict(st):
+    d = {}
+    for k, t in _RawStats._fields_:
+        v = getattr(st, k)
+        d[k] = {f: getattr(v, f) for f, _ in _RawStage._fields_} if t is _RawStage else v
+    return d
+
+
+_CB_T = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_RawOut))
+
+
+def _segment_callback(on_segment, engine_lib):
+    """the C callback that hands on_segment(dict) numpy copies of one segment's descriptors, results and PDU arena"""
     from . import abi
-    L = lib()
-    segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0, 0 if host else 1, 0) for t in segments])
-    st = _RawStats()
-    err = C.create_string_buffer(512)
-    cb_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(_RawOut))
-    eng = C.CDLL(engine_lib or ENGINE_LIB)
+    eng = C.CDLL(engine_lib)
     eng.c8p_buffer.restype = C.c_void_p
     eng.c8p_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     eng.c8p_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -209,23 +243,108 @@ def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_it
         n = o.n_packets
         pk = np.frombuffer(C.string_at(o.pkts, n * C.sizeof(abi.PktIn)), abi.PKT_IN_DT).copy() if n else np.zeros(0, abi.PKT_IN_DT)
         outs = np.frombuffer(C.string_at(o.outs, n * C.sizeof(abi.PktOut)), abi.PKT_OUT_DT).copy() if n else np.zeros(0, abi.PKT_OUT_DT)
+        strm = np.frombuffer(C.string_at(o.pkt_stream, 4 * n), np.uint32).copy() if n else np.zeros(0, np.uint32)
+        idx = np.frombuffer(C.string_at(o.pkt_index, 8 * n), np.uint64).copy() if n else np.zeros(0, np.uint64)
         nb = C.c_uint64(0)
         eng.c8p_buffer(o.rx, abi.BUF_PDU, C.byref(nb))
         pdu = np.zeros(nb.value, np.uint8)
         if nb.value:
             eng.c8p_fetch(o.rx, abi.BUF_PDU, pdu.ctypes.data, 0, nb.value)
-        on_segment({"segment": o.segment, "n_events": o.n_events, "pkts": pk, "outs": outs, "pdu_arena": pdu})
+        on_segment({"segment": o.segment, "n_events": o.n_events, "pkts": pk, "outs": outs, "pdu_arena": pdu, "pkt_stream": strm, "pkt_index": idx})
 
-    cbp = cb_t(cb) if on_segment else None
-    if stream_items:
-        (p0, n0), a1 = segments[0][:2], (segments[0][2] if len(segments[0]) > 2 else 0)
-        rc = L.c8p_rawchain_stream((engine_lib or ENGINE_LIB).encode(), device, int(p0), int(n0), int(a1), int(stream_items), cbp, None,
-                                   C.byref(st), err, len(err))
-    else:
-        rc = L.c8p_rawchain_run((engine_lib or ENGINE_LIB).encode(), device, segs, len(segments), cbp, None, C.byref(st), err, len(err))
-    if rc != 0:
-        raise RuntimeError("c8p_rawchain: %d %s" % (rc, err.value.decode()))
-    return {k: getattr(st, k) for k, _ in _RawStats._fields_}
+    return _CB_T(cb)
+
+
+class RawChain:
+    """host/c8p_rawchain.h: a handle that owns the pipeline's four engine contexts (streams, arenas) for as long as it lives.
+    reserve_*: arena shapes sized at create; streams / stream_round_items: live ingest of K independent streams (push / round / drain)."""
+
+    def __init__(self, device=0, engine_lib=None, reserve_seg_items=0, reserve_seg_events=0, reserve_seg_packets=0, reserve_pkt_items=0,
+                 reserve_host=False, reserve_ant=1, streams=0, stream_round_items=0):
+        self.L = lib()
+        self.engine_lib = engine_lib or ENGINE_LIB
+        cfg = _RawCfg(C.sizeof(_RawCfg), device, self.engine_lib.encode(), int(reserve_seg_items), int(reserve_seg_events),
+                      int(reserve_seg_packets), int(reserve_pkt_items), int(bool(reserve_host)), int(reserve_ant), int(streams), 0,
+                      int(stream_round_items))
+        err = C.create_string_buffer(512)
+        self.h = self.L.c8p_rawchain_create(C.byref(cfg), err, len(err))
+        if not self.h:
+            raise RuntimeError("c8p_rawchain_create: " + err.value.decode())
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.L.c8p_rawchain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, err=None):
+        if rc != 0:
+            msg = err.value.decode() if err is not None and err.value else (self.L.c8p_rawchain_error(self.h) or b"").decode()
+            raise RuntimeError("c8p_rawchain: %d %s" % (rc, msg))
+
+    def run(self, segments, on_segment=None, stream_items=0, host=False):
+        """segments = [(pointer, items[, item offset of antenna 1's stream inside the same allocation: rx2.grc's chain]), ...];
+        on_segment(dict) is called per segment in order.  host=True: the pointers are host memory (pinned for the DMA rate).
+        stream_items > 0: segments[0] is ONE capture worked through in pieces of that many items, state carried across the cuts.
+        Returns the run's c8p_rawchain_stats as a dict."""
+        segs = (_RawSeg * len(segments))(*[_RawSeg(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0, 0 if host else 1, 0) for t in segments])
+        st = _RawStats()
+        err = C.create_string_buffer(512)
+        cbp = _segment_callback(on_segment, self.engine_lib) if on_segment else None
+        if stream_items:
+            (p0, n0), a1 = segments[0][:2], (segments[0][2] if len(segments[0]) > 2 else 0)
+            rc = self.L.c8p_rawchain_stream(self.h, int(p0), int(n0), int(a1), int(stream_items), cbp, None, C.byref(st), err, len(err))
+        else:
+            rc = self.L.c8p_rawchain_run(self.h, segs, len(segments), cbp, None, C.byref(st), err, len(err))
+        self._chk(rc, err)
+        return _stats_dict(st)
+
+    def timeline(self):
+        """the last run's marks: one dict per segment, seconds since the start of the run"""
+        n = self.L.c8p_rawchain_timeline(self.h, None, 0)
+        arr = (_RawMark * max(int(n), 1))()
+        self.L.c8p_rawchain_timeline(self.h, arr, n)
+        return [{k: getattr(arr[i], k) for k, _ in _RawMark._fields_} for i in range(int(n))]
+
+    # live ingest
+    def live(self, on_round=None):
+        self._cb = _segment_callback(on_round, self.engine_lib) if on_round else None
+        self._chk(self.L.c8p_rawchain_live(self.h, self._cb, None))
+
+    def push(self, stream, items, host=True):
+        """items: a numpy complex64 array (host; kept alive until the next round()) or (device pointer, n) with host=False"""
+        if isinstance(items, tuple):
+            ptr, n = int(items[0]), int(items[1])
+        else:
+            a = np.ascontiguousarray(items, np.complex64)
+            self._keep = getattr(self, "_keep", [])
+            self._keep.append(a)
+            ptr, n = a.ctypes.data, len(a)
+        self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, 0 if host else 1))
+
+    def round(self):
+        self._chk(self.L.c8p_rawchain_round(self.h))
+        self._keep = []
+
+    def drain(self):
+        st = _RawStats()
+        self._chk(self.L.c8p_rawchain_drain(self.h, C.byref(st)))
+        return _stats_dict(st)
+
+
+def rawchain_run(segments, device=0, engine_lib=None, on_segment=None, stream_items=0, host=False):
+    """one-shot RawChain(...).run(...): a handle is made for this call alone (its contexts and arenas with it)"""
+    rc = RawChain(device=device, engine_lib=engine_lib)
+    try:
+        return rc.run(segments, on_segment=on_segment, stream_items=stream_items, host=host)
+    finally:
+        rc.close()
 
 
 def run_chain(a, b, chunk=1 << 16, nout=1 << 16):

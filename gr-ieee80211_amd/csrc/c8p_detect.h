@@ -33,6 +33,20 @@ struct TrigCand {                   // a plateau of >= 21 samples: [s, e); s < 0
   long long s, e;
 };
 
+// One stream of a detection pass.  c8p_detect has one, c8p_detect_multi K of them: the tiles of a k_detect_scan_multi launch are the
+// tiles of stream 0, then those of stream 1, ...; a tile never looks back past its own stream's first tile.
+struct DetStreamDev {
+  const cf* x;                  // the stream's first NEW item (x[-hist .. -1] = the history before its commit point)
+  long long hist;
+  unsigned long long n;         // new items
+  TrigSeg init;                 // the plateau that is open at the commit point
+  unsigned tile_base;           // first tile of this stream in the launch
+  int x_al16;                   // x is 16-byte aligned
+  unsigned long long out_off;   // where this stream's per-item outputs start: trig (bytes), ac / conj (items); a multiple of 8
+  float2 conj0;                 // d_conjMultiAvg at the commit point
+  unsigned long long idx_base;  // n_hist: event indices count from the first supplied item
+};
+
 __device__ __forceinline__ TrigSeg seg_identity() { TrigSeg r; r.all = 1; r.tstart = C8P_SEG_IDENT; r.tmax = 0.f; return r; }
 __device__ __forceinline__ TrigSeg seg_combine(const TrigSeg& L, const TrigSeg& R)   // L then R
 {
@@ -123,10 +137,13 @@ __device__ __forceinline__ TrigSeg seg_bcast(const TrigSeg& v, int src)
 // WAIT = false: every granule is known to be there (a later launch).  *gave_up is set when a granule did not arrive within
 // C8P_DET_SPINS polls (~tens of ms: a tile's predecessor is normally some microseconds away); the result is then meaningless
 // and the host repeats the launch with ticket numbering, under which a tile never waits for one that has not started.
+// Under ticket numbering every predecessor HAS started, so the wait always ends: a co-tenant, a pre-empted CU or a debugger may
+// stall it for a long time and the watchdog is only there to turn a lost GPU into an error (C8P_DET_SPINS_TICKET polls: many seconds).
 #define C8P_DET_SPINS (1 << 15)
+#define C8P_DET_SPINS_TICKET (1 << 24)
 template <bool WAIT>
 __device__ __forceinline__ TrigSeg trig_lookback(const unsigned long long* __restrict__ summ, long long tile, const TrigSeg& init,
-                                                 unsigned int* __restrict__ gave_up)
+                                                 unsigned int* __restrict__ gave_up, int spins = C8P_DET_SPINS)
 {
   const int lane = lane_id();
   TrigSeg acc = seg_identity();                       // tiles [base, tile)
@@ -147,7 +164,7 @@ __device__ __forceinline__ TrigSeg trig_lookback(const unsigned long long* __res
         const int j = 63 - __builtin_clzll(stop);      // nearest such tile that has published
         if ((have >> j) == (~0ull >> j)) break;        // and everything nearer than it
       }
-      if (spin >= C8P_DET_SPINS) { if (lane == 0) atomicOr(gave_up, 1u); return seg_identity(); }
+      if (spin >= spins) { if (lane == 0) atomicOr(gave_up, 1u); return seg_identity(); }
       __builtin_amdgcn_s_sleep(2);
     }
     const bool ok = t >= 0 && (g >> 63);               // (granules further back than the deciding tile may be missing: ignored by the combine)
@@ -267,24 +284,19 @@ __device__ __forceinline__ RunSeg run_combine(const RunSeg& L, const RunSeg& R)
 // started, which is all the look-back needs — HIP does not promise it, hence the watchdog in trig_lookback), 1 = by a ticket
 // counter (a promise, at the price of 16 910 same-address atomics per 33.5 M samples: 0.09 ms)
 #define C8P_CAND_OPEN_START C8P_SEG_IDENT      // TrigCand.s of "the run that was open when this (quiet) tile began": k_cand_gather fills it in
-__global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
-                                                     unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
-                                                     TrigSeg init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
-                                                     TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
-                                                     float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering)
+// one tile of one stream (`tile` counts from the stream's first tile; summ / tcand / tcount point at that tile's entries, fin at the stream's)
+__device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+                                                 unsigned long long* __restrict__ summ, unsigned int* __restrict__ gave_up,
+                                                 const TrigSeg& init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
+                                                 TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
+                                                 float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering, long long tile)
 {
   __shared__ TrigSeg s_cin;
   __shared__ RunSeg s_w[4];
-  __shared__ unsigned s_tile, s_wc[4];
+  __shared__ unsigned s_wc[4];
   __shared__ cf sX[8 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t
   __shared__ float sE[8 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-  long long tile = blockIdx.x;
-  if (numbering) {
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    tile = (long long)s_tile;
-  }
   const long long tile0 = tile * C8P_DET_TILE;
   cf Pv[8];
   float acv[8];
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x
     total.tmax = tot.pos + 1 < nexist ? tot.tmax : 0.f;
     if (tid == 0) __hip_atomic_store(summ + tile, seg_pack(total, tile0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 64) {
-      const TrigSeg c0 = trig_lookback<true>(summ, tile, init, ticket + 2);
+      const TrigSeg c0 = trig_lookback<true>(summ, tile, init, gave_up, numbering ? C8P_DET_SPINS_TICKET : C8P_DET_SPINS);
       if (tid == 0) {
         s_cin = c0;
         if (tile0 + nexist >= (long long)n) *fin = seg_combine(c0, total);      // the state at the end of the segment
@@ -427,6 +439,43 @@ __global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x
   }
 }
 
+__global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+                                                     unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
+                                                     TrigSeg init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
+                                                     TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
+                                                     float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering)
+{
+  __shared__ unsigned s_tile;
+  long long tile = blockIdx.x;
+  if (numbering) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = (long long)s_tile;
+  }
+  detect_scan_tile(x, hist, n, x_aligned16, summ, ticket + 2, init, fin, trig, tcand, tcount, ac, conj, keep, numbering, tile);
+}
+// K streams in one launch: tile g belongs to stream tile_stream[g]; everything a tile touches is that stream's own (its items, its
+// summaries, its outputs), so the streams do not see each other
+__global__ __launch_bounds__(256, 6) void k_detect_scan_multi(const DetStreamDev* __restrict__ ds, const unsigned short* __restrict__ tile_stream,
+                                                           unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
+                                                           TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
+                                                           TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
+                                                           float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering)
+{
+  __shared__ unsigned s_tile;
+  unsigned g = blockIdx.x;
+  if (numbering) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    g = s_tile;
+  }
+  const unsigned s = tile_stream[g];
+  const DetStreamDev D = ds[s];
+  const unsigned tb = D.tile_base;
+  detect_scan_tile(D.x, D.hist, D.n, D.x_al16, summ + tb, ticket + 2, D.init, fin + s, trig + D.out_off,
+                   tcand + (size_t)tb * C8P_DET_TILE_CAND, tcount + tb, ac + D.out_off, conj + D.out_off, keep, numbering, (long long)(g - tb));
+}
+
 // the per-tile candidate lists, concatenated in tile (= stream) order.  k_cand_offsets: one workgroup, a thread takes a
 // contiguous range of tiles (a multiple of 16: the counts are bytes, read 16 at a time; tcount is zero beyond ntile up to the
 // next multiple of 16) and writes where each tile's list goes; k_cand_gather: thread = tile, moves the list.
@@ -465,7 +514,8 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(const uint8_t* __restrict
 }
 __global__ __launch_bounds__(256) void k_cand_gather(const uint8_t* __restrict__ tcount, const unsigned int* __restrict__ toff,
                                                      const TrigCand* __restrict__ tcand, int ntile, const unsigned long long* __restrict__ summ,
-                                                     TrigSeg init, TrigCand* __restrict__ out, unsigned int cap)
+                                                     TrigSeg init, TrigCand* __restrict__ out, unsigned int cap,
+                                                     const DetStreamDev* __restrict__ ds, const unsigned short* __restrict__ tile_stream)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntile) return;
@@ -476,14 +526,27 @@ __global__ __launch_bounds__(256) void k_cand_gather(const uint8_t* __restrict__
     TrigCand k = tcand[(size_t)t * C8P_DET_TILE_CAND + i];
     if (k.s == C8P_CAND_OPEN_START) {
       // a quiet tile closed the run that was open at its first item: that run's start, from the summaries before the tile
+      // (ds: the tile's own stream only; positions count from that stream's commit point)
+      long long lo = 0;
+      if (ds) { const DetStreamDev& D = ds[tile_stream[t]]; lo = D.tile_base; init = D.init; }
       TrigSeg acc = seg_identity();
       long long u = t - 1;
-      for (; u >= 0; u--) { acc = seg_combine(seg_unpack(summ[u], u * C8P_DET_TILE), acc); if (!acc.all) break; }
-      if (u < 0) acc = seg_combine(init, acc);
+      for (; u >= lo; u--) { acc = seg_combine(seg_unpack(summ[u], (u - lo) * C8P_DET_TILE), acc); if (!acc.all) break; }
+      if (u < lo) acc = seg_combine(init, acc);
       k.s = seg_has_run(acc) ? acc.tstart : k.e;     // (s = e: no plateau, the host's walk skips it)
     }
     if (off < cap) out[off] = k;
   }
+}
+
+// where each stream's candidates start in the concatenated list: soff[s] (soff[K] = their number)
+__global__ void k_stream_offsets(const unsigned int* __restrict__ toff, const unsigned int* __restrict__ n_all, const DetStreamDev* __restrict__ ds,
+                                 int K, int ntile, unsigned int* __restrict__ soff)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > K) return;
+  // (a stream without tiles has the tile base of the next one: no candidates of its own)
+  soff[s] = (s < K && (int)ds[s].tile_base < ntile) ? toff[ds[s].tile_base] : *n_all;
 }
 
 // the maximum of ac over the items [lo, hi) of one plateau (d_conjAc at a commit point that falls inside it), from the
@@ -518,19 +581,26 @@ __global__ void k_trig_fire(uint8_t* __restrict__ trig, const unsigned long long
 struct SyncJob {            // one accepted trigger
   unsigned long long t;     // trigger item (sync_impl switches to SYNC_S_SYNC here)
   unsigned long long seen;  // first item the IDLE state scanned before reaching t
+  unsigned stream;          // whose (index into the DetStreamDev array)
+  unsigned first;           // index of that stream's first job
+  unsigned kind;            // 0: a trigger; 1: only the look-back (what IDLE has latched when it reaches the commit point)
+  unsigned rsv;
 };
 struct SyncMark {
   long long j;              // last item in [seen, t) with trigger bit 0x02, -1: none
   cf conj;                  // presiso output 1 at j
 };
 
-__global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ job, const uint8_t* __restrict__ trig,
-                                                  const cf* __restrict__ x, long long hist, SyncMark* __restrict__ out, int nj)
+__global__ __launch_bounds__(64) void k_sync_mark(const SyncJob* __restrict__ job, const uint8_t* __restrict__ trig_all,
+                                                  const DetStreamDev* __restrict__ ds, SyncMark* __restrict__ out, int nj)
 {
   const int k = blockIdx.x;
   if (k >= nj) return;
   const int lane = lane_id();
   const SyncJob J = job[k];
+  const cf* __restrict__ x = ds[J.stream].x;
+  const long long hist = ds[J.stream].hist;
+  const uint8_t* __restrict__ trig = trig_all + ds[J.stream].out_off;
   long long j = -1;
   for (long long hi = (long long)J.t; hi > (long long)J.seen && j < 0; hi -= 64) {   // newest 64 items first
     const long long g = hi - 1 - lane;
@@ -598,14 +668,18 @@ __device__ __forceinline__ void seq_slide(const float (&T)[C], const float (&p)[
 }
 
 __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job, const SyncMark* __restrict__ mark,
-                                                 const cf* __restrict__ x, c8p_sync_evt* __restrict__ evt,
-                                                 int* __restrict__ valid, int nj, cf conj0, unsigned long long idx_base)
+                                                 const DetStreamDev* __restrict__ ds, c8p_sync_evt* __restrict__ evt,
+                                                 int* __restrict__ valid, int nj)
 {
   __shared__ cf sig[C8P_SYNC_BUF + 16];
   const int k = blockIdx.x;
   if (k >= nj) return;
   const int lane = lane_id();
   const SyncJob J = job[k];
+  if (J.kind) { if (lane == 0) valid[k] = 0; return; }
+  const cf* __restrict__ x = ds[J.stream].x;
+  const cf conj0 = mk(ds[J.stream].conj0.x, ds[J.stream].conj0.y);
+  const unsigned long long idx_base = ds[J.stream].idx_base;
   // item i of the 240: lane i % 64, register i / 64 (the fourth register only in lanes 0..47)
   cf s[4];
   float pw[4];                                       // |sig[i]| * |sig[i]| as the reference forms it (hypotf squared)
@@ -618,7 +692,7 @@ __global__ __launch_bounds__(64) void k_sync_evt(const SyncJob* __restrict__ job
   }
   // d_conjMultiAvg: the last latch the IDLE state saw — this trigger's mark, or the one an earlier trigger left behind
   cf cavg = conj0;                                   // what the state at the commit point carried in
-  for (int kk = k; kk >= 0; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
+  for (int kk = k; kk >= (int)J.first; kk--) if (mark[kk].j >= 0) { cavg = mark[kk].conj; break; }
   cf xc[3];                                          // sig[i] * conj(sig[i + 64]), i = lane + 64 r
 #pragma unroll
   for (int r = 0; r < 3; r++) xc[r] = cmul(s[r], cconj(s[r + 1]));

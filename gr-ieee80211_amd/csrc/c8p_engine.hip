@@ -192,7 +192,7 @@ struct Slot {
   Buf d_tags, d_outs, d_H, d_mimo, d_muchan, d_llr, d_surv, d_bits, d_sbits, d_pdu, d_flags, d_sym2pkt, d_negsym, d_done4;
   Buf d_sig_raw, d_sig_pkt, d_sig_iq, d_sig_chan, d_sig_kept;    // signal front-end
   Buf d_det_raw, d_det_ac, d_det_trig, d_det_conj, d_det_zero, d_det_carry, d_det_cand, d_det_tcand, d_det_toff, d_det_job, d_det_mark,
-      d_det_evt, d_det_valid, d_det_fire;            // detection front-end
+      d_det_evt, d_det_valid, d_det_fire, d_det_ds, d_det_soff;            // detection front-end
   Buf d_tx_plan, d_tx_psdu, d_tx_coded, d_tx_sig, d_tx_u2p, d_tx_iq, d_tx_desc, d_tx_bfq;   // transmit chain
   std::vector<TrigCand> h_det_cand;                  // host-side work lists of c8p_detect (kept: no allocation per call)
   std::vector<unsigned long long> h_det_fire;
@@ -220,25 +220,35 @@ struct c8p_ctx {
   int64_t k_cnt[C8P_K_COUNT] = {};
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> ev_pool;
+  // c8p_counter
+  int64_t n_grow = 0, dev_bytes = 0, host_bytes = 0, det_giveups = 0, det_ticket_scans = 0;
+  // c8p_copy_*: a stream of its own, created on first use
+  hipStream_t copy_stream = nullptr;
+  Buf d_spans; void* h_spans = nullptr; size_t h_spans_cap = 0;
 };
 
 static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
 {
   if (bytes <= b.cap) return C8P_OK;
-  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; c->dev_bytes -= (int64_t)b.cap; b.cap = 0; }
   size_t want = bytes + bytes / 4 + 4096;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return C8P_ENOMEM; }
   b.cap = want;
+  c->n_grow++; c->dev_bytes += (int64_t)want;
   return C8P_OK;
 }
 static int ensure_host(c8p_ctx* c, size_t bytes)
 {
   if (bytes <= c->s->h_stage_cap) return C8P_OK;
-  if (c->s->h_stage) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipHostFree(c->s->h_stage)); c->s->h_stage = nullptr; }
+  if (c->s->h_stage) {
+    HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipHostFree(c->s->h_stage));
+    c->s->h_stage = nullptr; c->host_bytes -= (int64_t)c->s->h_stage_cap; c->s->h_stage_cap = 0;
+  }
   size_t want = bytes + bytes / 4 + 4096;
   HIPCHK(c, hipHostMalloc(&c->s->h_stage, want, hipHostMallocDefault));
   c->s->h_stage_cap = want;
+  c->n_grow++; c->host_bytes += (int64_t)want;
   return C8P_OK;
 }
 
@@ -328,12 +338,15 @@ extern "C" void c8p_destroy(c8p_ctx* c)
                    &sl.d_muchan, &sl.d_llr, &sl.d_surv, &sl.d_bits, &sl.d_sbits, &sl.d_pdu, &sl.d_flags, &sl.d_sym2pkt, &sl.d_negsym, &sl.d_done4,
                    &sl.d_sig_raw, &sl.d_sig_pkt, &sl.d_sig_iq, &sl.d_sig_chan, &sl.d_sig_kept, &sl.d_det_raw, &sl.d_det_ac, &sl.d_det_trig, &sl.d_det_tcand, &sl.d_det_toff,
                    &sl.d_det_conj, &sl.d_det_zero, &sl.d_det_carry, &sl.d_det_cand, &sl.d_det_job, &sl.d_det_mark,
-                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
+                   &sl.d_det_evt, &sl.d_det_valid, &sl.d_det_fire, &sl.d_det_ds, &sl.d_det_soff, &sl.d_tx_plan, &sl.d_tx_psdu, &sl.d_tx_bfq, &sl.d_tx_coded, &sl.d_tx_sig,
                    &sl.d_tx_u2p, &sl.d_tx_iq, &sl.d_tx_desc};
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
   }
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->d_spans.p) (void)hipFree(c->d_spans.p);
+  if (c->h_spans) (void)hipHostFree(c->h_spans);
   if (c->d_tab) (void)hipFree(c->d_tab);
   delete c;
 }
@@ -415,10 +428,34 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct RxFuse { const c8p_pkt_in* d_pk; const cf* d_iq; const cf* d_chan; bool any_2ant; };
 // d_cold: the FinCold record of this submit (device memory)
 
-static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
-                              const cf* d_mu, const Plan& P, const RxFuse* rx, const FinCold* d_cold)
+// The arenas of one submit, by stage (also what c8p_reserve sizes in advance).
+static size_t demod_stage_bytes(int n, size_t* o_lay = nullptr, size_t* o_cold = nullptr)
 {
-  const bool flags_ready = rx != nullptr;
+  const size_t ol = align256(sizeof(c8p_pkt_in) * (size_t)n), oc = align256(ol + sizeof(PktLayout) * (size_t)n);
+  if (o_lay) *o_lay = ol;
+  if (o_cold) *o_cold = oc;
+  return align256(oc + sizeof(FinCold));
+}
+static int ensure_demod_arenas(c8p_ctx* c, int n, const Plan& P, uint64_t host_iq, uint64_t host_chan)
+{
+  int rc;
+  const size_t stage_bytes = demod_stage_bytes(n);
+  if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
+  if (host_iq && (rc = ensure(c, c->s->d_iq, sizeof(cf) * host_iq)) != C8P_OK) return rc;
+  if (host_chan && (rc = ensure(c, c->s->d_chan, sizeof(cf) * host_chan)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_tags, sizeof(c8p_pkt_tags) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_H, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sym2pkt, sizeof(uint32_t) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_negsym, sizeof(float) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
+  return C8P_OK;
+}
+static int ensure_decode_arenas(c8p_ctx* c, int n, const Plan& P)
+{
   int rc;
   if ((rc = ensure(c, c->s->d_outs, sizeof(c8p_pkt_out) * (size_t)n)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_surv, sizeof(ulonglong2) * P.surv)) != C8P_OK) return rc;
@@ -426,6 +463,29 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   if ((rc = ensure(c, c->s->d_bits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_sbits, c->keep_bits ? P.bits : 16)) != C8P_OK) return rc;
   if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
+  return C8P_OK;
+}
+static int ensure_signal_arenas(c8p_ctx* c, size_t n, uint64_t iq_items, uint64_t host_raw)
+{
+  int rc;
+  const size_t up = align256(align256(sizeof(c8p_sig_in) * n) + sizeof(uint64_t) * n);           // flags + arena offsets on the way up
+  const size_t down = align256(sizeof(c8p_pkt_in) * n) + sizeof(int) * n;                         // descriptors + kept list on the way back
+  if ((rc = ensure_host(c, std::max(up, down))) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_stage, up)) != C8P_OK) return rc;
+  if (host_raw && (rc = ensure(c, c->s->d_sig_raw, sizeof(cf) * host_raw)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_pkt, sizeof(c8p_pkt_in) * n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_chan, sizeof(cf) * 64 * n)) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_iq, sizeof(cf) * std::max<uint64_t>(iq_items, 2))) != C8P_OK) return rc;
+  if ((rc = ensure(c, c->s->d_sig_kept, sizeof(int) * std::max<size_t>(n, 1))) != C8P_OK) return rc;
+  return C8P_OK;
+}
+
+static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, const PktLayout* d_lay, const float* d_llr,
+                              const cf* d_mu, const Plan& P, const RxFuse* rx, const FinCold* d_cold)
+{
+  const bool flags_ready = rx != nullptr;
+  int rc;
+  if ((rc = ensure_decode_arenas(c, n, P)) != C8P_OK) return rc;
   const uint32_t* d_flags = c->exact_only ? nullptr : (const uint32_t*)c->s->d_flags.p;
   hipStream_t dst = c->s->stream, fst = c->s->stream;
   {
@@ -523,30 +583,19 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if (rc != C8P_OK) return rc;
 
   // descriptors + layout (+ the record k_finish's cold path reads) in one pinned staging copy
-  const size_t o_pk = 0, o_lay = align256(o_pk + sizeof(c8p_pkt_in) * (size_t)n), o_cold = align256(o_lay + sizeof(PktLayout) * (size_t)n);
-  const size_t stage_bytes = align256(o_cold + sizeof(FinCold));
-  if ((rc = ensure_host(c, stage_bytes)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
+  size_t o_lay = 0, o_cold = 0;
+  const size_t o_pk = 0, stage_bytes = demod_stage_bytes(n, &o_lay, &o_cold);
+  if ((rc = ensure_demod_arenas(c, n, P, in->mem == C8P_MEM_HOST ? in->n_iq : 0, in->mem == C8P_MEM_HOST ? in->n_chan : 0)) != C8P_OK) return rc;
   const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
 
   const cf* d_iq = (const cf*)in->iq;
   const cf* d_chan = (const cf*)in->chan;
   if (in->mem == C8P_MEM_HOST) {
-    if ((rc = ensure(c, c->s->d_iq, sizeof(cf) * in->n_iq)) != C8P_OK) return rc;
-    if ((rc = ensure(c, c->s->d_chan, sizeof(cf) * in->n_chan)) != C8P_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s->d_iq.p, in->iq, sizeof(cf) * in->n_iq, hipMemcpyHostToDevice, c->s->stream));
     HIPCHK(c, hipMemcpyAsync(c->s->d_chan.p, in->chan, sizeof(cf) * in->n_chan, hipMemcpyHostToDevice, c->s->stream));
     d_iq = (const cf*)c->s->d_iq.p; d_chan = (const cf*)c->s->d_chan.p;
   }
-  if ((rc = ensure(c, c->s->d_tags, sizeof(c8p_pkt_tags) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_H, sizeof(cf) * 64 * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_mimo, sizeof(Mimo) * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_muchan, sizeof(cf) * 128 * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_llr, sizeof(float) * P.llr)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_flags, sizeof(uint32_t) * 3 * (size_t)n)) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_sym2pkt, sizeof(uint32_t) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
-  if ((rc = ensure(c, c->s->d_negsym, sizeof(float) * (size_t)(P.syms + 1))) != C8P_OK) return rc;
   // (the slot's stream was synchronised when the slot was taken, and nothing but the uploads above has been enqueued on it since: the
   // previous submit's asynchronous copy out of the pinned buffer has finished)
   memcpy((char*)c->s->h_stage + o_pk, in->pkts, sizeof(c8p_pkt_in) * (size_t)n);
@@ -712,18 +761,29 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
     int* kept = (int*)((char*)S.h_stage + o_kept);
     HIPCHK(c, hipMemcpyAsync(hpk, S.d_sig_pkt.p, sizeof(c8p_pkt_in) * (size_t)n, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
-    uint64_t pos = in->scan_from, used = 0;
-    bool waiting = false;
+    // (n_streams > 1: K signal blocks, one per stream; the flags come grouped by stream and the rule runs inside each group)
+    const int KS = in->n_streams > 1 ? in->n_streams : 1;
+    std::vector<uint64_t> posv((size_t)KS, 0);
+    std::vector<char> waitv((size_t)KS, 0);
+    if (KS == 1) posv[0] = in->scan_from;
+    else if (in->scan_from_v) for (int k = 0; k < KS; k++) posv[k] = in->scan_from_v[k];
+    uint64_t used = 0;
     int nk = 0;
+    uint32_t last_stream = 0;
     for (int e = 0; e < n; e++) {
       const c8p_sig_in& k = in->evts[e];
       c8p_pkt_in& p = hpk[e];
+      const uint32_t si = KS > 1 ? k.stream : 0u;
+      if (si >= (uint32_t)KS || si < last_stream) { c->err = "c8p_signal: flags must be grouped by stream, in ascending stream order"; return C8P_EINVAL; }
+      last_stream = si;
+      uint64_t& pos = posv[si];
+      char& waiting = waitv[si];
       const uint64_t idx = k.raw_off[0];
       if (waiting) { p.n_items = 0; p.rsv[0] = C8P_SIG_PENDING; continue; }
       if (idx < pos) { p.n_items = 0; p.rsv[0] = C8P_SIG_SKIPPED; continue; }
-      if (k.n_avail < 224u) { waiting = true; p.n_items = 0; p.rsv[0] = C8P_SIG_PENDING; continue; }     // S_DEMOD waits for 224 items
+      if (k.n_avail < 224u) { waiting = 1; p.n_items = 0; p.rsv[0] = C8P_SIG_PENDING; continue; }     // S_DEMOD waits for 224 items
       if (p.n_items == 0) {
-        if (p.rsv[0] == C8P_SIG_NEED_MORE) waiting = true;                                               // S_COPY waits for the rest of the packet
+        if (p.rsv[0] == C8P_SIG_NEED_MORE) waiting = 1;                                                  // S_COPY waits for the rest of the packet
         else pos = idx + 80;                                                                              // signal_impl.cc:157-160
         continue;
       }
@@ -733,7 +793,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
       pos = idx + 224 + (uint64_t)p.lsig_nsamp;                                                           // S_COPY consumed the packet
     }
     tot = used;
-    if (in->scan_next) *in->scan_next = pos;
+    if (in->scan_next) for (int k = 0; k < KS; k++) in->scan_next[k] = posv[k];
     if ((rc = ensure(c, S.d_sig_iq, sizeof(cf) * std::max<uint64_t>(tot, 2))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_sig_kept, sizeof(int) * (size_t)std::max(nk, 1))) != C8P_OK) return rc;
     if (in->pkt_host) memcpy(in->pkt_host, hpk, sizeof(c8p_pkt_in) * (size_t)n);
@@ -754,28 +814,109 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
 
 
 // ------------------------------------------------------------------------------------------------ detection front-end
-// presiso.grc -> trigger_impl -> sync_impl over one stream segment.  The dense work (windowed
-// autocorrelation, plateau / running-maximum scan) runs on the GPU; trigger_impl's countdown logic and sync_impl's
-// IDLE / SYNC alternation are sequential but touch only the few plateaus of >= 21 samples, so they run here on the
-// host over the compacted candidate list (trigger_impl.cc:86-109, sync_impl.cc:73-147).
-extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+// presiso.grc -> trigger_impl -> sync_impl over one stream segment, or over the segments of K independent
+// streams at once (c8p_detect_multi).  The dense work (windowed autocorrelation, plateau / running-maximum scan) runs on the GPU;
+// trigger_impl's countdown logic and sync_impl's IDLE / SYNC alternation are sequential but touch only the few plateaus of
+// >= 21 samples, so they run here on the host over the compacted candidate lists (trigger_impl.cc:86-109, sync_impl.cc:73-147).
+struct DetHost {                 // one stream of a detection pass, host side
+  uint64_t off = 0, n_total = 0, n_hist = 0;     // in: where its items lie in the arena
+  c8p_det_state st0;                             // in: state at the commit point
+  // derived
+  uint64_t n = 0;                                // new items
+  int ntile = 0; unsigned tile_base = 0, cap = 0;
+  uint64_t out_off = 0;
+  TrigSeg init;
+  // out
+  c8p_det_state st1;
+  uint64_t commit = 0;                           // relative to the first NEW item
+  uint32_t n_evt = 0;
+  // work
+  int job0 = 0, nj = 0;                          // its jobs: [job0, job0 + nj) triggers, job0 + nj the look-back at the commit point
+  long long pos = 0, prev_start = 0, commit_ll = 0, stop_run_start = 0, stop_prev = 0;
+  bool have = false, open_fired = false, stopped = false, stop_have = false, want_rmax = false;
+  float rmax0 = 0.f;
+};
+
+static int ensure_detect_arenas(c8p_ctx* c, Slot& S, uint64_t out_items, size_t ntile, size_t cap, int K, bool keep, size_t zero_bytes)
 {
-  if (!c) return C8P_EINVAL;
-  if (!in || (in->n > 0 && !in->raw) || in->n_hist > in->n) { c->err = "bad detect input"; return C8P_EINVAL; }
-  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
-  if (in->n > (1ull << 31)) { c->err = "stream segment too long (2^31 items max)"; return C8P_ERANGE; }
-  HIPCHK(c, hipSetDevice(c->device));
-  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
-  c->s = &c->slots[c->cur];
+  int rc;
+  if ((rc = ensure(c, S.d_det_ac, keep ? sizeof(float) * out_items : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_trig, out_items + 8)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_conj, keep ? sizeof(cf) * out_items : 16)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg) * (size_t)K)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_tcand, sizeof(TrigCand) * ntile * C8P_DET_TILE_CAND)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_zero, zero_bytes)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_toff, sizeof(unsigned) * (ntile + 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * cap)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_ds, sizeof(DetStreamDev) * (size_t)K + sizeof(unsigned short) * (ntile + 8) + 256)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_soff, sizeof(unsigned) * (size_t)(K + 1))) != C8P_OK) return rc;
+  return C8P_OK;
+}
+static int ensure_detect_jobs(c8p_ctx* c, Slot& S, size_t nf, size_t njobs)
+{
+  int rc;
+  if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * std::max<size_t>(nf, 1))) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * njobs)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * njobs)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * njobs)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_valid, sizeof(int) * njobs)) != C8P_OK) return rc;
+  return C8P_OK;
+}
+struct DetZero { size_t o_cnt, o_rmax, o_tc, o_summ, bytes; };
+static DetZero det_zero_layout(size_t ntile, int K)
+{
+  // what every launch needs zeroed lies in one block (one fill): [counters 64 B | per-stream range maxima | tile candidate counts | tile summaries]
+  DetZero z;
+  z.o_cnt = 0; z.o_rmax = 64;
+  z.o_tc = (z.o_rmax + sizeof(unsigned) * (size_t)K + 63) & ~(size_t)63;
+  z.o_summ = (z.o_tc + ((ntile + 15) & ~(size_t)15) + 63) & ~(size_t)63;
+  z.bytes = z.o_summ + sizeof(unsigned long long) * ntile;
+  return z;
+}
+
+// trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous countdown has run
+// out if that is later and the plateau still lasts; one trigger per plateau.  sync_impl.cc:73-147: IDLE scans up to a trigger,
+// SYNC needs 240 items from it and consumes 111.  The first countdown / search window that runs past the end of the segment
+// stops the walk: the commit point moves to the item where that countdown was armed, and the next call derives it again.
+static void det_walk(DetHost& H, const TrigCand* cand, size_t ncand, int stream, std::vector<unsigned long long>& fire, std::vector<SyncJob>& jobs)
+{
+  const c8p_det_state& st0 = H.st0;
+  const long long N = (long long)H.n;
+  H.have = st0.have_prev != 0; H.prev_start = st0.prev_start; H.pos = st0.sync_pos; H.commit_ll = N;
+  H.open_fired = false; H.stopped = false;
+  H.job0 = (int)jobs.size();
+  for (size_t i = 0; i < ncand; i++) {
+    const TrigCand& k = cand[i];
+    if (st0.in_run && st0.run_fired && k.s == st0.run_start) { if (k.e == N) H.open_fired = true; continue; }   // armed before the commit point
+    long long start = k.s + 20;
+    if (H.have && H.prev_start + 80 > start) start = H.prev_start + 80;
+    if (start >= k.e) continue;                        // the plateau ended before the previous countdown ran out
+    const long long t = start + 79;
+    const bool unseen = t < H.pos;                     // would fall inside the 111 items a SYNC pass consumes unseen
+    if (t >= N || (!unseen && N - t < C8P_SYNC_BUF)) { // countdown or search window runs past the end: not decidable yet
+      H.stopped = true; H.commit_ll = start; H.stop_run_start = k.s; H.stop_have = H.have; H.stop_prev = H.prev_start;
+      break;
+    }
+    H.have = true; H.prev_start = start;
+    if (k.e == N) H.open_fired = true;
+    fire.push_back(H.out_off + (unsigned long long)t);
+    if (unseen) continue;
+    SyncJob j; j.t = (unsigned long long)t; j.seen = (unsigned long long)std::max(H.pos, 0ll);
+    j.stream = (unsigned)stream; j.first = (unsigned)H.job0; j.kind = 0; j.rsv = 0;
+    jobs.push_back(j);
+    H.pos = t + C8P_SYNC_RES;
+  }
+  H.nj = (int)jobs.size() - H.job0;
+  // one more look-back job, not a trigger: what the IDLE state has latched when it reaches the commit point
+  SyncJob j; j.t = (unsigned long long)H.commit_ll; j.seen = (unsigned long long)std::min(std::max(H.pos, 0ll), H.commit_ll);
+  j.stream = (unsigned)stream; j.first = (unsigned)H.job0; j.kind = 1; j.rsv = 0;
+  jobs.push_back(j);
+}
+
+static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<DetHost>& hs, bool keep, bool multi)
+{
   Slot& S = *c->s;
-  HIPCHK(c, hipStreamSynchronize(S.stream));
-  drain_events(c);
-  S.n_pkt = 0;
-  for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
-  c8p_det_state st0;
-  memset(&st0, 0, sizeof(st0));
-  if (in->state) st0 = *in->state;
-  const long long hist = (long long)in->n_hist;
+  const int K = (int)hs.size();
   static const bool tlog = getenv("C8P_DET_TLOG") != nullptr;
   auto T0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -784,221 +925,311 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     fprintf(stderr, "[c8p_detect] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count());
     T0 = t;
   };
-  const uint64_t n = in->n - in->n_hist;              // new items: positions below are relative to the commit point
-  if (in->commit) *in->commit = in->n_hist;
-  if (in->state_out) *in->state_out = st0;
-  if (n == 0) return C8P_OK;
-  int rc;
-  const cf* d_all = (const cf*)in->raw;
-  if (in->mem == C8P_MEM_HOST) {
-    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * in->n)) != C8P_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * in->n, hipMemcpyHostToDevice, S.stream));
-    d_all = (const cf*)S.d_det_raw.p;
+  // ---- layout
+  size_t ntile = 0, cap = 0;
+  uint64_t out_items = 0;
+  for (DetHost& H : hs) {
+    H.n = H.n_total - H.n_hist;
+    H.ntile = (int)((H.n + C8P_DET_TILE - 1) / C8P_DET_TILE);
+    H.tile_base = (unsigned)ntile; ntile += (size_t)H.ntile;
+    H.cap = H.n ? (unsigned)(H.n / 22 + 16) : 0u;        // a plateau needs 21 samples above and one below
+    cap += H.cap;
+    H.out_off = out_items; out_items += (H.n + 7) & ~(uint64_t)7;
+    H.init.all = 0; H.init.tmax = 0.f; H.init.tstart = C8P_SEG_NONE;       // the plateau open at the commit point
+    if (H.st0.in_run) { H.init.all = 1; H.init.tstart = H.st0.run_start; H.init.tmax = H.st0.run_max; }
+    H.st1 = H.st0; H.commit = 0; H.n_evt = 0;
   }
-  const cf* d_raw = d_all + hist;                      // first new item
-  const int ntile = (int)((n + C8P_DET_TILE - 1) / C8P_DET_TILE);
-  const unsigned cap = (unsigned)(n / 22 + 16);        // a plateau needs 21 samples above and one below
-  const bool keep = in->keep != 0;
-  if ((rc = ensure(c, S.d_det_ac, keep ? sizeof(float) * n : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_trig, n + 8)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_conj, keep ? sizeof(cf) * n : 16)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_carry, sizeof(TrigSeg))) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_tcand, sizeof(TrigCand) * (size_t)ntile * C8P_DET_TILE_CAND)) != C8P_OK) return rc;
-  const size_t tcount_bytes = ((size_t)ntile + 15) & ~(size_t)15;
-  // what every launch needs zeroed lies in one block (one fill): [counters 64 B | tile candidate counts | tile summaries]
-  const size_t o_zcnt = 0, o_ztc = 64, o_zsumm = (o_ztc + tcount_bytes + 63) & ~(size_t)63, zero_bytes = o_zsumm + sizeof(unsigned long long) * (size_t)ntile;
-  if ((rc = ensure(c, S.d_det_zero, zero_bytes)) != C8P_OK) return rc;
-  unsigned* d_cnt = (unsigned*)((char*)S.d_det_zero.p + o_zcnt);          // [0] candidates, [1] tile tickets, [2] k_ac_range_max, [3] a look-back gave up
-  uint8_t* d_tcount = (uint8_t*)S.d_det_zero.p + o_ztc;
-  unsigned long long* d_summ = (unsigned long long*)((char*)S.d_det_zero.p + o_zsumm);
-  if ((rc = ensure(c, S.d_det_toff, sizeof(unsigned) * (size_t)ntile)) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_cand, sizeof(TrigCand) * (size_t)cap)) != C8P_OK) return rc;
-  TrigSeg init;                                        // the plateau open at the commit point
-  init.all = 0; init.tmax = 0.f; init.tstart = C8P_SEG_NONE;
-  if (st0.in_run) { init.all = 1; init.tstart = st0.run_start; init.tmax = st0.run_max; }
-  const int x_al16 = (int)(((uintptr_t)d_raw & 15u) == 0);
-  // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a
-  // synchronous staging hop each): [counters | final seg | first C8P_DET_SPEC candidates] come back with one sync
-  // (how many candidates come back with the first sync: a quarter more than the previous call of this context found)
-  const unsigned spec = std::min(cap, c->det_spec);
-  const size_t o_cnt = 0, o_fin = 64, o_cand = 128;
+  S.used[C8P_BUF_DET_RAW] = sizeof(cf) * n_all; S.ptr[C8P_BUF_DET_RAW] = d_all;
+  if (ntile == 0) return C8P_OK;                          // no stream has new items
+  if (ntile > 0x7fffffffu / C8P_DET_TILE_CAND) { c->err = "detect: too many items in one call"; return C8P_ERANGE; }
+  const DetZero Z = det_zero_layout(ntile, K);
+  int rc;
+  if ((rc = ensure_detect_arenas(c, S, out_items, ntile, cap, K, keep, Z.bytes)) != C8P_OK) return rc;
+  unsigned* d_cnt = (unsigned*)((char*)S.d_det_zero.p + Z.o_cnt);          // [0] candidates, [1] tile tickets, [3] a look-back gave up
+  unsigned* d_rmax = (unsigned*)((char*)S.d_det_zero.p + Z.o_rmax);
+  uint8_t* d_tcount = (uint8_t*)S.d_det_zero.p + Z.o_tc;
+  unsigned long long* d_summ = (unsigned long long*)((char*)S.d_det_zero.p + Z.o_summ);
+  const DetStreamDev* d_ds = (const DetStreamDev*)S.d_det_ds.p;
+  const size_t map_off = (sizeof(DetStreamDev) * (size_t)K + 255) & ~(size_t)255;
+  const unsigned short* d_map = (const unsigned short*)((const char*)S.d_det_ds.p + map_off);
+  // small device <-> host exchanges of this call go through the slot's pinned staging buffer (pageable copies cost a synchronous
+  // staging hop each).  up: [stream descriptors | tile -> stream map]; back with one sync: [counters | stream offsets | final segs |
+  // the first `spec` candidates] (how many: a quarter more than the previous call of this context found)
+  const unsigned spec = (unsigned)std::min<size_t>(cap, c->det_spec);
+  const size_t up_bytes = multi ? map_off + sizeof(unsigned short) * ntile : sizeof(DetStreamDev) * (size_t)K;
+  const size_t o_up = 0, o_cnt = (up_bytes + 63) & ~(size_t)63, o_soff = o_cnt + 64;
+  const size_t o_fin = (o_soff + sizeof(unsigned) * (size_t)(K + 1) + 63) & ~(size_t)63, o_cand = (o_fin + sizeof(TrigSeg) * (size_t)K + 63) & ~(size_t)63;
   if ((rc = ensure_host(c, o_cand + sizeof(TrigCand) * (size_t)spec)) != C8P_OK) return rc;
   char* hp = (char*)S.h_stage;
+  {
+    DetStreamDev* hd = (DetStreamDev*)(hp + o_up);
+    for (int s = 0; s < K; s++) {
+      const DetHost& H = hs[s];
+      DetStreamDev& D = hd[s];
+      memset(&D, 0, sizeof(D));
+      D.x = d_all + H.off + H.n_hist; D.hist = (long long)H.n_hist; D.n = H.n; D.init = H.init; D.tile_base = H.tile_base;
+      D.x_al16 = (int)(((uintptr_t)D.x & 15u) == 0); D.out_off = H.out_off;
+      D.conj0 = make_float2(H.st0.conj_avg.re, H.st0.conj_avg.im); D.idx_base = H.n_hist;
+    }
+    if (multi) {
+      unsigned short* hm = (unsigned short*)(hp + o_up + map_off);
+      for (int s = 0; s < K; s++) for (int t = 0; t < hs[s].ntile; t++) hm[hs[s].tile_base + (unsigned)t] = (unsigned short)s;
+    }
+    HIPCHK(c, hipMemcpyAsync(S.d_det_ds.p, hp + o_up, up_bytes, hipMemcpyHostToDevice, S.stream));
+  }
+  const DetHost& H0 = hs[0];
   const char* ft_env = getenv("C8P_DET_TICKETS");
   const int force_tickets = ft_env ? atoi(ft_env) : 0;   // 1: always, 2: pretend the first launch gave up (tests)
   for (int numbering = force_tickets == 1 ? 1 : 0; ; numbering = 1) {
-    HIPCHK(c, hipMemsetAsync(S.d_det_zero.p, 0, zero_bytes, S.stream));      // no tile summary published yet, no candidates, no tickets
+    HIPCHK(c, hipMemsetAsync(S.d_det_zero.p, 0, Z.bytes, S.stream));      // no tile summary published yet, no candidates, no tickets
+    if (numbering) c->det_ticket_scans++;
     {
       KTimer kt(c, C8P_K_PRESISO);
-      hipLaunchKernelGGL(k_detect_scan, dim3(ntile), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
-                         d_summ, d_cnt + 1, init, (TrigSeg*)S.d_det_carry.p,
-                         (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
-                         (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
+      if (!multi)
+        hipLaunchKernelGGL(k_detect_scan, dim3((unsigned)ntile), dim3(256), 0, S.stream, d_all + H0.off + H0.n_hist, (long long)H0.n_hist,
+                           (unsigned long long)H0.n, (int)(((uintptr_t)(d_all + H0.off + H0.n_hist) & 15u) == 0),
+                           d_summ, d_cnt + 1, H0.init, (TrigSeg*)S.d_det_carry.p,
+                           (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
+                           (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
+      else
+        hipLaunchKernelGGL(k_detect_scan_multi, dim3((unsigned)ntile), dim3(256), 0, S.stream, d_ds, d_map, d_summ, d_cnt + 1,
+                           (TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
+                           (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
     }
     {
       KTimer kt(c, C8P_K_TRIGGER);
-      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, S.stream, (const uint8_t*)d_tcount, ntile, (unsigned*)S.d_det_toff.p, d_cnt);
-      hipLaunchKernelGGL(k_cand_gather, dim3((ntile + 255) / 256), dim3(256), 0, S.stream, (const uint8_t*)d_tcount, (const unsigned*)S.d_det_toff.p,
-                         (const TrigCand*)S.d_det_tcand.p, ntile, (const unsigned long long*)d_summ, init, (TrigCand*)S.d_det_cand.p, cap);
+      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, S.stream, (const uint8_t*)d_tcount, (int)ntile, (unsigned*)S.d_det_toff.p, d_cnt);
+      hipLaunchKernelGGL(k_cand_gather, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, S.stream, (const uint8_t*)d_tcount, (const unsigned*)S.d_det_toff.p,
+                         (const TrigCand*)S.d_det_tcand.p, (int)ntile, (const unsigned long long*)d_summ, H0.init, (TrigCand*)S.d_det_cand.p, (unsigned)cap,
+                         multi ? d_ds : (const DetStreamDev*)nullptr, multi ? d_map : (const unsigned short*)nullptr);
+      if (multi)
+        hipLaunchKernelGGL(k_stream_offsets, dim3((unsigned)((K + 256) / 256)), dim3(256), 0, S.stream, (const unsigned*)S.d_det_toff.p, (const unsigned*)d_cnt,
+                           d_ds, K, (int)ntile, (unsigned*)S.d_det_soff.p);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hp + o_cnt, d_cnt, 16, hipMemcpyDeviceToHost, S.stream));
-    HIPCHK(c, hipMemcpyAsync(hp + o_fin, S.d_det_carry.p, sizeof(TrigSeg), hipMemcpyDeviceToHost, S.stream));
+    if (multi) HIPCHK(c, hipMemcpyAsync(hp + o_soff, S.d_det_soff.p, sizeof(unsigned) * (size_t)(K + 1), hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_fin, S.d_det_carry.p, sizeof(TrigSeg) * (size_t)K, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipMemcpyAsync(hp + o_cand, S.d_det_cand.p, sizeof(TrigCand) * (size_t)spec, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
     const bool gave_up = ((const unsigned*)(hp + o_cnt))[3] != 0 || (force_tickets == 2 && numbering == 0);
     if (!gave_up) break;
     // a tile waited for a predecessor that had not started (blockIdx numbering promises nothing): once more with tickets
     if (numbering == 1) { c->err = "detect: tile look-back timed out"; return C8P_EHIP; }
-    if (force_tickets != 2) fprintf(stderr, "[c8p_detect] a tile's look-back gave up waiting for its predecessor; repeating the scan with ticket numbering\n");
+    c->det_giveups++;
+    if (tlog) fprintf(stderr, "[c8p_detect] a tile's look-back gave up waiting for its predecessor; repeating the scan with ticket numbering\n");
   }
   lap("scan kernels + first sync");
   const unsigned ncand = *(const unsigned*)(hp + o_cnt);
-  const TrigSeg fin = *(const TrigSeg*)(hp + o_fin);
   if (ncand > cap) { c->err = "candidate list overflow"; return C8P_ERANGE; }
   c->det_spec = std::max(4096u, ncand + ncand / 4 + 64u);
-  // the plateaus of >= 21 samples, in stream order
+  // the plateaus of >= 21 samples, grouped by stream, in stream order
   std::vector<TrigCand>& cand = S.h_det_cand;
   cand.assign((const TrigCand*)(hp + o_cand), (const TrigCand*)(hp + o_cand) + std::min(ncand, spec));
   if (ncand > spec) {
     cand.resize(ncand);
     HIPCHK(c, hipMemcpy(cand.data() + spec, (const TrigCand*)S.d_det_cand.p + spec, sizeof(TrigCand) * (size_t)(ncand - spec), hipMemcpyDeviceToHost));
   }
-  const long long N = (long long)n;
-  // trigger_impl.cc:86-109: a plateau arms the 80-item countdown at its 21st sample, or as soon as the previous
-  // countdown has run out if that is later and the plateau still lasts; one trigger per plateau.
-  // sync_impl.cc:73-147: IDLE scans up to a trigger, SYNC needs 240 items from it and consumes 111.
-  // The first countdown / search window that runs past the end of the segment stops the walk: the commit point moves
-  // to the item where that countdown was armed, and the next call derives it again.
-  bool have = st0.have_prev != 0;
-  long long prev_start = st0.prev_start;
-  long long pos = st0.sync_pos;                       // first item IDLE looks at
-  long long commit = N;
-  c8p_det_state st1;
-  memset(&st1, 0, sizeof(st1));
+  std::vector<unsigned> soff((size_t)K + 1, 0u);
+  if (multi) memcpy(soff.data(), hp + o_soff, sizeof(unsigned) * (size_t)(K + 1));
+  else { soff[0] = 0; soff[1] = ncand; }
+  std::vector<TrigSeg> fin((const TrigSeg*)(hp + o_fin), (const TrigSeg*)(hp + o_fin) + K);     // (the pinned block is reused below)
   std::vector<unsigned long long>& fire = S.h_det_fire;
   std::vector<SyncJob>& jobs = S.h_det_jobs;
   fire.clear(); jobs.clear();
-  fire.reserve(cand.size() + 1); jobs.reserve(cand.size() + 2);
-  bool open_fired = false;                             // the plateau that is open at the end of the segment has armed
-  bool stopped = false;
-  long long stop_run_start = 0;
-  bool stop_have = false;
-  long long stop_prev = 0;
-  for (const TrigCand& k : cand) {
-    if (st0.in_run && st0.run_fired && k.s == st0.run_start) { if (k.e == N) open_fired = true; continue; }   // armed before the commit point
-    long long start = k.s + 20;
-    if (have && prev_start + 80 > start) start = prev_start + 80;
-    if (start >= k.e) continue;                        // the plateau ended before the previous countdown ran out
-    const long long t = start + 79;
-    const bool unseen = t < pos;                       // would fall inside the 111 items a SYNC pass consumes unseen
-    if (t >= N || (!unseen && N - t < C8P_SYNC_BUF)) { // countdown or search window runs past the end: not decidable yet
-      stopped = true; commit = start; stop_run_start = k.s; stop_have = have; stop_prev = prev_start;
-      break;
-    }
-    have = true; prev_start = start;
-    if (k.e == N) open_fired = true;
-    fire.push_back((unsigned long long)t);
-    if (unseen) continue;
-    SyncJob j; j.t = (unsigned long long)t; j.seen = (unsigned long long)std::max(pos, 0ll);
-    jobs.push_back(j);
-    pos = t + C8P_SYNC_RES;
+  fire.reserve(cand.size() + 1); jobs.reserve(cand.size() + (size_t)K + 1);
+  for (int s = 0; s < K; s++) {
+    DetHost& H = hs[s];
+    if (H.n == 0) { H.job0 = (int)jobs.size(); H.nj = -1; continue; }     // nothing new: no jobs, the state stays
+    if (soff[s] > soff[s + 1] || soff[s + 1] > ncand) { c->err = "detect: stream candidate offsets out of order"; return C8P_EHIP; }
+    det_walk(H, cand.data() + soff[s], soff[s + 1] - soff[s], s, fire, jobs);
   }
   lap("state machines");
-  // one more look-back job, not a trigger: what the IDLE state has latched when it reaches the commit point
-  const int nj = (int)jobs.size();
-  {
-    SyncJob j; j.t = (unsigned long long)commit; j.seen = (unsigned long long)std::min(std::max(pos, 0ll), commit);
-    jobs.push_back(j);
-  }
+  const int NJ = (int)jobs.size();                     // triggers and look-backs of every stream
   const int nf = (int)fire.size();
   std::vector<c8p_sync_evt> evts;
-  // pinned layout for the second exchange: [fires | jobs] up, [marks | events | valid] down, [compacted events] up
-  const size_t o_fire = 0, o_job = o_fire + sizeof(unsigned long long) * (size_t)(nf + 1);
-  const size_t o_mark = o_job + sizeof(SyncJob) * (size_t)(nj + 1), o_evt = o_mark + sizeof(SyncMark) * (size_t)(nj + 1);
-  const size_t o_val = o_evt + sizeof(c8p_sync_evt) * (size_t)(nj + 1), o_out = (o_val + sizeof(int) * (size_t)(nj + 1) + 63) & ~(size_t)63;
-  if ((rc = ensure_host(c, o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1) + 64)) != C8P_OK) return rc;   // (phase-1 data is consumed)
+  // pinned layout for the second exchange: [fires | jobs] up, [marks | events | valid | range maxima] down, [compacted events] up
+  const size_t o_fire = 0, o_job = (o_fire + sizeof(unsigned long long) * (size_t)(nf + 1) + 15) & ~(size_t)15;
+  const size_t o_mark = o_job + sizeof(SyncJob) * (size_t)(NJ + 1), o_evt = o_mark + sizeof(SyncMark) * (size_t)(NJ + 1);
+  const size_t o_val = o_evt + sizeof(c8p_sync_evt) * (size_t)(NJ + 1), o_rm = (o_val + sizeof(int) * (size_t)(NJ + 1) + 63) & ~(size_t)63;
+  const size_t o_out = (o_rm + sizeof(unsigned) * (size_t)K + 63) & ~(size_t)63;
+  if ((rc = ensure_host(c, o_out + sizeof(c8p_sync_evt) * (size_t)(NJ + 1) + 64)) != C8P_OK) return rc;   // (phase-1 data is consumed)
   hp = (char*)S.h_stage;
+  if ((rc = ensure_detect_jobs(c, S, (size_t)nf, (size_t)NJ + 1)) != C8P_OK) return rc;
   if (nf) {
-    if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * (size_t)nf)) != C8P_OK) return rc;
     memcpy(hp + o_fire, fire.data(), sizeof(unsigned long long) * (size_t)nf);
     HIPCHK(c, hipMemcpyAsync(S.d_det_fire.p, hp + o_fire, sizeof(unsigned long long) * (size_t)nf, hipMemcpyHostToDevice, S.stream));
     hipLaunchKernelGGL(k_trig_fire, dim3((nf + 255) / 256), dim3(256), 0, S.stream, (uint8_t*)S.d_det_trig.p,
                        (const unsigned long long*)S.d_det_fire.p, nf);
   }
   const SyncMark* marks = (const SyncMark*)(hp + o_mark);
-  {
-    if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * (size_t)(nj + 1))) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * (size_t)(nj + 1))) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * (size_t)(nj + 1))) != C8P_OK) return rc;
-    if ((rc = ensure(c, S.d_det_valid, sizeof(int) * (size_t)(nj + 1))) != C8P_OK) return rc;
-    memcpy(hp + o_job, jobs.data(), sizeof(SyncJob) * (size_t)(nj + 1));
-    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, hp + o_job, sizeof(SyncJob) * (size_t)(nj + 1), hipMemcpyHostToDevice, S.stream));
+  bool any_rmax = false;
+  if (NJ) {
+    memcpy(hp + o_job, jobs.data(), sizeof(SyncJob) * (size_t)NJ);
+    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, hp + o_job, sizeof(SyncJob) * (size_t)NJ, hipMemcpyHostToDevice, S.stream));
     {
       KTimer kt(c, C8P_K_SYNCEVT);
-      hipLaunchKernelGGL(k_sync_mark, dim3(nj + 1), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_raw,
-                         hist, (SyncMark*)S.d_det_mark.p, nj + 1);
-      if (nj)
-        hipLaunchKernelGGL(k_sync_evt, dim3(nj), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_raw,
-                           (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, nj, make_float2(st0.conj_avg.re, st0.conj_avg.im),
-                           (unsigned long long)in->n_hist);
+      hipLaunchKernelGGL(k_sync_mark, dim3(NJ), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_ds,
+                         (SyncMark*)S.d_det_mark.p, NJ);
+      if (NJ > K || !multi)      // (at least one trigger somewhere; kind = 1 jobs return at once)
+        hipLaunchKernelGGL(k_sync_evt, dim3(NJ), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_ds,
+                           (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, NJ);
+      else
+        HIPCHK(c, hipMemsetAsync(S.d_det_valid.p, 0, sizeof(int) * (size_t)NJ, S.stream));
+    }
+    // d_conjAc at a commit point inside a plateau: maximum of ac over the plateau so far.  ac is not stored: the same arithmetic
+    // once more over the tiles that stretch of the plateau touches
+    for (int s = 0; s < K; s++) {
+      DetHost& H = hs[s];
+      H.want_rmax = false;
+      if (H.nj < 0 || !H.stopped) continue;
+      H.rmax0 = (H.st0.in_run && H.stop_run_start == H.st0.run_start) ? H.st0.run_max : 0.f;
+      const long long lo = std::max(H.stop_run_start, 0ll);
+      if (H.commit_ll <= lo) continue;
+      const long long tl = lo / C8P_DET_TILE, th = (H.commit_ll - 1) / C8P_DET_TILE;
+      const cf* x = d_all + H.off + H.n_hist;
+      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(256), 0, S.stream, x, (long long)H.n_hist, (unsigned long long)H.n,
+                         (int)(((uintptr_t)x & 15u) == 0), tl, lo, H.commit_ll, d_rmax + s);
+      H.want_rmax = true; any_rmax = true;
     }
     HIPCHK(c, hipGetLastError());
     lap("second phase enqueue");
-    if (nj) {
-      HIPCHK(c, hipMemcpyAsync(hp + o_evt, S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
-      HIPCHK(c, hipMemcpyAsync(hp + o_val, S.d_det_valid.p, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, S.stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(hp + o_mark, S.d_det_mark.p, sizeof(SyncMark) * (size_t)(nj + 1), hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_evt, S.d_det_evt.p, sizeof(c8p_sync_evt) * (size_t)NJ, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_val, S.d_det_valid.p, sizeof(int) * (size_t)NJ, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK(c, hipMemcpyAsync(hp + o_mark, S.d_det_mark.p, sizeof(SyncMark) * (size_t)NJ, hipMemcpyDeviceToHost, S.stream));
+    if (any_rmax) HIPCHK(c, hipMemcpyAsync(hp + o_rm, d_rmax, sizeof(unsigned) * (size_t)K, hipMemcpyDeviceToHost, S.stream));
     HIPCHK(c, hipStreamSynchronize(S.stream));
     lap("sync kernels + second sync");
     const c8p_sync_evt* all = (const c8p_sync_evt*)(hp + o_evt);
     const int* valid = (const int*)(hp + o_val);
-    for (int k = 0; k < nj; k++) if (valid[k]) evts.push_back(all[k]);
-    if (!evts.empty()) {    // compacted, in stream order: what the sync block's output stream carries
+    for (int s = 0; s < K; s++) {
+      DetHost& H = hs[s];
+      if (H.nj < 0) continue;
+      for (int k = H.job0; k < H.job0 + H.nj; k++) if (valid[k]) { evts.push_back(all[k]); H.n_evt++; }
+    }
+    if (!evts.empty()) {    // compacted, grouped by stream, in stream order: what the sync blocks' output streams carry
       memcpy(hp + o_out, evts.data(), sizeof(c8p_sync_evt) * evts.size());
       HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, hp + o_out, sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
     }
   }
-  // ---- state at the new commit point
-  st1.conj_avg = st0.conj_avg;
-  for (int k = nj; k >= 0; k--) if (marks[k].j >= 0) { st1.conj_avg.re = marks[k].conj.x; st1.conj_avg.im = marks[k].conj.y; break; }
-  st1.sync_pos = pos - commit;
-  if (stopped) {
-    // the commit point is the item where the undecidable countdown is armed: its plateau is open, has not armed yet
-    st1.in_run = 1; st1.run_fired = 0; st1.run_start = stop_run_start - commit;
-    st1.have_prev = stop_have; st1.prev_start = stop_prev - commit;
-    // d_conjAc at that item: maximum of ac over the plateau so far
-    float rmax = (st0.in_run && stop_run_start == st0.run_start) ? st0.run_max : 0.f;
-    const long long lo = std::max(stop_run_start, 0ll);
-    if (commit > lo) {         // ac is not stored: the same arithmetic once more over the tiles this stretch of the plateau touches
-      const long long tl = lo / C8P_DET_TILE, th = (commit - 1) / C8P_DET_TILE;
-      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(256), 0, S.stream, d_raw, hist, (unsigned long long)n, x_al16,
-                         tl, lo, commit, d_cnt + 2);
-      HIPCHK(c, hipGetLastError());
-      float got = 0.f;
-      HIPCHK(c, hipMemcpyAsync(hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), d_cnt + 2, sizeof(float), hipMemcpyDeviceToHost, S.stream));
-      HIPCHK(c, hipStreamSynchronize(S.stream));
-      memcpy(&got, hp + o_out + sizeof(c8p_sync_evt) * (size_t)(nj + 1), sizeof(float));
-      if (got > rmax) rmax = got;
+  // ---- state at the new commit points
+  for (int s = 0; s < K; s++) {
+    DetHost& H = hs[s];
+    if (H.nj < 0) continue;
+    const c8p_det_state& st0 = H.st0;
+    c8p_det_state st1;
+    memset(&st1, 0, sizeof(st1));
+    const long long commit = H.commit_ll;
+    st1.conj_avg = st0.conj_avg;
+    for (int k = H.job0 + H.nj; k >= H.job0; k--) if (marks[k].j >= 0) { st1.conj_avg.re = marks[k].conj.x; st1.conj_avg.im = marks[k].conj.y; break; }
+    st1.sync_pos = H.pos - commit;
+    if (H.stopped) {
+      // the commit point is the item where the undecidable countdown is armed: its plateau is open, has not armed yet
+      st1.in_run = 1; st1.run_fired = 0; st1.run_start = H.stop_run_start - commit;
+      st1.have_prev = H.stop_have; st1.prev_start = H.stop_prev - commit;
+      float rmax = H.rmax0;
+      if (H.want_rmax) { float got = 0.f; memcpy(&got, hp + o_rm + sizeof(unsigned) * (size_t)s, sizeof(float)); if (got > rmax) rmax = got; }
+      st1.run_max = rmax;
+    } else {
+      const TrigSeg& f = fin[s];
+      st1.in_run = seg_has_run(f) ? 1 : 0;
+      st1.run_start = st1.in_run ? f.tstart - commit : 0;
+      st1.run_max = st1.in_run ? f.tmax : 0.f;
+      st1.run_fired = (st1.in_run && (H.open_fired || (st0.in_run && st0.run_fired && f.tstart == st0.run_start))) ? 1 : 0;
+      st1.have_prev = H.have; st1.prev_start = H.prev_start - commit;
     }
-    st1.run_max = rmax;
-  } else {
-    st1.in_run = seg_has_run(fin) ? 1 : 0;
-    st1.run_start = st1.in_run ? fin.tstart - commit : 0;
-    st1.run_max = st1.in_run ? fin.tmax : 0.f;
-    st1.run_fired = (st1.in_run && (open_fired || (st0.in_run && st0.run_fired && fin.tstart == st0.run_start))) ? 1 : 0;
-    st1.have_prev = have; st1.prev_start = prev_start - commit;
+    H.st1 = st1; H.commit = (uint64_t)commit;
   }
   lap("compaction + state");
   drain_events(c);     // (the compacted events' upload may still be in flight: c8p_fetch / the next submit order behind it)
-  if (in->commit) *in->commit = in->n_hist + (uint64_t)commit;
-  if (in->state_out) *in->state_out = st1;
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
-  S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * n : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
-  S.used[C8P_BUF_DET_TRIG] = n; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
-  S.used[C8P_BUF_DET_RAW] = sizeof(cf) * in->n; S.ptr[C8P_BUF_DET_RAW] = d_all;
-  S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * n : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
+  S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * out_items : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
+  S.used[C8P_BUF_DET_TRIG] = out_items; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
+  S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * out_items : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
+  return C8P_OK;
+}
+
+static int detect_begin(c8p_ctx* c)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
+  c->s = &c->slots[c->cur];
+  Slot& S = *c->s;
+  HIPCHK(c, hipStreamSynchronize(S.stream));
+  drain_events(c);
+  S.n_pkt = 0;
+  for (int i = 0; i < C8P_BUF_COUNT; i++) { S.used[i] = 0; S.ptr[i] = nullptr; }
+  return C8P_OK;
+}
+
+extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || (in->n > 0 && !in->raw) || in->n_hist > in->n) { c->err = "bad detect input"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  if (in->n > (1ull << 31)) { c->err = "stream segment too long (2^31 items max)"; return C8P_ERANGE; }
+  int rc;
+  if ((rc = detect_begin(c)) != C8P_OK) return rc;
+  Slot& S = *c->s;
+  std::vector<DetHost> hs(1);
+  DetHost& H = hs[0];
+  memset(&H.st0, 0, sizeof(H.st0));
+  if (in->state) H.st0 = *in->state;
+  H.off = 0; H.n_total = in->n; H.n_hist = in->n_hist;
+  if (in->commit) *in->commit = in->n_hist;
+  if (in->state_out) *in->state_out = H.st0;
+  if (in->n == in->n_hist) return C8P_OK;
+  const cf* d_all = (const cf*)in->raw;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * in->n)) != C8P_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * in->n, hipMemcpyHostToDevice, S.stream));
+    d_all = (const cf*)S.d_det_raw.p;
+  }
+  if ((rc = detect_run(c, d_all, in->n, hs, in->keep != 0, false)) != C8P_OK) return rc;
+  if (in->commit) *in->commit = in->n_hist + H.commit;
+  if (in->state_out) *in->state_out = H.st1;
+  return C8P_OK;
+}
+
+extern "C" int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->n_streams < 0 || (in->n_streams > 0 && (!in->streams || !in->raw))) { c->err = "bad detect input"; return C8P_EINVAL; }
+  if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
+  if (in->n_streams > 65535) { c->err = "at most 65535 streams per call"; return C8P_ERANGE; }
+  uint64_t total = 0;
+  for (int s = 0; s < in->n_streams; s++) {
+    const c8p_det_stream& k = in->streams[s];
+    if (k.n_hist > k.n || k.off + k.n > in->n_raw) { c->err = "stream items outside the raw arena"; return C8P_ERANGE; }
+    total += k.n;
+  }
+  if (total > (1ull << 31)) { c->err = "too many items in one call (2^31 max)"; return C8P_ERANGE; }
+  int rc;
+  if ((rc = detect_begin(c)) != C8P_OK) return rc;
+  Slot& S = *c->s;
+  const int K = in->n_streams;
+  if (K == 0) return C8P_OK;
+  std::vector<DetHost> hs((size_t)K);
+  for (int s = 0; s < K; s++) {
+    const c8p_det_stream& k = in->streams[s];
+    memset(&hs[s].st0, 0, sizeof(c8p_det_state));
+    if (k.has_state) hs[s].st0 = k.state;
+    hs[s].off = k.off; hs[s].n_total = k.n; hs[s].n_hist = k.n_hist;
+  }
+  const cf* d_all = (const cf*)in->raw;
+  if (in->mem == C8P_MEM_HOST) {
+    if ((rc = ensure(c, S.d_det_raw, sizeof(cf) * in->n_raw)) != C8P_OK) return rc;
+    for (int s = 0; s < K; s++)
+      if (hs[s].n_total)
+        HIPCHK(c, hipMemcpyAsync((cf*)S.d_det_raw.p + hs[s].off, in->raw + hs[s].off, sizeof(cf) * hs[s].n_total, hipMemcpyHostToDevice, S.stream));
+    d_all = (const cf*)S.d_det_raw.p;
+  }
+  if ((rc = detect_run(c, d_all, in->n_raw, hs, false, true)) != C8P_OK) return rc;
+  for (int s = 0; s < K; s++) {
+    c8p_det_stream& k = in->streams[s];
+    k.commit = k.n_hist + hs[s].commit; k.trig_off = hs[s].out_off; k.n_evt = hs[s].n_evt;
+    k.state = hs[s].st1; k.has_state = 1;
+  }
   return C8P_OK;
 }
 
@@ -1202,6 +1433,150 @@ extern "C" void* c8p_host_alloc(uint64_t bytes)
 }
 extern "C" void c8p_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// ------------------------------------------------------------------------------------------------ counters, reserve, caller arenas
+extern "C" int64_t c8p_counter(c8p_ctx* c, int which)
+{
+  if (!c) return C8P_EINVAL;
+  switch (which) {
+    case C8P_CNT_ARENA_GROWTHS: return c->n_grow;
+    case C8P_CNT_ARENA_BYTES: return c->dev_bytes;
+    case C8P_CNT_HOST_BYTES: return c->host_bytes;
+    case C8P_CNT_DET_GIVEUPS: return c->det_giveups;
+    case C8P_CNT_DET_TICKET_SCANS: return c->det_ticket_scans;
+    case C8P_CNT_SLOTS: return (int64_t)c->slots.size();
+    case C8P_CNT_SUBMITS: return (int64_t)c->seq;
+    default: return C8P_EINVAL;
+  }
+}
+
+// Every slot's arenas grown to what submits of the given shape will ask for (the same size formulas: the submit paths call the same
+// ensure_* helpers).  Slots that are in flight are synchronised by ensure() before an arena of theirs is replaced.
+extern "C" int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in)
+{
+  if (!c) return C8P_EINVAL;
+  if (!in || in->rx_packets < 0 || in->sig_events < 0 || in->det_events < 0 || in->det_streams < 0) { c->err = "bad reserve request"; return C8P_EINVAL; }
+  if (in->rx_packets > 0 && in->rx_ant != 1 && in->rx_ant != 2) { c->err = "rx_ant must be 1 or 2"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Slot* const keep_sel = c->s;
+  int rc = C8P_OK;
+  for (Slot& S : c->slots) {
+    c->s = &S;
+    if (in->rx_packets > 0) {
+      const int n = in->rx_packets;
+      std::vector<c8p_pkt_in> pk((size_t)n);
+      memset(pk.data(), 0, sizeof(c8p_pkt_in) * (size_t)n);
+      for (int p = 0; p < n; p++) { pk[p].n_items = in->rx_items; pk[p].n_ant = (uint8_t)in->rx_ant; }
+      c8p_batch_in b;
+      memset(&b, 0, sizeof(b));
+      b.n_pkt = n; b.pkts = pk.data(); b.n_iq = (uint64_t)n * in->rx_items * (uint64_t)in->rx_ant; b.n_chan = 64ull * (uint64_t)n;
+      Plan P;
+      if ((rc = plan_demod(c, &b, P)) != C8P_OK) break;
+      if ((rc = ensure_demod_arenas(c, n, P, in->rx_host ? b.n_iq : 0, in->rx_host ? b.n_chan : 0)) != C8P_OK) break;
+      if ((rc = ensure_decode_arenas(c, n, P)) != C8P_OK) break;
+    }
+    if (in->sig_events > 0) {
+      const size_t n = (size_t)in->sig_events;
+      if ((rc = ensure_signal_arenas(c, n, in->sig_items, in->sig_host ? in->sig_raw : 0)) != C8P_OK) break;
+    }
+    if (in->det_items > 0) {
+      const int K = std::max(1, in->det_streams);
+      // (every stream may end inside a tile of its own and supplies C8P_DET_HIST items that are not new)
+      const size_t ntile = (size_t)(in->det_items / C8P_DET_TILE) + (size_t)K + 1;
+      const size_t cap = (size_t)(in->det_items / 22) + 16 * (size_t)K;
+      const uint64_t out_items = in->det_items + 8ull * (uint64_t)K;
+      const DetZero Z = det_zero_layout(ntile, K);
+      if ((rc = ensure_detect_arenas(c, S, out_items, ntile, cap, K, in->det_keep != 0, Z.bytes)) != C8P_OK) break;
+      if (in->det_host && (rc = ensure(c, S.d_det_raw, sizeof(cf) * in->det_items)) != C8P_OK) break;
+      const size_t nj = (size_t)in->det_events + (size_t)K + 1;
+      if ((rc = ensure_detect_jobs(c, S, nj, nj)) != C8P_OK) break;
+      // the pinned exchanges of one call: phase 1 [descriptors | tile map | counters | offsets | final segs | candidates], phase 2 [fires | jobs | marks | events | valid | maxima | events]
+      const size_t ph1 = sizeof(DetStreamDev) * (size_t)K + 2 * ntile + 512 + 4 * (size_t)(K + 1) + sizeof(TrigSeg) * (size_t)K + 256 + sizeof(TrigCand) * std::min<size_t>(cap, 8192);
+      const size_t ph2 = (8 + sizeof(SyncJob) + sizeof(SyncMark) + 2 * sizeof(c8p_sync_evt) + 4) * (nj + 1) + 4 * (size_t)K + 512;
+      if ((rc = ensure_host(c, std::max(ph1, ph2))) != C8P_OK) break;
+    }
+  }
+  c->s = keep_sel;
+  return rc;
+}
+
+extern "C" void* c8p_dev_alloc(c8p_ctx* c, uint64_t bytes)
+{
+  if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { c->err = "c8p_dev_alloc: hipMalloc failed"; return nullptr; }
+  return p;
+}
+extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
+{
+  if (!c || !p) return;
+  (void)hipSetDevice(c->device);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  (void)hipFree(p);
+}
+static int copy_stream_of(c8p_ctx* c)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  return C8P_OK;
+}
+extern "C" int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes)
+{
+  if (!c || (bytes && (!dst || !src))) return C8P_EINVAL;
+  int rc;
+  if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
+  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->copy_stream));
+  return C8P_OK;
+}
+// thread = one 16-byte pair of items of one span (spans are short next to what they are cut from: a linear walk over a span table
+// held in LDS would not pay; the table is binary-searched per thread)
+__global__ __launch_bounds__(256) void k_copy_spans(cf* __restrict__ dst, const cf* __restrict__ src, const c8p_span* __restrict__ sp,
+                                                    const unsigned long long* __restrict__ first, int n, unsigned long long total)
+{
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;                              // last span whose first work item is <= i
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= i) lo = mid; else hi = mid - 1; }
+  const c8p_span S = sp[lo];
+  const unsigned long long k = i - first[lo];
+  dst[S.dst_off + k] = src[S.src_off + k];
+}
+extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* spans, int32_t n)
+{
+  if (!c || n < 0 || (n > 0 && (!dst || !src || !spans))) return C8P_EINVAL;
+  int rc;
+  if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
+  if (n == 0) return C8P_OK;
+  const size_t tab = (sizeof(c8p_span) + sizeof(unsigned long long)) * (size_t)n;
+  if (tab > c->h_spans_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (c->h_spans) HIPCHK(c, hipHostFree(c->h_spans));
+    c->h_spans = nullptr; c->h_spans_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_spans, tab * 2 + 4096, hipHostMallocDefault));
+    c->h_spans_cap = tab * 2 + 4096;
+    if (c->d_spans.p) { HIPCHK(c, hipFree(c->d_spans.p)); c->d_spans.p = nullptr; c->d_spans.cap = 0; }
+    HIPCHK(c, hipMalloc(&c->d_spans.p, tab * 2 + 4096));
+    c->d_spans.cap = tab * 2 + 4096;
+  } else
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));      // (the previous table may still be on its way up)
+  c8p_span* hs = (c8p_span*)c->h_spans;
+  unsigned long long* hf = (unsigned long long*)((char*)c->h_spans + sizeof(c8p_span) * (size_t)n);
+  unsigned long long total = 0;
+  for (int i = 0; i < n; i++) { hs[i] = spans[i]; hf[i] = total; total += spans[i].n; }
+  if (total == 0) return C8P_OK;
+  HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));
+  hipLaunchKernelGGL(k_copy_spans, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->copy_stream, (cf*)dst, (const cf*)src,
+                     (const c8p_span*)c->d_spans.p, (const unsigned long long*)((const char*)c->d_spans.p + sizeof(c8p_span) * (size_t)n), n, total);
+  HIPCHK(c, hipGetLastError());
+  return C8P_OK;
+}
+extern "C" int c8p_copy_wait(c8p_ctx* c)
+{
+  if (!c) return C8P_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  return C8P_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device self-test hooks
 // The scalar arithmetic primitives of c8p_dev.h, exposed so that a test can compare them with the CPU's libm / libgcc forms
 // on millions of operands ON the device (the kernels only exercise them on whatever the test packets contain).
@@ -1255,7 +1630,8 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
                        (int32_t)sizeof(c8p_cfg), (int32_t)sizeof(c8p_batch_in), (int32_t)sizeof(c8p_decode_in),
                        (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
                        (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state), (int32_t)sizeof(c8p_tx_pkt),
-                       (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan), (int32_t)sizeof(c8p_tx_mu)};
-  for (int i = 0; i < 17 && i < cap; i++) dst[i] = v[i];
-  return 17;
+                       (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan), (int32_t)sizeof(c8p_tx_mu),
+                       (int32_t)sizeof(c8p_det_stream), (int32_t)sizeof(c8p_detect_multi_in), (int32_t)sizeof(c8p_reserve_in), (int32_t)sizeof(c8p_span)};
+  for (int i = 0; i < 21 && i < cap; i++) dst[i] = v[i];
+  return 21;
 }

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
            "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait",
-           "c8p_host_alloc", "c8p_host_free", "c8p_selftest"]
+           "c8p_host_alloc", "c8p_host_free", "c8p_selftest", "c8p_detect_multi", "c8p_reserve", "c8p_counter",
+           "c8p_dev_alloc", "c8p_dev_free", "c8p_copy_async", "c8p_copy_spans", "c8p_copy_wait"]
 
 _LIB = None
 
@@ -44,6 +45,16 @@ def load_library():
     L.c8p_decode.argtypes = [C.c_void_p, C.POINTER(abi.DecodeIn)]
     L.c8p_signal.argtypes = [C.c_void_p, C.POINTER(abi.SignalIn)]
     L.c8p_detect.argtypes = [C.c_void_p, C.POINTER(abi.DetectIn)]
+    L.c8p_detect_multi.argtypes = [C.c_void_p, C.POINTER(abi.DetectMultiIn)]
+    L.c8p_reserve.argtypes = [C.c_void_p, C.POINTER(abi.ReserveIn)]
+    L.c8p_counter.restype = C.c_int64
+    L.c8p_counter.argtypes = [C.c_void_p, C.c_int]
+    L.c8p_dev_alloc.restype = C.c_void_p
+    L.c8p_dev_alloc.argtypes = [C.c_void_p, C.c_uint64]
+    L.c8p_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.c8p_copy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.c8p_copy_spans.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.c8p_copy_wait.argtypes = [C.c_void_p]
     L.c8p_tx.argtypes = [C.c_void_p, C.POINTER(abi.TxIn)]
     L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_tx_plan_mu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
@@ -63,12 +74,13 @@ def load_library():
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
-    sizes = np.zeros(17, np.int32)
-    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 17)
+    sizes = np.zeros(21, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 21)
     want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
             C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn),
             C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn), C.sizeof(abi.DetState), C.sizeof(abi.TxPkt), C.sizeof(abi.TxDesc),
-            C.sizeof(abi.TxIn), C.sizeof(abi.TxPlan), C.sizeof(abi.TxMu)]
+            C.sizeof(abi.TxIn), C.sizeof(abi.TxPlan), C.sizeof(abi.TxMu), C.sizeof(abi.DetStream), C.sizeof(abi.DetectMultiIn),
+            C.sizeof(abi.ReserveIn), C.sizeof(abi.Span)]
     if list(sizes) != want:
         raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
     _LIB = L
@@ -160,7 +172,7 @@ class Engine:
         self.n = len(tags)
         self._chk(self.L.c8p_decode(self.ctx, C.byref(d)))
 
-    def signal(self, evts, raw, consume=False):
+    def signal(self, evts, raw, consume=False, n_streams=0, scan_from=None):
         """signal / signal2 front-end: sync events + raw samples -> boundary descriptors, de-rotated items, chan.
         consume=True: evts are one stream's flags in order and the engine applies the block's scan rule (flags inside a
         copied packet are never looked at, SIG_SKIPPED); the kept packets lie back to back in BUF_SIG_IQ; returns the
@@ -168,8 +180,18 @@ class Engine:
         evts = np.ascontiguousarray(evts, abi.SIG_IN_DT)
         r_p, n_r, m, k1 = self._arena(raw, np.complex64)
         pk = np.zeros(len(evts), abi.PKT_IN_DT) if consume else None
-        d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, int(bool(consume)), 0, pk.ctypes.data if consume and len(evts) else None, 0, None)
-        self._keep = (evts, k1, d, pk)
+        K = int(n_streams)
+        if K > 1:       # K independent streams: evts grouped by evts["stream"]; scan_from = K positions (None: zeros)
+            sf = np.ascontiguousarray(scan_from if scan_from is not None else np.zeros(K), np.uint64)
+            self.scan_next = np.zeros(K, np.uint64)
+            d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, 1, K, pk.ctypes.data if len(evts) else None, 0,
+                             self.scan_next.ctypes.data, sf.ctypes.data)
+        else:
+            sf = None
+            self.scan_next = np.zeros(1, np.uint64)
+            d = abi.SignalIn(len(evts), m, evts.ctypes.data, r_p, n_r, int(bool(consume)), 0, pk.ctypes.data if consume and len(evts) else None,
+                             int(scan_from or 0), self.scan_next.ctypes.data if consume else None, None)
+        self._keep = (evts, k1, d, pk, sf)
         self.n = len(evts)
         self._chk(self.L.c8p_signal(self.ctx, C.byref(d)))
         return pk
@@ -187,6 +209,43 @@ class Engine:
         self._chk(self.L.c8p_detect(self.ctx, C.byref(d)))
         ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
         return (ev, st_out, commit.value) if stream else ev
+
+    def detect_multi(self, raw, streams):
+        """c8p_detect_multi: K independent streams whose items lie in one arena.  streams = list of dicts {off, n, n_hist, state
+        (abi.DetState or None)}; returns (events per stream [list of SYNC_EVT_DT arrays, index relative to off], the list of dicts
+        updated with commit / trig_off / state)"""
+        r_p, n_r, m, k1 = self._arena(raw, np.complex64)
+        K = len(streams)
+        arr = (abi.DetStream * max(K, 1))()
+        for s, d in enumerate(streams):
+            arr[s].off, arr[s].n, arr[s].n_hist = int(d["off"]), int(d["n"]), int(d.get("n_hist", 0))
+            st = d.get("state")
+            arr[s].has_state = int(st is not None)
+            if st is not None:
+                C.memmove(C.addressof(arr[s].state), C.addressof(st), C.sizeof(abi.DetState))
+        din = abi.DetectMultiIn(m, K, r_p, n_r, C.addressof(arr))
+        self._keep = (k1, din, arr)
+        self._chk(self.L.c8p_detect_multi(self.ctx, C.byref(din)))
+        ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
+        out, evs, o = [], [], 0
+        for s in range(K):
+            st = abi.DetState()
+            C.memmove(C.addressof(st), C.addressof(arr[s].state), C.sizeof(abi.DetState))
+            out.append(dict(streams[s], commit=int(arr[s].commit), trig_off=int(arr[s].trig_off), state=st, n_evt=int(arr[s].n_evt)))
+            evs.append(ev[o:o + int(arr[s].n_evt)].copy())
+            o += int(arr[s].n_evt)
+        assert o == len(ev)
+        return evs, out
+
+    def reserve(self, **kw):
+        """c8p_reserve(fields of c8p_reserve_in by name)"""
+        r = abi.ReserveIn()
+        for k, v in kw.items():
+            setattr(r, k, int(v))
+        self._chk(self.L.c8p_reserve(self.ctx, C.byref(r)))
+
+    def counter(self, which):
+        return int(self.L.c8p_counter(self.ctx, int(which)))
 
     def tx(self, pkts, psdu, tail_gap=0, mu=None, bfq=None):
         """transmit chain: pkts = TX_PKT_DT records, psdu = byte arena (host array or DevArray); MU-MIMO packets

@@ -56,6 +56,14 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.fetch_async = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch_async");
   a.host_alloc = (void* (*)(uint64_t))sym("c8p_host_alloc");
   a.host_free = (void (*)(void*))sym("c8p_host_free");
+  a.detect_multi = (int (*)(c8p_ctx*, const c8p_detect_multi_in*))sym("c8p_detect_multi");
+  a.reserve = (int (*)(c8p_ctx*, const c8p_reserve_in*))sym("c8p_reserve");
+  a.counter = (int64_t (*)(c8p_ctx*, int))sym("c8p_counter");
+  a.dev_alloc = (void* (*)(c8p_ctx*, uint64_t))sym("c8p_dev_alloc");
+  a.dev_free = (void (*)(c8p_ctx*, void*))sym("c8p_dev_free");
+  a.copy_async = (int (*)(c8p_ctx*, void*, const void*, uint64_t))sym("c8p_copy_async");
+  a.copy_spans = (int (*)(c8p_ctx*, c8p_c32*, const c8p_c32*, const c8p_span*, int32_t))sym("c8p_copy_spans");
+  a.copy_wait = (int (*)(c8p_ctx*))sym("c8p_copy_wait");
   return a;
 }
 

@@ -103,6 +103,15 @@ struct c8p_api {
   int (*fetch_async)(c8p_ctx*, int, void*, uint64_t, uint64_t);
   void* (*host_alloc)(uint64_t);
   void (*host_free)(void*);
+  // the raw-stream pipeline (c8p_rawchain): K streams per detection pass, arenas sized in advance, counters, caller-owned arenas
+  int (*detect_multi)(c8p_ctx*, const c8p_detect_multi_in*);
+  int (*reserve)(c8p_ctx*, const c8p_reserve_in*);
+  int64_t (*counter)(c8p_ctx*, int);
+  void* (*dev_alloc)(c8p_ctx*, uint64_t);
+  void (*dev_free)(c8p_ctx*, void*);
+  int (*copy_async)(c8p_ctx*, void*, const void*, uint64_t);
+  int (*copy_spans)(c8p_ctx*, c8p_c32*, const c8p_c32*, const c8p_span*, int32_t);
+  int (*copy_wait)(c8p_ctx*);
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);

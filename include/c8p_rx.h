@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define C8P_ABI_VERSION 2
+#define C8P_ABI_VERSION 3   /* 3: c8p_sig_in.stream, c8p_signal_in.n_streams / scan_from_v, C8P_BUF_DET_RAW, c8p_detect_multi, c8p_reserve, c8p_counter, c8p_dev_* */
 
 /* return codes */
 #define C8P_OK          0
@@ -146,6 +146,7 @@ typedef struct c8p_sig_in {
   float    snr, rssi;   /* tags "snr", "rssi" (pass-through)                                                  */
   uint8_t  n_ant;       /* 1: signal, 2: signal2                                                              */
   uint8_t  rsv[3];
+  uint32_t stream;      /* c8p_signal_in.n_streams > 1: which of the independent streams raised this flag     */
 } c8p_sig_in;
 
 /*
@@ -269,11 +270,15 @@ typedef struct c8p_signal_in {
                                 C8P_SIG_NEED_MORE) stops the scan, it and the flags behind it are C8P_SIG_PENDING.  Only the
                                 packets the block copies are copied, back to back in C8P_BUF_SIG_IQ.  The call blocks until the
                                 descriptors are known (the copies are only enqueued)                                          */
-  int32_t           rsv;
+  int32_t           n_streams; /* consume = 1.  0 or 1: evts belong to one stream.  K > 1: to K independent streams (one signal block each,
+                                 c8p_sig_in.stream = 0 .. K-1), grouped by stream in ascending order and in stream order inside a group; the
+                                 scan rule runs per stream, from scan_from_v[stream], and scan_next receives K positions            */
   c8p_pkt_in*       pkt_host; /* consume = 1: if not NULL, receives the n_evt descriptors (what C8P_BUF_SIG_PKT holds)         */
   uint64_t          scan_from; /* consume = 1: where the S_TRIGGER scan stands when it meets the first flag (raw_off[0] units): flags
                                  before it are C8P_SIG_SKIPPED — the position a previous call over the same stream left in *scan_next */
-  uint64_t*         scan_next; /* consume = 1: if not NULL, receives the scan position after the last flag that was looked at      */
+  uint64_t*         scan_next; /* consume = 1: if not NULL, receives the scan position after the last flag that was looked at
+                                 (n_streams > 1: one per stream; a stream without flags keeps its scan_from_v value)             */
+  const uint64_t*   scan_from_v; /* n_streams > 1: [n_streams] scan positions (NULL: all 0); scan_from is then ignored           */
 } c8p_signal_in;
 
 /* State of trigger_impl + sync_impl at a commit point of the stream: everything before it is final, nothing pending
@@ -307,6 +312,49 @@ typedef struct c8p_detect_in {
   uint64_t*      commit;        /* may be NULL; receives the new commit point (index into raw): triggers whose countdown or
                                    240-item search window runs past the end of raw are re-derived by the next call        */
 } c8p_detect_in;
+
+/* c8p_detect over K independent streams in ONE pass (one k_detect_scan launch: a tile belongs to a stream, the plateau look-back
+ * stops at a stream's first tile): what K chains of presiso.grc + trigger + sync do to K radios.  Every stream is a streaming
+ * c8p_detect_in of its own (history, state at its commit point) whose items lie in one arena; the fields marked "out" are written
+ * back.  A stream with no new items (n == n_hist) keeps its state.  C8P_BUF_DET_EVT holds the events of stream 0, then stream 1, ...
+ * (each stream's in stream order, index relative to the stream's `off`); C8P_BUF_DET_TRIG holds each stream's trigger bytes at
+ * trig_off. */
+typedef struct c8p_det_stream {
+  uint64_t off;             /* item offset of the stream's first supplied item (history included) inside raw            */
+  uint64_t n;               /* items supplied: n_hist of history, then the new ones                                     */
+  uint64_t n_hist;          /* as c8p_detect_in.n_hist                                                                   */
+  uint64_t commit;          /* out: the new commit point (index relative to off)                                         */
+  uint64_t trig_off;        /* out: byte offset of this stream's n - n_hist trigger bytes inside C8P_BUF_DET_TRIG        */
+  uint32_t n_evt;           /* out: sync events of this stream                                                           */
+  int32_t  has_state;       /* 0: the blocks' constructor state (`state` is ignored on the way in)                       */
+  c8p_det_state state;      /* in: state at the commit point; out: state at the new commit point                         */
+} c8p_det_stream;
+typedef struct c8p_detect_multi_in {
+  int32_t mem;              /* C8P_MEM_* of raw (host: every stream's items are uploaded to the same offsets of the engine's copy) */
+  int32_t n_streams;
+  const c8p_c32* raw;       /* the arena that holds every stream's items                                                */
+  uint64_t       n_raw;     /* items in it                                                                              */
+  c8p_det_stream* streams;  /* [n_streams], host memory, in / out                                                       */
+} c8p_detect_multi_in;
+
+/* Arena sizes known in advance: c8p_reserve grows every slot's arenas to what submits of this shape need, so that no allocation
+ * (hipMalloc / hipHostMalloc behind a stream synchronisation) happens inside a later submit.  Zero fields reserve nothing. */
+typedef struct c8p_reserve_in {
+  int32_t  rx_packets;      /* c8p_rx / c8p_demod / c8p_decode: packets per submit ...                                    */
+  int32_t  rx_ant;          /* ... their ports (1 or 2) ...                                                               */
+  uint32_t rx_items;        /* ... and items per packet and port (c8p_pkt_in.n_items of the longest one)                  */
+  int32_t  rx_host;         /* 1: their iq / chan arenas come from host memory (the engine's staging copies are sized too) */
+  int32_t  sig_events;      /* c8p_signal: flags per call                                                                 */
+  int32_t  sig_host;        /* 1: raw comes from host memory ...                                                          */
+  uint64_t sig_raw;         /* ... this many items of it                                                                  */
+  uint64_t sig_items;       /* items of C8P_BUF_SIG_IQ: consume = 1: the kept packets (n_items per port, summed); consume = 0:
+                               sum over the flags of (n_avail - 224 + 320) per port                                       */
+  uint64_t det_items;       /* c8p_detect / c8p_detect_multi: items per call (history included, all streams)              */
+  int32_t  det_host;        /* 1: they come from host memory                                                              */
+  int32_t  det_streams;     /* c8p_detect_multi: streams per call (0 or 1: c8p_detect)                                    */
+  int32_t  det_events;      /* accepted triggers per call (sync searches)                                                 */
+  int32_t  det_keep;        /* 1: c8p_detect_in.keep                                                                      */
+} c8p_reserve_in;
 
 typedef struct c8p_decode_in {
   int32_t n_pkt;
@@ -373,6 +421,8 @@ int c8p_decode(c8p_ctx* ctx, const c8p_decode_in* in);  /* fills OUT, PDU (BITS,
 int c8p_rx    (c8p_ctx* ctx, const c8p_batch_in* in);   /* fills everything but C8P_BUF_LLR (empty unless c8p_cfg.keep_llr) */
 int c8p_signal(c8p_ctx* ctx, const c8p_signal_in* in);  /* fills SIG_PKT, SIG_IQ, SIG_CHAN (feed them to c8p_rx) */
 int c8p_detect(c8p_ctx* ctx, const c8p_detect_in* in); /* fills DET_EVT, DET_TRIG (DET_AC, DET_CONJ); blocks until the events are known */
+int c8p_detect_multi(c8p_ctx* ctx, const c8p_detect_multi_in* in); /* the same for K streams at once; fills DET_EVT, DET_TRIG, DET_RAW */
+int c8p_reserve(c8p_ctx* ctx, const c8p_reserve_in* in);
 int c8p_tx    (c8p_ctx* ctx, const c8p_tx_in* in);      /* fills TX_IQ, TX_DESC, TX_CODED (SURVEY §8f-4, 1 spatial stream) */
 int c8p_tx_plan_of(int format, int mcs, int nss, int len, c8p_tx_plan* plan);   /* 1 if the combination is supported */
 int c8p_tx_plan_mu(int mcs0, int len0, int mcs1, int len1, c8p_tx_plan* plan2); /* C8P_F_VHT_MU: plan2[0], plan2[1] = the users */
@@ -401,6 +451,30 @@ int c8p_wait(c8p_ctx* ctx, int ticket);
 void* c8p_host_alloc(uint64_t bytes);
 void  c8p_host_free(void* p);
 
+/* Device memory for arenas a caller keeps across submits (host/c8p_rawchain.cc's stream arenas), and copies into / inside it that
+ * are ordered on a copy stream of their own: c8p_copy_async enqueues one copy (either pointer may be host — pinned for an
+ * asynchronous copy — or device memory), c8p_copy_spans moves n spans of items inside device memory with one launch,
+ * c8p_copy_wait returns when everything enqueued so far has been done.  The engine's submits do NOT wait for these copies. */
+typedef struct c8p_span { uint64_t dst_off, src_off, n; } c8p_span;      /* item (c8p_c32) offsets from dst / src, item count */
+void* c8p_dev_alloc(c8p_ctx* ctx, uint64_t bytes);
+void  c8p_dev_free(c8p_ctx* ctx, void* p);
+int   c8p_copy_async(c8p_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int   c8p_copy_spans(c8p_ctx* ctx, c8p_c32* dst, const c8p_c32* src, const c8p_span* spans, int32_t n);   /* spans: host memory */
+int   c8p_copy_wait(c8p_ctx* ctx);
+
+/* Counters of one ctx since c8p_create (monotonic unless stated otherwise). */
+#define C8P_CNT_ARENA_GROWTHS    0   /* device / pinned allocations made by submits and c8p_reserve (each one sits behind a stream
+                                        synchronisation: a submit that grows an arena is slow — warm up or c8p_reserve)          */
+#define C8P_CNT_ARENA_BYTES      1   /* device bytes held by the arenas now (not monotonic)                                      */
+#define C8P_CNT_HOST_BYTES       2   /* pinned host bytes held by the staging buffers now (not monotonic)                        */
+#define C8P_CNT_DET_GIVEUPS      3   /* k_detect_scan launches in which a tile's look-back gave up waiting for a predecessor that
+                                        had not started (the scan was then repeated with ticket numbering)                        */
+#define C8P_CNT_DET_TICKET_SCANS 4   /* k_detect_scan launches with ticket numbering (repeats + C8P_DET_TICKETS = 1)              */
+#define C8P_CNT_SLOTS            5   /* slots of this ctx (C8P_SLOTS; 1 on a caller-provided stream): results of that many submits stay resident */
+#define C8P_CNT_SUBMITS          6
+#define C8P_CNT_COUNT            7
+int64_t c8p_counter(c8p_ctx* ctx, int which);        /* < 0: C8P_EINVAL */
+
 /* profile=1: accumulated HIP-event time and launch count of one kernel since the last reset. */
 int c8p_kernel_time(c8p_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
 int c8p_profile_reset(c8p_ctx* ctx);
@@ -427,7 +501,8 @@ int c8p_table(int which, int sub, int32_t* dst, int cap);
 #define C8P_SELFTEST_AC   2
 int c8p_selftest(c8p_ctx* ctx, int which, const float* in, float* out, uint64_t n);
 
-/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc, tx_in, tx_plan} as compiled into the library. */
+/* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc,
+ * tx_in, tx_plan, tx_mu, det_stream, detect_multi_in, reserve_in, span} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

@@ -36,24 +36,7 @@ def load_npz(name):
     return groups
 
 
-def awgn(shape, sigma, rng):
-    return (rng.normal(0, sigma / np.sqrt(2), shape) + 1j * rng.normal(0, sigma / np.sqrt(2), shape)).astype(np.complex64)
-
-
-def through_channel(tx, H=None, snr_db=None, rng=None, lead=0, sig_amp=0.1875):
-    """tx: [nss][N] complex64 -> rx [n_rx][lead + N + PAD + 80]; H: [n_rx][nss] flat channel.
-    Noise sigma follows tools/performance/perf_siso.py:92 (sigma = sqrt(amp^2 / 10^(snr/10)))."""
-    tx = np.atleast_2d(tx)
-    nss, n = tx.shape
-    if H is None:
-        H = np.eye(nss, dtype=np.complex64)
-    H = np.asarray(H, np.complex64)
-    rx = np.zeros((H.shape[0], lead + n + PAD + 160), np.complex64)
-    rx[:, lead:lead + n] = (H @ tx).astype(np.complex64)
-    if snr_db is not None:
-        sigma = np.sqrt(sig_amp ** 2 / (10 ** (snr_db / 10.0)))
-        rx = rx + awgn(rx.shape, sigma, rng)
-    return rx.astype(np.complex64)
+from gr_ieee80211_amd.workloads import awgn, through_channel  # noqa: E402,F401
 
 
 def through_multipath(tx, taps, snr_db=None, rng=None, sig_amp=0.1875):

@@ -8,8 +8,11 @@
 
 #define SLOTS 3     /* like the engine's default: the results of the last 3 demod / decode / rx submits stay resident (c8p_ticket / c8p_select) */
 struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
+struct detst { c8p_c32* x; uint64_t n, commit; };      /* one stream of c8p_detect: every item it was ever given */
 struct c8p_ctx {
-  c8p_c32* det_x; uint64_t det_n, det_commit; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
+  struct detst det; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
+  struct detst* dets; int n_dets;                           /* c8p_detect_multi: the same per stream */
+  int64_t submits;
   const c8p_c32* det_raw; uint64_t det_raw_n;                                           /* C8P_BUF_DET_RAW: the caller's items */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   struct res r[SLOTS];
@@ -20,17 +23,25 @@ struct c8p_ctx {
 
 c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); c8p_ctx* c = (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); c->s = &c->r[0]; return c; }
 static void drop_res(struct res* r) { free(r->tags); free(r->outs); free(r->llr); free(r->pdu); free(r->mu); memset(r, 0, sizeof(*r)); }
-static void next_slot(c8p_ctx* c) { c->cur = (c->cur + 1) % SLOTS; c->s = &c->r[c->cur]; drop_res(c->s); c->s->ticket = ++c->seq; }
+static void next_slot(c8p_ctx* c) { c->submits++; c->cur = (c->cur + 1) % SLOTS; c->s = &c->r[c->cur]; drop_res(c->s); c->s->ticket = ++c->seq; }
 static void drop(c8p_ctx* c)
 {
-  free(c->det_x); free(c->det_evt); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
-  c->det_x = NULL; c->det_evt = NULL; c->sig_pkt = NULL; c->sig_iq = NULL; c->sig_chan = NULL;
-  c->det_n = c->det_commit = 0; c->det_nevt = 0; c->n_sig = 0; c->n_sig_iq = 0;
+  free(c->det.x); free(c->det_evt); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
+  for (int i = 0; i < c->n_dets; i++) free(c->dets[i].x);
+  free(c->dets); c->dets = NULL; c->n_dets = 0;
+  c->det.x = NULL; c->det_evt = NULL; c->sig_pkt = NULL; c->sig_iq = NULL; c->sig_chan = NULL;
+  c->det.n = c->det.commit = 0; c->det_nevt = 0; c->n_sig = 0; c->n_sig_iq = 0;
+}
+static void drop_sig(c8p_ctx* c)
+{
+  free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
+  c->sig_pkt = NULL; c->sig_iq = NULL; c->sig_chan = NULL; c->n_sig = 0; c->n_sig_iq = 0;
 }
 
 int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as the engine: per event cap = n_avail-224+320 items per antenna */
 {
-  drop(c);
+  drop_sig(c);
+  c->submits++;
   c->n_sig = in->n_evt;
   c->sig_pkt = (c8p_pkt_in*)calloc((size_t)in->n_evt + 1, sizeof(c8p_pkt_in));
   c->sig_chan = (c8p_c32*)calloc((size_t)in->n_evt * 64 + 1, sizeof(c8p_c32));
@@ -47,20 +58,28 @@ int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as
     if (!ok) c->sig_pkt[e].n_items = 0;
     off += cap * ev->n_ant;
   }
-  if (in->consume) {      /* the block's scan rule over the per-flag results (c8p_rx.h); the slots stay where they are */
-    uint64_t pos = in->scan_from;
-    int waiting = 0;
+  if (in->consume) {      /* the block's scan rule over the per-flag results (c8p_rx.h), per stream; the slots stay where they are */
+    const int KS = in->n_streams > 1 ? in->n_streams : 1;
+    uint64_t* posv = (uint64_t*)calloc((size_t)KS, sizeof(uint64_t));
+    char* waitv = (char*)calloc((size_t)KS, 1);
+    if (KS == 1) posv[0] = in->scan_from;
+    else if (in->scan_from_v) memcpy(posv, in->scan_from_v, sizeof(uint64_t) * (size_t)KS);
+    uint32_t last = 0;
     for (int e = 0; e < in->n_evt; e++) {
       c8p_pkt_in* p = &c->sig_pkt[e];
+      const uint32_t si = KS > 1 ? in->evts[e].stream : 0u;
+      if (si >= (uint32_t)KS || si < last) { free(posv); free(waitv); return C8P_EINVAL; }
+      last = si;
       const uint64_t idx = in->evts[e].raw_off[0];
-      if (waiting) { p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
-      if (idx < pos) { p->n_items = 0; p->rsv[0] = C8P_SIG_SKIPPED; continue; }
-      if (in->evts[e].n_avail < 224u) { waiting = 1; p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
-      if (p->n_items == 0) { if (p->rsv[0] == C8P_SIG_NEED_MORE) waiting = 1; else pos = idx + 80; continue; }
-      pos = idx + 224 + (uint64_t)p->lsig_nsamp;
+      if (waitv[si]) { p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
+      if (idx < posv[si]) { p->n_items = 0; p->rsv[0] = C8P_SIG_SKIPPED; continue; }
+      if (in->evts[e].n_avail < 224u) { waitv[si] = 1; p->n_items = 0; p->rsv[0] = C8P_SIG_PENDING; continue; }
+      if (p->n_items == 0) { if (p->rsv[0] == C8P_SIG_NEED_MORE) waitv[si] = 1; else posv[si] = idx + 80; continue; }
+      posv[si] = idx + 224 + (uint64_t)p->lsig_nsamp;
     }
-    if (in->scan_next) *in->scan_next = pos;
+    if (in->scan_next) memcpy(in->scan_next, posv, sizeof(uint64_t) * (size_t)KS);
     if (in->pkt_host) memcpy(in->pkt_host, c->sig_pkt, sizeof(c8p_pkt_in) * (size_t)in->n_evt);
+    free(posv); free(waitv);
   }
   return C8P_OK;
 }
@@ -101,40 +120,90 @@ static int decode_into(c8p_ctx* c, const c8p_decode_in* in)
   return C8P_OK;
 }
 int c8p_decode(c8p_ctx* c, const c8p_decode_in* in) { next_slot(c); return decode_into(c, in); }
-/* c8p_detect on the oracle: keeps every item it was ever given, re-runs the one-shot oracle over the whole stream and
+/* c8p_detect on the oracle: keeps every item a stream was ever given, re-runs the one-shot oracle over the whole stream and
  * reports the events between the old and the new commit point (new commit = 400 items before the end: every event
- * before it has its 240-item search window inside the stream, so later items cannot change it). */
-int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+ * before it has its 240-item search window inside the stream, so later items cannot change it).  Appends to *out. */
+static void detect_stream(struct detst* d, const c8p_c32* raw, uint64_t n, uint64_t n_hist, int fresh, uint64_t* commit_out,
+                          c8p_sync_evt** out, int* n_out)
 {
-  if (!in->state && in->n_hist == 0) { free(c->det_x); c->det_x = NULL; c->det_n = c->det_commit = 0; }   /* a segment from the constructor state */
-  c->det_raw = in->raw;
-  c->det_raw_n = in->n;
-  const uint64_t n_new = in->n - in->n_hist;
-  c->det_x = (c8p_c32*)realloc(c->det_x, (size_t)(c->det_commit + n_new + 1) * sizeof(c8p_c32));
-  memcpy(c->det_x + c->det_commit, in->raw + in->n_hist, (size_t)n_new * sizeof(c8p_c32));
-  c->det_n = c->det_commit + n_new;
-  const long N = (long)c->det_n;
+  if (fresh) { free(d->x); d->x = NULL; d->n = d->commit = 0; }   /* a segment from the constructor state */
+  const uint64_t n_new = n - n_hist;
+  d->x = (c8p_c32*)realloc(d->x, (size_t)(d->commit + n_new + 1) * sizeof(c8p_c32));
+  memcpy(d->x + d->commit, raw + n_hist, (size_t)n_new * sizeof(c8p_c32));
+  d->n = d->commit + n_new;
+  const long N = (long)d->n;
   float* ac = (float*)malloc(sizeof(float) * (size_t)(N + 1));
   c8p_c32* cj = (c8p_c32*)malloc(sizeof(c8p_c32) * (size_t)(N + 1));
   uint8_t* tr = (uint8_t*)malloc((size_t)N + 1);
   c8p_sync_evt* ev = (c8p_sync_evt*)malloc(sizeof(c8p_sync_evt) * (size_t)(N / 100 + 16));
-  c8po_presiso(c->det_x, N, ac, cj);
+  c8po_presiso(d->x, N, ac, cj);
   c8po_trigger(ac, N, tr);
-  const long nev = c8po_sync(tr, cj, c->det_x, N, ev, N / 100 + 16, NULL);
-  const uint64_t old = c->det_commit;
-  const uint64_t neu = c->det_n > 400 ? (c->det_n - 400 > old ? c->det_n - 400 : old) : old;
-  free(c->det_evt);
-  c->det_evt = (c8p_sync_evt*)calloc((size_t)nev + 1, sizeof(c8p_sync_evt));
-  c->det_nevt = 0;
-  const uint64_t origin = old - in->n_hist;            /* stream index of raw[0] */
+  const long nev = c8po_sync(tr, cj, d->x, N, ev, N / 100 + 16, NULL);
+  const uint64_t old = d->commit;
+  const uint64_t neu = d->n > 400 ? (d->n - 400 > old ? d->n - 400 : old) : old;
+  *out = (c8p_sync_evt*)realloc(*out, (size_t)(*n_out + nev + 1) * sizeof(c8p_sync_evt));
+  const uint64_t origin = old - n_hist;            /* stream index of raw[0] */
   for (long k = 0; k < nev; k++)
-    if (ev[k].index >= old && ev[k].index < neu) { c->det_evt[c->det_nevt] = ev[k]; c->det_evt[c->det_nevt].index -= origin; c->det_nevt++; }
-  c->det_commit = neu;
-  if (in->commit) *in->commit = neu - origin;
-  if (in->state_out) memset(in->state_out, 0, sizeof(*in->state_out));
+    if (ev[k].index >= old && ev[k].index < neu) { (*out)[*n_out] = ev[k]; (*out)[*n_out].index -= origin; (*n_out)++; }
+  d->commit = neu;
+  if (commit_out) *commit_out = neu - origin;
   free(ac); free(cj); free(tr); free(ev);
+}
+int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
+{
+  c->submits++;
+  c->det_raw = in->raw;
+  c->det_raw_n = in->n;
+  free(c->det_evt); c->det_evt = NULL; c->det_nevt = 0;
+  detect_stream(&c->det, in->raw, in->n, in->n_hist, !in->state && in->n_hist == 0, in->commit, &c->det_evt, &c->det_nevt);
+  if (in->state_out) memset(in->state_out, 0, sizeof(*in->state_out));
   return C8P_OK;
 }
+int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
+{
+  c->submits++;
+  c->det_raw = in->raw;
+  c->det_raw_n = in->n_raw;
+  free(c->det_evt); c->det_evt = NULL; c->det_nevt = 0;
+  if (in->n_streams > c->n_dets) {
+    c->dets = (struct detst*)realloc(c->dets, sizeof(struct detst) * (size_t)in->n_streams);
+    memset(c->dets + c->n_dets, 0, sizeof(struct detst) * (size_t)(in->n_streams - c->n_dets));
+    c->n_dets = in->n_streams;
+  }
+  uint64_t toff = 0;
+  for (int s = 0; s < in->n_streams; s++) {
+    c8p_det_stream* k = &in->streams[s];
+    if (k->off + k->n > in->n_raw || k->n_hist > k->n) return C8P_ERANGE;
+    const int before = c->det_nevt;
+    k->trig_off = toff; toff += (k->n - k->n_hist + 7) & ~(uint64_t)7;
+    if (k->n == k->n_hist) { k->commit = k->n_hist; k->n_evt = 0; continue; }
+    detect_stream(&c->dets[s], in->raw + k->off, k->n, k->n_hist, !k->has_state && k->n_hist == 0, &k->commit, &c->det_evt, &c->det_nevt);
+    k->n_evt = (uint32_t)(c->det_nevt - before);
+    memset(&k->state, 0, sizeof(k->state)); k->has_state = 1;
+  }
+  return C8P_OK;
+}
+int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in) { (void)c; (void)in; return C8P_OK; }
+int64_t c8p_counter(c8p_ctx* c, int which)
+{
+  switch (which) {
+    case C8P_CNT_SLOTS: return SLOTS;
+    case C8P_CNT_SUBMITS: return c->submits;
+    case C8P_CNT_ARENA_GROWTHS: case C8P_CNT_ARENA_BYTES: case C8P_CNT_HOST_BYTES: case C8P_CNT_DET_GIVEUPS: case C8P_CNT_DET_TICKET_SCANS: return 0;
+    default: return C8P_EINVAL;
+  }
+}
+/* caller arenas: "device" memory is the heap here, the copies are immediate */
+void* c8p_dev_alloc(c8p_ctx* c, uint64_t bytes) { (void)c; return calloc(bytes ? bytes : 1, 1); }
+void c8p_dev_free(c8p_ctx* c, void* p) { (void)c; free(p); }
+int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { (void)c; memmove(dst, src, bytes); return C8P_OK; }
+int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* sp, int32_t n)
+{
+  (void)c;
+  for (int i = 0; i < n; i++) memmove(dst + sp[i].dst_off, src + sp[i].src_off, sizeof(c8p_c32) * (size_t)sp[i].n);
+  return C8P_OK;
+}
+int c8p_copy_wait(c8p_ctx* c) { (void)c; return C8P_OK; }
 int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
 
 const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)

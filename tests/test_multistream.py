@@ -1,0 +1,281 @@
+"""K independent raw streams on one GPU (SURVEY.md §8f-1 / f-2 widened to "many independent 20 MHz packet streams"):
+c8p_detect_multi (one k_detect_scan launch over the tiles of every stream), c8p_signal's scan rule per stream, and the live ingest
+of host/c8p_rawchain (push / round / drain) — against c8p_detect per stream, and against the oracle's chain per stream
+(trigger_impl.cc:59-117, sync_impl.cc:62-192, signal_impl.cc:68-204 restated in oracle/)."""
+import numpy as np
+import pytest
+
+from c8p_cases import dewindow
+from c8p_testlib import abi, oracle, oracle_rx, through_channel
+from test_detect_frontend import CFOS, NAMES, SWEEP, burst_stream, near_tie, scan_rule, sig_events, stream
+
+
+def random_stream(seed, n_pkt, snr=(6.0, 35.0)):
+    """one antenna: n_pkt packets of random one-stream formats / MCS, carrier offsets of +-150 kHz, random SNR, gaps from 150 items up"""
+    rng = np.random.default_rng(seed)
+    names = [k for k in SWEEP if int(SWEEP[k]["nss"]) == 1]
+    parts = []
+    for _ in range(n_pkt):
+        d = SWEEP[names[int(rng.integers(len(names)))]]
+        rx = through_channel(np.atleast_2d(dewindow(d["tx"]))[:1], None, float(rng.uniform(*snr)), rng, lead=int(rng.choice([150, 260, 400, 900, 2500])))[0]
+        w = 2 * np.pi * float(rng.uniform(-150e3, 150e3)) / 20e6
+        parts.append((rx * np.exp(1j * w * np.arange(len(rx)))).astype(np.complex64))
+    parts.append((0.004 * (rng.normal(size=700) + 1j * rng.normal(size=700))).astype(np.complex64))
+    return np.concatenate(parts)
+
+
+def lay_out(xs, rng, pad=(0, 5)):
+    """the streams in one arena at offsets that are not multiples of anything (padding of random length between them)"""
+    offs, parts, pos = [], [], 0
+    for x in xs:
+        g = int(rng.integers(pad[0], pad[1] + 1))
+        parts.append((rng.normal(size=g) + 1j * rng.normal(size=g)).astype(np.complex64))     # loud garbage: must never be looked at
+        pos += g
+        offs.append(pos)
+        parts.append(x)
+        pos += len(x)
+    return np.concatenate(parts), offs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tickets", ["0", "1", "2"])
+def test_detect_multi_equals_detect_per_stream_and_the_oracle(tickets, monkeypatch):
+    """seven streams of very different lengths (a long one with plateaus that span tiles, short ones, one shorter than a tile, an empty
+    one, silence) in one arena, one c8p_detect_multi call: per stream the events and trigger bytes of c8p_detect on that stream alone —
+    bit for bit, they run the same arithmetic — and the oracle's events.  With blockIdx numbering, ticket numbering, and the repeat."""
+    from gr_ieee80211_amd import engine
+    monkeypatch.setenv("C8P_DET_TICKETS", tickets)
+    rng = np.random.default_rng(5)
+    xs = [burst_stream(31, n_burst=40), stream(NAMES, CFOS, seed=71)[0], random_stream(72, 12), stream(NAMES[:1], CFOS[:1], seed=73)[0][:1500],
+          np.zeros(0, np.complex64), np.zeros(5000, np.complex64), random_stream(74, 25)]
+    arena, offs = lay_out(xs, rng)
+    eng = engine.Engine(device=0)
+    evs, out = eng.detect_multi(arena, [dict(off=o, n=len(x)) for o, x in zip(offs, xs)])
+    trig_all = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+    assert eng.counter(abi.CNT_DET_TICKET_SCANS) == (0 if tickets == "0" else 1) and eng.counter(abi.CNT_DET_GIVEUPS) == (1 if tickets == "2" else 0)
+    o = oracle()
+    total = 0
+    for s, x in enumerate(xs):
+        e1 = eng.detect(x) if len(x) else np.zeros(0, abi.SYNC_EVT_DT)
+        t1 = eng.fetch(abi.BUF_DET_TRIG, np.uint8) if len(x) else np.zeros(0, np.uint8)
+        assert np.array_equal(evs[s], e1), s
+        assert out[s]["commit"] == len(x) and out[s]["trig_off"] % 8 == 0
+        assert np.array_equal(trig_all[out[s]["trig_off"]:out[s]["trig_off"] + len(x)], t1), s
+        if len(x):
+            ev = o.detect(x)[0]
+            assert np.array_equal(evs[s]["index"], ev["index"]) and np.allclose(evs[s]["rad"], ev["rad"], rtol=0, atol=5e-6), s
+            total += len(ev)
+    assert total >= 60
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_detect_multi_streaming_in_ragged_increments_equals_one_shot_per_stream(seed):
+    """five streams advanced together by c8p_detect_multi in increments of random size per stream and call (also none at all), each
+    stream continuing from ITS commit point and state with DET_HIST items of history: per stream the union of the events and the
+    stitched trigger bytes equal one c8p_detect over the whole stream — plateaus, countdowns and search windows that straddle the calls
+    of one stream never see another stream's items or state"""
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(100 + seed)
+    xs = [burst_stream(40 + seed, n_burst=30), random_stream(50 + seed, 20), stream(NAMES, CFOS, seed=60 + seed)[0], burst_stream(70 + seed, n_burst=10),
+          random_stream(80 + seed, 8)]
+    K = len(xs)
+    eng = engine.Engine(device=0)
+    one = [eng.detect(x) for x in xs]
+    one_trig = []
+    for x in xs:
+        eng.detect(x)
+        one_trig.append(eng.fetch(abi.BUF_DET_TRIG, np.uint8))
+    end, commit, state = [0] * K, [0] * K, [None] * K
+    got = [[] for _ in range(K)]
+    gtrig = [np.zeros(len(x), np.uint8) for x in xs]
+    ncall = 0
+    while any(e < len(x) for e, x in zip(end, xs)):
+        parts, streams, h0s, pos = [], [], [], 0
+        for s, x in enumerate(xs):
+            step = int(rng.choice([0, 97, 700, 1984, 1985, 5000, 12000]))
+            end[s] = min(len(x), end[s] + step)
+            h0 = max(0, commit[s] - abi.DET_HIST)
+            g = int(rng.integers(0, 4))
+            parts.append(np.full(g, 3 + 3j, np.complex64)); pos += g
+            streams.append(dict(off=pos, n=end[s] - h0, n_hist=commit[s] - h0, state=state[s]))
+            parts.append(x[h0:end[s]]); pos += end[s] - h0
+            h0s.append(h0)
+        arena = np.concatenate(parts + [np.zeros(1, np.complex64)])
+        evs, out = eng.detect_multi(arena, streams)
+        tb = eng.fetch(abi.BUF_DET_TRIG, np.uint8)
+        for s in range(K):
+            new_commit = h0s[s] + out[s]["commit"]
+            assert commit[s] <= new_commit <= end[s], (s, commit[s], new_commit, end[s])
+            gtrig[s][commit[s]:new_commit] = tb[out[s]["trig_off"]:out[s]["trig_off"] + new_commit - commit[s]]
+            for k in evs[s]:
+                got[s].append((int(k["index"]) + h0s[s], float(k["rad"]), float(k["snr"]), float(k["rssi"])))
+            commit[s] = new_commit
+            if streams[s]["n"] > streams[s]["n_hist"] or state[s] is not None:
+                state[s] = out[s]["state"]
+        ncall += 1
+    o = oracle()
+    for s, x in enumerate(xs):
+        assert [g[0] for g in got[s]] == [int(k["index"]) for k in one[s]], s
+        for j, f in enumerate(("rad", "snr", "rssi")):
+            assert np.array_equal(np.array([g[1 + j] for g in got[s]], np.float32), one[s][f]), (s, f)
+        c = commit[s]
+        assert c >= len(x) - 400
+        assert np.array_equal(gtrig[s][:c] & 1, one_trig[s][:c] & 1)
+        ac = o.detect(x)[1]
+        bad = np.nonzero((gtrig[s][:c] & 2) != (one_trig[s][:c] & 2))[0]
+        assert len(bad) <= 3 and all(near_tie(ac, i) for i in bad), (s, bad[:10])
+    print("seed %d: %d calls" % (seed, ncall))
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_signal_scan_rule_per_stream():
+    """c8p_signal_in.n_streams = 3: the flags of three streams in one call (one arena), the scan rule applied inside each stream from
+    that stream's position: per stream the descriptors and codes of a single-stream call over that stream's flags; kept packets back
+    to back in stream order; flags out of stream order are refused"""
+    from gr_ieee80211_amd import engine
+    eng = engine.Engine(device=0)
+    rng = np.random.default_rng(9)
+    xs = [np.concatenate([burst_stream(13, n_burst=10), stream(NAMES, CFOS, seed=21)[0]]), stream(NAMES[::-1], CFOS, seed=22)[0], random_stream(23, 15)]
+    arena, offs = lay_out(xs, rng, pad=(3, 40))
+    scan0 = [0, 3000, 0]
+    evts, single = [], []
+    for s, x in enumerate(xs):
+        ev = eng.detect(x)
+        q = sig_events(ev, len(x))
+        q["n_avail"] = np.minimum(q["n_avail"], 224 + 109280)
+        if s == 2:
+            q["n_avail"][-3:] = np.minimum(q["n_avail"][-3:], 300)       # the last packets of this stream wait for more items
+        pk1 = eng.signal(q, x, consume=True, scan_from=scan0[s])
+        single.append((q, pk1, int(eng.scan_next[0]), eng.fetch(abi.BUF_SIG_IQ, np.complex64)))
+        g = q.copy()
+        g["raw_off"][:, 0] += offs[s]
+        g["stream"] = s
+        evts.append(g)
+    allq = np.concatenate(evts)
+    pk = eng.signal(allq, arena, consume=True, n_streams=3, scan_from=[offs[s] + scan0[s] for s in range(3)])
+    iq = eng.fetch(abi.BUF_SIG_IQ, np.complex64)
+    nxt = eng.scan_next.copy()
+    k, used = 0, 0
+    for s, (q, pk1, nx, iq1) in enumerate(single):
+        mine = pk[k:k + len(q)]
+        for f in ("n_items", "lsig_mcs", "lsig_len", "lsig_nsamp", "cfo", "snr", "rssi"):
+            assert np.array_equal(mine[f], pk1[f]), (s, f)
+        assert np.array_equal(mine["rsv"][:, 0], pk1["rsv"][:, 0]), s
+        assert int(nxt[s]) == offs[s] + nx, s
+        kept = np.nonzero(mine["n_items"])[0]
+        assert len(kept) >= 5
+        for i in kept:
+            n = int(mine[i]["n_items"])
+            assert int(mine[i]["iq_off"][0]) == used
+            assert np.array_equal(iq[used:used + n], iq1[int(pk1[i]["iq_off"][0]):int(pk1[i]["iq_off"][0]) + n]), (s, i)
+            used += n
+        k += len(q)
+    assert np.isin(pk[k - 3:]["rsv"][:, 0], (abi.SIG_NEED_MORE, abi.SIG_PENDING)).any()      # (stream 2's last flags wait for more items)
+    with pytest.raises(RuntimeError, match="grouped by stream"):
+        eng.signal(allq[::-1].copy(), arena, consume=True, n_streams=3)
+    eng.close()
+
+
+def oracle_chain(o, x):
+    """the oracle's chain over one whole stream: (kept descriptors, their sync indices, per-packet oracle results)"""
+    ev = o.detect(x)[0]
+    s = sig_events(ev, len(x))
+    s["n_avail"] = np.minimum(s["n_avail"], 224 + 109280)
+    pk, iq, chan = o.signal_events(s, x)
+    kept, code = scan_rule(s, pk)
+    return pk[kept], [int(ev[i]["index"]) for i in kept], oracle_rx(pk[kept], iq, chan), len(ev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feed", ["host", "device"])
+def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain_per_stream(feed):
+    """K = 8 random streams (every one-stream format / MCS, carrier offsets of +-150 kHz, SNRs from 6 to 35 dB so that many fail
+    their FCS, gaps from 150 items up so that some preambles are missed or merged; one stream is silence, one starts late) pushed in
+    increments of random size per stream and round — rounds end inside preambles, inside packets, inside plateaus — through the live
+    ingest of host/c8p_rawchain (one c8p_detect_multi, one c8p_signal, one c8p_rx per round) and through the oracle's detect -> signal
+    (+ scan rule) -> demod + decode over each whole stream: per stream, in order, the same kept packets (sync index, L-SIG fields), the
+    same PDUs and FCS-failure counts."""
+    import torch
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    o = oracle()
+    rng = np.random.default_rng(77)
+    xs = [random_stream(200 + s, n) for s, n in enumerate([60, 45, 70, 30, 55, 40, 25])]
+    xs.insert(3, (0.004 * (rng.normal(size=90000) + 1j * rng.normal(size=90000))).astype(np.complex64))
+    K = len(xs)
+    late = 5                                            # this stream delivers nothing during the first rounds
+    ts = [torch.from_numpy(x.view(np.float32).copy()) for x in xs]
+    ts = [t.pin_memory() if feed == "host" else t.to(dev) for t in ts]
+    torch.cuda.synchronize()
+    got = []
+    h = blocks.RawChain(streams=K, stream_round_items=40000, reserve_seg_packets=64, reserve_pkt_items=6000)
+    h.live(got.append)
+    pos = [0] * K
+    r = 0
+    while any(p < len(x) for p, x in zip(pos, xs)):
+        for s, x in enumerate(xs):
+            n = int(rng.choice([0, 137, 2500, 9000, 20000, 39999]))
+            if s == late and r < 4:
+                n = 0
+            n = min(n, len(x) - pos[s])
+            if n:
+                h.push(s, (ts[s].data_ptr() + 8 * pos[s], n), host=(feed == "host"))
+                pos[s] += n
+        h.round()
+        r += 1
+    st = h.drain()
+    h.close()
+    assert st["segments"] == r == len(got) and st["items"] == sum(len(x) for x in xs) and st["det_giveups"] == 0
+    per = [dict(pk=[], idx=[], outs=[], recs=[]) for _ in range(K)]
+    for g in got:
+        assert np.all(np.diff(g["pkt_stream"].astype(np.int64)) >= 0)
+        for i in range(len(g["pkts"])):
+            P = per[int(g["pkt_stream"][i])]
+            oo = g["outs"][i]
+            P["pk"].append(g["pkts"][i]); P["idx"].append(int(g["pkt_index"][i])); P["outs"].append(oo)
+            P["recs"].append(g["pdu_arena"][int(oo["pdu_off"]):int(oo["pdu_off"]) + int(oo["pdu_bytes"])].tobytes())
+    n_pdu = n_fail = n_ev = 0
+    for s, x in enumerate(xs):
+        pk, idx, ref, nev = oracle_chain(o, x)
+        n_ev += nev
+        P = per[s]
+        assert P["idx"] == idx, s
+        for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "n_items", "n_ant"):
+            assert [int(p[f]) for p in P["pk"]] == [int(v) for v in pk[f]], (s, f)
+        assert np.allclose([float(p["cfo"]) for p in P["pk"]], pk["cfo"], rtol=0, atol=0.5)
+        for i, (rr, oo, rec) in enumerate(zip(ref, P["outs"], P["recs"])):
+            assert int(oo["n_pdu"]) == len(rr["pdus"]) and int(oo["n_crc_fail"]) == int(rr["out"]["n_crc_fail"]), (s, i)
+            for p in rr["pdus"]:
+                assert int.from_bytes(rec[:2], "little") == len(p) and rec[2:2 + len(p)] == p, (s, i)
+                rec = rec[2 + len(p):]
+            n_pdu += len(rr["pdus"]); n_fail += int(rr["out"]["n_crc_fail"])
+    assert st["pdus"] == n_pdu >= 150 and n_fail >= 30 and st["events"] == n_ev, (n_pdu, n_fail, n_ev, st)
+
+
+@pytest.mark.gpu
+def test_rawchain_handle_reserved_once_never_allocates_again():
+    """a handle with reserved arenas: no device / pinned allocation inside any run (c8p_rawchain_stats.arena_growths, from the engine's
+    own counters), the first run included; the same results from every run; per-stage clocks and marks are there"""
+    import torch
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    xs = [stream(NAMES, CFOS, seed=300 + i)[0] for i in range(6)]
+    ts = [torch.from_numpy(x.view(np.float32).copy()).to(dev) for x in xs]
+    pins = [torch.from_numpy(x.view(np.float32).copy()).pin_memory() for x in xs]
+    torch.cuda.synchronize()
+    h = blocks.RawChain(reserve_seg_items=max(len(x) for x in xs), reserve_seg_packets=16, reserve_pkt_items=2000, reserve_host=True)
+    first = None
+    for rep in range(3):
+        got = []
+        host = rep == 2
+        st = h.run([(t.data_ptr(), len(x)) for t, x in zip(pins if host else ts, xs)], on_segment=got.append, host=host)
+        assert st["arena_growths"] == 0, (rep, st)
+        assert st["segments"] == 6 and st["pdus"] == 6 * len(NAMES)
+        sig = [(g["segment"], g["pkts"]["lsig_len"].tolist(), g["outs"]["n_pdu"].tolist(), g["pdu_arena"][:int(g["outs"]["pdu_off"][-1])].tobytes()) for g in got]
+        first = first or sig
+        assert sig == first
+        assert len(h.timeline()) == 6 and st["rx"]["busy"] > 0 and st["steady_segments"] == 5
+    h.close()

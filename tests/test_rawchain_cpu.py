@@ -78,10 +78,124 @@ def test_rawchain_reports_errors_instead_of_hanging():
     x = with_tail(stream(NAMES[:2], CFOS[:2], seed=90)[0])
     seg = (blocks._RawSeg * 1)(blocks._RawSeg(x.ctypes.data, len(x), 0, 1, 0))
     st, err = blocks._RawStats(), C.create_string_buffer(256)
-    rc = L.c8p_rawchain_run(os.path.join(ROOT, "does", "not", "exist.so").encode(), 0, seg, 1, None, None, C.byref(st), err, len(err))
+    rc = L.c8p_rawchain_run_once(os.path.join(ROOT, "does", "not", "exist.so").encode(), 0, seg, 1, None, None, C.byref(st), err, len(err))
     assert rc != 0 and b"exist.so" in err.value
+    with pytest.raises(RuntimeError, match="exist.so"):
+        blocks.RawChain(engine_lib=os.path.join(ROOT, "does", "not", "exist.so"))
+    cfg = blocks._RawCfg(4, 0, FAKE.encode())                                             # a caller built against another struct layout
+    assert not L.c8p_rawchain_create(C.byref(cfg), err, len(err)) and b"struct_size" in err.value
     bad = (blocks._RawSeg * 1)(blocks._RawSeg(x.ctypes.data, len(x), 7, 0, 0))           # host items with a second antenna: refused
-    rc = L.c8p_rawchain_run(FAKE.encode(), 0, bad, 1, None, None, C.byref(st), err, len(err))
+    rc = L.c8p_rawchain_run_once(FAKE.encode(), 0, bad, 1, None, None, C.byref(st), err, len(err))
     assert rc != 0 and b"host segments" in err.value
-    rc = L.c8p_rawchain_stream(FAKE.encode(), 0, x.ctypes.data, len(x), 0, 16, None, None, C.byref(st), err, len(err))   # segments shorter than the history
+    rc = L.c8p_rawchain_stream_once(FAKE.encode(), 0, x.ctypes.data, len(x), 0, 16, None, None, C.byref(st), err, len(err))   # segments shorter than the history
     assert rc != 0
+    h = blocks.RawChain(engine_lib=FAKE)                                                  # no live streams configured
+    with pytest.raises(RuntimeError, match="without live streams"):
+        h.push(0, x)
+    h.close()
+
+
+def test_rawchain_handle_is_reused_and_its_stats_say_where_the_time_went():
+    """one handle, several runs: the contexts outlive a run; the stats carry per-stage clocks, the first-segment and steady-state
+    figures, and the timeline has one mark per segment in stage order"""
+    xs = [with_tail(stream(NAMES[:4], CFOS[:4], snr=33.0, seed=40 + i)[0], i) for i in range(9)]
+    segs = [(x.ctypes.data, len(x)) for x in xs]
+    h = blocks.RawChain(engine_lib=FAKE, reserve_seg_items=max(len(x) for x in xs), reserve_seg_packets=8, reserve_pkt_items=5000)
+    for rep in range(2):
+        got = []
+        st = h.run(segs, on_segment=got.append)
+        assert st["segments"] == 9 and st["pdus"] == 36 and [g["segment"] for g in got] == list(range(9))
+        assert st["steady_segments"] == 5 and st["steady_pdus"] == 20 and 0 < st["steady_s"] < st["seconds"]
+        assert 0 < st["first_segment_s"] <= st["seconds"] and st["arena_growths"] == 0 and st["det_giveups"] == 0
+        for k in ("detect", "signal", "rx"):
+            assert st[k]["busy"] > 0 and st[k]["busy"] + st[k]["wait_in"] + st[k]["wait_out"] <= st["seconds"] * 1.01
+        tl = h.timeline()
+        assert len(tl) == 9
+        for m in tl:
+            assert 0 <= m["det_begin"] <= m["det_end"] <= m["sig_begin"] <= m["sig_end"] <= m["rx_submit"] <= m["rx_done"] <= st["seconds"]
+        assert all(a["rx_done"] <= b["rx_done"] for a, b in zip(tl, tl[1:]))
+        for g in got:
+            assert np.array_equal(g["pkt_stream"], np.zeros(4, np.uint32)) and np.all(np.diff(g["pkt_index"].astype(np.int64)) > 0)
+    h.close()
+
+
+def chain_pdus(x):
+    """one pass of the chain over a whole stream (one-shot handle, fake backend): (pdus, sync-flag indices of the kept packets)"""
+    got = []
+    blocks.rawchain_run([(x.ctypes.data, len(x))], engine_lib=FAKE, on_segment=got.append)
+    return pdus_of(got[0]), [int(i) for i in got[0]["pkt_index"]]
+
+
+@pytest.mark.parametrize("chunks", ["even", "ragged", "ragged-short-carry"])
+def test_rawchain_live_streams_pushed_in_increments_equal_one_pass_per_stream(chunks, monkeypatch):
+    """K = 4 independent streams fed in increments (even: 6000 items per round; ragged: random sizes incl. empty ones, so that rounds
+    end inside preambles, inside packets and inside idle air): per stream, in order, the packets and PDUs of one pass over that stream.
+    short-carry: only the last 2600 items of a stream go into the next round (the packets here are at most 1600 + 224 items long), so
+    the arenas' origins move along the streams as they do after the first 110 000 items of a real one"""
+    short = chunks.endswith("short-carry")
+    if short:       # (no random bursts then: one of them may carry a valid L-SIG that claims a packet longer than this carry)
+        monkeypatch.setenv("C8P_RAWCHAIN_KEEP", "2600")
+        chunks = "ragged"
+    rng = np.random.default_rng(7 if chunks == "even" else 8)
+    orders = [NAMES, NAMES[::-1], NAMES[2:7], []]
+    xs = []
+    for i, nm in enumerate(orders):
+        parts = [stream(nm, CFOS[:len(nm)], snr=33.0, seed=120 + i)[0]] if nm else []
+        if i == 1 and not short:
+            parts.insert(0, burst_stream(21, n_burst=6))
+        if i == 2:
+            parts.append(stream(NAMES[:3], CFOS[:3], snr=33.0, seed=131)[0])
+        parts.append(0.004 * (rng.normal(size=3000) + 1j * rng.normal(size=3000)))
+        xs.append(np.concatenate(parts).astype(np.complex64))
+    want = [chain_pdus(x) for x in xs]
+    got = []
+    h = blocks.RawChain(engine_lib=FAKE, streams=4, stream_round_items=20000)
+    h.live(got.append)
+    pos = [0] * 4
+    while any(p < len(x) for p, x in zip(pos, xs)):
+        for s, x in enumerate(xs):
+            n = 6000 if chunks == "even" else int(rng.choice([0, 0, 137, 2500, 9000, 19999]))
+            n = min(n, len(x) - pos[s])
+            if n:
+                h.push(s, x[pos[s]:pos[s] + n])
+                pos[s] += n
+        h.round()
+    st = h.drain()
+    assert [g["segment"] for g in got] == list(range(len(got))) and st["segments"] == len(got) and st["items"] == sum(len(x) for x in xs)
+    per = [([], []) for _ in range(4)]
+    for g in got:
+        assert np.all(np.diff(g["pkt_stream"].astype(np.int64)) >= 0)
+        recs = pdus_of(g)
+        assert len(recs) == int(g["outs"]["n_pdu"].sum())
+        k = 0
+        for i in range(len(g["pkts"])):
+            s = int(g["pkt_stream"][i])
+            per[s][1].append(int(g["pkt_index"][i]))
+            for _ in range(int(g["outs"]["n_pdu"][i])):
+                per[s][0].append(recs[k]); k += 1
+    for s in range(4):
+        assert per[s][0] == want[s][0], s
+        assert per[s][1] == want[s][1], s
+    assert sum(len(w[0]) for w in want) == st["pdus"] >= 20
+    # the handle starts another session from the constructor state
+    got2 = []
+    h.live(got2.append)
+    half = len(xs[0]) // 2
+    h.push(0, xs[0][:half]); h.round()
+    h.push(0, xs[0][half:]); h.round()
+    st2 = h.drain()
+    assert st2["pdus"] == len(want[0][0]) and [p for g in got2 for p in pdus_of(g)] == want[0][0]
+    h.close()
+
+
+def test_rawchain_live_refuses_more_than_a_round_holds():
+    h = blocks.RawChain(engine_lib=FAKE, streams=2, stream_round_items=4096)
+    x = np.zeros(5000, np.complex64)
+    h.push(1, x[:4096])
+    with pytest.raises(RuntimeError, match="stream_round_items"):
+        for _ in range(40):
+            h.push(1, x)
+    with pytest.raises(RuntimeError, match="no such stream"):
+        h.push(2, x[:10])
+    h.drain()
+    h.close()
