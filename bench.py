@@ -953,7 +953,8 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
                    "whole-run figures beside it; compare `value` (the same packets handed over at the demod boundary)"}
     h = None
     try:
-        h = blocks.RawChain(device=local, reserve_seg_items=n, reserve_seg_events=reps + reps // 8 + 64, reserve_seg_packets=reps + 64,
+        # (this stream raises two sync flags per packet: the second falls inside the packet and the scan rule skips it)
+        h = blocks.RawChain(device=local, reserve_seg_items=n, reserve_seg_events=2 * reps + reps // 4 + 64, reserve_seg_packets=reps + 64,
                             reserve_pkt_items=unit_len, reserve_host=True)
         segs = [(arr.ptr, n)] * segments
         warm = h.run(segs[:4])                                                # untimed, the same handle: streams, clocks
@@ -998,7 +999,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     if pin is None:
         raise RuntimeError("no pinned capture")
     per_round_pk = streams * (round_items // unit_len + 2)
-    h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=per_round_pk + per_round_pk // 8,
+    h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
                         reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len)
     pdus = [0]
 

@@ -227,9 +227,12 @@ struct c8p_ctx {
   Buf d_spans; void* h_spans = nullptr; size_t h_spans_cap = 0;
 };
 
-static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
+static bool grow_log() { static const bool on = getenv("C8P_GROW_LOG") != nullptr; return on; }
+#define ensure(c, b, bytes) ensure_named(c, b, bytes, #b)
+static int ensure_named(c8p_ctx* c, Buf& b, size_t bytes, const char* name)
 {
   if (bytes <= b.cap) return C8P_OK;
+  if (grow_log()) fprintf(stderr, "[c8p grow] ctx %p submit %u: %s %zu -> %zu bytes\n", (void*)c, c->seq, name, b.cap, bytes);
   if (b.p) { HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; c->dev_bytes -= (int64_t)b.cap; b.cap = 0; }
   size_t want = bytes + bytes / 4 + 4096;
   hipError_t e = hipMalloc(&b.p, want);
@@ -241,6 +244,7 @@ static int ensure(c8p_ctx* c, Buf& b, size_t bytes)
 static int ensure_host(c8p_ctx* c, size_t bytes)
 {
   if (bytes <= c->s->h_stage_cap) return C8P_OK;
+  if (grow_log()) fprintf(stderr, "[c8p grow] ctx %p submit %u: pinned staging %zu -> %zu bytes\n", (void*)c, c->seq, c->s->h_stage_cap, bytes);
   if (c->s->h_stage) {
     HIPCHK(c, hipStreamSynchronize(c->s->stream)); HIPCHK(c, hipHostFree(c->s->h_stage));
     c->s->h_stage = nullptr; c->host_bytes -= (int64_t)c->s->h_stage_cap; c->s->h_stage_cap = 0;
@@ -1071,7 +1075,9 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
       KTimer kt(c, C8P_K_SYNCEVT);
       hipLaunchKernelGGL(k_sync_mark, dim3(NJ), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_ds,
                          (SyncMark*)S.d_det_mark.p, NJ);
-      if (NJ > K || !multi)      // (at least one trigger somewhere; kind = 1 jobs return at once)
+      int n_trig = 0;
+      for (const DetHost& H : hs) if (H.nj > 0) n_trig += H.nj;
+      if (n_trig > 0 || !multi)  // (at least one trigger somewhere; kind = 1 jobs return at once)
         hipLaunchKernelGGL(k_sync_evt, dim3(NJ), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const SyncMark*)S.d_det_mark.p, d_ds,
                            (c8p_sync_evt*)S.d_det_evt.p, (int*)S.d_det_valid.p, NJ);
       else
@@ -1143,9 +1149,10 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
   lap("compaction + state");
   drain_events(c);     // (the compacted events' upload may still be in flight: c8p_fetch / the next submit order behind it)
   S.used[C8P_BUF_DET_EVT] = sizeof(c8p_sync_evt) * evts.size(); S.ptr[C8P_BUF_DET_EVT] = S.d_det_evt.p;
-  S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * out_items : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
-  S.used[C8P_BUF_DET_TRIG] = out_items; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
-  S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * out_items : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
+  const uint64_t out_used = multi ? out_items : hs[0].n;      // (one stream: exactly its new items)
+  S.used[C8P_BUF_DET_AC] = keep ? sizeof(float) * out_used : 0; S.ptr[C8P_BUF_DET_AC] = S.d_det_ac.p;
+  S.used[C8P_BUF_DET_TRIG] = out_used; S.ptr[C8P_BUF_DET_TRIG] = S.d_det_trig.p;
+  S.used[C8P_BUF_DET_CONJ] = keep ? sizeof(cf) * out_used : 0; S.ptr[C8P_BUF_DET_CONJ] = S.d_det_conj.p;
   return C8P_OK;
 }
 

@@ -56,10 +56,11 @@ def test_detect_multi_equals_detect_per_stream_and_the_oracle(tickets, monkeypat
     o = oracle()
     total = 0
     for s, x in enumerate(xs):
-        e1 = eng.detect(x) if len(x) else np.zeros(0, abi.SYNC_EVT_DT)
+        e1, st1, c1 = eng.detect(x, stream=True) if len(x) else (np.zeros(0, abi.SYNC_EVT_DT), abi.DetState(), 0)
         t1 = eng.fetch(abi.BUF_DET_TRIG, np.uint8) if len(x) else np.zeros(0, np.uint8)
         assert np.array_equal(evs[s], e1), s
-        assert out[s]["commit"] == len(x) and out[s]["trig_off"] % 8 == 0
+        assert out[s]["commit"] == c1 and out[s]["trig_off"] % 8 == 0, (s, out[s]["commit"], c1)
+        assert bytes(out[s]["state"]) == bytes(st1), s
         assert np.array_equal(trig_all[out[s]["trig_off"]:out[s]["trig_off"] + len(x)], t1), s
         if len(x):
             ev = o.detect(x)[0]
@@ -262,7 +263,7 @@ def test_rawchain_handle_reserved_once_never_allocates_again():
     import torch
     from gr_ieee80211_amd import blocks
     dev = torch.device("cuda:0")
-    xs = [stream(NAMES, CFOS, seed=300 + i)[0] for i in range(6)]
+    xs = [stream(NAMES, CFOS, snr=33.0, seed=300 + i)[0] for i in range(6)]
     ts = [torch.from_numpy(x.view(np.float32).copy()).to(dev) for x in xs]
     pins = [torch.from_numpy(x.view(np.float32).copy()).pin_memory() for x in xs]
     torch.cuda.synchronize()
