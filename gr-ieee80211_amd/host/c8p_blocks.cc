@@ -205,7 +205,10 @@ public:
     d_cv.notify_all();
     if (d_th.joinable()) d_th.join();
   }
-  void poke() { d_cv.notify_one(); }         // (the front's state changed: a deadline may have appeared; caller holds the mutex or not)
+  // the front's state changed and a deadline may have appeared: wake the timer if it sleeps WITHOUT one.  The caller holds the
+  // front's mutex, as the timer does whenever it looks at d_idle: no wake-up is lost (the round-3 version remembered "was pending"
+  // on the scheduler's side only — the timer drained a burst, slept without a deadline, and the next burst did not wake it)
+  void poke() { if (d_idle) d_cv.notify_one(); }
   std::string error;                          // an engine error met on the timer thread is reported by the next general_work
 private:
   void loop()
@@ -213,7 +216,7 @@ private:
     std::unique_lock<std::mutex> lk(d_mu);
     while (!d_quit) {
       tick_t when;
-      if (!d_due(when)) { d_cv.wait(lk); continue; }
+      if (!d_due(when)) { d_idle = true; d_cv.wait(lk); d_idle = false; continue; }
       if (now_tick() < when) { d_cv.wait_until(lk, when); continue; }
       try { d_fire(); } catch (const std::exception& e) { error = e.what(); return; }
     }
@@ -224,6 +227,7 @@ private:
   std::condition_variable d_cv;
   std::thread d_th;
   bool d_quit = false;
+  bool d_idle = false;                        // asleep with no deadline to wait for
 };
 
 class engine_holder
@@ -337,8 +341,7 @@ public:
     d_io->consume_each(used);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     const bool pending = !d_st[d_fill].pk.empty() || d_st[d_fill ^ 1].ticket != 0;
-    if (pending && !d_was_pending) d_timer.poke();
-    d_was_pending = pending;
+    if (pending) d_timer.poke();
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
@@ -569,7 +572,6 @@ private:
   size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;
   std::deque<out_pkt> d_outq;
   std::vector<long> d_fused_ids;                   // handles this front parked in g_fused (the last 64k-128k of them)
-  bool d_was_pending = false;
   latency_timer d_timer;                           // last member: its thread uses everything above
 };
 
@@ -904,8 +906,7 @@ public:
     if (d_eng.d_cfg.flush_when_idle) age_check();
     d_io->consume_each(std::min(used, nproc));
     const bool pending = !d_st[d_fill].tags.empty() || d_st[d_fill ^ 1].ticket != 0;
-    if (pending && !d_was_pending) d_timer.poke();
-    d_was_pending = pending;
+    if (pending) d_timer.poke();
     return 0;
   }
 
@@ -1084,7 +1085,6 @@ private:
   int d_fill = 0;
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
   size_t d_hwm_pdu = 0;
-  bool d_was_pending = false;
   latency_timer d_timer;                           // last member: its thread uses everything above
 };
 

@@ -6,15 +6,30 @@ from c8p_testlib import abi, oracle_rx
 from gr_ieee80211_amd import engine
 
 
+def close_or_both_nan(a, b, tol):
+    a, b = float(a), float(b)
+    return (np.isnan(a) and np.isnan(b)) or abs(a - b) < tol
+
+
 def compare(res, ref, llr_tol=1e-5):
+    """one batch's results against the oracle's, packet by packet: status; the whole tag set of demod_impl.cc:224-253 /
+    demod2_impl.cc:230-250 — format, mcs, len, cr, ampdu, trellis, total (+ nsym, nss, is_ndp), the pass-through tags cfo / snr /
+    rssi / seq bit for bit, sssnr0 and sssnr1 (demod_impl.cc:393-410, demod2_impl.cc:632-758) within 1e-4 dB; the NDP's
+    "mu2x1chan" capture (128 complex64) bit for bit — it is a copy of input items; the LLR stream within llr_tol where it is in
+    memory; the PDUs byte for byte"""
     n_pdu = 0
     for p, (g, o) in enumerate(zip(res, ref)):
         assert g["tags"]["status"] == o["tags"]["status"], p
         if o["tags"]["status"] != abi.ST_OK:
             continue
-        for k in abi.TAG_KEYS + ("nsym", "nss", "is_ndp"):
+        for k in abi.TAG_KEYS + ("nsym", "nss", "is_ndp", "seq"):
             assert g["tags"][k] == o["tags"][k], (p, k)
-        assert abs(float(g["tags"]["sssnr0"]) - float(o["tags"]["sssnr0"])) < 1e-4, p
+        for k in ("cfo", "snr", "rssi"):
+            assert np.float32(g["tags"][k]).tobytes() == np.float32(o["tags"][k]).tobytes(), (p, k, g["tags"][k], o["tags"][k])
+        for k in ("sssnr0", "sssnr1"):
+            assert close_or_both_nan(g["tags"][k], o["tags"][k], 1e-4), (p, k, float(g["tags"][k]), float(o["tags"][k]))
+        if o["tags"]["is_ndp"] and "mu" in g:
+            assert np.array_equal(np.asarray(g["mu"], np.complex64).view(np.uint32), np.asarray(o["mu"], np.complex64).view(np.uint32)), p
         if "llr" in g:          # c8p_rx only leaves the LLR stream in memory when c8p_cfg.keep_llr is set (c8p_demod always does)
             assert len(g["llr"]) == len(o["llr"]), p
             if len(o["llr"]):

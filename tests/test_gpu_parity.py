@@ -11,7 +11,7 @@ import pytest
 
 from c8p_cases import ampdu_vht, cfg2_batch, dewindow, replicated_batch, sweep_batch
 from c8p_testlib import H22, load_npz, through_channel
-from c8p_smoke import compare
+from c8p_smoke import close_or_both_nan, compare
 from c8p_testlib import GOLD, Batch, abi, oracle, oracle_rx
 from gr_ieee80211_amd import engine
 
@@ -842,8 +842,13 @@ def test_soak_full_size_batches_against_the_oracle_on_all_cores():
             stride = len(pdu_o) // max(len(t_o), 1)
             for j in range(len(t_o)):
                 assert tags[p]["status"] == t_o[j]["status"], (kind, snr, p)
-                for key in abi.TAG_KEYS + ("nsym", "nss"):
+                for key in abi.TAG_KEYS + ("nsym", "nss", "seq"):
                     assert tags[p][key] == t_o[j][key], (kind, snr, p, key)
+                if t_o[j]["status"] == abi.ST_OK:
+                    for key in ("sssnr0", "sssnr1"):
+                        assert close_or_both_nan(tags[p][key], t_o[j][key], 1e-4), (kind, snr, p, key, float(tags[p][key]), float(t_o[j][key]))
+                    for key in ("cfo", "snr", "rssi"):
+                        assert np.float32(tags[p][key]).tobytes() == np.float32(t_o[j][key]).tobytes(), (kind, snr, p, key)
                 assert outs[p]["n_pdu"] == o_o[j]["n_pdu"] and outs[p]["n_crc_fail"] == o_o[j]["n_crc_fail"], (kind, snr, p)
                 nb = int(o_o[j]["pdu_bytes"])
                 assert int(outs[p]["pdu_bytes"]) == nb, (kind, snr, p)

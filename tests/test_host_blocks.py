@@ -487,6 +487,52 @@ def test_chain_with_a_single_engine_slot_on_gpu(monkeypatch):
         dem.close(); dec.close()
 
 
+@pytest.mark.parametrize("kind", ["demod", "demod_fused", "decode"])
+def test_a_second_burst_after_an_idle_gap_comes_out_too(kind):
+    """two bursts separated by far more than max_wait_us, no dry call, no flush: the latency timer drains the first burst, goes to
+    sleep without a deadline, and must be woken by the second burst's first general_work call (round 3 remembered "something was
+    pending" on the scheduler's side only: the partial batch of the second burst then stayed in the front until a third one came)"""
+    import time
+    b, _ = sweep_batch(snr_db=None, seed=2)
+    pk, iq, chan = split(b, 1)
+    bursts = [pk[:3], pk[3:7]]
+    ref = [oracle_rx(q, iq, chan) for q in bursts]
+    if kind == "decode":
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=256)
+        pos, want = 0, []
+        for r in ref:
+            for q in r:
+                if q["tags"]["status"] != 0:
+                    continue
+                t = q["tags"]
+                for key in abi.TAG_KEYS:
+                    dec.push_tag(pos, key, int(t[key]))
+                for key in ("cfo", "snr", "rssi"):
+                    dec.push_tag(pos, key, float(t[key]))
+                dec.push_tag(pos, "seq", int(t["seq"]))
+                dec.push_items(0, q["llr"])
+                pos += len(q["llr"])
+                want += [(len(x), x) for x in q["pdus"]]
+            dec.run_live(chunk=2048, nout=4096, linger_ms=60)
+            assert dec.messages() == want                    # this burst's PDUs are out before the next burst arrives
+            time.sleep(0.05)
+        assert len(want) >= 5
+        dec.close()
+        return
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=256, fused=(kind == "demod_fused"))
+    pushed = n_llr = n_tagged = 0
+    for q, r in zip(bursts, ref):
+        pushed += blocks.feed_demod(dem, q, iq, chan, base=pushed)
+        dem.run_live(chunk=1024, nout=4096, linger_ms=60)
+        n_llr += sum(len(x["llr"]) for x in r if x["tags"]["status"] == 0)
+        n_tagged += sum(1 for x in r if x["tags"]["status"] == 0)
+        assert len(dem.output()) == n_llr                       # all of this burst's items are out although nothing else arrived
+        assert sum(1 for _, k, _ in dem.tags() if k == "trellis") == n_tagged
+        time.sleep(0.05)
+    assert n_tagged >= 5
+    dem.close()
+
+
 def test_a_burst_comes_out_in_fused_mode_without_further_input():
     """the latency timer in fused mode (demod runs c8p_rx, decode publishes behind the handle tag): a 3-packet burst, no dry call, no flush"""
     b, _ = sweep_batch(snr_db=None, seed=2)
