@@ -545,6 +545,10 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
 
         def __init__(self, n, which, t0):
             self.bases, self.base, self.n, self.w, self.t0, self.tickets = [], 0, n, which, t0, []
+            # this set was last read by the all_gather of two steps ago, which runs on RCCL's stream: wait for it before the engine's
+            # streams write the set again (the host-side slot-reuse sync orders the engine's own work only)
+            if gather_evt[which] is not None:
+                gather_evt[which].synchronize()
 
         def take(self, a, b):
             _, ob = eng.buffer(abi.BUF_OUT)
@@ -565,11 +569,12 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
 
         def close(self):
             """waits for THIS step's sub-batches only (the next step's may already be running), then gathers"""
-            for t in self.tickets[-8:]:               # (a ticket whose slot has been taken again belongs to a finished submit)
+            for t in self.tickets[-8:]:               # (a ticket whose slot has been taken again belongs to a finished submit: only that)
                 try:
                     eng.wait(t)
-                except RuntimeError:
-                    pass
+                except RuntimeError as e:
+                    if "not resident" not in str(e):
+                        raise
             torch.cuda.current_stream(dev).synchronize()   # the previous step's gather is complete (NOT a device-wide sync: the next
                                                       # step's sub-batches are running on the engine's streams)
             rec = outs_res[self.w][:self.n * abi.PKT_OUT_DT.itemsize].view(torch.int64).view(self.n, 4)
@@ -584,11 +589,15 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
                 rec[:, 2] += off_cache[key]
             t3 = time.perf_counter()
             g = shard.gather_results(outs_res[self.w][:n_local * abi.PKT_OUT_DT.itemsize], pdu_res[self.w][:self.base], n_local, reuse_sizes=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))   # (the collective's completion is ordered into the current stream)
+            gather_evt[self.w] = ev
             return g, t3 - self.t0
 
     checked = False
     host_keep = None
     off_cache = {}
+    gather_evt = [None, None]
     state = {"pending": None, "i": 0, "g": None}
 
     def finalize():
@@ -674,11 +683,16 @@ def sharded_stream(torch, dev, local, rank, world, use_dist, n_total, steps, war
         v = v.tolist()
         counts, outs_all, pdu_all = state["g"]
         n_pdu, n_fail = shard.count_pdus(counts, outs_all)
+        last_ok = None
+        if rank == 0:                                 # the LAST timed step's gathered arenas, not only the first step's: every PDU again
+            got = shard.pdus_of(counts, outs_all, pdu_all, n_total)
+            last_ok = sum(1 for p, b in got if b == expected[p])
+            assert last_ok == len(got) and last_ok >= 0.97 * n_total, "sharded stream, last step of %s: %d PDUs, %d correct" % (feed_name, len(got), last_ok)
         res["feeds"][feed_name] = {"packets_per_s": n_total * steps / v[0], "ms_per_step": 1e3 * v[0] / steps, "steps": steps, "warmup": max(warmup, 1),
                                    "timeline_ms": {k: round(1e3 * x, 3) for k, x in zip(("descriptors", "last_sub_batch_submitted", "rx_done", "gather_issued"), v[1:])},
                                    "timeline_note": "ms after the step's start, mean over the steps, max over ranks; a step's results are collected "
                                                     "while the next step's first sub-batches run, so rx_done / gather_issued lie beyond ms_per_step",
-                                   "pdus_last_step": n_pdu, "fcs_failures_last_step": n_fail,
+                                   "pdus_last_step": n_pdu, "fcs_failures_last_step": n_fail, "pdus_equal_to_transmitted_last_step": last_ok,
                                    "gathered_bytes_per_rank": int(outs_all.shape[1] + pdu_all.shape[1])}
     # the same stream resident on ONE GPU, no scatter and no gather: what the pipeline is measured against at world 1
     if rank == 0:
@@ -988,7 +1002,7 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
     return out
 
 
-def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=16):
+def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
     per round (26 ms of air at 20 MS/s) out of pinned host memory — every stream a different stretch of the same packet-dense
     capture — through the live ingest of host/c8p_rawchain: per round ONE c8p_detect_multi over all streams, one c8p_signal (scan
@@ -1001,11 +1015,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     per_round_pk = streams * (round_items // unit_len + 2)
     h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
                         reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len)
-    pdus = [0]
-
-    def on_round(g):
-        pdus[0] += int(g["outs"]["n_pdu"].sum())
-    h.live(on_round)
+    h.live(None)                    # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
     base = pin.data_ptr()
     span = n - round_items * (rounds + 3)
     off = [(s * 7919 * unit_len) % max(span, 1) for s in range(streams)]      # every stream its own stretch of the capture

@@ -106,7 +106,9 @@ __device__ __forceinline__ TrigSeg seg_wave_inclusive(TrigSeg v)
 // step, one or two granules awaited in practice; a 400 000-sample carrier walks 4 steps.
 #define C8P_PRE_HALO 8
 #define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
-#define C8P_PRE_RS 264
+#ifndef C8P_PRE_RS
+#define C8P_PRE_RS 268     // (264 until round 4: rows four apart then share banks in the staging stores — SQ_LDS_BANK_CONFLICT = a third of the LDS cycles; 260 / 268 / 276 measured 1-2 % faster, profiles/r4a)
+#endif
 #define C8P_DET_TILE_CAND 96        // plateaus of >= 21 samples that can END inside one tile: ends lie >= 22 apart -> <= 91
 
 __device__ __forceinline__ unsigned long long seg_pack(const TrigSeg& v, long long tile0)

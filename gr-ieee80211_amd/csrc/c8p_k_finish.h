@@ -182,8 +182,14 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
 #define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #elif C8P_TB_SEGS == 40
 #define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+#elif C8P_TB_SEGS == 36
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #elif C8P_TB_SEGS == 32
 #define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#elif C8P_TB_SEGS == 28
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+#elif C8P_TB_SEGS == 24
+#define C8P_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #endif
 #define C8P_DECL(j) const int fb##j = s_btop[j * 4 + frow]; uint4 pf##j;
       C8P_ROWS16(C8P_DECL)

@@ -6,7 +6,8 @@
 #include "c8p_rx.h"
 #include "c8p_oracle.h"
 
-#define SLOTS 3     /* like the engine's default: the results of the last 3 demod / decode / rx submits stay resident (c8p_ticket / c8p_select) */
+#define SLOTS 3     /* like the engine's default: the results of the last 3 demod / decode / rx submits stay resident (c8p_ticket / c8p_select);
+                       C8P_SLOTS = 1 or 2 in the environment (read at create, like the engine) keeps fewer */
 struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
 struct detst { c8p_c32* x; uint64_t n, commit; };      /* one stream of c8p_detect: every item it was ever given */
 struct c8p_ctx {
@@ -16,14 +17,23 @@ struct c8p_ctx {
   const c8p_c32* det_raw; uint64_t det_raw_n;                                           /* C8P_BUF_DET_RAW: the caller's items */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   struct res r[SLOTS];
-  int cur, seq;
+  int cur, seq, slots;
   struct res* s;      /* selected submit */
 };
 #define PDU_STRIDE 8192
 
-c8p_ctx* c8p_create(const c8p_cfg* cfg) { (void)cfg; c8po_init(); c8p_ctx* c = (c8p_ctx*)calloc(1, sizeof(c8p_ctx)); c->s = &c->r[0]; return c; }
+c8p_ctx* c8p_create(const c8p_cfg* cfg)
+{
+  (void)cfg;
+  c8po_init();
+  c8p_ctx* c = (c8p_ctx*)calloc(1, sizeof(c8p_ctx));
+  const char* e = getenv("C8P_SLOTS");
+  c->slots = (e && atoi(e) >= 1 && atoi(e) <= SLOTS) ? atoi(e) : SLOTS;
+  c->s = &c->r[0];
+  return c;
+}
 static void drop_res(struct res* r) { free(r->tags); free(r->outs); free(r->llr); free(r->pdu); free(r->mu); memset(r, 0, sizeof(*r)); }
-static void next_slot(c8p_ctx* c) { c->submits++; c->cur = (c->cur + 1) % SLOTS; c->s = &c->r[c->cur]; drop_res(c->s); c->s->ticket = ++c->seq; }
+static void next_slot(c8p_ctx* c) { c->submits++; c->cur = (c->cur + 1) % c->slots; c->s = &c->r[c->cur]; drop_res(c->s); c->s->ticket = ++c->seq; }
 static void drop(c8p_ctx* c)
 {
   free(c->det.x); free(c->det_evt); free(c->sig_pkt); free(c->sig_iq); free(c->sig_chan);
@@ -187,7 +197,7 @@ int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in) { (void)c; (void)in; retur
 int64_t c8p_counter(c8p_ctx* c, int which)
 {
   switch (which) {
-    case C8P_CNT_SLOTS: return SLOTS;
+    case C8P_CNT_SLOTS: return c->slots;
     case C8P_CNT_SUBMITS: return c->submits;
     case C8P_CNT_ARENA_GROWTHS: case C8P_CNT_ARENA_BYTES: case C8P_CNT_HOST_BYTES: case C8P_CNT_DET_GIVEUPS: case C8P_CNT_DET_TICKET_SCANS: return 0;
     default: return C8P_EINVAL;

@@ -280,3 +280,30 @@ def test_rawchain_handle_reserved_once_never_allocates_again():
         assert sig == first
         assert len(h.timeline()) == 6 and st["rx"]["busy"] > 0 and st["steady_segments"] == 5
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", ["1", "2"])
+def test_rawchain_host_segments_with_fewer_engine_slots(slots, monkeypatch):
+    """C8P_SLOTS = 1 / 2 on the engine: host segments (the signal stage reads the detect context's per-slot copy of the items,
+    C8P_BUF_DET_RAW) and device segments deliver what three slots deliver — the detect stage does not reuse a slot before
+    c8p_signal is through with it, the rx stage collects before it submits when only one submit stays resident"""
+    import torch
+    from gr_ieee80211_amd import blocks
+    dev = torch.device("cuda:0")
+    xs = [stream(NAMES, CFOS, snr=33.0, seed=600 + i)[0] for i in range(9)]
+    pins = [torch.from_numpy(x.view(np.float32).copy()).pin_memory() for x in xs]
+    devs = [p.to(dev) for p in pins]
+    torch.cuda.synchronize()
+    ref = []
+    blocks.rawchain_run([(t.data_ptr(), len(x)) for t, x in zip(devs, xs)], on_segment=ref.append)
+    monkeypatch.setenv("C8P_SLOTS", slots)
+    for host in (True, False):
+        got = []
+        st = blocks.rawchain_run([(t.data_ptr(), len(x)) for t, x in zip(pins if host else devs, xs)], on_segment=got.append, host=host)
+        assert st["segments"] == 9 and st["pdus"] == 9 * len(NAMES)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a["outs"]["n_pdu"], b["outs"]["n_pdu"]) and np.array_equal(a["pkts"]["lsig_len"], b["pkts"]["lsig_len"])
+            for oa, ob in zip(a["outs"], b["outs"]):
+                assert np.array_equal(a["pdu_arena"][int(oa["pdu_off"]):int(oa["pdu_off"]) + int(oa["pdu_bytes"])],
+                                      b["pdu_arena"][int(ob["pdu_off"]):int(ob["pdu_off"]) + int(ob["pdu_bytes"])])

@@ -199,3 +199,20 @@ def test_rawchain_live_refuses_more_than_a_round_holds():
         h.push(2, x[:10])
     h.drain()
     h.close()
+
+
+@pytest.mark.parametrize("slots", ["1", "2"])
+def test_rawchain_with_fewer_engine_slots(slots, monkeypatch):
+    """C8P_SLOTS = 1 / 2 (a documented switch; tools/profile_gpu.sh sets 1): the rx stage collects a segment before it submits the next
+    when only one submit stays resident, and the detect stage holds at most `slots` segments between c8p_detect and the end of
+    c8p_signal (the engine's copy of host items lives in a slot): the same PDUs as with three slots, device and host segments"""
+    xs = [with_tail(stream(NAMES[:5], CFOS[:5], snr=33.0, seed=500 + i)[0], i) for i in range(7)]
+    segs = [(x.ctypes.data, len(x)) for x in xs]
+    ref = []
+    blocks.rawchain_run(segs, engine_lib=FAKE, on_segment=ref.append)
+    monkeypatch.setenv("C8P_SLOTS", slots)
+    for host in (False, True):
+        got = []
+        st = blocks.rawchain_run(segs, engine_lib=FAKE, on_segment=got.append, host=host)
+        assert st["segments"] == 7 and st["pdus"] == 35
+        assert [pdus_of(g) for g in got] == [pdus_of(g) for g in ref]

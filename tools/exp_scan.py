@@ -4,17 +4,16 @@ packets (about a third of its tiles hold a plateau) and (b) noise only (every ti
 rocprofv3 --pmc the two launches can be told apart by their order (a first)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from c8p_cases import dewindow
-from c8p_testlib import load_npz, through_channel
+from __graft_entry__ import load_package
+load_package()
 from gr_ieee80211_amd import engine
+from gr_ieee80211_amd.workloads import raw_stream_unit
 
 dev = torch.device("cuda:0")
-d = load_npz("packets_cfg.npz")["cfg2_VHT_mcs7_1458B_0"]
-rng = np.random.default_rng(1)
-unit = through_channel(dewindow(d["tx"])[:1], None, 30.0, rng, lead=600)[0]
+unit, _ = raw_stream_unit(0)
 reps = (32 << 20) // len(unit)
 xa = torch.from_numpy(unit.view(np.float32)).to(dev).repeat(reps)
 n = xa.numel() // 2
