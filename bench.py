@@ -997,6 +997,10 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
     h.close()
     try:
         out["live_streams"] = live_streams(torch, dev, local, pin, n, unit_len)
+        # the same link, four times as many radios, a quarter of the increment: what the per-round costs leave of the rate
+        more = live_streams(torch, dev, local, pin, n, unit_len, streams=256, round_items=1 << 17)
+        out["live_streams"]["streams_256"] = {k: more[k] for k in ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each",
+                                                                   "streams_at_realtime", "pcie_GBps", "pdus_ok", "arena_growths_in_session")}
     except Exception as e:
         out["live_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
@@ -1023,7 +1027,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     def one_round(r):
         for s in range(streams):
             h.push(s, (base + 8 * (off[s] + r * round_items), round_items), host=True)
-        h.round()
+        h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)
     t0 = time.perf_counter()
@@ -1041,8 +1045,9 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
             "pdus_ok": st["pdus"], "push_and_round_calls_s": round(t_push, 4),
             "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
             "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],
-            "note": "host-fed (pinned memory, 8 B per item over PCIe), results per stream through the callback; warm-up rounds are inside the "
-                    "session, so arena_growths_in_session counts them too"}
+            "note": "host-fed (pinned memory, 8 B per item over PCIe, moved by the engine's gather kernel — the shader cores read the host memory, no "
+                    "DMA engine; c8p_rawchain_round_async: the pipeline's first stage waits for its round's items); warm-up rounds are inside "
+                    "the session, so arena_growths_in_session counts them too"}
 
 
 def tx_rate(engine, local, n=4096):

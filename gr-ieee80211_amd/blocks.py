@@ -48,6 +48,8 @@ def lib():
         L.c8p_rawchain_live.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.c8p_rawchain_push.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int32]
         L.c8p_rawchain_round.argtypes = [C.c_void_p]
+        L.c8p_rawchain_round_async.argtypes = [C.c_void_p]
+        L.c8p_rawchain_ingested.argtypes = [C.c_void_p]
         L.c8p_rawchain_drain.argtypes = [C.c_void_p, C.c_void_p]
         L.c8p_rawchain_error.restype = C.c_char_p
         L.c8p_rawchain_error.argtypes = [C.c_void_p]
@@ -328,13 +330,24 @@ class RawChain:
             ptr, n = a.ctypes.data, len(a)
         self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, 0 if host else 1))
 
-    def round(self):
-        self._chk(self.L.c8p_rawchain_round(self.h))
-        self._keep = []
+    def round(self, wait=True):
+        """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until ingested() / drain() (they are kept here)"""
+        if wait:
+            self._chk(self.L.c8p_rawchain_round(self.h))
+            self._keep = []
+        else:
+            self._chk(self.L.c8p_rawchain_round_async(self.h))
+            self._held = getattr(self, "_held", []) + getattr(self, "_keep", [])
+            self._keep = []
+
+    def ingested(self):
+        self._chk(self.L.c8p_rawchain_ingested(self.h))
+        self._held = []
 
     def drain(self):
         st = _RawStats()
         self._chk(self.L.c8p_rawchain_drain(self.h, C.byref(st)))
+        self._held = []
         return _stats_dict(st)
 
 

@@ -225,6 +225,9 @@ struct c8p_ctx {
   // c8p_copy_*: a stream of its own, created on first use
   hipStream_t copy_stream = nullptr;
   Buf d_spans; void* h_spans = nullptr; size_t h_spans_cap = 0;
+  std::mutex copy_mu;                                // marks against copies enqueued from another thread
+  hipEvent_t copy_ev[64] = {};
+  uint64_t copy_marks = 0;
 };
 
 static bool grow_log() { static const bool on = getenv("C8P_GROW_LOG") != nullptr; return on; }
@@ -349,6 +352,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (hipEvent_t e : c->copy_ev) if (e) (void)hipEventDestroy(e);
   if (c->d_spans.p) (void)hipFree(c->d_spans.p);
   if (c->h_spans) (void)hipHostFree(c->h_spans);
   if (c->d_tab) (void)hipFree(c->d_tab);
@@ -1520,11 +1524,35 @@ extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   (void)hipFree(p);
 }
+extern "C" int c8p_copy_wait(c8p_ctx* c);
 static int copy_stream_of(c8p_ctx* c)
 {
   HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->copy_mu);
   if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   return C8P_OK;
+}
+extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
+{
+  if (!c || copy_stream_of(c) != C8P_OK) return 0;
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  hipEvent_t& e = c->copy_ev[c->copy_marks % 64];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0;
+  if (hipEventRecord(e, c->copy_stream) != hipSuccess) return 0;
+  return ++c->copy_marks;
+}
+extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
+{
+  if (!c) return C8P_EINVAL;
+  if (mark == 0) return c8p_copy_wait(c);
+  if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
+  hipEvent_t e = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c->copy_mu);
+    if (mark > c->copy_marks) return C8P_EINVAL;
+    e = c->copy_ev[(mark - 1) % 64];            // (re-recorded by a later mark if 64 marks have passed: a later point of the same stream)
+  }
+  return hipEventSynchronize(e) == hipSuccess ? C8P_OK : C8P_EHIP;
 }
 extern "C" int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes)
 {
@@ -1573,6 +1601,73 @@ extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, cons
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));
   hipLaunchKernelGGL(k_copy_spans, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->copy_stream, (cf*)dst, (const cf*)src,
                      (const c8p_span*)c->d_spans.p, (const unsigned long long*)((const char*)c->d_spans.p + sizeof(c8p_span) * (size_t)n), n, total);
+  HIPCHK(c, hipGetLastError());
+  return C8P_OK;
+}
+// thread = 16 bytes (two items) of one piece; pieces start at any item, so the first / last item of a piece may be moved alone
+struct PieceDev { const cf* src; unsigned long long dst_off, n, first; };      // first: index of the piece's first work item
+__global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+{
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;                              // last piece whose first work item is <= i
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].first <= i) lo = mid; else hi = mid - 1; }
+  const PieceDev P = pc[lo];
+  // work item k of a piece covers its items [2k - a, 2k - a + 2) where a = 1 if the source starts on an odd item (so that the
+  // 16-byte loads are aligned), clipped to the piece
+  const unsigned long long k = i - P.first;
+  const unsigned a = (unsigned)(((uintptr_t)P.src >> 3) & 1u);
+  const long long i0 = 2 * (long long)k - (long long)a;
+  const cf* s = P.src + i0;
+  cf* d = dst + P.dst_off + i0;
+  if (i0 >= 0 && (unsigned long long)i0 + 2 <= P.n) {
+    const float4 v = *(const float4*)s;
+    if ((((uintptr_t)d) & 15u) == 0) *(float4*)d = v;
+    else { d[0] = mk(v.x, v.y); d[1] = mk(v.z, v.w); }
+  } else {
+    if (i0 >= 0 && (unsigned long long)i0 < P.n) d[0] = s[0];
+    if (i0 + 1 >= 0 && (unsigned long long)(i0 + 1) < P.n) d[1] = s[1];
+  }
+}
+extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces, int32_t n)
+{
+  if (!c || n < 0 || (n > 0 && (!dst || !pieces))) return C8P_EINVAL;
+  int rc;
+  if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
+  if (n == 0) return C8P_OK;
+  for (int i = 0; i < n; i++) {
+    if (!pieces[i].n) continue;
+    if (!pieces[i].src || ((uintptr_t)pieces[i].src & 7u)) { c->err = "c8p_copy_gather: a piece without source or not 8-byte aligned"; return C8P_EINVAL; }
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, pieces[i].src) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost
+                                                                       && at.type != hipMemoryTypeManaged)) {
+      (void)hipGetLastError();
+      c->err = "c8p_copy_gather: a piece lies in host memory the device cannot read (pageable): pin it (c8p_host_alloc) or use c8p_copy_async";
+      return C8P_EINVAL;
+    }
+  }
+  const size_t tab = sizeof(PieceDev) * (size_t)n;
+  if (tab > c->h_spans_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (c->h_spans) HIPCHK(c, hipHostFree(c->h_spans));
+    c->h_spans = nullptr; c->h_spans_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_spans, tab * 2 + 4096, hipHostMallocDefault));
+    c->h_spans_cap = tab * 2 + 4096;
+    if (c->d_spans.p) { HIPCHK(c, hipFree(c->d_spans.p)); c->d_spans.p = nullptr; c->d_spans.cap = 0; }
+    HIPCHK(c, hipMalloc(&c->d_spans.p, tab * 2 + 4096));
+    c->d_spans.cap = tab * 2 + 4096;
+  } else
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));      // (the previous table may still be read)
+  PieceDev* hp = (PieceDev*)c->h_spans;
+  unsigned long long total = 0;
+  for (int i = 0; i < n; i++) {
+    hp[i].src = (const cf*)pieces[i].src; hp[i].dst_off = pieces[i].dst_off; hp[i].n = pieces[i].n; hp[i].first = total;
+    total += (pieces[i].n + 1 + (((uintptr_t)pieces[i].src >> 3) & 1u)) / 2;
+  }
+  if (total == 0) return C8P_OK;
+  HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
+  hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->copy_stream, (cf*)dst, (const PieceDev*)c->d_spans.p, n, total);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
@@ -1638,7 +1733,8 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
                        (int32_t)sizeof(c8p_sig_in), (int32_t)sizeof(c8p_signal_in), (int32_t)sizeof(c8p_sync_evt),
                        (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state), (int32_t)sizeof(c8p_tx_pkt),
                        (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan), (int32_t)sizeof(c8p_tx_mu),
-                       (int32_t)sizeof(c8p_det_stream), (int32_t)sizeof(c8p_detect_multi_in), (int32_t)sizeof(c8p_reserve_in), (int32_t)sizeof(c8p_span)};
-  for (int i = 0; i < 21 && i < cap; i++) dst[i] = v[i];
-  return 21;
+                       (int32_t)sizeof(c8p_det_stream), (int32_t)sizeof(c8p_detect_multi_in), (int32_t)sizeof(c8p_reserve_in), (int32_t)sizeof(c8p_span),
+                       (int32_t)sizeof(c8p_piece)};
+  for (int i = 0; i < 22 && i < cap; i++) dst[i] = v[i];
+  return 22;
 }

@@ -64,6 +64,9 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.copy_async = (int (*)(c8p_ctx*, void*, const void*, uint64_t))sym("c8p_copy_async");
   a.copy_spans = (int (*)(c8p_ctx*, c8p_c32*, const c8p_c32*, const c8p_span*, int32_t))sym("c8p_copy_spans");
   a.copy_wait = (int (*)(c8p_ctx*))sym("c8p_copy_wait");
+  a.copy_gather = (int (*)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t))sym("c8p_copy_gather");
+  a.copy_mark = (uint64_t (*)(c8p_ctx*))sym("c8p_copy_mark");
+  a.copy_wait_mark = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_wait_mark");
   return a;
 }
 

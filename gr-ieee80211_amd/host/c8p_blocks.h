@@ -112,6 +112,9 @@ struct c8p_api {
   int (*copy_async)(c8p_ctx*, void*, const void*, uint64_t);
   int (*copy_spans)(c8p_ctx*, c8p_c32*, const c8p_c32*, const c8p_span*, int32_t);
   int (*copy_wait)(c8p_ctx*);
+  int (*copy_gather)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t);
+  uint64_t (*copy_mark)(c8p_ctx*);
+  int (*copy_wait_mark)(c8p_ctx*, uint64_t);
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);

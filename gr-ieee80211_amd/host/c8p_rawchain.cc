@@ -383,7 +383,7 @@ int run_impl(c8p_rawchain* H, const c8p_rawchain_seg* segs, int64_t n_seg, bool 
 } // namespace
 
 // ------------------------------------------------------------------------------------------------ live ingest
-struct live_round { int64_t r = 0; int arena = 0; std::vector<stream_pos> pos; uint64_t new_items = 0; };
+struct live_round { int64_t r = 0; int arena = 0; std::vector<stream_pos> pos; uint64_t new_items = 0; uint64_t mark = 0; };
 
 struct live_session {
   run_state R;
@@ -395,6 +395,8 @@ struct live_session {
   int64_t round_no = 0;
   std::vector<stream_pos> open;
   uint64_t open_new = 0;
+  uint64_t last_mark = 0;                      // copy mark of the last round handed over
+  std::vector<c8p_piece> pieces;               // the open round's pushes that a kernel can gather (device / pinned host memory)
 };
 
 namespace {
@@ -428,6 +430,10 @@ void live_detect(c8p_rawchain* H, live_session& L)
       }
       k.off = (uint64_t)s * C + (lo[s] - P.base_abs); k.n = P.base_abs + P.fill - lo[s]; k.n_hist = commit[s] - lo[s];
       k.has_state = started[s]; if (started[s]) k.state = state[s];
+    }
+    if (rd.mark) {                                 // c8p_rawchain_round_async: the round's items may still be on their way
+      const int rcw = L.cd.in([&] { return api.copy_wait_mark(H->ing->c, rd.mark); });
+      if (rcw != C8P_OK) throw std::runtime_error("c8p_copy_wait_mark failed (" + std::to_string(rcw) + ")");
     }
     L.cd.busy([&] {
       c8p_detect_multi_in d;
@@ -567,6 +573,23 @@ extern "C" int c8p_rawchain_live(c8p_rawchain* h, c8p_rawchain_cb cb, void* user
   return C8P_OK;
 }
 
+static int flush_pieces(c8p_rawchain* h)
+{
+  live_session& L = *h->live;
+  if (L.pieces.empty()) return C8P_OK;
+  const c8p_api& api = h->api;
+  c8p_c32* dst = h->arena[L.open_arena];
+  int rc = api.copy_gather(h->ing->c, dst, L.pieces.data(), (int32_t)L.pieces.size());
+  if (rc == C8P_EINVAL) {                        // a piece the device cannot read: piece by piece through the DMA path
+    rc = C8P_OK;
+    for (const c8p_piece& pc : L.pieces)
+      if ((rc = api.copy_async(h->ing->c, dst + pc.dst_off, pc.src, sizeof(c8p_c32) * pc.n)) != C8P_OK) break;
+  }
+  if (rc != C8P_OK) h->err = std::string("live ingest copy: ") + api.last_error(h->ing->c);
+  L.pieces.clear();
+  return rc;
+}
+
 extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem)
 {
   if (!h) return C8P_EINVAL;
@@ -579,14 +602,19 @@ extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32
   stream_pos& P = L.open[stream];
   if (P.fill + n > h->C) { h->err = "c8p_rawchain_push: more than stream_round_items new items of one stream in a round"; return C8P_ERANGE; }
   if (n) {
-    rc = h->api.copy_async(h->ing->c, h->arena[L.open_arena] + (uint64_t)stream * h->C + P.fill, items, sizeof(c8p_c32) * n);
-    if (rc != C8P_OK) { h->err = std::string("c8p_copy_async: ") + h->api.last_error(h->ing->c); return rc; }
+    // the items move when the round is closed (or when 4096 pieces have gathered): all pieces with ONE kernel that reads the host memory
+    // itself — no DMA engine, so the bulk does not queue in front of the stages' small descriptor and result copies.  A source the
+    // device cannot read (pageable host memory) goes through c8p_copy_async at once
+    c8p_piece pc;
+    pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n;
+    L.pieces.push_back(pc);
+    if (L.pieces.size() >= 4096 && (rc = flush_pieces(h)) != C8P_OK) return rc;
   }
   P.fill += n; L.open_new += n;
   return C8P_OK;
 }
 
-extern "C" int c8p_rawchain_round(c8p_rawchain* h)
+static int round_impl(c8p_rawchain* h, bool wait)
 {
   if (!h) return C8P_EINVAL;
   int rc = live_start(h);
@@ -594,8 +622,15 @@ extern "C" int c8p_rawchain_round(c8p_rawchain* h)
   if ((rc = live_failed(h)) != C8P_OK) return rc;
   live_session& L = *h->live;
   const c8p_api& api = h->api;
-  if ((rc = api.copy_wait(h->ing->c)) != C8P_OK) { h->err = std::string("c8p_copy_wait: ") + api.last_error(h->ing->c); return rc; }
   live_round rd;
+  if ((rc = flush_pieces(h)) != C8P_OK) return rc;
+  if (wait) {
+    if ((rc = api.copy_wait(h->ing->c)) != C8P_OK) { h->err = std::string("c8p_copy_wait: ") + api.last_error(h->ing->c); return rc; }
+  } else {
+    rd.mark = api.copy_mark(h->ing->c);
+    if (!rd.mark) { h->err = "c8p_copy_mark failed"; return C8P_EHIP; }
+    L.last_mark = rd.mark;
+  }
   rd.r = L.round_no++; rd.arena = L.open_arena; rd.pos = L.open; rd.new_items = L.open_new;
   if (!L.q0.put(std::move(rd))) { (void)live_failed(h); return C8P_EHIP; }
   L.R.raw_arenas->acquire();                                   // the next arena: free once the round that used it is through c8p_signal
@@ -614,6 +649,16 @@ extern "C" int c8p_rawchain_round(c8p_rawchain* h)
   if (rc != C8P_OK) { h->err = std::string("c8p_copy_spans: ") + api.last_error(h->ing->c); return rc; }
   L.open_arena = next; L.open_new = 0;
   return C8P_OK;
+}
+extern "C" int c8p_rawchain_round(c8p_rawchain* h) { return round_impl(h, true); }
+extern "C" int c8p_rawchain_round_async(c8p_rawchain* h) { return round_impl(h, false); }
+extern "C" int c8p_rawchain_ingested(c8p_rawchain* h)
+{
+  if (!h) return C8P_EINVAL;
+  if (!h->live || !h->live->last_mark) return C8P_OK;
+  const int rc = h->api.copy_wait_mark(h->ing->c, h->live->last_mark);
+  if (rc != C8P_OK) h->err = "c8p_copy_wait_mark failed";
+  return rc;
 }
 
 extern "C" int c8p_rawchain_drain(c8p_rawchain* h, c8p_rawchain_stats* stats)

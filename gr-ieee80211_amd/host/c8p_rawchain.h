@@ -92,8 +92,9 @@ typedef struct c8p_rawchain_mark {      /* one segment's way through the stages:
   double det_begin, det_end, sig_begin, sig_end, rx_submit, rx_done;
 } c8p_rawchain_mark;
 
-/* err / errcap: message buffer of the caller, may be NULL.  Returns NULL on failure (no usable device, missing library or symbol,
- * an engine with fewer than three slots: C8P_SLOTS < 3 cannot hold three segments in flight). */
+/* err / errcap: message buffer of the caller, may be NULL.  Returns NULL on failure (no usable device, missing library or symbol, a
+ * reserve that does not fit).  An engine with fewer than three slots (C8P_SLOTS = 1 / 2) works, with less overlap: the rx stage then
+ * collects a segment before it submits the next, and the detect stage holds back until c8p_signal has read its copy of host items. */
 c8p_rawchain* c8p_rawchain_create(const c8p_rawchain_cfg* cfg, char* err, int errcap);
 void c8p_rawchain_destroy(c8p_rawchain* h);
 
@@ -117,19 +118,27 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
 /* ---- live ingest (c8p_rawchain_cfg.streams = K > 0, one antenna per stream) --------------------------------------------------
  * K independent streams, each what one radio delivers: its own trigger / sync state (c8p_det_state), commit point and signal-block
  * scan position live in the handle.  Items arrive in increments of any size:
- *   c8p_rawchain_push   appends n items to one stream (host memory — pinned for an asynchronous copy — or device memory; the copy
- *                       is only enqueued: the items must stay valid until the next c8p_rawchain_round returns)
+ *   c8p_rawchain_push   appends n items to one stream (device memory, or host memory — pinned: c8p_host_alloc / hipHostMalloc /
+ *                       hipHostRegister; pageable works, slowly).  Nothing moves yet: the items must stay valid until the next
+ *                       c8p_rawchain_round returns.  All pushes of a round are moved by ONE kernel that reads the host memory over
+ *                       PCIe itself (c8p_copy_gather): 54-56 GB/s whatever the size of the increments (the DMA engines fall to
+ *                       18 GB/s at 256 KB copies), and the DMA queues stay free for the stages' own descriptor / result copies
  *   c8p_rawchain_round  closes the round: everything pushed since the last one goes down the pipeline as ONE batch — one
  *                       c8p_detect_multi over all streams' new items, one c8p_signal with the scan rule per stream, one c8p_rx over
  *                       the packets of all streams; returns when the round's items are on the device (blocks while three rounds
  *                       are in flight).  The results arrive through the callback, on the pipeline's rx thread, round by round; a
  *                       packet whose items straddle rounds is delivered by the round that completes it.
+ *   c8p_rawchain_round_async  the same without waiting for the copies: the pipeline's first stage waits for them instead, so the next
+ *                       round's copies follow this round's without a gap on the link; the pushed items must then stay valid until
+ *                       c8p_rawchain_ingested() (or c8p_rawchain_drain) has returned
  *   c8p_rawchain_drain  waits until every round has been delivered and ends the session (flags still waiting for items yield
  *                       nothing); the handle can start another one (all streams from the constructor state).
  * One thread calls push / round / drain.  The first push or round starts the session with the callback given to c8p_rawchain_live. */
 int c8p_rawchain_live(c8p_rawchain* h, c8p_rawchain_cb cb, void* user);
 int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem);
 int c8p_rawchain_round(c8p_rawchain* h);
+int c8p_rawchain_round_async(c8p_rawchain* h);
+int c8p_rawchain_ingested(c8p_rawchain* h);          /* every item pushed before the last round call is on the device */
 int c8p_rawchain_drain(c8p_rawchain* h, c8p_rawchain_stats* stats);
 const char* c8p_rawchain_error(c8p_rawchain* h);     /* message of the last failing call on this handle */
 

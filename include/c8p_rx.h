@@ -461,6 +461,19 @@ void  c8p_dev_free(c8p_ctx* ctx, void* p);
 int   c8p_copy_async(c8p_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int   c8p_copy_spans(c8p_ctx* ctx, c8p_c32* dst, const c8p_c32* src, const c8p_span* spans, int32_t n);   /* spans: host memory */
 int   c8p_copy_wait(c8p_ctx* ctx);
+/* A mark on the copy stream: c8p_copy_mark returns a ticket (> 0) for "every copy enqueued so far"; c8p_copy_wait_mark(ticket) returns
+ * when those copies are done — from any thread, also while another thread keeps enqueuing copies on the same ctx (the one exception
+ * to "a ctx is not internally locked": marks and c8p_copy_async / c8p_copy_spans may be called concurrently).  The last 64 marks can
+ * be waited for; an older ticket waits for a newer mark (never too little). */
+/* n pieces gathered into dst by ONE kernel launch on the copy stream: piece i = n items from src (device memory, or host memory the
+ * device can read: c8p_host_alloc / hipHostMalloc / hipHostRegister-ed) to dst + dst_off.  The shader cores read the host memory
+ * over PCIe themselves, so no DMA engine is involved: bulk ingest through this call does not queue in front of the small
+ * descriptor / result copies of the engine's submits (measured: with the same 268 MB per round going through c8p_copy_async, a
+ * c8p_rx submit's own copies waited 5-10 ms).  A piece in pageable host memory is refused (C8P_EINVAL): use c8p_copy_async for it. */
+typedef struct c8p_piece { const c8p_c32* src; uint64_t dst_off; uint64_t n; } c8p_piece;
+int   c8p_copy_gather(c8p_ctx* ctx, c8p_c32* dst, const c8p_piece* pieces, int32_t n);           /* pieces: host memory */
+uint64_t c8p_copy_mark(c8p_ctx* ctx);
+int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);
 
 /* Counters of one ctx since c8p_create (monotonic unless stated otherwise). */
 #define C8P_CNT_ARENA_GROWTHS    0   /* device / pinned allocations made by submits and c8p_reserve (each one sits behind a stream
@@ -502,7 +515,7 @@ int c8p_table(int which, int sub, int32_t* dst, int cap);
 int c8p_selftest(c8p_ctx* ctx, int which, const float* in, float* out, uint64_t n);
 
 /* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc,
- * tx_in, tx_plan, tx_mu, det_stream, detect_multi_in, reserve_in, span} as compiled into the library. */
+ * tx_in, tx_plan, tx_mu, det_stream, detect_multi_in, reserve_in, span, piece} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

@@ -213,7 +213,15 @@ int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span*
   for (int i = 0; i < n; i++) memmove(dst + sp[i].dst_off, src + sp[i].src_off, sizeof(c8p_c32) * (size_t)sp[i].n);
   return C8P_OK;
 }
+int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
+{
+  (void)c;
+  for (int i = 0; i < n; i++) memmove(dst + pc[i].dst_off, pc[i].src, sizeof(c8p_c32) * (size_t)pc[i].n);
+  return C8P_OK;
+}
 int c8p_copy_wait(c8p_ctx* c) { (void)c; return C8P_OK; }
+uint64_t c8p_copy_mark(c8p_ctx* c) { return (uint64_t)++c->submits; }
+int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark) { (void)c; (void)mark; return C8P_OK; }
 int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
 
 const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)

@@ -225,7 +225,7 @@ def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain
             if n:
                 h.push(s, (ts[s].data_ptr() + 8 * pos[s], n), host=(feed == "host"))
                 pos[s] += n
-        h.round()
+        h.round(wait=(feed == "host"))             # device feed: c8p_rawchain_round_async (the detect stage waits for the round's copies)
         r += 1
     st = h.drain()
     h.close()

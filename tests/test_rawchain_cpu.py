@@ -159,7 +159,7 @@ def test_rawchain_live_streams_pushed_in_increments_equal_one_pass_per_stream(ch
             if n:
                 h.push(s, x[pos[s]:pos[s] + n])
                 pos[s] += n
-        h.round()
+        h.round(wait=(chunks != "even"))          # (even: c8p_rawchain_round_async, the detect stage waits for the copies)
     st = h.drain()
     assert [g["segment"] for g in got] == list(range(len(got))) and st["segments"] == len(got) and st["items"] == sum(len(x) for x in xs)
     per = [([], []) for _ in range(4)]

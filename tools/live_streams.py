@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""tools/live_streams.py [streams ...] — bench.py's live_streams leg alone, for several stream counts (and round lengths): how many
+independent 20 MS/s streams one MI355X serves, host-fed over PCIe, through host/c8p_rawchain's live ingest."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+import torch  # noqa: E402
+from gr_ieee80211_amd.workloads import raw_stream_unit  # noqa: E402
+
+dev = torch.device("cuda:0")
+unit, _ = raw_stream_unit(0)
+reps = (32 << 20) // len(unit)
+pin = torch.from_numpy(np.tile(unit, reps).view(np.float32)).pin_memory()
+n = pin.numel() // 2
+for arg in (sys.argv[1:] or ["64"]):
+    K, items = (int(v) for v in (arg.split(":") + ["524288"])[:2])
+    r = bench.live_streams(torch, dev, 0, pin, n, len(unit), streams=K, round_items=items, rounds=max(8, min(40, (n // items) - 6)))
+    print(json.dumps({k: r[k] for k in ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each", "streams_at_realtime",
+                                        "pcie_GBps", "packets_per_s", "pdus_ok", "push_and_round_calls_s", "host_thread_s")}))
