@@ -260,12 +260,14 @@ class StreamScatter:
 _SIZES = {}     # (group, n_local, outs bytes, pdu bytes) -> exchanged size table: a stream's steps repeat the same sizes
 
 
-def gather_results(outs_t, pdu_t, n_local, group=None, reuse_sizes=False):
+def gather_results(outs_t, pdu_t, n_local, group=None, reuse_sizes=False, works=None):
     """All-gather the fixed-stride result arenas, device-resident: `outs_t` = this rank's c8p_pkt_out records as bytes,
     `pdu_t` = its PDU arena (uint8 tensors on the backend's device).  Returns (counts [world] int64, outs_all [world, max
     bytes], pdu_all [world, max bytes]); rank r's records are outs_all[r, :counts[r] * 32] and its pdu_off values index
     pdu_all[r].  Two collectives besides the size exchange, no host copies, no per-PDU work.  reuse_sizes: skip the size exchange
-    when this rank's sizes are the ones of an earlier call (every rank must pass the same flag: the steps of one stream)."""
+    when this rank's sizes are the ones of an earlier call (every rank must pass the same flag: the steps of one stream).
+    works: a list — the two collectives are then issued with async_op=True and their Work handles appended: the caller polls
+    `is_completed()` before it rewrites the inputs or reads the outputs on the host (no event of its own is needed for that)."""
     world = dist.get_world_size(group)
     dev = outs_t.device
     key = (id(group), world, n_local, outs_t.numel(), pdu_t.numel(), str(dev))
@@ -300,7 +302,10 @@ def gather_results(outs_t, pdu_t, n_local, group=None, reuse_sizes=False):
             dist.all_gather(lst, t, group=group)
             return torch.stack(lst)
         out = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, t, group=group)
+        if works is not None:
+            works.append(dist.all_gather_into_tensor(out, t, group=group, async_op=True))
+        else:
+            dist.all_gather_into_tensor(out, t, group=group)
         return out.view(world, t.numel())
 
     return all_sizes[:, 0].clone(), gather(outs_t, m_o), gather(pdu_t, m_p)      # (counts: a host tensor)
