@@ -6,6 +6,51 @@
 // API = the public class of include/gnuradio/ieee80211/ (demod, demod2, decode), which derives from gr::block, so the
 // protected scheduler calls (get_tags_in_range, add_item_tag, ...) are made from inside the block, as in the reference's
 // own *_impl classes.  Tag values cross as the three PMT kinds the reference's blocks use: long, float, c32vector.
+//
+// AUDIT LIST — every GNU Radio / PMT member this header and lib/{demod,demod2,decode}_impl.{h,cc} touch, with a place where the
+// reference uses the same member the same way (paths relative to the reference tree).  None of this has met GNU Radio's own
+// headers: tests/gr_api_decls/ declares these members as WE READ the 3.10 API documentation and the adapters are type-checked
+// against that reading (tests/test_gnuradio_packaging.py); gnuradio/ci/run.sh is what checks them for real.
+//
+//   member (as used here)                                        the reference uses it at
+//   ---------------------------------------------------------------------------------------------------------------------------
+//   gr::block(name, io_signature::sptr in, out)  [ctor]          lib/demod_impl.cc:35-37, lib/decode_impl.cc:34-36
+//   gr::io_signature::make(min, max, sizeof_item)                lib/demod_impl.cc:36-37, lib/decode_impl.cc:35-36
+//   gnuradio::make_block_sptr<T>(args...)                        lib/demod_impl.cc:30, lib/decode_impl.cc:29
+//   set_tag_propagation_policy(gr::block::TPP_DONT)              lib/demod_impl.cc:46, lib/decode_impl.cc:47
+//   message_port_register_out(pmt::mp("out"))  [decode_impl.cc]  lib/decode_impl.cc:39
+//   message_port_register_in(pmt::mp(..))                        lib/pktgen_impl.cc:46, lib/modulation2_impl.cc:45
+//   set_msg_handler(pmt::mp(..), callable(pmt::pmt_t))           lib/pktgen_impl.cc:47 (boost::bind there, a lambda here)
+//   forecast(int, gr_vector_int&)  [override]                    lib/demod_impl.cc:53-57, lib/decode_impl.cc:54-58
+//   general_work(int, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star&)  [override]
+//                                                                lib/demod_impl.cc:59-63, lib/decode_impl.cc:60-64
+//   stop()  [override, calls gr::block::stop()]                  NOT used by the reference (its blocks hold nothing back at the end
+//                                                                of a finite flowgraph; a batching front does): gr::block::stop is
+//                                                                virtual bool stop() in gnuradio/block.h of 3.10
+//   nitems_read(unsigned), nitems_written(unsigned)              lib/demod_impl.cc:75, :259; lib/decode_impl.cc:70
+//   get_tags_in_range(std::vector<gr::tag_t>&, port, start, end) lib/demod_impl.cc:75, lib/decode_impl.cc:70
+//   gr::tag_t::offset / key / value                              lib/demod_impl.cc:79-80 (tag.key, tag.value)
+//   add_item_tag(port, offset, key, value, alias_pmt())          lib/demod_impl.cc:258-262
+//   consume_each(int)                                            lib/demod_impl.cc:102 ... :340
+//   message_port_pub(pmt::mp("out"), pmt::cons(meta, blob))      lib/decode_impl.cc:120, :419, :516
+//   _post(pmt::pmt_t port, pmt::pmt_t msg)  [wake()]             NOT used by the reference: gr::basic_block::_post is the public
+//                                                                entry point message delivery uses (gnuradio/basic_block.h of 3.10)
+//   pmt::mp(const char*) / pmt::mp(std::string)                  lib/demod_impl.cc:82 ...
+//   pmt::make_dict(), pmt::dict_add(dict, key, value)            lib/demod_impl.cc:224-226, lib/decode_impl.cc:73-75
+//   pmt::from_long(long), pmt::from_float(double)                lib/demod_impl.cc:225-237
+//   pmt::to_long(pmt_t), pmt::to_double(pmt_t)                   lib/demod_impl.cc:85 (to_long); the reference reads floats with
+//                                                                pmt::to_float (:82); to_double is the same accessor, 3.10 pmt.h
+//   pmt::init_c32vector(size_t, const std::vector<std::complex<float>>&)     lib/demod_impl.cc:247
+//   pmt::c32vector_elements(pmt_t) -> std::vector<std::complex<float>>       lib/demod_impl.cc:89, lib/decode_impl.cc:103
+//   pmt::make_blob(const void*, size_t)                          lib/decode_impl.cc:119, :418, :515
+//   pmt::cons(pmt_t, pmt_t)                                      lib/decode_impl.cc:120
+//   pmt::is_integer / is_real / is_c32vector(pmt_t)              NOT used by the reference (it looks tags up by key and assumes the
+//                                                                kind); predicates of 3.10 pmt.h
+//   pmt::symbol_to_string(pmt_t), pmt::string_to_symbol(string)  lib/pad2_impl.cc:154 (string_to_symbol); symbol_to_string: 3.10 pmt.h
+//   pmt::PMT_T                                                   3.10 pmt.h (the reference uses pmt::PMT_NIL, lib/demod_impl.cc:89)
+//
+// Five members have no call site in the reference (stop, _post, the three predicates + symbol_to_string / to_double / PMT_T): those
+// are the first things to look at if the module does not build against a real GNU Radio.
 #ifndef INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 #define INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 
