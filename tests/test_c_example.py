@@ -51,3 +51,72 @@ def test_example_turns_a_capture_file_into_pdus(tmp_path):
     for l, (fmt, mcs, mp, ps) in zip(pdus, specs):
         assert "%s mcs %d, %d bytes, crc32 correct" % (("legacy", "ht", "vht")[fmt], mcs, len(mp)) in l, l
         assert l.endswith("first bytes %02x %02x %02x %02x" % tuple(mp[:4])), l
+
+
+# ------------------------------------------------------------------------------------------------ examples/rx_live.c
+LIVE = os.path.join(ROOT, "examples", "rx_live")
+
+
+def build_live():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gr-ieee80211_amd", "host")])
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "gr-ieee80211_amd", "host"), os.path.join(ROOT, "examples", "rx_live.c"), "-o", LIVE,
+                           "-L" + os.path.join(ROOT, "gr-ieee80211_amd"), "-lc8p_blocks", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "gr-ieee80211_amd")])
+
+
+def live_streams_of(seed):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_detect_frontend import CFOS, NAMES, SWEEP, stream
+    order = [NAMES, NAMES[::-1], NAMES[2:6]]
+    xs = [np.concatenate([stream(nm, CFOS[:len(nm)], snr=33.0, seed=seed + i)[0], np.zeros(900, np.complex64)]) for i, nm in enumerate(order)]
+    return xs, [[SWEEP[k]["pdu"].tobytes() for k in nm] for nm in order]
+
+
+def check_live_output(out, want, rounds_min):
+    lines = out.strip().splitlines()
+    got = {s: [] for s in range(len(want))}
+    last = {}
+    for ln in lines[:-1]:
+        f = ln.split()
+        s, item = int(f[3]), int(f[5].rstrip(":"))
+        assert last.get(s, -1) < item, ln                    # per stream in stream order
+        last[s] = item
+        got[s].append((int(f[7]), ln.split("first bytes ")[1]))
+    for s, ps in enumerate(want):
+        assert [g[0] for g in got[s]] == [len(p) - 4 for p in ps], s
+        assert [g[1] for g in got[s]] == ["%02x %02x %02x %02x" % tuple(p[3:7]) for p in ps], s
+    tot = sum(len(p) for p in want)
+    assert lines[-1].startswith("%d streams, " % len(want)) and lines[-1].endswith("%d packets, %d PDUs" % (tot, tot)), lines[-1]
+    assert int(lines[-1].split()[2]) >= rounds_min
+
+
+def test_live_example_compiles_as_plain_c11_and_runs_on_the_test_engine(tmp_path):
+    """plain C against include/c8p_rx.h + host/c8p_rawchain.h; here with tests/fake_c8p (the C ABI on the oracle) as the engine
+    library: three capture files = three radios, pushed out of step, every stream's PDUs in order"""
+    build_live()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "fake_c8p")])
+    xs, want = live_streams_of(900)
+    files = []
+    for i, x in enumerate(xs):
+        f = tmp_path / ("radio%d.c64" % i)
+        x.astype(np.complex64).tofile(f)
+        files.append(str(f))
+    r = subprocess.run([LIVE, "-l", os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so"), "-r", "7000"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    check_live_output(r.stdout, want, 3)
+
+
+@pytest.mark.gpu
+def test_live_example_on_the_engine(tmp_path):
+    build_live()
+    xs, want = live_streams_of(910)
+    files = []
+    for i, x in enumerate(xs):
+        f = tmp_path / ("radio%d.c64" % i)
+        x.astype(np.complex64).tofile(f)
+        files.append(str(f))
+    r = subprocess.run([LIVE, "-l", os.path.join(ROOT, "gr-ieee80211_amd", "libc8p_rx.so"), "-r", "9000"] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    check_live_output(r.stdout, want, 3)
