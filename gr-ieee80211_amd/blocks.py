@@ -47,6 +47,7 @@ def lib():
         L.c8p_rawchain_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.c8p_rawchain_live.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.c8p_rawchain_push.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int32]
+        L.c8p_rawchain_push2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]
         L.c8p_rawchain_round.argtypes = [C.c_void_p]
         L.c8p_rawchain_round_async.argtypes = [C.c_void_p]
         L.c8p_rawchain_ingested.argtypes = [C.c_void_p]
@@ -217,7 +218,7 @@ class _RawOut(C.Structure):
 class _RawCfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("lib", C.c_char_p), ("reserve_seg_items", C.c_uint64),
                 ("reserve_seg_events", C.c_uint32), ("reserve_seg_packets", C.c_uint32), ("reserve_pkt_items", C.c_uint32),
-                ("reserve_host", C.c_int32), ("reserve_ant", C.c_int32), ("streams", C.c_uint32), ("rsv", C.c_uint32),
+                ("reserve_host", C.c_int32), ("reserve_ant", C.c_int32), ("streams", C.c_uint32), ("stream_ant", C.c_uint32),
                 ("stream_round_items", C.c_uint64)]
 
 
@@ -262,11 +263,11 @@ class RawChain:
     reserve_*: arena shapes sized at create; streams / stream_round_items: live ingest of K independent streams (push / round / drain)."""
 
     def __init__(self, device=0, engine_lib=None, reserve_seg_items=0, reserve_seg_events=0, reserve_seg_packets=0, reserve_pkt_items=0,
-                 reserve_host=False, reserve_ant=1, streams=0, stream_round_items=0):
+                 reserve_host=False, reserve_ant=1, streams=0, stream_round_items=0, stream_ant=1):
         self.L = lib()
         self.engine_lib = engine_lib or ENGINE_LIB
         cfg = _RawCfg(C.sizeof(_RawCfg), device, self.engine_lib.encode(), int(reserve_seg_items), int(reserve_seg_events),
-                      int(reserve_seg_packets), int(reserve_pkt_items), int(bool(reserve_host)), int(reserve_ant), int(streams), 0,
+                      int(reserve_seg_packets), int(reserve_pkt_items), int(bool(reserve_host)), int(reserve_ant), int(streams), int(stream_ant),
                       int(stream_round_items))
         err = C.create_string_buffer(512)
         self.h = self.L.c8p_rawchain_create(C.byref(cfg), err, len(err))
@@ -329,6 +330,19 @@ class RawChain:
             self._keep.append(a)
             ptr, n = a.ctypes.data, len(a)
         self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, 0 if host else 1))
+
+    def push2(self, stream, ant0, ant1, host=True):
+        """two antennas per stream (stream_ant=2): numpy complex64 arrays of equal length, or (pointer, n) tuples"""
+        def ptr(a):
+            if isinstance(a, tuple):
+                return int(a[0]), int(a[1])
+            a = np.ascontiguousarray(a, np.complex64)
+            self._keep = getattr(self, "_keep", [])
+            self._keep.append(a)
+            return a.ctypes.data, len(a)
+        (p0, n0), (p1, n1) = ptr(ant0), ptr(ant1)
+        assert n0 == n1
+        self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, 0 if host else 1))
 
     def round(self, wait=True):
         """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until ingested() / drain() (they are kept here)"""

@@ -171,6 +171,7 @@ struct c8p_rawchain {
   c8p_c32* arena[LIVE_ARENAS] = {nullptr, nullptr, nullptr};
   uint64_t C = 0;                              // items of one stream's region in an arena
   uint64_t keep = 0;                           // live_keep() when the handle was made
+  uint64_t A1 = 0;                             // two antennas per live stream: antenna 1's regions start A1 items into an arena (0: one antenna)
   ctx_holder* all[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t sum(int which) const { int64_t v = 0; for (ctx_holder* h : all) v += h->cnt(which); return v; }
 };
@@ -416,7 +417,7 @@ void live_detect(c8p_rawchain* H, live_session& L)
   live_round rd;
   while (L.cd.in([&] { return L.q0.get(rd); })) {
     seg_events o;
-    o.seg = rd.r; o.new_items = rd.new_items; o.raw_dev = H->arena[rd.arena]; o.n_raw = (uint64_t)K * C; o.pos = rd.pos;
+    o.seg = rd.r; o.new_items = rd.new_items; o.raw_dev = H->arena[rd.arena]; o.n_raw = (uint64_t)K * C * (H->A1 ? 2 : 1); o.pos = rd.pos;
     o.det_begin = now_s() - R.t0;
     for (uint32_t s = 0; s < K; s++) {
       const stream_pos& P = rd.pos[s];
@@ -438,7 +439,7 @@ void live_detect(c8p_rawchain* H, live_session& L)
     L.cd.busy([&] {
       c8p_detect_multi_in d;
       memset(&d, 0, sizeof(d));
-      d.mem = C8P_MEM_DEVICE; d.n_streams = (int32_t)K; d.raw = o.raw_dev; d.n_raw = o.n_raw; d.streams = ks.data();
+      d.mem = C8P_MEM_DEVICE; d.n_streams = (int32_t)K; d.raw = o.raw_dev; d.n_raw = (uint64_t)K * C; d.streams = ks.data();   // (antenna 0)
       det.check(api.detect_multi(det.c, &d), "c8p_detect_multi");
       uint64_t bytes = 0;
       (void)api.buffer(det.c, C8P_BUF_DET_EVT, &bytes);
@@ -496,6 +497,7 @@ void live_signal(c8p_rawchain* H, live_session& L)
       q.raw_off[0] = (uint64_t)f.stream * C + (f.abs - P.base_abs);
       q.n_avail = (uint32_t)std::min<uint64_t>(P.base_abs + P.fill - f.abs, MAX_PKT_ITEMS);
       q.cfo_rad = f.rad; q.snr = f.snr; q.rssi = f.rssi; q.n_ant = 1; q.stream = f.stream;
+      if (H->A1) { q.n_ant = 2; q.raw_off[1] = H->A1 + q.raw_off[0]; }
     }
     for (uint32_t s = 0; s < K; s++) {
       const stream_pos& P = in.pos[s];
@@ -590,7 +592,7 @@ static int flush_pieces(c8p_rawchain* h)
   return rc;
 }
 
-extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem)
+static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, const c8p_c32* ant1, uint64_t n, int32_t mem)
 {
   if (!h) return C8P_EINVAL;
   if (mem != C8P_MEM_HOST && mem != C8P_MEM_DEVICE) { h->err = "bad mem kind"; return C8P_EINVAL; }
@@ -598,6 +600,10 @@ extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32
   if (rc != C8P_OK) return rc;
   if ((rc = live_failed(h)) != C8P_OK) return rc;
   if (stream >= h->cfg.streams || (n && !items)) { h->err = "c8p_rawchain_push: no such stream / no items"; return C8P_EINVAL; }
+  if ((h->A1 != 0) != (ant1 != nullptr || n == 0) && n) {
+    h->err = h->A1 ? "this handle's streams have two antennas: c8p_rawchain_push2" : "this handle's streams have one antenna: c8p_rawchain_push";
+    return C8P_EINVAL;
+  }
   live_session& L = *h->live;
   stream_pos& P = L.open[stream];
   if (P.fill + n > h->C) { h->err = "c8p_rawchain_push: more than stream_round_items new items of one stream in a round"; return C8P_ERANGE; }
@@ -608,10 +614,20 @@ extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32
     c8p_piece pc;
     pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n;
     L.pieces.push_back(pc);
+    if (ant1) { pc.src = ant1; pc.dst_off += h->A1; L.pieces.push_back(pc); }
     if (L.pieces.size() >= 4096 && (rc = flush_pieces(h)) != C8P_OK) return rc;
   }
   P.fill += n; L.open_new += n;
   return C8P_OK;
+}
+extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem)
+{
+  return push_impl(h, stream, items, nullptr, n, mem);
+}
+extern "C" int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem)
+{
+  if (h && n && !ant1) { h->err = "c8p_rawchain_push2: no items for antenna 1"; return C8P_EINVAL; }
+  return push_impl(h, stream, ant0, ant1, n, mem);
 }
 
 static int round_impl(c8p_rawchain* h, bool wait)
@@ -638,11 +654,13 @@ static int round_impl(c8p_rawchain* h, bool wait)
   // every stream's last `keep` (110 000) items go with it into the next round: the detection history behind its commit point and the
   // items of packets that have begun (a flag that waits for more items is at most MAX_PKT_ITEMS back)
   const int next = (L.open_arena + 1) % LIVE_ARENAS;
-  std::vector<c8p_span> sp(h->cfg.streams);
-  for (uint32_t s = 0; s < h->cfg.streams; s++) {
+  const uint32_t K = h->cfg.streams;
+  std::vector<c8p_span> sp((size_t)K * (h->A1 ? 2 : 1));
+  for (uint32_t s = 0; s < K; s++) {
     stream_pos& P = L.open[s];
     const uint64_t T = std::min<uint64_t>(P.fill, h->keep);
     sp[s].dst_off = (uint64_t)s * h->C; sp[s].src_off = (uint64_t)s * h->C + P.fill - T; sp[s].n = T;
+    if (h->A1) { sp[K + s] = sp[s]; sp[K + s].dst_off += h->A1; sp[K + s].src_off += h->A1; }
     P.base_abs += P.fill - T; P.fill = T;
   }
   rc = api.copy_spans(h->ing->c, h->arena[next], h->arena[L.open_arena], sp.data(), (int32_t)sp.size());
@@ -694,7 +712,7 @@ extern "C" c8p_rawchain* c8p_rawchain_create(const c8p_rawchain_cfg* cfg, char* 
     H->det.reset(new ctx_holder(H->api, cfg->device)); H->sig0.reset(new ctx_holder(H->api, cfg->device));
     H->sig1.reset(new ctx_holder(H->api, cfg->device)); H->rx.reset(new ctx_holder(H->api, cfg->device));
     H->all[0] = H->det.get(); H->all[1] = H->sig0.get(); H->all[2] = H->sig1.get(); H->all[3] = H->rx.get();
-    const int ant = cfg->reserve_ant == 2 ? 2 : 1;
+    const int ant = (cfg->reserve_ant == 2 || cfg->stream_ant == 2) ? 2 : 1;
     if (cfg->streams) {
       if (cfg->streams > 65535u) return fail("at most 65535 live streams");
       const uint64_t per = cfg->stream_round_items ? cfg->stream_round_items : (1u << 20);
@@ -702,8 +720,9 @@ extern "C" c8p_rawchain* c8p_rawchain_create(const c8p_rawchain_cfg* cfg, char* 
       H->keep = live_keep();
       H->C = (H->keep + per + 7) & ~(uint64_t)7;
       H->ing.reset(new ctx_holder(H->api, cfg->device));
+      H->A1 = cfg->stream_ant == 2 ? H->C * cfg->streams : 0;
       for (int a = 0; a < LIVE_ARENAS; a++) {
-        H->arena[a] = (c8p_c32*)H->api.dev_alloc(H->ing->c, sizeof(c8p_c32) * H->C * cfg->streams);
+        H->arena[a] = (c8p_c32*)H->api.dev_alloc(H->ing->c, sizeof(c8p_c32) * H->C * cfg->streams * (H->A1 ? 2 : 1));
         if (!H->arena[a]) throw std::runtime_error("c8p_dev_alloc: no memory for the live streams' arenas");
       }
     }

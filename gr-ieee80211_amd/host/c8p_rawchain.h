@@ -38,7 +38,8 @@ typedef struct c8p_rawchain_cfg {
   int32_t  reserve_ant;        /* 1 or 2 antennas (0 = 1)                                                                   */
   /* live ingest; streams = 0: c8p_rawchain_push is not available */
   uint32_t streams;            /* K independent streams                                                                     */
-  uint32_t rsv;
+  uint32_t stream_ant;         /* antennas per live stream: 0 / 1 = one (rx.grc: signal -> demod), 2 = two (rx2.grc: signal2 ->
+                                  demod2; detection listens on antenna 0, c8p_rawchain_push2 delivers both)                 */
   uint64_t stream_round_items; /* most NEW items one stream may receive between two c8p_rawchain_round calls                */
 } c8p_rawchain_cfg;
 
@@ -117,7 +118,8 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
 
 /* ---- live ingest (c8p_rawchain_cfg.streams = K > 0, one antenna per stream) --------------------------------------------------
  * K independent streams, each what one radio delivers: its own trigger / sync state (c8p_det_state), commit point and signal-block
- * scan position live in the handle.  Items arrive in increments of any size:
+ * scan position live in the handle (c8p_rawchain_cfg.stream_ant = 2: two antennas per stream, c8p_rawchain_push2).  Items arrive in
+ * increments of any size:
  *   c8p_rawchain_push   appends n items to one stream (device memory, or host memory — pinned: c8p_host_alloc / hipHostMalloc /
  *                       hipHostRegister; pageable works, slowly).  Nothing moves yet: the items must stay valid until the next
  *                       c8p_rawchain_round returns.  All pushes of a round are moved by ONE kernel that reads the host memory over
@@ -136,6 +138,8 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  * One thread calls push / round / drain.  The first push or round starts the session with the callback given to c8p_rawchain_live. */
 int c8p_rawchain_live(c8p_rawchain* h, c8p_rawchain_cb cb, void* user);
 int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem);
+/* stream_ant = 2: the same n items of both antennas of one stream (they advance together) */
+int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem);
 int c8p_rawchain_round(c8p_rawchain* h);
 int c8p_rawchain_round_async(c8p_rawchain* h);
 int c8p_rawchain_ingested(c8p_rawchain* h);          /* every item pushed before the last round call is on the device */

@@ -24,6 +24,24 @@ def random_stream(seed, n_pkt, snr=(6.0, 35.0)):
     return np.concatenate(parts)
 
 
+def random_stream2(seed, n_pkt, snr=(10.0, 35.0)):
+    """two antennas: packets of every fixture format incl. the two-stream ones and the NDP through a 2x2 (or 2x1) flat channel"""
+    from c8p_testlib import H22
+    rng = np.random.default_rng(seed)
+    names = list(SWEEP)
+    parts = [[], []]
+    for _ in range(n_pkt):
+        d = SWEEP[names[int(rng.integers(len(names)))]]
+        nss = int(d["nss"])
+        Hc = H22 if nss == 2 else np.array([[1.0], [0.4 - 0.7j]], np.complex64)
+        rx = np.atleast_2d(through_channel(np.atleast_2d(dewindow(d["tx"]))[:nss], Hc, float(rng.uniform(*snr)), rng, lead=int(rng.choice([150, 400, 900, 2500]))))
+        w = 2 * np.pi * float(rng.uniform(-100e3, 100e3)) / 20e6
+        rx = (rx * np.exp(1j * w * np.arange(rx.shape[1]))).astype(np.complex64)
+        parts[0].append(rx[0]); parts[1].append(rx[1])
+    tail = (0.004 * (rng.normal(size=(2, 700)) + 1j * rng.normal(size=(2, 700)))).astype(np.complex64)
+    return np.concatenate(parts[0] + [tail[0]]), np.concatenate(parts[1] + [tail[1]])
+
+
 def lay_out(xs, rng, pad=(0, 5)):
     """the streams in one arena at offsets that are not multiples of anything (padding of random length between them)"""
     offs, parts, pos = [], [], 0
@@ -307,3 +325,64 @@ def test_rawchain_host_segments_with_fewer_engine_slots(slots, monkeypatch):
             for oa, ob in zip(a["outs"], b["outs"]):
                 assert np.array_equal(a["pdu_arena"][int(oa["pdu_off"]):int(oa["pdu_off"]) + int(oa["pdu_bytes"])],
                                       b["pdu_arena"][int(ob["pdu_off"]):int(ob["pdu_off"]) + int(ob["pdu_bytes"])])
+
+
+def live_two_antennas_equal_one_pass(engine_lib, n_pkt, dev=None):
+    """three two-antenna streams pushed in ragged increments (c8p_rawchain_push2) against ONE pass per stream through
+    c8p_rawchain_run with ant1_off (rx2.grc's chain, itself compared with the oracle's chain elsewhere): per stream the same packets
+    (sync index, L-SIG fields, both ports) and PDU bytes, in order"""
+    from gr_ieee80211_amd import blocks
+    rng = np.random.default_rng(31)
+    xs = [random_stream2(400 + s, n_pkt) for s in range(3)]
+    want = []
+    for a0, a1 in xs:
+        both = np.concatenate([a0, a1])
+        got = []
+        if dev is None:
+            blocks.rawchain_run([(both.ctypes.data, len(a0), len(a0))], engine_lib=engine_lib, on_segment=got.append)
+        else:
+            import torch
+            t = torch.from_numpy(both.view(np.float32).copy()).to(dev)
+            torch.cuda.synchronize()
+            blocks.rawchain_run([(t.data_ptr(), len(a0), len(a0))], engine_lib=engine_lib, on_segment=got.append)
+        g = got[0]
+        want.append(([int(i) for i in g["pkt_index"]], g["pkts"], [g["pdu_arena"][int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes() for o in g["outs"]]))
+    got = []
+    h = blocks.RawChain(engine_lib=engine_lib, streams=3, stream_round_items=30000, stream_ant=2)
+    h.live(got.append)
+    pos = [0] * 3
+    while any(p < len(x[0]) for p, x in zip(pos, xs)):
+        for s, (a0, a1) in enumerate(xs):
+            n = min(int(rng.choice([0, 137, 2500, 9000, 29999])), len(a0) - pos[s])
+            if n:
+                h.push2(s, a0[pos[s]:pos[s] + n], a1[pos[s]:pos[s] + n])
+                pos[s] += n
+        h.round()
+    with pytest.raises(RuntimeError, match="two antennas"):
+        h.push(0, xs[0][0][:10])
+    st = h.drain()
+    h.close()
+    per = [([], [], []) for _ in range(3)]
+    for g in got:
+        for i in range(len(g["pkts"])):
+            P = per[int(g["pkt_stream"][i])]
+            o = g["outs"][i]
+            P[0].append(int(g["pkt_index"][i])); P[1].append(g["pkts"][i])
+            P[2].append(g["pdu_arena"][int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes())
+    n_pdu = 0
+    for s in range(3):
+        assert per[s][0] == want[s][0], s
+        for f in ("lsig_mcs", "lsig_len", "lsig_nsamp", "n_items", "n_ant", "cfo"):
+            assert [p[f] for p in per[s][1]] == [p[f] for p in want[s][1]], (s, f)
+        assert per[s][2] == want[s][2], s
+        assert all(int(p["n_ant"]) == 2 for p in per[s][1])
+        n_pdu += sum(1 for r in want[s][2] if r)
+    assert st["pdus"] >= n_pdu >= 3 * n_pkt // 2
+    return st
+
+
+@pytest.mark.gpu
+def test_rawchain_live_two_antenna_streams_equal_one_pass_per_stream():
+    import torch
+    from gr_ieee80211_amd import blocks
+    live_two_antennas_equal_one_pass(blocks.ENGINE_LIB, 30, torch.device("cuda:0"))

@@ -216,3 +216,9 @@ def test_rawchain_with_fewer_engine_slots(slots, monkeypatch):
         st = blocks.rawchain_run(segs, engine_lib=FAKE, on_segment=got.append, host=host)
         assert st["segments"] == 7 and st["pdus"] == 35
         assert [pdus_of(g) for g in got] == [pdus_of(g) for g in ref]
+
+
+def test_rawchain_live_two_antenna_streams_on_the_test_engine():
+    """rx2.grc's chain per live stream (c8p_rawchain_cfg.stream_ant = 2, c8p_rawchain_push2): see test_multistream"""
+    from test_multistream import live_two_antennas_equal_one_pass
+    live_two_antennas_equal_one_pass(FAKE, 8)
