@@ -107,7 +107,7 @@ class Piece(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst_off", C.c_uint64), ("n", C.c_uint64)]
 
 
-CNT_ARENA_GROWTHS, CNT_ARENA_BYTES, CNT_HOST_BYTES, CNT_DET_GIVEUPS, CNT_DET_TICKET_SCANS, CNT_SLOTS, CNT_SUBMITS = range(7)
+CNT_ARENA_GROWTHS, CNT_ARENA_BYTES, CNT_HOST_BYTES, CNT_DET_GIVEUPS, CNT_DET_TICKET_SCANS, CNT_SLOTS, CNT_SUBMITS, CNT_DET_TILE = range(8)
 
 
 class TxPkt(C.Structure):

@@ -15,7 +15,14 @@
 #pragma once
 #include "c8p_dev.h"
 
-#define C8P_DET_TILE 1984           // samples per tile (248 blocks of 8: what one k_presiso workgroup writes)
+#ifndef C8P_DET_THREADS
+#define C8P_DET_THREADS 128         // threads of a scan workgroup = blocks of 8 samples it loads (the first 8 of them are history).
+                                    // 256 until round 4; measured per 33.5 M items, packets / noise (tools/ab_scan.sh, profiles/r4a):
+                                    // 128: 81.0 / 67.0 us, 192: 82.5 / 66.7, 256: 84.0 / 66.6, 512: 112.7 / 80.4 — with two waves per
+                                    // workgroup a plateau drags one other wave through the heavy path instead of three
+#endif
+#define C8P_DET_WAVES (C8P_DET_THREADS / 64)
+#define C8P_DET_TILE ((C8P_DET_THREADS - 8) * 8)       // samples a workgroup produces: 1984 with 256 threads
 #define C8P_AC_THR 0.3f             // trigger_impl.cc:77
 #define C8P_SYNC_BUF 240            // sync_impl.h:29
 #define C8P_SYNC_RES 111            // sync_impl.h:30
@@ -105,11 +112,11 @@ __device__ __forceinline__ TrigSeg seg_wave_inclusive(TrigSeg v)
 // tile fixes the state by itself — or the start of the segment (`init`).  Plateaus are a few hundred samples long: one
 // step, one or two granules awaited in practice; a 400 000-sample carrier walks 4 steps.
 #define C8P_PRE_HALO 8
-#define C8P_PRE_OUT_BLOCKS (256 - C8P_PRE_HALO)
+#define C8P_PRE_OUT_BLOCKS (C8P_DET_THREADS - C8P_PRE_HALO)
 #ifndef C8P_PRE_RS
-#define C8P_PRE_RS 268     // (264 until round 4: rows four apart then share banks in the staging stores — SQ_LDS_BANK_CONFLICT = a third of the LDS cycles; 260 / 268 / 276 measured 1-2 % faster, profiles/r4a)
+#define C8P_PRE_RS (C8P_DET_THREADS + 12)     // 268 (264 until round 4: rows four apart then share banks in the staging stores — SQ_LDS_BANK_CONFLICT = a third of the LDS cycles; 260 / 268 / 276 measured 1-2 % faster, profiles/r4a)
 #endif
-#define C8P_DET_TILE_CAND 96        // plateaus of >= 21 samples that can END inside one tile: ends lie >= 22 apart -> <= 91
+#define C8P_DET_TILE_CAND ((C8P_DET_TILE / 22 + 8) & ~7)   // plateaus of >= 21 samples that can END inside one tile: ends lie >= 22 apart (48 at 960 samples per tile, 96 at 1984)
 
 __device__ __forceinline__ unsigned long long seg_pack(const TrigSeg& v, long long tile0)
 {
@@ -185,12 +192,12 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
   const int tid = threadIdx.x;
   const long long blk0 = tile * C8P_PRE_OUT_BLOCKS - C8P_PRE_HALO;   // first block of this workgroup
   const long long base = blk0 * 8;
-  if (x_aligned16 && base >= -hist && base + 2048 <= (long long)n) {
+  if (x_aligned16 && base >= -hist && base + 8 * C8P_DET_THREADS <= (long long)n) {
     // interior workgroup: 16-byte loads, thread tid takes samples base + 2 tid + 512 k and the next one (base is a
     // multiple of 8, so these are 16-byte aligned whenever x is: the host passes that in)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int i = 2 * tid + 512 * k;
+      const int i = 2 * tid + 2 * C8P_DET_THREADS * k;
       const float4 v = *(const float4*)(x + base + i);
       sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = mk(v.x, v.y);
       sX[((i + 1) & 7) * C8P_PRE_RS + ((i + 1) >> 3)] = mk(v.z, v.w);
@@ -198,7 +205,7 @@ __device__ __forceinline__ long long tile_windows(const cf* __restrict__ x, long
   } else {
 #pragma unroll
     for (int k = 0; k < 8; k++) {           // coalesced: thread tid loads sample base + tid + 256 k
-      const int i = tid + 256 * k;
+      const int i = tid + C8P_DET_THREADS * k;
       const long long g = base + i;
       sX[(i & 7) * C8P_PRE_RS + (i >> 3)] = (g >= -hist && g < (long long)n) ? x[g] : mk(0.f, 0.f);
     }
@@ -267,7 +274,10 @@ __device__ __forceinline__ float ac_of(const cf P, const float E) { return sqrtf
 // fail this test for whole waves, which then skip the two correctly rounded operations per sample.
 __device__ __forceinline__ bool ac_surely_below(const cf P, const float E)
 {
-  const float Ec = fminf(E, 1.0e18f);       // (keeps the square finite; a smaller E only makes the test harder to pass)
+  // E clamped to 1e18 (keeps the square finite; a smaller E only makes the test harder to pass).  E is a sum of squares: >= 0, or NaN /
+  // inf — for those bit patterns the unsigned order is the float order and NaN / inf lie above every finite value, so one unsigned min
+  // gives what fminf(E, 1e18f) gives (fminf costs a canonicalising max in front of the min)
+  const float Ec = __uint_as_float(min(__float_as_uint(E), 0x5d5e0b6bu));
   return P.x * P.x + P.y * P.y < 0.08f * Ec * Ec;
 }
 
@@ -294,8 +304,8 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
                                                  float* __restrict__ ac, cf* __restrict__ conj, int keep, int numbering, long long tile)
 {
   __shared__ TrigSeg s_cin;
-  __shared__ RunSeg s_w[4];
-  __shared__ unsigned s_wc[4];
+  __shared__ RunSeg s_w[C8P_DET_WAVES];
+  __shared__ unsigned s_wc[C8P_DET_WAVES];
   __shared__ cf sX[8 * C8P_PRE_RS];         // samples, later sufP[j][t] = sum_{i=j..7} p_i of block t
   __shared__ float sE[8 * C8P_PRE_RS];      // sufE[j][t], later the ac values on their way out
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
@@ -308,10 +318,9 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
   const int r0 = (tid - C8P_PRE_HALO) * 8;  // the same, relative to the tile
   const int nv = live ? (int)min(8ll, max(0ll, (long long)n - n0)) : 0;     // how many of the 8 exist
   const float e_prev = acv[7];               // (halo's last thread: the energy window of the item before the tile)
-  unsigned sure = 0;                         // bit j: sample j is certainly not above the threshold
+  bool maybe = false;                        // one of this thread's samples is not certainly below the threshold (a lane mask: no VALU)
 #pragma unroll
-  for (int j = 0; j < 8; j++) sure |= (unsigned)ac_surely_below(Pv[j], acv[j]) << j;
-  const bool maybe = (~sure & ((1u << nv) - 1u)) != 0;
+  for (int j = 0; j < 8; j++) maybe |= j < nv && !ac_surely_below(Pv[j], acv[j]);
   unsigned m = 0;                            // bit j: sample j is above the threshold
   if (keep || __ballot(maybe)) {
 #pragma unroll
@@ -347,18 +356,26 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
     for (int j = 0; j < 8; j++) {
       if (j < nv) { if ((m >> j) & 1u) mine.tmax = fmaxf(mine.tmax, acv[j]); else { mine.pos = r0 + j; mine.tmax = 0.f; } }
     }
+    // A wave of a FULL tile with no sample above the threshold (the plateau lies in the tile's other waves): every lane's element is
+    // {its own last sample, 0}, so the last lane's element is the wave's total without a scan, the trigger bytes are zeros, and the only
+    // thing that can happen here is that a plateau of the previous wave ends at this wave's first sample.  (Round 4: these waves ran
+    // the six scan steps and the eight-sample walk like the others — ~170 of the ~300 VALU instructions of the heavy path.)
+    const bool wave_quiet = nexist == C8P_DET_TILE && __ballot(m != 0) == 0ull;
     RunSeg inc = mine;
+    if (!wave_quiet) {
 #define C8P_RUN_STEP(CTRL, ROWS) { RunSeg u; u.pos = dpp_i<CTRL, ROWS>(-1, inc.pos); u.tmax = dpp_f<CTRL, ROWS>(0.f, inc.tmax); inc = run_combine(u, inc); }
-    C8P_RUN_STEP(0x111, 0xf) C8P_RUN_STEP(0x112, 0xf) C8P_RUN_STEP(0x114, 0xf) C8P_RUN_STEP(0x118, 0xf)
-    C8P_RUN_STEP(0x142, 0xa) C8P_RUN_STEP(0x143, 0xc)
+      C8P_RUN_STEP(0x111, 0xf) C8P_RUN_STEP(0x112, 0xf) C8P_RUN_STEP(0x114, 0xf) C8P_RUN_STEP(0x118, 0xf)
+      C8P_RUN_STEP(0x142, 0xa) C8P_RUN_STEP(0x143, 0xc)
 #undef C8P_RUN_STEP
+    }
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    RunSeg ex; ex.pos = dpp_i<0x138, 0xf>(-1, inc.pos); ex.tmax = dpp_f<0x138, 0xf>(0.f, inc.tmax);     // wave_shr:1 (lane 0: the identity)
+    RunSeg ex; ex.pos = -1; ex.tmax = 0.f;              // (a quiet wave: only its first live lane looks at it, and nothing lies before that lane)
+    if (!wave_quiet) { ex.pos = dpp_i<0x138, 0xf>(-1, inc.pos); ex.tmax = dpp_f<0x138, 0xf>(0.f, inc.tmax); }     // wave_shr:1 (lane 0: the identity)
     RunSeg pre; pre.pos = -1; pre.tmax = 0.f;
     RunSeg tot = pre;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { if (k == wv) pre = tot; tot = run_combine(tot, s_w[k]); }
+    for (int k = 0; k < C8P_DET_WAVES; k++) { if (k == wv) pre = tot; tot = run_combine(tot, s_w[k]); }
     ex = run_combine(pre, ex);
     // the tile's summary: entirely above?  its trailing run (after the last sample that is not above), if the last sample is above
     TrigSeg total;
@@ -383,6 +400,9 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
     unsigned long long packed = 0;
     bool hasc = false;
     TrigCand mc; mc.s = 0; mc.e = 0;
+    if (wave_quiet) {
+      if (tid == (wv ? wv * 64 : C8P_PRE_HALO) && r0 - rs >= 21) { hasc = true; mc.s = rs < 0 ? cin.tstart : tile0 + rs; mc.e = tile0 + r0; }
+    } else
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (j < nv) {
@@ -410,16 +430,16 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
     unsigned rank = (unsigned)__builtin_popcountll(bm & ((1ull << lane) - 1ull));
     for (int w = 0; w < wv; w++) rank += s_wc[w];
     if (hasc) tcand[tile * C8P_DET_TILE_CAND + rank] = mc;
-    if (tid == 0) tcount[tile] = (uint8_t)(s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]);
+    if (tid == 0) { unsigned tc = 0; for (int w = 0; w < C8P_DET_WAVES; w++) tc += s_wc[w]; tcount[tile] = (uint8_t)tc; }
   }
   if (!keep) return;
   // test / debug path only: presiso's two output streams
   __syncthreads();
-  if (base >= 0 && base + 2048 <= (long long)n) {
+  if (base >= 0 && base + 8 * C8P_DET_THREADS <= (long long)n) {
     // interior workgroup: 16-byte stores, thread tid stores samples base + 4 tid + 1024 k .. +3 (base is a multiple of 8)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const int i = 4 * tid + 1024 * k;
+      const int i = 4 * tid + 4 * C8P_DET_THREADS * k;
       if ((i >> 3) >= C8P_PRE_HALO) {
         const int r = (i >> 3);
         const float4 v = make_float4(sE[(i & 7) * C8P_PRE_RS + r], sE[((i + 1) & 7) * C8P_PRE_RS + r],
@@ -430,7 +450,7 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
   } else {
 #pragma unroll
     for (int k = 0; k < 8; k++) {           // coalesced: thread tid stores sample base + tid + 256 k
-      const int i = tid + 256 * k;
+      const int i = tid + C8P_DET_THREADS * k;
       const long long g = base + i;
       if ((i >> 3) >= C8P_PRE_HALO && (unsigned long long)g < n && g >= 0) ac[g] = sE[(i & 7) * C8P_PRE_RS + (i >> 3)];
     }
@@ -441,7 +461,7 @@ __device__ __forceinline__ void detect_scan_tile(const cf* __restrict__ x, long 
   }
 }
 
-__global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+__global__ __launch_bounds__(C8P_DET_THREADS, 6) void k_detect_scan(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
                                                      unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
                                                      TrigSeg init, TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
                                                      TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(256, 6) void k_detect_scan(const cf* __restrict__ x
 }
 // K streams in one launch: tile g belongs to stream tile_stream[g]; everything a tile touches is that stream's own (its items, its
 // summaries, its outputs), so the streams do not see each other
-__global__ __launch_bounds__(256, 6) void k_detect_scan_multi(const DetStreamDev* __restrict__ ds, const unsigned short* __restrict__ tile_stream,
+__global__ __launch_bounds__(C8P_DET_THREADS, 6) void k_detect_scan_multi(const DetStreamDev* __restrict__ ds, const unsigned short* __restrict__ tile_stream,
                                                            unsigned long long* __restrict__ summ, unsigned int* __restrict__ ticket,
                                                            TrigSeg* __restrict__ fin, uint8_t* __restrict__ trig,
                                                            TrigCand* __restrict__ tcand, uint8_t* __restrict__ tcount,
@@ -553,7 +573,7 @@ __global__ void k_stream_offsets(const unsigned int* __restrict__ toff, const un
 
 // the maximum of ac over the items [lo, hi) of one plateau (d_conjAc at a commit point that falls inside it), from the
 // same arithmetic as k_detect_scan; ac > 0.3 > 0 there, so the float order is the order of the bit patterns
-__global__ __launch_bounds__(256) void k_ac_range_max(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
+__global__ __launch_bounds__(C8P_DET_THREADS) void k_ac_range_max(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
                                                       long long tile_lo, long long lo, long long hi, unsigned int* __restrict__ out_bits)
 {
   __shared__ cf sX[8 * C8P_PRE_RS];

@@ -994,13 +994,13 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
     {
       KTimer kt(c, C8P_K_PRESISO);
       if (!multi)
-        hipLaunchKernelGGL(k_detect_scan, dim3((unsigned)ntile), dim3(256), 0, S.stream, d_all + H0.off + H0.n_hist, (long long)H0.n_hist,
+        hipLaunchKernelGGL(k_detect_scan, dim3((unsigned)ntile), dim3(C8P_DET_THREADS), 0, S.stream, d_all + H0.off + H0.n_hist, (long long)H0.n_hist,
                            (unsigned long long)H0.n, (int)(((uintptr_t)(d_all + H0.off + H0.n_hist) & 15u) == 0),
                            d_summ, d_cnt + 1, H0.init, (TrigSeg*)S.d_det_carry.p,
                            (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
                            (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
       else
-        hipLaunchKernelGGL(k_detect_scan_multi, dim3((unsigned)ntile), dim3(256), 0, S.stream, d_ds, d_map, d_summ, d_cnt + 1,
+        hipLaunchKernelGGL(k_detect_scan_multi, dim3((unsigned)ntile), dim3(C8P_DET_THREADS), 0, S.stream, d_ds, d_map, d_summ, d_cnt + 1,
                            (TrigSeg*)S.d_det_carry.p, (uint8_t*)S.d_det_trig.p, (TrigCand*)S.d_det_tcand.p, d_tcount,
                            (float*)S.d_det_ac.p, (cf*)S.d_det_conj.p, (int)keep, numbering);
     }
@@ -1098,7 +1098,7 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
       if (H.commit_ll <= lo) continue;
       const long long tl = lo / C8P_DET_TILE, th = (H.commit_ll - 1) / C8P_DET_TILE;
       const cf* x = d_all + H.off + H.n_hist;
-      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(256), 0, S.stream, x, (long long)H.n_hist, (unsigned long long)H.n,
+      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(C8P_DET_THREADS), 0, S.stream, x, (long long)H.n_hist, (unsigned long long)H.n,
                          (int)(((uintptr_t)x & 15u) == 0), tl, lo, H.commit_ll, d_rmax + s);
       H.want_rmax = true; any_rmax = true;
     }
@@ -1456,6 +1456,7 @@ extern "C" int64_t c8p_counter(c8p_ctx* c, int which)
     case C8P_CNT_DET_TICKET_SCANS: return c->det_ticket_scans;
     case C8P_CNT_SLOTS: return (int64_t)c->slots.size();
     case C8P_CNT_SUBMITS: return (int64_t)c->seq;
+    case C8P_CNT_DET_TILE: return C8P_DET_TILE;
     default: return C8P_EINVAL;
   }
 }

@@ -485,7 +485,8 @@ int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);
 #define C8P_CNT_DET_TICKET_SCANS 4   /* k_detect_scan launches with ticket numbering (repeats + C8P_DET_TICKETS = 1)              */
 #define C8P_CNT_SLOTS            5   /* slots of this ctx (C8P_SLOTS; 1 on a caller-provided stream): results of that many submits stay resident */
 #define C8P_CNT_SUBMITS          6
-#define C8P_CNT_COUNT            7
+#define C8P_CNT_DET_TILE         7   /* a constant of the build: items per tile of the detection scan (the tests put plateaus on tile boundaries) */
+#define C8P_CNT_COUNT            8
 int64_t c8p_counter(c8p_ctx* ctx, int which);        /* < 0: C8P_EINVAL */
 
 /* profile=1: accumulated HIP-event time and launch count of one kernel since the last reset. */

@@ -199,6 +199,7 @@ int64_t c8p_counter(c8p_ctx* c, int which)
   switch (which) {
     case C8P_CNT_SLOTS: return c->slots;
     case C8P_CNT_SUBMITS: return c->submits;
+    case C8P_CNT_DET_TILE: return 960;
     case C8P_CNT_ARENA_GROWTHS: case C8P_CNT_ARENA_BYTES: case C8P_CNT_HOST_BYTES: case C8P_CNT_DET_GIVEUPS: case C8P_CNT_DET_TICKET_SCANS: return 0;
     default: return C8P_EINVAL;
   }

@@ -215,7 +215,7 @@ def test_gpu_trigger_and_sync_on_plateau_torture_streams(seed):
 
 @pytest.mark.gpu
 def test_gpu_detect_edge_lengths_and_silence():
-    """empty / shorter than one sync window / around the 1984-sample tile / exact zeros (ac = 0/0 = NaN) / a plateau that
+    """empty / shorter than one sync window / around the scan's tile (C8P_CNT_DET_TILE items, and the 1984 of rounds 1-3) / exact zeros (ac = 0/0 = NaN) / a plateau that
     is still open when the segment ends"""
     from gr_ieee80211_amd import engine
     o = oracle()
@@ -223,7 +223,8 @@ def test_gpu_detect_edge_lengths_and_silence():
     rng = np.random.default_rng(8)
     base, _, _ = stream(NAMES[:2], CFOS[:2], seed=12)
     per = (rng.normal(size=16) + 1j * rng.normal(size=16)) * 0.2
-    for n in (0, 1, 7, 100, 239, 240, 1983, 1984, 1985, 3968, 3969, len(base)):
+    T = eng.counter(abi.CNT_DET_TILE)                                    # items per tile of the scan (960; 1984 until round 4)
+    for n in sorted({0, 1, 7, 100, 239, 240, T - 1, T, T + 1, 2 * T, 2 * T + 1, 1983, 1984, 1985, 3968, 3969, len(base)}):
         x = base[:n].copy()
         if n == 3968:
             x[1000:3000] = 0                                            # digital silence inside the segment
@@ -245,7 +246,7 @@ def test_gpu_detect_edge_lengths_and_silence():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,chunks", [(1, (5000, 20000)), (2, (300, 3000)), (3, (97, 700)), (4, (1984, 1985))])
+@pytest.mark.parametrize("seed,chunks", [(1, (5000, 20000)), (2, (300, 3000)), (3, (97, 700)), (4, (1984, 1985)), (5, (960, 961))])
 def test_gpu_detect_streaming_equals_one_shot(seed, chunks):
     """the stream cut into segments of random length, each call continuing from the state and commit point the previous one
     returned (with DET_HIST items of history in front): the union of the events and the stitched trigger bytes equal the
@@ -481,13 +482,15 @@ def test_rawchain_driver_delivers_the_pdus_of_the_serial_chain_in_order():
 @pytest.mark.gpu
 def test_gpu_detect_scan_hand_offs_under_load_and_plateaus_that_end_on_tile_boundaries(monkeypatch):
     """k_detect_scan's tiles hand their summaries to their successors inside the launch (8-byte granules, agent scope).  (1) A stream
-    built so that plateaus end exactly at, one before and one after tile boundaries (tile = 1984 items) — the quiet-tile path that
+    built so that plateaus end exactly at, one before and one after tile boundaries (tile = C8P_CNT_DET_TILE items) — the quiet-tile path that
     closes the run open at its first item, whose start k_cand_gather fills in — against the oracle.  (2) The same 2 M-item stream
     of bursts scanned 30 times while another context keeps the GPU busy with c8p_rx batches (uneven load, warm caches), tiles
     numbered by blockIdx and by tickets: every run's trigger bytes and events identical to the first."""
     from c8p_cases import cfg2_batch
     from gr_ieee80211_amd import engine
     o = oracle()
+    eng = engine.Engine(device=0)
+    T = eng.counter(abi.CNT_DET_TILE)
     rng = np.random.default_rng(8)
     per = (rng.normal(size=16) + 1j * rng.normal(size=16)) * 0.2
     noise = lambda k: 0.004 * (rng.normal(size=k) + 1j * rng.normal(size=k))
@@ -498,15 +501,15 @@ def test_gpu_detect_scan_hand_offs_under_load_and_plateaus_that_end_on_tile_boun
         lead = noise(300).astype(np.complex64)
         a1 = o.detect(np.concatenate([lead, piece]))[1]
         e_local = int(np.flatnonzero(a1 > 0.3)[-1]) + 1 - 300               # first item after the plateau, relative to the piece (the
-        gap = 1984 * (3 * k + 2) + off - pos - e_local                      # items before the piece only reach 64 items into it)
+        q = (pos + e_local + 100 + T - 1) // T + 1                          # a tile boundary far enough ahead
+        gap = T * q + off - pos - e_local                                   # items before the piece only reach 64 items into it)
         assert gap >= 100
         parts += [noise(gap), piece]
         pos += gap + len(piece)
     x = np.concatenate(parts + [noise(3000)]).astype(np.complex64)
     ev, ac, cj, trig = o.detect(x)
     ends = np.flatnonzero((ac[:-1] > 0.3) & ~(ac[1:] > 0.3)) + 1             # first item after each plateau
-    assert len(set(int(e) % 1984 for e in ends) & {0, 1, 1983}) >= 2, sorted(int(e) % 1984 for e in ends)
-    eng = engine.Engine(device=0)
+    assert len(set(int(e) % T for e in ends) & {0, 1, T - 1}) >= 2, sorted(int(e) % T for e in ends)
     for mode in ("0", "1"):
         monkeypatch.setenv("C8P_DET_TICKETS", mode)
         gev = eng.detect(x)

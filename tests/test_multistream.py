@@ -113,7 +113,7 @@ def test_detect_multi_streaming_in_ragged_increments_equals_one_shot_per_stream(
     while any(e < len(x) for e, x in zip(end, xs)):
         parts, streams, h0s, pos = [], [], [], 0
         for s, x in enumerate(xs):
-            step = int(rng.choice([0, 97, 700, 1984, 1985, 5000, 12000]))
+            step = int(rng.choice([0, 97, 700, 960, 961, 1984, 1985, 5000, 12000]))
             end[s] = min(len(x), end[s] + step)
             h0 = max(0, commit[s] - abi.DET_HIST)
             g = int(rng.integers(0, 4))
