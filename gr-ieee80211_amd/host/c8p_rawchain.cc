@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -141,10 +142,12 @@ struct run_state {
   double t0 = 0;
   c8p_rawchain_cb cb = nullptr; void* user = nullptr;
   int64_t c0[4] = {0, 0, 0, 0};           // the contexts' counters at the start: growths, giveups, ticket scans
+  std::function<void()> also_close;       // live: the queue between the caller and the first stage
   run_state() { memset(&st, 0, sizeof(st)); }
   void fail(const std::string& m)
   {
     { std::lock_guard<std::mutex> g(err_mu); if (first_err.empty()) first_err = m; }
+    if (also_close) also_close();
     q1.close(); q2.close(); sig_arenas.open();
     if (det_slots) det_slots->open();
     if (raw_arenas) raw_arenas->open();
@@ -549,7 +552,8 @@ int live_start(c8p_rawchain* H)
   L.open.assign(H->cfg.streams, stream_pos{0, 0});
   start_counters(H, L.R);
   live_session* lp = Lp.get();
-  L.t_detect = std::thread([H, lp] { lp->R.stage([&] { live_detect(H, *lp); }); if (!lp->R.first_err.empty()) lp->q0.close(); });
+  L.R.also_close = [lp] { lp->q0.close(); };      // a failing stage also ends the caller's hand-over (c8p_rawchain_round then reports the error)
+  L.t_detect = std::thread([H, lp] { lp->R.stage([&] { live_detect(H, *lp); }); });
   L.t_signal = std::thread([H, lp] { lp->R.stage([&] { live_signal(H, *lp); }); });
   L.t_rx = std::thread([H, lp] { lp->R.stage([&] { rx_stage(H, lp->R, lp->cr); }); });
   H->live = std::move(Lp);

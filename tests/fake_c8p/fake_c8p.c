@@ -171,6 +171,8 @@ int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
 }
 int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
 {
+  /* C8P_FAKE_FAIL_DETECT_MULTI_AT = k: the k-th call of a context fails (tests of the callers' error paths) */
+  { const char* e = getenv("C8P_FAKE_FAIL_DETECT_MULTI_AT"); static int calls = 0; if (e && ++calls == atoi(e)) { calls = 0; return C8P_EHIP; } }
   c->submits++;
   c->det_raw = in->raw;
   c->det_raw_n = in->n_raw;

@@ -222,3 +222,33 @@ def test_rawchain_live_two_antenna_streams_on_the_test_engine():
     """rx2.grc's chain per live stream (c8p_rawchain_cfg.stream_ant = 2, c8p_rawchain_push2): see test_multistream"""
     from test_multistream import live_two_antennas_equal_one_pass
     live_two_antennas_equal_one_pass(FAKE, 8)
+
+
+def test_rawchain_live_session_reports_a_failing_stage_and_does_not_hang(monkeypatch):
+    """the third detection pass fails inside the engine: the caller's next round() (or the drain) reports it, nothing blocks, and the
+    handle starts a clean session afterwards"""
+    monkeypatch.setenv("C8P_FAKE_FAIL_DETECT_MULTI_AT", "3")
+    x = with_tail(stream(NAMES, CFOS, snr=33.0, seed=77)[0])
+    h = blocks.RawChain(engine_lib=FAKE, streams=2, stream_round_items=8192)
+    got = []
+    h.live(got.append)
+    raised = None
+    try:
+        for r in range(12):
+            h.push(0, x[4000 * r:4000 * r + 4000])
+            h.round()
+        h.drain()
+    except RuntimeError as e:
+        raised = str(e)
+    assert raised and "c8p_detect_multi" in raised, raised
+    try:
+        h.drain()
+    except RuntimeError:
+        pass
+    monkeypatch.delenv("C8P_FAKE_FAIL_DETECT_MULTI_AT")
+    got2 = []
+    h.live(got2.append)
+    h.push(1, x[:8000]); h.round()
+    st = h.drain()
+    assert st["segments"] == 1 and len(got2) == 1
+    h.close()
