@@ -1038,9 +1038,12 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     span = n - round_items * (rounds + 3)
     off = [(s * 7919 * unit_len) % max(span, 1) for s in range(streams)]      # every stream its own stretch of the capture
 
+    sid = np.arange(streams, dtype=np.uint32)
+    offs = np.asarray(off, np.uint64)
+    cnt = np.full(streams, round_items, np.uint64)
+
     def one_round(r):
-        for s in range(streams):
-            h.push(s, (base + 8 * (off[s] + r * round_items), round_items), host=True)
+        h.pushv(sid, np.uint64(base) + np.uint64(8) * (offs + np.uint64(r * round_items)), cnt, host=True)     # one call for all streams' increments
         h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)

@@ -47,6 +47,7 @@ def lib():
         L.c8p_rawchain_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.c8p_rawchain_live.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.c8p_rawchain_push.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int32]
+        L.c8p_rawchain_pushv.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.c8p_rawchain_push2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]
         L.c8p_rawchain_round.argtypes = [C.c_void_p]
         L.c8p_rawchain_round_async.argtypes = [C.c_void_p]
@@ -330,6 +331,13 @@ class RawChain:
             self._keep.append(a)
             ptr, n = a.ctypes.data, len(a)
         self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, 0 if host else 1))
+
+    def pushv(self, streams, ptrs, counts, host=True):
+        """c8p_rawchain_pushv: many pushes in one call; streams / ptrs / counts = integer sequences (ptrs = addresses the caller keeps valid)"""
+        st = np.ascontiguousarray(streams, np.uint32)
+        pt = np.ascontiguousarray(ptrs, np.uint64)
+        ct = np.ascontiguousarray(counts, np.uint64)
+        self._chk(self.L.c8p_rawchain_pushv(self.h, len(st), st.ctypes.data, pt.ctypes.data, ct.ctypes.data, 0 if host else 1))
 
     def push2(self, stream, ant0, ant1, host=True):
         """two antennas per stream (stream_ant=2): numpy complex64 arrays of equal length, or (pointer, n) tuples"""

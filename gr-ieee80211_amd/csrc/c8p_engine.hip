@@ -1605,12 +1605,19 @@ extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, cons
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
-// thread = 16 bytes (two items) of one piece; pieces start at any item, so the first / last item of a piece may be moved alone
+// work item = 16 bytes (two items) of one piece; pieces start at any item, so the first / last item of a piece may be moved alone.
+// A bounded grid walks the work items with a stride (at most C8P_GATHER_WGS workgroups of 256 threads, four independent 16-byte loads per
+// thread and step: a 55 GB/s link with ~2.5 us of latency needs ~140 KB in flight).  Measured with 64 / 256 / 1024 workgroups and with
+// one thread per work item (65 000 workgroups): the same 54-56 GB/s, and the same slow-down of the pipeline's other kernels and
+// copies beside it — while the host-to-device direction of the link is saturated the stages' own small transfers take milliseconds,
+// whichever engine moves the bulk (NOTES/frontend.md).
+#ifndef C8P_GATHER_WGS
+#define C8P_GATHER_WGS 1024
+#endif
 struct PieceDev { const cf* src; unsigned long long dst_off, n, first; };      // first: index of the piece's first work item
-__global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+__device__ __forceinline__ void gather_item(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, float4& v, cf*& d,
+                                            int& kind)
 {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
   int lo = 0, hi = n - 1;                              // last piece whose first work item is <= i
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].first <= i) lo = mid; else hi = mid - 1; }
   const PieceDev P = pc[lo];
@@ -1620,14 +1627,31 @@ __global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const
   const unsigned a = (unsigned)(((uintptr_t)P.src >> 3) & 1u);
   const long long i0 = 2 * (long long)k - (long long)a;
   const cf* s = P.src + i0;
-  cf* d = dst + P.dst_off + i0;
-  if (i0 >= 0 && (unsigned long long)i0 + 2 <= P.n) {
-    const float4 v = *(const float4*)s;
-    if ((((uintptr_t)d) & 15u) == 0) *(float4*)d = v;
-    else { d[0] = mk(v.x, v.y); d[1] = mk(v.z, v.w); }
-  } else {
-    if (i0 >= 0 && (unsigned long long)i0 < P.n) d[0] = s[0];
-    if (i0 + 1 >= 0 && (unsigned long long)(i0 + 1) < P.n) d[1] = s[1];
+  d = dst + P.dst_off + i0;
+  if (i0 >= 0 && (unsigned long long)i0 + 2 <= P.n) { v = *(const float4*)s; kind = 3; }
+  else {
+    kind = 0;
+    v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 >= 0 && (unsigned long long)i0 < P.n) { v.x = s[0].x; v.y = s[0].y; kind |= 1; }
+    if (i0 + 1 >= 0 && (unsigned long long)(i0 + 1) < P.n) { v.z = s[1].x; v.w = s[1].y; kind |= 2; }
+  }
+}
+__device__ __forceinline__ void gather_store(const float4 v, cf* d, int kind)
+{
+  if (kind == 3 && (((uintptr_t)d) & 15u) == 0) *(float4*)d = v;
+  else { if (kind & 1) d[0] = mk(v.x, v.y); if (kind & 2) d[1] = mk(v.z, v.w); }
+}
+__global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+{
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
+    float4 v[4];
+    cf* d[4];
+    int kind[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { kind[u] = 0; if (i + u * stride < total) gather_item(dst, pc, n, i + u * stride, v[u], d[u], kind[u]); }      // four loads in flight
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (kind[u]) gather_store(v[u], d[u], kind[u]);
   }
 }
 extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces, int32_t n)
@@ -1668,7 +1692,9 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   }
   if (total == 0) return C8P_OK;
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
-  hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->copy_stream, (cf*)dst, (const PieceDev*)c->d_spans.p, n, total);
+  static const unsigned wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : (unsigned)C8P_GATHER_WGS;
+  hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)std::min<unsigned long long>((total + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream, (cf*)dst,
+                     (const PieceDev*)c->d_spans.p, n, total);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }

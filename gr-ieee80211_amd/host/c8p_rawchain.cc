@@ -628,6 +628,15 @@ extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32
 {
   return push_impl(h, stream, items, nullptr, n, mem);
 }
+extern "C" int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const c8p_c32* const* items, const uint64_t* n, int32_t mem)
+{
+  if (!h || m < 0 || (m > 0 && (!streams || !items || !n))) return C8P_EINVAL;
+  for (int32_t i = 0; i < m; i++) {
+    const int rc = push_impl(h, streams[i], items[i], nullptr, n[i], mem);
+    if (rc != C8P_OK) return rc;
+  }
+  return C8P_OK;
+}
 extern "C" int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem)
 {
   if (h && n && !ant1) { h->err = "c8p_rawchain_push2: no items for antenna 1"; return C8P_EINVAL; }

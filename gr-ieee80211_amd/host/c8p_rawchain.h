@@ -140,6 +140,8 @@ int c8p_rawchain_live(c8p_rawchain* h, c8p_rawchain_cb cb, void* user);
 int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem);
 /* stream_ant = 2: the same n items of both antennas of one stream (they advance together) */
 int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem);
+/* m pushes in one call (one antenna per stream): streams[i], items[i], n[i] */
+int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const c8p_c32* const* items, const uint64_t* n, int32_t mem);
 int c8p_rawchain_round(c8p_rawchain* h);
 int c8p_rawchain_round_async(c8p_rawchain* h);
 int c8p_rawchain_ingested(c8p_rawchain* h);          /* every item pushed before the last round call is on the device */

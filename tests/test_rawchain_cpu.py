@@ -188,6 +188,27 @@ def test_rawchain_live_streams_pushed_in_increments_equal_one_pass_per_stream(ch
     h.close()
 
 
+def test_rawchain_pushv_is_many_pushes():
+    xs = [with_tail(stream(NAMES[:3], CFOS[:3], snr=33.0, seed=700 + i)[0]) for i in range(3)]
+    ref = [chain_pdus(x)[0] for x in xs]
+    got = []
+    h = blocks.RawChain(engine_lib=FAKE, streams=3, stream_round_items=30000)
+    h.live(got.append)
+    h.pushv([0, 1, 2], [x.ctypes.data for x in xs], [len(x) for x in xs])
+    h.round()
+    st = h.drain()
+    h.close()
+    assert st["pdus"] == sum(len(r) for r in ref) == 9
+    by = {s: [] for s in range(3)}
+    for g in got:
+        recs = pdus_of(g)
+        k = 0
+        for i in range(len(g["pkts"])):
+            for _ in range(int(g["outs"]["n_pdu"][i])):
+                by[int(g["pkt_stream"][i])].append(recs[k]); k += 1
+    assert [by[s] for s in range(3)] == ref
+
+
 def test_rawchain_live_refuses_more_than_a_round_holds():
     h = blocks.RawChain(engine_lib=FAKE, streams=2, stream_round_items=4096)
     x = np.zeros(5000, np.complex64)

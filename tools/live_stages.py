@@ -24,7 +24,7 @@ pin = torch.from_numpy(np.tile(unit, reps).view(np.float32)).pin_memory()
 devt = pin.to(dev)
 torch.cuda.synchronize()
 n = pin.numel() // 2
-K, items, rounds = 64, 1 << 19, 30
+K, items, rounds = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19), 30
 for feed in ("device", "host", "device", "host"):
     base = (pin if feed == "host" else devt).data_ptr()
     per = K * (items // len(unit) + 2)
