@@ -80,7 +80,7 @@ class DetState(C.Structure):
 
 class DetectIn(C.Structure):
     _fields_ = [("mem", C.c_int32), ("keep", C.c_int32), ("raw", C.c_void_p), ("n", C.c_uint64), ("n_hist", C.c_uint64),
-                ("state", C.c_void_p), ("state_out", C.c_void_p), ("commit", C.c_void_p)]
+                ("state", C.c_void_p), ("state_out", C.c_void_p), ("commit", C.c_void_p), ("evt_host", C.c_void_p), ("evt_cap", C.c_uint64)]
 
 
 class DetStream(C.Structure):
@@ -89,7 +89,8 @@ class DetStream(C.Structure):
 
 
 class DetectMultiIn(C.Structure):
-    _fields_ = [("mem", C.c_int32), ("n_streams", C.c_int32), ("raw", C.c_void_p), ("n_raw", C.c_uint64), ("streams", C.c_void_p)]
+    _fields_ = [("mem", C.c_int32), ("n_streams", C.c_int32), ("raw", C.c_void_p), ("n_raw", C.c_uint64), ("streams", C.c_void_p),
+                ("evt_host", C.c_void_p), ("evt_cap", C.c_uint64)]
 
 
 class ReserveIn(C.Structure):

@@ -921,7 +921,8 @@ static void det_walk(DetHost& H, const TrigCand* cand, size_t ncand, int stream,
   jobs.push_back(j);
 }
 
-static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<DetHost>& hs, bool keep, bool multi)
+static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<DetHost>& hs, bool keep, bool multi, c8p_sync_evt* evt_host,
+                      uint64_t evt_cap)
 {
   Slot& S = *c->s;
   const int K = (int)hs.size();
@@ -1117,6 +1118,7 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
       if (H.nj < 0) continue;
       for (int k = H.job0; k < H.job0 + H.nj; k++) if (valid[k]) { evts.push_back(all[k]); H.n_evt++; }
     }
+    if (evt_host && !evts.empty()) memcpy(evt_host, evts.data(), sizeof(c8p_sync_evt) * (size_t)std::min<uint64_t>(evts.size(), evt_cap));
     if (!evts.empty()) {    // compacted, grouped by stream, in stream order: what the sync blocks' output streams carry
       memcpy(hp + o_out, evts.data(), sizeof(c8p_sync_evt) * evts.size());
       HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, hp + o_out, sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
@@ -1196,7 +1198,7 @@ extern "C" int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
     HIPCHK(c, hipMemcpyAsync(S.d_det_raw.p, in->raw, sizeof(cf) * in->n, hipMemcpyHostToDevice, S.stream));
     d_all = (const cf*)S.d_det_raw.p;
   }
-  if ((rc = detect_run(c, d_all, in->n, hs, in->keep != 0, false)) != C8P_OK) return rc;
+  if ((rc = detect_run(c, d_all, in->n, hs, in->keep != 0, false, in->evt_host, in->evt_cap)) != C8P_OK) return rc;
   if (in->commit) *in->commit = in->n_hist + H.commit;
   if (in->state_out) *in->state_out = H.st1;
   return C8P_OK;
@@ -1235,7 +1237,7 @@ extern "C" int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
         HIPCHK(c, hipMemcpyAsync((cf*)S.d_det_raw.p + hs[s].off, in->raw + hs[s].off, sizeof(cf) * hs[s].n_total, hipMemcpyHostToDevice, S.stream));
     d_all = (const cf*)S.d_det_raw.p;
   }
-  if ((rc = detect_run(c, d_all, in->n_raw, hs, false, true)) != C8P_OK) return rc;
+  if ((rc = detect_run(c, d_all, in->n_raw, hs, false, true, in->evt_host, in->evt_cap)) != C8P_OK) return rc;
   for (int s = 0; s < K; s++) {
     c8p_det_stream& k = in->streams[s];
     k.commit = k.n_hist + hs[s].commit; k.trig_off = hs[s].out_off; k.n_evt = hs[s].n_evt;

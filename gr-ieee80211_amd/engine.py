@@ -208,7 +208,7 @@ class Engine:
         st_out = abi.DetState()
         commit = C.c_uint64(0)
         d = abi.DetectIn(m, int(keep), r_p, n_r, int(n_hist), C.addressof(state) if state is not None else None,
-                         C.addressof(st_out), C.addressof(commit))
+                         C.addressof(st_out), C.addressof(commit), None, 0)
         self._keep = (k1, d, state, st_out, commit)
         self._chk(self.L.c8p_detect(self.ctx, C.byref(d)))
         ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)
@@ -227,7 +227,7 @@ class Engine:
             arr[s].has_state = int(st is not None)
             if st is not None:
                 C.memmove(C.addressof(arr[s].state), C.addressof(st), C.sizeof(abi.DetState))
-        din = abi.DetectMultiIn(m, K, r_p, n_r, C.addressof(arr))
+        din = abi.DetectMultiIn(m, K, r_p, n_r, C.addressof(arr), None, 0)
         self._keep = (k1, din, arr)
         self._chk(self.L.c8p_detect_multi(self.ctx, C.byref(din)))
         ev = self.fetch(abi.BUF_DET_EVT, abi.SYNC_EVT_DT)

@@ -310,11 +310,19 @@ int run_impl(c8p_rawchain* H, const c8p_rawchain_seg* segs, int64_t n_seg, bool 
         if (o.det_raw_slot) cd.out([&] { R.det_slots->acquire(); return 0; });
         o.det_begin = now_s() - R.t0;
         cd.busy([&] {
+          // the events come back with the call (evt_host); only if there are more than the buffer holds are they fetched
+          if (ev.size() < 4096) ev.resize(4096);
+          ev.resize(ev.capacity());
+          d.evt_host = ev.data(); d.evt_cap = ev.size();
           det.check(api.detect(det.c, &d), "c8p_detect");
           uint64_t bytes = 0;
           (void)api.buffer(det.c, C8P_BUF_DET_EVT, &bytes);
-          ev.resize((size_t)(bytes / sizeof(c8p_sync_evt)));
-          if (bytes) det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
+          const size_t ne = (size_t)(bytes / sizeof(c8p_sync_evt));
+          if (ne > ev.size()) {
+            ev.resize(ne + ne / 4);
+            det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
+          }
+          ev.resize(ne);
           return 0;
         });
         o.det_end = now_s() - R.t0;
@@ -443,11 +451,18 @@ void live_detect(c8p_rawchain* H, live_session& L)
       c8p_detect_multi_in d;
       memset(&d, 0, sizeof(d));
       d.mem = C8P_MEM_DEVICE; d.n_streams = (int32_t)K; d.raw = o.raw_dev; d.n_raw = (uint64_t)K * C; d.streams = ks.data();   // (antenna 0)
+      if (ev.size() < 4096) ev.resize(4096);
+      ev.resize(ev.capacity());
+      d.evt_host = ev.data(); d.evt_cap = ev.size();
       det.check(api.detect_multi(det.c, &d), "c8p_detect_multi");
       uint64_t bytes = 0;
       (void)api.buffer(det.c, C8P_BUF_DET_EVT, &bytes);
-      ev.resize((size_t)(bytes / sizeof(c8p_sync_evt)));
-      if (bytes) det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
+      const size_t ne = (size_t)(bytes / sizeof(c8p_sync_evt));
+      if (ne > ev.size()) {                            // more events than the buffer held: fetch them (and keep the larger buffer)
+        ev.resize(ne + ne / 4);
+        det.check(api.fetch(det.c, C8P_BUF_DET_EVT, ev.data(), 0, bytes), "c8p_fetch(events)");
+      }
+      ev.resize(ne);
       return 0;
     });
     size_t e = 0;

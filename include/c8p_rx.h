@@ -311,6 +311,10 @@ typedef struct c8p_detect_in {
   c8p_det_state* state_out;     /* may be NULL; receives the state at the new commit point             */
   uint64_t*      commit;        /* may be NULL; receives the new commit point (index into raw): triggers whose countdown or
                                    240-item search window runs past the end of raw are re-derived by the next call        */
+  c8p_sync_evt*  evt_host;      /* may be NULL; receives the first evt_cap sync events (what C8P_BUF_DET_EVT holds; their number =
+                                   its size / sizeof(c8p_sync_evt)): the call has them on the host anyway, this saves the caller a
+                                   c8p_fetch — one device-to-host copy and one synchronisation per call                    */
+  uint64_t       evt_cap;
 } c8p_detect_in;
 
 /* c8p_detect over K independent streams in ONE pass (one k_detect_scan launch: a tile belongs to a stream, the plateau look-back
@@ -335,6 +339,8 @@ typedef struct c8p_detect_multi_in {
   const c8p_c32* raw;       /* the arena that holds every stream's items                                                */
   uint64_t       n_raw;     /* items in it                                                                              */
   c8p_det_stream* streams;  /* [n_streams], host memory, in / out                                                       */
+  c8p_sync_evt*  evt_host;  /* as c8p_detect_in.evt_host: the events of all streams, stream after stream                    */
+  uint64_t       evt_cap;
 } c8p_detect_multi_in;
 
 /* Arena sizes known in advance: c8p_reserve grows every slot's arenas to what submits of this shape need, so that no allocation

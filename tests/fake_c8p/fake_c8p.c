@@ -167,6 +167,7 @@ int c8p_detect(c8p_ctx* c, const c8p_detect_in* in)
   free(c->det_evt); c->det_evt = NULL; c->det_nevt = 0;
   detect_stream(&c->det, in->raw, in->n, in->n_hist, !in->state && in->n_hist == 0, in->commit, &c->det_evt, &c->det_nevt);
   if (in->state_out) memset(in->state_out, 0, sizeof(*in->state_out));
+  if (in->evt_host && c->det_nevt) memcpy(in->evt_host, c->det_evt, sizeof(c8p_sync_evt) * (size_t)((uint64_t)c->det_nevt < in->evt_cap ? (uint64_t)c->det_nevt : in->evt_cap));
   return C8P_OK;
 }
 int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
@@ -193,6 +194,7 @@ int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
     k->n_evt = (uint32_t)(c->det_nevt - before);
     memset(&k->state, 0, sizeof(k->state)); k->has_state = 1;
   }
+  if (in->evt_host && c->det_nevt) memcpy(in->evt_host, c->det_evt, sizeof(c8p_sync_evt) * (size_t)((uint64_t)c->det_nevt < in->evt_cap ? (uint64_t)c->det_nevt : in->evt_cap));
   return C8P_OK;
 }
 int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in) { (void)c; (void)in; return C8P_OK; }
