@@ -4,6 +4,8 @@
  * This is the drop-in boundary for the reference's demod / demod2 / decode blocks
  * (all citations are relative to the reference tree):
  *
+ *   (entry points added later cite what they replace where they are declared: c8p_detect / c8p_detect_multi, c8p_tx, the caller-arena
+ *   copies; include/../gr-ieee80211_amd/host/c8p_rawchain.h is the chain examples/rx.grc:753-767 as a pipeline)
  *   c8p_demod()   replaces  demod_impl::general_work   lib/demod_impl.cc:59-342
  *                 and       demod2_impl::general_work  lib/demod2_impl.cc:58-349
  *   c8p_decode()  replaces  decode_impl::general_work  lib/decode_impl.cc:60-162
@@ -270,7 +272,8 @@ typedef struct c8p_signal_in {
                                 C8P_SIG_NEED_MORE) stops the scan, it and the flags behind it are C8P_SIG_PENDING.  Only the
                                 packets the block copies are copied, back to back in C8P_BUF_SIG_IQ.  The call blocks until the
                                 descriptors are known (the copies are only enqueued)                                          */
-  int32_t           n_streams; /* consume = 1.  0 or 1: evts belong to one stream.  K > 1: to K independent streams (one signal block each,
+  int32_t           n_streams; /* consume = 1.  0 or 1: evts belong to one stream.  K > 1: to K independent streams (one signal block each:
+                                 K instances of signal_impl's S_TRIGGER / S_DEMOD / S_COPY machine, lib/signal_impl.cc:68-204;
                                  c8p_sig_in.stream = 0 .. K-1), grouped by stream in ascending order and in stream order inside a group; the
                                  scan rule runs per stream, from scan_from_v[stream], and scan_next receives K positions            */
   c8p_pkt_in*       pkt_host; /* consume = 1: if not NULL, receives the n_evt descriptors (what C8P_BUF_SIG_PKT holds)         */
@@ -318,7 +321,9 @@ typedef struct c8p_detect_in {
 } c8p_detect_in;
 
 /* c8p_detect over K independent streams in ONE pass (one k_detect_scan launch: a tile belongs to a stream, the plateau look-back
- * stops at a stream's first tile): what K chains of presiso.grc + trigger + sync do to K radios.  Every stream is a streaming
+ * stops at a stream's first tile): what K chains of presiso.grc + trigger + sync do to K radios — K instances of
+ * examples/presiso.grc:37-229 -> trigger_impl::general_work (lib/trigger_impl.cc:59-117) -> sync_impl::general_work
+ * (lib/sync_impl.cc:62-192), wired per radio as in examples/rx.grc:753-767; nothing crosses from one stream to another.  Every stream is a streaming
  * c8p_detect_in of its own (history, state at its commit point) whose items lie in one arena; the fields marked "out" are written
  * back.  A stream with no new items (n == n_hist) keeps its state.  C8P_BUF_DET_EVT holds the events of stream 0, then stream 1, ...
  * (each stream's in stream order, index relative to the stream's `off`); C8P_BUF_DET_TRIG holds each stream's trigger bytes at
