@@ -1043,7 +1043,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     cnt = np.full(streams, round_items, np.uint64)
 
     def one_round(r):
-        h.pushv(sid, np.uint64(base) + np.uint64(8) * (offs + np.uint64(r * round_items)), cnt, host=True)     # one call for all streams' increments
+        h.pushv(sid, np.uint64(base) + np.uint64(8) * (offs + np.uint64(r * round_items)), cnt, host="pinned")     # one call for all streams' increments
         h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)

@@ -321,8 +321,13 @@ class RawChain:
         self._cb = _segment_callback(on_round, self.engine_lib) if on_round else None
         self._chk(self.L.c8p_rawchain_live(self.h, self._cb, None))
 
+    @staticmethod
+    def _mem(host):
+        """host: True = any host memory (C8P_MEM_HOST), False = device memory, "pinned" = host memory the device can read (the caller vouches)"""
+        return 2 if host == "pinned" else (0 if host else 1)
+
     def push(self, stream, items, host=True):
-        """items: a numpy complex64 array (host; kept alive until the next round()) or (device pointer, n) with host=False"""
+        """items: a numpy complex64 array (host; kept alive until the next round()) or (pointer, n); host: see _mem"""
         if isinstance(items, tuple):
             ptr, n = int(items[0]), int(items[1])
         else:
@@ -330,14 +335,14 @@ class RawChain:
             self._keep = getattr(self, "_keep", [])
             self._keep.append(a)
             ptr, n = a.ctypes.data, len(a)
-        self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, 0 if host else 1))
+        self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, self._mem(host)))
 
     def pushv(self, streams, ptrs, counts, host=True):
         """c8p_rawchain_pushv: many pushes in one call; streams / ptrs / counts = integer sequences (ptrs = addresses the caller keeps valid)"""
         st = np.ascontiguousarray(streams, np.uint32)
         pt = np.ascontiguousarray(ptrs, np.uint64)
         ct = np.ascontiguousarray(counts, np.uint64)
-        self._chk(self.L.c8p_rawchain_pushv(self.h, len(st), st.ctypes.data, pt.ctypes.data, ct.ctypes.data, 0 if host else 1))
+        self._chk(self.L.c8p_rawchain_pushv(self.h, len(st), st.ctypes.data, pt.ctypes.data, ct.ctypes.data, self._mem(host)))
 
     def push2(self, stream, ant0, ant1, host=True):
         """two antennas per stream (stream_ant=2): numpy complex64 arrays of equal length, or (pointer, n) tuples"""
@@ -350,7 +355,7 @@ class RawChain:
             return a.ctypes.data, len(a)
         (p0, n0), (p1, n1) = ptr(ant0), ptr(ant1)
         assert n0 == n1
-        self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, 0 if host else 1))
+        self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, self._mem(host)))
 
     def round(self, wait=True):
         """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until ingested() / drain() (they are kept here)"""

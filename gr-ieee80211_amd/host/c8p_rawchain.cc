@@ -32,7 +32,7 @@ uint64_t live_keep()
   const char* e = getenv("C8P_RAWCHAIN_KEEP");
   return e && atoll(e) >= 1024 ? (uint64_t)atoll(e) : 110000u;
 }
-const int LIVE_ARENAS = 3;
+const int LIVE_ARENAS = 3;      // (4 and 6 measured in round 4: 5-10 % slower — more rounds in flight, more transfers contending for the link)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -408,6 +408,7 @@ struct live_session {
   std::vector<stream_pos> open;
   uint64_t open_new = 0;
   uint64_t last_mark = 0;                      // copy mark of the last round handed over
+  double t_last_round = 0.0;                   // C8P_RAWCHAIN_TLOG
   std::vector<c8p_piece> pieces;               // the open round's pushes that a kernel can gather (device / pinned host memory)
 };
 
@@ -614,7 +615,7 @@ static int flush_pieces(c8p_rawchain* h)
 static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, const c8p_c32* ant1, uint64_t n, int32_t mem)
 {
   if (!h) return C8P_EINVAL;
-  if (mem != C8P_MEM_HOST && mem != C8P_MEM_DEVICE) { h->err = "bad mem kind"; return C8P_EINVAL; }
+  if (mem != C8P_MEM_HOST && mem != C8P_MEM_DEVICE && mem != C8P_MEM_PINNED) { h->err = "bad mem kind"; return C8P_EINVAL; }
   int rc = live_start(h);
   if (rc != C8P_OK) return rc;
   if ((rc = live_failed(h)) != C8P_OK) return rc;
@@ -631,7 +632,7 @@ static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, con
     // itself — no DMA engine, so the bulk does not queue in front of the stages' small descriptor and result copies.  A source the
     // device cannot read (pageable host memory) goes through c8p_copy_async at once
     c8p_piece pc;
-    pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n;
+    pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n; pc.trusted = mem != C8P_MEM_HOST; pc.rsv = 0;
     L.pieces.push_back(pc);
     if (ant1) { pc.src = ant1; pc.dst_off += h->A1; L.pieces.push_back(pc); }
     if (L.pieces.size() >= 4096 && (rc = flush_pieces(h)) != C8P_OK) return rc;
@@ -667,7 +668,11 @@ static int round_impl(c8p_rawchain* h, bool wait)
   live_session& L = *h->live;
   const c8p_api& api = h->api;
   live_round rd;
+  // C8P_RAWCHAIN_TLOG=1: where the caller's thread spends a round (stderr, one line per round)
+  static const bool tlog = getenv("C8P_RAWCHAIN_TLOG") != nullptr;
+  const double t_in = tlog ? now_s() : 0.0;
   if ((rc = flush_pieces(h)) != C8P_OK) return rc;
+  const double t_flush = tlog ? now_s() : 0.0;
   if (wait) {
     if ((rc = api.copy_wait(h->ing->c)) != C8P_OK) { h->err = std::string("c8p_copy_wait: ") + api.last_error(h->ing->c); return rc; }
   } else {
@@ -677,7 +682,9 @@ static int round_impl(c8p_rawchain* h, bool wait)
   }
   rd.r = L.round_no++; rd.arena = L.open_arena; rd.pos = L.open; rd.new_items = L.open_new;
   if (!L.q0.put(std::move(rd))) { (void)live_failed(h); return C8P_EHIP; }
+  const double t_put = tlog ? now_s() : 0.0;
   L.R.raw_arenas->acquire();                                   // the next arena: free once the round that used it is through c8p_signal
+  const double t_acq = tlog ? now_s() : 0.0;
   if ((rc = live_failed(h)) != C8P_OK) return rc;
   // every stream's last `keep` (110 000) items go with it into the next round: the detection history behind its commit point and the
   // items of packets that have begun (a flag that waits for more items is at most MAX_PKT_ITEMS back)
@@ -694,6 +701,13 @@ static int round_impl(c8p_rawchain* h, bool wait)
   rc = api.copy_spans(h->ing->c, h->arena[next], h->arena[L.open_arena], sp.data(), (int32_t)sp.size());
   if (rc != C8P_OK) { h->err = std::string("c8p_copy_spans: ") + api.last_error(h->ing->c); return rc; }
   L.open_arena = next; L.open_new = 0;
+  if (tlog) {
+    const double t_out = now_s();
+    fprintf(stderr, "[c8p_rawchain] round %llu: since last %.0f us | gather call %.0f, mark+put %.0f, arena wait %.0f, carry call %.0f us\n",
+            (unsigned long long)L.round_no - 1, 1e6 * (t_in - L.t_last_round), 1e6 * (t_flush - t_in), 1e6 * (t_put - t_flush), 1e6 * (t_acq - t_put),
+            1e6 * (t_out - t_acq));
+    L.t_last_round = t_out;
+  }
   return C8P_OK;
 }
 extern "C" int c8p_rawchain_round(c8p_rawchain* h) { return round_impl(h, true); }

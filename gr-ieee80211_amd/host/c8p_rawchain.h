@@ -120,8 +120,9 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  * K independent streams, each what one radio delivers: its own trigger / sync state (c8p_det_state), commit point and signal-block
  * scan position live in the handle (c8p_rawchain_cfg.stream_ant = 2: two antennas per stream, c8p_rawchain_push2).  Items arrive in
  * increments of any size:
- *   c8p_rawchain_push   appends n items to one stream (device memory, or host memory — pinned: c8p_host_alloc / hipHostMalloc /
- *                       hipHostRegister; pageable works, slowly).  Nothing moves yet: the items must stay valid until the next
+ *   c8p_rawchain_push   appends n items to one stream.  mem = C8P_MEM_DEVICE, C8P_MEM_PINNED (host memory the device can read:
+ *                       c8p_host_alloc / hipHostMalloc / hipHostRegister — the caller vouches for it) or C8P_MEM_HOST (any host
+ *                       memory: every piece's pointer is queried, ~4 us each, and pageable memory takes a slow staged copy).  Nothing moves yet: the items must stay valid until the next
  *                       c8p_rawchain_round returns.  All pushes of a round are moved by ONE kernel that reads the host memory over
  *                       PCIe itself (c8p_copy_gather): 54-56 GB/s whatever the size of the increments (the DMA engines fall to
  *                       18 GB/s at 256 KB copies), and the DMA queues stay free for the stages' own descriptor / result copies

@@ -50,6 +50,8 @@ extern "C" {
 /* where a caller buffer lives */
 #define C8P_MEM_HOST    0
 #define C8P_MEM_DEVICE  1
+#define C8P_MEM_PINNED  2   /* host memory the device can read (c8p_host_alloc / hipHostMalloc / hipHostRegister): accepted where a call says
+                               so (c8p_rawchain_push*); the caller vouches for it, the engine does not query the pointer              */
 
 /* packet formats: lib/cloud80211phy.h:35-40 */
 #define C8P_F_L         0
@@ -481,7 +483,9 @@ int   c8p_copy_wait(c8p_ctx* ctx);
  * over PCIe themselves, so no DMA engine is involved: bulk ingest through this call does not queue in front of the small
  * descriptor / result copies of the engine's submits (measured: with the same 268 MB per round going through c8p_copy_async, a
  * c8p_rx submit's own copies waited 5-10 ms).  A piece in pageable host memory is refused (C8P_EINVAL): use c8p_copy_async for it. */
-typedef struct c8p_piece { const c8p_c32* src; uint64_t dst_off; uint64_t n; } c8p_piece;
+typedef struct c8p_piece { const c8p_c32* src; uint64_t dst_off; uint64_t n; uint32_t trusted; uint32_t rsv; } c8p_piece;
+/* trusted = 1: the caller vouches that the device can read src (device memory, pinned host memory): no pointer query — one
+ * hipPointerGetAttributes per piece costs ~4 us, a millisecond per round of 256 pushes */
 int   c8p_copy_gather(c8p_ctx* ctx, c8p_c32* dst, const c8p_piece* pieces, int32_t n);           /* pieces: host memory */
 uint64_t c8p_copy_mark(c8p_ctx* ctx);
 int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);

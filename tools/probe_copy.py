@@ -32,7 +32,7 @@ for chunk in (256 << 20, 32 << 20, 4 << 20, 1 << 20, 256 << 10):
 from gr_ieee80211_amd import abi  # noqa: E402
 for chunk in (256 << 20, 4 << 20, 1 << 20, 256 << 10, 64 << 10):
     n = total // chunk
-    pcs = (abi.Piece * n)(*[abi.Piece(pin.data_ptr() + i * chunk, i * chunk // 8, chunk // 8) for i in range(n)])
+    pcs = (abi.Piece * n)(*[abi.Piece(pin.data_ptr() + i * chunk, i * chunk // 8, chunk // 8, 1, 0) for i in range(n)])
     for rep in range(3):
         t0 = time.perf_counter()
         rc = L.c8p_copy_gather(e.ctx, C.c_void_p(dst), pcs, n)
@@ -45,7 +45,7 @@ back = torch.empty(total, dtype=torch.uint8)
 pin.copy_(torch.arange(total, dtype=torch.int64).to(torch.uint8))
 n = 64
 chunk = total // n
-pcs = (abi.Piece * n)(*[abi.Piece(pin.data_ptr() + i * chunk + 8 * (i % 2), (i * chunk) // 8 + 3 * (i % 3), chunk // 8 - 7) for i in range(n)])
+pcs = (abi.Piece * n)(*[abi.Piece(pin.data_ptr() + i * chunk + 8 * (i % 2), (i * chunk) // 8 + 3 * (i % 3), chunk // 8 - 7, 0, 0) for i in range(n)])
 L.c8p_copy_gather(e.ctx, C.c_void_p(dst), pcs, n); L.c8p_copy_wait(e.ctx)
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
