@@ -366,6 +366,8 @@ def legs_summary(out):
             "raw_chain_first_segment_ms": g("frontend_detect", "raw_stream_to_pdus", "first_segment_ms"),
             "raw_chain_pcie": g("frontend_detect", "raw_stream_to_pdus", "pcie_inclusive", "packets_per_s"),
             "live_streams_at_realtime": g("frontend_detect", "raw_stream_to_pdus", "live_streams", "streams_at_realtime"),
+            "live_streams_sc16_at_realtime": max(g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16", "streams_at_realtime") or 0.0,
+                                                 g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16_128", "streams_at_realtime") or 0.0) or None,
             "cpu_1thread": g("cpu_baseline", "value")}
     return {k: v for k, v in legs.items() if v is not None}
 
@@ -1015,24 +1017,37 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
         more = live_streams(torch, dev, local, pin, n, unit_len, streams=256, round_items=1 << 17)
         out["live_streams"]["streams_256"] = {k: more[k] for k in ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each",
                                                                    "streams_at_realtime", "pcie_GBps", "pdus_ok", "arena_growths_in_session")}
+        # the radios' own wire format: int16 I/Q pairs (rx.grc's UHD source, otw sc16), converted on the device instead of on the host
+        f32 = pin.numpy()
+        scale = np.float32(1.02 * float(np.abs(f32).max()) / 32767.0)
+        pin16 = torch.from_numpy(np.clip(np.rint(f32 / scale), -32768, 32767).astype(np.int16)).pin_memory()
+        keys = ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each", "streams_at_realtime", "pcie_GBps",
+                "bytes_per_item_over_pcie", "packets_per_s", "pdus_ok", "arena_growths_in_session", "lookback_giveups")
+        for name, K in (("sc16", 64), ("sc16_128", 128)):
+            more = live_streams(torch, dev, local, pin16, n, unit_len, streams=K, sc16_scale=scale)
+            out["live_streams"][name] = {k: more[k] for k in keys}
+        out["live_streams"]["sc16"]["note"] = ("the same capture as int16 I/Q pairs (scale %.3e): 4 B per item over the link, converted by the gather "
+                                               "kernel; pdus_ok must equal the complex64 leg's" % float(scale))
     except Exception as e:
         out["live_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
-def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40):
+def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40, sc16_scale=None):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
     per round (26 ms of air at 20 MS/s) out of pinned host memory — every stream a different stretch of the same packet-dense
     capture — through the live ingest of host/c8p_rawchain: per round ONE c8p_detect_multi over all streams, one c8p_signal (scan
     rule per stream), one c8p_rx over the packets of all streams; detection state, commit point and scan position per stream live in
     the handle.  PCIe is in the loop (8 B per item).  x_realtime_each = air time of a round / wall time of a round: how many times
-    faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU sustains at this packet density."""
+    faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU sustains at this packet density.
+    sc16_scale: `pin` holds int16 I/Q pairs as the radio sends them (4 B per item over PCIe, C8P_MEM_SC16): the gather kernel converts."""
     from gr_ieee80211_amd import blocks
     if pin is None:
         raise RuntimeError("no pinned capture")
     per_round_pk = streams * (round_items // unit_len + 2)
     h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
-                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len)
+                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(sc16_scale or 0.0))
+    item_bytes = 4 if sc16_scale else 8
     h.live(None)                    # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
     base = pin.data_ptr()
     span = n - round_items * (rounds + 3)
@@ -1043,7 +1058,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     cnt = np.full(streams, round_items, np.uint64)
 
     def one_round(r):
-        h.pushv(sid, np.uint64(base) + np.uint64(8) * (offs + np.uint64(r * round_items)), cnt, host="pinned")     # one call for all streams' increments
+        h.pushv(sid, np.uint64(base) + np.uint64(item_bytes) * (offs + np.uint64(r * round_items)), cnt, host="pinned", sc16=bool(sc16_scale))     # one call for all streams' increments
         h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)
@@ -1058,11 +1073,11 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     per_round = dt / rounds
     return {"streams": streams, "items_per_stream_per_round": round_items, "rounds": rounds, "ms_per_round": 1e3 * per_round,
             "x_realtime_each": air / per_round, "streams_at_realtime": streams * air / per_round,
-            "pcie_GBps": 8.0 * streams * round_items / per_round / 1e9, "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
+            "pcie_GBps": float(item_bytes) * streams * round_items / per_round / 1e9, "bytes_per_item_over_pcie": item_bytes, "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
             "pdus_ok": st["pdus"], "push_and_round_calls_s": round(t_push, 4),
             "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
             "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],
-            "note": "host-fed (pinned memory, 8 B per item over PCIe, moved by the engine's gather kernel — the shader cores read the host memory, no "
+            "note": "host-fed (pinned memory, 8 B per item over PCIe — 4 B with sc16 —, moved by the engine's gather kernel — the shader cores read the host memory, no "
                     "DMA engine; c8p_rawchain_round_async: the pipeline's first stage waits for its round's items); warm-up rounds are inside "
                     "the session, so arena_growths_in_session counts them too"}
 

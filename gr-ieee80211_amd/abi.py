@@ -9,6 +9,8 @@ import numpy as np
 
 ABI_VERSION = 3
 MEM_HOST, MEM_DEVICE, MEM_PINNED = 0, 1, 2
+MEM_SC16 = 0x100          # flag on the kind for RawChain.push*: int16 I/Q pairs
+FMT_C32, FMT_SC16 = 0, 1
 F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4
@@ -105,7 +107,8 @@ class Span(C.Structure):
 
 
 class Piece(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst_off", C.c_uint64), ("n", C.c_uint64), ("trusted", C.c_uint32), ("rsv", C.c_uint32)]
+    _fields_ = [("src", C.c_void_p), ("dst_off", C.c_uint64), ("n", C.c_uint64), ("trusted", C.c_uint32), ("fmt", C.c_uint32),
+                ("scale", C.c_float), ("rsv", C.c_uint32)]
 
 
 CNT_ARENA_GROWTHS, CNT_ARENA_BYTES, CNT_HOST_BYTES, CNT_DET_GIVEUPS, CNT_DET_TICKET_SCANS, CNT_SLOTS, CNT_SUBMITS, CNT_DET_TILE = range(8)

@@ -1616,7 +1616,7 @@ extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, cons
 #ifndef C8P_GATHER_WGS
 #define C8P_GATHER_WGS 1024
 #endif
-struct PieceDev { const cf* src; unsigned long long dst_off, n, first; };      // first: index of the piece's first work item
+struct PieceDev { const cf* src; unsigned long long dst_off, n, first; float scale; unsigned rsv; };      // first: index of the piece's first work item
 __device__ __forceinline__ void gather_item(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, float4& v, cf*& d,
                                             int& kind)
 {
@@ -1656,6 +1656,57 @@ __global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const
     for (int u = 0; u < 4; u++) if (kind[u]) gather_store(v[u], d[u], kind[u]);
   }
 }
+// C8P_FMT_SC16 pieces: an item is 4 bytes at the source (int16 I, int16 Q) and a complex64 in the arena.  Work item k of a piece =
+// the 16-byte aligned chunk k of its source = its items [4k - a, 4k - a + 4), a = the items between the aligned address below the
+// source and the source; clipped to the piece.
+__device__ __forceinline__ cf sc16_item(unsigned w, float scale)
+{
+  return mk((float)(short)(w & 0xffffu) * scale, (float)(short)(w >> 16) * scale);
+}
+__device__ __forceinline__ void gather_item_sc16(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, uint4& v, cf*& d,
+                                                 int& kind, float& scale)
+{
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].first <= i) lo = mid; else hi = mid - 1; }
+  const PieceDev P = pc[lo];
+  const unsigned long long k = i - P.first;
+  const unsigned* src = (const unsigned*)P.src;
+  const unsigned a = (unsigned)(((uintptr_t)src >> 2) & 3u);
+  const long long i0 = 4 * (long long)k - (long long)a;
+  const unsigned* s = src + i0;
+  d = dst + P.dst_off + i0;
+  scale = P.scale;
+  if (i0 >= 0 && (unsigned long long)i0 + 4 <= P.n) { v = *(const uint4*)s; kind = 15; }
+  else {                                               // the piece's first or last chunk: item by item, nothing outside the piece is read
+    const long long last = (long long)P.n;
+    v = make_uint4(0u, 0u, 0u, 0u);
+    kind = 0;
+    if (i0 >= 0 && i0 < last) { v.x = s[0]; kind |= 1; }
+    if (i0 + 1 >= 0 && i0 + 1 < last) { v.y = s[1]; kind |= 2; }
+    if (i0 + 2 >= 0 && i0 + 2 < last) { v.z = s[2]; kind |= 4; }
+    if (i0 + 3 >= 0 && i0 + 3 < last) { v.w = s[3]; kind |= 8; }
+  }
+}
+__device__ __forceinline__ void gather_store_sc16(const uint4 v, cf* d, int kind, float scale)
+{
+  const cf a = sc16_item(v.x, scale), b = sc16_item(v.y, scale), c = sc16_item(v.z, scale), e = sc16_item(v.w, scale);
+  if (kind == 15 && (((uintptr_t)d) & 15u) == 0) { *(float4*)d = make_float4(a.x, a.y, b.x, b.y); *(float4*)(d + 2) = make_float4(c.x, c.y, e.x, e.y); }
+  else { if (kind & 1) d[0] = a; if (kind & 2) d[1] = b; if (kind & 4) d[2] = c; if (kind & 8) d[3] = e; }
+}
+__global__ __launch_bounds__(256) void k_copy_gather_sc16(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+{
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
+    uint4 v[4];
+    cf* d[4];
+    int kind[4];
+    float sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { kind[u] = 0; if (i + u * stride < total) gather_item_sc16(dst, pc, n, i + u * stride, v[u], d[u], kind[u], sc[u]); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (kind[u]) gather_store_sc16(v[u], d[u], kind[u], sc[u]);
+  }
+}
 extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces, int32_t n)
 {
   if (!c || n < 0 || (n > 0 && (!dst || !pieces))) return C8P_EINVAL;
@@ -1664,7 +1715,11 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   if (n == 0) return C8P_OK;
   for (int i = 0; i < n; i++) {
     if (!pieces[i].n) continue;
-    if (!pieces[i].src || ((uintptr_t)pieces[i].src & 7u)) { c->err = "c8p_copy_gather: a piece without source or not 8-byte aligned"; return C8P_EINVAL; }
+    if (pieces[i].fmt != C8P_FMT_C32 && pieces[i].fmt != C8P_FMT_SC16) { c->err = "c8p_copy_gather: unknown c8p_piece.fmt"; return C8P_EINVAL; }
+    if (!pieces[i].src || ((uintptr_t)pieces[i].src & (pieces[i].fmt == C8P_FMT_SC16 ? 3u : 7u))) {
+      c->err = "c8p_copy_gather: a piece without source or not aligned to its items (complex64: 8 bytes, sc16: 4)";
+      return C8P_EINVAL;
+    }
     if (pieces[i].trusted) continue;
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
@@ -1690,17 +1745,26 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
     // stream never idle, was measured in round 4: 64 / 256 / 1024 live streams 4.86 / 6.5 / 7.8-8.3 ms a round against 4.75 / 6.2 /
     // 7.45 with this wait — the gaps it leaves are when the stages' own small transfers get through the link, NOTES/frontend.md)
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  // one table, the complex64 pieces first, then the sc16 pieces: one upload, one kernel per format that occurs
   PieceDev* hp = (PieceDev*)c->h_spans;
-  unsigned long long total = 0;
-  for (int i = 0; i < n; i++) {
-    hp[i].src = (const cf*)pieces[i].src; hp[i].dst_off = pieces[i].dst_off; hp[i].n = pieces[i].n; hp[i].first = total;
-    total += (pieces[i].n + 1 + (((uintptr_t)pieces[i].src >> 3) & 1u)) / 2;
-  }
-  if (total == 0) return C8P_OK;
+  unsigned long long total[2] = {0, 0};
+  int cnt[2] = {0, 0};
+  for (int f = 0; f < 2; f++)
+    for (int i = 0; i < n; i++) {
+      if ((int)pieces[i].fmt != f) continue;
+      PieceDev& P = hp[cnt[0] * f + cnt[f]++];
+      P.src = (const cf*)pieces[i].src; P.dst_off = pieces[i].dst_off; P.n = pieces[i].n; P.first = total[f]; P.scale = pieces[i].scale; P.rsv = 0;
+      total[f] += f == 0 ? (pieces[i].n + 1 + (((uintptr_t)pieces[i].src >> 3) & 1u)) / 2 : (pieces[i].n + 3 + (((uintptr_t)pieces[i].src >> 2) & 3u)) / 4;
+    }
+  if (total[0] + total[1] == 0) return C8P_OK;
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
   static const unsigned wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : (unsigned)C8P_GATHER_WGS;
-  hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)std::min<unsigned long long>((total + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream, (cf*)dst,
-                     (const PieceDev*)c->d_spans.p, n, total);
+  if (total[0])
+    hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)std::min<unsigned long long>((total[0] + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream,
+                       (cf*)dst, (const PieceDev*)c->d_spans.p, cnt[0], total[0]);
+  if (total[1])
+    hipLaunchKernelGGL(k_copy_gather_sc16, dim3((unsigned)std::min<unsigned long long>((total[1] + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream,
+                       (cf*)dst, (const PieceDev*)c->d_spans.p + cnt[0], cnt[1], total[1]);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }

@@ -604,17 +604,21 @@ static int flush_pieces(c8p_rawchain* h)
   int rc = api.copy_gather(h->ing->c, dst, L.pieces.data(), (int32_t)L.pieces.size());
   if (rc == C8P_EINVAL) {                        // a piece the device cannot read: piece by piece through the DMA path
     rc = C8P_OK;
-    for (const c8p_piece& pc : L.pieces)
+    for (const c8p_piece& pc : L.pieces) {
+      if (pc.fmt != C8P_FMT_C32) { h->err = "live ingest: sc16 items must lie in device or pinned host memory (c8p_host_alloc)"; L.pieces.clear(); return C8P_EINVAL; }
       if ((rc = api.copy_async(h->ing->c, dst + pc.dst_off, pc.src, sizeof(c8p_c32) * pc.n)) != C8P_OK) break;
+    }
   }
   if (rc != C8P_OK) h->err = std::string("live ingest copy: ") + api.last_error(h->ing->c);
   L.pieces.clear();
   return rc;
 }
 
-static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, const c8p_c32* ant1, uint64_t n, int32_t mem)
+static int push_impl(c8p_rawchain* h, uint32_t stream, const void* items, const void* ant1, uint64_t n, int32_t mem_and_fmt)
 {
   if (!h) return C8P_EINVAL;
+  const bool sc16 = (mem_and_fmt & C8P_MEM_SC16) != 0;
+  const int32_t mem = mem_and_fmt & ~C8P_MEM_SC16;
   if (mem != C8P_MEM_HOST && mem != C8P_MEM_DEVICE && mem != C8P_MEM_PINNED) { h->err = "bad mem kind"; return C8P_EINVAL; }
   int rc = live_start(h);
   if (rc != C8P_OK) return rc;
@@ -633,6 +637,8 @@ static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, con
     // device cannot read (pageable host memory) goes through c8p_copy_async at once
     c8p_piece pc;
     pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n; pc.trusted = mem != C8P_MEM_HOST; pc.rsv = 0;
+    pc.fmt = sc16 ? C8P_FMT_SC16 : C8P_FMT_C32;
+    pc.scale = h->cfg.sc16_scale != 0.0f ? h->cfg.sc16_scale : 1.0f / 32767.0f;
     L.pieces.push_back(pc);
     if (ant1) { pc.src = ant1; pc.dst_off += h->A1; L.pieces.push_back(pc); }
     if (L.pieces.size() >= 4096 && (rc = flush_pieces(h)) != C8P_OK) return rc;
@@ -640,11 +646,11 @@ static int push_impl(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, con
   P.fill += n; L.open_new += n;
   return C8P_OK;
 }
-extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem)
+extern "C" int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const void* items, uint64_t n, int32_t mem)
 {
   return push_impl(h, stream, items, nullptr, n, mem);
 }
-extern "C" int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const c8p_c32* const* items, const uint64_t* n, int32_t mem)
+extern "C" int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const void* const* items, const uint64_t* n, int32_t mem)
 {
   if (!h || m < 0 || (m > 0 && (!streams || !items || !n))) return C8P_EINVAL;
   for (int32_t i = 0; i < m; i++) {
@@ -653,7 +659,7 @@ extern "C" int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* st
   }
   return C8P_OK;
 }
-extern "C" int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem)
+extern "C" int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const void* ant0, const void* ant1, uint64_t n, int32_t mem)
 {
   if (h && n && !ant1) { h->err = "c8p_rawchain_push2: no items for antenna 1"; return C8P_EINVAL; }
   return push_impl(h, stream, ant0, ant1, n, mem);

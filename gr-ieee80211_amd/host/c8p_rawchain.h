@@ -41,6 +41,8 @@ typedef struct c8p_rawchain_cfg {
   uint32_t stream_ant;         /* antennas per live stream: 0 / 1 = one (rx.grc: signal -> demod), 2 = two (rx2.grc: signal2 ->
                                   demod2; detection listens on antenna 0, c8p_rawchain_push2 delivers both)                 */
   uint64_t stream_round_items; /* most NEW items one stream may receive between two c8p_rawchain_round calls                */
+  float    sc16_scale;         /* pushes flagged C8P_MEM_SC16: item = ((float)i * sc16_scale, (float)q * sc16_scale); 0 = 1 / 32767 (UHD's)  */
+  uint32_t rsv;
 } c8p_rawchain_cfg;
 
 typedef struct c8p_rawchain_seg {
@@ -122,7 +124,10 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  * increments of any size:
  *   c8p_rawchain_push   appends n items to one stream.  mem = C8P_MEM_DEVICE, C8P_MEM_PINNED (host memory the device can read:
  *                       c8p_host_alloc / hipHostMalloc / hipHostRegister — the caller vouches for it) or C8P_MEM_HOST (any host
- *                       memory: every piece's pointer is queried, ~4 us each, and pageable memory takes a slow staged copy).  Nothing moves yet: the items must stay valid until the next
+ *                       memory: every piece's pointer is queried, ~4 us each, and pageable memory takes a slow staged copy).
+ *                       mem | C8P_MEM_SC16: the items are int16 I/Q pairs as the radio sends them (4 bytes per item over the link
+ *                       instead of 8; converted in the gather kernel with c8p_rawchain_cfg.sc16_scale, include/c8p_rx.h
+ *                       C8P_FMT_SC16; device or pinned memory only).  Nothing moves yet: the items must stay valid until the next
  *                       c8p_rawchain_round returns.  All pushes of a round are moved by ONE kernel that reads the host memory over
  *                       PCIe itself (c8p_copy_gather): 54-56 GB/s whatever the size of the increments (the DMA engines fall to
  *                       18 GB/s at 256 KB copies), and the DMA queues stay free for the stages' own descriptor / result copies
@@ -138,11 +143,11 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  *                       nothing); the handle can start another one (all streams from the constructor state).
  * One thread calls push / round / drain.  The first push or round starts the session with the callback given to c8p_rawchain_live. */
 int c8p_rawchain_live(c8p_rawchain* h, c8p_rawchain_cb cb, void* user);
-int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const c8p_c32* items, uint64_t n, int32_t mem);
+int c8p_rawchain_push(c8p_rawchain* h, uint32_t stream, const void* items, uint64_t n, int32_t mem);
 /* stream_ant = 2: the same n items of both antennas of one stream (they advance together) */
-int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const c8p_c32* ant0, const c8p_c32* ant1, uint64_t n, int32_t mem);
+int c8p_rawchain_push2(c8p_rawchain* h, uint32_t stream, const void* ant0, const void* ant1, uint64_t n, int32_t mem);
 /* m pushes in one call (one antenna per stream): streams[i], items[i], n[i] */
-int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const c8p_c32* const* items, const uint64_t* n, int32_t mem);
+int c8p_rawchain_pushv(c8p_rawchain* h, int32_t m, const uint32_t* streams, const void* const* items, const uint64_t* n, int32_t mem);
 int c8p_rawchain_round(c8p_rawchain* h);
 int c8p_rawchain_round_async(c8p_rawchain* h);
 int c8p_rawchain_ingested(c8p_rawchain* h);          /* every item pushed before the last round call is on the device */

@@ -221,7 +221,16 @@ int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span*
 int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
 {
   (void)c;
-  for (int i = 0; i < n; i++) memmove(dst + pc[i].dst_off, pc[i].src, sizeof(c8p_c32) * (size_t)pc[i].n);
+  for (int i = 0; i < n; i++) {
+    if (pc[i].fmt == C8P_FMT_SC16) {          /* ((float)i * scale, (float)q * scale): one float32 multiply each, as the header says */
+      const int16_t* s = (const int16_t*)pc[i].src;
+      for (uint64_t k = 0; k < pc[i].n; k++) {
+        c8p_c32* d = dst + pc[i].dst_off + k;
+        d->re = (float)s[2 * k] * pc[i].scale; d->im = (float)s[2 * k + 1] * pc[i].scale;
+      }
+    } else if (pc[i].fmt == C8P_FMT_C32) memmove(dst + pc[i].dst_off, pc[i].src, sizeof(c8p_c32) * (size_t)pc[i].n);
+    else return C8P_EINVAL;
+  }
   return C8P_OK;
 }
 int c8p_copy_wait(c8p_ctx* c) { (void)c; return C8P_OK; }

@@ -208,15 +208,23 @@ def oracle_chain(o, x):
     return pk[kept], [int(ev[i]["index"]) for i in kept], oracle_rx(pk[kept], iq, chan), len(ev)
 
 
+def to_sc16(x, scale):
+    """what the radio sent: int16 I/Q pairs, and the complex64 stream a host-side conversion (UHD's: one float32 multiply per
+    component) makes of them — the stream the reference's first block sees"""
+    q = np.clip(np.rint(x.view(np.float32) / np.float32(scale)), -32768, 32767).astype(np.int16)
+    return q, (q.astype(np.float32) * np.float32(scale)).view(np.complex64)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("feed", ["host", "device"])
+@pytest.mark.parametrize("feed", ["host", "device", "host-sc16", "device-sc16"])
 def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain_per_stream(feed):
     """K = 8 random streams (every one-stream format / MCS, carrier offsets of +-150 kHz, SNRs from 6 to 35 dB so that many fail
     their FCS, gaps from 150 items up so that some preambles are missed or merged; one stream is silence, one starts late) pushed in
     increments of random size per stream and round — rounds end inside preambles, inside packets, inside plateaus — through the live
     ingest of host/c8p_rawchain (one c8p_detect_multi, one c8p_signal, one c8p_rx per round) and through the oracle's detect -> signal
     (+ scan rule) -> demod + decode over each whole stream: per stream, in order, the same kept packets (sync index, L-SIG fields), the
-    same PDUs and FCS-failure counts."""
+    same PDUs and FCS-failure counts.  -sc16: the streams arrive as int16 I/Q pairs (C8P_MEM_SC16, 4 bytes per item over the link) and
+    are converted by the gather kernel; the oracle runs over the host-side conversion of the same pairs."""
     import torch
     from gr_ieee80211_amd import blocks
     dev = torch.device("cuda:0")
@@ -226,11 +234,18 @@ def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain
     xs.insert(3, (0.004 * (rng.normal(size=90000) + 1j * rng.normal(size=90000))).astype(np.complex64))
     K = len(xs)
     late = 5                                            # this stream delivers nothing during the first rounds
-    ts = [torch.from_numpy(x.view(np.float32).copy()) for x in xs]
+    sc16 = feed.endswith("-sc16")
+    feed = feed.split("-")[0]
+    scale = np.float32(1.02 * max(float(np.abs(x.view(np.float32)).max()) for x in xs) / 32767.0)
+    if sc16:
+        qs, xs = zip(*[to_sc16(x, scale) for x in xs])
+        ts = [torch.from_numpy(q.copy()) for q in qs]
+    else:
+        ts = [torch.from_numpy(x.view(np.float32).copy()) for x in xs]
     ts = [t.pin_memory() if feed == "host" else t.to(dev) for t in ts]
     torch.cuda.synchronize()
     got = []
-    h = blocks.RawChain(streams=K, stream_round_items=40000, reserve_seg_packets=64, reserve_pkt_items=6000)
+    h = blocks.RawChain(streams=K, stream_round_items=40000, reserve_seg_packets=64, reserve_pkt_items=6000, sc16_scale=float(scale))
     h.live(got.append)
     pos = [0] * K
     r = 0
@@ -241,7 +256,7 @@ def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain
                 n = 0
             n = min(n, len(x) - pos[s])
             if n:
-                h.push(s, (ts[s].data_ptr() + 8 * pos[s], n), host=(feed == "host"))
+                h.push(s, (ts[s].data_ptr() + (4 if sc16 else 8) * pos[s], n), host=("pinned" if sc16 else True) if feed == "host" else False, sc16=sc16)
                 pos[s] += n
         h.round(wait=(feed == "host"))             # device feed: c8p_rawchain_round_async (the detect stage waits for the round's copies)
         r += 1
@@ -386,3 +401,48 @@ def test_rawchain_live_two_antenna_streams_equal_one_pass_per_stream():
     import torch
     from gr_ieee80211_amd import blocks
     live_two_antennas_equal_one_pass(blocks.ENGINE_LIB, 30, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment():
+    """c8p_copy_gather, C8P_FMT_SC16: pieces that start and end at any 4-byte item of pinned host memory, into any 8-byte item of the
+    arena, mixed with complex64 pieces in one call — every destination item = ((float)i * scale, (float)q * scale) bit for bit, nothing
+    outside the pieces is written; pageable or 2-byte aligned sources are refused"""
+    import ctypes as C
+    import torch
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(5)
+    e = engine.Engine(device=0)
+    L = e.L
+    n_src = 1 << 16
+    q = torch.from_numpy(rng.integers(-32768, 32768, size=2 * n_src, dtype=np.int16)).pin_memory()
+    f = torch.from_numpy((rng.normal(size=2 * 4096)).astype(np.float32)).pin_memory()
+    scale = np.float32(3.1e-5)
+    n_dst = 1 << 17
+    dst = torch.full((2 * n_dst,), -7.0, dtype=torch.float32, device="cuda:0")
+    want = np.full(2 * n_dst, -7.0, np.float32)
+    pcs, pos = [], 3
+    qn = q.numpy()
+    for i in range(40):
+        a = int(rng.integers(0, n_src - 3000))
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 64, 1000, 2999]))
+        pcs.append(abi.Piece(q.data_ptr() + 4 * a, pos, n, 1, abi.FMT_SC16, float(scale), 0))
+        want[2 * pos:2 * (pos + n)] = qn[2 * a:2 * (a + n)].astype(np.float32) * scale
+        pos += n + int(rng.integers(0, 4))
+        if i % 9 == 4:                               # a complex64 piece between them
+            m = int(rng.integers(1, 300))
+            pcs.append(abi.Piece(f.data_ptr() + 8 * 5, pos, m, 1, abi.FMT_C32, 0.0, 0))
+            want[2 * pos:2 * (pos + m)] = f.numpy()[10:10 + 2 * m]
+            pos += m + 1
+    arr = (abi.Piece * len(pcs))(*pcs)
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), arr, len(pcs)) == 0, L.c8p_last_error(e.ctx)
+    assert L.c8p_copy_wait(e.ctx) == 0
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    odd = (abi.Piece * 1)(abi.Piece(q.data_ptr() + 2, 0, 8, 1, abi.FMT_SC16, float(scale), 0))
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), odd, 1) == -22
+    pageable = np.zeros(64, np.int16)
+    pg = (abi.Piece * 1)(abi.Piece(pageable.ctypes.data, 0, 8, 0, abi.FMT_SC16, float(scale), 0))
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), pg, 1) == -22
+    bad = (abi.Piece * 1)(abi.Piece(q.data_ptr(), 0, 8, 1, 7, float(scale), 0))
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), bad, 1) == -22
+    e.close()
