@@ -573,23 +573,35 @@ __global__ void k_stream_offsets(const unsigned int* __restrict__ toff, const un
 
 // the maximum of ac over the items [lo, hi) of one plateau (d_conjAc at a commit point that falls inside it), from the
 // same arithmetic as k_detect_scan; ac > 0.3 > 0 there, so the float order is the order of the bit patterns
-__global__ __launch_bounds__(C8P_DET_THREADS) void k_ac_range_max(const cf* __restrict__ x, long long hist, unsigned long long n, int x_aligned16,
-                                                      long long tile_lo, long long lo, long long hi, unsigned int* __restrict__ out_bits)
+struct RmaxJob {            // one stream's plateau that is open at its commit point
+  const cf* x;              // the stream's first new item
+  long long hist;
+  unsigned long long n;
+  long long tile_lo, lo, hi;
+  unsigned int* out_bits;
+  unsigned first;           // index of the job's first workgroup in the launch
+  int x_aligned16;
+};
+// (one launch for all streams: a launch per stream was 30-250 small kernels in a row per round of 256 live streams)
+__global__ __launch_bounds__(C8P_DET_THREADS) void k_ac_range_max(const RmaxJob* __restrict__ jobs, int nj)
 {
   __shared__ cf sX[8 * C8P_PRE_RS];
   __shared__ float sE[8 * C8P_PRE_RS];
   cf Pv[8];
   float Ev[8];
-  const long long base = tile_windows(x, hist, n, tile_lo + blockIdx.x, x_aligned16, sX, sE, Pv, Ev);
+  int lo_j = 0, hi_j = nj - 1;
+  while (lo_j < hi_j) { const int mid = (lo_j + hi_j + 1) >> 1; if (jobs[mid].first <= blockIdx.x) lo_j = mid; else hi_j = mid - 1; }
+  const RmaxJob J = jobs[lo_j];
+  const long long base = tile_windows(J.x, J.hist, J.n, J.tile_lo + (long long)(blockIdx.x - J.first), J.x_aligned16, sX, sE, Pv, Ev);
   if (threadIdx.x < C8P_PRE_HALO) return;
   float m = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const long long g = base + threadIdx.x * 8 + j;
     const float a = ac_of(Pv[j], Ev[j]);
-    if (g >= lo && g < hi && a > m) m = a;
+    if (g >= J.lo && g < J.hi && a > m) m = a;
   }
-  if (m > 0.f) atomicMax(out_bits, __float_as_uint(m));
+  if (m > 0.f) atomicMax(J.out_bits, __float_as_uint(m));
 }
 
 // the host adds the trigger bits (0x01) it derived from the candidates

@@ -30,6 +30,28 @@
     }                                                                                      \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------ uploads of the engine's own staging
+// A submit's descriptors travel from PINNED staging memory (h_stage) to the device.  Through a DMA engine (hipMemcpyAsync) that is a
+// handful of read requests in flight; beside a bulk ingest that keeps megabytes of reads outstanding on the same link (c8p_copy_gather)
+// each of them waits its turn and a few hundred KB take milliseconds (NOTES/frontend.md).  k_pull has every 16 bytes requested at once
+// by its own lane: one trip through the link's queue for the whole table.  C8P_UPLOAD=dma: the copy engines, as before round 4.
+__global__ void k_pull(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, size_t tail_bytes)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+  else if (i - n16 < tail_bytes) ((unsigned char*)(dst + n16))[i - n16] = ((const unsigned char*)(src + n16))[i - n16];
+}
+static hipError_t upload(hipStream_t st, void* dst, const void* src_pinned, size_t bytes)
+{
+  static const bool dma = [] { const char* e = getenv("C8P_UPLOAD"); return e && !strcmp(e, "dma"); }();
+  if (bytes == 0) return hipSuccess;
+  if (dma || (((uintptr_t)dst | (uintptr_t)src_pinned) & 15u) || bytes < 1024)
+    return hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, st);
+  const size_t n16 = bytes / 16, tail = bytes % 16, thr = n16 + tail;
+  hipLaunchKernelGGL(k_pull, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, (uint4*)dst, (const uint4*)src_pinned, n16, tail);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ tables
 // Generated from the 802.11 formulas, not copied; tests compare them with SHA-256
 // digests of the reference's literals and with the Python toolbox's interleavers.
@@ -614,7 +636,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   }
   {
     KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+    HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, stage_bytes));
   }
 
   {
@@ -697,7 +719,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   }
   {
     KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+    HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, stage_bytes));
   }
   c->s->used[C8P_BUF_TAGS] = sizeof(c8p_pkt_tags) * (size_t)n; c->s->ptr[C8P_BUF_TAGS] = d_tags;
   return run_decode_kernels(c, n, d_tags, d_lay, d_llr, d_mu, P, nullptr, (const FinCold*)((char*)c->s->d_stage.p + o_cold));
@@ -735,7 +757,7 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
   if ((rc = ensure(c, c->s->d_stage, stage_bytes)) != C8P_OK) return rc;
   memcpy((char*)c->s->h_stage + o_ev, in->evts, sizeof(c8p_sig_in) * (size_t)n);
   memcpy((char*)c->s->h_stage + o_off, off.data(), sizeof(uint64_t) * (size_t)n);
-  HIPCHK(c, hipMemcpyAsync(c->s->d_stage.p, c->s->h_stage, stage_bytes, hipMemcpyHostToDevice, c->s->stream));
+  HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, stage_bytes));
   const cf* d_raw = (const cf*)in->raw;
   if (in->mem == C8P_MEM_HOST) {
     if ((rc = ensure(c, c->s->d_sig_raw, sizeof(cf) * in->n_raw)) != C8P_OK) return rc;
@@ -805,9 +827,9 @@ extern "C" int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)
     if ((rc = ensure(c, S.d_sig_iq, sizeof(cf) * std::max<uint64_t>(tot, 2))) != C8P_OK) return rc;
     if ((rc = ensure(c, S.d_sig_kept, sizeof(int) * (size_t)std::max(nk, 1))) != C8P_OK) return rc;
     if (in->pkt_host) memcpy(in->pkt_host, hpk, sizeof(c8p_pkt_in) * (size_t)n);
-    HIPCHK(c, hipMemcpyAsync(S.d_sig_pkt.p, hpk, sizeof(c8p_pkt_in) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    HIPCHK(c, upload(S.stream, S.d_sig_pkt.p, hpk, sizeof(c8p_pkt_in) * (size_t)n));
     if (nk) {
-      HIPCHK(c, hipMemcpyAsync(S.d_sig_kept.p, kept, sizeof(int) * (size_t)nk, hipMemcpyHostToDevice, S.stream));
+      HIPCHK(c, upload(S.stream, S.d_sig_kept.p, kept, sizeof(int) * (size_t)nk));
       KTimer kt(c, C8P_K_SIGNAL);
       hipLaunchKernelGGL(k_signal_copy, dim3(nk), dim3(64), 0, S.stream, d_ev, d_raw, (const c8p_pkt_in*)S.d_sig_pkt.p,
                          (const int*)S.d_sig_kept.p, (cf*)S.d_sig_iq.p, nk);
@@ -860,11 +882,12 @@ static int ensure_detect_arenas(c8p_ctx* c, Slot& S, uint64_t out_items, size_t 
   if ((rc = ensure(c, S.d_det_soff, sizeof(unsigned) * (size_t)(K + 1))) != C8P_OK) return rc;
   return C8P_OK;
 }
-static int ensure_detect_jobs(c8p_ctx* c, Slot& S, size_t nf, size_t njobs)
+static size_t rmax_jobs_off(size_t njobs) { return (sizeof(SyncJob) * njobs + 63) & ~(size_t)63; }      // the range-maximum jobs follow the sync jobs
+static int ensure_detect_jobs(c8p_ctx* c, Slot& S, size_t nf, size_t njobs, size_t K)
 {
   int rc;
   if ((rc = ensure(c, S.d_det_fire, sizeof(unsigned long long) * std::max<size_t>(nf, 1))) != C8P_OK) return rc;
-  if ((rc = ensure(c, S.d_det_job, sizeof(SyncJob) * njobs)) != C8P_OK) return rc;
+  if ((rc = ensure(c, S.d_det_job, rmax_jobs_off(njobs) + sizeof(RmaxJob) * std::max<size_t>(K, 1))) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_mark, sizeof(SyncMark) * njobs)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_evt, sizeof(c8p_sync_evt) * njobs)) != C8P_OK) return rc;
   if ((rc = ensure(c, S.d_det_valid, sizeof(int) * njobs)) != C8P_OK) return rc;
@@ -984,7 +1007,7 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
       unsigned short* hm = (unsigned short*)(hp + o_up + map_off);
       for (int s = 0; s < K; s++) for (int t = 0; t < hs[s].ntile; t++) hm[hs[s].tile_base + (unsigned)t] = (unsigned short)s;
     }
-    HIPCHK(c, hipMemcpyAsync(S.d_det_ds.p, hp + o_up, up_bytes, hipMemcpyHostToDevice, S.stream));
+    HIPCHK(c, upload(S.stream, S.d_det_ds.p, hp + o_up, up_bytes));
   }
   const DetHost& H0 = hs[0];
   const char* ft_env = getenv("C8P_DET_TICKETS");
@@ -1061,13 +1084,14 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
   const size_t o_fire = 0, o_job = (o_fire + sizeof(unsigned long long) * (size_t)(nf + 1) + 15) & ~(size_t)15;
   const size_t o_mark = o_job + sizeof(SyncJob) * (size_t)(NJ + 1), o_evt = o_mark + sizeof(SyncMark) * (size_t)(NJ + 1);
   const size_t o_val = o_evt + sizeof(c8p_sync_evt) * (size_t)(NJ + 1), o_rm = (o_val + sizeof(int) * (size_t)(NJ + 1) + 63) & ~(size_t)63;
-  const size_t o_out = (o_rm + sizeof(unsigned) * (size_t)K + 63) & ~(size_t)63;
+  const size_t o_rmj = (o_rm + sizeof(unsigned) * (size_t)K + 63) & ~(size_t)63;
+  const size_t o_out = (o_rmj + sizeof(RmaxJob) * (size_t)K + 63) & ~(size_t)63;
   if ((rc = ensure_host(c, o_out + sizeof(c8p_sync_evt) * (size_t)(NJ + 1) + 64)) != C8P_OK) return rc;   // (phase-1 data is consumed)
   hp = (char*)S.h_stage;
-  if ((rc = ensure_detect_jobs(c, S, (size_t)nf, (size_t)NJ + 1)) != C8P_OK) return rc;
+  if ((rc = ensure_detect_jobs(c, S, (size_t)nf, (size_t)NJ + 1, (size_t)K)) != C8P_OK) return rc;
   if (nf) {
     memcpy(hp + o_fire, fire.data(), sizeof(unsigned long long) * (size_t)nf);
-    HIPCHK(c, hipMemcpyAsync(S.d_det_fire.p, hp + o_fire, sizeof(unsigned long long) * (size_t)nf, hipMemcpyHostToDevice, S.stream));
+    HIPCHK(c, upload(S.stream, S.d_det_fire.p, hp + o_fire, sizeof(unsigned long long) * (size_t)nf));
     hipLaunchKernelGGL(k_trig_fire, dim3((nf + 255) / 256), dim3(256), 0, S.stream, (uint8_t*)S.d_det_trig.p,
                        (const unsigned long long*)S.d_det_fire.p, nf);
   }
@@ -1075,7 +1099,7 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
   bool any_rmax = false;
   if (NJ) {
     memcpy(hp + o_job, jobs.data(), sizeof(SyncJob) * (size_t)NJ);
-    HIPCHK(c, hipMemcpyAsync(S.d_det_job.p, hp + o_job, sizeof(SyncJob) * (size_t)NJ, hipMemcpyHostToDevice, S.stream));
+    HIPCHK(c, upload(S.stream, S.d_det_job.p, hp + o_job, sizeof(SyncJob) * (size_t)NJ));
     {
       KTimer kt(c, C8P_K_SYNCEVT);
       hipLaunchKernelGGL(k_sync_mark, dim3(NJ), dim3(64), 0, S.stream, (const SyncJob*)S.d_det_job.p, (const uint8_t*)S.d_det_trig.p, d_ds,
@@ -1090,6 +1114,8 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
     }
     // d_conjAc at a commit point inside a plateau: maximum of ac over the plateau so far.  ac is not stored: the same arithmetic
     // once more over the tiles that stretch of the plateau touches
+    int n_rmj = 0;
+    unsigned rm_blocks = 0;
     for (int s = 0; s < K; s++) {
       DetHost& H = hs[s];
       H.want_rmax = false;
@@ -1099,9 +1125,16 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
       if (H.commit_ll <= lo) continue;
       const long long tl = lo / C8P_DET_TILE, th = (H.commit_ll - 1) / C8P_DET_TILE;
       const cf* x = d_all + H.off + H.n_hist;
-      hipLaunchKernelGGL(k_ac_range_max, dim3((unsigned)(th - tl + 1)), dim3(C8P_DET_THREADS), 0, S.stream, x, (long long)H.n_hist, (unsigned long long)H.n,
-                         (int)(((uintptr_t)x & 15u) == 0), tl, lo, H.commit_ll, d_rmax + s);
+      RmaxJob& J = ((RmaxJob*)(hp + o_rmj))[n_rmj++];
+      J.x = x; J.hist = (long long)H.n_hist; J.n = (unsigned long long)H.n; J.tile_lo = tl; J.lo = lo; J.hi = H.commit_ll; J.out_bits = d_rmax + s;
+      J.first = rm_blocks; J.x_aligned16 = (int)(((uintptr_t)x & 15u) == 0);
+      rm_blocks += (unsigned)(th - tl + 1);
       H.want_rmax = true; any_rmax = true;
+    }
+    if (n_rmj) {
+      RmaxJob* d_rmj = (RmaxJob*)((char*)S.d_det_job.p + rmax_jobs_off((size_t)NJ + 1));
+      HIPCHK(c, upload(S.stream, d_rmj, hp + o_rmj, sizeof(RmaxJob) * (size_t)n_rmj));
+      hipLaunchKernelGGL(k_ac_range_max, dim3(rm_blocks), dim3(C8P_DET_THREADS), 0, S.stream, (const RmaxJob*)d_rmj, n_rmj);
     }
     HIPCHK(c, hipGetLastError());
     lap("second phase enqueue");
@@ -1121,7 +1154,7 @@ static int detect_run(c8p_ctx* c, const cf* d_all, uint64_t n_all, std::vector<D
     if (evt_host && !evts.empty()) memcpy(evt_host, evts.data(), sizeof(c8p_sync_evt) * (size_t)std::min<uint64_t>(evts.size(), evt_cap));
     if (!evts.empty()) {    // compacted, grouped by stream, in stream order: what the sync blocks' output streams carry
       memcpy(hp + o_out, evts.data(), sizeof(c8p_sync_evt) * evts.size());
-      HIPCHK(c, hipMemcpyAsync(S.d_det_evt.p, hp + o_out, sizeof(c8p_sync_evt) * evts.size(), hipMemcpyHostToDevice, S.stream));
+      HIPCHK(c, upload(S.stream, S.d_det_evt.p, hp + o_out, sizeof(c8p_sync_evt) * evts.size()));
     }
   }
   // ---- state at the new commit points
@@ -1502,10 +1535,10 @@ extern "C" int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in)
       if ((rc = ensure_detect_arenas(c, S, out_items, ntile, cap, K, in->det_keep != 0, Z.bytes)) != C8P_OK) break;
       if (in->det_host && (rc = ensure(c, S.d_det_raw, sizeof(cf) * in->det_items)) != C8P_OK) break;
       const size_t nj = (size_t)in->det_events + (size_t)K + 1;
-      if ((rc = ensure_detect_jobs(c, S, nj, nj)) != C8P_OK) break;
+      if ((rc = ensure_detect_jobs(c, S, nj, nj, (size_t)K)) != C8P_OK) break;
       // the pinned exchanges of one call: phase 1 [descriptors | tile map | counters | offsets | final segs | candidates], phase 2 [fires | jobs | marks | events | valid | maxima | events]
       const size_t ph1 = sizeof(DetStreamDev) * (size_t)K + 2 * ntile + 512 + 4 * (size_t)(K + 1) + sizeof(TrigSeg) * (size_t)K + 256 + sizeof(TrigCand) * std::min<size_t>(cap, 8192);
-      const size_t ph2 = (8 + sizeof(SyncJob) + sizeof(SyncMark) + 2 * sizeof(c8p_sync_evt) + 4) * (nj + 1) + 4 * (size_t)K + 512;
+      const size_t ph2 = (8 + sizeof(SyncJob) + sizeof(SyncMark) + 2 * sizeof(c8p_sync_evt) + 4) * (nj + 1) + (4 + sizeof(RmaxJob)) * (size_t)K + 768;
       if ((rc = ensure_host(c, std::max(ph1, ph2))) != C8P_OK) break;
     }
   }

@@ -41,6 +41,18 @@ for chunk in (256 << 20, 4 << 20, 1 << 20, 256 << 10, 64 << 10):
         t2 = time.perf_counter()
     assert rc == 0, (rc, L.c8p_last_error(e.ctx))
     print("gather %8d KB x %5d pieces: call %7.1f us, total %7.2f ms = %5.1f GB/s" % (chunk >> 10, n, 1e6 * (t1 - t0), 1e3 * (t2 - t0), total / (t2 - t0) / 1e9))
+dst2 = L.c8p_dev_alloc(e.ctx, 2 * total)                 # sc16: 4 B per item at the source, 8 B in the arena
+for chunk in (256 << 20, 4 << 20, 1 << 20, 256 << 10):
+    n = total // chunk
+    pcs = (abi.Piece * n)(*[abi.Piece(pin.data_ptr() + i * chunk, i * chunk // 4, chunk // 4, 1, abi.FMT_SC16, 3.0e-5, 0) for i in range(n)])
+    for rep in range(3):
+        t0 = time.perf_counter()
+        rc = L.c8p_copy_gather(e.ctx, C.c_void_p(dst2), pcs, n)
+        t1 = time.perf_counter()
+        L.c8p_copy_wait(e.ctx)
+        t2 = time.perf_counter()
+    assert rc == 0, (rc, L.c8p_last_error(e.ctx))
+    print("gather sc16 %5d KB x %5d pieces: call %7.1f us, total %7.2f ms = %5.1f GB/s over the link" % (chunk >> 10, n, 1e6 * (t1 - t0), 1e3 * (t2 - t0), total / (t2 - t0) / 1e9))
 back = torch.empty(total, dtype=torch.uint8)
 pin.copy_(torch.arange(total, dtype=torch.int64).to(torch.uint8))
 n = 64
