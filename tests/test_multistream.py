@@ -446,3 +446,31 @@ def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment():
     bad = (abi.Piece * 1)(abi.Piece(q.data_ptr(), 0, 8, 1, 7, float(scale), 0))
     assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), bad, 1) == -22
     e.close()
+
+
+@pytest.mark.gpu
+def test_copy_spans_moves_exactly_the_spans():
+    """c8p_copy_spans (the carry of every live stream's tail into the next round's arena): spans of any length (none, one item, across
+    chunk boundaries) at any item offsets of source and destination — the spans arrive, nothing else is touched"""
+    import ctypes as C
+    import torch
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(9)
+    e = engine.Engine(device=0)
+    L = e.L
+    n = 1 << 18
+    src = torch.from_numpy(rng.normal(size=2 * n).astype(np.float32)).to("cuda:0")
+    dst = torch.full((2 * n,), -3.0, dtype=torch.float32, device="cuda:0")
+    want = np.full(2 * n, -3.0, np.float32)
+    sh = src.cpu().numpy()
+    spans, pos = [], 1
+    for m in [0, 1, 2, 63, 64, 65, 511, 512, 513, 1023, 1025, 4097, 30000, 7, 0, 110000]:
+        a = int(rng.integers(0, n - m))
+        spans.append(abi.Span(pos, a, m))
+        want[2 * pos:2 * (pos + m)] = sh[2 * a:2 * (a + m)]
+        pos += m + int(rng.integers(0, 3))
+    arr = (abi.Span * len(spans))(*spans)
+    assert L.c8p_copy_spans(e.ctx, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), arr, len(spans)) == 0, L.c8p_last_error(e.ctx)
+    assert L.c8p_copy_wait(e.ctx) == 0
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    e.close()

@@ -53,6 +53,18 @@ for chunk in (256 << 20, 4 << 20, 1 << 20, 256 << 10):
         t2 = time.perf_counter()
     assert rc == 0, (rc, L.c8p_last_error(e.ctx))
     print("gather sc16 %5d KB x %5d pieces: call %7.1f us, total %7.2f ms = %5.1f GB/s over the link" % (chunk >> 10, n, 1e6 * (t1 - t0), 1e3 * (t2 - t0), total / (t2 - t0) / 1e9))
+for K, keep in ((64, 110000), (256, 110000), (1024, 110000)):           # the live carry: K spans of `keep` items between two arenas
+    Cn = keep + 32768
+    a0 = L.c8p_dev_alloc(e.ctx, 8 * K * Cn)
+    a1 = L.c8p_dev_alloc(e.ctx, 8 * K * Cn)
+    sp = (abi.Span * K)(*[abi.Span(s * Cn, s * Cn + 32768 - (s % 2), keep) for s in range(K)])
+    for rep in range(3):
+        t0 = time.perf_counter()
+        L.c8p_copy_spans(e.ctx, C.c_void_p(a1), C.c_void_p(a0), sp, K)
+        L.c8p_copy_wait(e.ctx)
+        t2 = time.perf_counter()
+    print("carry of %4d spans x %d items: %6.3f ms = %5.2f TB/s read + written" % (K, keep, 1e3 * (t2 - t0), 16.0 * K * keep / (t2 - t0) / 1e12))
+    L.c8p_dev_free(e.ctx, C.c_void_p(a0)); L.c8p_dev_free(e.ctx, C.c_void_p(a1))
 back = torch.empty(total, dtype=torch.uint8)
 pin.copy_(torch.arange(total, dtype=torch.int64).to(torch.uint8))
 n = 64
