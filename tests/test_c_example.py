@@ -108,6 +108,41 @@ def test_live_example_compiles_as_plain_c11_and_runs_on_the_test_engine(tmp_path
     check_live_output(r.stdout, want, 3)
 
 
+def sc16_files(tmp_path, xs):
+    """the captures as the radios would send them (int16 I/Q pairs) and the scale that turns them back into floats"""
+    scale = np.float32(1.02 * max(float(np.abs(x.view(np.float32)).max()) for x in xs) / 32767.0)
+    files = []
+    for i, x in enumerate(xs):
+        f = tmp_path / ("radio%d.sc16" % i)
+        np.clip(np.rint(x.astype(np.complex64).view(np.float32) / scale), -32768, 32767).astype(np.int16).tofile(f)
+        files.append(str(f))
+    return files, scale
+
+
+def test_live_example_takes_sc16_captures_on_the_test_engine(tmp_path):
+    """-s scale: the files hold int16 I/Q pairs, pushed with C8P_MEM_PINNED | C8P_MEM_SC16 out of c8p_host_alloc memory"""
+    build_live()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "fake_c8p")])
+    xs, want = live_streams_of(900)
+    files, scale = sc16_files(tmp_path, xs)
+    r = subprocess.run([LIVE, "-l", os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so"), "-r", "7000", "-s", repr(float(scale))] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    check_live_output(r.stdout, want, 3)
+
+
+@pytest.mark.gpu
+def test_live_example_takes_sc16_captures_on_the_engine(tmp_path):
+    build_live()
+    xs, want = live_streams_of(910)
+    files, scale = sc16_files(tmp_path, xs)
+    r = subprocess.run([LIVE, "-l", os.path.join(ROOT, "gr-ieee80211_amd", "libc8p_rx.so"), "-r", "9000", "-s", repr(float(scale))] + files,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    check_live_output(r.stdout, want, 3)
+
+
 @pytest.mark.gpu
 def test_live_example_on_the_engine(tmp_path):
     build_live()

@@ -342,13 +342,23 @@ def test_rawchain_host_segments_with_fewer_engine_slots(slots, monkeypatch):
                                       b["pdu_arena"][int(ob["pdu_off"]):int(ob["pdu_off"]) + int(ob["pdu_bytes"])])
 
 
-def live_two_antennas_equal_one_pass(engine_lib, n_pkt, dev=None):
+def live_two_antennas_equal_one_pass(engine_lib, n_pkt, dev=None, sc16=False):
     """three two-antenna streams pushed in ragged increments (c8p_rawchain_push2) against ONE pass per stream through
     c8p_rawchain_run with ant1_off (rx2.grc's chain, itself compared with the oracle's chain elsewhere): per stream the same packets
-    (sync index, L-SIG fields, both ports) and PDU bytes, in order"""
+    (sync index, L-SIG fields, both ports) and PDU bytes, in order.  sc16: both antennas arrive as int16 I/Q pairs (C8P_MEM_SC16); the
+    one pass runs over their host-side conversion"""
     from gr_ieee80211_amd import blocks
     rng = np.random.default_rng(31)
     xs = [random_stream2(400 + s, n_pkt) for s in range(3)]
+    scale, qs = 0.0, None
+    if sc16:
+        scale = np.float32(1.02 * max(float(np.abs(a.view(np.float32)).max()) for x in xs for a in x) / 32767.0)
+        conv = [[to_sc16(a, scale) for a in x] for x in xs]
+        qs = [[c[0] for c in cs] for cs in conv]
+        xs = [tuple(np.ascontiguousarray(c[1]) for c in cs) for cs in conv]
+        if dev is not None:                      # the device reads the pairs itself: pinned memory
+            import torch
+            qs = [[torch.from_numpy(q.copy()).pin_memory() for q in qq] for qq in qs]
     want = []
     for a0, a1 in xs:
         both = np.concatenate([a0, a1])
@@ -363,13 +373,17 @@ def live_two_antennas_equal_one_pass(engine_lib, n_pkt, dev=None):
         g = got[0]
         want.append(([int(i) for i in g["pkt_index"]], g["pkts"], [g["pdu_arena"][int(o["pdu_off"]):int(o["pdu_off"]) + int(o["pdu_bytes"])].tobytes() for o in g["outs"]]))
     got = []
-    h = blocks.RawChain(engine_lib=engine_lib, streams=3, stream_round_items=30000, stream_ant=2)
+    h = blocks.RawChain(engine_lib=engine_lib, streams=3, stream_round_items=30000, stream_ant=2, sc16_scale=float(scale))
     h.live(got.append)
     pos = [0] * 3
     while any(p < len(x[0]) for p, x in zip(pos, xs)):
         for s, (a0, a1) in enumerate(xs):
             n = min(int(rng.choice([0, 137, 2500, 9000, 29999])), len(a0) - pos[s])
-            if n:
+            if n and sc16:
+                p0, p1 = ((q.data_ptr() if dev is not None else q.ctypes.data) + 4 * pos[s] for q in qs[s])
+                h.push2(s, (p0, n), (p1, n), host="pinned", sc16=True)
+                pos[s] += n
+            elif n:
                 h.push2(s, a0[pos[s]:pos[s] + n], a1[pos[s]:pos[s] + n])
                 pos[s] += n
         h.round()
@@ -401,6 +415,7 @@ def test_rawchain_live_two_antenna_streams_equal_one_pass_per_stream():
     import torch
     from gr_ieee80211_amd import blocks
     live_two_antennas_equal_one_pass(blocks.ENGINE_LIB, 30, torch.device("cuda:0"))
+    live_two_antennas_equal_one_pass(blocks.ENGINE_LIB, 20, torch.device("cuda:0"), sc16=True)
 
 
 @pytest.mark.gpu

@@ -279,6 +279,7 @@ def test_rawchain_live_two_antenna_streams_on_the_test_engine():
     """rx2.grc's chain per live stream (c8p_rawchain_cfg.stream_ant = 2, c8p_rawchain_push2): see test_multistream"""
     from test_multistream import live_two_antennas_equal_one_pass
     live_two_antennas_equal_one_pass(FAKE, 8)
+    live_two_antennas_equal_one_pass(FAKE, 6, sc16=True)
 
 
 def test_rawchain_live_session_reports_a_failing_stage_and_does_not_hang(monkeypatch):
