@@ -339,3 +339,67 @@ def count_pdus(counts, outs_all):
         n_pdu += int(rec[:, 0].sum())
         n_fail += int(rec[:, 1].sum())
     return n_pdu, n_fail
+
+
+# ------------------------------------------------------------------------------------------------ live streams
+class LiveShard:
+    """K independent live streams over the GPUs of one node: stream g belongs to ONE rank (contiguous blocks, `partition(K, world, rank)`),
+    which runs it through its own host/c8p_rawchain handle on its own GPU — detection state, commit point and scan position of a stream
+    never leave its rank, so there is no exchange step and no collective in the data path (weak scaling in the number of radios).
+    `summary()` all-reduces the counts for a report; the PDUs stay where their radio's consumer is."""
+
+    def __init__(self, n_streams, stream_round_items, device=0, group=None, on_round=None, **rawchain_kw):
+        from . import blocks
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi = partition(int(n_streams), self.world, self.rank)
+        self.n_streams = int(n_streams)
+        self.h = blocks.RawChain(device=device, streams=max(self.hi - self.lo, 1), stream_round_items=stream_round_items, **rawchain_kw) \
+            if self.hi > self.lo else None
+        self._on_round = on_round
+        if self.h is not None:
+            self.h.live(self._deliver if on_round else None)
+        self.stats = None
+
+    def owner(self, g):
+        """rank that serves global stream g"""
+        for r in range(self.world):
+            lo, hi = partition(self.n_streams, self.world, r)
+            if lo <= g < hi:
+                return r
+        raise IndexError(g)
+
+    def mine(self):
+        return range(self.lo, self.hi)
+
+    def _deliver(self, g):
+        g["pkt_stream_global"] = g["pkt_stream"].astype(np.int64) + self.lo
+        self._on_round(g)
+
+    def push(self, g, items, **kw):
+        """items of GLOBAL stream g (must be one of mine())"""
+        if not self.lo <= g < self.hi:
+            raise ValueError("stream %d belongs to rank %d, not %d" % (g, self.owner(g), self.rank))
+        self.h.push(g - self.lo, items, **kw)
+
+    def round(self, wait=True):
+        if self.h is not None:
+            self.h.round(wait=wait)
+
+    def drain(self):
+        self.stats = self.h.drain() if self.h is not None else {"pdus": 0, "packets": 0, "events": 0, "items": 0, "segments": 0}
+        return self.stats
+
+    def summary(self, device="cpu"):
+        """whole-job counts (all ranks): pdus, packets, events, items"""
+        st = self.stats if self.stats is not None else self.drain()
+        t = torch.tensor([st["pdus"], st["packets"], st["events"], st["items"]], dtype=torch.int64, device=device)
+        if dist.is_initialized() and self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return dict(zip(("pdus", "packets", "events", "items"), (int(v) for v in t.cpu())))
+
+    def close(self):
+        if self.h is not None:
+            self.h.close()
+            self.h = None

@@ -177,3 +177,104 @@ def test_sharded_stream_matches_single_process(world):
         assert tmax == float(world)
         assert got == want
         assert n_pdu == len(want) and n_fail == sum(int(r["out"]["n_crc_fail"]) for r in ref)
+
+
+# ------------------------------------------------------------------------------------------------ live streams over ranks
+FAKE = os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so")
+
+
+def _live_streams(K):
+    from test_detect_frontend import CFOS, NAMES, stream
+    rng = np.random.default_rng(5)
+    xs = []
+    for g in range(K):
+        nm = NAMES[g % 3:g % 3 + 4 + g % 2]
+        tail = 0.004 * (rng.normal(size=700) + 1j * rng.normal(size=700))
+        xs.append(np.concatenate([stream(nm, CFOS[:len(nm)], snr=33.0, seed=300 + g)[0], tail]).astype(np.complex64))
+    return xs
+
+
+def _live_run(ls, xs, per_round):
+    """every rank pushes ITS streams in increments; returns {global stream: [PDU bytes in order]}"""
+    pos = {g: 0 for g in ls.mine()}
+    while any(pos[g] < len(xs[g]) for g in pos):
+        for g in pos:
+            n = min(per_round + 37 * g, len(xs[g]) - pos[g])
+            if n:
+                ls.push(g, xs[g][pos[g]:pos[g] + n])
+                pos[g] += n
+        ls.round()
+    return ls.drain()
+
+
+def _worker_live(rank, world, port, q, K):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for d in (ROOT, os.path.join(ROOT, "tests")):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xs = _live_streams(K)
+    per = {}
+
+    def on_round(g):
+        from test_rawchain_cpu import pdus_of
+        recs, k = pdus_of(g), 0
+        for i in range(len(g["pkts"])):
+            for _ in range(int(g["outs"]["n_pdu"][i])):
+                per.setdefault(int(g["pkt_stream_global"][i]), []).append(recs[k]); k += 1
+    ls = shard.LiveShard(K, 20000, on_round=on_round, engine_lib=FAKE)
+    assert [ls.owner(g) for g in ls.mine()] == [rank] * len(ls.mine())
+    with pytest.raises(ValueError):
+        ls.push((ls.hi) % K if world > 1 else K, xs[0][:10])        # somebody else's stream
+    _live_run(ls, xs, 6000)
+    tot = ls.summary()
+    ls.close()
+    q.put((rank, per, tot))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K", [(2, 5), (3, 4)])
+def test_live_streams_sharded_over_ranks_equal_one_handle(world, K):
+    """shard.LiveShard: K live streams over `world` ranks (contiguous blocks; every rank its own rawchain handle, here on the oracle-backed
+    test engine), no collective in the data path: per GLOBAL stream the PDUs of a single-process handle that serves all K, and the
+    all-reduced totals"""
+    import subprocess
+    from gr_ieee80211_amd import blocks
+    from test_rawchain_cpu import pdus_of
+    for d in ("oracle", os.path.join("tests", "fake_c8p"), os.path.join("gr-ieee80211_amd", "host")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, d)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_live, args=(r, world, port, q, K)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xs = _live_streams(K)
+    ref = {}
+    h = blocks.RawChain(engine_lib=FAKE, streams=K, stream_round_items=20000)
+
+    def on_round(g):
+        recs, k = pdus_of(g), 0
+        for i in range(len(g["pkts"])):
+            for _ in range(int(g["outs"]["n_pdu"][i])):
+                ref.setdefault(int(g["pkt_stream"][i]), []).append(recs[k]); k += 1
+    h.live(on_round)
+    for g, x in enumerate(xs):
+        h.push(g, x[:20000]); 
+    h.round()
+    for g, x in enumerate(xs):
+        h.push(g, x[20000:])
+    h.round()
+    st = h.drain()
+    h.close()
+    merged = {}
+    for rank, per, tot in outs:
+        assert not set(per) & set(merged)
+        merged.update(per)
+        assert tot["pdus"] == st["pdus"] and tot["items"] == st["items"] == sum(len(x) for x in xs) and tot["events"] == st["events"]
+    assert merged == ref and len(ref) == K and st["pdus"] >= 4 * K
