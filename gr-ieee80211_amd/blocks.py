@@ -22,6 +22,8 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libc8p_blocks.so is not built (make -C gr-ieee80211_amd/host)")
+        from .engine import prefer_torch_hip_runtime
+        prefer_torch_hip_runtime()         # (libc8p_blocks.so dlopens the engine library, which brings in a HIP runtime)
         L = C.CDLL(LIB_PATH)
         L.c8ph_create.restype = C.c_void_p
         L.c8ph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]

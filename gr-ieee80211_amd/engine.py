@@ -24,10 +24,34 @@ SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_deco
 _LIB = None
 
 
+def prefer_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so; libc8p_rx.so is linked against the system's.
+    Whichever is loaded first serves both (same soname) — and torch on top of the system's newer runtime reports "No HIP GPUs are
+    available", while the engine runs on either.  So if torch is installed but not imported yet, its runtime is loaded first (the
+    library only, not the package): a later `import torch` in the same process then finds the runtime it was built for."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    prefer_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libc8p_rx.so is not built (run `python __graft_entry__.py` / make -C gr-ieee80211_amd/csrc); "
                            "there is no CPU fallback")

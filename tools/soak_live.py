@@ -2,7 +2,8 @@
 """tools/soak_live.py [streams] [packets per stream] [sessions] — the LIVE ingest of host/c8p_rawchain (push / round / drain; one and two
 antennas per stream) against the oracle's detect -> signal (+ scan rule) -> demod + decode over each whole stream: random streams
 (every fixture format, carrier offsets of +-150 kHz, 6-35 dB, gaps from 150 items), pushed in increments of random size per stream and
-round; per stream the same kept packets (sync index, L-SIG fields), PDUs and FCS-failure counts, in order.  Run on the GPU box."""
+round; per stream the same kept packets (sync index, L-SIG fields), PDUs and FCS-failure counts, in order.  Sessions 2, 3 (mod 4) deliver
+int16 I/Q pairs out of pinned memory (C8P_MEM_SC16); the oracle then runs over their host-side conversion.  Run on the GPU box."""
 import os
 import sys
 import time
@@ -11,11 +12,13 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
+import torch  # noqa: E402
+torch.cuda.init()                  # (before the engine library brings up its own view of the runtime: pinned sc16 buffers come from torch)
 from bench import usable_cores  # noqa: E402
 from c8p_testlib import oracle, oracle_rx  # noqa: E402
 from gr_ieee80211_amd import blocks  # noqa: E402
 from test_detect_frontend import scan_rule, sig_events  # noqa: E402
-from test_multistream import random_stream, random_stream2  # noqa: E402
+from test_multistream import random_stream, random_stream2, to_sc16  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 120
@@ -43,15 +46,30 @@ for sess in range(sessions):
     n_ant = 1 + sess % 2
     rng = np.random.default_rng(5000 + sess)
     xs = [(random_stream(7000 + 100 * sess + s, per), None) if n_ant == 1 else random_stream2(7000 + 100 * sess + s, per, snr=(6.0, 35.0)) for s in range(K)]
+    sc16 = (sess // 2) % 2 == 1
+    scale, qs = 0.0, None
+    if sc16:
+        scale = np.float32(1.02 * max(float(np.abs(a.view(np.float32)).max()) for x in xs for a in x if a is not None) / 32767.0)
+        conv = [[to_sc16(a, scale) if a is not None else None for a in x] for x in xs]
+        qs = [[torch.from_numpy(c[0].copy()).pin_memory() if c is not None else None for c in cs] for cs in conv]
+        xs = [tuple(np.ascontiguousarray(c[1]) if c is not None else None for c in cs) for cs in conv]
+        tot["sc16_sessions"] = tot.get("sc16_sessions", 0) + 1
     got = []
-    h = blocks.RawChain(streams=K, stream_round_items=60000, stream_ant=n_ant)
+    h = blocks.RawChain(streams=K, stream_round_items=60000, stream_ant=n_ant, sc16_scale=float(scale))
     h.live(got.append)
     pos = [0] * K
     rounds = 0
     while any(p < len(x[0]) for p, x in zip(pos, xs)):
         for s, (a0, a1) in enumerate(xs):
             n = min(int(rng.choice([0, 0, 137, 1000, 2500, 9000, 20000, 59999])), len(a0) - pos[s])
-            if n:
+            if n and sc16:
+                p0 = qs[s][0].data_ptr() + 4 * pos[s]
+                if n_ant == 1:
+                    h.push(s, (p0, n), host="pinned", sc16=True)
+                else:
+                    h.push2(s, (p0, n), (qs[s][1].data_ptr() + 4 * pos[s], n), host="pinned", sc16=True)
+                pos[s] += n
+            elif n:
                 if n_ant == 1:
                     h.push(s, a0[pos[s]:pos[s] + n])
                 else:
@@ -83,7 +101,8 @@ for sess in range(sessions):
             tot["pdus"] += len(r["pdus"]); tot["fcs_fail"] += int(r["out"]["n_crc_fail"])
         tot["streams"] += 1; tot["items"] += len(xs[s][0]); tot["kept"] += len(idx); tot["mismatch"] += 0 if ok else 1
     tot["sessions"] += 1; tot["rounds"] += rounds
-print("live-ingest soak: %(sessions)d sessions (one and two antennas alternating), %(streams)d streams, %(items)d items in %(rounds)d rounds, "
+tot.setdefault("sc16_sessions", 0)
+print("live-ingest soak: %(sessions)d sessions (one and two antennas alternating, %(sc16_sessions)d of them fed sc16), %(streams)d streams, %(items)d items in %(rounds)d rounds, "
       "%(kept)d packets kept, %(pdus)d PDUs, %(fcs_fail)d FCS failures, %(mismatch)d streams that differ from the oracle's chain" % tot,
       "(%.0f s)" % (time.time() - t0))
 sys.exit(1 if tot["mismatch"] else 0)
