@@ -368,6 +368,7 @@ def legs_summary(out):
             "live_streams_at_realtime": g("frontend_detect", "raw_stream_to_pdus", "live_streams", "streams_at_realtime"),
             "live_streams_sc16_at_realtime": max(g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16", "streams_at_realtime") or 0.0,
                                                  g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16_128", "streams_at_realtime") or 0.0) or None,
+            "live_streams_sc8_at_realtime": g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc8_128", "streams_at_realtime"),
             "cpu_1thread": g("cpu_baseline", "value")}
     return {k: v for k, v in legs.items() if v is not None}
 
@@ -1026,6 +1027,11 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
         for name, K in (("sc16", 64), ("sc16_128", 128)):
             more = live_streams(torch, dev, local, pin16, n, unit_len, streams=K, sc16_scale=scale)
             out["live_streams"][name] = {k: more[k] for k in keys}
+        # UHD's narrower wire format, int8 pairs: 2 B per item — the link no longer binds, the chain's kernels do
+        scale8 = np.float32(1.02 * float(np.abs(f32).max()) / 127.0)
+        pin8 = torch.from_numpy(np.clip(np.rint(f32 / scale8), -128, 127).astype(np.int8)).pin_memory()
+        more = live_streams(torch, dev, local, pin8, n, unit_len, streams=128, sc16_scale=scale8, bits=8)
+        out["live_streams"]["sc8_128"] = {k: more[k] for k in keys}
         out["live_streams"]["sc16"]["note"] = ("the same capture as int16 I/Q pairs (scale %.3e): 4 B per item over the link, converted by the gather "
                                                "kernel; pdus_ok must equal the complex64 leg's" % float(scale))
     except Exception as e:
@@ -1033,21 +1039,22 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
     return out
 
 
-def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40, sc16_scale=None):
+def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40, sc16_scale=None, bits=16):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
     per round (26 ms of air at 20 MS/s) out of pinned host memory — every stream a different stretch of the same packet-dense
     capture — through the live ingest of host/c8p_rawchain: per round ONE c8p_detect_multi over all streams, one c8p_signal (scan
     rule per stream), one c8p_rx over the packets of all streams; detection state, commit point and scan position per stream live in
     the handle.  PCIe is in the loop (8 B per item).  x_realtime_each = air time of a round / wall time of a round: how many times
     faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU sustains at this packet density.
-    sc16_scale: `pin` holds int16 I/Q pairs as the radio sends them (4 B per item over PCIe, C8P_MEM_SC16): the gather kernel converts."""
+    sc16_scale: `pin` holds int16 (bits = 8: int8) I/Q pairs as the radio sends them (4 / 2 B per item over PCIe, C8P_MEM_SC16 / _SC8):
+    the gather kernel converts."""
     from gr_ieee80211_amd import blocks
     if pin is None:
         raise RuntimeError("no pinned capture")
     per_round_pk = streams * (round_items // unit_len + 2)
     h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
-                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(sc16_scale or 0.0))
-    item_bytes = 4 if sc16_scale else 8
+                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(sc16_scale or 0.0), sc8_scale=float(sc16_scale or 0.0))
+    item_bytes = (bits // 4) if sc16_scale else 8
     h.live(None)                    # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
     base = pin.data_ptr()
     span = n - round_items * (rounds + 3)
@@ -1058,7 +1065,7 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     cnt = np.full(streams, round_items, np.uint64)
 
     def one_round(r):
-        h.pushv(sid, np.uint64(base) + np.uint64(item_bytes) * (offs + np.uint64(r * round_items)), cnt, host="pinned", sc16=bool(sc16_scale))     # one call for all streams' increments
+        h.pushv(sid, np.uint64(base) + np.uint64(item_bytes) * (offs + np.uint64(r * round_items)), cnt, host="pinned", sc16=bits if sc16_scale else False)     # one call for all streams' increments
         h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)

@@ -222,7 +222,7 @@ class _RawCfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("lib", C.c_char_p), ("reserve_seg_items", C.c_uint64),
                 ("reserve_seg_events", C.c_uint32), ("reserve_seg_packets", C.c_uint32), ("reserve_pkt_items", C.c_uint32),
                 ("reserve_host", C.c_int32), ("reserve_ant", C.c_int32), ("streams", C.c_uint32), ("stream_ant", C.c_uint32),
-                ("stream_round_items", C.c_uint64), ("sc16_scale", C.c_float), ("rsv", C.c_uint32)]
+                ("stream_round_items", C.c_uint64), ("sc16_scale", C.c_float), ("sc8_scale", C.c_float)]
 
 
 def _stats_dict(st):
@@ -266,12 +266,12 @@ class RawChain:
     reserve_*: arena shapes sized at create; streams / stream_round_items: live ingest of K independent streams (push / round / drain)."""
 
     def __init__(self, device=0, engine_lib=None, reserve_seg_items=0, reserve_seg_events=0, reserve_seg_packets=0, reserve_pkt_items=0,
-                 reserve_host=False, reserve_ant=1, streams=0, stream_round_items=0, stream_ant=1, sc16_scale=0.0):
+                 reserve_host=False, reserve_ant=1, streams=0, stream_round_items=0, stream_ant=1, sc16_scale=0.0, sc8_scale=0.0):
         self.L = lib()
         self.engine_lib = engine_lib or ENGINE_LIB
         cfg = _RawCfg(C.sizeof(_RawCfg), device, self.engine_lib.encode(), int(reserve_seg_items), int(reserve_seg_events),
                       int(reserve_seg_packets), int(reserve_pkt_items), int(bool(reserve_host)), int(reserve_ant), int(streams), int(stream_ant),
-                      int(stream_round_items), float(sc16_scale), 0)
+                      int(stream_round_items), float(sc16_scale), float(sc8_scale))
         err = C.create_string_buffer(512)
         self.h = self.L.c8p_rawchain_create(C.byref(cfg), err, len(err))
         if not self.h:
@@ -332,29 +332,34 @@ class RawChain:
         """(pointer, items) of a push argument: a (pointer, n) tuple, a complex64 array, or — sc16 — an int16 array of I/Q pairs"""
         if isinstance(a, tuple):
             return int(a[0]), int(a[1])
-        a = np.ascontiguousarray(a, np.int16 if sc16 else np.complex64)
+        a = np.ascontiguousarray(a, np.int8 if sc16 == 8 else (np.int16 if sc16 else np.complex64))
         self._keep = getattr(self, "_keep", [])
         self._keep.append(a)
         return a.ctypes.data, a.size // 2 if sc16 else len(a)
+
+    @staticmethod
+    def _fmt(sc16):
+        """sc16: False = complex64 items, True / 16 = int16 pairs (C8P_MEM_SC16), 8 = int8 pairs (C8P_MEM_SC8)"""
+        return 0x200 if sc16 == 8 else (0x100 if sc16 else 0)
 
     def push(self, stream, items, host=True, sc16=False):
         """items: a numpy complex64 array (host; kept alive until the next round()) or (pointer, n); host: see _mem;
         sc16: the items are int16 I/Q pairs (C8P_MEM_SC16: pinned or device memory only), n counts pairs"""
         ptr, n = self._items(items, sc16)
-        self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, self._mem(host) | (0x100 if sc16 else 0)))
+        self._chk(self.L.c8p_rawchain_push(self.h, int(stream), ptr, n, self._mem(host) | self._fmt(sc16)))
 
     def pushv(self, streams, ptrs, counts, host=True, sc16=False):
         """c8p_rawchain_pushv: many pushes in one call; streams / ptrs / counts = integer sequences (ptrs = addresses the caller keeps valid)"""
         st = np.ascontiguousarray(streams, np.uint32)
         pt = np.ascontiguousarray(ptrs, np.uint64)
         ct = np.ascontiguousarray(counts, np.uint64)
-        self._chk(self.L.c8p_rawchain_pushv(self.h, len(st), st.ctypes.data, pt.ctypes.data, ct.ctypes.data, self._mem(host) | (0x100 if sc16 else 0)))
+        self._chk(self.L.c8p_rawchain_pushv(self.h, len(st), st.ctypes.data, pt.ctypes.data, ct.ctypes.data, self._mem(host) | self._fmt(sc16)))
 
     def push2(self, stream, ant0, ant1, host=True, sc16=False):
         """two antennas per stream (stream_ant=2): numpy arrays of equal length, or (pointer, n) tuples"""
         (p0, n0), (p1, n1) = self._items(ant0, sc16), self._items(ant1, sc16)
         assert n0 == n1
-        self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, self._mem(host) | (0x100 if sc16 else 0)))
+        self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, self._mem(host) | self._fmt(sc16)))
 
     def round(self, wait=True):
         """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until ingested() / drain() (they are kept here)"""

@@ -1697,55 +1697,71 @@ __global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const
     for (int u = 0; u < 4; u++) if (kind[u]) gather_store(v[u], d[u], kind[u]);
   }
 }
-// C8P_FMT_SC16 pieces: an item is 4 bytes at the source (int16 I, int16 Q) and a complex64 in the arena.  Work item k of a piece =
-// the 16-byte aligned chunk k of its source = its items [4k - a, 4k - a + 4), a = the items between the aligned address below the
-// source and the source; clipped to the piece.
-__device__ __forceinline__ cf sc16_item(unsigned w, float scale)
+// C8P_FMT_SC16 / C8P_FMT_SC8 pieces: an item is IB = 4 / 2 bytes at the source (int16 I, int16 Q / int8 I, int8 Q) and a complex64
+// in the arena.  Work item k of a piece = the 16-byte aligned chunk k of its source = its NI = 16 / IB items [NI k - a, NI k - a + NI),
+// a = the items between the aligned address below the source and the source; clipped to the piece.
+template <int IB> __device__ __forceinline__ unsigned q_raw(const uint4& v, int u)      // item u of a chunk, as stored
 {
-  return mk((float)(short)(w & 0xffffu) * scale, (float)(short)(w >> 16) * scale);
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  return IB == 4 ? w[u] : (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
 }
-__device__ __forceinline__ void gather_item_sc16(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, uint4& v, cf*& d,
-                                                 int& kind, float& scale)
+template <int IB> __device__ __forceinline__ cf q_item(unsigned r, float scale)
 {
+  return IB == 4 ? mk((float)(short)(r & 0xffffu) * scale, (float)(short)(r >> 16) * scale)
+                 : mk((float)(signed char)(r & 0xffu) * scale, (float)(signed char)(r >> 8) * scale);
+}
+template <int IB> __device__ __forceinline__ void gather_item_q(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, uint4& v,
+                                                                cf*& d, unsigned& kind, float& scale)
+{
+  constexpr int NI = 16 / IB;
   int lo = 0, hi = n - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].first <= i) lo = mid; else hi = mid - 1; }
   const PieceDev P = pc[lo];
   const unsigned long long k = i - P.first;
-  const unsigned* src = (const unsigned*)P.src;
-  const unsigned a = (unsigned)(((uintptr_t)src >> 2) & 3u);
-  const long long i0 = 4 * (long long)k - (long long)a;
-  const unsigned* s = src + i0;
+  const unsigned char* src = (const unsigned char*)P.src;
+  const unsigned a = (unsigned)(((uintptr_t)src / IB) & (NI - 1));
+  const long long i0 = NI * (long long)k - (long long)a;
+  const unsigned char* s = src + i0 * IB;
   d = dst + P.dst_off + i0;
   scale = P.scale;
-  if (i0 >= 0 && (unsigned long long)i0 + 4 <= P.n) { v = *(const uint4*)s; kind = 15; }
+  if (i0 >= 0 && (unsigned long long)i0 + NI <= P.n) { v = *(const uint4*)s; kind = (1u << NI) - 1u; }
   else {                                               // the piece's first or last chunk: item by item, nothing outside the piece is read
     const long long last = (long long)P.n;
-    v = make_uint4(0u, 0u, 0u, 0u);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
     kind = 0;
-    if (i0 >= 0 && i0 < last) { v.x = s[0]; kind |= 1; }
-    if (i0 + 1 >= 0 && i0 + 1 < last) { v.y = s[1]; kind |= 2; }
-    if (i0 + 2 >= 0 && i0 + 2 < last) { v.z = s[2]; kind |= 4; }
-    if (i0 + 3 >= 0 && i0 + 3 < last) { v.w = s[3]; kind |= 8; }
+#pragma unroll
+    for (int u = 0; u < NI; u++)
+      if (i0 + u >= 0 && i0 + u < last) {
+        if (IB == 4) w[u] = ((const unsigned*)s)[u];
+        else w[u >> 1] |= (unsigned)((const unsigned short*)s)[u] << (16 * (u & 1));
+        kind |= 1u << u;
+      }
+    v = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
-__device__ __forceinline__ void gather_store_sc16(const uint4 v, cf* d, int kind, float scale)
+template <int IB> __device__ __forceinline__ void gather_store_q(const uint4 v, cf* d, unsigned kind, float scale)
 {
-  const cf a = sc16_item(v.x, scale), b = sc16_item(v.y, scale), c = sc16_item(v.z, scale), e = sc16_item(v.w, scale);
-  if (kind == 15 && (((uintptr_t)d) & 15u) == 0) { *(float4*)d = make_float4(a.x, a.y, b.x, b.y); *(float4*)(d + 2) = make_float4(c.x, c.y, e.x, e.y); }
-  else { if (kind & 1) d[0] = a; if (kind & 2) d[1] = b; if (kind & 4) d[2] = c; if (kind & 8) d[3] = e; }
+  constexpr int NI = 16 / IB;
+  const bool whole = kind == (1u << NI) - 1u && (((uintptr_t)d) & 15u) == 0;
+#pragma unroll
+  for (int u = 0; u < NI; u += 2) {
+    const cf a = q_item<IB>(q_raw<IB>(v, u), scale), b = q_item<IB>(q_raw<IB>(v, u + 1), scale);
+    if (whole) *(float4*)(d + u) = make_float4(a.x, a.y, b.x, b.y);
+    else { if (kind & (1u << u)) d[u] = a; if (kind & (2u << u)) d[u + 1] = b; }
+  }
 }
-__global__ __launch_bounds__(256) void k_copy_gather_sc16(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+template <int IB> __global__ __launch_bounds__(256) void k_copy_gather_q(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
 {
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
     uint4 v[4];
     cf* d[4];
-    int kind[4];
+    unsigned kind[4];
     float sc[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { kind[u] = 0; if (i + u * stride < total) gather_item_sc16(dst, pc, n, i + u * stride, v[u], d[u], kind[u], sc[u]); }
+    for (int u = 0; u < 4; u++) { kind[u] = 0; if (i + u * stride < total) gather_item_q<IB>(dst, pc, n, i + u * stride, v[u], d[u], kind[u], sc[u]); }
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (kind[u]) gather_store_sc16(v[u], d[u], kind[u], sc[u]);
+    for (int u = 0; u < 4; u++) if (kind[u]) gather_store_q<IB>(v[u], d[u], kind[u], sc[u]);
   }
 }
 extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces, int32_t n)
@@ -1756,9 +1772,9 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   if (n == 0) return C8P_OK;
   for (int i = 0; i < n; i++) {
     if (!pieces[i].n) continue;
-    if (pieces[i].fmt != C8P_FMT_C32 && pieces[i].fmt != C8P_FMT_SC16) { c->err = "c8p_copy_gather: unknown c8p_piece.fmt"; return C8P_EINVAL; }
-    if (!pieces[i].src || ((uintptr_t)pieces[i].src & (pieces[i].fmt == C8P_FMT_SC16 ? 3u : 7u))) {
-      c->err = "c8p_copy_gather: a piece without source or not aligned to its items (complex64: 8 bytes, sc16: 4)";
+    if (pieces[i].fmt > C8P_FMT_SC8) { c->err = "c8p_copy_gather: unknown c8p_piece.fmt"; return C8P_EINVAL; }
+    if (!pieces[i].src || ((uintptr_t)pieces[i].src & (pieces[i].fmt == C8P_FMT_SC16 ? 3u : pieces[i].fmt == C8P_FMT_SC8 ? 1u : 7u))) {
+      c->err = "c8p_copy_gather: a piece without source or not aligned to its items (complex64: 8 bytes, sc16: 4, sc8: 2)";
       return C8P_EINVAL;
     }
     if (pieces[i].trusted) continue;
@@ -1786,26 +1802,29 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
     // stream never idle, was measured in round 4: 64 / 256 / 1024 live streams 4.86 / 6.5 / 7.8-8.3 ms a round against 4.75 / 6.2 /
     // 7.45 with this wait — the gaps it leaves are when the stages' own small transfers get through the link, NOTES/frontend.md)
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-  // one table, the complex64 pieces first, then the sc16 pieces: one upload, one kernel per format that occurs
+  // one table, grouped by format (complex64, sc16, sc8): one upload, one kernel per format that occurs
   PieceDev* hp = (PieceDev*)c->h_spans;
-  unsigned long long total[2] = {0, 0};
-  int cnt[2] = {0, 0};
-  for (int f = 0; f < 2; f++)
+  unsigned long long total[3] = {0, 0, 0};
+  int cnt[3] = {0, 0, 0}, at = 0, first_of[3] = {0, 0, 0};
+  for (int f = 0; f < 3; f++) {
+    first_of[f] = at;
     for (int i = 0; i < n; i++) {
       if ((int)pieces[i].fmt != f) continue;
-      PieceDev& P = hp[cnt[0] * f + cnt[f]++];
+      PieceDev& P = hp[at++];
+      cnt[f]++;
       P.src = (const cf*)pieces[i].src; P.dst_off = pieces[i].dst_off; P.n = pieces[i].n; P.first = total[f]; P.scale = pieces[i].scale; P.rsv = 0;
-      total[f] += f == 0 ? (pieces[i].n + 1 + (((uintptr_t)pieces[i].src >> 3) & 1u)) / 2 : (pieces[i].n + 3 + (((uintptr_t)pieces[i].src >> 2) & 3u)) / 4;
+      const uintptr_t sa = (uintptr_t)pieces[i].src;
+      total[f] += f == 0 ? (pieces[i].n + 1 + ((sa >> 3) & 1u)) / 2 : f == 1 ? (pieces[i].n + 3 + ((sa >> 2) & 3u)) / 4 : (pieces[i].n + 7 + ((sa >> 1) & 7u)) / 8;
     }
-  if (total[0] + total[1] == 0) return C8P_OK;
+  }
+  if (total[0] + total[1] + total[2] == 0) return C8P_OK;
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
   static const unsigned wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : (unsigned)C8P_GATHER_WGS;
-  if (total[0])
-    hipLaunchKernelGGL(k_copy_gather, dim3((unsigned)std::min<unsigned long long>((total[0] + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream,
-                       (cf*)dst, (const PieceDev*)c->d_spans.p, cnt[0], total[0]);
-  if (total[1])
-    hipLaunchKernelGGL(k_copy_gather_sc16, dim3((unsigned)std::min<unsigned long long>((total[1] + 1023) / 1024, wgs)), dim3(256), 0, c->copy_stream,
-                       (cf*)dst, (const PieceDev*)c->d_spans.p + cnt[0], cnt[1], total[1]);
+  const PieceDev* dp = (const PieceDev*)c->d_spans.p;
+  auto grid = [&](unsigned long long t) { return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, wgs)); };
+  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[0], cnt[0], total[0]);
+  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[1], cnt[1], total[1]);
+  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[2], cnt[2], total[2]);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }

@@ -605,7 +605,7 @@ static int flush_pieces(c8p_rawchain* h)
   if (rc == C8P_EINVAL) {                        // a piece the device cannot read: piece by piece through the DMA path
     rc = C8P_OK;
     for (const c8p_piece& pc : L.pieces) {
-      if (pc.fmt != C8P_FMT_C32) { h->err = "live ingest: sc16 items must lie in device or pinned host memory (c8p_host_alloc)"; L.pieces.clear(); return C8P_EINVAL; }
+      if (pc.fmt != C8P_FMT_C32) { h->err = "live ingest: sc16 / sc8 items must lie in device or pinned host memory (c8p_host_alloc)"; L.pieces.clear(); return C8P_EINVAL; }
       if ((rc = api.copy_async(h->ing->c, dst + pc.dst_off, pc.src, sizeof(c8p_c32) * pc.n)) != C8P_OK) break;
     }
   }
@@ -617,8 +617,9 @@ static int flush_pieces(c8p_rawchain* h)
 static int push_impl(c8p_rawchain* h, uint32_t stream, const void* items, const void* ant1, uint64_t n, int32_t mem_and_fmt)
 {
   if (!h) return C8P_EINVAL;
-  const bool sc16 = (mem_and_fmt & C8P_MEM_SC16) != 0;
-  const int32_t mem = mem_and_fmt & ~C8P_MEM_SC16;
+  const bool sc16 = (mem_and_fmt & C8P_MEM_SC16) != 0, sc8 = (mem_and_fmt & C8P_MEM_SC8) != 0;
+  const int32_t mem = mem_and_fmt & ~(C8P_MEM_SC16 | C8P_MEM_SC8);
+  if (sc16 && sc8) { h->err = "C8P_MEM_SC16 and C8P_MEM_SC8 together"; return C8P_EINVAL; }
   if (mem != C8P_MEM_HOST && mem != C8P_MEM_DEVICE && mem != C8P_MEM_PINNED) { h->err = "bad mem kind"; return C8P_EINVAL; }
   int rc = live_start(h);
   if (rc != C8P_OK) return rc;
@@ -637,8 +638,8 @@ static int push_impl(c8p_rawchain* h, uint32_t stream, const void* items, const 
     // device cannot read (pageable host memory) goes through c8p_copy_async at once
     c8p_piece pc;
     pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n; pc.trusted = mem != C8P_MEM_HOST; pc.rsv = 0;
-    pc.fmt = sc16 ? C8P_FMT_SC16 : C8P_FMT_C32;
-    pc.scale = h->cfg.sc16_scale != 0.0f ? h->cfg.sc16_scale : 1.0f / 32767.0f;
+    pc.fmt = sc16 ? C8P_FMT_SC16 : sc8 ? C8P_FMT_SC8 : C8P_FMT_C32;
+    pc.scale = sc8 ? (h->cfg.sc8_scale != 0.0f ? h->cfg.sc8_scale : 1.0f / 127.0f) : (h->cfg.sc16_scale != 0.0f ? h->cfg.sc16_scale : 1.0f / 32767.0f);
     L.pieces.push_back(pc);
     if (ant1) { pc.src = ant1; pc.dst_off += h->A1; L.pieces.push_back(pc); }
     if (L.pieces.size() >= 4096 && (rc = flush_pieces(h)) != C8P_OK) return rc;

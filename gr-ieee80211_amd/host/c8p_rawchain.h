@@ -42,7 +42,7 @@ typedef struct c8p_rawchain_cfg {
                                   demod2; detection listens on antenna 0, c8p_rawchain_push2 delivers both)                 */
   uint64_t stream_round_items; /* most NEW items one stream may receive between two c8p_rawchain_round calls                */
   float    sc16_scale;         /* pushes flagged C8P_MEM_SC16: item = ((float)i * sc16_scale, (float)q * sc16_scale); 0 = 1 / 32767 (UHD's)  */
-  uint32_t rsv;
+  float    sc8_scale;          /* pushes flagged C8P_MEM_SC8 (int8 pairs): 0 = 1 / 127                                                       */
 } c8p_rawchain_cfg;
 
 typedef struct c8p_rawchain_seg {
@@ -127,7 +127,7 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  *                       memory: every piece's pointer is queried, ~4 us each, and pageable memory takes a slow staged copy).
  *                       mem | C8P_MEM_SC16: the items are int16 I/Q pairs as the radio sends them (4 bytes per item over the link
  *                       instead of 8; converted in the gather kernel with c8p_rawchain_cfg.sc16_scale, include/c8p_rx.h
- *                       C8P_FMT_SC16; device or pinned memory only).  Nothing moves yet: the items must stay valid until the next
+ *                       C8P_FMT_SC16; device or pinned memory only); mem | C8P_MEM_SC8: int8 pairs, 2 bytes per item.  Nothing moves yet: the items must stay valid until the next
  *                       c8p_rawchain_round returns.  All pushes of a round are moved by ONE kernel that reads the host memory over
  *                       PCIe itself (c8p_copy_gather): 54-56 GB/s whatever the size of the increments (the DMA engines fall to
  *                       18 GB/s at 256 KB copies), and the DMA queues stay free for the stages' own descriptor / result copies

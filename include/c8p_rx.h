@@ -53,6 +53,7 @@ extern "C" {
 #define C8P_MEM_PINNED  2   /* host memory the device can read (c8p_host_alloc / hipHostMalloc / hipHostRegister): accepted where a call says
                                so (c8p_rawchain_push*); the caller vouches for it, the engine does not query the pointer              */
 #define C8P_MEM_SC16    0x100 /* a flag on top of the kind, accepted by c8p_rawchain_push*: the items are int16 I/Q pairs (C8P_FMT_SC16) */
+#define C8P_MEM_SC8     0x200 /* ... int8 I/Q pairs (C8P_FMT_SC8) */
 
 /* packet formats: lib/cloud80211phy.h:35-40 */
 #define C8P_F_L         0
@@ -485,13 +486,13 @@ int   c8p_copy_wait(c8p_ctx* ctx);
  * descriptor / result copies of the engine's submits (measured: with the same 268 MB per round going through c8p_copy_async, a
  * c8p_rx submit's own copies waited 5-10 ms).  A piece in pageable host memory is refused (C8P_EINVAL): use c8p_copy_async for it. */
 typedef struct c8p_piece {
-  const void* src;          /* n items: complex64 (8-byte aligned) or, fmt = C8P_FMT_SC16, interleaved int16 I/Q pairs (4-byte aligned) */
+  const void* src;          /* n items: complex64 (8-byte aligned); fmt = C8P_FMT_SC16 / _SC8: int16 / int8 I/Q pairs (4 / 2-byte aligned) */
   uint64_t dst_off;         /* items                                                                                                   */
   uint64_t n;
   uint32_t trusted;         /* 1: the caller vouches that the device can read src (device memory, pinned host memory): no pointer query
                                — one hipPointerGetAttributes per piece costs ~4 us, a millisecond per round of 256 pushes               */
   uint32_t fmt;             /* C8P_FMT_*                                                                                               */
-  float    scale;           /* C8P_FMT_SC16: item = ((float)i * scale, (float)q * scale), one float32 multiply each                    */
+  float    scale;           /* C8P_FMT_SC16 / _SC8: item = ((float)i * scale, (float)q * scale), one float32 multiply each             */
   uint32_t rsv;
 } c8p_piece;
 /* C8P_FMT_SC16: what the radio puts on the wire.  The reference's flowgraph takes its stream from a UHD source with the default wire
@@ -501,6 +502,7 @@ typedef struct c8p_piece {
  * caller's scale, UHD: 1/32767) is exact to reproduce on the host, so the stream the detector sees is bit for bit the converted one. */
 #define C8P_FMT_C32   0
 #define C8P_FMT_SC16  1
+#define C8P_FMT_SC8   2   /* UHD's other wire format: int8 I, int8 Q (2-byte aligned), a quarter of the link bytes of complex64 */
 int   c8p_copy_gather(c8p_ctx* ctx, c8p_c32* dst, const c8p_piece* pieces, int32_t n);           /* pieces: host memory */
 uint64_t c8p_copy_mark(c8p_ctx* ctx);
 int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);

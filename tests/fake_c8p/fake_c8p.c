@@ -228,6 +228,12 @@ int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
         c8p_c32* d = dst + pc[i].dst_off + k;
         d->re = (float)s[2 * k] * pc[i].scale; d->im = (float)s[2 * k + 1] * pc[i].scale;
       }
+    } else if (pc[i].fmt == C8P_FMT_SC8) {
+      const int8_t* s = (const int8_t*)pc[i].src;
+      for (uint64_t k = 0; k < pc[i].n; k++) {
+        c8p_c32* d = dst + pc[i].dst_off + k;
+        d->re = (float)s[2 * k] * pc[i].scale; d->im = (float)s[2 * k + 1] * pc[i].scale;
+      }
     } else if (pc[i].fmt == C8P_FMT_C32) memmove(dst + pc[i].dst_off, pc[i].src, sizeof(c8p_c32) * (size_t)pc[i].n);
     else return C8P_EINVAL;
   }

@@ -209,24 +209,25 @@ def test_rawchain_pushv_is_many_pushes():
     assert [by[s] for s in range(3)] == ref
 
 
-def test_rawchain_live_sc16_items_are_the_converted_stream():
+@pytest.mark.parametrize("bits", [16, 8])
+def test_rawchain_live_sc16_items_are_the_converted_stream(bits):
     """pushes flagged C8P_MEM_SC16: int16 I/Q pairs in ragged increments (so the pieces start at any 4-byte item) = one pass over the
     complex64 stream a host-side conversion makes of the same pairs; the handle's scale is c8p_rawchain_cfg.sc16_scale"""
     from test_multistream import to_sc16
     rng = np.random.default_rng(31)
     xs = [with_tail(stream(nm, CFOS[:len(nm)], snr=33.0, seed=900 + i)[0], seed=i) for i, nm in enumerate([NAMES, NAMES[::-1][:6], NAMES[3:8]])]
-    scale = np.float32(1.02 * max(float(np.abs(x.view(np.float32)).max()) for x in xs) / 32767.0)
-    qs, xf = zip(*[to_sc16(x, scale) for x in xs])
+    scale = np.float32(1.02 * max(float(np.abs(x.view(np.float32)).max()) for x in xs) / ((1 << (bits - 1)) - 1))
+    qs, xf = zip(*[to_sc16(x, scale, bits) for x in xs])
     want = [chain_pdus(np.ascontiguousarray(x)) for x in xf]
     got = []
-    h = blocks.RawChain(engine_lib=FAKE, streams=3, stream_round_items=20000, sc16_scale=float(scale))
+    h = blocks.RawChain(engine_lib=FAKE, streams=3, stream_round_items=20000, sc16_scale=float(scale), sc8_scale=float(scale))
     h.live(got.append)
     pos = [0] * 3
     while any(p < len(x) for p, x in zip(pos, xf)):
         for s, q in enumerate(qs):
             n = min(int(rng.choice([0, 1, 137, 2501, 9000, 19999])), len(xf[s]) - pos[s])
             if n:
-                h.push(s, q[2 * pos[s]:2 * (pos[s] + n)], host="pinned", sc16=True)
+                h.push(s, q[2 * pos[s]:2 * (pos[s] + n)], host="pinned", sc16=bits)
                 pos[s] += n
         h.round()
     st = h.drain()
@@ -242,7 +243,7 @@ def test_rawchain_live_sc16_items_are_the_converted_stream():
                 per[s][0].append(recs[k]); k += 1
     for s in range(3):
         assert per[s][0] == want[s][0] and per[s][1] == want[s][1], s
-    assert st["pdus"] == sum(len(w[0]) for w in want) >= 15 and st["items"] == sum(len(x) for x in xf)
+    assert st["pdus"] == sum(len(w[0]) for w in want) >= (15 if bits == 16 else 8) and st["items"] == sum(len(x) for x in xf)
 
 
 def test_rawchain_live_refuses_more_than_a_round_holds():
