@@ -1819,12 +1819,15 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   }
   if (total[0] + total[1] + total[2] == 0) return C8P_OK;
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
-  static const unsigned wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : (unsigned)C8P_GATHER_WGS;
+  // grid: as many workgroups as keep the link full.  complex64 and sc16 items: 1024 (the link binds; 512 / 256 / 128 cost 2-6 % of a
+  // 64-stream round).  sc8: 256 — there the chain's kernels bind and every resident gather wave takes a slot from them (64 / 128
+  // streams 2.06-2.12 / 3.69-3.73 ms a round against 2.16-2.19 / 4.00-4.05 with 1024).  C8P_GATHER_WGS overrides all three
+  static const unsigned env_wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : 0u;
   const PieceDev* dp = (const PieceDev*)c->d_spans.p;
-  auto grid = [&](unsigned long long t) { return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, wgs)); };
-  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[0], cnt[0], total[0]);
-  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[1], cnt[1], total[1]);
-  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2]), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[2], cnt[2], total[2]);
+  auto grid = [&](unsigned long long t, unsigned wgs) { return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, env_wgs ? env_wgs : wgs)); };
+  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[0], cnt[0], total[0]);
+  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[1], cnt[1], total[1]);
+  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[2], cnt[2], total[2]);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
