@@ -2,8 +2,9 @@
 """tools/soak_live.py [streams] [packets per stream] [sessions] — the LIVE ingest of host/c8p_rawchain (push / round / drain; one and two
 antennas per stream) against the oracle's detect -> signal (+ scan rule) -> demod + decode over each whole stream: random streams
 (every fixture format, carrier offsets of +-150 kHz, 6-35 dB, gaps from 150 items), pushed in increments of random size per stream and
-round; per stream the same kept packets (sync index, L-SIG fields), PDUs and FCS-failure counts, in order.  Sessions 2, 3 (mod 4) deliver
-int16 I/Q pairs out of pinned memory (C8P_MEM_SC16); the oracle then runs over their host-side conversion.  Run on the GPU box."""
+round; per stream the same kept packets (sync index, L-SIG fields), PDUs and FCS-failure counts, in order.  Sessions 2, 3 (mod 6) deliver
+int16 I/Q pairs out of pinned memory (C8P_MEM_SC16), sessions 4, 5 int8 pairs (C8P_MEM_SC8, every radio scaled to its own peak); the
+oracle then runs over their host-side conversion.  Run on the GPU box."""
 import os
 import sys
 import time
@@ -46,16 +47,19 @@ for sess in range(sessions):
     n_ant = 1 + sess % 2
     rng = np.random.default_rng(5000 + sess)
     xs = [(random_stream(7000 + 100 * sess + s, per), None) if n_ant == 1 else random_stream2(7000 + 100 * sess + s, per, snr=(6.0, 35.0)) for s in range(K)]
-    sc16 = (sess // 2) % 2 == 1
+    bits = (0, 16, 8)[(sess // 2) % 3]
+    sc16 = bits or False
     scale, qs = 0.0, None
+    if bits == 8:
+        xs = [tuple((a / np.float32(max(float(np.abs(x[0].view(np.float32)).max()), 1e-9))).astype(np.complex64) if a is not None else None for a in x) for x in xs]
     if sc16:
-        scale = np.float32(1.02 * max(float(np.abs(a.view(np.float32)).max()) for x in xs for a in x if a is not None) / 32767.0)
-        conv = [[to_sc16(a, scale) if a is not None else None for a in x] for x in xs]
+        scale = np.float32(1.02 * max(float(np.abs(a.view(np.float32)).max()) for x in xs for a in x if a is not None) / ((1 << (bits - 1)) - 1))
+        conv = [[to_sc16(a, scale, bits) if a is not None else None for a in x] for x in xs]
         qs = [[torch.from_numpy(c[0].copy()).pin_memory() if c is not None else None for c in cs] for cs in conv]
         xs = [tuple(np.ascontiguousarray(c[1]) if c is not None else None for c in cs) for cs in conv]
         tot["sc16_sessions"] = tot.get("sc16_sessions", 0) + 1
     got = []
-    h = blocks.RawChain(streams=K, stream_round_items=60000, stream_ant=n_ant, sc16_scale=float(scale))
+    h = blocks.RawChain(streams=K, stream_round_items=60000, stream_ant=n_ant, sc16_scale=float(scale), sc8_scale=float(scale))
     h.live(got.append)
     pos = [0] * K
     rounds = 0
@@ -63,11 +67,11 @@ for sess in range(sessions):
         for s, (a0, a1) in enumerate(xs):
             n = min(int(rng.choice([0, 0, 137, 1000, 2500, 9000, 20000, 59999])), len(a0) - pos[s])
             if n and sc16:
-                p0 = qs[s][0].data_ptr() + 4 * pos[s]
+                p0 = qs[s][0].data_ptr() + (bits // 4) * pos[s]
                 if n_ant == 1:
-                    h.push(s, (p0, n), host="pinned", sc16=True)
+                    h.push(s, (p0, n), host="pinned", sc16=sc16)
                 else:
-                    h.push2(s, (p0, n), (qs[s][1].data_ptr() + 4 * pos[s], n), host="pinned", sc16=True)
+                    h.push2(s, (p0, n), (qs[s][1].data_ptr() + (bits // 4) * pos[s], n), host="pinned", sc16=sc16)
                 pos[s] += n
             elif n:
                 if n_ant == 1:
@@ -102,7 +106,7 @@ for sess in range(sessions):
         tot["streams"] += 1; tot["items"] += len(xs[s][0]); tot["kept"] += len(idx); tot["mismatch"] += 0 if ok else 1
     tot["sessions"] += 1; tot["rounds"] += rounds
 tot.setdefault("sc16_sessions", 0)
-print("live-ingest soak: %(sessions)d sessions (one and two antennas alternating, %(sc16_sessions)d of them fed sc16), %(streams)d streams, %(items)d items in %(rounds)d rounds, "
+print("live-ingest soak: %(sessions)d sessions (one and two antennas alternating, %(sc16_sessions)d of them fed sc16 or sc8), %(streams)d streams, %(items)d items in %(rounds)d rounds, "
       "%(kept)d packets kept, %(pdus)d PDUs, %(fcs_fail)d FCS failures, %(mismatch)d streams that differ from the oracle's chain" % tot,
       "(%.0f s)" % (time.time() - t0))
 sys.exit(1 if tot["mismatch"] else 0)
