@@ -935,7 +935,7 @@ def frontend_detect(torch, dev, local, n_target=32 << 20):
     eng.close()
     pre_s = kt["presiso"] * 1e-3
     tx = tx_rate(engine, local)
-    chain = raw_stream_chain(torch, dev, local, arr, n, reps, len(unit))
+    chain = raw_stream_chain(torch, dev, local, arr, n, reps, unit)
     return {"tx_packets_per_s": tx, "samples": n, "packets_in_stream": reps, "sync_events": int(len(ev)), "samples_per_s": n / dt,
             "x_realtime_20MSps": n / dt / 20e6, "ms_per_call": 1e3 * dt,
             "kernel_ms": {"scan": round(kt["presiso"], 4), "candidates": round(kt["trigger"], 4), "syncevt": round(kt["syncevt"], 4)},
@@ -969,7 +969,7 @@ def chain_report(st, tl, packets_per_segment):
             "lookback_giveups": st["det_giveups"], "ticket_scans": st["det_ticket_scans"]}
 
 
-def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
+def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
     """the chain from the RAW stream (rx.grc from the SDR source on) as a pipeline over `segments` passes over one resident
     33.5 M-item segment: host/c8p_rawchain.cc — segment i+2 in c8p_detect while i+1 is in c8p_signal (consume: the block's scan
     rule inside the engine, the kept packets back to back) and i in c8p_rx; each stage has its own engine context (own HIP
@@ -977,6 +977,7 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
     same contexts as the timed run, and the run reports where its time went (chain_report).  Every PDU is counted from the
     per-packet results fetched back."""
     from gr_ieee80211_amd import blocks
+    unit_len = len(unit)
     out = {"samples_per_segment": n,
            "note": "c8p_detect -> c8p_signal (consume) -> c8p_rx through one host/c8p_rawchain handle (three host threads, four engine contexts "
                    "that outlive the runs, arenas reserved at create), everything resident in HBM, no state carried between segments; "
@@ -1013,60 +1014,66 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit_len, segments=24):
         out["pcie_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
     h.close()
     try:
-        out["live_streams"] = live_streams(torch, dev, local, pin, n, unit_len)
-        # the same link, four times as many radios, a quarter of the increment: what the per-round costs leave of the rate
-        more = live_streams(torch, dev, local, pin, n, unit_len, streams=256, round_items=1 << 17)
-        out["live_streams"]["streams_256"] = {k: more[k] for k in ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each",
-                                                                   "streams_at_realtime", "pcie_GBps", "pdus_ok", "arena_growths_in_session")}
-        # the radios' own wire format: int16 I/Q pairs (rx.grc's UHD source, otw sc16), converted on the device instead of on the host
-        f32 = pin.numpy()
-        scale = np.float32(1.02 * float(np.abs(f32).max()) / 32767.0)
-        pin16 = torch.from_numpy(np.clip(np.rint(f32 / scale), -32768, 32767).astype(np.int16)).pin_memory()
+        out["live_streams"] = live_streams(torch, dev, local, unit)
         keys = ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each", "streams_at_realtime", "pcie_GBps",
-                "bytes_per_item_over_pcie", "packets_per_s", "pdus_ok", "arena_growths_in_session", "lookback_giveups")
-        for name, K in (("sc16", 64), ("sc16_128", 128)):
-            more = live_streams(torch, dev, local, pin16, n, unit_len, streams=K, sc16_scale=scale)
+                "bytes_per_item_over_pcie", "packets_per_s", "pdus_ok", "pdus_in_the_items_pushed", "arena_growths_in_session", "lookback_giveups")
+        # the same link, four times as many radios, a quarter of the increment: what the per-round costs leave of the rate
+        more = live_streams(torch, dev, local, unit, streams=256, round_items=1 << 17)
+        out["live_streams"]["streams_256"] = {k: more[k] for k in keys}
+        # the radios' own wire formats: int16 I/Q pairs (rx.grc's UHD source, otw sc16) converted on the device instead of on the host;
+        # UHD's narrower one, int8 pairs: 2 B per item — the link no longer binds alone
+        for name, K, bits in (("sc16", 64, 16), ("sc16_128", 128, 16), ("sc8_128", 128, 8)):
+            more = live_streams(torch, dev, local, unit, streams=K, bits=bits)
             out["live_streams"][name] = {k: more[k] for k in keys}
-        # UHD's narrower wire format, int8 pairs: 2 B per item — the link no longer binds, the chain's kernels do
-        scale8 = np.float32(1.02 * float(np.abs(f32).max()) / 127.0)
-        pin8 = torch.from_numpy(np.clip(np.rint(f32 / scale8), -128, 127).astype(np.int8)).pin_memory()
-        more = live_streams(torch, dev, local, pin8, n, unit_len, streams=128, sc16_scale=scale8, bits=8)
-        out["live_streams"]["sc8_128"] = {k: more[k] for k in keys}
-        out["live_streams"]["sc16"]["note"] = ("the same capture as int16 I/Q pairs (scale %.3e): 4 B per item over the link, converted by the gather "
-                                               "kernel; pdus_ok must equal the complex64 leg's" % float(scale))
     except Exception as e:
         out["live_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
-def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 << 19, rounds=40, sc16_scale=None, bits=16):
+def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, rounds=40, bits=0):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
-    per round (26 ms of air at 20 MS/s) out of pinned host memory — every stream a different stretch of the same packet-dense
-    capture — through the live ingest of host/c8p_rawchain: per round ONE c8p_detect_multi over all streams, one c8p_signal (scan
-    rule per stream), one c8p_rx over the packets of all streams; detection state, commit point and scan position per stream live in
-    the handle.  PCIe is in the loop (8 B per item).  x_realtime_each = air time of a round / wall time of a round: how many times
-    faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU sustains at this packet density.
-    sc16_scale: `pin` holds int16 (bits = 8: int8) I/Q pairs as the radio sends them (4 / 2 B per item over PCIe, C8P_MEM_SC16 / _SC8):
+    per round (26 ms of air at 20 MS/s) out of pinned host memory through the live ingest of host/c8p_rawchain: per round ONE
+    c8p_detect_multi over all streams, one c8p_signal (scan rule per stream), one c8p_rx over the packets of all streams; detection
+    state, commit point and scan position per stream live in the handle.  PCIe is in the loop.  x_realtime_each = air time of a round
+    / wall time of a round: how many times faster than real time EVERY stream is served; streams x that = 20 MS/s streams one GPU
+    sustains at this packet density.
+    Every stream has its OWN ring of pinned memory (as a driver's receive ring: two rounds long, the packet-dense capture `unit`
+    repeated, read from a different phase per stream, wrapping): no two streams share a source byte, a ring comes round again only
+    after all the others have been read (>= 67 MB later), so every byte crosses the link every round.  (Until late in round 4 the
+    streams read overlapping stretches of ONE capture: with 2-byte items two streams' windows lay 1 MB apart in the gather kernel's
+    walk and the L2 served part of the reads — 146 GB/s "over PCIe".)
+    bits = 16 / 8: the rings hold int16 / int8 I/Q pairs as the radio sends them (4 / 2 B per item over PCIe, C8P_MEM_SC16 / _SC8):
     the gather kernel converts."""
     from gr_ieee80211_amd import blocks
-    if pin is None:
-        raise RuntimeError("no pinned capture")
+    unit_len = len(unit)
+    item_bytes = bits // 4 if bits else 8
+    scale = 0.0
+    if bits:
+        top = (1 << (bits - 1)) - 1
+        scale = np.float32(1.02 * float(np.abs(unit.view(np.float32)).max()) / top)
+        unit_q = np.clip(np.rint(unit.view(np.float32) / scale), -top - 1, top).astype(np.int16 if bits == 16 else np.int8)
+    else:
+        unit_q = unit.view(np.float32)
+    m = -(-2 * round_items // unit_len)                 # units per ring: two rounds, rounded up
+    W = m * unit_len                                    # items per ring
+    ring = torch.empty((streams, 2 * W), dtype={0: torch.float32, 16: torch.int16, 8: torch.int8}[bits]).pin_memory()
+    ring.numpy()[:] = np.tile(unit_q, m)[None, :]
     per_round_pk = streams * (round_items // unit_len + 2)
     h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
-                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(sc16_scale or 0.0), sc8_scale=float(sc16_scale or 0.0))
-    item_bytes = (bits // 4) if sc16_scale else 8
+                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(scale), sc8_scale=float(scale))
     h.live(None)                    # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
-    base = pin.data_ptr()
-    span = n - round_items * (rounds + 3)
-    off = [(s * 7919 * unit_len) % max(span, 1) for s in range(streams)]      # every stream its own stretch of the capture
-
+    base = np.uint64(ring.data_ptr()) + np.arange(streams, dtype=np.uint64) * np.uint64(W * item_bytes)
+    pos0 = (np.arange(streams, dtype=np.uint64) * np.uint64(7919 * 131)) % np.uint64(W)      # every radio at its own point of the capture
     sid = np.arange(streams, dtype=np.uint32)
-    offs = np.asarray(off, np.uint64)
-    cnt = np.full(streams, round_items, np.uint64)
 
     def one_round(r):
-        h.pushv(sid, np.uint64(base) + np.uint64(item_bytes) * (offs + np.uint64(r * round_items)), cnt, host="pinned", sc16=bits if sc16_scale else False)     # one call for all streams' increments
-        h.round(wait=False)             # the capture stays where it is: no need to wait for the copies, the next round's follow at once
+        p = (pos0 + np.uint64(r * round_items)) % np.uint64(W)
+        n1 = np.minimum(np.uint64(round_items), np.uint64(W) - p)             # up to the end of the ring ...
+        n2 = np.uint64(round_items) - n1                                      # ... and the rest from its start
+        wrap = n2 > 0
+        h.pushv(np.concatenate([sid, sid[wrap]]), np.concatenate([base + p * np.uint64(item_bytes), base[wrap]]), np.concatenate([n1, n2[wrap]]),
+                host="pinned", sc16=bits or False)                            # one call for all streams' increments
+        h.round(wait=False)             # the rings stay where they are: no need to wait for the copies, the next round's follow at once
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)
     t0 = time.perf_counter()
@@ -1076,17 +1083,22 @@ def live_streams(torch, dev, local, pin, n, unit_len, streams=64, round_items=1 
     st = h.drain()
     dt = time.perf_counter() - t0
     h.close()
+    del ring
     air = round_items / 20e6
     per_round = dt / rounds
+    want_pdus = streams * ((rounds + 3) * round_items // unit_len)
     return {"streams": streams, "items_per_stream_per_round": round_items, "rounds": rounds, "ms_per_round": 1e3 * per_round,
             "x_realtime_each": air / per_round, "streams_at_realtime": streams * air / per_round,
-            "pcie_GBps": float(item_bytes) * streams * round_items / per_round / 1e9, "bytes_per_item_over_pcie": item_bytes, "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
-            "pdus_ok": st["pdus"], "push_and_round_calls_s": round(t_push, 4),
+            "pcie_GBps": float(item_bytes) * streams * round_items / per_round / 1e9, "bytes_per_item_over_pcie": item_bytes,
+            "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
+            "pdus_ok": st["pdus"], "pdus_in_the_items_pushed": [want_pdus - 2 * streams, want_pdus + streams],
+            "push_and_round_calls_s": round(t_push, 4),
             "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
             "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],
-            "note": "host-fed (pinned memory, 8 B per item over PCIe — 4 B with sc16 —, moved by the engine's gather kernel — the shader cores read the host memory, no "
-                    "DMA engine; c8p_rawchain_round_async: the pipeline's first stage waits for its round's items); warm-up rounds are inside "
-                    "the session, so arena_growths_in_session counts them too"}
+            "note": "host-fed: every stream its own ring of pinned memory (%d B per item over PCIe), moved by the engine's gather kernel — the shader "
+                    "cores read the host memory, no DMA engine; c8p_rawchain_round_async: the pipeline's first stage waits for its round's items; "
+                    "warm-up rounds are inside the session, so arena_growths_in_session counts them too; pdus_in_the_items_pushed: every stream's "
+                    "items hold that many whole packets, give or take the one at either end" % item_bytes}
 
 
 def tx_rate(engine, local, n=4096):

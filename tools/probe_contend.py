@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from gr_ieee80211_amd import abi, engine  # noqa: E402
 
 if len(sys.argv) == 1:
-    for w in ("dma", "64", "256", "1024"):
+    for w in ("dma", "16", "64", "256", "1024"):
         env = dict(os.environ)
         if w != "dma":
             env["C8P_GATHER_WGS"] = w
@@ -45,6 +45,10 @@ def bulk(reps):
             L.c8p_copy_gather(e.ctx, C.c_void_p(dst), pcs, n)
 
 
+from gr_ieee80211_amd.workloads import cfg2_workload_on_device  # noqa: E402
+dev = torch.device("cuda:0")
+pk, iq_a, chan_a, _exp, _keep = cfg2_workload_on_device(4096, 30.0, 0, torch, dev)
+rx_eng = engine.Engine(device=0)
 a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 b = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
 small = [(a[i << 20:(i + 1) << 20], b[i << 20:(i + 1) << 20]) for i in range(256)]
@@ -55,12 +59,27 @@ def work(kind):
         b.copy_(a)
     elif kind == "memset":
         b.zero_()
+    elif kind == "c8p_rx":
+        rx_eng.rx(pk, iq_a, chan_a)
+        rx_eng.sync()
     else:
         for x, y in small:
             y.copy_(x)
 
 
 def timed(kind, beside):
+    if kind == "c8p_rx":                      # (its own streams: host clock around submit + sync)
+        work(kind)
+        L.c8p_copy_wait(e.ctx)
+        if beside:
+            bulk(12)
+            time.sleep(0.01)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            work(kind)
+        ms = 1e3 * (time.perf_counter() - t0) / 8
+        L.c8p_copy_wait(e.ctx)
+        return ms
     work(kind)
     torch.cuda.synchronize()
     L.c8p_copy_wait(e.ctx)
@@ -83,7 +102,7 @@ bulk(4)
 L.c8p_copy_wait(e.ctx)
 rate = 4 * total / (time.perf_counter() - t0) / 1e9
 out = ["bulk = %-5s %5.1f GB/s" % (mode, rate)]
-for kind in ("d2d", "memset", "train"):
+for kind in ("d2d", "memset", "train", "c8p_rx"):
     alone, with_bulk = timed(kind, False), timed(kind, True)
     out.append("%s %.3f -> %.3f ms (x%.2f)" % (kind, alone, with_bulk, with_bulk / alone))
 print(" | ".join(out))
