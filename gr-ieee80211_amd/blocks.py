@@ -17,6 +17,12 @@ _LIB = None
 DEMOD, DEMOD2, DECODE, SIGNAL, SIGNAL2, DETECT = 0, 1, 2, 3, 4, 5
 
 
+def RX_CHAIN(n_streams):
+    """kind of the rx_chain mirror (rx.grc's whole receive chain for n_streams radios as one block): n_streams complex input ports,
+    max_batch = items per stream and round, messages() / message_streams() = the PDUs and whose they are"""
+    return 100 + int(n_streams)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -82,6 +88,8 @@ def lib():
         L.c8ph_tag_vec.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.c8ph_msg_len.restype = C.c_long
         L.c8ph_msg_len.argtypes = [C.c_void_p, C.c_long]
+        L.c8ph_msg_stream.restype = C.c_long
+        L.c8ph_msg_stream.argtypes = [C.c_void_p, C.c_long]
         L.c8ph_msg_copy.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.c8ph_dbg_get.argtypes = [C.c_void_p, C.c_long, C.c_char_p, C.c_int]
         _LIB = L
@@ -183,6 +191,10 @@ class Block:
             self.L.c8ph_msg_copy(self.h, i, b.ctypes.data)
             res.append((n, b.tobytes()))
         return res
+
+    def message_streams(self):
+        """rx_chain: the input port (radio) of every message, in messages() order (-1 for the other blocks)"""
+        return [int(self.L.c8ph_msg_stream(self.h, i)) for i in range(self.L.c8ph_msg_count(self.h))]
 
     def debug_lines(self):
         res = []

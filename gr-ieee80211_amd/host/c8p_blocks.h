@@ -63,6 +63,7 @@ struct tag_t {
 struct pdu_t {
   long len = 0;
   std::vector<uint8_t> blob;
+  int stream = -1;          // rx_chain only: which input port's radio (the reference's dict has no such entry: one flowgraph, one radio)
 };
 
 // the slice of gr::block a general_work() needs
@@ -204,6 +205,19 @@ public:
   typedef std::shared_ptr<decode> sptr;
   static sptr make(bool ifdebug);
   static sptr make(bool ifdebug, const c8p_api& api, const batching_cfg& cfg);
+};
+
+// The WHOLE receive chain of rx.grc (examples/rx.grc:753-767: presiso -> trigger -> sync -> signal -> demod -> decode) for K radios as
+// ONE block: K complex input ports (port s = what radio s's source block delivers), no stream output, message port "out" = the PDUs
+// decode publishes (lib/decode_impl.cc:105-120), pdu_t.stream = the port.  Behind it one host/c8p_rawchain handle: per stream its own
+// trigger / sync state, commit point and scan position; every `items_per_round` items per stream (or when the input dries up) ONE
+// detection pass, one signal call and one decode batch for all K streams.  The items are copied once, into pinned memory the device reads.
+class rx_chain : virtual public c8p_block
+{
+public:
+  typedef std::shared_ptr<rx_chain> sptr;
+  static sptr make(int n_streams);
+  static sptr make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg);      // cfg.detect_items = items per stream and round
 };
 
 C8P_MIRROR_NS_END

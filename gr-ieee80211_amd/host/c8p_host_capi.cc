@@ -91,6 +91,10 @@ void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_
     else if (kind == 2) { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
     else if (kind == 3) { h->blk = signal::make(api, cfg); h->nports = 2; h->port0_size = 1; h->out_size = sizeof(gr_complex); }
     else if (kind == 4) { h->blk = signal2::make(api, cfg); h->nports = 3; h->port0_size = 1; h->out_size = sizeof(gr_complex); h->nout = 2; }
+    else if (kind >= 100) {                                  // rx_chain with kind - 100 streams; max_batch = items per stream and round
+      cfg.detect_items = max_batch;
+      h->blk = rx_chain::make(kind - 100, lib, cfg); h->nports = kind - 100;
+    }
     else { cfg.detect_items = max_batch; h->blk = detect::make(api, cfg); h->nports = 1; h->out_size = 1; }   // max_batch = items per call
     h->in.resize(h->nports);
     h->in_pos.assign(h->nports, 0);
@@ -378,6 +382,7 @@ void c8ph_tag_vec(void* p, long i, float* reim)
 }
 long c8ph_msg_count(void* p) { return (long)static_cast<harness*>(p)->msgs.size(); }
 long c8ph_msg_len(void* p, long i) { return static_cast<harness*>(p)->msgs[(size_t)i].len; }
+long c8ph_msg_stream(void* p, long i) { return static_cast<harness*>(p)->msgs[(size_t)i].stream; }
 void c8ph_msg_copy(void* p, long i, uint8_t* dst)
 {
   const pdu_t& m = static_cast<harness*>(p)->msgs[(size_t)i];

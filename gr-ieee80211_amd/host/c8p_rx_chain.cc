@@ -1,0 +1,148 @@
+// c8p_rx_chain.cc — rx_chain: rx.grc's receive chain for K radios as one block, on host/c8p_rawchain's live ingest (see c8p_blocks.h).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "c8p_blocks.h"
+#include "c8p_rawchain.h"
+
+C8P_MIRROR_NS_BEGIN
+
+namespace {
+
+class rx_chain_front : public rx_chain
+{
+public:
+  rx_chain_front(int n_streams, const std::string& engine_lib, const batching_cfg& cfg)
+    : d_k(n_streams), d_per(std::max(cfg.detect_items, 1024)), d_idle_flush(cfg.flush_when_idle), d_api(load_c8p_api(engine_lib))
+  {
+    if (n_streams < 1 || n_streams > 65535) throw std::runtime_error("rx_chain: 1 .. 65535 streams");
+    c8p_rawchain_cfg rc;
+    memset(&rc, 0, sizeof(rc));
+    rc.struct_size = sizeof(rc); rc.device = cfg.device; rc.lib = engine_lib.c_str();
+    rc.streams = (uint32_t)d_k; rc.stream_round_items = (uint64_t)d_per;
+    char err[512] = "";
+    d_h = c8p_rawchain_create(&rc, err, (int)sizeof(err));
+    if (!d_h) throw std::runtime_error(std::string("rx_chain: c8p_rawchain_create: ") + err);
+    // one staging area of pinned memory: stream s's items of the open round at d_stage + s * d_per
+    d_stage = static_cast<gr_complex*>(d_api.host_alloc(sizeof(gr_complex) * (uint64_t)d_k * (uint64_t)d_per));
+    if (!d_stage) { c8p_rawchain_destroy(d_h); throw std::runtime_error("rx_chain: no pinned memory for the staging area"); }
+    if (c8p_rawchain_live(d_h, &rx_chain_front::on_round, this) != C8P_OK) {
+      const std::string m = c8p_rawchain_error(d_h);
+      c8p_rawchain_destroy(d_h); d_api.host_free(d_stage);
+      throw std::runtime_error("rx_chain: c8p_rawchain_live: " + m);
+    }
+  }
+  ~rx_chain_front() override
+  {
+    if (d_h) c8p_rawchain_destroy(d_h);          // (waits for the pipeline's threads: no callback after this)
+    if (d_stage) d_api.host_free(d_stage);
+  }
+
+  void forecast(int noutput_items, gr_vector_int& req) override { for (auto& r : req) r = noutput_items; }
+
+  int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
+  {
+    int n = ninput_items.empty() ? 0 : ninput_items[0];
+    for (int v : ninput_items) n = std::min(n, v);
+    n = std::min<int>(n, d_per - d_fill);                                      // the streams advance together (consume_each)
+    for (int s = 0; s < d_k && n > 0; s++)
+      memcpy(d_stage + (size_t)s * (size_t)d_per + (size_t)d_fill, input_items[(size_t)s], sizeof(gr_complex) * (size_t)n);
+    d_fill += n;
+    d_io->consume_each(n);
+    if (d_fill == d_per || (d_fill > 0 && n == 0 && d_idle_flush)) close_round();
+    publish();
+    return 0;
+  }
+
+  // end of stream: the open round, then everything that is still in the pipeline (flags that wait for more items yield nothing)
+  void flush() override
+  {
+    if (d_fill > 0) close_round();
+    c8p_rawchain_stats st;
+    if (c8p_rawchain_drain(d_h, &st) != C8P_OK) fail("c8p_rawchain_drain");
+    publish();
+    if (c8p_rawchain_live(d_h, &rx_chain_front::on_round, this) != C8P_OK) fail("c8p_rawchain_live");       // the next session, should items follow
+  }
+
+private:
+  [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("rx_chain: ") + what + ": " + c8p_rawchain_error(d_h)); }
+
+  void close_round()
+  {
+    for (int s = 0; s < d_k; s++)
+      if (c8p_rawchain_push(d_h, (uint32_t)s, d_stage + (size_t)s * (size_t)d_per, (uint64_t)d_fill, C8P_MEM_PINNED) != C8P_OK) fail("c8p_rawchain_push");
+    if (c8p_rawchain_round(d_h) != C8P_OK) fail("c8p_rawchain_round");           // returns when the items are on the device: the staging area is free
+    d_fill = 0;
+  }
+
+  // on the pipeline's rx thread, round by round: the PDU records of all streams -> the queue general_work publishes from
+  static void on_round(void* user, const c8p_rawchain_out* o)
+  {
+    rx_chain_front* self = static_cast<rx_chain_front*>(user);
+    uint64_t nb = 0;
+    (void)self->d_api.buffer(o->rx, C8P_BUF_PDU, &nb);
+    std::vector<uint8_t> pdu((size_t)nb);
+    if (nb && self->d_api.fetch(o->rx, C8P_BUF_PDU, pdu.data(), 0, nb) != C8P_OK) {
+      std::lock_guard<std::mutex> g(self->d_mu);
+      self->d_failed = true;
+      return;
+    }
+    std::vector<pdu_t> out;
+    for (int p = 0; p < o->n_packets; p++) {
+      const c8p_pkt_out& r = o->outs[p];
+      size_t off = (size_t)r.pdu_off;
+      for (int k = 0; k < r.n_pdu; k++) {                   // records {u16 len, blob = format, len lo, len hi, MPDU.., mcs}
+        const int len = pdu[off] | (pdu[off + 1] << 8);
+        pdu_t m;
+        m.len = len; m.stream = (int)o->pkt_stream[p];
+        m.blob.assign(pdu.begin() + (std::ptrdiff_t)off + 2, pdu.begin() + (std::ptrdiff_t)off + 2 + len);
+        off += 2 + (size_t)len;
+        out.push_back(std::move(m));
+      }
+    }
+    if (out.empty()) return;
+    { std::lock_guard<std::mutex> g(self->d_mu); for (pdu_t& m : out) self->d_q.push_back(std::move(m)); }
+    if (self->d_io) self->d_io->wake();                     // results while no input arrives: get general_work called
+  }
+
+  void publish()
+  {
+    std::deque<pdu_t> q;
+    {
+      std::lock_guard<std::mutex> g(d_mu);
+      q.swap(d_q);
+      if (d_failed) throw std::runtime_error("rx_chain: fetching a round's PDUs failed");
+    }
+    for (const pdu_t& m : q) d_io->message_port_pub("out", m);
+  }
+
+  const int d_k, d_per;
+  const bool d_idle_flush;
+  c8p_api d_api;
+  c8p_rawchain* d_h = nullptr;
+  gr_complex* d_stage = nullptr;
+  int d_fill = 0;
+  std::mutex d_mu;
+  std::deque<pdu_t> d_q;
+  bool d_failed = false;
+};
+
+} // namespace
+
+rx_chain::sptr rx_chain::make(int n_streams)
+{
+  const char* e = getenv("C8P_RX_LIB");
+  return make(n_streams, e ? e : "libc8p_rx.so", batching_cfg());
+}
+rx_chain::sptr rx_chain::make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg)
+{
+  return std::shared_ptr<rx_chain>(new rx_chain_front(n_streams, engine_lib, cfg));
+}
+
+C8P_MIRROR_NS_END

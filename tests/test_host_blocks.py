@@ -552,3 +552,51 @@ def test_a_burst_comes_out_in_fused_mode_without_further_input():
     dec.run_live(chunk=2048, nout=4096, linger_ms=100)
     assert dec.messages() == want
     dem.close(); dec.close()
+
+
+# ------------------------------------------------------------------------------------------------ rx_chain
+def rx_chain_streams(seed, K):
+    """K equally long raw streams (the block's ports advance together): different packet sequences, idle air behind the shorter ones"""
+    from test_detect_frontend import CFOS, NAMES, SWEEP, stream
+    order = [NAMES, NAMES[::-1], NAMES[2:7], NAMES[1:4]][:K]
+    xs = [stream(nm, CFOS[:len(nm)], snr=33.0, seed=seed + i)[0] for i, nm in enumerate(order)]
+    n = max(len(x) for x in xs) + 900
+    rng = np.random.default_rng(seed)
+    xs = [np.concatenate([x, 0.004 * (rng.normal(size=n - len(x)) + 1j * rng.normal(size=n - len(x)))]).astype(np.complex64) for x in xs]
+    return xs, [[SWEEP[k]["pdu"].tobytes() for k in nm] for nm in order]
+
+
+def run_rx_chain(engine_lib, seed, K=3, per_round=7000, jitter=0):
+    xs, want = rx_chain_streams(seed, K)
+    b = blocks.Block(blocks.RX_CHAIN(K), engine_lib=engine_lib, max_batch=per_round)
+    for s, x in enumerate(xs):
+        b.push_items(s, x)
+    if jitter:
+        b.set_jitter(jitter)
+    b.run(chunk=2500, nout=4096)
+    msgs, who = b.messages(), b.message_streams()
+    b.close()
+    got = {s: [] for s in range(K)}
+    for (n, blob), s in zip(msgs, who):
+        assert n == len(blob)
+        got[s].append(blob)
+    for s in range(K):
+        assert got[s] == want[s], s
+    return len(msgs)
+
+
+def test_rx_chain_block_on_the_test_engine():
+    """rx_chain (rx.grc's receive chain for K radios as ONE block, on host/c8p_rawchain's live ingest) through the scheduler harness, with
+    tests/fake_c8p as the engine: per input port, in order, the PDUs decode would publish for that radio (blob = format, len, MPDU, mcs)"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "fake_c8p")])
+    fake = os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so")
+    assert run_rx_chain(fake, 400) >= 15
+    assert run_rx_chain(fake, 410, K=2, per_round=3000, jitter=7) >= 10         # ragged general_work calls, rounds that end inside packets
+
+
+@pytest.mark.gpu
+def test_rx_chain_block_on_the_engine():
+    from gr_ieee80211_amd.blocks import ENGINE_LIB
+    assert run_rx_chain(ENGINE_LIB, 420, K=4, per_round=9000) >= 20
+    assert run_rx_chain(ENGINE_LIB, 430, K=3, per_round=4000, jitter=11) >= 15
