@@ -310,7 +310,16 @@ def main():
             import importlib.util
             spec = importlib.util.spec_from_file_location("bench_blocks", os.path.join(ROOT, "tools", "bench_blocks.py"))
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
-            r = bb.run(2048, batches=(256,), quiet=True)
+            if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
+                iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
+            r = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected))
+            try:
+                out["block_rx_chain"] = bb.rx_chain_rate(local=local)
+                out["block_rx_chain"]["note"] = ("gr::ieee80211::rx_chain (host/c8p_rx_chain.cc): rx.grc's whole receive chain for 8 radios as ONE "
+                                                 "block of the mirror, fed raw item streams in scheduler-sized chunks; every port's items are "
+                                                 "copied once into pinned memory, one round per 524 288 items per stream")
+            except Exception as e:
+                out["block_rx_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
             out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
             out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
@@ -327,12 +336,7 @@ def main():
                                      "over 2048 packets, max_batch 256, %d of 2048 PDUs correct in the worst leg" % r["pdus_ok_min"])
         if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
-                iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
-                torch.cuda.synchronize(dev)
-                import ctypes
-                hip = ctypes.CDLL("libamdhip64.so")
-                hip.hipMemcpy(ctypes.c_void_p(iq.ctypes.data), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(iq.nbytes), ctypes.c_int(2))
-                hip.hipMemcpy(ctypes.c_void_p(chan.ctypes.data), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(chan.nbytes), ctypes.c_int(2))
+                iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
             out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
@@ -345,6 +349,17 @@ def main():
     if rank == 0:
         out["legs"] = legs_summary(out)                   # last key of the line: what survives when only the tail of the line is kept
         emit(out)
+
+
+def arenas_to_host(torch, dev, iq_dev, chan_dev):
+    """the two arenas at the signal -> demod boundary as host arrays (the CPU legs and the block mirrors read host memory)"""
+    import ctypes
+    iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
+    torch.cuda.synchronize(dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(iq.ctypes.data), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(iq.nbytes), ctypes.c_int(2))
+    hip.hipMemcpy(ctypes.c_void_p(chan.ctypes.data), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(chan.nbytes), ctypes.c_int(2))
+    return iq, chan
 
 
 def legs_summary(out):
@@ -361,6 +376,7 @@ def legs_summary(out):
             "cfg4_share": g("configs", "cfg4_one_gpu_share", "packets_per_s"), "cfg5_sta0": g("configs", "cfg5_station0", "packets_per_s"),
             "sharded_rccl": g("sharded_stream", "feeds", "rccl_scatter", "packets_per_s"), "pcie": g("pcie_inclusive_packets_per_s"),
             "block_chain": g("block_chain_packets_per_s"), "block_fused": g("block_chain_fused_packets_per_s"),
+            "block_rx_chain": g("block_rx_chain", "packets_per_s"),
             "detect_samples_per_s": g("frontend_detect", "samples_per_s"), "tx": g("frontend_detect", "tx_packets_per_s"),
             "raw_chain": g("frontend_detect", "raw_stream_to_pdus", "packets_per_s"),
             "raw_chain_first_segment_ms": g("frontend_detect", "raw_stream_to_pdus", "first_segment_ms"),

@@ -139,6 +139,7 @@ def scan_fragment(text):
 # legs by the END of their key path; True: bigger is better
 LEGS = [(("legs", "headline"), True), (("legs", "cfg1"), True), (("legs", "cfg3"), True), (("legs", "cfg4_share"), True), (("legs", "cfg5_sta0"), True),
         (("legs", "sharded_rccl"), True), (("legs", "pcie"), True), (("legs", "block_chain"), True), (("legs", "block_fused"), True),
+        (("legs", "block_rx_chain"), True),
         (("legs", "detect_samples_per_s"), True), (("legs", "tx"), True), (("legs", "raw_chain"), True), (("legs", "raw_chain_pcie"), True),
         (("legs", "live_streams_at_realtime"), True), (("legs", "live_streams_sc16_at_realtime"), True), (("legs", "live_streams_sc8_at_realtime"), True),
         (("value",), True), (("raw_stream_to_pdus", "packets_per_s"), True), (("raw_stream_to_pdus", "ms_per_segment"), False),

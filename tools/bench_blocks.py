@@ -7,23 +7,65 @@ thread (thread-per-block).  Three figures per batch size:
                                PCIe twice (57 KB per packet down, 57 KB up)
   chain_fused                  batching_cfg::fused (C8P_FUSED=1): demod runs c8p_rx, decode publishes behind the handle;
                                35 KB per packet up, 1.5 KB down
+  rx_chain                     rx.grc's whole receive chain for K radios as ONE block (host/c8p_rx_chain.cc): raw 20 MS/s item streams in,
+                               PDUs out; 8 B per item down, the PDUs up
 Prints one JSON line per max_batch and a final {"best": ...} line.  Run on the GPU box."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
-from c8p_cases import cfg2_batch
+from __graft_entry__ import load_package
+load_package()
 from gr_ieee80211_amd import blocks
 
 
 PASSES = 5
 
 
-def run(n=4096, batches=(256, 1024), quiet=False):
+def host_batch(n, local=0):
+    """BASELINE configs[1] from the build's own generator (workloads.cfg2_workload_on_device), brought to the host: descriptors, the two
+    arenas, the PDU every packet must yield"""
+    import ctypes
+    import torch
+    from gr_ieee80211_amd.workloads import cfg2_workload_on_device
+    dev = torch.device("cuda:%d" % local)
+    pk, iq_dev, chan_dev, exp, keep = cfg2_workload_on_device(n, 30.0, 0, torch, dev, local)
+    iq = np.zeros(iq_dev.n, np.complex64); chan = np.zeros(chan_dev.n, np.complex64)
+    torch.cuda.synchronize(dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(iq.ctypes.data), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(iq.nbytes), ctypes.c_int(2))
+    hip.hipMemcpy(ctypes.c_void_p(chan.ctypes.data), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(chan.nbytes), ctypes.c_int(2))
+    del keep
+    return pk, iq, chan, exp
+
+
+def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0):
+    """the rx_chain mirror fed K packet-dense raw streams the way a scheduler feeds a block (bounded chunks, all ports advancing together)"""
+    from gr_ieee80211_amd.workloads import raw_stream_unit
+    unit, pdu = raw_stream_unit(local)
+    reps = items_per_stream // len(unit)
+    b = blocks.Block(blocks.RX_CHAIN(K), max_batch=per_round)
+    ts, n_ok = [], 0
+    for rep in range(3):
+        for s in range(K):
+            b.push_items(s, np.tile(np.roll(unit, 97 * s), reps))            # (rolled: the radios are not in step; a roll keeps whole packets but one)
+        t0 = time.perf_counter(); b.run(chunk=1 << 16, nout=1 << 16); ts.append(time.perf_counter() - t0)
+    msgs = b.messages()
+    n_ok = sum(1 for _, m in msgs if m == pdu)
+    b.close()
+    dt = float(np.median(ts[1:]))
+    per_pass = len(msgs) / 3.0
+    return {"streams": K, "items_per_stream": reps * len(unit), "items_per_round": per_round, "packets_per_s": round(per_pass / dt),
+            "x_realtime_each": round(reps * len(unit) / 20e6 / dt, 2), "pdus": len(msgs), "pdus_correct": n_ok,
+            "pdus_in_the_streams": 3 * K * reps}
+
+
+def run(n=4096, batches=(256, 1024), quiet=False, batch=None):
     """every figure is the median of PASSES passes over the same block instances after a first untimed one (which grows the
-    pinned staging and the device arenas, creates streams, pages the library in)"""
-    b, exp = cfg2_batch(n, snr_db=30.0, seed=1)
-    pk, iq, chan = b.arrays()
+    pinned staging and the device arenas, creates streams, pages the library in).  batch = (descriptors, iq, chan, expected PDUs) on
+    the host; None: host_batch(n)"""
+    pk, iq, chan, exp = batch if batch is not None else host_batch(n)
+    pk, exp = pk[:n], exp[:n]
     best = {}
     for max_batch in batches:
         dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False)
@@ -84,3 +126,4 @@ def run(n=4096, batches=(256, 1024), quiet=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     print(json.dumps({"best": run(n)}))
+    print(json.dumps({"rx_chain": rx_chain_rate()}))
