@@ -315,6 +315,7 @@ def main():
             r = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected))
             try:
                 out["block_rx_chain"] = bb.rx_chain_rate(local=local)
+                out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
                 out["block_rx_chain"]["note"] = ("gr::ieee80211::rx_chain (host/c8p_rx_chain.cc): rx.grc's whole receive chain for 8 radios as ONE "
                                                  "block of the mirror, fed raw item streams in scheduler-sized chunks; every port's items are "
                                                  "copied once into pinned memory, one round per 524 288 items per stream")
@@ -376,7 +377,7 @@ def legs_summary(out):
             "cfg4_share": g("configs", "cfg4_one_gpu_share", "packets_per_s"), "cfg5_sta0": g("configs", "cfg5_station0", "packets_per_s"),
             "sharded_rccl": g("sharded_stream", "feeds", "rccl_scatter", "packets_per_s"), "pcie": g("pcie_inclusive_packets_per_s"),
             "block_chain": g("block_chain_packets_per_s"), "block_fused": g("block_chain_fused_packets_per_s"),
-            "block_rx_chain": g("block_rx_chain", "packets_per_s"),
+            "block_rx_chain": g("block_rx_chain", "packets_per_s"), "block_rx_chain_sc16": g("block_rx_chain", "sc16_ports", "packets_per_s"),
             "detect_samples_per_s": g("frontend_detect", "samples_per_s"), "tx": g("frontend_detect", "tx_packets_per_s"),
             "raw_chain": g("frontend_detect", "raw_stream_to_pdus", "packets_per_s"),
             "raw_chain_first_segment_ms": g("frontend_detect", "raw_stream_to_pdus", "first_segment_ms"),

@@ -88,6 +88,8 @@ def lib():
         L.c8ph_tag_vec.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.c8ph_msg_len.restype = C.c_long
         L.c8ph_msg_len.argtypes = [C.c_void_p, C.c_long]
+        L.c8ph_create_rx_chain.restype = C.c_void_p
+        L.c8ph_create_rx_chain.argtypes = [C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.c8ph_msg_stream.restype = C.c_long
         L.c8ph_msg_stream.argtypes = [C.c_void_p, C.c_long]
         L.c8ph_msg_copy.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
@@ -97,12 +99,17 @@ def lib():
 
 
 class Block:
-    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None):
-        """fused: batching_cfg::fused (None = its default, the environment variable C8P_FUSED)"""
+    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None, item_format=0, scale=0.0):
+        """fused: batching_cfg::fused (None = its default, the environment variable C8P_FUSED); item_format / scale: rx_chain only — the
+        ports carry complex64 (0), int16 pairs (abi.FMT_SC16) or int8 pairs (abi.FMT_SC8) and the engine converts with `scale`"""
         self.L = lib()
         err = C.create_string_buffer(512)
-        self.h = self.L.c8ph_create_ex(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
-                                       int(flush_when_idle), -1 if fused is None else int(fused), err, 512)
+        if kind >= 100 and item_format:
+            self.h = self.L.c8ph_create_rx_chain(kind - 100, int(item_format), float(scale), (engine_lib or ENGINE_LIB).encode(), max_batch,
+                                                 int(flush_when_idle), err, 512)
+        else:
+            self.h = self.L.c8ph_create_ex(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
+                                           int(flush_when_idle), -1 if fused is None else int(fused), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
         self.kind = kind

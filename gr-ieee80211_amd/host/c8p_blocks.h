@@ -218,6 +218,10 @@ public:
   typedef std::shared_ptr<rx_chain> sptr;
   static sptr make(int n_streams);
   static sptr make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg);      // cfg.detect_items = items per stream and round
+  // item_format = C8P_FMT_C32: gr_complex ports.  C8P_FMT_SC16 / C8P_FMT_SC8: the ports carry what the radio sends — std::complex<short> /
+  // std::complex<char> items (a UHD source with cpu_format sc16 / sc8) — and the conversion UHD would do on the host
+  // ((float)v * scale; 0: 1 / 32767, 1 / 127) happens in the engine's gather kernel: 4 / 2 bytes per item to copy and to send
+  static sptr make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg, int item_format, float scale);
 };
 
 C8P_MIRROR_NS_END

@@ -105,6 +105,24 @@ void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_
     return nullptr;
   }
 }
+// rx_chain with item_format C8P_FMT_* ports (gr_complex / std::complex<short> / std::complex<char> items) and its conversion scale
+void* c8ph_create_rx_chain(int n_streams, int item_format, float scale, const char* lib, int items_per_round, int flush_idle, char* errbuf, int errcap)
+{
+  try {
+    harness* h = new harness();
+    batching_cfg cfg; cfg.detect_items = items_per_round; cfg.flush_when_idle = flush_idle != 0;
+    h->blk = rx_chain::make(n_streams, lib, cfg, item_format, scale);
+    h->nports = n_streams;
+    h->item_size = item_format == C8P_FMT_SC16 ? 4 : item_format == C8P_FMT_SC8 ? 2 : sizeof(gr_complex);
+    h->in.resize(h->nports);
+    h->in_pos.assign(h->nports, 0);
+    h->blk->set_io(h);
+    return h;
+  } catch (const std::exception& e) {
+    if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
+    return nullptr;
+  }
+}
 void* c8ph_create(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, char* errbuf, int errcap)
 {
   return c8ph_create_ex(kind, mupos, ifdebug, lib, max_batch, flush_idle, -1, errbuf, errcap);

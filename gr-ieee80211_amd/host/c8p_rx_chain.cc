@@ -18,19 +18,23 @@ namespace {
 class rx_chain_front : public rx_chain
 {
 public:
-  rx_chain_front(int n_streams, const std::string& engine_lib, const batching_cfg& cfg)
-    : d_k(n_streams), d_per(std::max(cfg.detect_items, 1024)), d_idle_flush(cfg.flush_when_idle), d_api(load_c8p_api(engine_lib))
+  rx_chain_front(int n_streams, const std::string& engine_lib, const batching_cfg& cfg, int fmt, float scale)
+    : d_k(n_streams), d_per(std::max(cfg.detect_items, 1024)), d_idle_flush(cfg.flush_when_idle),
+      d_ib(fmt == C8P_FMT_SC16 ? 4 : fmt == C8P_FMT_SC8 ? 2 : 8), d_memflag(fmt == C8P_FMT_SC16 ? C8P_MEM_SC16 : fmt == C8P_FMT_SC8 ? C8P_MEM_SC8 : 0),
+      d_api(load_c8p_api(engine_lib))
   {
     if (n_streams < 1 || n_streams > 65535) throw std::runtime_error("rx_chain: 1 .. 65535 streams");
+    if (fmt != C8P_FMT_C32 && fmt != C8P_FMT_SC16 && fmt != C8P_FMT_SC8) throw std::runtime_error("rx_chain: unknown item format");
     c8p_rawchain_cfg rc;
     memset(&rc, 0, sizeof(rc));
     rc.struct_size = sizeof(rc); rc.device = cfg.device; rc.lib = engine_lib.c_str();
     rc.streams = (uint32_t)d_k; rc.stream_round_items = (uint64_t)d_per;
+    rc.sc16_scale = rc.sc8_scale = scale;
     char err[512] = "";
     d_h = c8p_rawchain_create(&rc, err, (int)sizeof(err));
     if (!d_h) throw std::runtime_error(std::string("rx_chain: c8p_rawchain_create: ") + err);
     // one staging area of pinned memory: stream s's items of the open round at d_stage + s * d_per
-    d_stage = static_cast<gr_complex*>(d_api.host_alloc(sizeof(gr_complex) * (uint64_t)d_k * (uint64_t)d_per));
+    d_stage = static_cast<uint8_t*>(d_api.host_alloc((uint64_t)d_ib * (uint64_t)d_k * (uint64_t)d_per));
     if (!d_stage) { c8p_rawchain_destroy(d_h); throw std::runtime_error("rx_chain: no pinned memory for the staging area"); }
     if (c8p_rawchain_live(d_h, &rx_chain_front::on_round, this) != C8P_OK) {
       const std::string m = c8p_rawchain_error(d_h);
@@ -52,7 +56,7 @@ public:
     for (int v : ninput_items) n = std::min(n, v);
     n = std::min<int>(n, d_per - d_fill);                                      // the streams advance together (consume_each)
     for (int s = 0; s < d_k && n > 0; s++)
-      memcpy(d_stage + (size_t)s * (size_t)d_per + (size_t)d_fill, input_items[(size_t)s], sizeof(gr_complex) * (size_t)n);
+      memcpy(d_stage + ((size_t)s * (size_t)d_per + (size_t)d_fill) * d_ib, input_items[(size_t)s], d_ib * (size_t)n);
     d_fill += n;
     d_io->consume_each(n);
     if (d_fill == d_per || (d_fill > 0 && n == 0 && d_idle_flush)) close_round();
@@ -76,7 +80,7 @@ private:
   void close_round()
   {
     for (int s = 0; s < d_k; s++)
-      if (c8p_rawchain_push(d_h, (uint32_t)s, d_stage + (size_t)s * (size_t)d_per, (uint64_t)d_fill, C8P_MEM_PINNED) != C8P_OK) fail("c8p_rawchain_push");
+      if (c8p_rawchain_push(d_h, (uint32_t)s, d_stage + (size_t)s * (size_t)d_per * d_ib, (uint64_t)d_fill, C8P_MEM_PINNED | d_memflag) != C8P_OK) fail("c8p_rawchain_push");
     if (c8p_rawchain_round(d_h) != C8P_OK) fail("c8p_rawchain_round");           // returns when the items are on the device: the staging area is free
     d_fill = 0;
   }
@@ -124,9 +128,11 @@ private:
 
   const int d_k, d_per;
   const bool d_idle_flush;
+  const size_t d_ib;                  // bytes per input item
+  const int d_memflag;
   c8p_api d_api;
   c8p_rawchain* d_h = nullptr;
-  gr_complex* d_stage = nullptr;
+  uint8_t* d_stage = nullptr;
   int d_fill = 0;
   std::mutex d_mu;
   std::deque<pdu_t> d_q;
@@ -142,7 +148,11 @@ rx_chain::sptr rx_chain::make(int n_streams)
 }
 rx_chain::sptr rx_chain::make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg)
 {
-  return std::shared_ptr<rx_chain>(new rx_chain_front(n_streams, engine_lib, cfg));
+  return make(n_streams, engine_lib, cfg, C8P_FMT_C32, 0.0f);
+}
+rx_chain::sptr rx_chain::make(int n_streams, const std::string& engine_lib, const batching_cfg& cfg, int item_format, float scale)
+{
+  return std::shared_ptr<rx_chain>(new rx_chain_front(n_streams, engine_lib, cfg, item_format, scale));
 }
 
 C8P_MIRROR_NS_END

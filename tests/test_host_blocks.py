@@ -566,9 +566,17 @@ def rx_chain_streams(seed, K):
     return xs, [[SWEEP[k]["pdu"].tobytes() for k in nm] for nm in order]
 
 
-def run_rx_chain(engine_lib, seed, K=3, per_round=7000, jitter=0):
+def run_rx_chain(engine_lib, seed, K=3, per_round=7000, jitter=0, bits=0):
+    """bits = 16 / 8: the ports carry int16 / int8 I/Q pairs (what a UHD source with cpu_format sc16 / sc8 emits); 33 dB packets survive
+    either quantisation, so the PDUs are the fixtures' all the same"""
     xs, want = rx_chain_streams(seed, K)
-    b = blocks.Block(blocks.RX_CHAIN(K), engine_lib=engine_lib, max_batch=per_round)
+    if bits:
+        top = (1 << (bits - 1)) - 1
+        scale = np.float32(1.02 * max(float(np.abs(x.view(np.float32)).max()) for x in xs) / top)
+        xs = [np.clip(np.rint(x.view(np.float32) / scale), -top - 1, top).astype(np.int16 if bits == 16 else np.int8).reshape(-1, 2) for x in xs]
+        b = blocks.Block(blocks.RX_CHAIN(K), engine_lib=engine_lib, max_batch=per_round, item_format=abi.FMT_SC16 if bits == 16 else abi.FMT_SC8, scale=float(scale))
+    else:
+        b = blocks.Block(blocks.RX_CHAIN(K), engine_lib=engine_lib, max_batch=per_round)
     for s, x in enumerate(xs):
         b.push_items(s, x)
     if jitter:
@@ -593,6 +601,8 @@ def test_rx_chain_block_on_the_test_engine():
     fake = os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so")
     assert run_rx_chain(fake, 400) >= 15
     assert run_rx_chain(fake, 410, K=2, per_round=3000, jitter=7) >= 10         # ragged general_work calls, rounds that end inside packets
+    assert run_rx_chain(fake, 400, K=2, bits=16) >= 10                          # std::complex<short> ports
+    assert run_rx_chain(fake, 400, K=2, per_round=5000, bits=8) >= 10           # std::complex<char> ports
 
 
 @pytest.mark.gpu
@@ -600,3 +610,5 @@ def test_rx_chain_block_on_the_engine():
     from gr_ieee80211_amd.blocks import ENGINE_LIB
     assert run_rx_chain(ENGINE_LIB, 420, K=4, per_round=9000) >= 20
     assert run_rx_chain(ENGINE_LIB, 430, K=3, per_round=4000, jitter=11) >= 15
+    assert run_rx_chain(ENGINE_LIB, 420, K=3, bits=16) >= 15
+    assert run_rx_chain(ENGINE_LIB, 420, K=3, per_round=5000, jitter=5, bits=8) >= 15

@@ -39,23 +39,30 @@ def host_batch(n, local=0):
     return pk, iq, chan, exp
 
 
-def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0):
+def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bits=0):
     """the rx_chain mirror fed K packet-dense raw streams the way a scheduler feeds a block (bounded chunks, all ports advancing together)"""
     from gr_ieee80211_amd.workloads import raw_stream_unit
     unit, pdu = raw_stream_unit(local)
     reps = items_per_stream // len(unit)
-    b = blocks.Block(blocks.RX_CHAIN(K), max_batch=per_round)
+    if bits:                                       # the ports carry int16 / int8 pairs, as a UHD source with cpu_format sc16 / sc8 emits them
+        from gr_ieee80211_amd import abi
+        top = (1 << (bits - 1)) - 1
+        scale = np.float32(1.02 * float(np.abs(unit.view(np.float32)).max()) / top)
+        unit = np.clip(np.rint(unit.view(np.float32) / scale), -top - 1, top).astype(np.int16 if bits == 16 else np.int8).reshape(-1, 2)
+        b = blocks.Block(blocks.RX_CHAIN(K), max_batch=per_round, item_format=abi.FMT_SC16 if bits == 16 else abi.FMT_SC8, scale=float(scale))
+    else:
+        b = blocks.Block(blocks.RX_CHAIN(K), max_batch=per_round)
     ts, n_ok = [], 0
     for rep in range(3):
         for s in range(K):
-            b.push_items(s, np.tile(np.roll(unit, 97 * s), reps))            # (rolled: the radios are not in step; a roll keeps whole packets but one)
+            b.push_items(s, np.tile(np.roll(unit, 97 * s, axis=0), (reps, 1) if bits else reps))      # (rolled: the radios are not in step)
         t0 = time.perf_counter(); b.run(chunk=1 << 16, nout=1 << 16); ts.append(time.perf_counter() - t0)
     msgs = b.messages()
     n_ok = sum(1 for _, m in msgs if m == pdu)
     b.close()
     dt = float(np.median(ts[1:]))
     per_pass = len(msgs) / 3.0
-    return {"streams": K, "items_per_stream": reps * len(unit), "items_per_round": per_round, "packets_per_s": round(per_pass / dt),
+    return {"streams": K, "bytes_per_item": (bits // 4) if bits else 8, "items_per_stream": reps * len(unit), "items_per_round": per_round, "packets_per_s": round(per_pass / dt),
             "x_realtime_each": round(reps * len(unit) / 20e6 / dt, 2), "pdus": len(msgs), "pdus_correct": n_ok,
             "pdus_in_the_streams": 3 * K * reps}
 
@@ -127,3 +134,4 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     print(json.dumps({"best": run(n)}))
     print(json.dumps({"rx_chain": rx_chain_rate()}))
+    print(json.dumps({"rx_chain_sc16": rx_chain_rate(bits=16)}))
