@@ -245,8 +245,13 @@ struct c8p_ctx {
   // c8p_counter
   int64_t n_grow = 0, dev_bytes = 0, host_bytes = 0, det_giveups = 0, det_ticket_scans = 0;
   // c8p_copy_*: a stream of its own, created on first use
-  hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream = nullptr;                 // c8p_copy_async, c8p_copy_gather: confined to a few CUs (copy_stream_of)
+  hipStream_t span_stream = nullptr;                 // c8p_copy_spans: device-to-device, the whole chip
+  hipEvent_t ev_before_spans = nullptr, ev_spans = nullptr;
+  bool spans_pending = false;                        // a span copy the next mark / wait has to include
+  int copy_cus = 0;                                  // CUs the copy stream may use (0: all)
   Buf d_spans; void* h_spans = nullptr; size_t h_spans_cap = 0;
+  void* d_spans2 = nullptr; void* h_spans2 = nullptr; size_t spans2_cap = 0;      // c8p_copy_spans' own table
   std::mutex copy_mu;                                // marks against copies enqueued from another thread
   hipEvent_t copy_ev[64] = {};
   uint64_t copy_marks = 0;
@@ -374,6 +379,11 @@ extern "C" void c8p_destroy(c8p_ctx* c)
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->span_stream) { (void)hipStreamSynchronize(c->span_stream); (void)hipStreamDestroy(c->span_stream); }
+  if (c->ev_before_spans) (void)hipEventDestroy(c->ev_before_spans);
+  if (c->ev_spans) (void)hipEventDestroy(c->ev_spans);
+  if (c->d_spans2) (void)hipFree(c->d_spans2);
+  if (c->h_spans2) (void)hipHostFree(c->h_spans2);
   for (hipEvent_t e : c->copy_ev) if (e) (void)hipEventDestroy(e);
   if (c->d_spans.p) (void)hipFree(c->d_spans.p);
   if (c->h_spans) (void)hipHostFree(c->h_spans);
@@ -1561,11 +1571,37 @@ extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
   (void)hipFree(p);
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c);
-static int copy_stream_of(c8p_ctx* c)
+static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
 {
   HIPCHK(c, hipSetDevice(c->device));
   std::lock_guard<std::mutex> g(c->copy_mu);
-  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) {
+    // The gather kernel's waves spend their lives waiting for host memory; on a CU they share with the waves of the chain's kernels they
+    // hold its memory pipeline, and with a gather wave on EVERY CU (1024 workgroups over 256 CUs) every kernel beside it ran 2-10 x slower
+    // (NOTES/frontend.md).  So the copy stream may only use C8P_COPY_CUS compute units (default 32 = 4 of the 32 of every XCD — the low
+    // bits of a CU mask go round the XCDs — each filled to the brim with gather waves), and the other 224 never see one: 64 live streams
+    // 6.0-6.3 -> 5.25 ms a round, sc16 3.7 -> 2.9.  0: no mask.  (hipExtStreamCreateWithCUMask has no flags argument: the stream is a
+    // BLOCKING one, it orders itself against work on the null stream — which this library never uses.)
+    // 32 / 48 / 64 CUs, ms per round: 64 streams of complex64 5.28-5.40 / 5.76 / 5.66; 128 of sc16 6.32 / 5.94 / 5.96; 128 of sc8 4.29 /
+    // 4.23 / 3.76 — narrow items leave the link slack and the conversion wants lanes: the first gather's item format decides.
+    const char* ce = getenv("C8P_COPY_CUS");
+    int ncu = ce ? atoi(ce) : (first_fmt == C8P_FMT_C32 ? 32 : 64);
+    int dev_cus = 0;
+    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) dev_cus = 0;
+    if (ncu < 0 || ncu >= dev_cus || dev_cus > 256) ncu = 0;
+    bool masked = false;
+    if (ncu > 0) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
+      masked = hipExtStreamCreateWithCUMask(&c->copy_stream, 8, mask) == hipSuccess;
+      if (!masked) { (void)hipGetLastError(); c->copy_stream = nullptr; }
+    }
+    if (!masked) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    c->copy_cus = masked ? ncu : 0;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->span_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_before_spans, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_spans, hipEventDisableTiming));
+  }
   return C8P_OK;
 }
 extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
@@ -1574,6 +1610,10 @@ extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
   std::lock_guard<std::mutex> g(c->copy_mu);
   hipEvent_t& e = c->copy_ev[c->copy_marks % 64];
   if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 0;
+  if (c->spans_pending) {                      // "every copy enqueued so far" includes the span copies, which run on their own stream
+    if (hipStreamWaitEvent(c->copy_stream, c->ev_spans, 0) != hipSuccess) return 0;
+    c->spans_pending = false;
+  }
   if (hipEventRecord(e, c->copy_stream) != hipSuccess) return 0;
   return ++c->copy_marks;
 }
@@ -1626,26 +1666,31 @@ extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, cons
   if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
   if (n == 0) return C8P_OK;
   const size_t tab = (sizeof(c8p_span) + sizeof(unsigned long long)) * (size_t)n;
-  if (tab > c->h_spans_cap) {
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    if (c->h_spans) HIPCHK(c, hipHostFree(c->h_spans));
-    c->h_spans = nullptr; c->h_spans_cap = 0;
-    HIPCHK(c, hipHostMalloc(&c->h_spans, tab * 2 + 4096, hipHostMallocDefault));
-    c->h_spans_cap = tab * 2 + 4096;
-    if (c->d_spans.p) { HIPCHK(c, hipFree(c->d_spans.p)); c->d_spans.p = nullptr; c->d_spans.cap = 0; }
-    HIPCHK(c, hipMalloc(&c->d_spans.p, tab * 2 + 4096));
-    c->d_spans.cap = tab * 2 + 4096;
-  } else
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));      // (the previous table may still be on its way up)
-  c8p_span* hs = (c8p_span*)c->h_spans;
-  unsigned long long* hf = (unsigned long long*)((char*)c->h_spans + sizeof(c8p_span) * (size_t)n);
+  HIPCHK(c, hipStreamSynchronize(c->span_stream));        // (the previous table may still be read: that copy is a round old)
+  if (tab > c->spans2_cap) {
+    if (c->h_spans2) HIPCHK(c, hipHostFree(c->h_spans2));
+    if (c->d_spans2) HIPCHK(c, hipFree(c->d_spans2));
+    c->h_spans2 = c->d_spans2 = nullptr; c->spans2_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_spans2, tab * 2 + 4096, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(&c->d_spans2, tab * 2 + 4096));
+    c->spans2_cap = tab * 2 + 4096;
+  }
+  c8p_span* hs = (c8p_span*)c->h_spans2;
+  unsigned long long* hf = (unsigned long long*)((char*)c->h_spans2 + sizeof(c8p_span) * (size_t)n);
   unsigned long long total = 0;
   for (int i = 0; i < n; i++) { hs[i] = spans[i]; hf[i] = total; total += (spans[i].n + C8P_SPAN_CHUNK - 1) / C8P_SPAN_CHUNK; }      // chunks
   if (total == 0) return C8P_OK;
-  HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));
-  hipLaunchKernelGGL(k_copy_spans, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, c->copy_stream, (cf*)dst, (const cf*)src,
-                     (const c8p_span*)c->d_spans.p, (const unsigned long long*)((const char*)c->d_spans.p + sizeof(c8p_span) * (size_t)n), n, total);
+  // in stream order behind everything enqueued on the copy stream so far (the gather that filled the spans' source), but on the
+  // span stream: a device-to-device copy wants the whole chip, the copy stream has 32 CUs
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  HIPCHK(c, hipEventRecord(c->ev_before_spans, c->copy_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->span_stream, c->ev_before_spans, 0));
+  HIPCHK(c, upload(c->span_stream, c->d_spans2, c->h_spans2, tab));
+  hipLaunchKernelGGL(k_copy_spans, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, c->span_stream, (cf*)dst, (const cf*)src,
+                     (const c8p_span*)c->d_spans2, (const unsigned long long*)((const char*)c->d_spans2 + sizeof(c8p_span) * (size_t)n), n, total);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev_spans, c->span_stream));
+  c->spans_pending = true;
   return C8P_OK;
 }
 // work item = 16 bytes (two items) of one piece; pieces start at any item, so the first / last item of a piece may be moved alone.
@@ -1768,7 +1813,7 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
 {
   if (!c || n < 0 || (n > 0 && (!dst || !pieces))) return C8P_EINVAL;
   int rc;
-  if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
+  if ((rc = copy_stream_of(c, n > 0 && pieces[0].fmt <= C8P_FMT_SC8 ? (int)pieces[0].fmt : C8P_FMT_C32)) != C8P_OK) return rc;
   if (n == 0) return C8P_OK;
   for (int i = 0; i < n; i++) {
     if (!pieces[i].n) continue;
@@ -1824,7 +1869,11 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   // streams 2.06-2.12 / 3.69-3.73 ms a round against 2.16-2.19 / 4.00-4.05 with 1024).  C8P_GATHER_WGS overrides all three
   static const unsigned env_wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : 0u;
   const PieceDev* dp = (const PieceDev*)c->d_spans.p;
-  auto grid = [&](unsigned long long t, unsigned wgs) { return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, env_wgs ? env_wgs : wgs)); };
+  // (on a masked copy stream: eight 256-thread workgroups per CU = every wave slot of the CUs the stream may use)
+  auto grid = [&](unsigned long long t, unsigned wgs) {
+    const unsigned g = env_wgs ? env_wgs : (c->copy_cus ? 8u * (unsigned)c->copy_cus : wgs);
+    return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, g));
+  };
   if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[0], cnt[0], total[0]);
   if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[1], cnt[1], total[1]);
   if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[2], cnt[2], total[2]);
@@ -1836,6 +1885,7 @@ extern "C" int c8p_copy_wait(c8p_ctx* c)
   if (!c) return C8P_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  if (c->span_stream) HIPCHK(c, hipStreamSynchronize(c->span_stream));
   return C8P_OK;
 }
 
