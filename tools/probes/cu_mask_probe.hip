@@ -1,3 +1,5 @@
+// tools/probes/cu_mask_probe.hip — which CUs of which XCD does a hipExtStreamCreateWithCUMask mask select?  hipcc --offload-arch=gfx950 -O2 -o tools/probes/cu_mask_probe tools/probes/cu_mask_probe.hip;
+// run on the GPU box: cu_mask_probe N low | cu_mask_probe N spread.  (NOTES/frontend.md, last section)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
