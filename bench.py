@@ -1021,11 +1021,17 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
         pin = torch.empty(2 * n, dtype=torch.float32).pin_memory()
         pin.copy_(arr.keepalive)
         torch.cuda.synchronize(dev)
-        hs = [(pin.data_ptr(), n)] * 12
+        # 40 segments: with 12 the steady window is 8 completions long and they come in bunches — 55-70 GB/s "over PCIe" from run to run
+        # (tools/rawchain_pcie.py); 36 completions give 47-49 GB/s every time, and the whole run with its fill 45-47
+        hs = [(pin.data_ptr(), n)] * 40
         h.run(hs[:3], host=True)
+        t_run = time.perf_counter()
         sp = h.run(hs, host=True)
+        t_run = time.perf_counter() - t_run
         pc = chain_report(sp, h.timeline(), reps)
         pc["GB_per_s_over_pcie"] = 8.0 * pc["samples_per_s"] / 1e9
+        pc["whole_run"] = {"segments": len(hs), "ms": round(1e3 * t_run, 2), "GB_per_s_over_pcie": round(8.0 * n * len(hs) / t_run / 1e9, 2),
+                           "packets_per_s": round(sp["pdus"] / t_run)}
         out["pcie_inclusive"] = pc
     except Exception as e:
         out["pcie_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
