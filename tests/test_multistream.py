@@ -423,13 +423,17 @@ def test_rawchain_live_two_antenna_streams_equal_one_pass_per_stream():
 
 
 @pytest.mark.gpu
-def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment():
+@pytest.mark.parametrize("cus", ["default", "0", "8"])
+def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment(cus, monkeypatch):
     """c8p_copy_gather, C8P_FMT_SC16: pieces that start and end at any 4-byte item of pinned host memory, into any 8-byte item of the
     arena, mixed with complex64 pieces in one call — every destination item = ((float)i * scale, (float)q * scale) bit for bit, nothing
-    outside the pieces is written; pageable or 2-byte aligned sources are refused"""
+    outside the pieces is written; pageable or 2-byte aligned sources are refused.  cus: C8P_COPY_CUS — the copy stream confined to 4 CUs
+    of every XCD (default), unconfined (0: a plain non-blocking stream), or to one CU per XCD"""
     import ctypes as C
     import torch
     from gr_ieee80211_amd import engine
+    if cus != "default":
+        monkeypatch.setenv("C8P_COPY_CUS", cus)
     rng = np.random.default_rng(5)
     e = engine.Engine(device=0)
     L = e.L
@@ -476,20 +480,28 @@ def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment():
 
 
 @pytest.mark.gpu
-def test_copy_spans_moves_exactly_the_spans():
+@pytest.mark.parametrize("cus", ["default", "0"])
+def test_copy_spans_moves_exactly_the_spans(cus, monkeypatch):
     """c8p_copy_spans (the carry of every live stream's tail into the next round's arena): spans of any length (none, one item, across
-    chunk boundaries) at any item offsets of source and destination — the spans arrive, nothing else is touched"""
+    chunk boundaries) at any item offsets of source and destination — the spans arrive, nothing else is touched; behind a gather into
+    the spans' source on the copy stream (the carry runs on a stream of its own, ordered by an event) and in front of a mark"""
     import ctypes as C
     import torch
     from gr_ieee80211_amd import engine
+    if cus != "default":
+        monkeypatch.setenv("C8P_COPY_CUS", cus)
     rng = np.random.default_rng(9)
     e = engine.Engine(device=0)
     L = e.L
     n = 1 << 18
-    src = torch.from_numpy(rng.normal(size=2 * n).astype(np.float32)).to("cuda:0")
+    host = torch.from_numpy(rng.normal(size=2 * n).astype(np.float32)).pin_memory()
+    src = torch.zeros(2 * n, dtype=torch.float32, device="cuda:0")
     dst = torch.full((2 * n,), -3.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     want = np.full(2 * n, -3.0, np.float32)
-    sh = src.cpu().numpy()
+    sh = host.numpy()
+    fill = (abi.Piece * 1)(abi.Piece(host.data_ptr(), 0, n, 1, abi.FMT_C32, 0.0, 0))      # the source arrives through the copy stream ...
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(src.data_ptr()), fill, 1) == 0, L.c8p_last_error(e.ctx)
     spans, pos = [], 1
     for m in [0, 1, 2, 63, 64, 65, 511, 512, 513, 1023, 1025, 4097, 30000, 7, 0, 110000]:
         a = int(rng.integers(0, n - m))
@@ -498,6 +510,7 @@ def test_copy_spans_moves_exactly_the_spans():
         pos += m + int(rng.integers(0, 3))
     arr = (abi.Span * len(spans))(*spans)
     assert L.c8p_copy_spans(e.ctx, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), arr, len(spans)) == 0, L.c8p_last_error(e.ctx)
-    assert L.c8p_copy_wait(e.ctx) == 0
+    mark = L.c8p_copy_mark(e.ctx)                                                            # ... and "every copy so far" covers the spans
+    assert mark > 0 and L.c8p_copy_wait_mark(e.ctx, mark) == 0
     assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
     e.close()
