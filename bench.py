@@ -1039,7 +1039,8 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
     try:
         out["live_streams"] = live_streams(torch, dev, local, unit)
         keys = ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each", "streams_at_realtime", "pcie_GBps",
-                "bytes_per_item_over_pcie", "packets_per_s", "pdus_ok", "pdus_in_the_items_pushed", "arena_growths_in_session", "lookback_giveups")
+                "bytes_per_item_over_pcie", "packets_per_s", "pdus_ok", "pdus_in_the_items_pushed", "round_closed_to_pdus_ms",
+                "arena_growths_in_session", "lookback_giveups")
         # the same link, four times as many radios, a quarter of the increment: what the per-round costs leave of the rate
         more = live_streams(torch, dev, local, unit, streams=256, round_items=1 << 17)
         out["live_streams"]["streams_256"] = {k: more[k] for k in keys}
@@ -1105,6 +1106,7 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
     t_push = time.perf_counter() - t0
     st = h.drain()
     dt = time.perf_counter() - t0
+    lat = sorted(1e3 * (m["rx_done"] - m["det_begin"]) for m in h.timeline()[3:]) or [0.0]      # round closed -> its PDUs fetched
     h.close()
     del ring
     air = round_items / 20e6
@@ -1116,6 +1118,7 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
             "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
             "pdus_ok": st["pdus"], "pdus_in_the_items_pushed": [want_pdus - 2 * streams, want_pdus + streams],
             "push_and_round_calls_s": round(t_push, 4),
+            "round_closed_to_pdus_ms": {"median": round(lat[len(lat) // 2], 2), "p90": round(lat[(9 * len(lat)) // 10], 2), "max": round(lat[-1], 2)},
             "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
             "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],
             "note": "host-fed: every stream its own ring of pinned memory (%d B per item over PCIe), moved by the engine's gather kernel — the shader "

@@ -24,4 +24,4 @@ for arg in (sys.argv[1:] or ["64"]):                 # K[:items per round][:sc16
     bits = {"sc16": 16, "sc8": 8}.get(f[2] if len(f) > 2 else "", 0)
     r = bench.live_streams(torch, dev, 0, unit, streams=K, round_items=items, rounds=40, bits=bits)
     print(json.dumps({k: r[k] for k in ("streams", "items_per_stream_per_round", "rounds", "ms_per_round", "x_realtime_each", "streams_at_realtime",
-                                        "pcie_GBps", "packets_per_s", "pdus_ok", "pdus_in_the_items_pushed", "push_and_round_calls_s", "host_thread_s")}))
+                                        "pcie_GBps", "packets_per_s", "pdus_ok", "pdus_in_the_items_pushed", "round_closed_to_pdus_ms", "push_and_round_calls_s", "host_thread_s")}))
