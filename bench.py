@@ -1049,12 +1049,16 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
         for name, K, bits in (("sc16", 64, 16), ("sc16_128", 128, 16), ("sc8_128", 128, 8)):
             more = live_streams(torch, dev, local, unit, streams=K, bits=bits)
             out["live_streams"][name] = {k: more[k] for k in keys}
+        # at the radios' own pace: 256 streams x 6.5 ms rounds of complex64 = 85-90 % of what the link carries; how long after a round
+        # is closed its PDUs are out when the pipeline is not kept full on purpose
+        more = live_streams(torch, dev, local, unit, streams=256, round_items=1 << 17, rounds=80, pace=1.0)
+        out["live_streams"]["paced_256"] = {k: more[k] for k in keys + ("paced_at", "behind_ms")}
     except Exception as e:
         out["live_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
-def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, rounds=40, bits=0):
+def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, rounds=40, bits=0, pace=0.0):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
     per round (26 ms of air at 20 MS/s) out of pinned host memory through the live ingest of host/c8p_rawchain: per round ONE
     c8p_detect_multi over all streams, one c8p_signal (scan rule per stream), one c8p_rx over the packets of all streams; detection
@@ -1067,7 +1071,9 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
     streams read overlapping stretches of ONE capture: with 2-byte items two streams' windows lay 1 MB apart in the gather kernel's
     walk and the L2 served part of the reads — 146 GB/s "over PCIe".)
     bits = 16 / 8: the rings hold int16 / int8 I/Q pairs as the radio sends them (4 / 2 B per item over PCIe, C8P_MEM_SC16 / _SC8):
-    the gather kernel converts."""
+    the gather kernel converts.
+    pace > 0: the rounds are closed at `pace` times the radios' own pace (1.0 = a round every round_items / 20 MS/s seconds), not as
+    fast as they go: what round_closed_to_pdus_ms is when the machine is not saturated, and whether it keeps up (behind_ms)."""
     from gr_ieee80211_amd import blocks
     unit_len = len(unit)
     item_bytes = bits // 4 if bits else 8
@@ -1101,7 +1107,13 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
     for r in range(3):                                                           # untimed: the same handle
         one_round(r)
     t0 = time.perf_counter()
+    behind = 0.0
     for r in range(3, 3 + rounds):
+        if pace > 0:
+            due = t0 + (r - 3) * (round_items / 20e6) / pace
+            while time.perf_counter() < due:
+                pass
+            behind = max(behind, time.perf_counter() - due)
         one_round(r)
     t_push = time.perf_counter() - t0
     st = h.drain()
@@ -1117,7 +1129,7 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
             "pcie_GBps": float(item_bytes) * streams * round_items / per_round / 1e9, "bytes_per_item_over_pcie": item_bytes,
             "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),
             "pdus_ok": st["pdus"], "pdus_in_the_items_pushed": [want_pdus - 2 * streams, want_pdus + streams],
-            "push_and_round_calls_s": round(t_push, 4),
+            "push_and_round_calls_s": round(t_push, 4), "paced_at": pace or None, "behind_ms": round(1e3 * behind, 2) if pace > 0 else None,
             "round_closed_to_pdus_ms": {"median": round(lat[len(lat) // 2], 2), "p90": round(lat[(9 * len(lat)) // 10], 2), "max": round(lat[-1], 2)},
             "host_thread_s": {k: {f: round(v, 5) for f, v in st[k].items()} for k in ("detect", "signal", "rx")},
             "arena_growths_in_session": st["arena_growths"], "lookback_giveups": st["det_giveups"],

@@ -1478,6 +1478,22 @@ extern "C" int c8p_wait(c8p_ctx* c, int ticket)
   return C8P_ERANGE;
 }
 
+extern "C" int c8p_done(c8p_ctx* c, int ticket)
+{
+  if (!c) return C8P_EINVAL;
+  for (Slot& sl : c->slots)
+    if (sl.ticket != 0 && (int)(sl.ticket & 0x7fffffffu) == ticket) {
+      HIPCHK(c, hipSetDevice(c->device));
+      const hipError_t q = hipStreamQuery(sl.stream);
+      if (q == hipSuccess) return 1;
+      if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+      c->err = std::string("hipStreamQuery: ") + hipGetErrorString(q);
+      return C8P_EHIP;
+    }
+  c->err = "ticket is not resident any more (its slot has been reused) or was never issued";
+  return C8P_ERANGE;
+}
+
 // Pinned host memory for the caller's staging arenas: a C8P_MEM_HOST submit reads them with asynchronous copies (they must stay
 // untouched until c8p_wait / c8p_sync), c8p_fetch_async writes into them.  Plain malloc memory works everywhere too, at
 // pageable-copy speed and without overlap.

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 # every entry point include/c8p_rx.h declares
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
-           "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait",
+           "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait", "c8p_done",
            "c8p_host_alloc", "c8p_host_free", "c8p_selftest", "c8p_detect_multi", "c8p_reserve", "c8p_counter",
            "c8p_dev_alloc", "c8p_dev_free", "c8p_copy_async", "c8p_copy_spans", "c8p_copy_wait", "c8p_copy_mark", "c8p_copy_wait_mark", "c8p_copy_gather"]
 
@@ -94,6 +94,7 @@ def load_library():
     L.c8p_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
     L.c8p_fetch_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
     L.c8p_wait.argtypes = [C.c_void_p, C.c_int]
+    L.c8p_done.argtypes = [C.c_void_p, C.c_int]
     L.c8p_host_alloc.restype = C.c_void_p
     L.c8p_host_alloc.argtypes = [C.c_uint64]
     L.c8p_host_free.argtypes = [C.c_void_p]
@@ -309,6 +310,13 @@ class Engine:
         out = np.zeros((n, 2) if which == 1 else n, np.float32)
         self._chk(self.L.c8p_selftest(self.ctx, which, a.ctypes.data, out.ctypes.data, n))
         return out
+
+    def done(self, ticket):
+        """c8p_done: True once the submit behind `ticket` has finished; never blocks"""
+        r = self.L.c8p_done(self.ctx, int(ticket))
+        if r < 0:
+            self._chk(r)
+        return r == 1
 
     def wait(self, ticket):
         """wait for ONE submit (uploads, kernels, the fetch_async copies behind it)"""

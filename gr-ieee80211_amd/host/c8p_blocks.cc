@@ -53,6 +53,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.ticket = (int (*)(c8p_ctx*))sym("c8p_ticket");
   a.select = (int (*)(c8p_ctx*, int))sym("c8p_select");
   a.wait = (int (*)(c8p_ctx*, int))sym("c8p_wait");
+  a.done = (int (*)(c8p_ctx*, int))sym("c8p_done");
   a.fetch_async = (int (*)(c8p_ctx*, int, void*, uint64_t, uint64_t))sym("c8p_fetch_async");
   a.host_alloc = (void* (*)(uint64_t))sym("c8p_host_alloc");
   a.host_free = (void (*)(void*))sym("c8p_host_free");

@@ -101,6 +101,7 @@ struct c8p_api {
   int (*ticket)(c8p_ctx*);
   int (*select)(c8p_ctx*, int);
   int (*wait)(c8p_ctx*, int);
+  int (*done)(c8p_ctx*, int);
   int (*fetch_async)(c8p_ctx*, int, void*, uint64_t, uint64_t);
   void* (*host_alloc)(uint64_t);
   void (*host_free)(void*);

@@ -58,6 +58,17 @@ public:
     d_cv.notify_all();
     return true;
   }
+  // 0: got one; 1: nothing arrived within `us` microseconds; 2: closed and empty
+  int get_for(T& v, int us)
+  {
+    std::unique_lock<std::mutex> g(d_mu);
+    if (!d_cv.wait_for(g, std::chrono::microseconds(us), [&] { return !d_q.empty() || d_closed; })) return 1;
+    if (d_q.empty()) return 2;
+    v = std::move(d_q.front());
+    d_q.pop_front();
+    d_cv.notify_all();
+    return 0;
+  }
   void close() { std::lock_guard<std::mutex> g(d_mu); d_closed = true; d_cv.notify_all(); }
 private:
   std::mutex d_mu;
@@ -244,7 +255,21 @@ void rx_stage(c8p_rawchain* H, run_state& R, clocked& ck)
     R.sig_arenas.release();
   };
   for (;;) {
-    const bool more = ck.in([&] { return R.q2.get(cur); });
+    // With a segment in flight: whichever comes first, the next segment (submitted BEFORE the one in flight is collected, so that the
+    // GPU is never idle) or the end of the one in flight (c8p_done, polled every 100 us) — a pipeline that is kept full sees the
+    // former, a live one that runs at the radios' pace the latter: its results must not wait for the next round to come by (64 streams
+    // x 26 ms rounds: PDUs 32 ms after the round was closed instead of 7)
+    int got = have_prev ? 1 : ck.in([&] { return R.q2.get(cur) ? 0 : 2; });
+    while (got == 1) {
+      got = ck.in([&] { return R.q2.get_for(cur, 100); });
+      if (got == 1) {
+        const int d = api.done(rx.c, prev_ticket);
+        if (d < 0) rx.check(d, "c8p_done");
+        if (d == 1) break;
+      }
+    }
+    if (got == 1) { collect(); have_prev = false; continue; }
+    const bool more = got == 0;
     if (more) {
       cur.mark.rx_submit = now_s() - R.t0;
       ck.busy([&] {

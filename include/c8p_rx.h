@@ -461,6 +461,8 @@ int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t byte
 int c8p_fetch_async(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
 /* Wait for one submit (uploads, kernels, the c8p_fetch_async copies behind it); C8P_ERANGE once its slot has been reused. */
 int c8p_wait(c8p_ctx* ctx, int ticket);
+/* 1: the submit behind `ticket` has finished (c8p_wait would return at once); 0: not yet; < 0: a C8P_E* code.  Never blocks. */
+int c8p_done(c8p_ctx* ctx, int ticket);
 /* Pinned host memory for staging arenas (what the block fronts use: lib/demod_impl.cc's scheduler buffers are pageable and
  * only valid during general_work, so the fronts copy packets into these).  NULL on failure. */
 void* c8p_host_alloc(uint64_t bytes);

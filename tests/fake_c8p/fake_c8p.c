@@ -289,6 +289,7 @@ int c8p_select(c8p_ctx* c, int ticket)
   return C8P_ERANGE;
 }
 int c8p_wait(c8p_ctx* c, int ticket) { (void)c; (void)ticket; return C8P_OK; }
+int c8p_done(c8p_ctx* c, int ticket) { (void)c; (void)ticket; return 1; }
 int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes) { return c8p_fetch(c, which, dst, offset, bytes); }
 void* c8p_host_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
 void c8p_host_free(void* p) { free(p); }

@@ -413,6 +413,13 @@ def test_tickets_keep_earlier_submits_fetchable():
             assert tags[p]["status"] == r["tags"]["status"] and outs[p]["n_pdu"] == r["out"]["n_pdu"], (k, p)
             o = int(outs[p]["pdu_off"])
             assert abi.split_pdus(area[o:o + int(outs[p]["pdu_bytes"])], int(outs[p]["n_pdu"])) == r["pdus"], (k, p)
+    import time as _time
+    t_end = _time.time() + 30.0
+    while not all(e.done(t) for t in tickets):                     # c8p_done never blocks; all three submits finish on their own
+        assert _time.time() < t_end
+        _time.sleep(0.0005)
+    with pytest.raises(RuntimeError, match="ticket"):
+        e.done(tickets[2] + 1000)
     with pytest.raises(RuntimeError, match="ticket"):
         e.select(tickets[2] + 1000)
     for _ in range(4):                                            # four more submits: every slot has been reused
