@@ -514,3 +514,10 @@ def test_copy_spans_moves_exactly_the_spans(cus, monkeypatch):
     assert mark > 0 and L.c8p_copy_wait_mark(e.ctx, mark) == 0
     assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
     e.close()
+
+
+@pytest.mark.gpu
+def test_rawchain_live_rounds_are_delivered_without_waiting_for_the_next():
+    from gr_ieee80211_amd import blocks
+    from test_rawchain_cpu import live_rounds_are_delivered_without_waiting_for_the_next
+    live_rounds_are_delivered_without_waiting_for_the_next(blocks.ENGINE_LIB)

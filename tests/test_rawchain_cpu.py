@@ -246,6 +246,31 @@ def test_rawchain_live_sc16_items_are_the_converted_stream(bits):
     assert st["pdus"] == sum(len(w[0]) for w in want) >= (15 if bits == 16 else 8) and st["items"] == sum(len(x) for x in xf)
 
 
+def live_rounds_are_delivered_without_waiting_for_the_next(engine_lib, timeout_s=5.0):
+    """a live session at a radio's pace: every round's callback fires on its own — not when the next round comes by (the rx stage collects
+    a round when it has finished OR the next one arrives, whichever comes first)"""
+    import time
+    x = with_tail(stream(NAMES, CFOS[:len(NAMES)], snr=33.0, seed=77)[0])
+    got = []
+    h = blocks.RawChain(engine_lib=engine_lib, streams=1, stream_round_items=20000)
+    h.live(got.append)
+    step = 6000
+    for r, pos in enumerate(range(0, len(x), step)):
+        h.push(0, x[pos:pos + step])
+        h.round()
+        t_end = time.time() + timeout_s
+        while len(got) < r + 1:                      # nothing else is pushed until this round has been delivered
+            assert time.time() < t_end, "round %d was not delivered before the next one was pushed" % r
+            time.sleep(0.001)
+    st = h.drain()
+    h.close()
+    assert st["segments"] == len(got) and [p for g in got for p in pdus_of(g)] == chain_pdus(x)[0]
+
+
+def test_rawchain_live_rounds_are_delivered_without_waiting_for_the_next():
+    live_rounds_are_delivered_without_waiting_for_the_next(FAKE)
+
+
 def test_rawchain_live_refuses_more_than_a_round_holds():
     h = blocks.RawChain(engine_lib=FAKE, streams=2, stream_round_items=4096)
     x = np.zeros(5000, np.complex64)
