@@ -221,7 +221,9 @@ private:
     while (!d_quit) {
       tick_t when;
       if (!d_due(when)) { d_idle = true; d_cv.wait(lk); d_idle = false; continue; }
-      if (now_tick() < when) { d_cv.wait_until(lk, when); continue; }
+      // (a system_clock deadline = pthread_cond_timedwait; a steady-clock one is pthread_cond_clockwait, which this toolchain's
+      // ThreadSanitizer does not intercept — it then reports the mutex as held across the wait)
+      if (now_tick() < when) { d_cv.wait_until(lk, std::chrono::system_clock::now() + (when - now_tick())); continue; }
       try { d_fire(); } catch (const std::exception& e) { error = e.what(); return; }
     }
   }

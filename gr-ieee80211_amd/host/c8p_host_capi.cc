@@ -17,6 +17,9 @@ namespace {
 
 struct harness : public block_io {
   std::shared_ptr<c8p_block> blk;
+  // the block goes first: its threads (a front's latency timer, rx_chain's pipeline) call wake() / message_port_pub() on this object
+  // until they are joined, and `blk` is the first member — it would be destroyed LAST, after the mutexes and the condition variable
+  ~harness() override { blk.reset(); }
   int nports = 1, nout = 1;
   size_t item_size = sizeof(gr_complex);        // items of the stream ports
   size_t port0_size = 0;                        // != 0: port 0 carries items of another size (signal: sync bytes)
@@ -346,7 +349,7 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
         std::unique_lock<std::mutex> lk(h->wake_mu);
         if (!h->woken) {
           if (std::chrono::steady_clock::now() - idle_since >= t_end_idle) break;
-          h->wake_cv.wait_for(lk, std::chrono::milliseconds(1));
+          h->wake_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(1));
         }
         h->woken = false;
         continue;

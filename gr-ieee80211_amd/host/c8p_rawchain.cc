@@ -62,7 +62,9 @@ public:
   int get_for(T& v, int us)
   {
     std::unique_lock<std::mutex> g(d_mu);
-    if (!d_cv.wait_for(g, std::chrono::microseconds(us), [&] { return !d_q.empty() || d_closed; })) return 1;
+    // (system_clock: pthread_cond_timedwait — the steady-clock wait is pthread_cond_clockwait, which this toolchain's ThreadSanitizer
+    // does not intercept and then reports the mutex as held across the wait; a clock step can only stretch one 100 us poll)
+    if (!d_cv.wait_until(g, std::chrono::system_clock::now() + std::chrono::microseconds(us), [&] { return !d_q.empty() || d_closed; })) return 1;
     if (d_q.empty()) return 2;
     v = std::move(d_q.front());
     d_q.pop_front();

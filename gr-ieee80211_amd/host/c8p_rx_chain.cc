@@ -48,7 +48,14 @@ public:
     if (d_stage) d_api.host_free(d_stage);
   }
 
-  void forecast(int noutput_items, gr_vector_int& req) override { for (auto& r : req) r = noutput_items; }
+  // PDUs that wait to be published ask for a call WITHOUT input (the rawchain's callback wakes the scheduler): a source that pauses must
+  // not hold back the results of the rounds it has already delivered
+  void forecast(int noutput_items, gr_vector_int& req) override
+  {
+    bool pending;
+    { std::lock_guard<std::mutex> g(d_mu); pending = !d_q.empty(); }
+    for (auto& r : req) r = pending ? 0 : noutput_items;
+  }
 
   int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
   {

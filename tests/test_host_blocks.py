@@ -605,6 +605,28 @@ def test_rx_chain_block_on_the_test_engine():
     assert run_rx_chain(fake, 400, K=2, per_round=5000, bits=8) >= 10           # std::complex<char> ports
 
 
+def test_rx_chain_block_publishes_the_rounds_it_has_when_the_source_pauses():
+    """a LIVE scheduler (no flush; general_work only while there is input or the block asks for none): after the input is used up the
+    PDUs of every round that was closed are published all the same — forecast() asks for no input while PDUs wait and the rawchain's
+    callback wakes the scheduler; only the open round's packets stay behind"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "fake_c8p")])
+    fake = os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so")
+    xs, want = rx_chain_streams(440, 2)
+    b = blocks.Block(blocks.RX_CHAIN(2), engine_lib=fake, max_batch=3000, flush_when_idle=False)
+    for s, x in enumerate(xs):
+        b.push_items(s, x)
+    b.run_live(chunk=2500, nout=4096, linger_ms=300)
+    msgs, who = b.messages(), b.message_streams()
+    b.close()
+    got = {0: [], 1: []}
+    for (n, blob), s in zip(msgs, who):
+        got[s].append(blob)
+    for s in range(2):
+        assert got[s] == want[s][:len(got[s])] and len(got[s]) >= len(want[s]) - 2, (s, len(got[s]), len(want[s]))
+    assert len(msgs) >= 8
+
+
 @pytest.mark.gpu
 def test_rx_chain_block_on_the_engine():
     from gr_ieee80211_amd.blocks import ENGINE_LIB
