@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak_live.py [streams] [packets per stream] [sessions] — the LIVE ingest of host/c8p_rawchain (push / round / drain; one and two
+"""tools/soak_live.py [streams] [packets per stream] [sessions] [seed offset] — the LIVE ingest of host/c8p_rawchain (push / round / drain; one and two
 antennas per stream) against the oracle's detect -> signal (+ scan rule) -> demod + decode over each whole stream: random streams
 (every fixture format, carrier offsets of +-150 kHz, 6-35 dB, gaps from 150 items), pushed in increments of random size per stream and
 round; per stream the same kept packets (sync index, L-SIG fields), PDUs and FCS-failure counts, in order.  Sessions 2, 3 (mod 6) deliver
@@ -24,6 +24,7 @@ from test_multistream import random_stream, random_stream2, to_sc16  # noqa: E40
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 sessions = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 o = oracle()
 tot = {"sessions": 0, "streams": 0, "items": 0, "rounds": 0, "kept": 0, "pdus": 0, "fcs_fail": 0, "mismatch": 0}
 t0 = time.time()
@@ -45,8 +46,8 @@ def chain(args):
 
 for sess in range(sessions):
     n_ant = 1 + sess % 2
-    rng = np.random.default_rng(5000 + sess)
-    xs = [(random_stream(7000 + 100 * sess + s, per), None) if n_ant == 1 else random_stream2(7000 + 100 * sess + s, per, snr=(6.0, 35.0)) for s in range(K)]
+    rng = np.random.default_rng(5000 + sess + 977 * seed0)
+    xs = [(random_stream(7000 + 100 * sess + s + 100003 * seed0, per), None) if n_ant == 1 else random_stream2(7000 + 100 * sess + s + 100003 * seed0, per, snr=(6.0, 35.0)) for s in range(K)]
     bits = (0, 16, 8)[(sess // 2) % 3]
     sc16 = bits or False
     scale, qs = 0.0, None
