@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from gr_ieee80211_amd.workloads import raw_stream_unit  # noqa: E402
 
 dev = torch.device("cuda:0")
-unit, _ = raw_stream_unit(0)
+unit, _ = raw_stream_unit(0, lead=int(os.environ.get("C8P_LIVE_LEAD", "600")))      # C8P_LIVE_LEAD: idle items in front of every packet (600: packet-dense)
 for arg in (sys.argv[1:] or ["64"]):                 # K[:items per round][:sc16 | sc8][:pace]
     f = arg.split(":")
     K, items = int(f[0]), int(f[1]) if len(f) > 1 and f[1] else 524288
