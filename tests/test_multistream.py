@@ -217,8 +217,8 @@ def to_sc16(x, scale, bits=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("feed", ["host", "device", "host-sc16", "device-sc16", "host-sc8"])
-def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain_per_stream(feed):
+@pytest.mark.parametrize("feed", ["host", "device", "host-sc16", "device-sc16", "host-sc8", "host-nomask", "host-sc16-nomask"])
+def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain_per_stream(feed, monkeypatch):
     """K = 8 random streams (every one-stream format / MCS, carrier offsets of +-150 kHz, SNRs from 6 to 35 dB so that many fail
     their FCS, gaps from 150 items up so that some preambles are missed or merged; one stream is silence, one starts late) pushed in
     increments of random size per stream and round — rounds end inside preambles, inside packets, inside plateaus — through the live
@@ -235,6 +235,9 @@ def test_rawchain_live_eight_streams_in_ragged_increments_equal_the_oracle_chain
     xs.insert(3, (0.004 * (rng.normal(size=90000) + 1j * rng.normal(size=90000))).astype(np.complex64))
     K = len(xs)
     late = 5                                            # this stream delivers nothing during the first rounds
+    if feed.endswith("-nomask"):                        # the copy stream on all CUs, non-blocking (C8P_COPY_CUS=0): the path before the mask
+        monkeypatch.setenv("C8P_COPY_CUS", "0")
+        feed = feed[:-len("-nomask")]
     bits = 16 if feed.endswith("-sc16") else (8 if feed.endswith("-sc8") else 0)
     sc16 = bits or False                                # (what RawChain.push takes: False / 16 / 8)
     feed = feed.split("-")[0]
