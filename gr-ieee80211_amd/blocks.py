@@ -35,6 +35,11 @@ def lib():
         L.c8ph_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.c8ph_create_ex.restype = C.c_void_p
         L.c8ph_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.c8ph_create_ex2.restype = C.c_void_p
+        L.c8ph_create_ex2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.c8ph_set_poison.argtypes = [C.c_void_p, C.c_int]
+        L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
+        L.c8ph_output_pinned.argtypes = [C.c_void_p]
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
@@ -99,17 +104,21 @@ def lib():
 
 
 class Block:
-    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None, item_format=0, scale=0.0):
+    def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None, item_format=0, scale=0.0,
+                 pinned_io=None, defer_consume=None):
         """fused: batching_cfg::fused (None = its default, the environment variable C8P_FUSED); item_format / scale: rx_chain only — the
-        ports carry complex64 (0), int16 pairs (abi.FMT_SC16) or int8 pairs (abi.FMT_SC8) and the engine converts with `scale`"""
+        ports carry complex64 (0), int16 pairs (abi.FMT_SC16) or int8 pairs (abi.FMT_SC8) and the engine converts with `scale`;
+        pinned_io / defer_consume: batching_cfg's fields of those names (None = their defaults, C8P_PINNED_IO / C8P_DEFER_CONSUME): the
+        harness allocates a port's buffer through the block's buffer type — pinned host memory — when the block names one"""
         self.L = lib()
         err = C.create_string_buffer(512)
         if kind >= 100 and item_format:
             self.h = self.L.c8ph_create_rx_chain(kind - 100, int(item_format), float(scale), (engine_lib or ENGINE_LIB).encode(), max_batch,
                                                  int(flush_when_idle), err, 512)
         else:
-            self.h = self.L.c8ph_create_ex(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
-                                           int(flush_when_idle), -1 if fused is None else int(fused), err, 512)
+            self.h = self.L.c8ph_create_ex2(kind, mupos, int(ifdebug), (engine_lib or ENGINE_LIB).encode(), max_batch,
+                                            int(flush_when_idle), -1 if fused is None else int(fused), -1 if pinned_io is None else int(pinned_io),
+                                            -1 if defer_consume is None else int(defer_consume), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
         self.kind = kind
@@ -136,6 +145,16 @@ class Block:
     def set_capture(self, on):
         """off: run() counts the produced items instead of keeping them (throughput measurements)"""
         self.L.c8ph_set_capture(self.h, int(on))
+
+    def set_poison(self, on):
+        """from now on consumed input items are overwritten at once (a test: nothing may still be reading them)"""
+        self.L.c8ph_set_poison(self.h, int(on))
+
+    def input_pinned(self, port=0):
+        return bool(self.L.c8ph_input_pinned(self.h, port))
+
+    def output_pinned(self):
+        return bool(self.L.c8ph_output_pinned(self.h))
 
     def set_jitter(self, seed):
         """random item counts per general_work call from now on (0 = off): what a busy scheduler hands a block"""
@@ -381,13 +400,17 @@ class RawChain:
         self._chk(self.L.c8p_rawchain_push2(self.h, int(stream), p0, p1, n0, self._mem(host) | self._fmt(sc16)))
 
     def round(self, wait=True):
-        """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until ingested() / drain() (they are kept here)"""
+        """wait=False: c8p_rawchain_round_async — the pushed arrays must stay alive until their items are on the device.  They are kept
+        here: this round's until the round AFTER the next has been closed (a round call returns only once an arena is free again, and
+        of the three arenas the one it frees belongs to the round two back, which c8p_signal — and so that round's gather — is through
+        with), or until ingested() / drain()."""
         if wait:
-            self._chk(self.L.c8p_rawchain_round(self.h))
-            self._keep = []
+            self._chk(self.L.c8p_rawchain_round(self.h))          # returns when everything pushed so far is on the device
+            self._keep, self._held = [], []
         else:
             self._chk(self.L.c8p_rawchain_round_async(self.h))
-            self._held = getattr(self, "_held", []) + getattr(self, "_keep", [])
+            held = getattr(self, "_held", [])
+            self._held = held[-1:] + [getattr(self, "_keep", [])]   # batches of the last two async rounds
             self._keep = []
 
     def ingested(self):
@@ -396,8 +419,10 @@ class RawChain:
 
     def drain(self):
         st = _RawStats()
-        self._chk(self.L.c8p_rawchain_drain(self.h, C.byref(st)))
-        self._held = []
+        try:
+            self._chk(self.L.c8p_rawchain_drain(self.h, C.byref(st)))
+        finally:
+            self._held = []
         return _stats_dict(st)
 
 

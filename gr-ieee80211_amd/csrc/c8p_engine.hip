@@ -255,6 +255,8 @@ struct c8p_ctx {
   std::mutex copy_mu;                                // marks against copies enqueued from another thread
   hipEvent_t copy_ev[64] = {};
   uint64_t copy_marks = 0;
+  hipEvent_t ev_fence = nullptr;                     // c8p_copy_fence: what the next submit's stream waits for
+  bool fence_pending = false;
 };
 
 static bool grow_log() { static const bool on = getenv("C8P_GROW_LOG") != nullptr; return on; }
@@ -385,6 +387,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   if (c->d_spans2) (void)hipFree(c->d_spans2);
   if (c->h_spans2) (void)hipHostFree(c->h_spans2);
   for (hipEvent_t e : c->copy_ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_fence) (void)hipEventDestroy(c->ev_fence);
   if (c->d_spans.p) (void)hipFree(c->d_spans.p);
   if (c->h_spans) (void)hipHostFree(c->h_spans);
   if (c->d_tab) (void)hipFree(c->d_tab);
@@ -603,6 +606,17 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
   return C8P_OK;
 }
 
+
+// c8p_copy_fence: the slot's stream waits (on the device) for the copies that were on the copy stream when the fence was set
+static int honour_fence(c8p_ctx* c)
+{
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  if (!c->fence_pending) return C8P_OK;
+  HIPCHK(c, hipStreamWaitEvent(c->s->stream, c->ev_fence, 0));
+  c->fence_pending = false;
+  return C8P_OK;
+}
+
 static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
 {
   if (!c) return C8P_EINVAL;
@@ -614,6 +628,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
+  { const int rf = honour_fence(c); if (rf != C8P_OK) return rf; }
   const int n = in->n_pkt;
   c->s->n_pkt = n;
   for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
@@ -691,6 +706,7 @@ extern "C" int c8p_decode(c8p_ctx* c, const c8p_decode_in* in)
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
   drain_events(c);
+  { const int rf = honour_fence(c); if (rf != C8P_OK) return rf; }
   const int n = in->n_pkt;
   c->s->n_pkt = n;
   for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
@@ -1719,6 +1735,9 @@ extern "C" int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, cons
 #define C8P_GATHER_WGS 1024
 #endif
 struct PieceDev { const cf* src; unsigned long long dst_off, n, first; float scale; unsigned rsv; };      // first: index of the piece's first work item
+// A short piece list travels in the launch's own arguments (no table upload, no table to protect from the next call: what a block
+// mirror enqueues per general_work call is a handful of pieces); a long one (a live round's hundreds) through the table in device memory.
+struct PieceTab { PieceDev p[C8P_GATHER_INLINE]; };
 __device__ __forceinline__ void gather_item(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long i, float4& v, cf*& d,
                                             int& kind)
 {
@@ -1745,8 +1764,10 @@ __device__ __forceinline__ void gather_store(const float4 v, cf* d, int kind)
   if (kind == 3 && (((uintptr_t)d) & 15u) == 0) *(float4*)d = v;
   else { if (kind & 1) d[0] = mk(v.x, v.y); if (kind & 2) d[1] = mk(v.z, v.w); }
 }
-__global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+__global__ __launch_bounds__(256) void k_copy_gather(cf* __restrict__ dst, const PieceDev* __restrict__ pc_mem, const PieceTab tab, int n,
+                                                     unsigned long long total)
 {
+  const PieceDev* __restrict__ pc = pc_mem ? pc_mem : tab.p;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
     float4 v[4];
@@ -1811,8 +1832,10 @@ template <int IB> __device__ __forceinline__ void gather_store_q(const uint4 v, 
     else { if (kind & (1u << u)) d[u] = a; if (kind & (2u << u)) d[u + 1] = b; }
   }
 }
-template <int IB> __global__ __launch_bounds__(256) void k_copy_gather_q(cf* __restrict__ dst, const PieceDev* __restrict__ pc, int n, unsigned long long total)
+template <int IB> __global__ __launch_bounds__(256) void k_copy_gather_q(cf* __restrict__ dst, const PieceDev* __restrict__ pc_mem, const PieceTab tab, int n,
+                                                                          unsigned long long total)
 {
+  const PieceDev* __restrict__ pc = pc_mem ? pc_mem : tab.p;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
     uint4 v[4];
@@ -1825,17 +1848,63 @@ template <int IB> __global__ __launch_bounds__(256) void k_copy_gather_q(cf* __r
     for (int u = 0; u < 4; u++) if (kind[u]) gather_store_q<IB>(v[u], d[u], kind[u], sc[u]);
   }
 }
+// C8P_FMT_F32 pieces: 4-byte items moved as they are.  Work item k of a piece = the 16-byte aligned chunk k of its source = its items
+// [4k - a, 4k - a + 4), a = the items between the aligned address below the source and the source; clipped to the piece.
+__global__ __launch_bounds__(256) void k_copy_gather_w(unsigned* __restrict__ dst, const PieceDev* __restrict__ pc_mem, const PieceTab tab, int n,
+                                                       unsigned long long total)
+{
+  const PieceDev* __restrict__ pc = pc_mem ? pc_mem : tab.p;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 4 * stride) {
+    uint4 v[4];
+    unsigned* d[4];
+    unsigned kind[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      kind[u] = 0;
+      const unsigned long long iu = i + u * stride;
+      if (iu >= total) continue;
+      int lo = 0, hi = n - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].first <= iu) lo = mid; else hi = mid - 1; }
+      const PieceDev P = pc[lo];
+      const unsigned* src = (const unsigned*)P.src;
+      const unsigned a = (unsigned)(((uintptr_t)src >> 2) & 3u);
+      const long long i0 = 4 * (long long)(iu - P.first) - (long long)a;
+      const unsigned* sp = src + i0;
+      d[u] = dst + P.dst_off + i0;
+      if (i0 >= 0 && (unsigned long long)i0 + 4 <= P.n) { v[u] = *(const uint4*)sp; kind[u] = 15u; }
+      else {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i0 + k >= 0 && i0 + k < (long long)P.n) { w[k] = sp[k]; kind[u] |= 1u << k; }
+        v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (!kind[u]) continue;
+      if (kind[u] == 15u && (((uintptr_t)d[u]) & 15u) == 0) *(uint4*)d[u] = v[u];
+      else {
+        const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (kind[u] & (1u << k)) d[u][k] = w[k];
+      }
+    }
+  }
+}
 extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces, int32_t n)
 {
   if (!c || n < 0 || (n > 0 && (!dst || !pieces))) return C8P_EINVAL;
   int rc;
   if ((rc = copy_stream_of(c, n > 0 && pieces[0].fmt <= C8P_FMT_SC8 ? (int)pieces[0].fmt : C8P_FMT_C32)) != C8P_OK) return rc;
   if (n == 0) return C8P_OK;
+  bool any_f32 = false, any_other = false;
   for (int i = 0; i < n; i++) {
     if (!pieces[i].n) continue;
-    if (pieces[i].fmt > C8P_FMT_SC8) { c->err = "c8p_copy_gather: unknown c8p_piece.fmt"; return C8P_EINVAL; }
-    if (!pieces[i].src || ((uintptr_t)pieces[i].src & (pieces[i].fmt == C8P_FMT_SC16 ? 3u : pieces[i].fmt == C8P_FMT_SC8 ? 1u : 7u))) {
-      c->err = "c8p_copy_gather: a piece without source or not aligned to its items (complex64: 8 bytes, sc16: 4, sc8: 2)";
+    if (pieces[i].fmt > C8P_FMT_F32) { c->err = "c8p_copy_gather: unknown c8p_piece.fmt"; return C8P_EINVAL; }
+    (pieces[i].fmt == C8P_FMT_F32 ? any_f32 : any_other) = true;
+    if (!pieces[i].src || ((uintptr_t)pieces[i].src & (pieces[i].fmt == C8P_FMT_SC16 || pieces[i].fmt == C8P_FMT_F32 ? 3u : pieces[i].fmt == C8P_FMT_SC8 ? 1u : 7u))) {
+      c->err = "c8p_copy_gather: a piece without source or not aligned to its items (complex64: 8 bytes, sc16 / f32: 4, sc8: 2)";
       return C8P_EINVAL;
     }
     if (pieces[i].trusted) continue;
@@ -1845,55 +1914,79 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
                                                                        && at.type != hipMemoryTypeManaged)) {
       (void)hipGetLastError();
       c->err = "c8p_copy_gather: a piece lies in host memory the device cannot read (pageable): pin it (c8p_host_alloc) or use c8p_copy_async";
-      return C8P_EINVAL;
+      return C8P_ENOTDEV;
     }
   }
-  const size_t tab = sizeof(PieceDev) * (size_t)n;
-  if (tab > c->h_spans_cap) {
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    if (c->h_spans) HIPCHK(c, hipHostFree(c->h_spans));
-    c->h_spans = nullptr; c->h_spans_cap = 0;
-    HIPCHK(c, hipHostMalloc(&c->h_spans, tab * 2 + 4096, hipHostMallocDefault));
-    c->h_spans_cap = tab * 2 + 4096;
-    if (c->d_spans.p) { HIPCHK(c, hipFree(c->d_spans.p)); c->d_spans.p = nullptr; c->d_spans.cap = 0; }
-    HIPCHK(c, hipMalloc(&c->d_spans.p, tab * 2 + 4096));
-    c->d_spans.cap = tab * 2 + 4096;
-  } else
-    // (the previous table may still be read.  A ring of tables guarded by events, which leaves the caller's thread free and the copy
-    // stream never idle, was measured in round 4: 64 / 256 / 1024 live streams 4.86 / 6.5 / 7.8-8.3 ms a round against 4.75 / 6.2 /
-    // 7.45 with this wait — the gaps it leaves are when the stages' own small transfers get through the link, NOTES/frontend.md)
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-  // one table, grouped by format (complex64, sc16, sc8): one upload, one kernel per format that occurs
-  PieceDev* hp = (PieceDev*)c->h_spans;
-  unsigned long long total[3] = {0, 0, 0};
-  int cnt[3] = {0, 0, 0}, at = 0, first_of[3] = {0, 0, 0};
-  for (int f = 0; f < 3; f++) {
+  if (any_f32 && any_other) { c->err = "c8p_copy_gather: C8P_FMT_F32 pieces cannot share a call with 8-byte-item pieces (dst_off units differ)"; return C8P_EINVAL; }
+  const bool inl = n <= C8P_GATHER_INLINE;
+  PieceTab itab;
+  PieceDev* hp = itab.p;
+  if (!inl) {
+    const size_t tab = sizeof(PieceDev) * (size_t)n;
+    if (tab > c->h_spans_cap) {
+      HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+      if (c->h_spans) HIPCHK(c, hipHostFree(c->h_spans));
+      c->h_spans = nullptr; c->h_spans_cap = 0;
+      HIPCHK(c, hipHostMalloc(&c->h_spans, tab * 2 + 4096, hipHostMallocDefault));
+      c->h_spans_cap = tab * 2 + 4096;
+      if (c->d_spans.p) { HIPCHK(c, hipFree(c->d_spans.p)); c->d_spans.p = nullptr; c->d_spans.cap = 0; }
+      HIPCHK(c, hipMalloc(&c->d_spans.p, tab * 2 + 4096));
+      c->d_spans.cap = tab * 2 + 4096;
+    } else
+      // (the previous table may still be read.  A ring of tables guarded by events, which leaves the caller's thread free and the copy
+      // stream never idle, was measured in round 4: 64 / 256 / 1024 live streams 4.86 / 6.5 / 7.8-8.3 ms a round against 4.75 / 6.2 /
+      // 7.45 with this wait — the gaps it leaves are when the stages' own small transfers get through the link, NOTES/frontend.md)
+      HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    hp = (PieceDev*)c->h_spans;
+  }
+  // one table, grouped by format (complex64, sc16, sc8, f32): one upload (none for a short list), one kernel per format that occurs
+  unsigned long long total[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0}, at = 0, first_of[4] = {0, 0, 0, 0};
+  for (int f = 0; f < 4; f++) {
     first_of[f] = at;
     for (int i = 0; i < n; i++) {
-      if ((int)pieces[i].fmt != f) continue;
+      if ((int)pieces[i].fmt != f || !pieces[i].n) continue;
       PieceDev& P = hp[at++];
       cnt[f]++;
       P.src = (const cf*)pieces[i].src; P.dst_off = pieces[i].dst_off; P.n = pieces[i].n; P.first = total[f]; P.scale = pieces[i].scale; P.rsv = 0;
       const uintptr_t sa = (uintptr_t)pieces[i].src;
-      total[f] += f == 0 ? (pieces[i].n + 1 + ((sa >> 3) & 1u)) / 2 : f == 1 ? (pieces[i].n + 3 + ((sa >> 2) & 3u)) / 4 : (pieces[i].n + 7 + ((sa >> 1) & 7u)) / 8;
+      total[f] += f == 0 ? (pieces[i].n + 1 + ((sa >> 3) & 1u)) / 2 : f == 2 ? (pieces[i].n + 7 + ((sa >> 1) & 7u)) / 8 : (pieces[i].n + 3 + ((sa >> 2) & 3u)) / 4;
     }
   }
-  if (total[0] + total[1] + total[2] == 0) return C8P_OK;
-  HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, tab, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
+  if (total[0] + total[1] + total[2] + total[3] == 0) return C8P_OK;
+  if (!inl) HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->h_spans, sizeof(PieceDev) * (size_t)at, hipMemcpyHostToDevice, c->copy_stream));      // (small: the DMA queues hold no bulk copies)
   // grid: as many workgroups as keep the link full.  complex64 and sc16 items: 1024 (the link binds; 512 / 256 / 128 cost 2-6 % of a
   // 64-stream round).  sc8: 256 — there the chain's kernels bind and every resident gather wave takes a slot from them (64 / 128
   // streams 2.06-2.12 / 3.69-3.73 ms a round against 2.16-2.19 / 4.00-4.05 with 1024).  C8P_GATHER_WGS overrides all three
   static const unsigned env_wgs = getenv("C8P_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("C8P_GATHER_WGS"))) : 0u;
-  const PieceDev* dp = (const PieceDev*)c->d_spans.p;
+  const PieceDev* dp = inl ? nullptr : (const PieceDev*)c->d_spans.p;
   // (on a masked copy stream: eight 256-thread workgroups per CU = every wave slot of the CUs the stream may use)
   auto grid = [&](unsigned long long t, unsigned wgs) {
     const unsigned g = env_wgs ? env_wgs : (c->copy_cus ? 8u * (unsigned)c->copy_cus : wgs);
     return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, g));
   };
-  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[0], cnt[0], total[0]);
-  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[1], cnt[1], total[1]);
-  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, c->copy_stream, (cf*)dst, dp + first_of[2], cnt[2], total[2]);
+  // a format's pieces are a contiguous run of the table: the inline table is passed shifted to that run
+  auto sub = [&](int f) { PieceTab t; memset(&t, 0, sizeof(t)); if (inl) memcpy(t.p, itab.p + first_of[f], sizeof(PieceDev) * (size_t)cnt[f]); return t; };
+  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[0], sub(0), cnt[0], total[0]);
+  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[1], sub(1), cnt[1], total[1]);
+  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[2], sub(2), cnt[2], total[2]);
+  if (total[3]) hipLaunchKernelGGL(k_copy_gather_w, grid(total[3], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (unsigned*)dst, inl ? nullptr : dp + first_of[3], sub(3), cnt[3], total[3]);
   HIPCHK(c, hipGetLastError());
+  return C8P_OK;
+}
+extern "C" int c8p_copy_fence(c8p_ctx* c)
+{
+  if (!c) return C8P_EINVAL;
+  int rc;
+  if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  if (!c->ev_fence) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
+  if (c->spans_pending) {                      // "every copy enqueued so far" includes the span copies, which run on their own stream
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_spans, 0));
+    c->spans_pending = false;
+  }
+  HIPCHK(c, hipEventRecord(c->ev_fence, c->copy_stream));
+  c->fence_pending = true;
   return C8P_OK;
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c)

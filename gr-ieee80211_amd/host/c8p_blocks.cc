@@ -68,6 +68,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.copy_gather = (int (*)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t))sym("c8p_copy_gather");
   a.copy_mark = (uint64_t (*)(c8p_ctx*))sym("c8p_copy_mark");
   a.copy_wait_mark = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_wait_mark");
+  a.copy_fence = (int (*)(c8p_ctx*))sym("c8p_copy_fence");
   return a;
 }
 
@@ -88,40 +89,26 @@ bool batching_cfg::default_fused()
   const char* e = getenv("C8P_FUSED");
   return e && e[0] == '1';
 }
-
-// Fused mode hand-over (batching_cfg::fused): what `demod` learned about a packet from c8p_rx, parked until `decode` meets
-// the "c8p_fused" tag that names it.  Both mirrors live in the flowgraph's process; the tag travels through the scheduler.
-struct fused_pkt {
-  std::vector<pdu_t> pdus;
-  int n_crc_fail = 0;
-};
-static std::mutex g_fused_mu;
-static std::map<long, fused_pkt> g_fused;
-static std::atomic<long> g_fused_next{1};
-// A handle is erased when `decode` meets its tag.  If no decode is downstream (or tags are dropped, or the flowgraph stops first)
-// nobody does: the map is therefore bounded — the oldest handles go once more than C8P_FUSED_MAX are parked — and a demod front
-// takes the handles it issued with it when it is destroyed.
-static const size_t C8P_FUSED_MAX = 1u << 16;
-static void fused_park(long id, fused_pkt&& f)
+bool batching_cfg::default_pinned_io()
 {
-  std::lock_guard<std::mutex> g(g_fused_mu);
-  g_fused[id] = std::move(f);
-  while (g_fused.size() > C8P_FUSED_MAX) g_fused.erase(g_fused.begin());     // (ids grow: begin() is the oldest)
+  const char* e = getenv("C8P_PINNED_IO");
+  return !(e && e[0] == '0');
 }
-static void fused_purge(const std::vector<long>& ids)
+bool batching_cfg::default_defer_consume()
 {
-  std::lock_guard<std::mutex> g(g_fused_mu);
-  for (long id : ids) g_fused.erase(id);
+  const char* e = getenv("C8P_DEFER_CONSUME");
+  return !(e && e[0] == '0');
 }
 
-// growable array in pinned host memory (uninitialised growth: no zero fill of tens of megabytes per batch)
+// growable array in pinned host memory (uninitialised growth: no zero fill of tens of megabytes per batch).  Holds the allocator's two
+// entry points, not the table they came from: a result arena handed to another block (fused mode) may outlive the front that made it.
 template <typename T> class pinned_vec
 {
 public:
-  explicit pinned_vec(const c8p_api* a) : d_a(a) {}
+  explicit pinned_vec(const c8p_api* a) : d_alloc(a->host_alloc), d_free(a->host_free) {}
   pinned_vec(const pinned_vec&) = delete;
   pinned_vec& operator=(const pinned_vec&) = delete;
-  ~pinned_vec() { if (d_p) d_a->host_free(d_p); }
+  ~pinned_vec() { if (d_p) d_free(d_p); }
   T* data() { return d_p; }
   const T* data() const { return d_p; }
   size_t size() const { return d_n; }
@@ -131,30 +118,107 @@ public:
   {
     if (want <= d_cap) return;
     const size_t nc = std::max<size_t>(std::max(want, d_cap * 2), 1u << 14);
-    T* q = static_cast<T*>(d_a->host_alloc(nc * sizeof(T)));
+    T* q = static_cast<T*>(d_alloc(nc * sizeof(T)));
     if (!q) throw std::runtime_error("c8p_host_alloc failed");
     if (d_n) memcpy(static_cast<void*>(q), static_cast<const void*>(d_p), d_n * sizeof(T));
-    if (d_p) d_a->host_free(d_p);
+    if (d_p) d_free(d_p);
     d_p = q; d_cap = nc;
   }
   T* grow(size_t extra) { reserve(d_n + extra); T* r = d_p + d_n; d_n += extra; return r; }
   void resize_uninit(size_t n) { reserve(n); d_n = n; }
 
 private:
-  const c8p_api* d_a;
+  void* (*d_alloc)(uint64_t);
+  void (*d_free)(void*);
   T* d_p = nullptr;
   size_t d_n = 0, d_cap = 0;
 };
 
+// Fused mode hand-over (batching_cfg::fused): what `demod` learned about a BATCH from c8p_rx — the per-packet results and the PDU arena,
+// as downloaded, nothing unpacked — parked until `decode` meets the "c8p_fused" tags that name its packets (value = batch id << 20 |
+// packet index).  Both mirrors live in the flowgraph's process; the tags travel through the scheduler.  One registry operation per
+// batch on either side (rounds 2-4: one map insert, one PDU unpacking and one lookup under the mutex per PACKET).
+struct fused_batch {
+  explicit fused_batch(const c8p_api* a) : outs(a), pdu(a) {}
+  pinned_vec<c8p_pkt_out> outs;       // [packets of the batch]
+  pinned_vec<uint8_t> pdu;            // the PDU arena (whole: its layout is fixed-stride)
+};
+static const int C8P_FUSED_IDX_BITS = 20;
+static std::mutex g_fused_mu;
+static std::map<long, std::shared_ptr<fused_batch>> g_fused;
+static std::atomic<long> g_fused_next{1};
+// A batch is erased when `decode` moves on to the next one.  If no decode is downstream (or tags are dropped, or the flowgraph stops
+// first) nobody does: the map is therefore bounded — the oldest batches go once more than C8P_FUSED_MAX are parked — and a demod front
+// takes the batches it issued with it when it is destroyed.
+static const size_t C8P_FUSED_MAX = 256;
+static void fused_park(long id, std::shared_ptr<fused_batch> f)
+{
+  std::lock_guard<std::mutex> g(g_fused_mu);
+  g_fused[id] = std::move(f);
+  while (g_fused.size() > C8P_FUSED_MAX) g_fused.erase(g_fused.begin());     // (ids grow: begin() is the oldest)
+}
+static std::shared_ptr<fused_batch> fused_find(long id)
+{
+  std::lock_guard<std::mutex> g(g_fused_mu);
+  auto it = g_fused.find(id);
+  return it == g_fused.end() ? std::shared_ptr<fused_batch>() : it->second;
+}
+static void fused_purge(const std::vector<long>& ids)
+{
+  std::lock_guard<std::mutex> g(g_fused_mu);
+  for (long id : ids) g_fused.erase(id);
+}
+
+// the tags of ONE item: [first, last) of a vector sorted by offset
+struct tag_span {
+  const tag_t* first; const tag_t* last;
+  const tag_value* find(const char* key) const
+  {
+    for (const tag_t* t = first; t != last; ++t) if (t->key == key) return &t->value;
+    return nullptr;
+  }
+  long get_long(const char* key, long dflt) const
+  {
+    const tag_value* v = find(key);
+    return v ? (v->kind == tag_value::FLOAT ? (long)v->f : v->l) : dflt;
+  }
+  float get_float(const char* key, float dflt) const
+  {
+    const tag_value* v = find(key);
+    return v ? (v->kind == tag_value::LONG ? (float)v->l : v->f) : dflt;
+  }
+};
+// The tags of the items one general_work call may look at, fetched ONCE per call (rounds 1-4 asked the scheduler per packet:
+// get_tags_in_range locks the buffer and walks its tag list every time) and then walked in step with the items.
+struct tag_cursor {
+  std::vector<tag_t> tags;
+  size_t i = 0;
+  void load(block_io* io, uint64_t a, uint64_t b)
+  {
+    tags.clear(); i = 0;
+    if (b <= a) return;
+    io->get_tags_in_range(tags, 0, a, b);
+    auto by_off = [](const tag_t& x, const tag_t& y) { return x.offset < y.offset; };
+    if (!std::is_sorted(tags.begin(), tags.end(), by_off)) std::stable_sort(tags.begin(), tags.end(), by_off);
+  }
+  // the tags on item `pos`; false: it carries none, and `next` = the next item that does (or `end`)
+  bool at(uint64_t pos, uint64_t end, tag_span& sp, uint64_t& next)
+  {
+    while (i < tags.size() && tags[i].offset < pos) i++;
+    if (i < tags.size() && tags[i].offset == pos) {
+      sp.first = &tags[i];
+      while (i < tags.size() && tags[i].offset == pos) i++;
+      sp.last = tags.data() + i;
+      return true;
+    }
+    next = i < tags.size() ? std::min(tags[i].offset, end) : end;
+    return false;
+  }
+};
 static const tag_value* find_tag(const std::vector<tag_t>& tags, const char* key)
 {
   for (const auto& t : tags) if (t.key == key) return &t.value;
   return nullptr;
-}
-static long tag_long(const std::vector<tag_t>& tags, const char* key, long dflt)
-{
-  const tag_value* v = find_tag(tags, key);
-  return v ? (v->kind == tag_value::FLOAT ? (long)v->f : v->l) : dflt;
 }
 static float tag_float(const std::vector<tag_t>& tags, const char* key, float dflt)
 {
@@ -169,8 +233,8 @@ static long us_since(tick_t t) { return (long)std::chrono::duration_cast<std::ch
 // host-side time per phase of a front (microseconds, accumulated, EXCLUSIVE: entering a phase stops the clock of the one around
 // it): what tools/bench_blocks.py reports as host_phase_us
 struct phase_clock {
-  enum { CUT, SUBMIT, ENQ, ALLOC, WAIT, FETCH, REPLAY, DRAIN, N };
-  double us[N] = {0, 0, 0, 0, 0, 0, 0, 0};
+  enum { CUT, SUBMIT, ENQ, ALLOC, WAIT, FETCH, REPLAY, DRAIN, GATHER, GWAIT, N };
+  double us[N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int cur = -1;
   tick_t t_last;
   void charge()
@@ -187,12 +251,13 @@ struct phase_clock {
   };
   std::string str() const
   {
-    static const char* nm[N] = {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain"};
+    static const char* nm[N] = {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain", "gather_enqueue", "gather_wait"};
     std::string s;
     for (int i = 0; i < N; i++) s += std::string(nm[i]) + "=" + std::to_string((long)us[i]) + ";";
     return s;
   }
 };
+
 typedef phase_clock::scope sub_scope;
 
 // The latency timer of a front.  general_work() only runs while items arrive; `due()` tells when the oldest gathered packet or the
@@ -264,10 +329,77 @@ public:
     if (bytes) check(d_api.fetch(d_ctx, which, v.data(), 0, v.size() * sizeof(T)));
     return v;
   }
+  // device memory a front keeps across submits (the arenas its gathers fill): grown x 2, the first keep_bytes moved along by a copy
+  // on the copy stream (behind every gather enqueued so far); c8p_dev_free waits for that stream before it frees
+  struct dev_buf { void* p = nullptr; size_t cap = 0; };
+  void dev_reserve(dev_buf& b, size_t bytes, size_t keep_bytes)
+  {
+    if (bytes <= b.cap) return;
+    const size_t nc = std::max<size_t>(std::max(bytes, 2 * b.cap), 1u << 20);
+    void* q = d_api.dev_alloc(d_ctx, nc);
+    if (!q) throw std::runtime_error(std::string("c8p_dev_alloc failed: ") + d_api.last_error(d_ctx));
+    if (b.p) {
+      if (keep_bytes) check(d_api.copy_async(d_ctx, q, b.p, keep_bytes), "arena move");
+      d_api.dev_free(d_ctx, b.p);
+    }
+    b.p = q; b.cap = nc;
+  }
+  void dev_release(dev_buf& b) { if (b.p) d_api.dev_free(d_ctx, b.p); b.p = nullptr; b.cap = 0; }
   c8p_api d_api;
   batching_cfg d_cfg;
   c8p_ctx* d_ctx = nullptr;
   bool d_two_resident = true;
+};
+typedef engine_holder::dev_buf dev_buf;
+
+// The pieces one general_work call cuts out of a pinned scheduler buffer, and when their items may be consumed.  All pieces of a call
+// go to the device with ONE c8p_copy_gather (`flush`); with batching_cfg::defer_consume the items are consumed one call later — by then
+// the gather has had a scheduler round trip to finish and `settle` returns at once — otherwise at the end of the same call, after a wait.
+struct gather_lane {
+  std::vector<c8p_piece> pieces;
+  uint64_t scan_abs = 0;                 // port 0: items cut so far (absolute); items before it are never looked at again
+  uint64_t prev_mark = 0, prev_scan = 0; // the copy-stream mark behind the previous call's gather and the scan position it covers
+  bool have_prev = false;
+  void add(const void* src, uint64_t dst_off, uint64_t n, uint32_t fmt)
+  {
+    if (!n) return;
+    // (a packet cut by a call boundary continues where the last piece ended, in the buffer and in the arena: one piece)
+    if (!pieces.empty()) {
+      c8p_piece& b = pieces.back();
+      const size_t isz = fmt == C8P_FMT_F32 ? 4 : 8;
+      if (b.fmt == fmt && (const char*)b.src + b.n * isz == (const char*)src && b.dst_off + b.n == dst_off) { b.n += n; return; }
+    }
+    c8p_piece pc;
+    memset(&pc, 0, sizeof(pc));
+    pc.src = src; pc.dst_off = dst_off; pc.n = n; pc.trusted = 1; pc.fmt = fmt; pc.scale = 1.0f;
+    pieces.push_back(pc);
+  }
+  void flush(engine_holder& E, void* dst)
+  {
+    if (pieces.empty()) return;
+    E.check(E.d_api.copy_gather(E.d_ctx, static_cast<c8p_c32*>(dst), pieces.data(), (int32_t)pieces.size()), "c8p_copy_gather");
+    pieces.clear();
+    dirty = true;
+  }
+  // at the end of a call that looked at the items [rd, rd + used): how many of them may be consumed now
+  int settle(engine_holder& E, uint64_t rd, int used, phase_clock& ph)
+  {
+    scan_abs = std::max(scan_abs, rd + (uint64_t)used);
+    if (!dirty && !have_prev) return used;                                           // nothing of this window is on its way
+    const c8p_api& A = E.d_api;
+    uint64_t m = prev_mark;
+    if (dirty) { m = A.copy_mark(E.d_ctx); if (!m) throw std::runtime_error("c8p_copy_mark failed"); dirty = false; }
+    sub_scope w(ph, phase_clock::GWAIT);
+    if (!E.d_cfg.defer_consume) { E.check(A.copy_wait_mark(E.d_ctx, m), "c8p_copy_wait_mark"); have_prev = false; return used; }
+    int cons = 0;
+    if (have_prev) {
+      E.check(A.copy_wait_mark(E.d_ctx, prev_mark), "c8p_copy_wait_mark");
+      cons = (int)std::min<uint64_t>(prev_scan > rd ? prev_scan - rd : 0, (uint64_t)used);
+    }
+    prev_mark = m; prev_scan = scan_abs; have_prev = rd + (uint64_t)cons < scan_abs;     // (everything consumed: nothing left to settle)
+    return cons;
+  }
+  bool dirty = false;                    // a gather has been enqueued since the last mark
 };
 
 // ================================================================================================ demod / demod2
@@ -283,8 +415,16 @@ public:
   ~demod_front() override
   {
     d_timer.stop();
-    fused_purge(d_fused_ids);                      // the handles this front parked and no decode picked up
+    fused_purge(d_fused_ids);                      // the batches this front parked and no decode picked up
+    d_outq.clear(); d_hold.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
+    for (stage& st : d_st) { d_eng.dev_release(st.d_iq); d_eng.dev_release(st.d_chan); }
   }
+
+  // the io_signature's buffer type (c8p_blocks.h): pinned host memory for the item ports; in fused mode the output items are never written
+  bool wants_pinned_input(unsigned) const override { return d_eng.d_cfg.pinned_io; }
+  bool wants_pinned_output(unsigned) const override { return d_eng.d_cfg.pinned_io && !d_eng.d_cfg.fused; }
+  void* buffer_alloc(size_t bytes) override { return d_eng.d_api.host_alloc(bytes); }
+  void buffer_free(void* p) override { d_eng.d_api.host_free(p); }
 
   void forecast(int noutput_items, gr_vector_int& req) override   // demod_impl.cc:53-57
   {
@@ -302,39 +442,55 @@ public:
     std::lock_guard<std::mutex> g(d_mu);
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
+    if (!d_mode_known) {
+      d_in_dev = d_eng.d_cfg.pinned_io;
+      for (int p = 0; p < d_nports; p++) d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p);
+      d_out_dev = d_eng.d_cfg.pinned_io && !d_eng.d_cfg.fused && d_io->output_is_pinned(0);
+      d_mode_known = true;
+    }
     int nproc = ninput_items[0];
     for (int p = 1; p < d_nports; p++) nproc = std::min(nproc, ninput_items[p]);
+    const uint64_t rd = d_io->nitems_read(0);
+    // A pinned output buffer: the LLR items that are ready start moving FIRST — one kernel that writes them where the scheduler wants
+    // them — and the input work below runs meanwhile; the call waits for them last
+    int produced = 0;
+    uint64_t out_mark = 0;
+    if (d_out_dev) produced = drain_scatter(static_cast<float*>(output_items[0]), noutput_items, out_mark);
     int used = 0;
+    if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
+      if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
+      used = (int)std::min<uint64_t>(d_lane.scan_abs - rd, (uint64_t)nproc);
+    }
+    d_tc.load(d_io, rd + (uint64_t)used, rd + (uint64_t)nproc);
     while (used < nproc) {
-      stage& st = d_st[d_fill];
       if (d_state == S_RDTAG) {
-        std::vector<tag_t> tags;
-        const uint64_t pos = d_io->nitems_read(0) + used;
-        d_io->get_tags_in_range(tags, 0, pos, pos + 1);
-        if (tags.empty()) { used++; continue; }     // the reference would wait here forever; we resynchronise
+        tag_span tg;
+        uint64_t next = 0;
+        if (!d_tc.at(rd + (uint64_t)used, rd + (uint64_t)nproc, tg, next)) { used = (int)(next - rd); continue; }   // the reference would wait here forever; we resynchronise
+        stage& st = d_st[d_fill];
         memset(&d_cur, 0, sizeof(d_cur));
-        d_cur.cfo = tag_float(tags, "cfo", 0.f); d_cur.snr = tag_float(tags, "snr", 0.f); d_cur.rssi = tag_float(tags, "rssi", 0.f);
-        d_cur.seq = (int32_t)tag_long(tags, "seq", -1);
-        d_cur.lsig_mcs = (int32_t)tag_long(tags, "mcs", -1);
-        d_cur.lsig_len = (int32_t)tag_long(tags, "len", -1);
-        d_cur.lsig_nsamp = (int32_t)tag_long(tags, "nsamp", -1);
+        d_cur.cfo = tg.get_float("cfo", 0.f); d_cur.snr = tg.get_float("snr", 0.f); d_cur.rssi = tg.get_float("rssi", 0.f);
+        d_cur.seq = (int32_t)tg.get_long("seq", -1);
+        d_cur.lsig_mcs = (int32_t)tg.get_long("mcs", -1);
+        d_cur.lsig_len = (int32_t)tg.get_long("len", -1);
+        d_cur.lsig_nsamp = (int32_t)tg.get_long("nsamp", -1);
         d_cur.n_ant = (uint8_t)d_nports; d_cur.mupos = (uint8_t)(d_mupos ? 1 : 0);
         d_cur.n_items = (uint32_t)std::max(d_cur.lsig_nsamp, 0) + 320u;     // demod_impl.cc:92
         d_cur.chan_off = (uint32_t)st.chan.size();
-        const tag_value* ch = find_tag(tags, "chan");
+        const tag_value* ch = tg.find("chan");
         gr_complex* c = st.chan.grow(64);
         for (int i = 0; i < 64; i++) c[i] = ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f);
-        for (int p = 0; p < d_nports; p++) {
-          d_cur.iq_off[p] = st.iq.size();
-          st.iq.grow(d_cur.n_items);
-        }
+        for (int p = 0; p < d_nports; p++) d_cur.iq_off[p] = iq_alloc(st, d_cur.n_items);
         d_have = 0;
         d_state = S_COLLECT;
       }
+      stage& st = d_st[d_fill];
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.n_items - d_have);
-      for (int p = 0; p < d_nports; p++)
-        memcpy(static_cast<void*>(st.iq.data() + d_cur.iq_off[p] + d_have), static_cast<const gr_complex*>(input_items[p]) + used,
-               sizeof(gr_complex) * (size_t)take);
+      for (int p = 0; p < d_nports; p++) {
+        const gr_complex* src = static_cast<const gr_complex*>(input_items[p]) + used;
+        if (d_in_dev) d_lane.add(src, d_cur.iq_off[p] + (uint64_t)d_have, (uint64_t)take, C8P_FMT_C32);
+        else memcpy(static_cast<void*>(st.iq.data() + d_cur.iq_off[p] + d_have), src, sizeof(gr_complex) * (size_t)take);
+      }
       d_have += take; used += take;
       if (d_have == (int)d_cur.n_items) {
         if (st.pk.empty()) st.t_first = now_tick();
@@ -344,10 +500,20 @@ public:
       }
     }
     if (d_eng.d_cfg.flush_when_idle) age_check();
-    d_io->consume_each(used);
+    int cons = used;
+    if (d_in_dev) {
+      { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_iq.p); }
+      cons = d_lane.settle(d_eng, rd, used, d_ph);
+    }
+    d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     const bool pending = !d_st[d_fill].pk.empty() || d_st[d_fill ^ 1].ticket != 0;
     if (pending) d_timer.poke();
+    if (d_out_dev) {
+      if (out_mark) { sub_scope w(d_ph, phase_clock::GWAIT); d_eng.check(d_eng.d_api.copy_wait_mark(d_eng.d_ctx, out_mark), "c8p_copy_wait_mark"); }
+      d_hold.clear();
+      return produced;
+    }
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
@@ -387,44 +553,74 @@ public:
 
 private:
   struct result {             // downloaded arenas of one batch, shared by its packets until they have been drained
-    explicit result(const c8p_api* a) : llr(a), outs(a), pdu(a) {}
-    pinned_vec<float> llr;
-    pinned_vec<c8p_pkt_out> outs;     // fused mode: per-packet results and the PDU arena (whole: its layout is fixed-stride)
-    pinned_vec<uint8_t> pdu;
+    result(engine_holder* e) : eng(e), llr(&e->d_api) {}
+    ~result() { eng->dev_release(dev_llr); }
+    engine_holder* eng;
+    pinned_vec<float> llr;            // pageable output buffer: the LLR arena on the host
+    dev_buf dev_llr;                  // pinned output buffer: a device copy of the LLR arena (the engine's own is recycled with its slot)
   };
   struct stage {              // one batch being gathered / in flight: its arenas must stay untouched until the submit has completed
     explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a) {}
-    pinned_vec<gr_complex> iq, chan;
+    pinned_vec<gr_complex> iq, chan;    // host staging (iq: pageable input buffers only)
+    dev_buf d_iq, d_chan;               // pinned input buffers: the batch's arenas on the device, filled by the gathers
+    size_t iq_items = 0;                // ... and the items laid out in d_iq so far
     std::vector<c8p_pkt_in> pk;
     int ticket = 0;
     tick_t t_first, t_submit;   // when the first packet was complete / when the batch was submitted
     pinned_vec<c8p_pkt_tags> tags;      // downloads enqueued at submit time, right behind the kernels: they run while the
     std::shared_ptr<result> res;        // next batch is being gathered; collect() only waits
+    std::shared_ptr<fused_batch> fb;    // fused mode: the decoded results, handed to decode as they are
   };
   struct out_pkt {
     std::vector<std::pair<std::string, tag_value>> tags;
     std::shared_ptr<result> res;
-    const float* llr = nullptr;   // null (fused mode): the items are produced, their values are not written
+    const float* llr = nullptr;       // host copy (pageable output) or device copy (pinned output); null (fused mode): the items are
+    bool on_device = false;           // produced, their values are not written
     size_t n = 0, sent = 0;
   };
+
+  // where the next packet's items go in the batch's arena
+  uint64_t iq_alloc(stage& st, uint32_t n)
+  {
+    if (!d_in_dev) { const uint64_t off = st.iq.size(); st.iq.grow(n); return off; }
+    const uint64_t off = st.iq_items;
+    st.iq_items += n;
+    if (st.iq_items * sizeof(gr_complex) > st.d_iq.cap) {
+      // (pieces carry offsets; the base they are added to is about to change: what was cut so far goes to the old arena first)
+      d_lane.flush(d_eng, st.d_iq.p);
+      const size_t first = (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 4096u * (size_t)d_nports * sizeof(gr_complex);
+      d_eng.dev_reserve(st.d_iq, std::max(first, (size_t)st.iq_items * sizeof(gr_complex)), (size_t)off * sizeof(gr_complex));
+    }
+    return off;
+  }
 
   // A result's pinned buffers are sized for the largest batch seen so far by ANY result (d_hwm_*): batches cut short by the
   // latency bound have all sizes, and a buffer that grows batch by batch is a hipHostMalloc + hipHostFree of tens of megabytes
   // each time (measured: 1.5-2.9 us per packet of the chain, profiles/r3c/blocks_phases.txt)
-  std::shared_ptr<result> acquire(size_t llr_items, size_t n_pkt, size_t pdu_bytes)
+  std::shared_ptr<result> acquire(size_t llr_items, size_t n_pkt)
   {
     // (scaled to a full batch at once: batch sizes are random, and a mark that creeps up record by record re-allocates every
     // pooled buffer at each new record)
     const size_t full = (size_t)std::max(d_eng.d_cfg.max_batch, 1), np = std::max<size_t>(n_pkt, 1);
     d_hwm_llr = std::max(d_hwm_llr, (llr_items + np - 1) / np * full);
-    d_hwm_pkt = std::max(d_hwm_pkt, std::max(n_pkt, full));
-    d_hwm_pdu = std::max(d_hwm_pdu, (pdu_bytes + np - 1) / np * full);
     std::shared_ptr<result> r;
     for (auto& q : d_pool) if (q.use_count() == 1) { r = q; break; }
-    if (!r) { d_pool.push_back(std::make_shared<result>(&d_eng.d_api)); r = d_pool.back(); }
-    r->llr.clear(); r->outs.clear(); r->pdu.clear();
-    if (llr_items) r->llr.reserve(d_hwm_llr);
-    if (pdu_bytes) { r->outs.reserve(d_hwm_pkt); r->pdu.reserve(d_hwm_pdu); }
+    if (!r) { d_pool.push_back(std::make_shared<result>(&d_eng)); r = d_pool.back(); }
+    r->llr.clear();
+    if (llr_items && !d_out_dev) r->llr.reserve(d_hwm_llr);
+    if (llr_items && d_out_dev) d_eng.dev_reserve(r->dev_llr, d_hwm_llr * sizeof(float), 0);
+    return r;
+  }
+  std::shared_ptr<fused_batch> acquire_fused(size_t n_pkt, size_t pdu_bytes)
+  {
+    const size_t full = (size_t)std::max(d_eng.d_cfg.max_batch, 1), np = std::max<size_t>(n_pkt, 1);
+    d_hwm_pkt = std::max(d_hwm_pkt, std::max(n_pkt, full));
+    d_hwm_pdu = std::max(d_hwm_pdu, (pdu_bytes + np - 1) / np * full);
+    std::shared_ptr<fused_batch> r;
+    for (auto& q : d_fpool) if (q.use_count() == 1) { r = q; break; }     // (decode has let go of it and it has left the registry)
+    if (!r) { d_fpool.push_back(std::make_shared<fused_batch>(&d_eng.d_api)); r = d_fpool.back(); }
+    r->outs.reserve(d_hwm_pkt); r->pdu.reserve(d_hwm_pdu);
+    r->outs.resize_uninit(n_pkt); r->pdu.resize_uninit(pdu_bytes);
     return r;
   }
 
@@ -433,42 +629,64 @@ private:
   void submit(bool last)
   {
     stage& st = d_st[d_fill];
+    const c8p_api& A = d_eng.d_api;
     // a packet that is still being received lives at the end of this stage's arenas: it moves to the next stage
     std::vector<gr_complex> part_iq[2], part_chan;
+    uint64_t part_off[2] = {0, 0};
     if (d_state == S_COLLECT) {
-      for (int p = 0; p < d_nports; p++) part_iq[p].assign(st.iq.data() + d_cur.iq_off[p], st.iq.data() + d_cur.iq_off[p] + d_have);
+      for (int p = 0; p < d_nports; p++) {
+        part_off[p] = d_cur.iq_off[p];
+        if (!d_in_dev) part_iq[p].assign(st.iq.data() + d_cur.iq_off[p], st.iq.data() + d_cur.iq_off[p] + d_have);
+      }
       part_chan.assign(st.chan.data() + d_cur.chan_off, st.chan.data() + d_cur.chan_off + 64);
     }
     if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_batch_in b;
     memset(&b, 0, sizeof(b));
-    b.n_pkt = (int32_t)st.pk.size(); b.mem = C8P_MEM_HOST; b.pkts = st.pk.data();
-    b.iq = reinterpret_cast<const c8p_c32*>(st.iq.data()); b.n_iq = st.iq.size();
-    b.chan = reinterpret_cast<const c8p_c32*>(st.chan.data()); b.n_chan = st.chan.size();
+    b.n_pkt = (int32_t)st.pk.size(); b.pkts = st.pk.data();
+    if (!d_in_dev) {
+      b.mem = C8P_MEM_HOST;
+      b.iq = reinterpret_cast<const c8p_c32*>(st.iq.data()); b.n_iq = st.iq.size();
+      b.chan = reinterpret_cast<const c8p_c32*>(st.chan.data()); b.n_chan = st.chan.size();
+    } else {
+      // the items are on the device already or on their way (the calls' gathers); the channel estimates follow on the same stream, and
+      // the submit's own stream waits for all of it ON THE DEVICE (c8p_copy_fence): no host thread waits for the link
+      sub_scope pg(d_ph, phase_clock::GATHER);
+      d_lane.flush(d_eng, st.d_iq.p);
+      d_eng.dev_reserve(st.d_chan, std::max<size_t>(st.chan.size(), (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 64u) * sizeof(gr_complex), 0);
+      d_eng.check(A.copy_async(d_eng.d_ctx, st.d_chan.p, st.chan.data(), st.chan.size() * sizeof(gr_complex)), "chan upload");
+      d_eng.check(A.copy_fence(d_eng.d_ctx), "c8p_copy_fence");
+      b.mem = C8P_MEM_DEVICE;
+      b.iq = static_cast<const c8p_c32*>(st.d_iq.p); b.n_iq = st.iq_items;
+      b.chan = static_cast<const c8p_c32*>(st.d_chan.p); b.n_chan = st.chan.size();
+    }
     sub_scope ph(d_ph, phase_clock::SUBMIT);
-    d_eng.check(d_eng.d_cfg.fused ? d_eng.d_api.rx(d_eng.d_ctx, &b) : d_eng.d_api.demod(d_eng.d_ctx, &b));
-    st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
+    d_eng.check(d_eng.d_cfg.fused ? A.rx(d_eng.d_ctx, &b) : A.demod(d_eng.d_ctx, &b));
+    st.ticket = A.ticket(d_eng.d_ctx);
     st.t_submit = now_tick();
     {
       sub_scope phq(d_ph, phase_clock::ENQ);
-      const c8p_api& A = d_eng.d_api;
       st.tags.resize_uninit(st.pk.size());
       d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_TAGS, st.tags.data(), 0, st.pk.size() * sizeof(c8p_pkt_tags)), "tags");
       uint64_t bytes = 0, pbytes = 0;
       {
         sub_scope pha(d_ph, phase_clock::ALLOC);
-        if (!d_eng.d_cfg.fused) A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
-        else A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
-        st.res = acquire(bytes / sizeof(float), st.pk.size(), pbytes);
-        st.res->llr.resize_uninit(bytes / sizeof(float));
+        if (!d_eng.d_cfg.fused) {
+          A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
+          st.res = acquire(bytes / sizeof(float), st.pk.size());
+          if (!d_out_dev) st.res->llr.resize_uninit(bytes / sizeof(float));
+        } else {
+          A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
+          st.fb = acquire_fused(st.pk.size(), pbytes);
+        }
       }
-      if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use)
-        if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, st.res->llr.data(), 0, bytes), "llr");
+      if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use):
+        // to the host (a pageable output buffer: drain() copies the packets' items out of it) or into a device buffer of this front
+        // (a pinned one: drain_scatter() moves the items from there, however long the scheduler takes to offer the space)
+        if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, d_out_dev ? st.res->dev_llr.p : (void*)st.res->llr.data(), 0, bytes), "llr");
       } else {                        // fused: the decoded results, enqueued behind the kernels like the tags (collect() only waits)
-        st.res->outs.resize_uninit(st.pk.size());
-        st.res->pdu.resize_uninit(pbytes);
-        d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.res->outs.data(), 0, st.pk.size() * sizeof(c8p_pkt_out)), "outs");
-        if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.res->pdu.data(), 0, pbytes), "pdu");
+        d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.fb->outs.data(), 0, st.pk.size() * sizeof(c8p_pkt_out)), "outs");
+        if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.fb->pdu.data(), 0, pbytes), "pdu");
       }
     }
     ph.end();
@@ -476,14 +694,20 @@ private:
     if (prev.ticket) collect(prev);
     if (last) collect(st);
     else d_fill ^= 1;
+    // (device arenas: a packet that is still being received always moves to the OTHER stage's arena — collected above, so free —
+    // and never inside one arena, where source and destination could overlap)
+    if (last && d_state == S_COLLECT && d_in_dev) d_fill ^= 1;
     if (d_state == S_COLLECT) {
       stage& nx = d_st[d_fill];
       d_cur.chan_off = (uint32_t)nx.chan.size();
       memcpy(static_cast<void*>(nx.chan.grow(64)), part_chan.data(), 64 * sizeof(gr_complex));
       for (int p = 0; p < d_nports; p++) {
-        d_cur.iq_off[p] = nx.iq.size();
-        gr_complex* dst = nx.iq.grow(d_cur.n_items);
-        if (d_have) memcpy(static_cast<void*>(dst), part_iq[p].data(), sizeof(gr_complex) * (size_t)d_have);
+        d_cur.iq_off[p] = iq_alloc(nx, d_cur.n_items);
+        if (!d_have) continue;
+        if (!d_in_dev) memcpy(static_cast<void*>(nx.iq.data() + d_cur.iq_off[p]), part_iq[p].data(), sizeof(gr_complex) * (size_t)d_have);
+        else                                                        // device to device, behind the gathers that brought the items
+          d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<gr_complex*>(nx.d_iq.p) + d_cur.iq_off[p],
+                                   static_cast<const gr_complex*>(st.d_iq.p) + part_off[p], sizeof(gr_complex) * (size_t)d_have), "partial packet move");
       }
     }
   }
@@ -498,54 +722,45 @@ private:
       d_eng.check(A.wait(ctx, st.ticket), "wait");               // kernels + the downloads enqueued behind them
     }
     sub_scope ph(d_ph, phase_clock::REPLAY);
-    d_eng.check(A.select(ctx, st.ticket), "select");
     const c8p_pkt_tags* tags = st.tags.data();
     const bool fused = d_eng.d_cfg.fused;
     std::shared_ptr<result> res = st.res;
     st.res.reset();
-    const c8p_pkt_out* outs = res->outs.data();      // fused mode (downloaded behind the kernels)
-    const uint8_t* pdu = res->pdu.data();
-    const uint64_t pdu_base = 0;
+    long fb_id = 0;
+    if (fused) {                                   // the whole batch behind ONE handle; a packet's tag names its index
+      fb_id = g_fused_next.fetch_add(1);
+      d_fused_ids.push_back(fb_id);
+      if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
+      fused_park(fb_id, st.fb);
+      st.fb.reset();
+    }
+    bool selected = false;
     for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = tags[p];
       if (t.status != C8P_ST_OK) continue;          // DEMOD_S_CLEAN without tags: nothing reaches decode
-      out_pkt o;
-      auto L = [&](const char* k, long v) { o.tags.push_back({k, tag_value::from_long(v)}); };
-      auto F = [&](const char* k, float v) { o.tags.push_back({k, tag_value::from_float(v)}); };
+      d_outq.emplace_back();
+      out_pkt& o = d_outq.back();
+      o.tags.reserve(16);
+      auto L = [&](const char* k, long v) { o.tags.emplace_back(k, tag_value::from_long(v)); };
+      auto F = [&](const char* k, float v) { o.tags.emplace_back(k, tag_value::from_float(v)); };
       F("cfo", t.cfo); F("snr", t.snr);
       if (t.format == C8P_F_VHT) { F("sssnr0", t.sssnr0); if (d_nports == 2 && t.nss == 2) F("sssnr1", t.sssnr1); }
       F("rssi", t.rssi);
       L("format", t.format); L("mcs", t.mcs); L("len", t.len); L("cr", t.cr); L("ampdu", t.ampdu); L("trellis", t.trellis);
       if (t.is_ndp) {
         std::vector<gr_complex> c(128);
+        if (!selected) { d_eng.check(A.select(ctx, st.ticket), "select"); selected = true; }
         d_eng.check(A.fetch(ctx, C8P_BUF_MUCHAN, c.data(), 128 * p * sizeof(gr_complex), 128 * sizeof(gr_complex)));
-        o.tags.push_back({"mu2x1chan", tag_value::from_c32vector(c)});
+        o.tags.emplace_back("mu2x1chan", tag_value::from_c32vector(c));
       }
       L("total", t.total);
       o.n = (size_t)std::max(t.total, 0);
-      if (!fused) { o.res = res; o.llr = res->llr.data() + t.llr_off; }
-      else {
-        fused_pkt f;
-        const c8p_pkt_out& po = outs[p];
-        size_t off = (size_t)(po.pdu_off - pdu_base);
-        for (int k = 0; k < po.n_pdu; k++) {
-          const int len = pdu[off] | (pdu[off + 1] << 8);
-          pdu_t m;
-          m.len = len;
-          m.blob.assign(pdu + off + 2, pdu + off + 2 + len);
-          off += 2 + (size_t)len;
-          f.pdus.push_back(std::move(m));
-        }
-        f.n_crc_fail = po.n_crc_fail;
-        const long id = g_fused_next.fetch_add(1);
-        d_fused_ids.push_back(id);
-        if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
-        fused_park(id, std::move(f));
-        L("c8p_fused", id);
-      }
-      d_outq.push_back(std::move(o));
+      if (!fused) {
+        o.res = res; o.on_device = d_out_dev;
+        o.llr = (d_out_dev ? static_cast<const float*>(res->dev_llr.p) : res->llr.data()) + t.llr_off;
+      } else L("c8p_fused", (fb_id << C8P_FUSED_IDX_BITS) | (long)p);
     }
-    st.pk.clear(); st.iq.clear(); st.chan.clear(); st.ticket = 0;
+    st.pk.clear(); st.iq.clear(); st.chan.clear(); st.iq_items = 0; st.ticket = 0;
   }
 
   int drain(float* out, int noutput_items)
@@ -557,10 +772,42 @@ private:
       if (o.sent == 0)
         for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
       const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
+      // (fused mode: the items exist and are counted, their VALUES ARE NOT WRITTEN — c8p_blocks.h; 57 KB of zeros per packet was a
+      // third of this thread's time, and nothing downstream of a fused demod may read them)
       if (o.llr) memcpy(out + produced, o.llr + o.sent, sizeof(float) * k);
-      else memset(out + produced, 0, sizeof(float) * k);     // fused mode: the items exist, their values are zeros (not stale memory)
       o.sent += k; produced += (int)k;
       if (o.sent == o.n) d_outq.pop_front();
+    }
+    return produced;
+  }
+
+  // drain() for a pinned output buffer: the items of every packet that fits go from the front's device copy of the LLR arena into the
+  // scheduler's buffer with ONE c8p_copy_gather (device -> pinned host: the shader cores write over PCIe), only the bytes the packets
+  // use (the arena's layout is ~1.8x that), no host copy in between.  mark: what to wait for before the items may be reported
+  int drain_scatter(float* out, int noutput_items, uint64_t& mark)
+  {
+    sub_scope ph(d_ph, phase_clock::DRAIN);
+    int produced = 0;
+    d_opieces.clear();
+    while (!d_outq.empty() && produced < noutput_items) {
+      out_pkt& o = d_outq.front();
+      if (o.sent == 0)
+        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
+      const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
+      if (k && o.llr) {
+        c8p_piece pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.src = o.llr + o.sent; pc.dst_off = (uint64_t)produced; pc.n = k; pc.trusted = 1; pc.fmt = C8P_FMT_F32; pc.scale = 1.0f;
+        d_opieces.push_back(pc);
+      }
+      o.sent += k; produced += (int)k;
+      if (o.sent == o.n) { d_hold.push_back(std::move(o.res)); d_outq.pop_front(); }    // (its arena is being read until the mark)
+    }
+    if (!d_opieces.empty()) {
+      const c8p_api& A = d_eng.d_api;
+      d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
+      mark = A.copy_mark(d_eng.d_ctx);
+      if (!mark) throw std::runtime_error("c8p_copy_mark failed");
     }
     return produced;
   }
@@ -570,14 +817,19 @@ private:
   phase_clock d_ph;
   engine_holder d_eng;
   int d_nports, d_mupos, d_mugid;
+  bool d_mode_known = false, d_in_dev = false, d_out_dev = false;     // pinned scheduler buffers on the input ports / the output port
   c8p_pkt_in d_cur;
   int d_have = 0;
   stage d_st[2];
   int d_fill = 0;                                  // the stage being gathered; the other one may be in flight
-  std::vector<std::shared_ptr<result>> d_pool;
+  tag_cursor d_tc;
+  gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
+  std::vector<c8p_piece> d_opieces;
+  std::vector<std::shared_ptr<result>> d_pool, d_hold;
+  std::vector<std::shared_ptr<fused_batch>> d_fpool;
   size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;
   std::deque<out_pkt> d_outq;
-  std::vector<long> d_fused_ids;                   // handles this front parked in g_fused (the last 64k-128k of them)
+  std::vector<long> d_fused_ids;                   // batches this front parked in g_fused (the last 256-512 of them)
   latency_timer d_timer;                           // last member: its thread uses everything above
 };
 
@@ -850,7 +1102,16 @@ public:
     memset(d_htMcsCount, 0, sizeof(d_htMcsCount));
     if (cfg.flush_when_idle) d_timer.start();       // (its results are messages: published from the timer thread, no call needed)
   }
-  ~decode_front() override { d_timer.stop(); }
+  ~decode_front() override
+  {
+    d_timer.stop();
+    for (stage& st : d_st) { d_eng.dev_release(st.d_llr); d_eng.dev_release(st.d_mu); }
+  }
+
+  // the io_signature's buffer type (c8p_blocks.h): the LLR stream arrives in pinned host memory
+  bool wants_pinned_input(unsigned) const override { return d_eng.d_cfg.pinned_io; }
+  void* buffer_alloc(size_t bytes) override { return d_eng.d_api.host_alloc(bytes); }
+  void buffer_free(void* p) override { d_eng.d_api.host_free(p); }
 
   std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
   void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
@@ -866,37 +1127,48 @@ public:
     std::lock_guard<std::mutex> g(d_mu);
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
+    if (!d_mode_known) { d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0); d_mode_known = true; }
     const float* in = static_cast<const float*>(input_items[0]);
     const int nproc = ninput_items[0];
+    const uint64_t rd = d_io->nitems_read(0);
     int used = 0;
+    if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
+      if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
+      used = (int)std::min<uint64_t>(d_lane.scan_abs - rd, (uint64_t)nproc);
+    }
+    d_tc.load(d_io, rd + (uint64_t)used, rd + (uint64_t)nproc);
     while (used < nproc) {
-      stage& st = d_st[d_fill];
       if (d_state == S_IDLE) {
-        std::vector<tag_t> tags;
-        const uint64_t pos = d_io->nitems_read(0) + used;
-        d_io->get_tags_in_range(tags, 0, pos, pos + 1);
-        if (tags.empty()) { used++; continue; }
+        tag_span tg;
+        uint64_t next = 0;
+        if (!d_tc.at(rd + (uint64_t)used, rd + (uint64_t)nproc, tg, next)) { used = (int)(next - rd); continue; }
+        stage& st = d_st[d_fill];
         memset(&d_cur, 0, sizeof(d_cur));
         d_cur.status = C8P_ST_OK;
-        d_cur.format = (int32_t)tag_long(tags, "format", 99999); d_cur.len = (int32_t)tag_long(tags, "len", 99999);
-        d_cur.total = (int32_t)tag_long(tags, "total", 99999); d_cur.cr = (int32_t)tag_long(tags, "cr", 99999);
-        d_cur.mcs = (int32_t)tag_long(tags, "mcs", 99999); d_cur.ampdu = (int32_t)tag_long(tags, "ampdu", 99999);
-        d_cur.trellis = (int32_t)tag_long(tags, "trellis", 99999);
-        d_cur.cfo = tag_float(tags, "cfo", 0.f); d_cur.snr = tag_float(tags, "snr", 0.f); d_cur.rssi = tag_float(tags, "rssi", 0.f);
-        d_cur.sssnr0 = tag_float(tags, "sssnr0", 0.f); d_cur.sssnr1 = tag_float(tags, "sssnr1", 0.f);
+        d_cur.format = (int32_t)tg.get_long("format", 99999); d_cur.len = (int32_t)tg.get_long("len", 99999);
+        d_cur.total = (int32_t)tg.get_long("total", 99999); d_cur.cr = (int32_t)tg.get_long("cr", 99999);
+        d_cur.mcs = (int32_t)tg.get_long("mcs", 99999); d_cur.ampdu = (int32_t)tg.get_long("ampdu", 99999);
+        d_cur.trellis = (int32_t)tg.get_long("trellis", 99999);
+        d_cur.cfo = tg.get_float("cfo", 0.f); d_cur.snr = tg.get_float("snr", 0.f); d_cur.rssi = tg.get_float("rssi", 0.f);
+        d_cur.sssnr0 = tg.get_float("sssnr0", 0.f); d_cur.sssnr1 = tg.get_float("sssnr1", 0.f);
         d_cur.is_ndp = d_cur.trellis == 0;
-        d_cur_fused = tag_long(tags, "c8p_fused", -1);
+        d_cur_fused = tg.get_long("c8p_fused", -1);
         if (d_cur_fused < 0) {
-          d_cur.llr_off = st.llr.size();
-          const tag_value* mu = find_tag(tags, "mu2x1chan");
+          d_cur.llr_off = llr_alloc(st, (size_t)std::max(d_cur.total, 0));
+          const tag_value* mu = tg.find("mu2x1chan");
+          d_cur_mu = mu != nullptr;
+          if (mu) st.any_mu = true;
           for (int i = 0; i < 128; i++) st.mu.push_back(mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f));
-          st.llr.grow((size_t)std::max(d_cur.total, 0));
         }
         d_have = 0;
         d_state = S_COLLECT;
       }
+      stage& st = d_st[d_fill];
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.total - d_have);
-      if (take > 0 && d_cur_fused < 0) memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
+      if (take > 0 && d_cur_fused < 0) {
+        if (d_in_dev) d_lane.add(in + used, d_cur.llr_off + (uint64_t)d_have, (uint64_t)take, C8P_FMT_F32);
+        else memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
+      }
       d_have += std::max(take, 0); used += std::max(take, 0);
       if (d_have >= d_cur.total) {
         d_state = S_IDLE;
@@ -909,8 +1181,14 @@ public:
         }
       }
     }
+    used = std::min(used, nproc);
     if (d_eng.d_cfg.flush_when_idle) age_check();
-    d_io->consume_each(std::min(used, nproc));
+    int cons = used;
+    if (d_in_dev) {
+      { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_llr.p); }
+      cons = d_lane.settle(d_eng, rd, used, d_ph);
+    }
+    d_io->consume_each(cons);
     const bool pending = !d_st[d_fill].tags.empty() || d_st[d_fill ^ 1].ticket != 0;
     if (pending) d_timer.poke();
     return 0;
@@ -944,7 +1222,10 @@ public:
 private:
   struct stage {
     explicit stage(const c8p_api* a) : llr(a), outs(a), pdu(a) {}
-    pinned_vec<float> llr;
+    pinned_vec<float> llr;            // host staging (a pageable input buffer only)
+    dev_buf d_llr, d_mu;              // a pinned input buffer: the batch's LLR arena on the device, filled by the calls' gathers
+    size_t llr_items = 0;
+    bool any_mu = false;              // a packet of the batch carries "mu2x1chan" (an NDP): its captures have to travel too
     std::vector<c8p_pkt_tags> tags;
     std::vector<gr_complex> mu;
     int ticket = 0;
@@ -953,32 +1234,63 @@ private:
     pinned_vec<uint8_t> pdu;          // (the whole fixed-stride PDU arena: ~1 MB per 256 packets)
   };
 
+  // where the next packet's LLR items go in the batch's arena
+  uint64_t llr_alloc(stage& st, size_t n)
+  {
+    if (!d_in_dev) { const uint64_t off = st.llr.size(); st.llr.grow(n); return off; }
+    const uint64_t off = st.llr_items;
+    st.llr_items += n;
+    if (st.llr_items * sizeof(float) > st.d_llr.cap) {
+      d_lane.flush(d_eng, st.d_llr.p);             // (what was cut so far goes to the old arena; the move below follows it)
+      const size_t first = (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 16384u * sizeof(float);
+      d_eng.dev_reserve(st.d_llr, std::max(first, st.llr_items * sizeof(float)), (size_t)off * sizeof(float));
+    }
+    return off;
+  }
+
   void submit(bool last)
   {
     stage& st = d_st[d_fill];
+    const c8p_api& A = d_eng.d_api;
     const bool part = d_state == S_COLLECT && d_cur_fused < 0;      // a packet still being received moves to the next stage
     std::vector<float> part_llr;
     std::vector<gr_complex> part_mu;
+    const uint64_t part_off = d_cur.llr_off;
     if (part) {
-      part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
+      if (!d_in_dev) part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
       part_mu.assign(st.mu.end() - 128, st.mu.end());
     }
     if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_decode_in b;
     memset(&b, 0, sizeof(b));
-    b.n_pkt = (int32_t)st.tags.size(); b.mem = C8P_MEM_HOST; b.tags = st.tags.data();
-    if (st.llr.empty()) *st.llr.grow(1) = 0.f;
-    b.llr = st.llr.data(); b.n_llr = st.llr.size();
-    b.mu2x1chan = reinterpret_cast<const c8p_c32*>(st.mu.data());
+    b.n_pkt = (int32_t)st.tags.size(); b.tags = st.tags.data();
+    if (!d_in_dev) {
+      b.mem = C8P_MEM_HOST;
+      if (st.llr.empty()) *st.llr.grow(1) = 0.f;
+      b.llr = st.llr.data(); b.n_llr = st.llr.size();
+      b.mu2x1chan = reinterpret_cast<const c8p_c32*>(st.mu.data());
+    } else {
+      // the LLR items are on the device or on their way; the submit's stream waits for them on the device (c8p_copy_fence)
+      sub_scope pg(d_ph, phase_clock::GATHER);
+      if (!st.d_llr.p) d_eng.dev_reserve(st.d_llr, 4096, 0);
+      d_lane.flush(d_eng, st.d_llr.p);
+      if (st.any_mu) {                             // NDP captures ride along (rare: one sounding per channel update)
+        d_eng.dev_reserve(st.d_mu, st.mu.size() * sizeof(gr_complex), 0);
+        d_eng.check(A.copy_async(d_eng.d_ctx, st.d_mu.p, st.mu.data(), st.mu.size() * sizeof(gr_complex)), "mu2x1chan upload");
+      }
+      d_eng.check(A.copy_fence(d_eng.d_ctx), "c8p_copy_fence");
+      b.mem = C8P_MEM_DEVICE;
+      b.llr = static_cast<const float*>(st.d_llr.p); b.n_llr = std::max<size_t>(st.llr_items, 1);
+      b.mu2x1chan = st.any_mu ? static_cast<const c8p_c32*>(st.d_mu.p) : nullptr;
+    }
     {
       sub_scope ph(d_ph, phase_clock::SUBMIT);
-      d_eng.check(d_eng.d_api.decode(d_eng.d_ctx, &b), "decode");
-      st.ticket = d_eng.d_api.ticket(d_eng.d_ctx);
+      d_eng.check(A.decode(d_eng.d_ctx, &b), "decode");
+      st.ticket = A.ticket(d_eng.d_ctx);
       st.t_submit = now_tick();
     }
     {
       sub_scope ph(d_ph, phase_clock::ENQ);
-      const c8p_api& A = d_eng.d_api;
       uint64_t pbytes = 0;
       A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
       {
@@ -996,11 +1308,16 @@ private:
     if (prev.ticket) collect(prev);
     if (last) collect(st);
     else d_fill ^= 1;
+    if (last && part && d_in_dev) d_fill ^= 1;      // (see demod_front::submit: never a move inside one device arena)
     if (part) {
       stage& nx = d_st[d_fill];
-      d_cur.llr_off = nx.llr.size();
-      float* dst = nx.llr.grow((size_t)std::max(d_cur.total, 0));
-      if (d_have) memcpy(dst, part_llr.data(), sizeof(float) * (size_t)d_have);
+      d_cur.llr_off = llr_alloc(nx, (size_t)std::max(d_cur.total, 0));
+      if (d_have) {
+        if (!d_in_dev) memcpy(nx.llr.data() + d_cur.llr_off, part_llr.data(), sizeof(float) * (size_t)d_have);
+        else d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<float*>(nx.d_llr.p) + d_cur.llr_off, static_cast<const float*>(st.d_llr.p) + part_off,
+                                      sizeof(float) * (size_t)d_have), "partial packet move");
+      }
+      if (d_cur_mu) nx.any_mu = true;
       nx.mu.insert(nx.mu.end(), part_mu.begin(), part_mu.end());
     }
   }
@@ -1016,45 +1333,42 @@ private:
     }
     const c8p_pkt_out* outs = st.outs.data();
     const uint8_t* pdu = st.pdu.data();
-    const uint64_t lo = 0;
     sub_scope phr(d_ph, phase_clock::REPLAY);
-    for (size_t p = 0; p < n; p++) {
-      const c8p_pkt_tags& t = st.tags[p];
-      const c8p_pkt_out& o = outs[p];
-      size_t off = o.n_pdu > 0 ? (size_t)(o.pdu_off - lo) : 0;
-      for (int k = 0; k < o.n_pdu; k++) {
-        const int len = pdu[off] | (pdu[off + 1] << 8);
-        pdu_t m;
-        m.len = len;
-        m.blob.assign(pdu + off + 2, pdu + off + 2 + len);
-        off += 2 + (size_t)len;
-        if (t.trellis != 0) debug_line(t, true);
-        d_io->message_port_pub("out", m);
-      }
-      for (int k = 0; k < o.n_crc_fail; k++) debug_line(t, false);
-    }
-    st.tags.clear(); st.llr.clear(); st.mu.clear(); st.ticket = 0;
+    for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], outs[p], pdu);
+    st.tags.clear(); st.llr.clear(); st.mu.clear(); st.llr_items = 0; st.any_mu = false; st.ticket = 0;
   }
 
-  // fused mode: the packet was decoded on the device when `demod` ran c8p_rx; its results wait behind the handle.
+  // one packet's records {u16 len, blob} out of a PDU arena -> messages, with the reference's debug lines
+  void publish_packet(const c8p_pkt_tags& t, const c8p_pkt_out& o, const uint8_t* pdu)
+  {
+    size_t off = o.n_pdu > 0 ? (size_t)o.pdu_off : 0;
+    for (int k = 0; k < o.n_pdu; k++) {
+      const int len = pdu[off] | (pdu[off + 1] << 8);
+      d_msg.len = len;
+      d_msg.blob.assign(pdu + off + 2, pdu + off + 2 + len);
+      off += 2 + (size_t)len;
+      if (t.trellis != 0) debug_line(t, true);
+      d_io->message_port_pub("out", d_msg);
+    }
+    for (int k = 0; k < o.n_crc_fail; k++) debug_line(t, false);
+  }
+
+  // fused mode: the packet was decoded on the device when `demod` ran c8p_rx; its batch's results wait behind the handle.
   // Everything gathered before it is published first, so the message order stays the arrival order.
   void publish_fused()
   {
     if (!d_st[d_fill].tags.empty()) submit(true);
     else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
-    fused_pkt f;
-    {
-      std::lock_guard<std::mutex> g(g_fused_mu);
-      auto it = g_fused.find(d_cur_fused);
-      if (it == g_fused.end()) return;            // a handle from another process / a replayed capture: nothing to publish
-      f = std::move(it->second);
-      g_fused.erase(it);
+    const long id = d_cur_fused >> C8P_FUSED_IDX_BITS;
+    const size_t idx = (size_t)(d_cur_fused & ((1L << C8P_FUSED_IDX_BITS) - 1));
+    if (id != d_fb_id) {                           // the next batch: the one before it has been published, it leaves the registry
+      if (d_fb) fused_purge(std::vector<long>(1, d_fb_id));
+      d_fb = fused_find(id);
+      d_fb_id = id;
     }
-    for (const pdu_t& m : f.pdus) {
-      if (d_cur.trellis != 0) debug_line(d_cur, true);
-      d_io->message_port_pub("out", m);
-    }
-    for (int k = 0; k < f.n_crc_fail; k++) debug_line(d_cur, false);
+    if (!d_fb || idx >= d_fb->outs.size()) return;                  // a handle from another process / a replayed capture: nothing to publish
+    sub_scope phr(d_ph, phase_clock::REPLAY);
+    publish_packet(d_cur, d_fb->outs.data()[idx], d_fb->pdu.data());
   }
 
   // decode_impl.cc:375-411 (vht) and :454-509 (legacy / ht)
@@ -1084,11 +1398,18 @@ private:
   phase_clock d_ph;
   engine_holder d_eng;
   bool d_debug;
+  bool d_mode_known = false, d_in_dev = false;     // the input port's buffer is pinned host memory
   c8p_pkt_tags d_cur;
   int d_have = 0;
   long d_cur_fused = -1;
+  bool d_cur_mu = false;                           // the packet being received carries "mu2x1chan"
+  long d_fb_id = 0;                                // fused mode: the batch whose packets are arriving
+  std::shared_ptr<fused_batch> d_fb;
+  pdu_t d_msg;                                     // (reused: its blob keeps its capacity)
   stage d_st[2];
   int d_fill = 0;
+  tag_cursor d_tc;
+  gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
   size_t d_hwm_pdu = 0;
   latency_timer d_timer;                           // last member: its thread uses everything above

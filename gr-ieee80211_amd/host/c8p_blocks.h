@@ -82,6 +82,14 @@ public:
   // scheduler to call general_work() again — forecast() then asks for no input, so the call is made even though there is none.
   // (A gr::block does it by posting a message to a port of its own, which wakes its scheduler thread.)
   virtual void wake() {}
+  // GNU Radio 3.10 custom buffers.  A gr::block names a gr::buffer_type per port in its io_signature and the scheduler allocates the
+  // buffer of that edge through it (flat_flowgraph::allocate_buffer; gnuradio-runtime's host_buffer is the template).  The mirrors' type
+  // is PINNED HOST MEMORY (c8p_block::buffer_alloc): the upstream block writes its items where the device can read them, so a front
+  // gathers the packets out of the scheduler's buffer with one kernel (c8p_copy_gather) instead of memcpy -> pinned staging -> H2D, and
+  // demod's LLR items are written into the output buffer by the device.  These two say whether the scheduler did so for a port
+  // (false: an ordinary pageable buffer — the fronts then stage through pinned copies of their own, as in rounds 1-4).
+  virtual bool input_is_pinned(unsigned port) { return false; }
+  virtual bool output_is_pinned(unsigned port) { return false; }
 };
 
 // the C ABI the blocks call; defaults to the symbols of libc8p_rx.so, tests inject another table
@@ -117,6 +125,7 @@ struct c8p_api {
   int (*copy_gather)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t);
   uint64_t (*copy_mark)(c8p_ctx*);
   int (*copy_wait_mark)(c8p_ctx*, uint64_t);
+  int (*copy_fence)(c8p_ctx*);
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);
@@ -136,7 +145,15 @@ struct batching_cfg {
   // items whose VALUES ARE NOT WRITTEN, and `decode` publishes the PDUs behind the handle instead of decoding the items.
   // Tags, item counts, PDU bytes and debug lines are unchanged; anything else that reads the LLR items must not use it.
   bool fused = default_fused();
+  // Custom buffers (block_io::input_is_pinned / output_is_pinned): use them when the scheduler provides them (default; environment
+  // C8P_PINNED_IO=0 turns it off).  defer_consume: a front then consumes the items of a general_work call during the NEXT call, when
+  // the gather that moves them has had a scheduler round trip to finish — nothing waits for the link; 0 (C8P_DEFER_CONSUME=0): the gather is
+  // waited for at the end of the same call (what a single-mapped custom buffer that relocates unread items asks for).
+  bool pinned_io = default_pinned_io();
+  bool defer_consume = default_defer_consume();
   static bool default_fused();
+  static bool default_pinned_io();
+  static bool default_defer_consume();
   static int default_max_wait_us();
 };
 
@@ -152,6 +169,12 @@ public:
   // where the host side of this block spent its time, in microseconds since it was made: "name=us;..." (tools/bench_blocks.py)
   virtual std::string host_phase_us() { return std::string(); }
   virtual void host_phase_reset() {}
+  // The buffer type this block's io_signature names for its ports (see block_io::input_is_pinned): which ports want a buffer from
+  // buffer_alloc, and the allocator itself (pinned host memory of the engine library; nullptr: the block has no engine to ask)
+  virtual bool wants_pinned_input(unsigned port) const { return false; }
+  virtual bool wants_pinned_output(unsigned port) const { return false; }
+  virtual void* buffer_alloc(size_t bytes) { return nullptr; }
+  virtual void buffer_free(void* p) {}
   void set_io(block_io* io) { d_io = io; }
 
 protected:

@@ -2,6 +2,7 @@
 // an in-memory block_io (tagged item streams in, items/tags/messages out) plus a tiny run loop that calls
 // general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -19,23 +20,71 @@ struct harness : public block_io {
   std::shared_ptr<c8p_block> blk;
   // the block goes first: its threads (a front's latency timer, rx_chain's pipeline) call wake() / message_port_pub() on this object
   // until they are joined, and `blk` is the first member — it would be destroyed LAST, after the mutexes and the condition variable
-  ~harness() override { blk.reset(); }
+  ~harness() override { if (blk) release_buffers(); blk.reset(); }
   int nports = 1, nout = 1;
   size_t item_size = sizeof(gr_complex);        // items of the stream ports
   size_t port0_size = 0;                        // != 0: port 0 carries items of another size (signal: sync bytes)
   size_t out_size = sizeof(float);
   size_t isz(int q) const { return (q == 0 && port0_size) ? port0_size : item_size; }
-  std::vector<std::vector<uint8_t>> in;         // per port; the unread part starts at in_pos[port] bytes (compacted now and then)
-  std::vector<size_t> in_pos;
-  size_t avail(int q) const { return (in[q].size() - in_pos[q]) / isz(q); }
-  const uint8_t* rd(int q) const { return in[q].data() + in_pos[q]; }
+  // One input buffer per port; the unread part starts at `pos` bytes.  When the block's io_signature names its buffer type for the port
+  // (c8p_block::wants_pinned_input) the memory comes from the block's allocator, as GNU Radio 3.10 allocates an edge's buffer through the
+  // gr::buffer_type of the block behind it: pinned host memory, which is never moved or compacted while items of it may be on their way
+  // to the device.
+  struct ibuf {
+    uint8_t* p = nullptr; size_t size = 0, cap = 0, pos = 0; bool pinned = false;
+  };
+  std::vector<ibuf> in;
+  bool pinned_out = false;
+  bool poison = false;                          // consumed input items are overwritten at once (a test: nothing may still be reading them)
+  void* balloc(size_t bytes, bool pinned) { void* q = pinned ? blk->buffer_alloc(bytes) : malloc(bytes); if (!q) throw std::runtime_error("harness: no memory for a buffer"); return q; }
+  void bfree(void* q, bool pinned) { if (!q) return; if (pinned) blk->buffer_free(q); else free(q); }
+  void setup_buffers()
+  {
+    in.resize(nports);
+    for (int q = 0; q < nports; q++) in[q].pinned = blk->wants_pinned_input((unsigned)q);
+    pinned_out = blk->wants_pinned_output(0);
+  }
+  // the segments of an edge this harness allocated for c8ph_run_chain: kept from one run to the next (pinning 96 MB takes tens of ms)
+  std::vector<float*> edge; size_t edge_floats = 0; bool edge_pinned = false;
+  float** edge_segments(size_t floats, bool pinned)
+  {
+    if (edge.size() == 3 && edge_floats >= floats && edge_pinned == pinned) return edge.data();
+    for (float* q : edge) bfree(q, edge_pinned);
+    edge.clear();
+    for (int i = 0; i < 3; i++) edge.push_back(static_cast<float*>(balloc(floats * sizeof(float), pinned)));
+    edge_floats = floats; edge_pinned = pinned;
+    return edge.data();
+  }
+  void release_buffers()
+  {
+    for (ibuf& b : in) { bfree(b.p, b.pinned); b.p = nullptr; }
+    for (float* q : edge) bfree(q, edge_pinned);
+    edge.clear();
+  }
+  void append(int q, const uint8_t* src, size_t bytes)
+  {
+    ibuf& b = in[q];
+    if (b.size + bytes > b.cap) {
+      const size_t nc = std::max<size_t>(std::max(b.size + bytes, 2 * b.cap), 1u << 16);
+      uint8_t* np = static_cast<uint8_t*>(balloc(nc, b.pinned));
+      if (b.size > b.pos) memcpy(np + b.pos, b.p + b.pos, b.size - b.pos);
+      bfree(b.p, b.pinned);
+      b.p = np; b.cap = nc;
+    }
+    memcpy(b.p + b.size, src, bytes);
+    b.size += bytes;
+  }
+  size_t avail(int q) const { return (in[q].size - in[q].pos) / isz(q); }
+  const uint8_t* rd(int q) const { return in[q].p + in[q].pos; }
   void advance(int q, size_t items)
   {
-    in_pos[q] += items * isz(q);
-    // consumed items are dropped in bulk, rarely: a scheduler's circular buffer costs nothing per item, and an erase here is a
+    ibuf& b = in[q];
+    if (poison && items) memset(b.p + b.pos, 0xff, items * isz(q));
+    b.pos += items * isz(q);
+    // consumed items are dropped in bulk, rarely: a scheduler's circular buffer costs nothing per item, and a compaction here is a
     // memmove of everything still unread (tens of megabytes in a throughput run: 2-3 us per packet of the chain when done at 4 MB)
-    if (in_pos[q] == in[q].size()) { in[q].clear(); in_pos[q] = 0; }
-    else if (in_pos[q] > (1u << 28) && in_pos[q] * 2 > in[q].size()) { in[q].erase(in[q].begin(), in[q].begin() + (long)in_pos[q]); in_pos[q] = 0; }
+    if (b.pos == b.size) { b.size = 0; b.pos = 0; }
+    else if (!b.pinned && b.pos > (1u << 28) && b.pos * 2 > b.size) { memmove(b.p, b.p + b.pos, b.size - b.pos); b.size -= b.pos; b.pos = 0; }
   }
   bool tags_sorted = true;
   std::vector<tag_t> in_tags;                   // port 0, absolute offsets
@@ -71,6 +120,16 @@ struct harness : public block_io {
   void debug_print(const std::string& s) override { std::lock_guard<std::mutex> g(msg_mu); dbg.push_back(s); }
   // the front's latency timer asks for a call (results became ready while no input was arriving)
   void wake() override { { std::lock_guard<std::mutex> g(wake_mu); woken = true; } wake_cv.notify_all(); }
+  bool input_is_pinned(unsigned port) override { return port < in.size() && in[port].pinned; }
+  bool output_is_pinned(unsigned) override { return pinned_out; }
+  // an output buffer of n floats, from the block's allocator when its io_signature says so
+  struct obuf_t {
+    harness* h; float* p; bool pinned;
+    obuf_t(harness* h_, size_t n) : h(h_), pinned(h_->pinned_out) { p = static_cast<float*>(h->balloc(std::max<size_t>(n, 16) * sizeof(float), pinned)); }
+    ~obuf_t() { h->bfree(p, pinned); }
+    obuf_t(const obuf_t&) = delete;
+    obuf_t& operator=(const obuf_t&) = delete;
+  };
   std::mutex msg_mu, wake_mu;
   std::condition_variable wake_cv;
   bool woken = false;
@@ -82,13 +141,17 @@ struct harness : public block_io {
 extern "C" {
 
 // fused: 0 / 1 = batching_cfg::fused, -1 = its default (environment C8P_FUSED)
-void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, int fused, char* errbuf, int errcap)
+// pinned_io / defer_consume: 0 / 1 = batching_cfg's fields, -1 = their defaults (environment C8P_PINNED_IO, C8P_DEFER_CONSUME)
+void* c8ph_create_ex2(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, int fused, int pinned_io, int defer_consume,
+                      char* errbuf, int errcap)
 {
   try {
     harness* h = new harness();
     c8p_api api = load_c8p_api(lib);
     batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
     if (fused >= 0) cfg.fused = fused != 0;
+    if (pinned_io >= 0) cfg.pinned_io = pinned_io != 0;
+    if (defer_consume >= 0) cfg.defer_consume = defer_consume != 0;
     if (kind == 0) { h->blk = demod::make(mupos, 0, api, cfg); h->nports = 1; }
     else if (kind == 1) { h->blk = demod2::make(api, cfg); h->nports = 2; }
     else if (kind == 2) { h->blk = decode::make(ifdebug != 0, api, cfg); h->nports = 1; h->item_size = sizeof(float); }
@@ -99,14 +162,17 @@ void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_
       h->blk = rx_chain::make(kind - 100, lib, cfg); h->nports = kind - 100;
     }
     else { cfg.detect_items = max_batch; h->blk = detect::make(api, cfg); h->nports = 1; h->out_size = 1; }   // max_batch = items per call
-    h->in.resize(h->nports);
-    h->in_pos.assign(h->nports, 0);
+    h->setup_buffers();
     h->blk->set_io(h);
     return h;
   } catch (const std::exception& e) {
     if (errbuf && errcap > 0) { strncpy(errbuf, e.what(), errcap - 1); errbuf[errcap - 1] = 0; }
     return nullptr;
   }
+}
+void* c8ph_create_ex(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, int fused, char* errbuf, int errcap)
+{
+  return c8ph_create_ex2(kind, mupos, ifdebug, lib, max_batch, flush_idle, fused, -1, -1, errbuf, errcap);
 }
 // rx_chain with item_format C8P_FMT_* ports (gr_complex / std::complex<short> / std::complex<char> items) and its conversion scale
 void* c8ph_create_rx_chain(int n_streams, int item_format, float scale, const char* lib, int items_per_round, int flush_idle, char* errbuf, int errcap)
@@ -117,8 +183,7 @@ void* c8ph_create_rx_chain(int n_streams, int item_format, float scale, const ch
     h->blk = rx_chain::make(n_streams, lib, cfg, item_format, scale);
     h->nports = n_streams;
     h->item_size = item_format == C8P_FMT_SC16 ? 4 : item_format == C8P_FMT_SC8 ? 2 : sizeof(gr_complex);
-    h->in.resize(h->nports);
-    h->in_pos.assign(h->nports, 0);
+    h->setup_buffers();
     h->blk->set_io(h);
     return h;
   } catch (const std::exception& e) {
@@ -135,8 +200,7 @@ void c8ph_destroy(void* p) { delete static_cast<harness*>(p); }
 void c8ph_push_items(void* p, int port, const void* data, long n_items)
 {
   harness* h = static_cast<harness*>(p);
-  const uint8_t* b = static_cast<const uint8_t*>(data);
-  h->in[port].insert(h->in[port].end(), b, b + (size_t)n_items * h->isz(port));
+  h->append(port, static_cast<const uint8_t*>(data), (size_t)n_items * h->isz(port));
 }
 void c8ph_push_tag_long(void* p, uint64_t off, const char* key, long v)
 {
@@ -159,6 +223,11 @@ void c8ph_push_tag_c32(void* p, uint64_t off, const char* key, const float* reim
 // others, sometimes none) and a random output space (1..nout) on every call, the way a busy scheduler does
 void c8ph_set_capture(void* p, int on) { static_cast<harness*>(p)->capture = on != 0; }
 void c8ph_set_jitter(void* p, unsigned long long seed) { static_cast<harness*>(p)->jitter = seed ? seed : 0; }
+// from now on every consumed input item (and every recycled buffer of c8ph_run_chain's edge) is overwritten with 0xff bytes at once: a
+// block that lets go of items something is still reading — a gather it has not waited for — produces wrong results instead of passing by luck
+void c8ph_set_poison(void* p, int on) { static_cast<harness*>(p)->poison = on != 0; }
+int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->input_is_pinned((unsigned)port) ? 1 : 0; }
+int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
 
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 {
@@ -167,7 +236,8 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     long calls = 0;
     int idle = 0, starved = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);   // floats per output item (byte items: widened below)
-    std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
+    harness::obuf_t ob0(h, (size_t)std::max(nout, 1) * fpi), ob1(h, (size_t)std::max(nout, 1) * fpi);
+    float* const obuf = ob0.p; float* const obuf1 = ob1.p;
     while (idle < 4) {
       size_t avail = h->avail(0);
       for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->avail(q));
@@ -186,8 +256,8 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       }
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
-      gr_vector_void_star outs(1, obuf.data());
-      if (h->nout == 2) outs.push_back(obuf1.data());
+      gr_vector_void_star outs(1, obuf);
+      if (h->nout == 2) outs.push_back(obuf1);
       h->consumed_this_call = 0;
       const int produced = h->blk->general_work(nout_call, nin, ins, outs);
       calls++;
@@ -195,11 +265,11 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       h->n_read += h->consumed_this_call;
       if (!h->capture) {
       } else if (h->out_size == 1) {                                // byte stream: one float per item in the capture
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf.data());
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf);
         for (int i = 0; i < produced; i++) h->out_items.push_back((float)b[i]);
       } else
-        h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
-      if (h->nout == 2 && h->capture) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
+        h->out_items.insert(h->out_items.end(), obuf, obuf + (size_t)produced * fpi);
+      if (h->nout == 2 && h->capture) h->out_items1.insert(h->out_items1.end(), obuf1, obuf1 + (size_t)produced * fpi);
       h->n_written += produced;
       if (!full) {                                                  // a starved call that got nowhere proves nothing
         if (produced || h->consumed_this_call) { idle = 0; starved = 0; } else starved++;
@@ -216,26 +286,40 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
   }
 }
 // Two blocks the way a flowgraph runs them: each on its own thread (GNU Radio's thread-per-block scheduler), A's output
-// port 0 (items + tags) feeding B's input port 0 through a queue.  A's items are not captured (c8ph_out_count stays 0), B's
-// messages / debug lines are.  Returns the number of general_work calls of both, -1 on error (c8ph_error of either).
+// port 0 (items + tags) feeding B's input port 0 through the buffer of that edge.  A's items are not captured (c8ph_out_count stays 0),
+// B's messages / debug lines are.  Returns the number of general_work calls of both, -1 on error (c8ph_error of either).
 long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
 {
   harness* A = static_cast<harness*>(pa);
   harness* B = static_cast<harness*>(pb);
-  // As between two GNU Radio blocks, an item crosses the edge with ONE write (A's general_work, straight into the buffer) and ONE
-  // read (B's general_work, straight out of it): buffers travel through the queue and back through a free list, nothing is copied
-  // in between.  (The first version copied every piece twice more; at 57 KB of LLRs per packet that was a third of the chain's time.)
-  struct piece { std::vector<float> items; size_t n = 0; std::vector<tag_t> tags; };
+  // The edge's buffer, as between two GNU Radio blocks: an item crosses it with ONE write (A's general_work, straight into the buffer)
+  // and ONE read (B's general_work, straight out of it), A's output pointer continues where its last call stopped, and B reads what A
+  // has produced while A goes on producing.  A ring is stood in for by three long segments that are used in turn (A moves on when the
+  // space left in one is less than a call's worth, B when it has consumed a closed one to its end): no item ever moves.  The memory
+  // comes from the blocks' buffer type when either names one for this edge (pinned host memory), as flat_flowgraph::allocate_buffer
+  // picks an edge's gr::buffer_type.
+  const size_t fpi = std::max<size_t>(A->out_size / sizeof(float), 1);
+  const bool pin_edge = A->pinned_out || B->in[0].pinned;
+  harness* owner = A->pinned_out ? A : B;
+  A->pinned_out = pin_edge; B->in[0].pinned = pin_edge;          // what the two blocks are told about the edge
+  const size_t seg_floats = std::max<size_t>((size_t)std::max(nout, 1) * fpi * 16, (size_t)1 << 23);
+  struct segment { float* items = nullptr; size_t n = 0; bool closed = false; };      // n, closed: under mu
+  segment segs[3];
+  {
+    float** e = owner->edge_segments(seg_floats, pin_edge);
+    for (int i = 0; i < 3; i++) segs[i].items = e[i];
+  }
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::unique_ptr<piece>> q, pool;
-  bool a_done = false, failed = false;
+  std::deque<int> filled, spare = {0, 1, 2};   // segments A has written into (in order; the last one may still be open) / free ones
+  std::deque<tag_t> tagq;                      // A's tags on their way to B's input (moved before the items they sit on are published)
+  bool a_done = false;
+  std::atomic<bool> failed{false};
   long calls_a = 0, calls_b = 0;
-  const size_t fpi = std::max<size_t>(A->out_size / sizeof(float), 1);
   std::thread ta([&] {
     try {
-      int idle = 0;
-      std::unique_ptr<piece> cur;
+      int idle = 0, cur = -1;
+      size_t wpos = 0;                           // floats of the current segment handed to B so far
       while (idle < 4) {
         size_t avail = A->avail(0);
         for (int qq = 1; qq < A->nports; qq++) avail = std::min(avail, A->avail(qq));
@@ -243,12 +327,21 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         gr_vector_int nin(A->nports, n);
         gr_vector_const_void_star ins(A->nports);
         for (int qq = 0; qq < A->nports; qq++) ins[qq] = A->rd(qq);
-        if (!cur) {
-          std::lock_guard<std::mutex> g(mu);
-          if (!pool.empty()) { cur = std::move(pool.front()); pool.pop_front(); }
+        if (cur >= 0 && seg_floats - wpos < (size_t)std::max(nout, 1) * fpi) {     // not a call's worth of space left: the next segment
+          { std::lock_guard<std::mutex> g(mu); segs[cur].closed = true; }
+          cv.notify_all();
+          cur = -1;
         }
-        if (!cur) { cur.reset(new piece()); cur->items.resize((size_t)std::max(nout, 1) * fpi); }
-        gr_vector_void_star outs(1, cur->items.data());
+        if (cur < 0) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !spare.empty() || failed; });                   // (back-pressure: B has not finished a segment yet)
+          if (failed) break;
+          cur = spare.front(); spare.pop_front();
+          segs[cur].n = 0; segs[cur].closed = false;
+          filled.push_back(cur);
+          wpos = 0;
+        }
+        gr_vector_void_star outs(1, segs[cur].items + wpos);
         A->consumed_this_call = 0;
         const size_t tags_before = A->out_tags.size();
         const int produced = A->blk->general_work(nout, nin, ins, outs);
@@ -256,68 +349,76 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
         A->n_read += A->consumed_this_call;
         A->n_written += produced;
-        if (produced > 0) {
-          cur->n = (size_t)produced * fpi;
-          cur->tags.assign(std::make_move_iterator(A->out_tags.begin() + (std::ptrdiff_t)tags_before), std::make_move_iterator(A->out_tags.end()));
+        if (produced > 0 || A->out_tags.size() > tags_before) {
+          std::lock_guard<std::mutex> g(mu);
+          for (size_t k = tags_before; k < A->out_tags.size(); k++) tagq.push_back(std::move(A->out_tags[k]));
           A->out_tags.resize(tags_before);
-          { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(cur)); }
-          cv.notify_one();
+          wpos += (size_t)produced * fpi;
+          segs[cur].n = wpos;
         }
+        if (produced > 0) cv.notify_all();
         idle = (produced == 0 && A->consumed_this_call == 0) ? idle + 1 : 0;
         if (idle == 2 && avail == 0) A->blk->flush();
       }
+      if (cur >= 0) { std::lock_guard<std::mutex> g(mu); segs[cur].closed = true; }
     } catch (const std::exception& e) { A->err = e.what(); failed = true; }
     { std::lock_guard<std::mutex> g(mu); a_done = true; }
-    cv.notify_one();
+    cv.notify_all();
   });
   try {
     std::vector<float> dummy(16);
     gr_vector_void_star outs(1, dummy.data());
-    std::vector<float> carry;                      // items B left unconsumed at the end of a piece (it never does: kept for safety)
+    int cur = -1;
+    size_t rpos = 0;                             // floats of the current segment B has consumed
+    int fruitless = 0;                           // calls in a row that consumed nothing although nothing new had arrived
+    size_t seen = 0;
     for (;;) {
-      std::unique_ptr<piece> pc;
-      bool fin;
+      size_t n_avail = 0;
+      bool closed = false, fin = false;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !q.empty() || a_done; });
-        if (!q.empty()) { pc = std::move(q.front()); q.pop_front(); }
-        fin = a_done && !pc;
+        for (;;) {
+          if (cur < 0 && !filled.empty()) { cur = filled.front(); rpos = 0; seen = 0; fruitless = 0; }
+          if (cur >= 0) {
+            n_avail = segs[cur].n - rpos; closed = segs[cur].closed;
+            if (closed && n_avail == 0) {           // consumed to its end: back to A
+              if (B->poison) memset(segs[cur].items, 0xff, seg_floats * sizeof(float));
+              filled.pop_front(); spare.push_back(cur); cur = -1;
+              cv.notify_all();
+              continue;
+            }
+            // something to offer: new items, or items B has looked at but not let go of yet (a deferred consume: the next call settles it)
+            if (n_avail > 0 && (segs[cur].n > seen || fruitless < 2)) break;
+          }
+          if (a_done && filled.empty()) { fin = true; break; }
+          if (a_done && cur >= 0 && fruitless >= 2) { fin = true; break; }          // (never: a block that sits on items it will not consume)
+          cv.wait(lk);
+        }
+        while (!tagq.empty()) { B->push_tag(std::move(tagq.front())); tagq.pop_front(); }
+        if (cur >= 0) seen = segs[cur].n;
       }
       if (fin) break;
-      for (tag_t& t : pc->tags) B->push_tag(std::move(t));
-      pc->tags.clear();
-      const float* base = pc->items.data();
-      size_t n = pc->n;
-      if (!carry.empty()) { carry.insert(carry.end(), base, base + n); base = carry.data(); n = carry.size(); }
-      size_t pos = 0;
-      int stuck = 0;
-      while (pos < n && stuck < 2) {
-        const int k = (int)std::min<size_t>(n - pos, (size_t)chunk);
-        gr_vector_int nin(1, k);
-        gr_vector_const_void_star ins(1, base + pos);
-        B->consumed_this_call = 0;
-        B->blk->general_work(0, nin, ins, outs);
-        calls_b++;
-        pos += (size_t)B->consumed_this_call;
-        B->n_read += B->consumed_this_call;
-        stuck = B->consumed_this_call == 0 ? stuck + 1 : 0;
-      }
-      std::vector<float> rest(base + pos, base + n);
-      carry.swap(rest);
-      { std::lock_guard<std::mutex> g(mu); pool.push_back(std::move(pc)); }
-    }
-    // the producer is done and everything it made was offered: a few dry calls, then end of stream
-    for (int idle = 0; idle < 4; idle++) {
-      gr_vector_int nin(1, (int)carry.size());
-      gr_vector_const_void_star ins(1, carry.data());
+      const int k = (int)std::min<size_t>(n_avail, (size_t)chunk);
+      gr_vector_int nin(1, k);
+      gr_vector_const_void_star ins(1, segs[cur].items + rpos);
       B->consumed_this_call = 0;
       B->blk->general_work(0, nin, ins, outs);
       calls_b++;
+      if (B->poison && B->consumed_this_call) memset(segs[cur].items + rpos, 0xff, (size_t)B->consumed_this_call * sizeof(float));
+      rpos += (size_t)B->consumed_this_call;
       B->n_read += B->consumed_this_call;
-      carry.erase(carry.begin(), carry.begin() + B->consumed_this_call);
+      fruitless = B->consumed_this_call == 0 ? fruitless + 1 : 0;
+    }
+    // the producer is done and everything it made was offered: a few dry calls, then end of stream
+    for (int idle = 0; idle < 4; idle++) {
+      gr_vector_int nin(1, 0);
+      gr_vector_const_void_star ins(1, dummy.data());
+      B->consumed_this_call = 0;
+      B->blk->general_work(0, nin, ins, outs);
+      calls_b++;
       if (idle == 1) B->blk->flush();
     }
-  } catch (const std::exception& e) { B->err = e.what(); failed = true; }
+  } catch (const std::exception& e) { B->err = e.what(); { std::lock_guard<std::mutex> g(mu); failed = true; } cv.notify_all(); }
   ta.join();
   return failed ? -1 : calls_a + calls_b;
 }
@@ -332,7 +433,8 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
   try {
     long calls = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);
-    std::vector<float> obuf((size_t)std::max(nout, 1) * fpi), obuf1((size_t)std::max(nout, 1) * fpi);
+    harness::obuf_t ob0(h, (size_t)std::max(nout, 1) * fpi), ob1(h, (size_t)std::max(nout, 1) * fpi);
+    float* const obuf = ob0.p; float* const obuf1 = ob1.p;
     const auto t_end_idle = std::chrono::milliseconds(linger_ms);
     auto idle_since = std::chrono::steady_clock::now();
     for (;;) {
@@ -357,16 +459,16 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
       gr_vector_int nin(h->nports, n);
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
-      gr_vector_void_star outs(1, obuf.data());
-      if (h->nout == 2) outs.push_back(obuf1.data());
+      gr_vector_void_star outs(1, obuf);
+      if (h->nout == 2) outs.push_back(obuf1);
       h->consumed_this_call = 0;
       const int produced = h->blk->general_work(nout, nin, ins, outs);
       calls++;
       for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
       h->n_read += h->consumed_this_call;
       if (h->capture) {
-        h->out_items.insert(h->out_items.end(), obuf.begin(), obuf.begin() + (size_t)produced * fpi);
-        if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1.begin(), obuf1.begin() + (size_t)produced * fpi);
+        h->out_items.insert(h->out_items.end(), obuf, obuf + (size_t)produced * fpi);
+        if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1, obuf1 + (size_t)produced * fpi);
       }
       h->n_written += produced;
       if (produced || h->consumed_this_call) idle_since = std::chrono::steady_clock::now();

@@ -150,8 +150,24 @@ struct run_state {
   std::mutex err_mu;
   std::string first_err;
   c8p_rawchain_stats st;
+  // one record and one mark per segment / round.  A run reserves them (n_seg is known); a LIVE session has no end, so it keeps a
+  // bounded window: the last LIVE_HISTORY..2 LIVE_HISTORY rounds (80 B a round: unbounded, 0.25-1 GB a day and a whole-history copy
+  // on the rx thread at every doubling).  The counters in `st` are running sums and do not depend on the window.
   std::vector<seg_record> rec;
   std::vector<c8p_rawchain_mark> marks;
+  bool bounded = false;
+  int64_t n_rec = 0;            // records ever made
+  double first_done = 0;        // rec[0].done of the very first one
+  void record(const c8p_rawchain_mark& m, const seg_record& r)
+  {
+    static const size_t LIVE_HISTORY = 4096;
+    if (n_rec++ == 0) first_done = r.done;
+    if (bounded && rec.size() >= 2 * LIVE_HISTORY) {
+      rec.erase(rec.begin(), rec.begin() + (std::ptrdiff_t)LIVE_HISTORY);
+      marks.erase(marks.begin(), marks.begin() + (std::ptrdiff_t)LIVE_HISTORY);
+    }
+    marks.push_back(m); rec.push_back(r);
+  }
   double t0 = 0;
   c8p_rawchain_cb cb = nullptr; void* user = nullptr;
   int64_t c0[4] = {0, 0, 0, 0};           // the contexts' counters at the start: growths, giveups, ticket scans
@@ -210,9 +226,10 @@ void finish_stats(c8p_rawchain* H, run_state& R, const clocked& cd, const clocke
   st.det_giveups = H->sum(C8P_CNT_DET_GIVEUPS) - R.c0[1];
   st.det_ticket_scans = H->sum(C8P_CNT_DET_TICKET_SCANS) - R.c0[2];
   const int64_t n = (int64_t)R.rec.size();
-  if (n > 0) st.first_segment_s = R.rec[0].done;
-  // steady state: everything but the pipeline's fill (the first segments' results wait for three stages, later ones for the slowest)
-  const int64_t m = n >= 8 ? n - 4 : (n >= 2 ? n - 1 : 0);
+  if (R.n_rec > 0) st.first_segment_s = R.first_done;
+  // steady state: everything but the pipeline's fill (the first segments' results wait for three stages, later ones for the slowest);
+  // of a live session that outgrew its window: the window (its oldest record only lends its time stamp)
+  const int64_t m = R.n_rec > n ? n - 1 : (n >= 8 ? n - 4 : (n >= 2 ? n - 1 : 0));
   if (m > 0) {
     st.steady_segments = m;
     st.steady_s = R.rec[(size_t)n - 1].done - R.rec[(size_t)(n - 1 - m)].done;
@@ -252,8 +269,7 @@ void rx_stage(c8p_rawchain* H, run_state& R, clocked& ck)
       return 0;
     });
     prev.mark.rx_done = now_s() - R.t0;
-    R.marks.push_back(prev.mark);
-    R.rec.push_back(seg_record{prev.mark.rx_done, (int64_t)prev.new_items, (int64_t)prev.pk.size(), pdus});
+    R.record(prev.mark, seg_record{prev.mark.rx_done, (int64_t)prev.new_items, (int64_t)prev.pk.size(), pdus});
     R.sig_arenas.release();
   };
   for (;;) {
@@ -592,6 +608,7 @@ int live_start(c8p_rawchain* H)
   live_session& L = *Lp;
   L.R.cb = H->live_cb; L.R.user = H->live_user;
   L.R.raw_arenas.reset(new counter(LIVE_ARENAS - 1));
+  L.R.bounded = true;                                          // no end in sight: the per-round history is a window
   L.open.assign(H->cfg.streams, stream_pos{0, 0});
   start_counters(H, L.R);
   live_session* lp = Lp.get();
@@ -628,12 +645,20 @@ static int flush_pieces(c8p_rawchain* h)
   if (L.pieces.empty()) return C8P_OK;
   const c8p_api& api = h->api;
   c8p_c32* dst = h->arena[L.open_arena];
-  int rc = api.copy_gather(h->ing->c, dst, L.pieces.data(), (int32_t)L.pieces.size());
-  if (rc == C8P_EINVAL) {                        // a piece the device cannot read: piece by piece through the DMA path
-    rc = C8P_OK;
-    for (const c8p_piece& pc : L.pieces) {
-      if (pc.fmt != C8P_FMT_C32) { h->err = "live ingest: sc16 / sc8 items must lie in device or pinned host memory (c8p_host_alloc)"; L.pieces.clear(); return C8P_EINVAL; }
-      if ((rc = api.copy_async(h->ing->c, dst + pc.dst_off, pc.src, sizeof(c8p_c32) * pc.n)) != C8P_OK) break;
+  // Pieces the caller vouched for (C8P_MEM_PINNED / _DEVICE) and pieces of unknown host memory (C8P_MEM_HOST) go in separate gathers:
+  // if the engine finds that the device cannot read the latter (C8P_ENOTDEV — the only refusal answered this way; any other error is
+  // an argument error and propagates), THEY, and only they, go through the DMA path piece by piece.
+  std::vector<c8p_piece> vouched, unknown;
+  for (const c8p_piece& pc : L.pieces) (pc.trusted ? vouched : unknown).push_back(pc);
+  int rc = vouched.empty() ? C8P_OK : api.copy_gather(h->ing->c, dst, vouched.data(), (int32_t)vouched.size());
+  if (rc == C8P_OK && !unknown.empty()) {
+    rc = api.copy_gather(h->ing->c, dst, unknown.data(), (int32_t)unknown.size());
+    if (rc == C8P_ENOTDEV) {
+      rc = C8P_OK;
+      for (const c8p_piece& pc : unknown) {
+        if (pc.fmt != C8P_FMT_C32) { h->err = "live ingest: sc16 / sc8 items must lie in device or pinned host memory (c8p_host_alloc)"; L.pieces.clear(); return C8P_EINVAL; }
+        if ((rc = api.copy_async(h->ing->c, dst + pc.dst_off, pc.src, sizeof(c8p_c32) * pc.n)) != C8P_OK) break;
+      }
     }
   }
   if (rc != C8P_OK) h->err = std::string("live ingest copy: ") + api.last_error(h->ing->c);
@@ -662,7 +687,7 @@ static int push_impl(c8p_rawchain* h, uint32_t stream, const void* items, const 
   if (n) {
     // the items move when the round is closed (or when 4096 pieces have gathered): all pieces with ONE kernel that reads the host memory
     // itself — no DMA engine, so the bulk does not queue in front of the stages' small descriptor and result copies.  A source the
-    // device cannot read (pageable host memory) goes through c8p_copy_async at once
+    // device cannot read (pageable host memory) goes through c8p_copy_async when the pieces are flushed (flush_pieces)
     c8p_piece pc;
     pc.src = items; pc.dst_off = (uint64_t)stream * h->C + P.fill; pc.n = n; pc.trusted = mem != C8P_MEM_HOST; pc.rsv = 0;
     pc.fmt = sc16 ? C8P_FMT_SC16 : sc8 ? C8P_FMT_SC8 : C8P_FMT_C32;

@@ -115,7 +115,8 @@ int c8p_rawchain_run(c8p_rawchain* h, const c8p_rawchain_seg* segs, int64_t n_se
 int c8p_rawchain_stream(c8p_rawchain* h, const c8p_c32* raw, uint64_t n, uint64_t ant1_off, uint64_t seg_items,
                         c8p_rawchain_cb cb, void* user, c8p_rawchain_stats* stats, char* err, int errcap);
 
-/* The marks of the last run / stream / live session, one per segment; returns how many there are (copies at most cap). */
+/* The marks of the last run / stream / live session, one per segment; returns how many there are (copies at most cap).  A live
+ * session keeps a window — its last 4096 to 8192 rounds — and its steady-state figures are taken over that window. */
 int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t cap);
 
 /* ---- live ingest (c8p_rawchain_cfg.streams = K > 0, one antenna per stream) --------------------------------------------------
@@ -138,7 +139,10 @@ int64_t c8p_rawchain_timeline(c8p_rawchain* h, c8p_rawchain_mark* dst, int64_t c
  *                       packet whose items straddle rounds is delivered by the round that completes it.
  *   c8p_rawchain_round_async  the same without waiting for the copies: the pipeline's first stage waits for them instead, so the next
  *                       round's copies follow this round's without a gap on the link; the pushed items must then stay valid until
- *                       c8p_rawchain_ingested() (or c8p_rawchain_drain) has returned
+ *                       c8p_rawchain_ingested() (or c8p_rawchain_drain) has returned.  NOT a call that never blocks: a round of more
+                       than C8P_GATHER_INLINE pushes goes through the engine's one piece table, and c8p_copy_gather waits for the
+                       copy stream before it rewrites that table (include/c8p_rx.h) — with rounds back to back the call (and a push
+                       that flushes 4096 pieces) blocks for what is left of the PREVIOUS round's transfer
  *   c8p_rawchain_drain  waits until every round has been delivered and ends the session (flags still waiting for items yield
  *                       nothing); the handle can start another one (all streams from the constructor state).
  * One thread calls push / round / drain.  The first push or round starts the session with the callback given to c8p_rawchain_live. */

@@ -1,5 +1,6 @@
 // c8p_rx_chain.cc — rx_chain: rx.grc's receive chain for K radios as one block, on host/c8p_rawchain's live ingest (see c8p_blocks.h).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -19,7 +20,7 @@ class rx_chain_front : public rx_chain
 {
 public:
   rx_chain_front(int n_streams, const std::string& engine_lib, const batching_cfg& cfg, int fmt, float scale)
-    : d_k(n_streams), d_per(std::max(cfg.detect_items, 1024)), d_idle_flush(cfg.flush_when_idle),
+    : d_k(n_streams), d_per(std::max(cfg.detect_items, 1024)), d_idle_flush(cfg.flush_when_idle), d_max_wait_us(cfg.max_wait_us),
       d_ib(fmt == C8P_FMT_SC16 ? 4 : fmt == C8P_FMT_SC8 ? 2 : 8), d_memflag(fmt == C8P_FMT_SC16 ? C8P_MEM_SC16 : fmt == C8P_FMT_SC8 ? C8P_MEM_SC8 : 0),
       d_api(load_c8p_api(engine_lib))
   {
@@ -59,14 +60,22 @@ public:
 
   int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
   {
+    bool publish_only;                       // forecast asked for no input: this call is here for the PDUs, it says nothing about the sources
+    { std::lock_guard<std::mutex> g(d_mu); publish_only = !d_q.empty(); }
     int n = ninput_items.empty() ? 0 : ninput_items[0];
     for (int v : ninput_items) n = std::min(n, v);
     n = std::min<int>(n, d_per - d_fill);                                      // the streams advance together (consume_each)
+    if (n > 0 && d_fill == 0) d_t_open = std::chrono::steady_clock::now();
     for (int s = 0; s < d_k && n > 0; s++)
       memcpy(d_stage + ((size_t)s * (size_t)d_per + (size_t)d_fill) * d_ib, input_items[(size_t)s], d_ib * (size_t)n);
     d_fill += n;
     d_io->consume_each(n);
-    if (d_fill == d_per || (d_fill > 0 && n == 0 && d_idle_flush)) close_round();
+    // An open round is closed early only when the input has REALLY dried up: a call that came for input and found none on some port,
+    // and the round either an eighth full or open for max_wait_us.  (Round 4 closed it on any call without items — one port momentarily
+    // empty, or a wake-up to publish PDUs — and a busy scheduler cut the stream into many tiny, blocking rounds.)
+    const bool dried_up = d_idle_flush && d_fill > 0 && n == 0 && !publish_only &&
+                          (d_fill >= d_per / 8 || std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - d_t_open).count() >= d_max_wait_us);
+    if (d_fill == d_per || dried_up) close_round();
     publish();
     return 0;
   }
@@ -135,6 +144,8 @@ private:
 
   const int d_k, d_per;
   const bool d_idle_flush;
+  const int d_max_wait_us;
+  std::chrono::steady_clock::time_point d_t_open;      // when the open round received its first items
   const size_t d_ib;                  // bytes per input item
   const int d_memflag;
   c8p_api d_api;

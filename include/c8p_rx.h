@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define C8P_ABI_VERSION 3   /* 3: c8p_sig_in.stream, c8p_signal_in.n_streams / scan_from_v, C8P_BUF_DET_RAW, c8p_detect_multi, c8p_reserve, c8p_counter, c8p_dev_* */
+#define C8P_ABI_VERSION 4   /* 3: c8p_sig_in.stream, c8p_signal_in.n_streams / scan_from_v, C8P_BUF_DET_RAW, c8p_detect_multi, c8p_reserve, c8p_counter, c8p_dev_*
+                               4: C8P_FMT_F32 pieces, c8p_copy_gather towards host memory, c8p_copy_fence, C8P_ENOTDEV */
 
 /* return codes */
 #define C8P_OK          0
@@ -46,6 +47,8 @@ extern "C" {
 #define C8P_ENODEV     (-19)
 #define C8P_EHIP       (-5)
 #define C8P_ERANGE     (-34)
+#define C8P_ENOTDEV    (-14)  /* c8p_copy_gather: a piece lies in memory the device cannot reach (pageable host memory) — the one
+                                 refusal a caller answers with c8p_copy_async; every other bad argument stays C8P_EINVAL        */
 
 /* where a caller buffer lives */
 #define C8P_MEM_HOST    0
@@ -486,14 +489,22 @@ int   c8p_copy_wait(c8p_ctx* ctx);
  * device can read: c8p_host_alloc / hipHostMalloc / hipHostRegister-ed) to dst + dst_off.  The shader cores read the host memory
  * over PCIe themselves, so no DMA engine is involved and the rate does not depend on the size of the pieces (54-57 GB/s alone;
  * measured in the live pipeline, 268 MB a round: 256 pieces of 1 MB 6.0 ms through this call, 17 ms through c8p_copy_async; 64 pieces of
- * 4 MB 6.0 against 6.3 ms).  A piece in pageable host memory is refused (C8P_EINVAL): use c8p_copy_async for it. */
+ * 4 MB 6.0 against 6.3 ms).  A piece in pageable host memory is refused (C8P_ENOTDEV): use c8p_copy_async for it.
+ * Either side may be the host: with src in device memory and dst (+ dst_off) in pinned host memory the same launch SCATTERS results
+ * into a caller's buffers (the block mirrors write a batch's LLR items straight into the scheduler's output buffer with it).
+ * Blocking behaviour.  Up to C8P_GATHER_INLINE pieces travel in the launch's own arguments and the call only enqueues.  A longer
+ * list goes through ONE table in pinned memory: the call then first waits until every copy enqueued on the copy stream before it has
+ * finished (the table may still be read) — a round's whole transfer time when rounds follow each other back to back; measured against
+ * a ring of tables in round 4, the wait was the faster variant (the gaps it leaves are when the pipeline's small transfers get through
+ * the link).  c8p_rawchain_push / _round_async inherit this: they can block for as long as the previous round's gather takes. */
+#define C8P_GATHER_INLINE 96
 typedef struct c8p_piece {
   const void* src;          /* n items: complex64 (8-byte aligned); fmt = C8P_FMT_SC16 / _SC8: int16 / int8 I/Q pairs (4 / 2-byte aligned) */
   uint64_t dst_off;         /* items                                                                                                   */
   uint64_t n;
   uint32_t trusted;         /* 1: the caller vouches that the device can read src (device memory, pinned host memory): no pointer query
                                — one hipPointerGetAttributes per piece costs ~4 us, a millisecond per round of 256 pushes               */
-  uint32_t fmt;             /* C8P_FMT_*                                                                                               */
+  uint32_t fmt;             /* C8P_FMT_* (one c8p_copy_gather call may mix them, except C8P_FMT_F32 with the others: dst_off units differ)     */
   float    scale;           /* C8P_FMT_SC16 / _SC8: item = ((float)i * scale, (float)q * scale), one float32 multiply each             */
   uint32_t rsv;
 } c8p_piece;
@@ -505,9 +516,15 @@ typedef struct c8p_piece {
 #define C8P_FMT_C32   0
 #define C8P_FMT_SC16  1
 #define C8P_FMT_SC8   2   /* UHD's other wire format: int8 I, int8 Q (2-byte aligned), a quarter of the link bytes of complex64 */
+#define C8P_FMT_F32   3   /* 4-byte items moved as they are (the float LLR stream between demod and decode): src 4-byte aligned, n and dst_off
+                             count 4-byte items from (float*)dst */
 int   c8p_copy_gather(c8p_ctx* ctx, c8p_c32* dst, const c8p_piece* pieces, int32_t n);           /* pieces: host memory */
 uint64_t c8p_copy_mark(c8p_ctx* ctx);
 int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);
+/* The NEXT submit of this ctx (c8p_demod / c8p_decode / c8p_rx) waits ON THE DEVICE for every copy enqueued on the copy stream so far:
+ * how a caller that fills its own C8P_MEM_DEVICE arenas with c8p_copy_gather / c8p_copy_async hands them to a submit without
+ * blocking a host thread in between (the block mirrors: pieces of the scheduler's pinned input buffer -> the batch's arena -> c8p_rx). */
+int   c8p_copy_fence(c8p_ctx* ctx);
 
 /* Counters of one ctx since c8p_create (monotonic unless stated otherwise). */
 #define C8P_CNT_ARENA_GROWTHS    0   /* device / pinned allocations made by submits and c8p_reserve (each one sits behind a stream

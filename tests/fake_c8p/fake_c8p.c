@@ -9,6 +9,7 @@
 #define SLOTS 3     /* like the engine's default: the results of the last 3 demod / decode / rx submits stay resident (c8p_ticket / c8p_select);
                        C8P_SLOTS = 1 or 2 in the environment (read at create, like the engine) keeps fewer */
 struct res { int n, ticket; c8p_pkt_tags* tags; c8p_pkt_out* outs; float* llr; uint64_t n_llr; uint8_t* pdu; uint64_t n_pdu; c8p_c32* mu; };
+struct pend;
 struct detst { c8p_c32* x; uint64_t n, commit; };      /* one stream of c8p_detect: every item it was ever given */
 struct c8p_ctx {
   struct detst det; c8p_sync_evt* det_evt; int det_nevt;   /* c8p_detect: the whole stream so far */
@@ -17,6 +18,7 @@ struct c8p_ctx {
   const c8p_c32* det_raw; uint64_t det_raw_n;                                           /* C8P_BUF_DET_RAW: the caller's items */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   struct res r[SLOTS];
+  struct pend *pend_head, *pend_tail;                       /* c8p_copy_gather calls not yet executed (see run_pending) */
   int cur, seq, slots;
   struct res* s;      /* selected submit */
 };
@@ -93,7 +95,8 @@ int c8p_signal(c8p_ctx* c, const c8p_signal_in* in)      /* same arena layout as
   }
   return C8P_OK;
 }
-void c8p_destroy(c8p_ctx* c) { if (c) { drop(c); for (int i = 0; i < SLOTS; i++) drop_res(&c->r[i]); free(c); } }
+static void run_pending(c8p_ctx* c);
+void c8p_destroy(c8p_ctx* c) { if (c) { run_pending(c); drop(c); for (int i = 0; i < SLOTS; i++) drop_res(&c->r[i]); free(c); } }
 const char* c8p_last_error(const c8p_ctx* c) { (void)c; return "fake backend"; }
 
 int c8p_demod(c8p_ctx* c, const c8p_batch_in* in)
@@ -210,17 +213,16 @@ int64_t c8p_counter(c8p_ctx* c, int which)
 }
 /* caller arenas: "device" memory is the heap here, the copies are immediate */
 void* c8p_dev_alloc(c8p_ctx* c, uint64_t bytes) { (void)c; return calloc(bytes ? bytes : 1, 1); }
-void c8p_dev_free(c8p_ctx* c, void* p) { (void)c; free(p); }
-int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { (void)c; memmove(dst, src, bytes); return C8P_OK; }
-int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* sp, int32_t n)
+static void run_pending(c8p_ctx* c);
+void c8p_dev_free(c8p_ctx* c, void* p) { run_pending(c); free(p); }
+/* The copy stream is ASYNCHRONOUS here too, so that a caller that releases a gather's source too early (a block mirror consuming
+ * scheduler items whose gather it has not waited for) or forgets c8p_copy_fence before a submit FAILS on this backend as it would race
+ * on the device: a c8p_copy_gather only records its pieces; they are executed — in order — by whatever the header says completes or
+ * orders them: c8p_copy_wait / _wait_mark, c8p_copy_fence, a later copy on the same stream (c8p_copy_async, c8p_copy_spans, a long
+ * c8p_copy_gather, which waits for the stream), c8p_dev_free.  Submits do NOT run them. */
+struct pend { c8p_c32* dst; c8p_piece* pc; int n; struct pend* next; };
+static int run_gather(c8p_c32* dst, const c8p_piece* pc, int32_t n)
 {
-  (void)c;
-  for (int i = 0; i < n; i++) memmove(dst + sp[i].dst_off, src + sp[i].src_off, sizeof(c8p_c32) * (size_t)sp[i].n);
-  return C8P_OK;
-}
-int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
-{
-  (void)c;
   for (int i = 0; i < n; i++) {
     if (pc[i].fmt == C8P_FMT_SC16) {          /* ((float)i * scale, (float)q * scale): one float32 multiply each, as the header says */
       const int16_t* s = (const int16_t*)pc[i].src;
@@ -235,13 +237,44 @@ int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
         d->re = (float)s[2 * k] * pc[i].scale; d->im = (float)s[2 * k + 1] * pc[i].scale;
       }
     } else if (pc[i].fmt == C8P_FMT_C32) memmove(dst + pc[i].dst_off, pc[i].src, sizeof(c8p_c32) * (size_t)pc[i].n);
+    else if (pc[i].fmt == C8P_FMT_F32) memmove((float*)dst + pc[i].dst_off, pc[i].src, sizeof(float) * (size_t)pc[i].n);
     else return C8P_EINVAL;
   }
   return C8P_OK;
 }
-int c8p_copy_wait(c8p_ctx* c) { (void)c; return C8P_OK; }
+static void run_pending(c8p_ctx* c)
+{
+  struct pend* p = c->pend_head;
+  c->pend_head = c->pend_tail = NULL;
+  while (p) { struct pend* nx = p->next; run_gather(p->dst, p->pc, p->n); free(p->pc); free(p); p = nx; }
+}
+int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { run_pending(c); memmove(dst, src, bytes); return C8P_OK; }
+int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* sp, int32_t n)
+{
+  run_pending(c);
+  for (int i = 0; i < n; i++) memmove(dst + sp[i].dst_off, src + sp[i].src_off, sizeof(c8p_c32) * (size_t)sp[i].n);
+  return C8P_OK;
+}
+int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
+{
+  int f32 = 0, other = 0;
+  for (int i = 0; i < n; i++) {
+    if (pc[i].fmt > C8P_FMT_F32) return C8P_EINVAL;
+    if (pc[i].n) { if (pc[i].fmt == C8P_FMT_F32) f32 = 1; else other = 1; }
+  }
+  if (f32 && other) return C8P_EINVAL;
+  if (n > C8P_GATHER_INLINE) run_pending(c);        /* the long-list path waits for the copy stream before it reuses its table */
+  struct pend* p = (struct pend*)calloc(1, sizeof(struct pend));
+  p->dst = dst; p->n = n; p->pc = (c8p_piece*)malloc(sizeof(c8p_piece) * (size_t)(n > 0 ? n : 1));
+  if (n > 0) memcpy(p->pc, pc, sizeof(c8p_piece) * (size_t)n);
+  if (c->pend_tail) c->pend_tail->next = p; else c->pend_head = p;
+  c->pend_tail = p;
+  return C8P_OK;
+}
+int c8p_copy_wait(c8p_ctx* c) { run_pending(c); return C8P_OK; }
 uint64_t c8p_copy_mark(c8p_ctx* c) { return (uint64_t)++c->submits; }
-int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark) { (void)c; (void)mark; return C8P_OK; }
+int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark) { (void)mark; run_pending(c); return C8P_OK; }
+int c8p_copy_fence(c8p_ctx* c) { run_pending(c); return C8P_OK; }
 int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
 
 const void* c8p_buffer(c8p_ctx* c, int which, uint64_t* bytes)

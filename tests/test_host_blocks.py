@@ -339,14 +339,89 @@ def test_detect_mirror_under_random_scheduler_chunks_with_fake_backend(seed):
 
 
 # ---------------------------------------------------------------------------------------------- fused mode, threaded chain
-def _chain_threads(engine_lib, pk, iq, chan, n_ant, max_batch, fused):
-    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=engine_lib, max_batch=max_batch, fused=fused)
-    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=engine_lib, max_batch=max_batch, fused=fused)
+def _chain_threads(engine_lib, pk, iq, chan, n_ant, max_batch, fused, pinned_io=None, defer_consume=None, poison=False, chunk=3000, nout=5000):
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=engine_lib, max_batch=max_batch, fused=fused,
+                       pinned_io=pinned_io, defer_consume=defer_consume)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=engine_lib, max_batch=max_batch, fused=fused, pinned_io=pinned_io,
+                       defer_consume=defer_consume)
+    if poison:
+        dem.set_poison(True); dec.set_poison(True)
     blocks.feed_demod(dem, pk, iq, chan)
-    blocks.run_chain(dem, dec, chunk=3000, nout=5000)
+    blocks.run_chain(dem, dec, chunk=chunk, nout=nout)
     res = (dec.messages(), dec.debug_lines())
     dem.close(); dec.close()
     return res
+
+
+# ---------------------------------------------------------------------------------------------- custom (pinned) scheduler buffers
+@pytest.mark.parametrize("n_ant", [1, 2])
+@pytest.mark.parametrize("pinned_io,defer", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("chunk,nout,max_batch", [(4096, 8192, 256), (333, 500, 5), (80, 97, 1)])
+def test_block_mirror_with_and_without_pinned_buffers(n_ant, pinned_io, defer, chunk, nout, max_batch):
+    """The mirrors with the scheduler's buffers allocated through their buffer type (pinned: the packets are gathered out of the input
+    buffer by the device, demod's LLR items are written into the output buffer by the device; the items are consumed one call later, or in
+    the same call after a wait) and with ordinary buffers (staged through pinned copies): the same streams, tags, PDUs, debug lines.
+    The harness OVERWRITES every consumed item at once and the test engine's gathers run only when something orders or awaits them
+    (tests/fake_c8p: as asynchronous as the device), so an item let go of too early or a submit without c8p_copy_fence shows."""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=FAKE, max_batch=max_batch, pinned_io=pinned_io, defer_consume=defer)
+    assert dem.input_pinned(0) == pinned_io and dem.output_pinned() == pinned_io
+    dem.set_poison(True)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=chunk, nout=nout)
+    llr, tags = dem.output(), dem.tags()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=max_batch, pinned_io=pinned_io, defer_consume=defer)
+    assert dec.input_pinned(0) == pinned_io
+    dec.set_poison(True)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run(chunk=chunk, nout=nout)
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("defer", [False, True])
+def test_pinned_buffers_under_random_scheduler_chunks(seed, defer):
+    """pinned buffers + a scheduler that hands out random item counts (sometimes fewer than the block has already looked at, sometimes
+    none): consumed items are overwritten at once"""
+    rng = np.random.default_rng(40 + seed)
+    n_ant = 1 + seed % 2
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
+    dem.set_poison(True)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.set_jitter(5000 + seed)
+    dem.run(chunk=int(rng.integers(100, 3000)), nout=int(rng.integers(50, 5000)))
+    llr, tags = dem.output(), dem.tags()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
+    dec.set_poison(True)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.set_jitter(6000 + seed)
+    dec.run(chunk=int(rng.integers(200, 4000)), nout=int(rng.integers(1, 300)))
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert check_against_oracle(res, pk, iq, chan) >= 10
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("pinned_io,defer", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("chunk,nout", [(3000, 5000), (700, 40000), (1 << 16, 1 << 18)])
+def test_chain_on_two_threads_with_and_without_pinned_buffers(fused, pinned_io, defer, chunk, nout):
+    """demod -> decode on two threads through ONE edge buffer that decode reads while demod writes it; consumed items (and recycled
+    segments of the edge) are overwritten at once"""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    msgs, dbg = _chain_threads(FAKE, pk, iq, chan, 1, 7, fused, pinned_io=pinned_io, defer_consume=defer, poison=True, chunk=chunk, nout=nout)
+    assert msgs == ref[2] and len(msgs) >= 10
+    assert dbg == ref[3]
 
 
 @pytest.mark.parametrize("n_ant", [1, 2])
@@ -430,7 +505,7 @@ def test_a_burst_comes_out_without_further_input_and_without_flush():
     dec.run_live(chunk=1024, nout=4096, linger_ms=200)
     assert dec.messages() == want
     ph = dem.host_phase_us()
-    assert set(ph) == {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain"} and ph["cut_and_stage"] >= 0
+    assert set(ph) == {"cut_and_stage", "submit", "enqueue_downloads", "staging_alloc", "wait", "fetch", "replay", "drain", "gather_enqueue", "gather_wait"} and ph["cut_and_stage"] >= 0
     dem.close(); dec.close()
 
 
@@ -543,7 +618,7 @@ def test_a_burst_comes_out_in_fused_mode_without_further_input():
     blocks.feed_demod(dem, pk, iq, chan)
     dem.run_live(chunk=2048, nout=4096, linger_ms=200)
     llr, tags = dem.output(), dem.tags()
-    assert len(llr) > 0 and not llr.any()                  # the items exist, their values are zeros
+    assert len(llr) > 0                                    # the items exist; their values are not written (c8p_blocks.h, batching_cfg::fused)
     assert sum(1 for _, k, _ in tags if k == "c8p_fused") == sum(1 for r in oracle_rx(pk, iq, chan) if r["tags"]["status"] == 0)
     dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=256, fused=True)
     dec.push_items(0, llr)

@@ -476,9 +476,60 @@ def test_copy_gather_converts_sc16_pieces_exactly_at_any_alignment(cus, monkeypa
     assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), odd8, 1) == -22
     pageable = np.zeros(64, np.int16)
     pg = (abi.Piece * 1)(abi.Piece(pageable.ctypes.data, 0, 8, 0, abi.FMT_SC16, float(scale), 0))
-    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), pg, 1) == -22
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), pg, 1) == -14          # C8P_ENOTDEV: the one refusal answered with c8p_copy_async
     bad = (abi.Piece * 1)(abi.Piece(q.data_ptr(), 0, 8, 1, 7, float(scale), 0))
     assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), bad, 1) == -22
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pieces", [7, 300])
+def test_copy_gather_moves_f32_pieces_both_ways_exactly(n_pieces):
+    """C8P_FMT_F32 pieces (the LLR stream between the demod and decode mirrors): 4-byte items from any 4-byte aligned address of pinned
+    host memory into any float of a device arena — and, with source and destination swapped, from the device into pinned host memory
+    (how demod's LLR items reach a pinned scheduler buffer).  7 pieces travel in the launch's arguments, 300 through the table; nothing
+    outside the pieces is written; an F32 piece in a call with 8-byte-item pieces is refused; c8p_copy_fence orders a following submit."""
+    import ctypes as C
+    import torch
+    from gr_ieee80211_amd import engine
+    rng = np.random.default_rng(17 + n_pieces)
+    e = engine.Engine(device=0)
+    L = e.L
+    n_src = 1 << 18
+    src = torch.from_numpy(rng.normal(size=n_src).astype(np.float32)).pin_memory()
+    n_dst = 1 << 19
+    dst = torch.full((n_dst,), -7.0, dtype=torch.float32, device="cuda:0")
+    want = np.full(n_dst, -7.0, np.float32)
+    pcs, pos, spans = [], 1, []
+    for i in range(n_pieces):
+        a = int(rng.integers(0, n_src - 3000))
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 64, 1000, 2999])) if n_pieces < 100 else int(rng.choice([1, 2, 3, 5, 9, 33, 500]))
+        pcs.append(abi.Piece(src.data_ptr() + 4 * a, pos, n, 1, abi.FMT_F32, 1.0, 0))
+        want[pos:pos + n] = src.numpy()[a:a + n]
+        spans.append((pos, n))
+        pos += n + int(rng.integers(0, 5))
+    arr = (abi.Piece * len(pcs))(*pcs)
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), arr, len(pcs)) == 0, L.c8p_last_error(e.ctx)
+    assert L.c8p_copy_wait(e.ctx) == 0
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # the other way: the same spans of the device arena into a pinned host buffer, packed back to back from an odd float on
+    back = torch.full((n_dst,), -3.0, dtype=torch.float32).pin_memory()
+    wantb = np.full(n_dst, -3.0, np.float32)
+    pcs2, o = [], 3
+    for (p0, n) in spans:
+        pcs2.append(abi.Piece(dst.data_ptr() + 4 * p0, o, n, 1, abi.FMT_F32, 1.0, 0))
+        wantb[o:o + n] = want[p0:p0 + n]
+        o += n
+    arr2 = (abi.Piece * len(pcs2))(*pcs2)
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(back.data_ptr()), arr2, len(pcs2)) == 0, L.c8p_last_error(e.ctx)
+    mark = L.c8p_copy_mark(e.ctx)
+    assert mark > 0 and L.c8p_copy_wait_mark(e.ctx, mark) == 0
+    assert np.array_equal(back.numpy().view(np.uint32), wantb.view(np.uint32))
+    mixed = (abi.Piece * 2)(abi.Piece(src.data_ptr(), 0, 8, 1, abi.FMT_F32, 1.0, 0), abi.Piece(src.data_ptr(), 64, 8, 1, abi.FMT_C32, 0.0, 0))
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), mixed, 2) == -22
+    odd = (abi.Piece * 1)(abi.Piece(src.data_ptr() + 2, 0, 8, 1, abi.FMT_F32, 1.0, 0))
+    assert L.c8p_copy_gather(e.ctx, C.c_void_p(dst.data_ptr()), odd, 1) == -22
+    assert L.c8p_copy_fence(e.ctx) == 0
     e.close()
 
 
