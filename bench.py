@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--min-timed-s", type=float, default=1.2, help="repeat the K-step region until the timed wall adds up to this (0: --repeats only)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configs (`configs` object of the line)")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the headline's sensitivity legs (21 dB, windowed TX, 3-tap channel, mixed formats, with delivery)")
     ap.add_argument("--batch", type=int, default=4096, help="packets per GPU per step")
     ap.add_argument("--snr", type=float, default=30.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -287,6 +288,8 @@ def main():
             fe_unit = out["frontend_detect"].pop("_unit", None)
         if not args.no_configs and world == 1:
             out["configs"] = config_legs(torch, dev, local, args.snr)
+        if not args.no_sensitivity and world == 1 and not other:
+            out["sensitivity"] = sensitivity_legs(torch, dev, local, n_pkt, value)
     # BASELINE configs[3] beside the headline: ONE stream scattered from rank 0, decoded, gathered (every rank takes part).  The
     # headline above is complete at this point and this leg's collectives have never run on more than one GPU: it runs under a
     # watchdog on every rank, so that neither an exception on one rank nor a collective that never returns can cost the line.
@@ -306,7 +309,8 @@ def main():
     if rank == 0:
         if not args.no_host_legs and world == 1:
             # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
-            out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local)
+            out["pcie_inclusive_detail"] = {}
+            out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, detail=out["pcie_inclusive_detail"])
             import importlib.util
             spec = importlib.util.spec_from_file_location("bench_blocks", os.path.join(ROOT, "tools", "bench_blocks.py"))
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
@@ -330,8 +334,9 @@ def main():
                                             "cut_and_stage = tag reads + the copy of the items into pinned staging, submit = the c8p_* call, "
                                             "wait = blocked on the batch, fetch = synchronous result copies, replay = tags / PDUs / debug lines, "
                                             "drain = the LLR items into the output buffer; wall = chain time per packet (two threads)"}
-            out["host_legs_note"] = ("pcie_inclusive: c8p_rx from pinned host arenas, PDUs + results fetched back, batch i+1 submitted "
-                                     "before batch i is fetched (c8p_ticket / c8p_select); block_chain: the gr::ieee80211::demod -> decode "
+            out["host_legs_note"] = ("pcie_inclusive: the arenas start in pinned host memory every step (one c8p_copy_gather + c8p_copy_fence, then "
+                                     "c8p_rx on the device copy), c8p_pkt_out + PDU arena fetched back to pinned memory behind the kernels, step i+1 "
+                                     "submitted before step i is waited for; block_chain: the gr::ieee80211::demod -> decode "
                                      "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
                                      "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
                                      "over 2048 packets, max_batch 256, %d of 2048 PDUs correct in the worst leg" % r["pdus_ok_min"])
@@ -386,7 +391,12 @@ def legs_summary(out):
             "live_streams_sc16_at_realtime": max(g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16", "streams_at_realtime") or 0.0,
                                                  g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc16_128", "streams_at_realtime") or 0.0) or None,
             "live_streams_sc8_at_realtime": g("frontend_detect", "raw_stream_to_pdus", "live_streams", "sc8_128", "streams_at_realtime"),
-            "cpu_1thread": g("cpu_baseline", "value")}
+            "cpu_1thread": g("cpu_baseline", "value"),
+            "sens_21dB": g("sensitivity", "snr_21dB", "packets_per_s"), "sens_windowed": g("sensitivity", "windowed_tx", "packets_per_s"),
+            "sens_3tap": g("sensitivity", "selective_3tap", "packets_per_s"), "sens_mixed": g("sensitivity", "mixed_formats", "packets_per_s"),
+            "sens_mixed_steps_per_s": g("sensitivity", "mixed_formats", "trellis_steps_per_s"),
+            "with_delivery": g("sensitivity", "with_delivery", "packets_per_s"),
+            "host_wall_us_fused": g("host_phase_us", "chain_fused", "wall"), "host_wall_us_chain": g("host_phase_us", "chain", "wall")}
     return {k: v for k, v in legs.items() if v is not None}
 
 
@@ -799,6 +809,83 @@ def config_legs(torch, dev, local, snr_db=30.0, timed_s=0.35):
     return res
 
 
+def sensitivity_legs(torch, dev, local, n_pkt, headline, timed_s=0.35):
+    """The headline's sensitivity to its input: the same 4096-packet cfg-2 batch size, resident in HBM, the
+    same timing code (warm-up, then K steps of c8p_rx between two syncs), with what the headline's input leaves out — the decoder's fast path
+    is data-dependent (integer-compare blocks need provably positive path metrics, LLRs outside the lean range go to the clamp-exact
+    kernel): 21 dB (most frames fail the FCS), the toolbox's symbol-edge windowing (tools/phy80211header.py:894-899), a 3-tap
+    frequency-selective channel, a batch of mixed formats / rates / lengths (uneven trellis lengths), and the headline batch WITH
+    delivery: every step's c8p_pkt_out records and PDU arena fetched to pinned host memory inside the timed region."""
+    from gr_ieee80211_amd import abi, engine
+    from gr_ieee80211_amd.workloads import TAPS3, workload_on_device
+    cases = [("snr_21dB", "cfg2", dict(snr=21.0), "cfg 2 at 21 dB AWGN"),
+             ("windowed_tx", "cfg2", dict(snr=30.0, window=True), "cfg 2, TX with the toolbox's half-amplitude symbol edges (flags = 0), 30 dB"),
+             ("selective_3tap", "cfg2", dict(snr=30.0, taps=TAPS3), "cfg 2 through a 3-tap channel (0 / -9 / -15 dB at 0 / 1 / 2 samples), 30 dB"),
+             ("mixed_formats", "random1", dict(snr=30.0), "random legacy / HT / VHT, MCS and length (14-3000 B) per packet, 30 dB"),
+             ("with_delivery", "cfg2", dict(snr=30.0, deliver=True), "the headline batch, c8p_pkt_out + PDU arena fetched to pinned host memory every step")]
+    res = {}
+    eng = engine.Engine(device=local)
+    for name, kind, o, what in cases:
+        try:
+            pk, A, C_, exp, keep = workload_on_device(kind, n_pkt, o["snr"], 0, torch, dev, local, window=o.get("window", False), taps=o.get("taps"))
+            eng.rx(pk, A, C_)
+            eng.sync()
+            r = eng.results(want_llr=False)
+            rng_flags, flt_blocks, _ = eng.decstat()
+            tr = eng.tags()["trellis"].astype(np.int64)
+            lean = rng_flags == 0
+            n_ok = sum(1 for g, e in zip(r, exp) if g["pdus"] == [e])
+            for g, e in zip(r, exp):                    # whatever is published is the transmitted MPDU, at any SNR
+                assert g["pdus"] in ([], [e]), "%s: a published PDU differs from the transmitted MPDU" % name
+            deliver = o.get("deliver", False)
+            bufs = None
+            if deliver:                                 # two pinned sets: step i's copies land while step i+1 is submitted
+                _, ob = eng.buffer(abi.BUF_OUT)
+                _, pb = eng.buffer(abi.BUF_PDU)
+                bufs = [(torch.empty(ob, dtype=torch.uint8).pin_memory(), torch.empty(pb, dtype=torch.uint8).pin_memory()) for _ in range(3)]
+
+            def step(i):
+                eng.rx(pk, A, C_)
+                if deliver:
+                    o_, p_ = bufs[i % 3]
+                    eng.fetch_async(abi.BUF_OUT, o_.data_ptr(), 0, o_.numel())
+                    eng.fetch_async(abi.BUF_PDU, p_.data_ptr(), 0, p_.numel())
+            t = time.perf_counter()
+            i = 0
+            while time.perf_counter() - t < 0.1:
+                step(i); i += 1
+            eng.sync()
+            t = time.perf_counter()
+            for i in range(8):
+                step(i)
+            eng.sync()
+            k = int(max(8, timed_s / max((time.perf_counter() - t) / 8, 1e-6)))
+            t = time.perf_counter()
+            for i in range(k):
+                step(i)
+            eng.sync()
+            dt = time.perf_counter() - t
+            pps = len(pk) * k / dt
+            res[name] = {"workload": what + ", %d packets/step" % len(pk), "packets_per_s": pps, "ms_per_step": 1e3 * dt / k, "steps": k,
+                         "vs_headline": pps / headline if headline else None, "fcs_ok_fraction": n_ok / max(len(pk), 1),
+                         "exact_kernel_packets": int(rng_flags.sum()),
+                         "float_step_block_fraction": float(flt_blocks[lean].sum()) / max(1, int((tr[lean] // 30).sum())),
+                         "trellis_steps_per_packet_mean": float(tr.mean()),
+                         "trellis_steps_per_s": float(tr.sum()) * k / dt}
+            if deliver:
+                got = np.frombuffer(bufs[(k - 1) % 3][0].numpy().tobytes(), abi.PKT_OUT_DT)
+                res[name]["delivered_bytes_per_step"] = int(bufs[0][0].numel() + bufs[0][1].numel())
+                assert int((got["n_pdu"] == 1).sum()) == n_ok, "with_delivery: the fetched c8p_pkt_out records disagree with the check pass"
+            del keep, A, C_
+        except Exception as e:                            # (a leg must not cost the headline)
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    eng.close()
+    res["note"] = ("same batch size and timing code as the headline (inputs resident, K steps of c8p_rx between two syncs, ~%.2f s timed each); "
+                   "vs_headline = packets_per_s / value; mixed_formats has fewer trellis steps per packet than cfg 2 — compare trellis_steps_per_s "
+                   "(cfg 2: 11 960 steps per packet)" % timed_s)
+    return res
+
+
 def lean_step_mix(T, float_frac=0.0, cr_num=5):
     """VALU wave-instructions of the lean forward pass per packet of T trellis steps at code rate 5/6, by opcode, from the kernel's
     structure (csrc/c8p_viterbi_lean.h, tools/gen_lean_asm.py): every step one packed candidate fma, steps with both LLRs present
@@ -895,9 +982,13 @@ def pmc_traffic(dom):
     return per[names[dom]], os.path.relpath(best, ROOT), whole
 
 
-def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
-    """PCIe-inclusive rate of the same batch (tools/pcie_rate.py's pipelined case): IQ + chan in pinned host memory, c8p_rx
-    copies them in, per-packet results and the PDU arena are fetched back; submit i+1, then fetch i."""
+def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12, detail=None):
+    """PCIe-inclusive rate of the same batch: IQ + chan start in PINNED HOST memory every step and the per-packet results and the
+    PDU arena end there.  The arenas go down with ONE c8p_copy_gather per step (the shader cores read the pinned memory over PCIe: no
+    DMA engine, 54-57 GB/s against the ~42 the copy engines reach on this part) into one of two device arena sets, c8p_copy_fence
+    orders the step's c8p_rx behind it on the device, and the step's c8p_pkt_out records + PDU arena are fetched into one of three
+    pinned result sets behind its kernels (c8p_fetch_async); the host waits for step i - 1 after it has submitted step i.
+    Round 4's leg (hipMemcpyAsync of the arenas inside c8p_rx, a synchronous fetch per step) is kept as `dma_path` in `detail`."""
     import ctypes
     from gr_ieee80211_amd import abi, engine
     hip = ctypes.CDLL("libamdhip64.so")
@@ -907,25 +998,82 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12):
     hip.hipMemcpy(ctypes.c_void_p(iq_pin.data_ptr()), ctypes.c_void_p(iq_dev.ptr), ctypes.c_size_t(8 * iq_dev.n), ctypes.c_int(2))
     hip.hipMemcpy(ctypes.c_void_p(ch_pin.data_ptr()), ctypes.c_void_p(chan_dev.ptr), ctypes.c_size_t(8 * chan_dev.n), ctypes.c_int(2))
     a, c = iq_pin.numpy().view(np.complex64), ch_pin.numpy().view(np.complex64)
-    eng = engine.Engine(device=local)
-    for _ in range(3):
-        eng.rx(pk, a, c); eng.sync()
-    t = time.perf_counter()
-    prev = cur = None
-    outs = None
-    for i in range(steps + 1):
-        if i < steps:
-            eng.rx(pk, a, c)
-            cur = eng.ticket()
-        if prev is not None:
-            eng.select(prev)
-            outs = eng.outs()
-            eng.fetch(abi.BUF_PDU, np.uint8)
-        prev = cur
-    dt = time.perf_counter() - t
-    eng.close()
-    assert int((outs["n_pdu"] == 1).sum()) >= 0.99 * len(pk)
-    return len(pk) * steps / dt
+
+    def dma_path():
+        eng = engine.Engine(device=local)
+        for _ in range(3):
+            eng.rx(pk, a, c); eng.sync()
+        t = time.perf_counter()
+        prev = cur = None
+        outs = None
+        for i in range(steps + 1):
+            if i < steps:
+                eng.rx(pk, a, c)
+                cur = eng.ticket()
+            if prev is not None:
+                eng.select(prev)
+                outs = eng.outs()
+                eng.fetch(abi.BUF_PDU, np.uint8)
+            prev = cur
+        dt = time.perf_counter() - t
+        eng.close()
+        assert int((outs["n_pdu"] == 1).sum()) >= 0.99 * len(pk)
+        return len(pk) * steps / dt
+
+    def gather_path():
+        eng = engine.Engine(device=local)
+        L = eng.L
+        # one arena per set: [iq | chan] (chan starts on a 16-byte boundary: iq_dev.n is even or padded)
+        n_iq = iq_dev.n + (iq_dev.n & 1)
+        sets = [torch.zeros(2 * (n_iq + chan_dev.n), dtype=torch.float32, device=dev) for _ in range(2)]
+        torch.cuda.synchronize(dev)
+        pcs = (abi.Piece * 2)(abi.Piece(iq_pin.data_ptr(), 0, iq_dev.n, 1, abi.FMT_C32, 0.0, 0),
+                              abi.Piece(ch_pin.data_ptr(), n_iq, chan_dev.n, 1, abi.FMT_C32, 0.0, 0))
+        res_sets = None
+        tickets = [None] * 3
+
+        def submit(i):
+            nonlocal res_sets
+            s_ = sets[i % 2]
+            eng._chk(L.c8p_copy_gather(eng.ctx, ctypes.c_void_p(s_.data_ptr()), pcs, 2))
+            eng._chk(L.c8p_copy_fence(eng.ctx))
+            eng.rx(pk, engine.DevArray(s_.data_ptr(), iq_dev.n), engine.DevArray(s_.data_ptr() + 8 * n_iq, chan_dev.n))
+            if res_sets is None:
+                _, ob = eng.buffer(abi.BUF_OUT)
+                _, pb = eng.buffer(abi.BUF_PDU)
+                res_sets = [(torch.empty(ob, dtype=torch.uint8).pin_memory(), torch.empty(pb, dtype=torch.uint8).pin_memory()) for _ in range(3)]
+            o_, p_ = res_sets[i % 3]
+            eng.fetch_async(abi.BUF_OUT, o_.data_ptr(), 0, o_.numel())
+            eng.fetch_async(abi.BUF_PDU, p_.data_ptr(), 0, p_.numel())
+            tickets[i % 3] = eng.ticket()
+        for i in range(4):
+            submit(i)
+        eng.sync()
+        t = time.perf_counter()
+        for i in range(steps + 1):
+            if i < steps:
+                submit(i)                                  # (set i % 2 was last read by step i - 2, waited for below one step ago)
+            if i > 0:
+                eng.wait(tickets[(i - 1) % 3])             # step i - 1: kernels done, its results are in pinned host memory
+        dt = time.perf_counter() - t
+        outs = np.frombuffer(res_sets[(steps - 1) % 3][0].numpy().tobytes(), abi.PKT_OUT_DT)
+        n_ok = int((outs["n_pdu"] == 1).sum())
+        bytes_down = 8 * (iq_dev.n + chan_dev.n)
+        bytes_up = int(res_sets[0][0].numel() + res_sets[0][1].numel())
+        eng.close()
+        assert n_ok >= 0.99 * len(pk), "pcie_inclusive: %d of %d packets delivered" % (n_ok, len(pk))
+        return len(pk) * steps / dt, bytes_down, bytes_up
+    rate, down, up = gather_path()
+    if detail is not None:
+        detail["gather_path_packets_per_s"] = rate
+        detail["host_to_device_GBps"] = rate / len(pk) * down / 1e9
+        detail["device_to_host_GBps"] = rate / len(pk) * up / 1e9
+        detail["bytes_per_step"] = {"down": down, "up": up}
+        try:
+            detail["dma_path_packets_per_s"] = dma_path()
+        except Exception as e:
+            detail["dma_path_packets_per_s"] = "%s: %s" % (type(e).__name__, e)
+    return rate
 
 
 def frontend_detect(torch, dev, local, n_target=32 << 20):

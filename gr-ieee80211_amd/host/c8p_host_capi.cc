@@ -3,6 +3,9 @@
 // general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -316,7 +319,13 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   bool a_done = false;
   std::atomic<bool> failed{false};
   long calls_a = 0, calls_b = 0;
+  // C8P_CHAIN_TLOG=1: where the two scheduler threads spent the run (stderr): inside general_work, waiting for the other, the rest
+  static const bool tlog = getenv("C8P_CHAIN_TLOG") != nullptr;
+  typedef std::chrono::steady_clock clk;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  double a_work = 0, a_wait = 0, a_all = 0, b_work = 0, b_wait = 0, b_all = 0;
   std::thread ta([&] {
+    const clk::time_point ta0 = clk::now();
     try {
       int idle = 0, cur = -1;
       size_t wpos = 0;                           // floats of the current segment handed to B so far
@@ -333,8 +342,10 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
           cur = -1;
         }
         if (cur < 0) {
+          const clk::time_point tw = clk::now();
           std::unique_lock<std::mutex> lk(mu);
           cv.wait(lk, [&] { return !spare.empty() || failed; });                   // (back-pressure: B has not finished a segment yet)
+          a_wait += secs(tw, clk::now());
           if (failed) break;
           cur = spare.front(); spare.pop_front();
           segs[cur].n = 0; segs[cur].closed = false;
@@ -344,7 +355,9 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         gr_vector_void_star outs(1, segs[cur].items + wpos);
         A->consumed_this_call = 0;
         const size_t tags_before = A->out_tags.size();
+        const clk::time_point tg = clk::now();
         const int produced = A->blk->general_work(nout, nin, ins, outs);
+        a_work += secs(tg, clk::now());
         calls_a++;
         for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
         A->n_read += A->consumed_this_call;
@@ -362,9 +375,11 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
       }
       if (cur >= 0) { std::lock_guard<std::mutex> g(mu); segs[cur].closed = true; }
     } catch (const std::exception& e) { A->err = e.what(); failed = true; }
+    a_all = secs(ta0, clk::now());
     { std::lock_guard<std::mutex> g(mu); a_done = true; }
     cv.notify_all();
   });
+  const clk::time_point tb0 = clk::now();
   try {
     std::vector<float> dummy(16);
     gr_vector_void_star outs(1, dummy.data());
@@ -392,17 +407,22 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
           }
           if (a_done && filled.empty()) { fin = true; break; }
           if (a_done && cur >= 0 && fruitless >= 2) { fin = true; break; }          // (never: a block that sits on items it will not consume)
+          const clk::time_point tw = clk::now();
           cv.wait(lk);
+          b_wait += secs(tw, clk::now());
         }
         while (!tagq.empty()) { B->push_tag(std::move(tagq.front())); tagq.pop_front(); }
         if (cur >= 0) seen = segs[cur].n;
       }
       if (fin) break;
-      const int k = (int)std::min<size_t>(n_avail, (size_t)chunk);
+      // (what is in the buffer, up to what one call of A can have put there: a reader is offered all the items its buffer holds)
+      const int k = (int)std::min<size_t>(n_avail, std::max((size_t)chunk, (size_t)std::max(nout, 1) * fpi));
       gr_vector_int nin(1, k);
       gr_vector_const_void_star ins(1, segs[cur].items + rpos);
       B->consumed_this_call = 0;
+      const clk::time_point tg = clk::now();
       B->blk->general_work(0, nin, ins, outs);
+      b_work += secs(tg, clk::now());
       calls_b++;
       if (B->poison && B->consumed_this_call) memset(segs[cur].items + rpos, 0xff, (size_t)B->consumed_this_call * sizeof(float));
       rpos += (size_t)B->consumed_this_call;
@@ -419,7 +439,11 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
       if (idle == 1) B->blk->flush();
     }
   } catch (const std::exception& e) { B->err = e.what(); { std::lock_guard<std::mutex> g(mu); failed = true; } cv.notify_all(); }
+  b_all = secs(tb0, clk::now());
   ta.join();
+  if (tlog)
+    fprintf(stderr, "[c8ph_run_chain] A: %ld calls, %.2f ms in general_work, %.2f ms waiting for a segment, %.2f ms all | B: %ld calls, %.2f ms in general_work, "
+            "%.2f ms waiting for items, %.2f ms all\n", calls_a, 1e3 * a_work, 1e3 * a_wait, 1e3 * a_all, calls_b, 1e3 * b_work, 1e3 * b_wait, 1e3 * b_all);
   return failed ? -1 : calls_a + calls_b;
 }
 

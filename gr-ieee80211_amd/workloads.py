@@ -91,13 +91,21 @@ WORKLOADS = {
 }
 
 
-def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, seed_base=None):
+# a 3-tap frequency-selective channel (delays 0, 1, 2 samples, inside the 16-sample guard interval): -9 and -15 dB echoes with fixed
+# phases, unit total power.  |H(f)| swings between 0.55 and 1.38 across the 56 tones (+2.8 / -5.2 dB).
+TAPS3 = (np.array([1.0, 0.35 * np.exp(0.9j), 0.18 * np.exp(-2.1j)]) / np.sqrt(1.0 + 0.35 ** 2 + 0.18 ** 2)).astype(np.complex64)
+
+
+def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, seed_base=None, window=False, taps=None):
     """A BASELINE.json config (WORKLOADS) as SURVEY.md §8d specifies it, generated on the box by the build's own transmitter:
     packet p carries its own MPDU (bytes from numpy.random.default_rng(seed_base + seed + p) + CRC-32; inside an A-MPDU for VHT),
     amplitude as tools/pktGenExample.py (multiplier 12, x sqrt(2) on two chains), clean OFDM symbols (C8P_TX_NO_WINDOW: the toolbox's
     half-amplitude symbol edges cost 19.6 dB of self-interference at the receiver's FFT window), a flat channel
     H e^{j theta_p} and AWGN at snr_db (sigma per tools/performance/perf_siso.py:92).  c8p_tx -> channel (torch, on the device) ->
     c8p_signal at the nominal sync item (L-LTF + 24, CFO 0) gives the packets at the signal -> demod boundary, all resident in HBM.
+    window=True: the toolbox's half-amplitude symbol edges ARE applied (c8p_tx_pkt.flags = 0: the waveform of tools/phy80211.py, whose
+    self-interference caps the effective SNR at 19.6 dB); taps: a complex FIR applied to every transmit chain's stream before H (a
+    frequency-selective channel; TAPS3).
     Returns (descriptors [host], iq DevArray, chan DevArray, expected PDUs, keep-alive objects)."""
     import zlib
     from . import engine, shard
@@ -131,7 +139,7 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
         pk[p]["psdu_off"], pk[p]["len"], pk[p]["format"], pk[p]["mcs"] = put(ps[0]), len(ps[0]), fmt, mcs
         pk[p]["scr_seed"], pk[p]["gap"], pk[p]["nss"] = 93, GAP, nchain
         pk[p]["mult"] = 12.0 * (np.sqrt(2.0) if nchain == 2 else 1.0)
-        pk[p]["flags"] = abi.TX_NO_WINDOW
+        pk[p]["flags"] = 0 if window else abi.TX_NO_WINDOW
         if fmt == 3:
             mu[p]["psdu_off"], mu[p]["len"], mu[p]["mcs"], mu[p]["group_id"], mu[p]["q_off"] = put(ps[1]), len(ps[1]), mcs, 2, 0
         m = mpdus[mupos]
@@ -155,6 +163,11 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
     idx = (torch.searchsorted(starts, torch.arange(ntot, device=dev), right=True) - 1).clamp(min=0)
     ph = torch.polar(torch.ones(n, device=dev), theta)[idx]
     Hm = torch.from_numpy(np.eye(1, dtype=np.complex64) if H is None else np.asarray(H, np.complex64)).to(dev)
+    if taps is not None:                                       # echoes: z[t] <- sum_k taps[k] z[t - k] (the streams end in idle air)
+        zt = torch.zeros_like(z)
+        for k_, h_ in enumerate(np.asarray(taps, np.complex64)):
+            zt[:, k_:] += complex(h_) * z[:, :ntot - k_]
+        z = zt
     rx = (Hm @ z) * ph                                         # [n_ant][ntot]
     sigma = float(np.sqrt(0.1875 ** 2 / (10 ** (snr_db / 10.0))))
     noise = torch.randn(n_ant, ntot, 2, generator=g, device=dev, dtype=torch.float32) * (sigma / np.sqrt(2))

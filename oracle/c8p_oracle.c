@@ -454,6 +454,55 @@ static int check_vht_a(const uint8_t* b)   /* signalCheckVhtA :753-771 */
   return 1;
 }
 
+/* The SIG checks and parsers on their own (test entry points: tests/test_oracle_rx_golden.py compares them with the reference
+ * toolbox's procCheckSig* / procParserSig* / modulation on fuzzed fields).  out[10] = {format, mcs, len, nSS, nBPSCS, nCBPS, nDBPS, cr,
+ * nSym, nLTF}; return value: the check (signalCheckLegacy :650-728, signalCheckHt :730-751, signalCheckVhtA :753-771). */
+static void mod_out(const mod_t* m, int* out)
+{
+  out[0] = m->format; out[1] = m->mcs; out[2] = m->len; out[3] = m->nSS; out[4] = m->nBPSCS; out[5] = m->nCBPS; out[6] = m->nDBPS; out[7] = m->cr;
+  out[8] = m->nSym; out[9] = m->nLTF;
+}
+int c8po_sig_legacy(const uint8_t* bits24, int* out)
+{
+  c8po_init();
+  memset(out, 0, sizeof(int) * 10);
+  const uint8_t* bits = bits24;
+  if (!bits[3]) return 0;
+  if (bits[4]) return 0;
+  int par = 0; for (int i = 0; i < 17; i++) par += bits[i];
+  if ((par & 1) ^ bits[17]) return 0;
+  int rate = 0; for (int i = 0; i < 4; i++) rate |= ((int)bits[i]) << i;
+  int mcs;
+  switch (rate) {
+    case 11: mcs = 0; break; case 15: mcs = 1; break; case 10: mcs = 2; break; case 14: mcs = 3; break;
+    case 9:  mcs = 4; break; case 13: mcs = 5; break; case 8:  mcs = 6; break; case 12: mcs = 7; break;
+    default: mcs = 0; break;
+  }
+  int len = 0; for (int i = 0; i < 12; i++) len |= ((int)bits[i + 5]) << i;
+  if (len > 4095 || len < 14) return 0;
+  mod_t m;
+  parse_legacy(mcs, len, &m);
+  mod_out(&m, out);
+  return 1;
+}
+int c8po_sig_ht(const uint8_t* bits48, int* out)
+{
+  c8po_init();
+  mod_t m;
+  parse_ht(bits48, &m);
+  mod_out(&m, out);
+  return check_ht(bits48);
+}
+int c8po_sig_vht_a(const uint8_t* bits48, int* out)
+{
+  c8po_init();
+  mod_t m;
+  parse_vht_a(bits48, &m);
+  mod_out(&m, out);
+  out[2] = -1; out[8] = -1;                     /* length and symbol count come with SIG-B */
+  return check_vht_a(bits48);
+}
+
 /* ------------------------------------------------------------------ LLR demapper  procSymQamToLlr cloud80211phy.cc:2090-2148 */
 void c8po_qam_to_llr(cf* q, float* o, int nsd, int nbpscs)
 {

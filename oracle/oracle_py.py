@@ -266,3 +266,27 @@ def tx_packet_mu(mcs, ampdus, gid, bfq, scr_seed=93, mult=12.0 * np.sqrt(2.0)):
 def tx_sig_xor(mask):
     """test hook: bits flipped in HT-SIG / VHT-SIG-A (bits 0..33, CRC recomputed) by the following tx_packet* calls; 0 = off"""
     lib().c8po_tx_test_sig_xor(C.c_ulonglong(int(mask)))
+
+
+# ---- SIG checks and parsers on bit fields (c8p_oracle.c: c8po_sig_*)
+_SIG_FIELDS = ("format", "mcs", "len", "nSS", "nBPSCS", "nCBPS", "nDBPS", "cr", "nSym", "nLTF")
+
+
+def _sig(fn, bits, n):
+    b = np.ascontiguousarray(bits, np.uint8)
+    assert b.size == n
+    out = np.zeros(10, np.int32)
+    ok = getattr(lib(), fn)(_p(b), _p(out))
+    return bool(ok), dict(zip(_SIG_FIELDS, (int(v) for v in out)))
+
+
+def sig_legacy(bits24):
+    return _sig("c8po_sig_legacy", bits24, 24)
+
+
+def sig_ht(bits48):
+    return _sig("c8po_sig_ht", bits48, 48)
+
+
+def sig_vht_a(bits48):
+    return _sig("c8po_sig_vht_a", bits48, 48)

@@ -316,6 +316,121 @@ def gen_mu_tx():
     return out
 
 
+# ----------------------------------------------------------------------------- (a) the toolbox's RECEIVE side
+def gen_rx_side():
+    """tools/phy80211.py:842-1016 (procSisoRx and the private steps it calls) on the toolbox's own transmissions at CFO 0 / +-50 kHz
+    with 35 dB of AWGN: STF trigger index, coarse CFO, LTF sync index, coarse + fine CFO, LTF SNR, the legacy channel estimate, the L-SIG
+    constellation / bits / SNR, HT-SIG and VHT-SIG-A bits, the VHT channel and SIG-B LLRs — every intermediate the method computes (it only
+    prints them), taken by calling its steps in its own order.  And tools/phy80211header.py:1055-1175 on fuzzed bit fields: procCheckSig*,
+    procParserSigLegacy / procParserSigHt, and the `modulation` tables for every HT / VHT rate."""
+    out = {}
+    rng = np.random.default_rng(802110)
+    cases = [("L", 0, 60), ("L", 4, 200), ("L", 7, 333), ("HT", 0, 80), ("HT", 5, 300), ("VHT", 0, 70), ("VHT", 4, 150), ("VHT", 7, 400)]
+    k = 0
+    for fmt, mcs, ln in cases:
+        for cfo in (0.0, 50000.0, -50000.0):
+            mpdu = mpdu_bytes(rng, ln)
+            ins = phy80211.phy80211(ifDebug=False)
+            if fmt == "VHT":
+                mod = p8h.modulation(p8h.F.VHT, mcs, p8h.BW.BW20, 1, False)
+                ins.genFromAmpdu(mac80211.genAmpduVHT([mpdu]), mod, vhtPartialAid=0, vhtGroupId=0)
+            else:
+                mod = p8h.modulation(p8h.F.L if fmt == "L" else p8h.F.HT, mcs, p8h.BW.BW20, 1, False)
+                ins.genFromMpdu(mpdu, mod)
+            sig = ins.genFinalSig(multiplier=MULT, cfoHz=cfo, num=1, gap=False, gapLen=0)
+            lead = 300 + 7 * k
+            x = np.concatenate([np.zeros(lead), np.array(sig, np.complex128).reshape(-1), np.zeros(400)])
+            sigma = np.sqrt(0.1875 ** 2 / 10 ** 3.5)
+            x = x + (rng.normal(0, sigma / np.sqrt(2), len(x)) + 1j * rng.normal(0, sigma / np.sqrt(2), len(x)))
+            x = x.astype(np.complex64)                 # what a receiver is handed (and what the fixture stores)
+            rx = [complex(v) for v in x]
+            R = phy80211.phy80211(ifDebug=False)
+            R.rxSisoSig = rx
+            trig = R._phy80211__procRxLegacyStfTrigger(rx)
+            assert trig >= 0
+            coarse = R._phy80211__procRxLegacyStfCoarseCfoEst(rx[trig:], 64)
+            mid = R._phy80211__procRxLegacyLtfSync(rx[trig + 80:trig + 320], coarse)
+            assert mid >= 0
+            ltf = trig + 80 + mid + 10
+            rad = R.rxCfo * 2 * np.pi / 20000000
+            leg = [rx[ltf + i] * complex(np.cos(rad * i), np.sin(rad * i)) for i in range(0, 208)]
+            R._phy80211__procRxLegacyChanEst(leg[0:128])
+            qam = R._phy80211__procRxLegacySigDemod(leg[144:])
+            inted = list(np.real(qam))
+            coded = p8h.procDeinterleaveSigL(inted)
+            bits = p8h.procViterbiDecoder(coded, 24, p8h.CR.CR12)
+            d = {"x": x, "lead": np.int32(lead), "cfo_hz": np.float64(cfo), "trigger": np.int32(trig), "coarse_cfo_hz": np.float64(coarse),
+                 "ltf_sync": np.int32(mid), "ltf_index": np.int32(ltf), "rx_cfo_hz": np.float64(R.rxCfo), "rx_snr_db": np.float64(R.rxSnrDb),
+                 "chan_l": np.array(R.rxChanL, np.complex128), "lsig_qam": np.array(qam, np.complex128), "lsig_llr_coded": np.array(coded, np.float64),
+                 "lsig_bits": np.array(bits, np.uint8), "lsig_snr": np.float64(p8h.procSnrSigLegacy(qam, bits)),
+                 "lsig_check": np.int32(bool(p8h.procCheckSigLegacy(bits))), "fmt": np.int32({"L": 0, "HT": 1, "VHT": 2}[fmt]), "mcs": np.int32(mcs),
+                 "mpdu_len": np.int32(ln)}
+            if fmt != "L":
+                _, _, nsym_l = p8h.procParserSigLegacy(bits)
+                nsym_l = min(nsym_l, 8)                # (its rate table only knows 6 and 54 Mb/s: enough symbols for the SIG fields either way)
+                ss = [rx[ltf + 208 + i] * complex(np.cos(rad * i), np.sin(rad * i)) for i in range(0, max(nsym_l, 6) * 80)]
+                nl = R._phy80211__procRxNonLegacySigDemod(ss[16:80] + ss[96:160])
+                ht_c = p8h.procDeinterleaveSigL(list(np.imag(nl[0:48]))) + p8h.procDeinterleaveSigL(list(np.imag(nl[48:96])))
+                vht_c = p8h.procDeinterleaveSigL(list(np.real(nl[0:48]))) + p8h.procDeinterleaveSigL(list(np.imag(nl[48:96])))
+                hb = p8h.procViterbiDecoder(ht_c, 48, p8h.CR.CR12)
+                vb = p8h.procViterbiDecoder(vht_c, 48, p8h.CR.CR12)
+                d.update({"nl_qam": np.array(nl, np.complex128), "ht_bits": np.array(hb, np.uint8), "vht_a_bits": np.array(vb, np.uint8),
+                          "ht_check": np.int32(bool(p8h.procCheckSigHt(hb))), "vht_a_check": np.int32(bool(p8h.procCheckSigVhtA(vb)))})
+            out.update(flat("rx%02d_%s%d" % (k, fmt, mcs), d))
+            k += 1
+    out["n_cases"] = np.int32(k)
+    # the checks and parsers on fuzzed fields: 400 random words per field + every single-bit flip of a valid one
+    fz = np.random.default_rng(802111)
+
+    def words(n, valid):
+        w = [fz.integers(0, 2, n).astype(np.uint8) for _ in range(400)]
+        for b in range(n):
+            v = valid.copy(); v[b] ^= 1
+            w.append(v)
+        w.append(valid.copy())
+        return np.array(w, np.uint8)
+    lv = np.array([1, 1, 0, 1, 0] + [(300 >> i) & 1 for i in range(12)] + [0] + [0] * 6, np.uint8)
+    lv[17] = lv[0:17].sum() % 2
+    lw = words(24, lv)
+    for i in range(0, 400, 2):                         # half of the random ones: a valid rate field, tail and parity, random length
+        lw[i][0:4] = [1, 1, 0, 1]; lw[i][4] = 0; lw[i][18:24] = 0; lw[i][17] = lw[i][0:17].sum() % 2
+    out["fuzz_l_bits"] = lw
+    out["fuzz_l_check"] = np.array([bool(p8h.procCheckSigLegacy([int(b) for b in w])) for w in lw], np.uint8)
+    out["fuzz_l_parse"] = np.array([p8h.procParserSigLegacy([int(b) for b in w]) for w in lw], np.int32)
+    hv = np.array([(5 >> i) & 1 for i in range(7)] + [0] + [(1234 >> i) & 1 for i in range(16)] + [1, 0, 1, 1, 0, 0, 0, 0, 0, 0], np.uint8)
+    hv = np.concatenate([hv, np.array(p8h.genBitBitCrc8([int(b) for b in hv]), np.uint8), np.zeros(6, np.uint8)])
+    hw = words(48, hv)
+    for i in range(0, 400, 2):                         # half of the random ones carry a correct CRC-8
+        hw[i][34:42] = p8h.genBitBitCrc8([int(b) for b in hw[i][0:34]])
+    out["fuzz_ht_bits"] = hw
+    out["fuzz_ht_check"] = np.array([bool(p8h.procCheckSigHt([int(b) for b in w])) for w in hw], np.uint8)
+    hp = []
+    for w in hw:
+        m = p8h.procParserSigHt([int(b) for b in w])
+        ln = sum(int(w[i + 8]) << i for i in range(16))
+        hp.append([int(m.mcs) if m.initRes else -1, ln, int(m.nSS) if m.initRes else -1, int(m.nBPSCS) if m.initRes else -1,
+                   int(m.nCBPS) if m.initRes else -1, int(m.nDBPS) if m.initRes else -1, int(m.initRes)])
+    out["fuzz_ht_parse"] = np.array(hp, np.int32)
+    vv = np.array([0, 0, 1, 0] + [0] * 6 + [0, 0, 0] + [0] * 9 + [0, 1, 0, 0, 0, 0] + [(7 >> i) & 1 for i in range(4)] + [0, 1], np.uint8)
+    vv = np.concatenate([vv, np.array(p8h.genBitBitCrc8([int(b) for b in vv]), np.uint8), np.zeros(6, np.uint8)])
+    vw = words(48, vv)
+    for i in range(0, 400, 2):
+        vw[i][34:42] = p8h.genBitBitCrc8([int(b) for b in vw[i][0:34]])
+    out["fuzz_vht_bits"] = vw
+    out["fuzz_vht_check"] = np.array([bool(p8h.procCheckSigVhtA([int(b) for b in w])) for w in vw], np.uint8)
+    # the rate tables: modulation(format, mcs, BW20, nSTS) for every HT / VHT rate of one and two streams
+    mt = []
+    for f, fcode, rates in ((p8h.F.L, 0, range(8)), (p8h.F.HT, 1, range(16)), (p8h.F.VHT, 2, range(10))):
+        for mcs in rates:
+            for nsts in ((1,) if fcode == 0 else ((mcs // 8 + 1,) if fcode == 1 else (1, 2))):
+                m = p8h.modulation(f, mcs, p8h.BW.BW20, nsts, False)
+                if not m.initRes:
+                    continue
+                mt.append([fcode, mcs, nsts, int(m.nSS), int(m.nBPSCS), int(m.nCBPS), int(m.nDBPS), int(m.nLtf), int(m.nSD)])
+    out["mod_table"] = np.array(mt, np.int32)
+    return out
+
+
 def flat(prefix, d):
     return {prefix + "/" + k: v for k, v in d.items()}
 
@@ -324,6 +439,10 @@ def main():
     if "--mu-recorded" in sys.argv:  # cfg 5 with the reference's recorded NDP captures (round 3); own seed, leaves the others untouched
         np.savez_compressed(os.path.join(OUT, "packets_mu_recorded.npz"), **gen_mu_recorded())
         print("packets_mu_recorded.npz written")
+        return
+    if "--rx-side" in sys.argv:     # round 5: the toolbox's receive side; own seeds, leaves the other files untouched
+        np.savez_compressed(os.path.join(OUT, "rx_side.npz"), **gen_rx_side())
+        print("rx_side.npz written")
         return
     if "--mu-tx" in sys.argv:       # added later than the other files; own seeds, leaves them untouched
         np.savez_compressed(os.path.join(OUT, "packets_mu_tx.npz"), **gen_mu_tx())
