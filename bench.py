@@ -84,6 +84,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)                         # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local)
+    from __graft_entry__ import load_package
+    load_package()
+    from gr_ieee80211_amd import hostbind
+    # this rank's host side — the engines' stage threads, the fronts' timers, RCCL's proxy threads, every pinned allocation — on the NUMA
+    # node its GPU hangs off (reported in the line: host_binding)
+    binding = hostbind.bind_rank(local, torch)
+    binding["rank"] = rank
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,10 +98,10 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the RCCL communicator has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
-    from __graft_entry__ import load_package
-    load_package()
     from gr_ieee80211_amd import engine
     from gr_ieee80211_amd.workloads import WORKLOADS, workload_on_device
+    engine.load_library()
+    binding["hip_runtimes_mapped"] = hostbind.assert_single_hip_runtime()      # torch's and the engine's must be ONE (raises otherwise)
 
     if args.workload == "cfg4":
         st = sharded_stream(torch, dev, local, rank, world, use_dist, args.stream_packets, max(args.steps, 1) if args.steps != 200 else 5,
@@ -306,7 +313,25 @@ def main():
         guard.done()
         if rank == 0:
             out["sharded_stream"] = stream_res
+    # world > 1: the host-fed legs, EVERY rank at the same time (each GPU has its own link; whether the host feeds them all at once is what
+    # is asked): live ingest through shard.LiveShard (64 streams per rank) and the PCIe-inclusive c8p_rx, per-rank figures in the line
+    bindings = [binding]
+    if use_dist:
+        bindings = [None] * world
+        dist.all_gather_object(bindings, binding)
+    if world > 1 and not args.no_host_legs:
+        guard = LegGuard(out, rank, float(os.environ.get("C8P_HOST_LEG_TIMEOUT_S", "240")), "multi_gpu_host_fed")
+        try:
+            mine = multi_gpu_host_fed(torch, dev, local, rank, world, pk, iq_dev, chan_dev)
+        except Exception as e:
+            mine = {"rank": rank, "error": "%s: %s" % (type(e).__name__, e)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        guard.done()
+        if rank == 0:
+            out["multi_gpu_host_fed"] = summarize_host_fed(every)
     if rank == 0:
+        out["host_binding"] = bindings
         if not args.no_host_legs and world == 1:
             # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
             out["pcie_inclusive_detail"] = {}
@@ -400,6 +425,44 @@ def legs_summary(out):
     return {k: v for k, v in legs.items() if v is not None}
 
 
+def multi_gpu_host_fed(torch, dev, local, rank, world, pk, iq_dev, chan_dev, streams_per_rank=64, rounds=20):
+    """One rank's share of the host-fed legs at world > 1, started together on all ranks (barriers): live ingest of
+    streams_per_rank x world radios through shard.LiveShard — a stream belongs to one rank, which keeps its detection state; no
+    collective in the data path — and the PCIe-inclusive c8p_rx of this rank's batch.  Returns this rank's figures."""
+    import torch.distributed as dist
+    from gr_ieee80211_amd import shard
+    from gr_ieee80211_amd.workloads import raw_stream_unit
+    res = {"rank": rank, "gpu": local}
+    unit, _pdu = raw_stream_unit(local)
+    dist.barrier()
+    ls = live_streams(torch, dev, local, unit, streams=streams_per_rank, rounds=rounds, shard_world=(shard, streams_per_rank * world))
+    res["live_streams"] = {k: ls[k] for k in ("streams", "ms_per_round", "x_realtime_each", "streams_at_realtime", "pcie_GBps", "packets_per_s", "pdus_ok",
+                                              "pdus_in_the_items_pushed", "round_closed_to_pdus_ms") if k in ls}
+    res["live_streams"]["global_streams"] = ls.get("global_streams")
+    dist.barrier()
+    det = {}
+    res["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, detail=det)
+    res["pcie_host_to_device_GBps"] = det.get("host_to_device_GBps")
+    dist.barrier()
+    return res
+
+
+def summarize_host_fed(every):
+    """rank 0: the ranks' figures side by side + their sums (weak scaling: every rank serves its own radios / batches)"""
+    ok = [e for e in every if isinstance(e, dict) and "error" not in e]
+    out = {"per_rank": every, "ranks_ok": len(ok)}
+    if ok:
+        out["live_streams_at_realtime_total"] = sum(e["live_streams"]["streams_at_realtime"] for e in ok)
+        out["live_pcie_GBps_total"] = sum(e["live_streams"]["pcie_GBps"] for e in ok)
+        out["pcie_inclusive_packets_per_s_total"] = sum(e["pcie_inclusive_packets_per_s"] for e in ok)
+        v = [e["live_streams"]["streams_at_realtime"] for e in ok]
+        out["live_streams_at_realtime_min_max"] = [min(v), max(v)]
+    out["note"] = ("all ranks run these at the same time between barriers: shard.LiveShard (each rank the streams partition() gives it, its own "
+                   "c8p_rawchain handle, rings of pinned memory allocated after hostbind.bind_rank) and pcie_inclusive (one c8p_copy_gather + "
+                   "c8p_rx + result fetch per step); totals are sums over ranks, no collective in either data path")
+    return out
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` started by hand (no RANK in the environment): start the N ranks, one per GPU, exactly as the driver
     does — python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>
@@ -443,6 +506,16 @@ def dry_launch(args):
         dist.init_process_group(backend="gloo")
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the communicator has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    # what every rank does before it touches its GPU: find the device's NUMA node, bind to it (no GPU here: nothing to find, and the
+    # record says so), check that one HIP runtime is mapped; and the partition of the live streams over the ranks (shard.LiveShard's)
+    from __graft_entry__ import load_package
+    load_package()
+    from gr_ieee80211_amd import hostbind, shard
+    binding = hostbind.bind_rank(int(os.environ.get("LOCAL_RANK", "0")), torch)
+    binding["rank"] = rank
+    binding["hip_runtimes_mapped"] = hostbind.assert_single_hip_runtime()
+    lo, hi = shard.partition(64 * world, world, rank)
+    my_leg = {"rank": rank, "live_streams": {"global_streams": [lo, hi, 64 * world], "streams": hi - lo}, "pcie_inclusive_packets_per_s": None}
     n_pkt = args.batch
     for _ in range(args.warmup):
         time.sleep(1e-4)
@@ -464,10 +537,18 @@ def dry_launch(args):
         v[rank] = per_rank[0]
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         per_rank = [float(x) for x in v.tolist()]
+    bindings, legs_ = [binding], [my_leg]
+    if use_dist:
+        bindings, legs_ = [None] * world, [None] * world
+        dist.all_gather_object(bindings, binding)
+        dist.all_gather_object(legs_, my_leg)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        emit({"metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": None, "unit": "packets/s", "n_gpus": world, "steps": args.steps,
+        emit({"metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": None, "host_binding": bindings,
+              "multi_gpu_host_fed": {"dry": True, "per_rank": legs_, "ranks_ok": len(legs_),
+                                     "note": "dry launch: the partition of the live streams over the ranks and the gathering of the per-rank records; "
+                                             "no engine, no figures — UNMEASURED at N > 1"}, "unit": "packets/s", "n_gpus": world, "steps": args.steps,
               "warmup": args.warmup, "ms_per_step": 1e3 * el / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "none (dry launch)", "dry_launch": True,
               "per_rank_packets_per_s": {"values": per_rank, "min": min(per_rank), "max": max(per_rank), "note": "sleeps, not packets"},
@@ -1206,7 +1287,7 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
     return out
 
 
-def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, rounds=40, bits=0, pace=0.0):
+def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, rounds=40, bits=0, pace=0.0, shard_world=None):
     """north_star's unit of parallelism: many independent 20 MHz streams on one GPU.  `streams` radios deliver round_items items each
     per round (26 ms of air at 20 MS/s) out of pinned host memory through the live ingest of host/c8p_rawchain: per round ONE
     c8p_detect_multi over all streams, one c8p_signal (scan rule per stream), one c8p_rx over the packets of all streams; detection
@@ -1237,9 +1318,16 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
     ring = torch.empty((streams, 2 * W), dtype={0: torch.float32, 16: torch.int16, 8: torch.int8}[bits]).pin_memory()
     ring.numpy()[:] = np.tile(unit_q, m)[None, :]
     per_round_pk = streams * (round_items // unit_len + 2)
-    h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, reserve_seg_events=2 * per_round_pk + per_round_pk // 4,
-                        reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len, sc16_scale=float(scale), sc8_scale=float(scale))
-    h.live(None)                    # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
+    kw = dict(reserve_seg_events=2 * per_round_pk + per_round_pk // 4, reserve_seg_packets=per_round_pk, reserve_pkt_items=unit_len,
+              sc16_scale=float(scale), sc8_scale=float(scale))
+    lshard = None
+    if shard_world is not None:     # (shard module, streams of the whole job): this rank's `streams` of them through shard.LiveShard
+        lshard = shard_world[0].LiveShard(shard_world[1], round_items, device=local, **kw)
+        assert lshard.hi - lshard.lo == streams, "LiveShard gave this rank %d streams, the leg feeds %d" % (lshard.hi - lshard.lo, streams)
+        h = lshard.h
+    else:
+        h = blocks.RawChain(device=local, streams=streams, stream_round_items=round_items, **kw)
+        h.live(None)                # (the per-packet results are fetched by the rx stage and counted; no Python in the pipeline's threads)
     base = np.uint64(ring.data_ptr()) + np.arange(streams, dtype=np.uint64) * np.uint64(W * item_bytes)
     pos0 = (np.arange(streams, dtype=np.uint64) * np.uint64(7919 * 131)) % np.uint64(W)      # every radio at its own point of the capture
     sid = np.arange(streams, dtype=np.uint32)
@@ -1272,7 +1360,8 @@ def live_streams(torch, dev, local, unit, streams=64, round_items=1 << 19, round
     air = round_items / 20e6
     per_round = dt / rounds
     want_pdus = streams * ((rounds + 3) * round_items // unit_len)
-    return {"streams": streams, "items_per_stream_per_round": round_items, "rounds": rounds, "ms_per_round": 1e3 * per_round,
+    return {"streams": streams, "global_streams": ([lshard.lo, lshard.hi, lshard.n_streams] if lshard is not None else None),
+            "items_per_stream_per_round": round_items, "rounds": rounds, "ms_per_round": 1e3 * per_round,
             "x_realtime_each": air / per_round, "streams_at_realtime": streams * air / per_round,
             "pcie_GBps": float(item_bytes) * streams * round_items / per_round / 1e9, "bytes_per_item_over_pcie": item_bytes,
             "packets_per_s": st["steady_pdus"] / max(st["steady_s"], 1e-9),

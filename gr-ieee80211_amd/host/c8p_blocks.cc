@@ -358,8 +358,12 @@ typedef engine_holder::dev_buf dev_buf;
 struct gather_lane {
   std::vector<c8p_piece> pieces;
   uint64_t scan_abs = 0;                 // port 0: items cut so far (absolute); items before it are never looked at again
-  uint64_t prev_mark = 0, prev_scan = 0; // the copy-stream mark behind the previous call's gather and the scan position it covers
-  bool have_prev = false;
+  // the gathers that have been enqueued and not waited for, oldest first: the copy-stream mark behind each and the scan position it
+  // covers.  A call consumes what the gathers of TWO calls ago moved (DEPTH = 2: a gather takes ~20 us from enqueue to done whatever
+  // its size — launch, PCIe round trips, the event — and a call of a busy block comes round faster than that)
+  enum { DEPTH = 2 };
+  struct pend_t { uint64_t mark, scan; };
+  std::deque<pend_t> pend;
   void add(const void* src, uint64_t dst_off, uint64_t n, uint32_t fmt)
   {
     if (!n) return;
@@ -384,20 +388,28 @@ struct gather_lane {
   // at the end of a call that looked at the items [rd, rd + used): how many of them may be consumed now
   int settle(engine_holder& E, uint64_t rd, int used, phase_clock& ph)
   {
+    const bool fresh = rd + (uint64_t)used > scan_abs;                                // this call cut items no call had seen
     scan_abs = std::max(scan_abs, rd + (uint64_t)used);
-    if (!dirty && !have_prev) return used;                                           // nothing of this window is on its way
+    if (!dirty && pend.empty()) return used;                                         // nothing of this window is on its way
     const c8p_api& A = E.d_api;
-    uint64_t m = prev_mark;
-    if (dirty) { m = A.copy_mark(E.d_ctx); if (!m) throw std::runtime_error("c8p_copy_mark failed"); dirty = false; }
+    if (dirty) {
+      const uint64_t m = A.copy_mark(E.d_ctx);
+      if (!m) throw std::runtime_error("c8p_copy_mark failed");
+      pend.push_back(pend_t{m, scan_abs});
+      dirty = false;
+    } else if (!pend.empty()) pend.back().scan = scan_abs;                           // (items without a gather of their own: skipped ones)
     sub_scope w(ph, phase_clock::GWAIT);
-    if (!E.d_cfg.defer_consume) { E.check(A.copy_wait_mark(E.d_ctx, m), "c8p_copy_wait_mark"); have_prev = false; return used; }
-    int cons = 0;
-    if (have_prev) {
-      E.check(A.copy_wait_mark(E.d_ctx, prev_mark), "c8p_copy_wait_mark");
-      cons = (int)std::min<uint64_t>(prev_scan > rd ? prev_scan - rd : 0, (uint64_t)used);
+    // with deferral: all but the newest DEPTH gathers are waited for; a call that brought nothing new settles everything (the
+    // scheduler has nothing more to offer until these items are let go of)
+    const size_t keep = (E.d_cfg.defer_consume && fresh) ? (size_t)DEPTH : 0;
+    uint64_t done_scan = rd;
+    while (pend.size() > keep) {
+      E.check(A.copy_wait_mark(E.d_ctx, pend.front().mark), "c8p_copy_wait_mark");
+      done_scan = std::max(done_scan, pend.front().scan);
+      pend.pop_front();
     }
-    prev_mark = m; prev_scan = scan_abs; have_prev = rd + (uint64_t)cons < scan_abs;     // (everything consumed: nothing left to settle)
-    return cons;
+    if (pend.empty()) return used;
+    return (int)std::min<uint64_t>(done_scan - rd, (uint64_t)used);
   }
   bool dirty = false;                    // a gather has been enqueued since the last mark
 };
@@ -430,8 +442,9 @@ public:
   {
     // results waiting for output space need no input to be handed out (the timer thread collected them while none arrived)
     std::lock_guard<std::mutex> g(d_mu);
-    for (auto& r : req) r = d_outq.empty() ? noutput_items : 0;
+    for (auto& r : req) r = (d_outq.empty() && !d_ready && !d_inflight) ? noutput_items : 0;
   }
+  int output_ahead() override { std::lock_guard<std::mutex> g(d_mu); return (int)(d_ready + d_inflight); }
 
   std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
   void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
@@ -451,11 +464,10 @@ public:
     int nproc = ninput_items[0];
     for (int p = 1; p < d_nports; p++) nproc = std::min(nproc, ninput_items[p]);
     const uint64_t rd = d_io->nitems_read(0);
-    // A pinned output buffer: the LLR items that are ready start moving FIRST — one kernel that writes them where the scheduler wants
-    // them — and the input work below runs meanwhile; the call waits for them last
+    // A pinned output buffer: the LLR items that are ready start moving — one kernel that writes them where the scheduler wants them —
+    // and are REPORTED by the next call, when the device has had a scheduler round trip to write them (drain_scatter)
     int produced = 0;
-    uint64_t out_mark = 0;
-    if (d_out_dev) produced = drain_scatter(static_cast<float*>(output_items[0]), noutput_items, out_mark);
+    if (d_out_dev) produced = drain_scatter(static_cast<float*>(output_items[0]), noutput_items);
     int used = 0;
     if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
       if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
@@ -509,11 +521,7 @@ public:
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     const bool pending = !d_st[d_fill].pk.empty() || d_st[d_fill ^ 1].ticket != 0;
     if (pending) d_timer.poke();
-    if (d_out_dev) {
-      if (out_mark) { sub_scope w(d_ph, phase_clock::GWAIT); d_eng.check(d_eng.d_api.copy_wait_mark(d_eng.d_ctx, out_mark), "c8p_copy_wait_mark"); }
-      d_hold.clear();
-      return produced;
-    }
+    if (d_out_dev) return produced;
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
@@ -783,33 +791,47 @@ private:
 
   // drain() for a pinned output buffer: the items of every packet that fits go from the front's device copy of the LLR arena into the
   // scheduler's buffer with ONE c8p_copy_gather (device -> pinned host: the shader cores write over PCIe), only the bytes the packets
-  // use (the arena's layout is ~1.8x that), no host copy in between.  mark: what to wait for before the items may be reported
-  int drain_scatter(float* out, int noutput_items, uint64_t& mark)
+  // use (the arena's layout is ~1.8x that), no host copy in between.  The items are written AHEAD: this call places them behind what
+  // earlier calls placed and reports what the PREVIOUS call placed — [0, d_ready) of the space it is given is complete, [d_ready,
+  // d_ready + d_inflight) is being written (d_mark).  A scheduler's output pointer continues where produce() stopped, so the items
+  // of this call are where the next call's space begins (c8p_blocks.h, output_ahead).
+  int drain_scatter(float* out, int noutput_items)
   {
     sub_scope ph(d_ph, phase_clock::DRAIN);
-    int produced = 0;
+    const c8p_api& A = d_eng.d_api;
+    if (d_inflight) {
+      sub_scope w(d_ph, phase_clock::GWAIT);
+      d_eng.check(A.copy_wait_mark(d_eng.d_ctx, d_mark), "c8p_copy_wait_mark");
+      d_ready += d_inflight; d_inflight = 0;
+      d_hold.clear();
+    }
+    size_t pos = d_ready;
     d_opieces.clear();
-    while (!d_outq.empty() && produced < noutput_items) {
+    while (!d_outq.empty() && pos < (size_t)noutput_items) {
       out_pkt& o = d_outq.front();
       if (o.sent == 0)
-        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
-      const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
+        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + pos, kv.first, kv.second);
+      const size_t k = std::min(o.n - o.sent, (size_t)noutput_items - pos);
       if (k && o.llr) {
         c8p_piece pc;
         memset(&pc, 0, sizeof(pc));
-        pc.src = o.llr + o.sent; pc.dst_off = (uint64_t)produced; pc.n = k; pc.trusted = 1; pc.fmt = C8P_FMT_F32; pc.scale = 1.0f;
+        pc.src = o.llr + o.sent; pc.dst_off = (uint64_t)pos; pc.n = k; pc.trusted = 1; pc.fmt = C8P_FMT_F32; pc.scale = 1.0f;
         d_opieces.push_back(pc);
       }
-      o.sent += k; produced += (int)k;
+      o.sent += k; pos += k;
       if (o.sent == o.n) { d_hold.push_back(std::move(o.res)); d_outq.pop_front(); }    // (its arena is being read until the mark)
     }
-    if (!d_opieces.empty()) {
-      const c8p_api& A = d_eng.d_api;
-      d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
-      mark = A.copy_mark(d_eng.d_ctx);
-      if (!mark) throw std::runtime_error("c8p_copy_mark failed");
+    if (pos > d_ready) {
+      if (!d_opieces.empty()) {
+        d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
+        d_mark = A.copy_mark(d_eng.d_ctx);
+        if (!d_mark) throw std::runtime_error("c8p_copy_mark failed");
+        d_inflight = pos - d_ready;
+      } else d_ready = pos;                          // (packets without items: nothing to wait for)
     }
-    return produced;
+    const size_t produced = std::min(d_ready, (size_t)noutput_items);
+    d_ready -= produced;
+    return (int)produced;
   }
 
   enum { S_RDTAG, S_COLLECT } d_state = S_RDTAG;
@@ -825,6 +847,8 @@ private:
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   std::vector<c8p_piece> d_opieces;
+  size_t d_ready = 0, d_inflight = 0;              // drain_scatter: items placed in the output buffer and not reported yet (complete / being written)
+  uint64_t d_mark = 0;                             // ... the copy-stream mark behind the ones being written
   std::vector<std::shared_ptr<result>> d_pool, d_hold;
   std::vector<std::shared_ptr<fused_batch>> d_fpool;
   size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;

@@ -175,6 +175,12 @@ public:
   virtual bool wants_pinned_output(unsigned port) const { return false; }
   virtual void* buffer_alloc(size_t bytes) { return nullptr; }
   virtual void buffer_free(void* p) {}
+  // Items of output port 0 this block has placed in the output buffer BEYOND what it has reported as produced (demod with a pinned
+  // output buffer: the device is still writing them; they are reported by the next call).  They sit at the start of the space the next
+  // call is given — a scheduler's ring continues where the last call's produce() stopped — so whoever moves the block's output
+  // pointer somewhere else (a buffer that is not a ring and has come to its end) first calls general_work with noutput_items = this
+  // number: the block then reports them and places nothing new.
+  virtual int output_ahead() { return 0; }
   void set_io(block_io* io) { d_io = io; }
 
 protected:

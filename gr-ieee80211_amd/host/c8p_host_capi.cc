@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -90,7 +91,8 @@ struct harness : public block_io {
     else if (!b.pinned && b.pos > (1u << 28) && b.pos * 2 > b.size) { memmove(b.p, b.p + b.pos, b.size - b.pos); b.size -= b.pos; b.pos = 0; }
   }
   bool tags_sorted = true;
-  std::vector<tag_t> in_tags;                   // port 0, absolute offsets
+  std::deque<tag_t> in_tags;                    // port 0, absolute offsets; tags of consumed items are dropped (as a scheduler prunes them)
+  void prune_tags() { if (tags_sorted) while (!in_tags.empty() && in_tags.front().offset < n_read) in_tags.pop_front(); }
   uint64_t n_read = 0, n_written = 0;
   int consumed_this_call = 0;
   std::vector<float> out_items;                 // output port 0 (as floats: a complex item is two of them)
@@ -109,6 +111,7 @@ struct harness : public block_io {
   {
     v.clear();
     if (!tags_sorted) { std::stable_sort(in_tags.begin(), in_tags.end(), [](const tag_t& x, const tag_t& y) { return x.offset < y.offset; }); tags_sorted = true; }
+    prune_tags();
     auto it = std::lower_bound(in_tags.begin(), in_tags.end(), a, [](const tag_t& t, uint64_t off) { return t.offset < off; });
     for (; it != in_tags.end() && it->offset < b; ++it) v.push_back(*it);
   }
@@ -239,8 +242,39 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     long calls = 0;
     int idle = 0, starved = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);   // floats per output item (byte items: widened below)
-    harness::obuf_t ob0(h, (size_t)std::max(nout, 1) * fpi), ob1(h, (size_t)std::max(nout, 1) * fpi);
-    float* const obuf = ob0.p; float* const obuf1 = ob1.p;
+    // The output buffer: the pointer a call is given continues where the last call's produce() stopped (a block may have placed items
+    // beyond what it reported: c8p_block::output_ahead); at the end of the buffer the block is first asked for exactly those items
+    const size_t ocap = (size_t)std::max(nout, 1) * fpi * 4;
+    harness::obuf_t ob0(h, ocap), ob1(h, ocap);
+    size_t wpos = 0;
+    auto take = [&](int produced, const float* o0, const float* o1) {
+      if (!h->capture) {
+      } else if (h->out_size == 1) {                                // byte stream: one float per item in the capture
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(o0);
+        for (int i = 0; i < produced; i++) h->out_items.push_back((float)b[i]);
+      } else
+        h->out_items.insert(h->out_items.end(), o0, o0 + (size_t)produced * fpi);
+      if (h->nout == 2 && h->capture) h->out_items1.insert(h->out_items1.end(), o1, o1 + (size_t)produced * fpi);
+      h->n_written += produced;
+      wpos += (size_t)produced * fpi;
+    };
+    auto wrap_if_needed = [&](int want_items) {
+      if (ocap - wpos >= (size_t)want_items * fpi) return;
+      const int ahead = h->blk->output_ahead();
+      if (ahead > 0) {                                              // a call without input and with room for exactly the items under way
+        gr_vector_int nin0(h->nports, 0);
+        gr_vector_const_void_star ins0(h->nports);
+        for (int q = 0; q < h->nports; q++) ins0[q] = h->rd(q);
+        gr_vector_void_star outs0(1, ob0.p + wpos);
+        if (h->nout == 2) outs0.push_back(ob1.p + wpos);
+        h->consumed_this_call = 0;
+        const int produced = h->blk->general_work(ahead, nin0, ins0, outs0);
+        for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
+        h->n_read += h->consumed_this_call;
+        take(produced, ob0.p + wpos, ob1.p + wpos);
+      }
+      wpos = 0;
+    };
     while (idle < 4) {
       size_t avail = h->avail(0);
       for (int q = 1; q < h->nports; q++) avail = std::min(avail, h->avail(q));
@@ -259,6 +293,8 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       }
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
+      wrap_if_needed(std::max(nout, 1));
+      float* const obuf = ob0.p + wpos; float* const obuf1 = ob1.p + wpos;
       gr_vector_void_star outs(1, obuf);
       if (h->nout == 2) outs.push_back(obuf1);
       h->consumed_this_call = 0;
@@ -266,20 +302,14 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       calls++;
       for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
       h->n_read += h->consumed_this_call;
-      if (!h->capture) {
-      } else if (h->out_size == 1) {                                // byte stream: one float per item in the capture
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(obuf);
-        for (int i = 0; i < produced; i++) h->out_items.push_back((float)b[i]);
-      } else
-        h->out_items.insert(h->out_items.end(), obuf, obuf + (size_t)produced * fpi);
-      if (h->nout == 2 && h->capture) h->out_items1.insert(h->out_items1.end(), obuf1, obuf1 + (size_t)produced * fpi);
-      h->n_written += produced;
+      take(produced, obuf, obuf1);
       if (!full) {                                                  // a starved call that got nowhere proves nothing
-        if (produced || h->consumed_this_call) { idle = 0; starved = 0; } else starved++;
+        if (produced || h->consumed_this_call || h->blk->output_ahead()) { idle = 0; starved = 0; } else starved++;
         continue;
       }
       starved = 0;
-      idle = (produced == 0 && h->consumed_this_call == 0) ? idle + 1 : 0;
+      // (a call that only PLACED items in the output buffer — reported by the next one — has made progress)
+      idle = (produced == 0 && h->consumed_this_call == 0 && h->blk->output_ahead() == 0) ? idle + 1 : 0;
       if (idle == 2 && flush_at_end && avail == 0) h->blk->flush();
     }
     return calls;
@@ -337,6 +367,23 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         gr_vector_const_void_star ins(A->nports);
         for (int qq = 0; qq < A->nports; qq++) ins[qq] = A->rd(qq);
         if (cur >= 0 && seg_floats - wpos < (size_t)std::max(nout, 1) * fpi) {     // not a call's worth of space left: the next segment
+          const int ahead = A->blk->output_ahead();                                // (items the block has placed beyond what it reported)
+          if (ahead > 0) {
+            gr_vector_int nin0(A->nports, 0);
+            gr_vector_void_star outs0(1, segs[cur].items + wpos);
+            A->consumed_this_call = 0;
+            const size_t tb = A->out_tags.size();
+            const int produced = A->blk->general_work(ahead, nin0, ins, outs0);
+            calls_a++;
+            for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
+            A->n_read += A->consumed_this_call;
+            A->n_written += produced;
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t k = tb; k < A->out_tags.size(); k++) tagq.push_back(std::move(A->out_tags[k]));
+            A->out_tags.resize(tb);
+            wpos += (size_t)produced * fpi;
+            segs[cur].n = wpos;
+          }
           { std::lock_guard<std::mutex> g(mu); segs[cur].closed = true; }
           cv.notify_all();
           cur = -1;
@@ -370,7 +417,7 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
           segs[cur].n = wpos;
         }
         if (produced > 0) cv.notify_all();
-        idle = (produced == 0 && A->consumed_this_call == 0) ? idle + 1 : 0;
+        idle = (produced == 0 && A->consumed_this_call == 0 && A->blk->output_ahead() == 0) ? idle + 1 : 0;
         if (idle == 2 && avail == 0) A->blk->flush();
       }
       if (cur >= 0) { std::lock_guard<std::mutex> g(mu); segs[cur].closed = true; }
@@ -402,11 +449,12 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
               cv.notify_all();
               continue;
             }
-            // something to offer: new items, or items B has looked at but not let go of yet (a deferred consume: the next call settles it)
-            if (n_avail > 0 && (segs[cur].n > seen || fruitless < 2)) break;
+            // something to offer: new items, or items B has looked at but not let go of yet (a deferred consume: calls that bring new
+            // items may consume nothing — the block lets go of items two calls late — and the first call without new ones settles it all)
+            if (n_avail > 0 && (segs[cur].n > seen || fruitless < 4)) break;
           }
           if (a_done && filled.empty()) { fin = true; break; }
-          if (a_done && cur >= 0 && fruitless >= 2) { fin = true; break; }          // (never: a block that sits on items it will not consume)
+          if (a_done && cur >= 0 && fruitless >= 4) { fin = true; break; }          // (never: a block that sits on items it will not consume)
           const clk::time_point tw = clk::now();
           cv.wait(lk);
           b_wait += secs(tw, clk::now());
@@ -443,7 +491,8 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   ta.join();
   if (tlog)
     fprintf(stderr, "[c8ph_run_chain] A: %ld calls, %.2f ms in general_work, %.2f ms waiting for a segment, %.2f ms all | B: %ld calls, %.2f ms in general_work, "
-            "%.2f ms waiting for items, %.2f ms all\n", calls_a, 1e3 * a_work, 1e3 * a_wait, 1e3 * a_all, calls_b, 1e3 * b_work, 1e3 * b_wait, 1e3 * b_all);
+            "%.2f ms waiting for items, %.2f ms all | items written %llu read %llu\n", calls_a, 1e3 * a_work, 1e3 * a_wait, 1e3 * a_all, calls_b, 1e3 * b_work, 1e3 * b_wait, 1e3 * b_all,
+            (unsigned long long)A->n_written, (unsigned long long)B->n_read);
   return failed ? -1 : calls_a + calls_b;
 }
 
@@ -457,8 +506,9 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
   try {
     long calls = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);
-    harness::obuf_t ob0(h, (size_t)std::max(nout, 1) * fpi), ob1(h, (size_t)std::max(nout, 1) * fpi);
-    float* const obuf = ob0.p; float* const obuf1 = ob1.p;
+    const size_t ocap = (size_t)std::max(nout, 1) * fpi * 4;      // the output pointer continues where produce() stopped (see c8ph_run)
+    harness::obuf_t ob0(h, ocap), ob1(h, ocap);
+    size_t wpos = 0;
     const auto t_end_idle = std::chrono::milliseconds(linger_ms);
     auto idle_since = std::chrono::steady_clock::now();
     for (;;) {
@@ -483,10 +533,17 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
       gr_vector_int nin(h->nports, n);
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
+      int nout_call = nout;
+      if (ocap - wpos < (size_t)std::max(nout, 1) * fpi) {        // the end of the buffer: first the items the block has placed ahead, alone
+        const int ahead = h->blk->output_ahead();
+        if (ahead > 0) { nout_call = ahead; for (int q = 0; q < h->nports; q++) nin[q] = 0; }
+        else wpos = 0;
+      }
+      float* const obuf = ob0.p + wpos; float* const obuf1 = ob1.p + wpos;
       gr_vector_void_star outs(1, obuf);
       if (h->nout == 2) outs.push_back(obuf1);
       h->consumed_this_call = 0;
-      const int produced = h->blk->general_work(nout, nin, ins, outs);
+      const int produced = h->blk->general_work(nout_call, nin, ins, outs);
       calls++;
       for (int q = 0; q < h->nports; q++) h->advance(q, (size_t)h->consumed_this_call);
       h->n_read += h->consumed_this_call;
@@ -495,6 +552,7 @@ long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
         if (h->nout == 2) h->out_items1.insert(h->out_items1.end(), obuf1, obuf1 + (size_t)produced * fpi);
       }
       h->n_written += produced;
+      wpos += (size_t)produced * fpi;
       if (produced || h->consumed_this_call) idle_since = std::chrono::steady_clock::now();
       else if (want == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (asked for a call and did nothing: do not spin)
     }

@@ -247,6 +247,14 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     pr = j["per_rank_packets_per_s"]
     assert len(pr["values"]) == 2 and pr["min"] == min(pr["values"]) > 0 and pr["values"][0] > pr["values"][1]       # (rank 1 sleeps twice as long)
     assert j["ms_per_step"] >= 1e3 * 4096 / pr["min"] * 0.99                                                          # the slowest rank sets the time
+    # round 5: every rank reports where its host side runs (hostbind.bind_rank: the GPU's NUMA node, or that there is none to find) and
+    # that ONE HIP runtime is mapped; the live leg's streams are partitioned over the ranks as shard.LiveShard does; the line still says
+    # that nothing was measured
+    hb = j["host_binding"]
+    assert [b["rank"] for b in hb] == [0, 1] and all("numa_node" in b and "affinity" in b and len(b["hip_runtimes_mapped"]) <= 1 for b in hb)
+    mg = j["multi_gpu_host_fed"]
+    assert mg["dry"] is True and "UNMEASURED" in mg["note"]
+    assert [r["live_streams"]["global_streams"] for r in mg["per_rank"]] == [[0, 64, 128], [64, 128, 128]]
 
 
 def test_bench_refuses_a_world_that_is_not_what_was_asked_for():
