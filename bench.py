@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 B_ALG = 8 * 4400 + 512 + 32 + 1462       # algorithmic bytes per packet, SURVEY.md §8(d) = 37 206
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PROFILE_EVERY = 4                        # c8p_cfg.profile: sample the per-kernel HIP events on every 4th submit
+# The committed rocprofv3 profile the line's counter-derived figures come from (roofline.traffic, roofline_valu.counters, the opcode
+# costs): ONE directory, named here and in the line — taken with tools/profile_gpu.sh + tools/summarize_prof.py on the code as it is.
+PROFILE_TAG = os.environ.get("C8P_PROFILE_TAG", "r5p")
 
 
 def main():
@@ -273,6 +276,7 @@ def main():
             # SIMD finishing staggered) takes longer than a pipelined step, so it is a latency, not a per-step cost (frac_exclusive)
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved_step, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_step / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "profile": "profiles/" + PROFILE_TAG, "residency_3slots": residency_3slots(),
                          "traffic_whole_step": traffic_step,
                          "frac_step": achieved_step / HBM_PEAK_GBS, "achieved_step": achieved_step,
                          "frac_exclusive": achieved / HBM_PEAK_GBS, "achieved_exclusive": achieved,
@@ -341,7 +345,9 @@ def main():
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
             if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
-            r = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected))
+            r = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected))                     # the blocks' own (pinned) buffers
+            r64 = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
+            rpg = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
             try:
                 out["block_rx_chain"] = bb.rx_chain_rate(local=local)
                 out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
@@ -352,6 +358,14 @@ def main():
                 out["block_rx_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
             out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
+            out["block_chain_variants"] = {
+                "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"]},
+                "sched64k_pinned": {"items_per_call": r64["items_per_call"], "chain": r64["chain_packets_per_s"], "chain_fused": r64["chain_fused_packets_per_s"]},
+                "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
+                                      "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},
+                "note": "block_chain_* (and legs.block_chain / block_fused) = custom_buffers: the edge buffers are allocated through the mirrors' buffer type "
+                        "(GNU Radio 3.10 custom buffers: pinned host memory, 8 MB per edge, a call sees half), the packets are gathered out of them by the "
+                        "device and demod's LLR items are written into them by the device"}
             out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
             out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
             out["host_phase_us"] = {"chain": r.get("chain_host_phase_us_per_packet"), "chain_fused": r.get("chain_fused_host_phase_us_per_packet"),
@@ -997,20 +1011,23 @@ def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
     finish one after the other and the last runs alone, latency-bound (profiles/r2b/decoder_wave_cycles.txt: 27 SIMD cycles per
     wave-step at 4 waves, 24 at 8 waves, against 21.7 from the opcode costs) — the exclusive launch cannot reach the ceiling, the
     pipelined step (other batches fill the tail) is what `value` measures."""
-    import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "opcode_costs.json")))
-    if not fs or kern_x.get("viterbi_fwd", 0) <= 0:
+    pdir = os.path.join(ROOT, "profiles", PROFILE_TAG)
+    f_cost, f_pmc = os.path.join(pdir, "opcode_costs.json"), os.path.join(pdir, "pmc_hbm.json")
+    if not os.path.exists(f_cost) or kern_x.get("viterbi_fwd", 0) <= 0:
         return None
-    cost = json.load(open(fs[-1]))["lean_step_opcodes"]
+    cost = json.load(open(f_cost))["lean_step_opcodes"]
     mix = lean_step_mix(T, float_frac)
     dec_instr = sum(mix.values()) * n_pkt
     cycles = sum(mix[k] * cost[k] for k in mix) * n_pkt            # SIMD-cycles summed over the chip
-    other, other_src = 0.0, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm.json"))):
-        ks = json.load(open(f))["kernels"]
-        k = ks.get("k_rx_1ss_lds") or ks.get("k_rx_1ss")
+    other, other_src, busy = 0.0, None, None
+    if os.path.exists(f_pmc):
+        k = json.load(open(f_pmc))["kernels"].get("k_rx_1ss_lds")
         if k and k.get("sq_insts_valu"):
-            other, other_src = max(0.0, k["sq_insts_valu"] * n_pkt / 4096.0 - dec_instr), os.path.relpath(f, ROOT)
+            other, other_src = max(0.0, k["sq_insts_valu"] * n_pkt / 4096.0 - dec_instr), os.path.relpath(f_pmc, ROOT)
+            if k.get("valu_busy"):
+                busy = {"valu_busy": k["valu_busy"], "sq_active_inst_valu_quad_cycles": k.get("sq_active_inst_valu"), "grbm_gui_active_cycles_8xcd": k.get("grbm_gui_active"),
+                        "formula": "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), averages per launch of the PMC passes (C8P_SLOTS=1)",
+                        "source": os.path.relpath(f_pmc, ROOT) + " (= " + os.path.relpath(os.path.join(pdir, "pmc_summary.txt"), ROOT) + ")"}
     cycles += other * 4.15
     n_simd, clk = 256 * 4, 2.4e9
     ceiling_ms = cycles / n_simd / clk * 1e3
@@ -1021,7 +1038,18 @@ def valu_roofline(kern_x, n_pkt, float_frac, T=11960):
             "forward_pass_issue_cycles_per_step": sum(mix[k] * cost[k] for k in mix) / T, "float_step_block_fraction": float_frac,
             "other_instr_per_launch": other, "other_instr_source": other_src,
             "achieved_G_wave_instr_per_s": (dec_instr + other) / (dur_ms * 1e-3) / 1e9,
-            "source": os.path.relpath(fs[-1], ROOT) + " (measured cycles per opcode) x lean_step_mix(); nominal 2.4 GHz"}
+            "counters": busy,
+            "source": os.path.relpath(f_cost, ROOT) + " (measured cycles per opcode, tools/probe_issue.hip on the box that took the profile) x lean_step_mix(); nominal 2.4 GHz"}
+
+
+def residency_3slots():
+    """the dominant kernel as the bench runs it (three slots): profiles/<tag>/residency_3slots.json from the kernel trace"""
+    f = os.path.join(ROOT, "profiles", PROFILE_TAG, "residency_3slots.json")
+    if not os.path.exists(f):
+        return None
+    r = json.load(open(f))
+    r["file"] = os.path.relpath(f, ROOT)
+    return r
 
 
 def pmc_traffic(dom):
@@ -1032,13 +1060,8 @@ def pmc_traffic(dom):
     64-byte requests and counted in full, so that kernel = FETCH_SIZE as reported + half of the sample bytes.  The whole step also
     counts the second, nearly empty launch of k_rx_1ss (only_flagged) and k_viterbi_fwd.  See DESIGN.md §7."""
     names = {"viterbi_fwd": "k_rx_1ss_lds", "finish": "k_finish", "classify": "k_classify"}
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, d, "pmc_hbm.json")
-        if os.path.exists(f):
-            best = f
-    if not best:
+    best = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_hbm.json")
+    if not os.path.exists(best):
         return None, None, None
     j = json.load(open(best))
 
@@ -1251,7 +1274,7 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
         pin.copy_(arr.keepalive)
         torch.cuda.synchronize(dev)
         # 40 segments: with 12 the steady window is 8 completions long and they come in bunches — 55-70 GB/s "over PCIe" from run to run
-        # (tools/rawchain_pcie.py); 36 completions give 47-49 GB/s every time, and the whole run with its fill 45-47
+        # (tools/probes/rawchain_pcie.py); 36 completions give 47-49 GB/s every time, and the whole run with its fill 45-47
         hs = [(pin.data_ptr(), n)] * 40
         h.run(hs[:3], host=True)
         t_run = time.perf_counter()

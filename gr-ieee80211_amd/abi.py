@@ -111,6 +111,10 @@ class Piece(C.Structure):
                 ("scale", C.c_float), ("rsv", C.c_uint32)]
 
 
+class FetchPiece(C.Structure):
+    _fields_ = [("which", C.c_int32), ("rsv", C.c_uint32), ("offset", C.c_uint64), ("bytes", C.c_uint64), ("dst", C.c_void_p)]
+
+
 CNT_ARENA_GROWTHS, CNT_ARENA_BYTES, CNT_HOST_BYTES, CNT_DET_GIVEUPS, CNT_DET_TICKET_SCANS, CNT_SLOTS, CNT_SUBMITS, CNT_DET_TILE = range(8)
 
 

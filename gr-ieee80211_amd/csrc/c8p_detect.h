@@ -17,7 +17,7 @@
 
 #ifndef C8P_DET_THREADS
 #define C8P_DET_THREADS 128         // threads of a scan workgroup = blocks of 8 samples it loads (the first 8 of them are history).
-                                    // 256 until round 4; measured per 33.5 M items, packets / noise (tools/ab_scan.sh, profiles/r4a):
+                                    // 256 until round 4; measured per 33.5 M items, packets / noise (tools/probes/ab_scan.sh, profiles/r4a):
                                     // 128: 81.0 / 67.0 us, 192: 82.5 / 66.7, 256: 84.0 / 66.6, 512: 112.7 / 80.4 — with two waves per
                                     // workgroup a plateau drags one other wave through the heavy path instead of three
 #endif

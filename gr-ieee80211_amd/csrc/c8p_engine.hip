@@ -1974,6 +1974,34 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
+// Result arenas to host (or device) memory with one launch on the selected submit's own stream, behind its kernels: the pieces' sources
+// are the slot's arenas, the destination offsets are taken from address 0 (k_copy_gather_w adds word offsets to its base pointer).
+extern "C" int c8p_fetch_gather(c8p_ctx* c, const c8p_fetch_piece* pieces, int32_t n)
+{
+  if (!c || n < 0 || (n > 0 && !pieces)) return C8P_EINVAL;
+  if (n > C8P_GATHER_INLINE) { c->err = "c8p_fetch_gather: more than C8P_GATHER_INLINE pieces"; return C8P_EINVAL; }
+  HIPCHK(c, hipSetDevice(c->device));
+  PieceTab tab;
+  memset(&tab, 0, sizeof(tab));
+  unsigned long long total = 0;
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const c8p_fetch_piece& f = pieces[i];
+    if (f.which < 0 || f.which >= C8P_BUF_COUNT || (f.bytes && !f.dst)) { c->err = "c8p_fetch_gather: bad piece"; return C8P_EINVAL; }
+    if (f.offset + f.bytes > c->s->used[f.which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
+    if ((f.offset | f.bytes | (uint64_t)(uintptr_t)f.dst) & 3u) { c->err = "c8p_fetch_gather: offset, bytes and dst must be multiples of 4"; return C8P_EINVAL; }
+    if (!f.bytes) continue;
+    PieceDev& P = tab.p[m++];
+    P.src = (const cf*)((const char*)c->s->ptr[f.which] + f.offset);
+    P.dst_off = (unsigned long long)(uintptr_t)f.dst / 4u; P.n = f.bytes / 4u; P.first = total; P.scale = 1.0f; P.rsv = 0;
+    total += (P.n + 3 + (((uintptr_t)P.src >> 2) & 3u)) / 4;
+  }
+  if (!total) return C8P_OK;
+  const dim3 grid((unsigned)std::min<unsigned long long>((total + 1023) / 1024, 256ull));
+  hipLaunchKernelGGL(k_copy_gather_w, grid, dim3(256), 0, c->s->stream, (unsigned*)nullptr, (const PieceDev*)nullptr, tab, m, total);
+  HIPCHK(c, hipGetLastError());
+  return C8P_OK;
+}
 extern "C" int c8p_copy_fence(c8p_ctx* c)
 {
   if (!c) return C8P_EINVAL;
@@ -2053,7 +2081,7 @@ extern "C" int c8p_abi_sizes(int32_t* dst, int cap)
                        (int32_t)sizeof(c8p_detect_in), (int32_t)sizeof(c8p_det_state), (int32_t)sizeof(c8p_tx_pkt),
                        (int32_t)sizeof(c8p_tx_desc), (int32_t)sizeof(c8p_tx_in), (int32_t)sizeof(c8p_tx_plan), (int32_t)sizeof(c8p_tx_mu),
                        (int32_t)sizeof(c8p_det_stream), (int32_t)sizeof(c8p_detect_multi_in), (int32_t)sizeof(c8p_reserve_in), (int32_t)sizeof(c8p_span),
-                       (int32_t)sizeof(c8p_piece)};
-  for (int i = 0; i < 22 && i < cap; i++) dst[i] = v[i];
-  return 22;
+                       (int32_t)sizeof(c8p_piece), (int32_t)sizeof(c8p_fetch_piece)};
+  for (int i = 0; i < 23 && i < cap; i++) dst[i] = v[i];
+  return 23;
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_finish(const c8p_pkt_tags* __restrict__ 
   static_assert(C8P_TB_SEGS % 4 == 0 && C8P_TB_SEGS <= 64, "the tile is fetched four rows per instruction");
   const int p = blockIdx.x;
   if (p >= n) return;
-#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)   // experiment build (tools/exp_finclock.py): shader cycles per phase of this wave instead of the results
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_FINCLOCK)   // experiment build (tools/probes/exp_finclock.py): shader cycles per phase of this wave instead of the results
   const unsigned long long exp_t0 = clock64();
   unsigned long long exp_t1 = exp_t0, exp_t2 = exp_t0, exp_t3 = exp_t0;
 #endif

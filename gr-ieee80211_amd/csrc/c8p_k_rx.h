@@ -8,7 +8,7 @@
 // area and right away runs the survivor blocks whose LLRs are complete, reading them back through the scalar cache.  k_demod_sym's
 // 46 short waves per packet (and their launch) disappear, the next symbol's samples are in flight while the current one is decoded,
 // and the decoder never waits for HBM: +3 % packets/s over the two kernels.  What it does NOT do on this part is save
-// HBM reads: tools/probe_l2rw.hip shows that a read of a line the same wave just wrote is a TCC hit and still an EA read request
+// HBM reads: tools/probes/probe_l2rw.hip shows that a read of a line the same wave just wrote is a TCC hit and still an EA read request
 // (FETCH_SIZE counts it) — keeping the LLRs out of the memory counters would take an LDS ring and VGPR-fed LLRs.
 // (demod_impl.cc:279-314 -> decode_impl.cc:128-141, 205-281.)
 // Scalar-cache coherence: a 64-byte line is only ever read when all of it has been written (`safe` below) and waited for
@@ -143,7 +143,7 @@ __device__ __forceinline__ void lds_tap(float* __restrict__ dst, const float* sr
 // The wave scatters a symbol's de-interleaved LLRs into its own LDS buffer (behind what the last round left over), runs every
 // survivor block that is complete with the LLRs as VGPR operands (lean_blocks_lds: broadcast ds_read_b128 into a rotating set of 12
 // registers that only exist inside the block loop) and moves the < 60 left-over LLRs to the front.  Neither the 235 MB of LLR
-// stores nor their read-back (an EA read even when it hits L2, tools/probe_l2rw.hip) exist any more: 1.58 -> 1.1 GB per
+// stores nor their read-back (an EA read even when it hits L2, tools/probes/probe_l2rw.hip) exist any more: 1.58 -> 1.1 GB per
 // 4096-packet step.  Buffer (C8P_LBUF floats): 59 left over + two 64-QAM symbols (one 256-QAM symbol = 416 LLRs).  A packet with an LLR outside the integer
 // loop's range is rare: the wave flags it and stops; k_finish demodulates a flagged packet into the LLR arena (redemod_packet), runs the
 // clamp-exact forward pass and goes on with its traceback.  Symbols that only carry padding behind the last trellis step are not demodulated at all.

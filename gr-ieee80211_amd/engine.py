@@ -19,7 +19,7 @@ SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_deco
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
            "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait", "c8p_done",
            "c8p_host_alloc", "c8p_host_free", "c8p_selftest", "c8p_detect_multi", "c8p_reserve", "c8p_counter",
-           "c8p_dev_alloc", "c8p_dev_free", "c8p_copy_async", "c8p_copy_spans", "c8p_copy_wait", "c8p_copy_mark", "c8p_copy_wait_mark", "c8p_copy_gather", "c8p_copy_fence"]
+           "c8p_dev_alloc", "c8p_dev_free", "c8p_copy_async", "c8p_copy_spans", "c8p_copy_wait", "c8p_copy_mark", "c8p_copy_wait_mark", "c8p_copy_gather", "c8p_copy_fence", "c8p_fetch_gather"]
 
 _LIB = None
 
@@ -84,6 +84,7 @@ def load_library():
     L.c8p_copy_mark.argtypes = [C.c_void_p]
     L.c8p_copy_wait_mark.argtypes = [C.c_void_p, C.c_uint64]
     L.c8p_copy_fence.argtypes = [C.c_void_p]
+    L.c8p_fetch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.c8p_tx.argtypes = [C.c_void_p, C.POINTER(abi.TxIn)]
     L.c8p_tx_plan_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
     L.c8p_tx_plan_mu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.TxPlan)]
@@ -104,13 +105,13 @@ def load_library():
     L.c8p_profile_reset.argtypes = [C.c_void_p]
     L.c8p_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.c8p_abi_sizes.argtypes = [C.c_void_p, C.c_int]
-    sizes = np.zeros(22, np.int32)
-    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 22)
+    sizes = np.zeros(23, np.int32)
+    L.c8p_abi_sizes(sizes.ctypes.data_as(C.c_void_p), 23)
     want = [abi.ABI_VERSION, C.sizeof(abi.PktIn), C.sizeof(abi.PktTags), C.sizeof(abi.PktOut), C.sizeof(abi.Cfg),
             C.sizeof(abi.BatchIn), C.sizeof(abi.DecodeIn), C.sizeof(abi.SigIn), C.sizeof(abi.SignalIn),
             C.sizeof(abi.SyncEvt), C.sizeof(abi.DetectIn), C.sizeof(abi.DetState), C.sizeof(abi.TxPkt), C.sizeof(abi.TxDesc),
             C.sizeof(abi.TxIn), C.sizeof(abi.TxPlan), C.sizeof(abi.TxMu), C.sizeof(abi.DetStream), C.sizeof(abi.DetectMultiIn),
-            C.sizeof(abi.ReserveIn), C.sizeof(abi.Span), C.sizeof(abi.Piece)]
+            C.sizeof(abi.ReserveIn), C.sizeof(abi.Span), C.sizeof(abi.Piece), C.sizeof(abi.FetchPiece)]
     if list(sizes) != want:
         raise RuntimeError("ABI mismatch between abi.py and libc8p_rx.so: %s vs %s" % (list(sizes), want))
     _LIB = L

@@ -69,6 +69,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.copy_mark = (uint64_t (*)(c8p_ctx*))sym("c8p_copy_mark");
   a.copy_wait_mark = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_wait_mark");
   a.copy_fence = (int (*)(c8p_ctx*))sym("c8p_copy_fence");
+  a.fetch_gather = (int (*)(c8p_ctx*, const c8p_fetch_piece*, int32_t))sym("c8p_fetch_gather");
   return a;
 }
 
@@ -364,6 +365,19 @@ struct gather_lane {
   enum { DEPTH = 2 };
   struct pend_t { uint64_t mark, scan; };
   std::deque<pend_t> pend;
+  // How far this call looks.  A scheduler offers a block everything its input buffer holds; a front that cut all of it at once would then
+  // find nothing new in the next call and could only wait for its own gather.  With deferred consume it takes a THIRD of the largest
+  // window it has been offered per call: two gathers are on their way while the third of the buffer they have left is refilled —
+  // the upstream block writes, this one cuts, the device copies, all at once.  (A window too small for that — under ~3 x 20 us of items —
+  // just runs at the gathers' latency.)
+  int hwm_window = 0;
+  int cap_window(engine_holder& E, int used, int nproc)
+  {
+    hwm_window = std::max(hwm_window, nproc);
+    if (!E.d_cfg.defer_consume) return nproc;
+    const int third = std::max(hwm_window / 3, 4096);
+    return std::min(nproc, used + third);
+  }
   void add(const void* src, uint64_t dst_off, uint64_t n, uint32_t fmt)
   {
     if (!n) return;
@@ -473,6 +487,7 @@ public:
       if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
       used = (int)std::min<uint64_t>(d_lane.scan_abs - rd, (uint64_t)nproc);
     }
+    nproc = d_lane.cap_window(d_eng, used, nproc);
     d_tc.load(d_io, rd + (uint64_t)used, rd + (uint64_t)nproc);
     while (used < nproc) {
       if (d_state == S_RDTAG) {
@@ -481,15 +496,23 @@ public:
         if (!d_tc.at(rd + (uint64_t)used, rd + (uint64_t)nproc, tg, next)) { used = (int)(next - rd); continue; }   // the reference would wait here forever; we resynchronise
         stage& st = d_st[d_fill];
         memset(&d_cur, 0, sizeof(d_cur));
-        d_cur.cfo = tg.get_float("cfo", 0.f); d_cur.snr = tg.get_float("snr", 0.f); d_cur.rssi = tg.get_float("rssi", 0.f);
-        d_cur.seq = (int32_t)tg.get_long("seq", -1);
-        d_cur.lsig_mcs = (int32_t)tg.get_long("mcs", -1);
-        d_cur.lsig_len = (int32_t)tg.get_long("len", -1);
-        d_cur.lsig_nsamp = (int32_t)tg.get_long("nsamp", -1);
+        d_cur.seq = d_cur.lsig_mcs = d_cur.lsig_len = d_cur.lsig_nsamp = -1;
+        const tag_value* ch = nullptr;
+        for (const tag_t* t = tg.first; t != tg.last; ++t) {        // one pass over the item's tags (signal_impl.cc:135-143 writes eight)
+          const std::string& k = t->key;
+          const tag_value& v = t->value;
+          if (k == "cfo") d_cur.cfo = v.as_float();
+          else if (k == "snr") d_cur.snr = v.as_float();
+          else if (k == "rssi") d_cur.rssi = v.as_float();
+          else if (k == "seq") d_cur.seq = (int32_t)v.as_long();
+          else if (k == "mcs") d_cur.lsig_mcs = (int32_t)v.as_long();
+          else if (k == "len") d_cur.lsig_len = (int32_t)v.as_long();
+          else if (k == "nsamp") d_cur.lsig_nsamp = (int32_t)v.as_long();
+          else if (k == "chan") ch = &v;
+        }
         d_cur.n_ant = (uint8_t)d_nports; d_cur.mupos = (uint8_t)(d_mupos ? 1 : 0);
         d_cur.n_items = (uint32_t)std::max(d_cur.lsig_nsamp, 0) + 320u;     // demod_impl.cc:92
         d_cur.chan_off = (uint32_t)st.chan.size();
-        const tag_value* ch = tg.find("chan");
         gr_complex* c = st.chan.grow(64);
         for (int i = 0; i < 64; i++) c[i] = ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f);
         for (int p = 0; p < d_nports; p++) d_cur.iq_off[p] = iq_alloc(st, d_cur.n_items);
@@ -674,8 +697,18 @@ private:
     st.t_submit = now_tick();
     {
       sub_scope phq(d_ph, phase_clock::ENQ);
+      // the batch's downloads — tags; fused mode: per-packet results + the PDU arena — with ONE launch behind its kernels
+      // (c8p_fetch_gather: the device writes the pinned buffers; three hipMemcpyAsync cost 15 us of this thread per batch, and on some
+      // boxes the first of them ~0.1 ms); collect() only waits
       st.tags.resize_uninit(st.pk.size());
-      d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_TAGS, st.tags.data(), 0, st.pk.size() * sizeof(c8p_pkt_tags)), "tags");
+      c8p_fetch_piece fp[3];
+      int nfp = 0;
+      auto piece = [&](int which, void* dst, uint64_t bytes) {
+        c8p_fetch_piece& f = fp[nfp++];
+        memset(&f, 0, sizeof(f));
+        f.which = which; f.offset = 0; f.bytes = bytes; f.dst = dst;
+      };
+      piece(C8P_BUF_TAGS, st.tags.data(), st.pk.size() * sizeof(c8p_pkt_tags));
       uint64_t bytes = 0, pbytes = 0;
       {
         sub_scope pha(d_ph, phase_clock::ALLOC);
@@ -692,10 +725,11 @@ private:
         // to the host (a pageable output buffer: drain() copies the packets' items out of it) or into a device buffer of this front
         // (a pinned one: drain_scatter() moves the items from there, however long the scheduler takes to offer the space)
         if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, d_out_dev ? st.res->dev_llr.p : (void*)st.res->llr.data(), 0, bytes), "llr");
-      } else {                        // fused: the decoded results, enqueued behind the kernels like the tags (collect() only waits)
-        d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.fb->outs.data(), 0, st.pk.size() * sizeof(c8p_pkt_out)), "outs");
-        if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.fb->pdu.data(), 0, pbytes), "pdu");
+      } else {
+        piece(C8P_BUF_OUT, st.fb->outs.data(), st.pk.size() * sizeof(c8p_pkt_out));
+        if (pbytes) piece(C8P_BUF_PDU, st.fb->pdu.data(), pbytes & ~(uint64_t)3);
       }
+      d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, nfp), "c8p_fetch_gather");
     }
     ph.end();
     stage& prev = d_st[d_fill ^ 1];
@@ -1153,13 +1187,14 @@ public:
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     if (!d_mode_known) { d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0); d_mode_known = true; }
     const float* in = static_cast<const float*>(input_items[0]);
-    const int nproc = ninput_items[0];
+    int nproc = ninput_items[0];
     const uint64_t rd = d_io->nitems_read(0);
     int used = 0;
     if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
       if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
       used = (int)std::min<uint64_t>(d_lane.scan_abs - rd, (uint64_t)nproc);
     }
+    nproc = d_lane.cap_window(d_eng, used, nproc);
     d_tc.load(d_io, rd + (uint64_t)used, rd + (uint64_t)nproc);
     while (used < nproc) {
       if (d_state == S_IDLE) {
@@ -1169,17 +1204,30 @@ public:
         stage& st = d_st[d_fill];
         memset(&d_cur, 0, sizeof(d_cur));
         d_cur.status = C8P_ST_OK;
-        d_cur.format = (int32_t)tg.get_long("format", 99999); d_cur.len = (int32_t)tg.get_long("len", 99999);
-        d_cur.total = (int32_t)tg.get_long("total", 99999); d_cur.cr = (int32_t)tg.get_long("cr", 99999);
-        d_cur.mcs = (int32_t)tg.get_long("mcs", 99999); d_cur.ampdu = (int32_t)tg.get_long("ampdu", 99999);
-        d_cur.trellis = (int32_t)tg.get_long("trellis", 99999);
-        d_cur.cfo = tg.get_float("cfo", 0.f); d_cur.snr = tg.get_float("snr", 0.f); d_cur.rssi = tg.get_float("rssi", 0.f);
-        d_cur.sssnr0 = tg.get_float("sssnr0", 0.f); d_cur.sssnr1 = tg.get_float("sssnr1", 0.f);
+        d_cur.format = d_cur.len = d_cur.total = d_cur.cr = d_cur.mcs = d_cur.ampdu = d_cur.trellis = 99999;
+        d_cur_fused = -1;
+        const tag_value* mu = nullptr;
+        for (const tag_t* t = tg.first; t != tg.last; ++t) {        // one pass over the item's tags (demod_impl.cc:224-253 writes up to fourteen)
+          const std::string& k = t->key;
+          const tag_value& v = t->value;
+          if (k == "format") d_cur.format = (int32_t)v.as_long();
+          else if (k == "len") d_cur.len = (int32_t)v.as_long();
+          else if (k == "total") d_cur.total = (int32_t)v.as_long();
+          else if (k == "cr") d_cur.cr = (int32_t)v.as_long();
+          else if (k == "mcs") d_cur.mcs = (int32_t)v.as_long();
+          else if (k == "ampdu") d_cur.ampdu = (int32_t)v.as_long();
+          else if (k == "trellis") d_cur.trellis = (int32_t)v.as_long();
+          else if (k == "cfo") d_cur.cfo = v.as_float();
+          else if (k == "snr") d_cur.snr = v.as_float();
+          else if (k == "rssi") d_cur.rssi = v.as_float();
+          else if (k == "sssnr0") d_cur.sssnr0 = v.as_float();
+          else if (k == "sssnr1") d_cur.sssnr1 = v.as_float();
+          else if (k == "c8p_fused") d_cur_fused = v.as_long();
+          else if (k == "mu2x1chan") mu = &v;
+        }
         d_cur.is_ndp = d_cur.trellis == 0;
-        d_cur_fused = tg.get_long("c8p_fused", -1);
         if (d_cur_fused < 0) {
           d_cur.llr_off = llr_alloc(st, (size_t)std::max(d_cur.total, 0));
-          const tag_value* mu = tg.find("mu2x1chan");
           d_cur_mu = mu != nullptr;
           if (mu) st.any_mu = true;
           for (int i = 0; i < 128; i++) st.mu.push_back(mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f));
@@ -1325,8 +1373,11 @@ private:
       st.pdu.reserve(d_hwm_pdu);
       st.outs.resize_uninit(st.tags.size());
       st.pdu.resize_uninit(pbytes);
-      d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_OUT, st.outs.data(), 0, st.tags.size() * sizeof(c8p_pkt_out)), "outs");
-      if (pbytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_PDU, st.pdu.data(), 0, pbytes), "pdu");
+      c8p_fetch_piece fp[2];                       // results + PDU arena with one launch behind the kernels (see demod_front::submit)
+      memset(fp, 0, sizeof(fp));
+      fp[0].which = C8P_BUF_OUT; fp[0].bytes = st.tags.size() * sizeof(c8p_pkt_out); fp[0].dst = st.outs.data();
+      fp[1].which = C8P_BUF_PDU; fp[1].bytes = pbytes & ~(uint64_t)3; fp[1].dst = st.pdu.data();
+      d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, pbytes ? 2 : 1), "c8p_fetch_gather");
     }
     stage& prev = d_st[d_fill ^ 1];
     if (prev.ticket) collect(prev);

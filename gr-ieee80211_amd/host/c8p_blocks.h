@@ -50,6 +50,8 @@ struct tag_value {
   long l = 0;
   float f = 0.f;
   std::vector<gr_complex> v;
+  long as_long() const { return kind == FLOAT ? (long)f : l; }
+  float as_float() const { return kind == LONG ? (float)l : f; }
   static tag_value from_long(long x) { tag_value t; t.kind = LONG; t.l = x; return t; }
   static tag_value from_float(float x) { tag_value t; t.kind = FLOAT; t.f = x; return t; }
   static tag_value from_c32vector(const std::vector<gr_complex>& x) { tag_value t; t.kind = C32VECTOR; t.v = x; return t; }
@@ -126,6 +128,7 @@ struct c8p_api {
   uint64_t (*copy_mark)(c8p_ctx*);
   int (*copy_wait_mark)(c8p_ctx*, uint64_t);
   int (*copy_fence)(c8p_ctx*);
+  int (*fetch_gather)(c8p_ctx*, const c8p_fetch_piece*, int32_t);
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define C8P_ABI_VERSION 4   /* 3: c8p_sig_in.stream, c8p_signal_in.n_streams / scan_from_v, C8P_BUF_DET_RAW, c8p_detect_multi, c8p_reserve, c8p_counter, c8p_dev_*
-                               4: C8P_FMT_F32 pieces, c8p_copy_gather towards host memory, c8p_copy_fence, C8P_ENOTDEV */
+                               4: C8P_FMT_F32 pieces, c8p_copy_gather towards host memory, c8p_copy_fence, c8p_fetch_gather, C8P_ENOTDEV */
 
 /* return codes */
 #define C8P_OK          0
@@ -462,6 +462,18 @@ int c8p_fetch(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t byte
  * submit or c8p_sync().  dst should come from c8p_host_alloc (pinned), otherwise the call may block like c8p_fetch; dst may
  * also be device memory (device-to-device: results gathered without touching the host). */
 int c8p_fetch_async(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_t bytes);
+/* Several c8p_fetch_async in ONE kernel launch behind the selected submit's kernels: piece i = bytes of result arena `which` from
+ * `offset` to dst (pinned host memory — c8p_host_alloc — or device memory; offset, bytes and dst multiples of 4).  The shader cores
+ * write the host memory over PCIe themselves: no copy-engine call per arena (on some boxes the first hipMemcpyAsync behind a submit's
+ * kernels holds the calling thread for ~0.1 ms: what the block mirrors' per-batch downloads of tags, results and PDUs cost them).
+ * At most C8P_GATHER_INLINE pieces.  Complete after c8p_wait(ticket) of that submit or c8p_sync(). */
+typedef struct c8p_fetch_piece {
+  int32_t  which;           /* C8P_BUF_*                                  */
+  uint32_t rsv;
+  uint64_t offset, bytes;
+  void*    dst;
+} c8p_fetch_piece;
+int c8p_fetch_gather(c8p_ctx* ctx, const c8p_fetch_piece* pieces, int32_t n);
 /* Wait for one submit (uploads, kernels, the c8p_fetch_async copies behind it); C8P_ERANGE once its slot has been reused. */
 int c8p_wait(c8p_ctx* ctx, int ticket);
 /* 1: the submit behind `ticket` has finished (c8p_wait would return at once); 0: not yet; < 0: a C8P_E* code.  Never blocks. */
@@ -567,7 +579,7 @@ int c8p_table(int which, int sub, int32_t* dst, int cap);
 int c8p_selftest(c8p_ctx* ctx, int which, const float* in, float* out, uint64_t n);
 
 /* {ABI version, sizeof pkt_in, pkt_tags, pkt_out, cfg, batch_in, decode_in, sig_in, signal_in, sync_evt, detect_in, det_state, tx_pkt, tx_desc,
- * tx_in, tx_plan, tx_mu, det_stream, detect_multi_in, reserve_in, span, piece} as compiled into the library. */
+ * tx_in, tx_plan, tx_mu, det_stream, detect_multi_in, reserve_in, span, piece, fetch_piece} as compiled into the library. */
 int c8p_abi_sizes(int32_t* dst, int cap);
 
 #ifdef __cplusplus

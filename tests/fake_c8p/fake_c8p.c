@@ -324,5 +324,15 @@ int c8p_select(c8p_ctx* c, int ticket)
 int c8p_wait(c8p_ctx* c, int ticket) { (void)c; (void)ticket; return C8P_OK; }
 int c8p_done(c8p_ctx* c, int ticket) { (void)c; (void)ticket; return 1; }
 int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t bytes) { return c8p_fetch(c, which, dst, offset, bytes); }
+int c8p_fetch_gather(c8p_ctx* c, const c8p_fetch_piece* pc, int32_t n)
+{
+  if (n > C8P_GATHER_INLINE) return C8P_EINVAL;
+  for (int i = 0; i < n; i++) {
+    if ((pc[i].offset | pc[i].bytes | (uint64_t)(uintptr_t)pc[i].dst) & 3u) return C8P_EINVAL;
+    const int rc = pc[i].bytes ? c8p_fetch(c, pc[i].which, pc[i].dst, pc[i].offset, pc[i].bytes) : C8P_OK;
+    if (rc != C8P_OK) return rc;
+  }
+  return C8P_OK;
+}
 void* c8p_host_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
 void c8p_host_free(void* p) { free(p); }

@@ -67,45 +67,53 @@ def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bit
             "pdus_in_the_streams": 3 * K * reps}
 
 
-def run(n=4096, batches=(256, 1024), quiet=False, batch=None):
+# What one general_work call is offered / may produce: (items of the demod input per call, LLR items of its output per call).
+# "custom": the edge buffers come from the blocks' own buffer type (pinned host memory, c8p_block::buffer_alloc) and that type sizes
+# them — 8 MB per edge, of which a call sees half: 4 MB = 524 288 complex items in, 1 048 576 floats out.  "sched64k": the sizes rounds
+# 1-4 measured with (512 KB / 1 MB a call), kept for continuity.
+IO_SIZES = {"custom": (1 << 19, 1 << 20), "sched64k": (1 << 16, 1 << 18)}
+
+
+def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None):
     """every figure is the median of PASSES passes over the same block instances after a first untimed one (which grows the
     pinned staging and the device arenas, creates streams, pages the library in).  batch = (descriptors, iq, chan, expected PDUs) on
-    the host; None: host_batch(n)"""
+    the host; None: host_batch(n).  io: a key of IO_SIZES; pinned_io: batching_cfg::pinned_io (None: its default)"""
     pk, iq, chan, exp = batch if batch is not None else host_batch(n)
     pk, exp = pk[:n], exp[:n]
+    chunk_in, nout_llr = IO_SIZES[io]
     best = {}
     for max_batch in batches:
-        dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False)
+        dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False, pinned_io=pinned_io)
         n_in = blocks.feed_demod(dem, pk, iq, chan)
-        dem.run(chunk=1 << 16, nout=1 << 18)
+        dem.run(chunk=chunk_in, nout=nout_llr)
         llr, tags = dem.output(), dem.tags()                 # the LLR stream + tags feed the decode-alone measurement
         dem.set_capture(False)
         ts = []
         for rep in range(1, 1 + PASSES):
             blocks.feed_demod(dem, pk, iq, chan, base=rep * n_in)
-            t0 = time.perf_counter(); dem.run(chunk=1 << 16, nout=1 << 18); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); dem.run(chunk=chunk_in, nout=nout_llr); ts.append(time.perf_counter() - t0)
         t_dem = float(np.median(ts))
         dem.close()
-        dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=False)
+        dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=False, pinned_io=pinned_io)
         ts = []
         for rep in range(1 + PASSES):
             dec.push_items(0, llr)
             for off, key, val in tags:
                 dec.push_tag(off + rep * len(llr), key, val)
-            t0 = time.perf_counter(); dec.run(chunk=1 << 18, nout=1 << 16); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); dec.run(chunk=nout_llr, nout=1 << 16); ts.append(time.perf_counter() - t0)
         t_dec = float(np.median(ts[1:]))
         msgs = dec.messages()
         ok_dec = sum(1 for (ln, m), e in zip(msgs[-n:], exp) if m == e)
         dec.close()
-        res = {"packets": n, "max_batch": max_batch, "demod_block_packets_per_s": round(n / t_dem),
+        res = {"packets": n, "max_batch": max_batch, "io": io, "items_per_call": {"demod_in": chunk_in, "llr": nout_llr}, "demod_block_packets_per_s": round(n / t_dem),
                "decode_block_packets_per_s": round(n / t_dec), "pdus_ok_decode_alone": ok_dec}
         for fused in (False, True):
-            dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=fused)
-            dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=fused)
+            dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=fused, pinned_io=pinned_io)
+            dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=fused, pinned_io=pinned_io)
             ts = []
             for rep in range(1 + PASSES):
                 blocks.feed_demod(dem, pk, iq, chan, base=rep * n_in)
-                t0 = time.perf_counter(); blocks.run_chain(dem, dec, chunk=1 << 16, nout=1 << 18); ts.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); blocks.run_chain(dem, dec, chunk=chunk_in, nout=nout_llr); ts.append(time.perf_counter() - t0)
                 if rep == 0:                                # (the first pass allocates the pinned staging: tens of ms)
                     dem.host_phase_reset(); dec.host_phase_reset()
             dt = float(np.median(ts[1:]))
@@ -127,11 +135,16 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None):
                 best[k] = max(best.get(k, 0), v)
         best["pdus_ok_min"] = min(best.get("pdus_ok_min", n), res["pdus_ok_chain"], res["pdus_ok_chain_fused"], ok_dec)
     best["packets"] = n
+    best["io"] = io
+    best["items_per_call"] = {"demod_in": chunk_in, "llr": nout_llr}
     return best
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    print(json.dumps({"best": run(n)}))
+    b = host_batch(n)
+    print(json.dumps({"best": run(n, batch=b)}))
+    print(json.dumps({"best_sched64k": run(n, batch=b, io="sched64k", quiet=True)}))
+    print(json.dumps({"best_sched64k_pageable": run(n, batch=b, io="sched64k", quiet=True, pinned_io=False)}))
     print(json.dumps({"rx_chain": rx_chain_rate()}))
     print(json.dumps({"rx_chain_sc16": rx_chain_rate(bits=16)}))

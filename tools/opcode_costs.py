@@ -33,6 +33,9 @@ table = {
         "v_cmp_class_f32": g("p_cmpclass"), "v_cmp_gt_f32": g("p_cmpgt"), "v_addc_co_u32": g("p_addc"),
         "v_permlane16_swap_b32": g("p_swap16"), "v_permlane32_swap_b32": g("p_swap32"), "v_max_f32": g("p_max"),
         "v_or_b32": g("p_or"), "v_cmpx_class_f32": g("p_cmpclass"), "v_cmpx_gt_f32": g("p_cmpgt"),
+        # the integer-compare block loop (round 2 on): borrow / max through DPP, the swap phases' plain max / borrow, the carry shift's xor
+        "v_subb_co_u32_dpp": g("p_subb_dpp"), "v_max_u32_dpp": g("p_max_u32_dpp"), "v_max_u32": g("p_max_u32"),
+        "v_sub_co_u32": g("p_add_co"), "v_xor_b32": g("p_xor"),
     },
     "whole_step_cycles_W8": {k: g(k) for k in rows if k.startswith("p_step") or k.startswith("p_chain")},
     "all": rows,

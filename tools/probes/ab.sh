@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab.sh <lib> [<lib> ...] — alternate builds of libc8p_rx.so on the same box (bench.py --no-check: kernel-variant timing
+# tools/probes/ab.sh <lib> [<lib> ...] — alternate builds of libc8p_rx.so on the same box (bench.py --no-check: kernel-variant timing
 # experiments, the line is INVALID as a result), three rounds; prints packets/s, ms per step and the exclusive kernel times
 for i in 1 2 3; do
   for l in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_env.sh VAR=a VAR=b ... — alternate settings of ONE environment switch of the engine on the same box (bench.py, cfg 2), three rounds;
+# tools/probes/ab_env.sh VAR=a VAR=b ... — alternate settings of ONE environment switch of the engine on the same box (bench.py, cfg 2), three rounds;
 # prints packets/s, ms per step and the exclusive kernel times (classify, demod, forward pass, finish)
 for i in 1 2 3; do
   for kv in "$@"; do

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""tools/bench_configs.py — c8p_rx throughput on the OTHER BASELINE.json configs (the bench line is configs[1] only):
+"""tools/probes/bench_configs.py — c8p_rx throughput on the OTHER BASELINE.json configs (the bench line is configs[1] only):
 cfg3 HT MCS15 2x2 x1024, cfg4 VHT MCS8 x8192, cfg5 MU-MIMO 1024 per station, cfg1 legacy MCS0 x4096.  Batches are noisy
 copies of the committed reference-TX fixtures, resident in HBM; every published PDU is checked.  Prints one dict per config.
-Run on the GPU box: python tools/bench_configs.py"""
+Run on the GPU box: python tools/probes/bench_configs.py"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

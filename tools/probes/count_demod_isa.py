@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/count_demod_isa.py — static instruction counts of the pieces of one OFDM symbol's demodulation (tools/demod_probe.hip: one
+"""tools/probes/count_demod_isa.py — static instruction counts of the pieces of one OFDM symbol's demodulation (tools/probes/demod_probe.hip: one
 small kernel per piece, compiled with the engine's flags; hipcc cross-compiles without a GPU).  DESIGN.md §9 quotes the table:
 it is the account of what k_rx_1ss_lds spends outside the Viterbi forward pass (measured: 69 M of its 313 M VALU wave-instructions
 per 4096 packets = 368 per symbol)."""
@@ -9,7 +9,7 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt "
          "-mllvm -disable-promote-alloca-to-lds=1").split()
 

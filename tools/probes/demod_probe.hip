@@ -1,4 +1,4 @@
-// ISA accounting of one OFDM symbol's demodulation (tools/count_demod_isa.py): each kernel isolates one piece so that its VALU
+// ISA accounting of one OFDM symbol's demodulation (tools/probes/count_demod_isa.py): each kernel isolates one piece so that its VALU
 // instructions can be counted in the compiler's output.  Not part of the product.
 #include "c8p_kernels.h"
 extern "C" __global__ void p_fft(const cf* x, cf* y, const DevTables* T) { y[lane_id()] = wave_fft64(x[lane_id()], T); }

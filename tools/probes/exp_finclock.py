@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""tools/exp_finclock.py — where a k_finish wave spends its life (needs a library built with -DC8P_EXPERIMENTS -DC8P_EXP_FINCLOCK, loaded through
+"""tools/probes/exp_finclock.py — where a k_finish wave spends its life (needs a library built with -DC8P_EXPERIMENTS -DC8P_EXP_FINCLOCK, loaded through
 C8P_LIB: every wave then leaves its shader-clock deltas per phase in c8p_pkt_out instead of the results).  One 4096-packet cfg-2 batch at a time
 (C8P_SLOTS=1).  Prints mean cycles per phase.
 Build: source tools/hipflags.sh; $C8P_HIPCC -DC8P_EXPERIMENTS -DC8P_EXP_FINCLOCK -shared -o /tmp/libc8p_fin.so gr-ieee80211_amd/csrc/c8p_engine.hip"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["C8P_SLOTS"] = "1"
 from c8p_cases import cfg2_workload_on_device

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/exp_phases.py — where does the pipelined step go?  Saturated (software-pipelined over the engine's slots) throughput of
+"""tools/probes/exp_phases.py — where does the pipelined step go?  Saturated (software-pipelined over the engine's slots) throughput of
 c8p_rx, of c8p_demod alone and of c8p_decode alone on the cfg-2 batch, resident in HBM.  If rx = demod + decode the two halves
 compete for the same resource; a decode-only time well above its VALU bound says the decoder does not fill the machine by itself."""
 import sys, os, time, numpy as np, torch

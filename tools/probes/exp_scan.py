@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/exp_scan.py — k_detect_scan alone: its duration (HIP events) over a 33.5 M-item stream that is (a) the bench stream of cfg-2
+"""tools/probes/exp_scan.py — k_detect_scan alone: its duration (HIP events) over a 33.5 M-item stream that is (a) the bench stream of cfg-2
 packets (about a third of its tiles hold a plateau) and (b) noise only (every tile takes the quiet path).  Run on the GPU box; under
 rocprofv3 --pmc the two launches can be told apart by their order (a first)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

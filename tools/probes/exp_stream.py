@@ -1,10 +1,10 @@
-"""tools/exp_stream.py — what a host-side extra per sub-batch or per step costs the resident 65536-packet cfg-4 loop (the yardstick of
+"""tools/probes/exp_stream.py — what a host-side extra per sub-batch or per step costs the resident 65536-packet cfg-4 loop (the yardstick of
 bench.py's sharded_stream leg): extra ctypes calls, result copies, 0.4 ms of host work per step, a sync per step.  Run on the GPU box.
 profiles/r3b/exp_stream.txt: nothing but the per-step sync shows (-5 %); what cost the stream leg 8 % was a host-blocking copy inside
 shard.gather_results (the packet counts moved to the device behind the 192 MB all_gather)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 torch.zeros(1, device="cuda")

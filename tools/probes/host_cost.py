@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/host_cost.py — host-side cost of one c8p_rx submit, and the step time with the per-kernel HIP events off / sampled /
+"""tools/probes/host_cost.py — host-side cost of one c8p_rx submit, and the step time with the per-kernel HIP events off / sampled /
 on every launch (c8p_cfg.profile = 0 / 4 / 1), alternated in one process.  Run on the GPU box."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 torch.cuda.init(); dev = torch.device("cuda", 0)

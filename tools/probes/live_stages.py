@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/live_stages.py — the live ingest's per-round stage durations (c8p_rawchain_timeline), host-fed against device-fed:
+"""tools/probes/live_stages.py — the live ingest's per-round stage durations (c8p_rawchain_timeline), host-fed against device-fed:
 does the bulk PCIe traffic slow the stages' own small transfers?"""
 import json
 import os
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/live_streams.py [streams ...] — bench.py's live_streams leg alone, for several stream counts (and round lengths): how many
+"""tools/probes/live_streams.py [streams ...] — bench.py's live_streams leg alone, for several stream counts (and round lengths): how many
 independent 20 MS/s streams one MI355X serves, host-fed over PCIe, through host/c8p_rawchain's live ingest."""
 import json
 import os
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/pcie_rate.py — the PCIe-inclusive rate of the same workload as bench.py (never the bench `value`): IQ + channel
+"""tools/probes/pcie_rate.py — the PCIe-inclusive rate of the same workload as bench.py (never the bench `value`): IQ + channel
 estimates start in HOST memory (pageable numpy arrays, then pinned torch tensors), c8p_rx copies them in, and the PDU and
 per-packet result arenas are fetched back to the host after every step.  Run on the GPU box."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes
 import numpy as np, torch

@@ -1,4 +1,4 @@
-"""tools/pick.py <label> — reads bench.py's JSON line from stdin, prints packets/s, ms per step and the exclusive forward / finish times"""
+"""tools/probes/pick.py <label> — reads bench.py's JSON line from stdin, prints packets/s, ms per step and the exclusive forward / finish times"""
 import json, sys
 for line in sys.stdin:
     if line.startswith('{"metric"'):

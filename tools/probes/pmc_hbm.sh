@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_hbm.sh <tag> — run ON the GPU box: HBM traffic per kernel of one c8p_rx step (FETCH_SIZE / WRITE_SIZE, one rocprofv3 --pmc pass
+# tools/probes/pmc_hbm.sh <tag> — run ON the GPU box: HBM traffic per kernel of one c8p_rx step (FETCH_SIZE / WRITE_SIZE, one rocprofv3 --pmc pass
 # each, kernels serialised: C8P_SLOTS=1), raw csv under gpurun_out/pmc_<tag>/; prints bytes per launch (FETCH doubled per MI355X_MICROARCH.md,
 # raw beside it).
 set -u

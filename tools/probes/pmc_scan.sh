@@ -1,13 +1,13 @@
 #!/bin/bash
-# tools/pmc_scan.sh <tag> — run ON the GPU box: k_detect_scan's instruction counts per wave (SQ_INSTS_VALU / SALU / LDS, SQ_WAVES; one
-# rocprofv3 --pmc pass per counter pair) over the two streams of tools/exp_scan.py: launches 1.. of the packet-dense bench stream first,
+# tools/probes/pmc_scan.sh <tag> — run ON the GPU box: k_detect_scan's instruction counts per wave (SQ_INSTS_VALU / SALU / LDS, SQ_WAVES; one
+# rocprofv3 --pmc pass per counter pair) over the two streams of tools/probes/exp_scan.py: launches 1.. of the packet-dense bench stream first,
 # then the noise-only one (every tile on the quiet path).
 set -u
 TAG=${1:-x}; OUT=gpurun_out/pmcscan_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python tools/exp_scan.py > $OUT/plain.json 2> $OUT/plain.err; cat $OUT/plain.json
+python tools/probes/exp_scan.py > $OUT/plain.json 2> $OUT/plain.err; cat $OUT/plain.json
 for c in "SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   d=$(echo $c | tr ' ' '_')
-  EXP_SCAN_REPS=2 rocprofv3 --kernel-trace --pmc $c -d $OUT/$d -o pmc --output-format csv -- python $PWD/tools/exp_scan.py > $OUT/$d.log 2>&1
+  EXP_SCAN_REPS=2 rocprofv3 --kernel-trace --pmc $c -d $OUT/$d -o pmc --output-format csv -- python $PWD/tools/probes/exp_scan.py > $OUT/$d.log 2>&1
 done
 python - $OUT <<'P'
 import csv, glob, sys, collections

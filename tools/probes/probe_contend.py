@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/probe_contend.py — what a host-to-device bulk transfer in flight costs kernels that only touch HBM.
+"""tools/probes/probe_contend.py — what a host-to-device bulk transfer in flight costs kernels that only touch HBM.
 
 One stream keeps the link busy (c8p_copy_gather from pinned memory, by workgroup count; or c8p_copy_async = the DMA engine), another
 runs a device-to-device copy (1 GiB read + 1 GiB write), a memset (1 GiB) and a small-kernel train (256 launches of 1 MB copies): each
@@ -10,7 +10,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""tools/probe_copy.py — c8p_copy_async from pinned host memory: cost of the call and rate, by copy size"""
+"""tools/probes/probe_copy.py — c8p_copy_async from pinned host memory: cost of the call and rate, by copy size"""
 import ctypes as C
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 

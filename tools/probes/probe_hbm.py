@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/probe_hbm.py — what a trivial streaming kernel reaches on this box, as a yardstick for k_presiso (8 B in, 4 B out per
+"""tools/probes/probe_hbm.py — what a trivial streaming kernel reaches on this box, as a yardstick for k_presiso (8 B in, 4 B out per
 sample): torch.abs on complex64 (same traffic shape), a float32 copy, and a float32 fill."""
 import time
 import torch

@@ -1,7 +1,7 @@
-// tools/probe_stride.hip — what a k_finish-shaped read costs on MI355X: one wave per packet reads its 102 KB survivor area, 7 "tiles" of
+// tools/probes/probe_stride.hip — what a k_finish-shaped read costs on MI355X: one wave per packet reads its 102 KB survivor area, 7 "tiles" of
 // 57 rows x 256 bytes, 16 bytes per lane.  Variant 0: the rows of a tile 1792 bytes apart (block (btop_j - i) of every segment: today's
 // layout).  Variant 1: the rows of a tile contiguous (a tile-major layout).  Dynamic LDS sets the waves per CU as in k_finish.
-//   hipcc --offload-arch=gfx950 -O3 -o probe_stride tools/probe_stride.hip && ./probe_stride
+//   hipcc --offload-arch=gfx950 -O3 -o probe_stride tools/probes/probe_stride.hip && ./probe_stride
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,6 +1,6 @@
-// tools/probe_wgsize.hip — how many single-wave workgroups does a CU run at a time?  Every wave spins for a fixed number of clock
+// tools/probes/probe_wgsize.hip — how many single-wave workgroups does a CU run at a time?  Every wave spins for a fixed number of clock
 // cycles; the grid holds 12288 waves either as 12288 workgroups of 64 threads or as 3072 of 256, with and without an LDS footprint.
-//   hipcc --offload-arch=gfx950 -O2 tools/probe_wgsize.hip -o /tmp/probe_wgsize && /tmp/probe_wgsize
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/probe_wgsize.hip -o /tmp/probe_wgsize && /tmp/probe_wgsize
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/rawchain_growth.py — which arenas still grow inside a raw-chain run after c8p_rawchain_create reserved them
+"""tools/probes/rawchain_growth.py — which arenas still grow inside a raw-chain run after c8p_rawchain_create reserved them
 (C8P_GROW_LOG=1 prints every growth): bench.py's leg in small."""
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["C8P_GROW_LOG"] = "1"
 from __graft_entry__ import load_package  # noqa: E402

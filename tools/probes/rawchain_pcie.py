@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/rawchain_pcie.py — the host-fed raw chain (c8p_rawchain_run over segments in pinned host memory) for runs of 12 and 40 segments:
+"""tools/probes/rawchain_pcie.py — the host-fed raw chain (c8p_rawchain_run over segments in pinned host memory) for runs of 12 and 40 segments:
 the steady-state figure of a 12-segment run is a window of 8 completions that arrive in bunches (55-70 GB/s "over PCIe"), 36 completions
 and the whole run say 45-49.  Run on the GPU box."""
 import os, sys, time

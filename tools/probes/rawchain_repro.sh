@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/rawchain_repro.sh <tag> — the raw-stream legs of bench.py on THIS lease under the switches VERDICT r3 asked about:
+# tools/probes/rawchain_repro.sh <tag> — the raw-stream legs of bench.py on THIS lease under the switches VERDICT r3 asked about:
 # default, ticket numbering forced (C8P_DET_TICKETS=1), and the runtime's hardware-queue count varied (GPU_MAX_HW_QUEUES).
-# One JSON line per variant into gpurun_out/repro_<tag>.jsonl; tools/rawchain_repro_table.py turns the files into the table.
+# One JSON line per variant into gpurun_out/repro_<tag>.jsonl; tools/probes/rawchain_repro_table.py turns the files into the table.
 tag=${1:-x}
 out=gpurun_out/repro_$tag.jsonl
 mkdir -p gpurun_out; : > $out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/rawchain_repro_table.py gpurun_out/repro_*.jsonl > profiles/<round>/rawchain_repro.txt — the table of tools/rawchain_repro.sh runs
+"""tools/probes/rawchain_repro_table.py gpurun_out/repro_*.jsonl > profiles/<round>/rawchain_repro.txt — the table of tools/probes/rawchain_repro.sh runs
 (one fresh MI355X lease per file, five variants per lease)."""
 import json
 import sys

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/run_detect.py — c8p_detect over a 32M-sample synthetic stream, a few calls (profiling driver)."""
+"""tools/probes/run_detect.py — c8p_detect over a 32M-sample synthetic stream, a few calls (profiling driver)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -47,9 +47,13 @@ for k in sorted(counters):
         continue
     fk, wk = avg(c["FETCH_SIZE"]), avg(c.get("WRITE_SIZE", []))
     hbm["kernels"][k] = {"fetch_size_kb_raw": fk, "write_size_kb": wk}
-    for extra_c in ("SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+    for extra_c in ("SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"):
         if extra_c in c:
             hbm["kernels"][k][extra_c.lower()] = avg(c[extra_c])
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and avg(c["GRBM_GUI_ACTIVE"]) > 0:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over its 8 XCDs:
+        # VALU-busy cycles per SIMD / cycles the launch lasted
+        hbm["kernels"][k]["valu_busy"] = (avg(c["SQ_ACTIVE_INST_VALU"]) * 4.0 / 1024.0) / (avg(c["GRBM_GUI_ACTIVE"]) / 8.0)
     lines.append("%s, %d, %.1f, %d, %.1f, %d, %d, %d" % (k, len(c["FETCH_SIZE"]), fk, fk * 2048, wk, wk * 1024, fk * 2048 + wk * 1024, avg(durs.get(k, []))))
 lines += ["", "SQ / GRBM counters, average per launch (SQ_*_CYCLES, SQ_ACTIVE_*, SQ_WAIT_* are in quad-cycles summed over waves / SIMDs)"]
 for k in sorted(counters):
@@ -109,6 +113,42 @@ if cr:
                                        **{n.lower(): avg(v) for n, v in c.items() if n not in ("FETCH_SIZE", "WRITE_SIZE")}}
         lines.append("%s: %.1f us, FETCH x2 = %.1f MB, WRITE = %.1f MB, " % (k, rd.get(k, 0.0) / 1e3, fk * 2048 / 1e6, wk * 1024 / 1e6) +
                      ", ".join("%s=%d" % (n, avg(c[n])) for n in sorted(c) if n not in ("FETCH_SIZE", "WRITE_SIZE")))
+# opcode issue costs measured in the same session (tools/probe_issue.hip -> tools/opcode_costs.py)
+pi = os.path.join(src, "probe_issue.txt")
+if os.path.exists(pi):
+    import subprocess
+    open(os.path.join(dst, "probe_issue.txt"), "w").write(open(pi).read())
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "opcode_costs.py"), os.path.join(dst, "probe_issue.txt"),
+                           os.path.join(dst, "opcode_costs.json")], stdout=subprocess.DEVNULL)
+# the dominant kernel AS THE BENCH RUNS IT: three slots, launches of consecutive batches co-resident.  From the kernel trace of the
+# default run: the k_rx_1ss_lds dispatches of the timed steps (the long ones: a second, nearly empty launch per step handles flagged
+# packets), the middle half of them — per step: the period between consecutive starts, the time during which at least one such
+# launch is resident (union of the intervals / steps), the mean duration of a launch and how many are resident on average
+for f in glob.glob(os.path.join(src, "trace3", "**", "*kernel_trace.csv"), recursive=True):
+    iv = []
+    for r in csv.DictReader(open(f)):
+        if short(r["Kernel_Name"]).startswith("k_rx_1ss_lds"):
+            iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    iv.sort()
+    if len(iv) >= 16:
+        med = sorted(e - b for b, e in iv)[len(iv) // 2]
+        iv = [(b, e) for b, e in iv if e - b > 0.5 * med]                      # the full-size launches
+        iv = iv[len(iv) // 4: len(iv) - len(iv) // 4]                           # steady state: the middle half
+        union, cur_b, cur_e = 0, iv[0][0], iv[0][1]
+        for b, e in iv[1:]:
+            if b > cur_e:
+                union += cur_e - cur_b; cur_b, cur_e = b, e
+            else:
+                cur_e = max(cur_e, e)
+        union += cur_e - cur_b
+        n = len(iv)
+        span = iv[-1][1] - iv[0][0]
+        res = {"source": "rocprofv3 --kernel-trace of bench.py --steps 60 (C8P_SLOTS default 3), k_rx_1ss_lds dispatches, middle half",
+               "launches": n, "step_period_us": (iv[-1][0] - iv[0][0]) / (n - 1) / 1e3, "launch_duration_us_mean": sum(e - b for b, e in iv) / n / 1e3,
+               "resident_us_per_step": union / n / 1e3, "resident_fraction_of_span": union / span,
+               "launches_resident_on_average": sum(e - b for b, e in iv) / span}
+        json.dump(res, open(os.path.join(dst, "residency_3slots.json"), "w"), indent=1)
+        lines += ["", "k_rx_1ss_lds as the bench runs it (3 slots, kernel trace): " + json.dumps(res)]
 json.dump(hbm, open(os.path.join(dst, "pmc_hbm.json"), "w"), indent=1)
 open(os.path.join(dst, "pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
