@@ -345,9 +345,10 @@ def main():
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
             if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
-            r = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected))                     # the blocks' own (pinned) buffers
+            r = bb.run(2048, batches=(256, 1024), quiet=True, batch=(pk, iq, chan, expected))                # the blocks' own (pinned) buffers
             r64 = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
             rpg = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
+            rfl = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
             try:
                 out["block_rx_chain"] = bb.rx_chain_rate(local=local)
                 out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
@@ -359,13 +360,17 @@ def main():
             out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
             out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
             out["block_chain_variants"] = {
-                "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"]},
+                "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"],
+                                   "chain_threads_on_cpus": r.get("chain_threads_on_cpus")},
+                "custom_buffers_threads_floating": {"items_per_call": rfl["items_per_call"], "chain": rfl["chain_packets_per_s"], "chain_fused": rfl["chain_fused_packets_per_s"],
+                                                    "note": "the two scheduler threads wherever the OS puts them (no core affinity set on the blocks)"},
                 "sched64k_pinned": {"items_per_call": r64["items_per_call"], "chain": r64["chain_packets_per_s"], "chain_fused": r64["chain_fused_packets_per_s"]},
                 "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
                                       "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},
                 "note": "block_chain_* (and legs.block_chain / block_fused) = custom_buffers: the edge buffers are allocated through the mirrors' buffer type "
                         "(GNU Radio 3.10 custom buffers: pinned host memory, 8 MB per edge, a call sees half), the packets are gathered out of them by the "
-                        "device and demod's LLR items are written into them by the device"}
+                        "device and demod's LLR items are written into them by the device; the two scheduler threads sit on two cores that share an L3 "
+                        "(hostbind.cpu_pair_sharing_l3: what a flowgraph sets with the blocks' core affinity)"}
             out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
             out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
             out["host_phase_us"] = {"chain": r.get("chain_host_phase_us_per_packet"), "chain_fused": r.get("chain_fused_host_phase_us_per_packet"),

@@ -48,6 +48,9 @@
 //                                                                kind); predicates of 3.10 pmt.h
 //   pmt::symbol_to_string(pmt_t), pmt::string_to_symbol(string)  lib/pad2_impl.cc:154 (string_to_symbol); symbol_to_string: 3.10 pmt.h
 //   pmt::PMT_T                                                   3.10 pmt.h (the reference uses pmt::PMT_NIL, lib/demod_impl.cc:89)
+//   input_signature() / output_signature() -> io_signature::sptr   gr::basic_block (3.10 basic_block.h); NOT used by the reference
+//   io_signature::stream_buffer_type(size_t)                     3.10 io_signature.h (custom buffers: see c8p_pinned_buffer.h, which
+//                                                                continues this list with the gr::buffer members the buffer type uses)
 //
 // Five members have no call site in the reference (stop, _post, the three predicates + symbol_to_string / to_double / PMT_T): those
 // are the first things to look at if the module does not build against a real GNU Radio.
@@ -64,6 +67,7 @@
 #include <vector>
 
 #include "c8p_blocks.h"
+#include "c8p_pinned_buffer.h"
 
 namespace gr {
 namespace ieee80211 {
@@ -140,6 +144,11 @@ private:
   // the front's latency timer collected results while no input was arriving: after the (empty) handler the scheduler thread
   // evaluates forecast() — which asks for no input while results wait for output space — and calls general_work()
   void wake() override { this->_post(pmt::mp("c8p_tick"), pmt::PMT_T); }
+
+  // custom buffers (c8p_pinned_buffer.h): the scheduler allocated this port's buffer through the module's buffer type when the
+  // io_signature names it — which the impl classes' constructors do; a flowgraph that overrides it gets pageable staging back
+  bool input_is_pinned(unsigned port) override { return this->input_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
+  bool output_is_pinned(unsigned port) override { return this->output_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
 
   std::shared_ptr<c8p::c8p_block> d_front;
 };

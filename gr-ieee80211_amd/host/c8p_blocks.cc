@@ -73,11 +73,12 @@ c8p_api load_c8p_api(const std::string& so_path)
   return a;
 }
 
-static c8p_api default_api()
+c8p_api default_c8p_api()
 {
   const char* e = getenv("C8P_RX_LIB");
   return load_c8p_api(e ? e : "libc8p_rx.so");
 }
+static c8p_api default_api() { return default_c8p_api(); }
 
 int batching_cfg::default_max_wait_us()
 {

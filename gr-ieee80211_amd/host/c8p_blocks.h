@@ -132,6 +132,8 @@ struct c8p_api {
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);
+// the table the one-argument factories use: the library named by the environment's C8P_RX_LIB, or "libc8p_rx.so" on the loader path
+c8p_api default_c8p_api();
 
 struct batching_cfg {
   int max_batch = 256;          // packets per c8p_* call

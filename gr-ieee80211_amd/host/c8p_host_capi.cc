@@ -1,6 +1,9 @@
 // c8p_host_capi.cc — C entry points around the block mirror, used by the Python tests and by INTEGRATION examples:
 // an in-memory block_io (tagged item streams in, items/tags/messages out) plus a tiny run loop that calls
 // general_work() the way the GNU Radio scheduler does (bounded chunks, zero-progress calls allowed).
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -354,7 +357,19 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   typedef std::chrono::steady_clock clk;
   auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   double a_work = 0, a_wait = 0, a_all = 0, b_work = 0, b_wait = 0, b_all = 0;
+  // C8P_CHAIN_PIN="a,b": the two scheduler threads on CPUs a and b (GNU Radio: block::set_processor_affinity) — on a host whose
+  // logical CPUs are hyper-thread pairs, two busy threads that land on one core each run at ~60 %
+  int pin_a = -1, pin_b = -1;
+  if (const char* e = getenv("C8P_CHAIN_PIN")) sscanf(e, "%d,%d", &pin_a, &pin_b);
+  auto pin_self = [](int cpu) {
+    if (cpu < 0) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpu, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+  };
   std::thread ta([&] {
+    pin_self(pin_a);
     const clk::time_point ta0 = clk::now();
     try {
       int idle = 0, cur = -1;
@@ -427,6 +442,9 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
     cv.notify_all();
   });
   const clk::time_point tb0 = clk::now();
+  cpu_set_t b_before;
+  const bool b_saved = pin_b >= 0 && pthread_getaffinity_np(pthread_self(), sizeof(b_before), &b_before) == 0;
+  pin_self(pin_b);
   try {
     std::vector<float> dummy(16);
     gr_vector_void_star outs(1, dummy.data());
@@ -488,6 +506,7 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
     }
   } catch (const std::exception& e) { B->err = e.what(); { std::lock_guard<std::mutex> g(mu); failed = true; } cv.notify_all(); }
   b_all = secs(tb0, clk::now());
+  if (b_saved) (void)pthread_setaffinity_np(pthread_self(), sizeof(b_before), &b_before);
   ta.join();
   if (tlog)
     fprintf(stderr, "[c8ph_run_chain] A: %ld calls, %.2f ms in general_work, %.2f ms waiting for a segment, %.2f ms all | B: %ld calls, %.2f ms in general_work, "

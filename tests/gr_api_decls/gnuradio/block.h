@@ -32,6 +32,10 @@ public:
 protected:
   basic_block(void);
   basic_block(const std::string& name, io_signature::sptr input_signature, io_signature::sptr output_signature);
+
+public:
+  io_signature::sptr input_signature() const;
+  io_signature::sptr output_signature() const;
 };
 
 class block : public basic_block

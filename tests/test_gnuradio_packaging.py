@@ -78,9 +78,11 @@ def test_bindings_and_adapters_keep_names_and_signatures():
     assert 'm, "demod2"' in bind["demod2"] and 'm, "decode"' in bind["decode"] and 'py::arg("ifdebug")' in bind["decode"]
     mod = open(os.path.join(GR, "python", "ieee80211", "bindings", "python_bindings.cc")).read()
     assert "PYBIND11_MODULE(ieee80211_python, m)" in mod
-    sig = {"demod": ("make(1, 1, sizeof(gr_complex))", "make(1, 1, sizeof(float))"),        # demod_impl.cc:36-37
-           "demod2": ("make(2, 2, sizeof(gr_complex))", "make(1, 1, sizeof(float))"),       # demod2_impl.cc:36-37
-           "decode": ("make(1, 1, sizeof(float))", "make(0, 0, 0)")}                        # decode_impl.cc:35-38
+    # the reference's ports (stream counts, item sizes); round 5: every stream port also names the module's buffer type (pinned host
+    # memory, gnuradio/lib/c8p_pinned_buffer.h) — the fourth argument of GNU Radio 3.10's io_signature::make
+    sig = {"demod": ("make(1, 1, sizeof(gr_complex), c8p_pinned_buffer::type)", "make(1, 1, sizeof(float), c8p_pinned_buffer::type)"),     # demod_impl.cc:36-37
+           "demod2": ("make(2, 2, sizeof(gr_complex), c8p_pinned_buffer::type)", "make(1, 1, sizeof(float), c8p_pinned_buffer::type)"),    # demod2_impl.cc:36-37
+           "decode": ("make(1, 1, sizeof(float), c8p_pinned_buffer::type)", "make(0, 0, 0)")}                                               # decode_impl.cc:35-38
     for b, (i, o) in sig.items():
         src = open(os.path.join(GR, "lib", b + "_impl.cc")).read()
         assert "io_signature::" + i in src and "io_signature::" + o in src

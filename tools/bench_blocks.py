@@ -74,13 +74,21 @@ def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bit
 IO_SIZES = {"custom": (1 << 19, 1 << 20), "sched64k": (1 << 16, 1 << 18)}
 
 
-def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None):
+def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto"):
     """every figure is the median of PASSES passes over the same block instances after a first untimed one (which grows the
     pinned staging and the device arenas, creates streams, pages the library in).  batch = (descriptors, iq, chan, expected PDUs) on
     the host; None: host_batch(n).  io: a key of IO_SIZES; pinned_io: batching_cfg::pinned_io (None: its default)"""
     pk, iq, chan, exp = batch if batch is not None else host_batch(n)
     pk, exp = pk[:n], exp[:n]
     chunk_in, nout_llr = IO_SIZES[io]
+    # the chain's two scheduler threads on two cores that share an L3 (GNU Radio: the blocks' core affinity); pin=None: left to the OS
+    if pin == "auto":
+        from gr_ieee80211_amd import hostbind
+        pin = hostbind.cpu_pair_sharing_l3()
+    if pin:
+        os.environ["C8P_CHAIN_PIN"] = "%d,%d" % tuple(pin)
+    else:
+        os.environ.pop("C8P_CHAIN_PIN", None)
     best = {}
     for max_batch in batches:
         dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False, pinned_io=pinned_io)
@@ -135,6 +143,8 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinne
                 best[k] = max(best.get(k, 0), v)
         best["pdus_ok_min"] = min(best.get("pdus_ok_min", n), res["pdus_ok_chain"], res["pdus_ok_chain_fused"], ok_dec)
     best["packets"] = n
+    best["chain_threads_on_cpus"] = list(pin) if pin else None
+    os.environ.pop("C8P_CHAIN_PIN", None)
     best["io"] = io
     best["items_per_call"] = {"demod_in": chunk_in, "llr": nout_llr}
     return best
