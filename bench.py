@@ -439,6 +439,7 @@ def legs_summary(out):
             "sens_21dB": g("sensitivity", "snr_21dB", "packets_per_s"), "sens_windowed": g("sensitivity", "windowed_tx", "packets_per_s"),
             "sens_3tap": g("sensitivity", "selective_3tap", "packets_per_s"), "sens_mixed": g("sensitivity", "mixed_formats", "packets_per_s"),
             "sens_mixed_steps_per_s": g("sensitivity", "mixed_formats", "trellis_steps_per_s"),
+            "sens_mixed_air_items_per_s": g("sensitivity", "mixed_formats", "air_items_per_s"), "headline_air_items_per_s": g("sensitivity", "with_delivery", "air_items_per_s"),
             "with_delivery": g("sensitivity", "with_delivery", "packets_per_s"),
             "host_wall_us_fused": g("host_phase_us", "chain_fused", "wall"), "host_wall_us_chain": g("host_phase_us", "chain", "wall")}
     return {k: v for k, v in legs.items() if v is not None}
@@ -971,7 +972,9 @@ def sensitivity_legs(torch, dev, local, n_pkt, headline, timed_s=0.35):
                          "exact_kernel_packets": int(rng_flags.sum()),
                          "float_step_block_fraction": float(flt_blocks[lean].sum()) / max(1, int((tr[lean] // 30).sum())),
                          "trellis_steps_per_packet_mean": float(tr.mean()),
-                         "trellis_steps_per_s": float(tr.sum()) * k / dt}
+                         "trellis_steps_per_s": float(tr.sum()) * k / dt,
+                         "items_per_packet_mean": float(pk["n_items"].mean()),
+                         "air_items_per_s": float(pk["n_items"].astype(np.int64).sum()) * k / dt}
             if deliver:
                 got = np.frombuffer(bufs[(k - 1) % 3][0].numpy().tobytes(), abi.PKT_OUT_DT)
                 res[name]["delivered_bytes_per_step"] = int(bufs[0][0].numel() + bufs[0][1].numel())
@@ -981,8 +984,10 @@ def sensitivity_legs(torch, dev, local, n_pkt, headline, timed_s=0.35):
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     eng.close()
     res["note"] = ("same batch size and timing code as the headline (inputs resident, K steps of c8p_rx between two syncs, ~%.2f s timed each); "
-                   "vs_headline = packets_per_s / value; mixed_formats has fewer trellis steps per packet than cfg 2 — compare trellis_steps_per_s "
-                   "(cfg 2: 11 960 steps per packet)" % timed_s)
+                   "vs_headline = packets_per_s / value.  mixed_formats is NOT the same unit of work per packet: random rate and length put ~4 x the air "
+                   "time of a cfg-2 packet into the average packet (items_per_packet_mean; a 3000-byte BPSK frame is 1000 symbols to demodulate for "
+                   "24 000 trellis steps, a cfg-2 frame 46 symbols for 11 960) — compare air_items_per_s (cfg 2: 4400 items per packet); the engine "
+                   "decodes a batch of mixed lengths longest first" % timed_s)
     return res
 
 

@@ -468,16 +468,18 @@ static int plan_decode(c8p_ctx* c, const c8p_decode_in* in, Plan& P)
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // c8p_rx hands over what the fused single-stream kernel needs (k_rx_1ss); c8p_decode passes nullptr
-struct RxFuse { const c8p_pkt_in* d_pk; const cf* d_iq; const cf* d_chan; bool any_2ant; };
+struct RxFuse { const c8p_pkt_in* d_pk; const cf* d_iq; const cf* d_chan; bool any_2ant; const uint32_t* d_order; };
 // d_cold: the FinCold record of this submit (device memory)
 
 // The arenas of one submit, by stage (also what c8p_reserve sizes in advance).
-static size_t demod_stage_bytes(int n, size_t* o_lay = nullptr, size_t* o_cold = nullptr)
+static size_t demod_stage_bytes(int n, size_t* o_lay = nullptr, size_t* o_cold = nullptr, size_t* o_ord = nullptr)
 {
   const size_t ol = align256(sizeof(c8p_pkt_in) * (size_t)n), oc = align256(ol + sizeof(PktLayout) * (size_t)n);
+  const size_t oo = align256(oc + sizeof(FinCold));          // the launch order of the packets (uint32[n]; used when their lengths differ)
   if (o_lay) *o_lay = ol;
   if (o_cold) *o_cold = oc;
-  return align256(oc + sizeof(FinCold));
+  if (o_ord) *o_ord = oo;
+  return align256(oo + sizeof(uint32_t) * (size_t)n);
 }
 static int ensure_demod_arenas(c8p_ctx* c, int n, const Plan& P, uint64_t host_iq, uint64_t host_chan)
 {
@@ -545,10 +547,10 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
       } else if (rx) {   // the LLR stream stays in LDS; what the lean decoder cannot take is flagged and left to k_finish
         float* tap = c->keep_llr == 2 ? (float*)c->s->d_llr.p : nullptr;     // the parity tests' view of the on-chip LLRs
         hipLaunchKernelGGL(k_rx_1ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, rx->d_chan, d_lay, (const DevTables*)c->d_tab,
-                           d_tags, (const cf*)c->s->d_H.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+                           d_tags, (const cf*)c->s->d_H.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, rx->d_order);
         if (rx->any_2ant)
           hipLaunchKernelGGL(k_rx_2ss_lds, dim3((n + 3) / 4), dim3(256), 0, dst, rx->d_pk, rx->d_iq, d_lay, (const DevTables*)c->d_tab,
-                             d_tags, (const Mimo*)c->s->d_mimo.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n);
+                             d_tags, (const Mimo*)c->s->d_mimo.p, tap, (ulonglong2*)c->s->d_surv.p, (uint32_t*)c->s->d_flags.p, n, rx->d_order);
       }
       // c8p_decode: quads of packets with the same rate and length can go through the four-packets-per-wave kernel (17 % fewer VALU
       // instructions per packet, but 4 x fewer waves): it wins when one batch alone gives every SIMD several of its fat waves —
@@ -638,8 +640,8 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if (rc != C8P_OK) return rc;
 
   // descriptors + layout (+ the record k_finish's cold path reads) in one pinned staging copy
-  size_t o_lay = 0, o_cold = 0;
-  const size_t o_pk = 0, stage_bytes = demod_stage_bytes(n, &o_lay, &o_cold);
+  size_t o_lay = 0, o_cold = 0, o_ord = 0;
+  const size_t o_pk = 0, stage_bytes = demod_stage_bytes(n, &o_lay, &o_cold, &o_ord);
   if ((rc = ensure_demod_arenas(c, n, P, in->mem == C8P_MEM_HOST ? in->n_iq : 0, in->mem == C8P_MEM_HOST ? in->n_chan : 0)) != C8P_OK) return rc;
   const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
@@ -659,9 +661,24 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
     const FinCold fc = {d_pk, d_iq, d_chan, (const cf*)c->s->d_H.p, (const Mimo*)c->s->d_mimo.p, (float*)c->s->d_llr.p};
     memcpy((char*)c->s->h_stage + o_cold, &fc, sizeof(fc));
   }
+  // A batch whose packets differ in length is decoded longest first (the on-chip kernels of c8p_rx: four packets share a workgroup and
+  // its LDS until the longest of them is done; measured on 4096 packets of random format / rate / length: +13 % packets/s).  The
+  // results stay where the caller's order puts them: only the launch order changes.
+  const uint32_t* d_order = nullptr;
+  if (with_decode && n > 4) {
+    uint32_t lo = in->pkts[0].n_items, hi = lo;
+    for (int p = 1; p < n; p++) { lo = std::min(lo, in->pkts[p].n_items); hi = std::max(hi, in->pkts[p].n_items); }
+    if (hi > lo + lo / 8) {
+      uint32_t* ord = (uint32_t*)((char*)c->s->h_stage + o_ord);
+      for (int p = 0; p < n; p++) ord[p] = (uint32_t)p;
+      const c8p_pkt_in* pkts = in->pkts;
+      std::stable_sort(ord, ord + n, [pkts](uint32_t a, uint32_t b) { return (uint64_t)pkts[a].n_items * pkts[a].n_ant > (uint64_t)pkts[b].n_items * pkts[b].n_ant; });
+      d_order = (const uint32_t*)((char*)c->s->d_stage.p + o_ord);
+    }
+  }
   {
     KTimer kt(c, C8P_K_LAYOUT);
-    HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, stage_bytes));
+    HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, d_order ? stage_bytes : o_ord));
   }
 
   {
@@ -687,7 +704,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   // (keep_llr = 2, the tap: the kernels do not write the padding between two packets' LLR areas, and the tests read only the areas)
   c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
   if (!with_decode) return C8P_OK;
-  const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant};
+  const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant, d_order};
   return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, &rx,
                             (const FinCold*)((char*)c->s->d_stage.p + o_cold));
 }

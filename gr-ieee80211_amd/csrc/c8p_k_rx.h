@@ -151,10 +151,14 @@ __device__ __forceinline__ void lds_tap(float* __restrict__ dst, const float* sr
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr_tap,
-                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n,
+                                                const uint32_t* __restrict__ order)
 {
-  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
-  if (p >= n) return;
+  // wave w of the launch takes packet order[w]: a batch of mixed lengths is laid out longest first, so that the four waves of a
+  // workgroup (which hold its LDS until the last of them is done) carry packets of like length (nullptr: w itself)
+  const int w_ = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (w_ >= n) return;
+  const int p = order ? __builtin_amdgcn_readfirstlane((int)order[w_]) : w_;
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   const c8p_pkt_in P = pk[p];
@@ -296,10 +300,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rx_2ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const Mimo* __restrict__ mimo, float* __restrict__ llr_tap,
-                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n)
+                                                ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n,
+                                                const uint32_t* __restrict__ order)
 {
-  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
-  if (p >= n) return;
+  const int w_ = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
+  if (w_ >= n) return;
+  const int p = order ? __builtin_amdgcn_readfirstlane((int)order[w_]) : w_;           // (see k_rx_1ss_lds)
   const c8p_pkt_tags t = tags[p];
   if (t.status != C8P_ST_OK) return;
   const c8p_pkt_in P = pk[p];
