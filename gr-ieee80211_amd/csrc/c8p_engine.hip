@@ -255,6 +255,10 @@ struct c8p_ctx {
   std::mutex copy_mu;                                // marks against copies enqueued from another thread
   hipEvent_t copy_ev[64] = {};
   uint64_t copy_marks = 0;
+  hipStream_t out_stream = nullptr;                  // c8p_copy_gather with C8P_PIECE_TO_HOST pieces: device -> host, the link's other direction
+  hipEvent_t out_ev[64] = {};                        // ... what a mark records there (only while out_dirty)
+  bool out_ev_valid[64] = {};
+  bool out_dirty = false;                            // something was enqueued on out_stream since the last mark
   hipEvent_t ev_fence = nullptr;                     // c8p_copy_fence: what the next submit's stream waits for
   bool fence_pending = false;
 };
@@ -381,6 +385,8 @@ extern "C" void c8p_destroy(c8p_ctx* c)
     if (c->own_stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->out_stream) { (void)hipStreamSynchronize(c->out_stream); (void)hipStreamDestroy(c->out_stream); }
+  for (hipEvent_t e : c->out_ev) if (e) (void)hipEventDestroy(e);
   if (c->span_stream) { (void)hipStreamSynchronize(c->span_stream); (void)hipStreamDestroy(c->span_stream); }
   if (c->ev_before_spans) (void)hipEventDestroy(c->ev_before_spans);
   if (c->ev_spans) (void)hipEventDestroy(c->ev_spans);
@@ -1617,6 +1623,7 @@ extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
   if (!c || !p) return;
   (void)hipSetDevice(c->device);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
   (void)hipFree(p);
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c);
@@ -1648,6 +1655,7 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
     if (!masked) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     c->copy_cus = masked ? ncu : 0;
     HIPCHK(c, hipStreamCreateWithFlags(&c->span_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_before_spans, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_spans, hipEventDisableTiming));
   }
@@ -1664,6 +1672,15 @@ extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
     c->spans_pending = false;
   }
   if (hipEventRecord(e, c->copy_stream) != hipSuccess) return 0;
+  const size_t slot = c->copy_marks % 64;
+  c->out_ev_valid[slot] = false;
+  if (c->out_dirty) {                          // ... and what went the other way (its own stream)
+    hipEvent_t& eo = c->out_ev[slot];
+    if (!eo && hipEventCreateWithFlags(&eo, hipEventDisableTiming) != hipSuccess) return 0;
+    if (hipEventRecord(eo, c->out_stream) != hipSuccess) return 0;
+    c->out_ev_valid[slot] = true;
+    c->out_dirty = false;
+  }
   return ++c->copy_marks;
 }
 extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
@@ -1671,13 +1688,15 @@ extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
   if (!c) return C8P_EINVAL;
   if (mark == 0) return c8p_copy_wait(c);
   if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
-  hipEvent_t e = nullptr;
+  hipEvent_t e = nullptr, eo = nullptr;
   {
     std::lock_guard<std::mutex> g(c->copy_mu);
     if (mark > c->copy_marks) return C8P_EINVAL;
     e = c->copy_ev[(mark - 1) % 64];            // (re-recorded by a later mark if 64 marks have passed: a later point of the same stream)
+    if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
   }
-  return hipEventSynchronize(e) == hipSuccess ? C8P_OK : C8P_EHIP;
+  if (hipEventSynchronize(e) != hipSuccess) return C8P_EHIP;
+  return (!eo || hipEventSynchronize(eo) == hipSuccess) ? C8P_OK : C8P_EHIP;
 }
 extern "C" int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes)
 {
@@ -1936,6 +1955,11 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   }
   if (any_f32 && any_other) { c->err = "c8p_copy_gather: C8P_FMT_F32 pieces cannot share a call with 8-byte-item pieces (dst_off units differ)"; return C8P_EINVAL; }
   const bool inl = n <= C8P_GATHER_INLINE;
+  // device -> host pieces (the caller says so) on the stream of that direction; a long list stays on the copy stream (its table lives there)
+  bool to_host = inl;
+  for (int i = 0; i < n && to_host; i++) to_host = (pieces[i].rsv & C8P_PIECE_TO_HOST) != 0;
+  const hipStream_t gst = to_host ? c->out_stream : c->copy_stream;
+  if (to_host) { std::lock_guard<std::mutex> g(c->copy_mu); c->out_dirty = true; }
   PieceTab itab;
   PieceDev* hp = itab.p;
   if (!inl) {
@@ -1979,17 +2003,26 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   const PieceDev* dp = inl ? nullptr : (const PieceDev*)c->d_spans.p;
   // (on a masked copy stream: eight 256-thread workgroups per CU = every wave slot of the CUs the stream may use)
   auto grid = [&](unsigned long long t, unsigned wgs) {
-    const unsigned g = env_wgs ? env_wgs : (c->copy_cus ? 8u * (unsigned)c->copy_cus : wgs);
+    const unsigned g = env_wgs ? env_wgs : (to_host ? 256u : (c->copy_cus ? 8u * (unsigned)c->copy_cus : wgs));
     return dim3((unsigned)std::min<unsigned long long>((t + 1023) / 1024, g));
   };
   // a format's pieces are a contiguous run of the table: the inline table is passed shifted to that run
   auto sub = [&](int f) { PieceTab t; memset(&t, 0, sizeof(t)); if (inl) memcpy(t.p, itab.p + first_of[f], sizeof(PieceDev) * (size_t)cnt[f]); return t; };
-  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[0], sub(0), cnt[0], total[0]);
-  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[1], sub(1), cnt[1], total[1]);
-  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, c->copy_stream, (cf*)dst, inl ? nullptr : dp + first_of[2], sub(2), cnt[2], total[2]);
-  if (total[3]) hipLaunchKernelGGL(k_copy_gather_w, grid(total[3], C8P_GATHER_WGS), dim3(256), 0, c->copy_stream, (unsigned*)dst, inl ? nullptr : dp + first_of[3], sub(3), cnt[3], total[3]);
+  if (total[0]) hipLaunchKernelGGL(k_copy_gather, grid(total[0], C8P_GATHER_WGS), dim3(256), 0, gst, (cf*)dst, inl ? nullptr : dp + first_of[0], sub(0), cnt[0], total[0]);
+  if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, gst, (cf*)dst, inl ? nullptr : dp + first_of[1], sub(1), cnt[1], total[1]);
+  if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, gst, (cf*)dst, inl ? nullptr : dp + first_of[2], sub(2), cnt[2], total[2]);
+  if (total[3]) hipLaunchKernelGGL(k_copy_gather_w, grid(total[3], C8P_GATHER_WGS), dim3(256), 0, gst, (unsigned*)dst, inl ? nullptr : dp + first_of[3], sub(3), cnt[3], total[3]);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
+}
+// c8p_fetch_gather's flag piece: a second, one-wave launch behind the gather on the same stream — stream order puts it after the
+// gather's last store, the system-scope fence after the stores' visibility to the host
+__global__ void k_set_flag(uint32_t* dst, uint32_t value)
+{
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(dst, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // Result arenas to host (or device) memory with one launch on the selected submit's own stream, behind its kernels: the pieces' sources
 // are the slot's arenas, the destination offsets are taken from address 0 (k_copy_gather_w adds word offsets to its base pointer).
@@ -2002,8 +2035,15 @@ extern "C" int c8p_fetch_gather(c8p_ctx* c, const c8p_fetch_piece* pieces, int32
   memset(&tab, 0, sizeof(tab));
   unsigned long long total = 0;
   int m = 0;
+  uint32_t* flag = nullptr;
+  uint32_t flag_value = 0;
   for (int i = 0; i < n; i++) {
     const c8p_fetch_piece& f = pieces[i];
+    if (f.which == C8P_BUF_FLAG) {
+      if (!f.dst || ((uintptr_t)f.dst & 3u) || flag) { c->err = "c8p_fetch_gather: bad flag piece (one per call, 4-byte aligned)"; return C8P_EINVAL; }
+      flag = (uint32_t*)f.dst; flag_value = (uint32_t)f.offset;
+      continue;
+    }
     if (f.which < 0 || f.which >= C8P_BUF_COUNT || (f.bytes && !f.dst)) { c->err = "c8p_fetch_gather: bad piece"; return C8P_EINVAL; }
     if (f.offset + f.bytes > c->s->used[f.which]) { c->err = "fetch outside the arena"; return C8P_ERANGE; }
     if ((f.offset | f.bytes | (uint64_t)(uintptr_t)f.dst) & 3u) { c->err = "c8p_fetch_gather: offset, bytes and dst must be multiples of 4"; return C8P_EINVAL; }
@@ -2013,9 +2053,11 @@ extern "C" int c8p_fetch_gather(c8p_ctx* c, const c8p_fetch_piece* pieces, int32
     P.dst_off = (unsigned long long)(uintptr_t)f.dst / 4u; P.n = f.bytes / 4u; P.first = total; P.scale = 1.0f; P.rsv = 0;
     total += (P.n + 3 + (((uintptr_t)P.src >> 2) & 3u)) / 4;
   }
-  if (!total) return C8P_OK;
-  const dim3 grid((unsigned)std::min<unsigned long long>((total + 1023) / 1024, 256ull));
-  hipLaunchKernelGGL(k_copy_gather_w, grid, dim3(256), 0, c->s->stream, (unsigned*)nullptr, (const PieceDev*)nullptr, tab, m, total);
+  if (total) {
+    const dim3 grid((unsigned)std::min<unsigned long long>((total + 1023) / 1024, 256ull));
+    hipLaunchKernelGGL(k_copy_gather_w, grid, dim3(256), 0, c->s->stream, (unsigned*)nullptr, (const PieceDev*)nullptr, tab, m, total);
+  }
+  if (flag) hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, c->s->stream, flag, flag_value);
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
@@ -2040,6 +2082,7 @@ extern "C" int c8p_copy_wait(c8p_ctx* c)
   HIPCHK(c, hipSetDevice(c->device));
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   if (c->span_stream) HIPCHK(c, hipStreamSynchronize(c->span_stream));
+  if (c->out_stream) HIPCHK(c, hipStreamSynchronize(c->out_stream));
   return C8P_OK;
 }
 

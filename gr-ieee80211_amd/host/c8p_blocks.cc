@@ -851,6 +851,7 @@ private:
         c8p_piece pc;
         memset(&pc, 0, sizeof(pc));
         pc.src = o.llr + o.sent; pc.dst_off = (uint64_t)pos; pc.n = k; pc.trusted = 1; pc.fmt = C8P_FMT_F32; pc.scale = 1.0f;
+        pc.rsv = C8P_PIECE_TO_HOST;                  // (the link's other direction: its own copy stream, beside the samples coming down)
         d_opieces.push_back(pc);
       }
       o.sent += k; pos += k;

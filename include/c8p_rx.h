@@ -467,8 +467,11 @@ int c8p_fetch_async(c8p_ctx* ctx, int which, void* dst, uint64_t offset, uint64_
  * write the host memory over PCIe themselves: no copy-engine call per arena (on some boxes the first hipMemcpyAsync behind a submit's
  * kernels holds the calling thread for ~0.1 ms: what the block mirrors' per-batch downloads of tags, results and PDUs cost them).
  * At most C8P_GATHER_INLINE pieces.  Complete after c8p_wait(ticket) of that submit or c8p_sync(). */
+#define C8P_BUF_FLAG (-1)   /* c8p_fetch_piece.which: not an arena — when every other piece of the call has landed, the 32-bit value `offset` is
+                               written to dst (4 bytes of pinned host memory): a caller that polls that word needs no c8p_wait, and
+                               may do so on ANOTHER thread than the one that submits on this ctx (the word is the whole interface)  */
 typedef struct c8p_fetch_piece {
-  int32_t  which;           /* C8P_BUF_*                                  */
+  int32_t  which;           /* C8P_BUF_*, or C8P_BUF_FLAG                 */
   uint32_t rsv;
   uint64_t offset, bytes;
   void*    dst;
@@ -518,8 +521,13 @@ typedef struct c8p_piece {
                                — one hipPointerGetAttributes per piece costs ~4 us, a millisecond per round of 256 pushes               */
   uint32_t fmt;             /* C8P_FMT_* (one c8p_copy_gather call may mix them, except C8P_FMT_F32 with the others: dst_off units differ)     */
   float    scale;           /* C8P_FMT_SC16 / _SC8: item = ((float)i * scale, (float)q * scale), one float32 multiply each             */
-  uint32_t rsv;
+  uint32_t rsv;             /* C8P_PIECE_TO_HOST or 0 (every piece of a call the same)                                                 */
 } c8p_piece;
+/* c8p_piece.rsv: the pieces of this call travel FROM the device TO host memory.  Such a call (up to C8P_GATHER_INLINE pieces) runs on a
+ * copy stream of its own, so that a block that feeds the device and drains it at the same time (the demod mirror: samples down, LLR
+ * items up) uses both directions of the link at once instead of queueing one transfer behind the other — each launch takes ~18 us
+ * from enqueue to done whatever its size.  c8p_copy_mark / _wait_mark / _wait cover both streams. */
+#define C8P_PIECE_TO_HOST 1u
 /* C8P_FMT_SC16: what the radio puts on the wire.  The reference's flowgraph takes its stream from a UHD source with the default wire
  * format sc16 and CPU format fc32 (/root/reference/examples/rx.grc:689 `otw: ''`, :744 `type: fc32`): the host converts every sample
  * to float before the first block sees it.  Here the 4-byte samples cross PCIe and the gather kernel converts them on their way into

@@ -327,11 +327,14 @@ int c8p_fetch_async(c8p_ctx* c, int which, void* dst, uint64_t offset, uint64_t 
 int c8p_fetch_gather(c8p_ctx* c, const c8p_fetch_piece* pc, int32_t n)
 {
   if (n > C8P_GATHER_INLINE) return C8P_EINVAL;
+  uint32_t* flag = NULL; uint32_t fv = 0;
   for (int i = 0; i < n; i++) {
+    if (pc[i].which == C8P_BUF_FLAG) { flag = (uint32_t*)pc[i].dst; fv = (uint32_t)pc[i].offset; continue; }
     if ((pc[i].offset | pc[i].bytes | (uint64_t)(uintptr_t)pc[i].dst) & 3u) return C8P_EINVAL;
     const int rc = pc[i].bytes ? c8p_fetch(c, pc[i].which, pc[i].dst, pc[i].offset, pc[i].bytes) : C8P_OK;
     if (rc != C8P_OK) return rc;
   }
+  if (flag) __atomic_store_n(flag, fv, __ATOMIC_RELEASE);
   return C8P_OK;
 }
 void* c8p_host_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
