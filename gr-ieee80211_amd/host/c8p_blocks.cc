@@ -313,10 +313,8 @@ public:
     c.abi_version = C8P_ABI_VERSION; c.device = cfg.device;
     d_ctx = d_api.create(&c);
     if (!d_ctx) throw std::runtime_error("c8p_create failed: no usable HIP device (there is no CPU fallback)");
-    // The fronts submit batch i+1 before they collect batch i, which needs the result arenas of TWO submits to stay resident.
-    // The engine keeps C8P_SLOTS of them (default 3; documented values start at 1): with one slot the previous batch is collected first.
-    const char* e = getenv("C8P_SLOTS");
-    d_two_resident = !(e && atoi(e) == 1);
+    // (The fronts keep several batches in flight; everything they need of a batch is downloaded behind its kernels, so the engine's
+    // result arenas need not stay resident: any C8P_SLOTS works — with one slot a submit waits inside the engine for its predecessor.)
   }
   ~engine_holder() { if (d_ctx) d_api.destroy(d_ctx); }
   void check(int rc, const char* what = "")
@@ -350,7 +348,6 @@ public:
   c8p_api d_api;
   batching_cfg d_cfg;
   c8p_ctx* d_ctx = nullptr;
-  bool d_two_resident = true;
 };
 typedef engine_holder::dev_buf dev_buf;
 
@@ -434,14 +431,20 @@ class demod_front : public demod, public demod2
 {
 public:
   demod_front(int nports, int mupos, int mugid, const c8p_api& api, const batching_cfg& cfg)
-      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)},
+      : d_eng(api, cfg), d_nports(nports), d_mupos(mupos), d_mugid(mugid),
+        d_st{stage(&d_eng.d_api), stage(&d_eng.d_api), stage(&d_eng.d_api), stage(&d_eng.d_api)},
         d_timer(d_mu, [this](tick_t& w) { return next_deadline(w); }, [this] { on_timer(); })
   {
+    d_st[0].state = stage::FILLING;
+    d_worker = std::thread([this] { worker(); });
     if (cfg.flush_when_idle) d_timer.start();
   }
   ~demod_front() override
   {
     d_timer.stop();
+    { std::lock_guard<std::mutex> g(d_mu); d_quit.store(true); }
+    d_cv_work.notify_all();
+    if (d_worker.joinable()) d_worker.join();
     fused_purge(d_fused_ids);                      // the batches this front parked and no decode picked up
     d_outq.clear(); d_hold.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
     for (stage& st : d_st) { d_eng.dev_release(st.d_iq); d_eng.dev_release(st.d_chan); }
@@ -467,8 +470,11 @@ public:
   int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& output_items) override
   {
-    std::lock_guard<std::mutex> g(d_mu);
+    std::unique_lock<std::mutex> lk(d_mu);
+    d_lk = &lk;
+    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
+    if (!d_werr.empty()) throw std::runtime_error(d_werr);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     if (!d_mode_known) {
       d_in_dev = d_eng.d_cfg.pinned_io;
@@ -543,44 +549,35 @@ public:
     }
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
-    const bool pending = !d_st[d_fill].pk.empty() || d_st[d_fill ^ 1].ticket != 0;
-    if (pending) d_timer.poke();
+    if (!d_st[d_fill].pk.empty()) d_timer.poke();
     if (d_out_dev) return produced;
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    std::lock_guard<std::mutex> g(d_mu);
+    std::unique_lock<std::mutex> lk(d_mu);
+    d_lk = &lk;
+    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
     if (!d_st[d_fill].pk.empty()) submit(true);
-    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+    while (!d_fly.empty() && d_werr.empty()) d_cv_done.wait(lk);      // everything in flight has been replayed
+    if (!d_werr.empty()) throw std::runtime_error(d_werr);
   }
 
-  // the timer thread (holds d_mu): when does the oldest thing this front is sitting on reach max_wait_us?
+  // the timer thread (holds d_mu): when has the batch being gathered waited max_wait_us?  (Batches in flight need no deadline: the
+  // completion thread replays each the moment its results are in host memory.)
   bool next_deadline(tick_t& when)
   {
-    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
-    bool have = false;
-    if (!d_st[d_fill].pk.empty()) { when = d_st[d_fill].t_first + w; have = true; }
-    const stage& fl = d_st[d_fill ^ 1];
-    if (fl.ticket && (!have || fl.t_submit + w < when)) { when = fl.t_submit + w; have = true; }
-    return have;
+    if (d_st[d_fill].pk.empty() || free_stage() < 0) return false;       // (no stage to go on with: the completion thread pokes when one frees up)
+    when = d_st[d_fill].t_first + std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    return true;
   }
-  void on_timer()
-  {
-    const size_t before = d_outq.size();
-    age_check();
-    if (d_outq.size() > before && d_io) d_io->wake();      // no input is coming that would get general_work called: ask for a call
-  }
+  void on_timer() { age_check(); }
 
-  // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us (asynchronously: its
-  // predecessor is collected, it stays in flight); a batch in flight is collected once it is that old
+  // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us
   void age_check()
   {
-    const long w = d_eng.d_cfg.max_wait_us;
-    if (!d_st[d_fill].pk.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
-    stage& fl = d_st[d_fill ^ 1];
-    if (fl.ticket && us_since(fl.t_submit) >= w) collect(fl);
+    if (!d_st[d_fill].pk.empty() && us_since(d_st[d_fill].t_first) >= d_eng.d_cfg.max_wait_us && (d_lk || free_stage() >= 0)) submit(false);
   }
 
 private:
@@ -592,16 +589,20 @@ private:
     dev_buf dev_llr;                  // pinned output buffer: a device copy of the LLR arena (the engine's own is recycled with its slot)
   };
   struct stage {              // one batch being gathered / in flight: its arenas must stay untouched until the submit has completed
-    explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a) {}
+    explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a), muchan(a), flag(a) {}
+    enum { FREE, FILLING, INFLIGHT } state = FREE;      // FILLING: the scheduler thread's; INFLIGHT: the completion thread's
     pinned_vec<gr_complex> iq, chan;    // host staging (iq: pageable input buffers only)
     dev_buf d_iq, d_chan;               // pinned input buffers: the batch's arenas on the device, filled by the gathers
     size_t iq_items = 0;                // ... and the items laid out in d_iq so far
     std::vector<c8p_pkt_in> pk;
-    int ticket = 0;
     tick_t t_first, t_submit;   // when the first packet was complete / when the batch was submitted
-    pinned_vec<c8p_pkt_tags> tags;      // downloads enqueued at submit time, right behind the kernels: they run while the
-    std::shared_ptr<result> res;        // next batch is being gathered; collect() only waits
+    pinned_vec<c8p_pkt_tags> tags;      // downloads enqueued at submit time, right behind the kernels (one c8p_fetch_gather): they run while
+    pinned_vec<gr_complex> muchan;      // the next batches are gathered; the NDP captures ride along (1 KB per packet)
+    pinned_vec<uint32_t> flag;          // ... and behind them the engine writes flag_want here: the completion thread polls this word
+    uint32_t flag_want = 0;
+    std::shared_ptr<result> res;
     std::shared_ptr<fused_batch> fb;    // fused mode: the decoded results, handed to decode as they are
+    long fb_id = 0;
   };
   struct out_pkt {
     std::vector<std::pair<std::string, tag_value>> tags;
@@ -656,8 +657,15 @@ private:
     return r;
   }
 
-  // submit the batch being gathered; while full batches follow each other (last = false) the previous one is collected
-  // only now, after its successor has been enqueued
+  int free_stage() const
+  {
+    for (int i = 0; i < NST; i++) if (d_st[i].state == stage::FREE) return i;
+    return -1;
+  }
+
+  // Submit the batch being gathered and go on with a free stage.  Nothing is collected here: the batch's downloads and a completion
+  // word follow its kernels (c8p_fetch_gather), and the completion thread replays it when the word arrives.  The caller holds d_mu;
+  // general_work / flush may wait for a stage (d_lk), the timer only submits when one is free.  last: return when nothing is in flight.
   void submit(bool last)
   {
     stage& st = d_st[d_fill];
@@ -672,7 +680,6 @@ private:
       }
       part_chan.assign(st.chan.data() + d_cur.chan_off, st.chan.data() + d_cur.chan_off + 64);
     }
-    if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_batch_in b;
     memset(&b, 0, sizeof(b));
     b.n_pkt = (int32_t)st.pk.size(); b.pkts = st.pk.data();
@@ -694,32 +701,36 @@ private:
     }
     sub_scope ph(d_ph, phase_clock::SUBMIT);
     d_eng.check(d_eng.d_cfg.fused ? A.rx(d_eng.d_ctx, &b) : A.demod(d_eng.d_ctx, &b));
-    st.ticket = A.ticket(d_eng.d_ctx);
     st.t_submit = now_tick();
     {
       sub_scope phq(d_ph, phase_clock::ENQ);
-      // the batch's downloads — tags; fused mode: per-packet results + the PDU arena — with ONE launch behind its kernels
-      // (c8p_fetch_gather: the device writes the pinned buffers; three hipMemcpyAsync cost 15 us of this thread per batch, and on some
-      // boxes the first of them ~0.1 ms); collect() only waits
-      st.tags.resize_uninit(st.pk.size());
-      c8p_fetch_piece fp[3];
+      // the batch's downloads — tags, NDP captures; fused mode: per-packet results + the PDU arena — and, behind them, the completion
+      // word, with ONE launch behind its kernels (c8p_fetch_gather: the device writes the pinned buffers)
+      const size_t n = st.pk.size();
+      st.tags.resize_uninit(n);
+      st.muchan.resize_uninit(128 * n);
+      if (st.flag.empty()) st.flag.resize_uninit(1);
+      st.flag_want = ++d_flag_seq ? d_flag_seq : ++d_flag_seq;      // never 0
+      __atomic_store_n(st.flag.data(), 0u, __ATOMIC_RELAXED);
+      c8p_fetch_piece fp[5];
       int nfp = 0;
-      auto piece = [&](int which, void* dst, uint64_t bytes) {
+      auto piece = [&](int which, void* dst, uint64_t bytes, uint64_t off) {
         c8p_fetch_piece& f = fp[nfp++];
         memset(&f, 0, sizeof(f));
-        f.which = which; f.offset = 0; f.bytes = bytes; f.dst = dst;
+        f.which = which; f.offset = off; f.bytes = bytes; f.dst = dst;
       };
-      piece(C8P_BUF_TAGS, st.tags.data(), st.pk.size() * sizeof(c8p_pkt_tags));
+      piece(C8P_BUF_TAGS, st.tags.data(), n * sizeof(c8p_pkt_tags), 0);
+      piece(C8P_BUF_MUCHAN, st.muchan.data(), n * 128 * sizeof(gr_complex), 0);
       uint64_t bytes = 0, pbytes = 0;
       {
         sub_scope pha(d_ph, phase_clock::ALLOC);
         if (!d_eng.d_cfg.fused) {
           A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
-          st.res = acquire(bytes / sizeof(float), st.pk.size());
+          st.res = acquire(bytes / sizeof(float), n);
           if (!d_out_dev) st.res->llr.resize_uninit(bytes / sizeof(float));
         } else {
           A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
-          st.fb = acquire_fused(st.pk.size(), pbytes);
+          st.fb = acquire_fused(n, pbytes);
         }
       }
       if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use):
@@ -727,62 +738,107 @@ private:
         // (a pinned one: drain_scatter() moves the items from there, however long the scheduler takes to offer the space)
         if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, d_out_dev ? st.res->dev_llr.p : (void*)st.res->llr.data(), 0, bytes), "llr");
       } else {
-        piece(C8P_BUF_OUT, st.fb->outs.data(), st.pk.size() * sizeof(c8p_pkt_out));
-        if (pbytes) piece(C8P_BUF_PDU, st.fb->pdu.data(), pbytes & ~(uint64_t)3);
+        piece(C8P_BUF_OUT, st.fb->outs.data(), n * sizeof(c8p_pkt_out), 0);
+        if (pbytes) piece(C8P_BUF_PDU, st.fb->pdu.data(), pbytes & ~(uint64_t)3, 0);
       }
+      piece(C8P_BUF_FLAG, st.flag.data(), 0, st.flag_want);
       d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, nfp), "c8p_fetch_gather");
     }
     ph.end();
-    stage& prev = d_st[d_fill ^ 1];
-    if (prev.ticket) collect(prev);
-    if (last) collect(st);
-    else d_fill ^= 1;
-    // (device arenas: a packet that is still being received always moves to the OTHER stage's arena — collected above, so free —
-    // and never inside one arena, where source and destination could overlap)
-    if (last && d_state == S_COLLECT && d_in_dev) d_fill ^= 1;
+    // hand the batch to the completion thread; go on with a free stage (wait for one if every other stage is in flight)
+    const int old = d_fill;
+    st.state = stage::INFLIGHT;
+    d_fly.push_back(old);
+    d_cv_work.notify_one();
+    int nx = free_stage();
+    if (nx < 0 || last) {
+      sub_scope pw(d_ph, phase_clock::WAIT);
+      if (!d_lk) throw std::runtime_error("c8p_blocks: submit without a free stage from a caller that cannot wait");
+      while ((((nx = free_stage()) < 0) || (last && !d_fly.empty())) && d_werr.empty()) d_cv_done.wait(*d_lk);
+      if (!d_werr.empty()) throw std::runtime_error(d_werr);
+    }
+    // (device arenas: a packet that is still being received always moves to ANOTHER stage's arena, never inside one)
+    if (nx == old) { for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; } }
+    d_st[nx].state = stage::FILLING;
+    d_fill = nx;
     if (d_state == S_COLLECT) {
-      stage& nx = d_st[d_fill];
-      d_cur.chan_off = (uint32_t)nx.chan.size();
-      memcpy(static_cast<void*>(nx.chan.grow(64)), part_chan.data(), 64 * sizeof(gr_complex));
+      stage& from = d_st[old];
+      stage& to = d_st[nx];
+      d_cur.chan_off = (uint32_t)to.chan.size();
+      memcpy(static_cast<void*>(to.chan.grow(64)), part_chan.data(), 64 * sizeof(gr_complex));
       for (int p = 0; p < d_nports; p++) {
-        d_cur.iq_off[p] = iq_alloc(nx, d_cur.n_items);
+        d_cur.iq_off[p] = iq_alloc(to, d_cur.n_items);
         if (!d_have) continue;
-        if (!d_in_dev) memcpy(static_cast<void*>(nx.iq.data() + d_cur.iq_off[p]), part_iq[p].data(), sizeof(gr_complex) * (size_t)d_have);
+        if (!d_in_dev) memcpy(static_cast<void*>(to.iq.data() + d_cur.iq_off[p]), part_iq[p].data(), sizeof(gr_complex) * (size_t)d_have);
         else                                                        // device to device, behind the gathers that brought the items
-          d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<gr_complex*>(nx.d_iq.p) + d_cur.iq_off[p],
-                                   static_cast<const gr_complex*>(st.d_iq.p) + part_off[p], sizeof(gr_complex) * (size_t)d_have), "partial packet move");
+          d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<gr_complex*>(to.d_iq.p) + d_cur.iq_off[p],
+                                   static_cast<const gr_complex*>(from.d_iq.p) + part_off[p], sizeof(gr_complex) * (size_t)d_have), "partial packet move");
       }
     }
   }
 
-  void collect(stage& st)
+  // The completion thread: batches in submit order; polls the batch's completion word (pinned host memory the engine writes behind the
+  // batch's kernels and downloads — no call into the engine, whose contexts are not locked), replays the batch into out-packets WITHOUT
+  // the front's mutex, then hands them over under it and frees the stage.
+  void worker()
   {
-    const c8p_api& A = d_eng.d_api;
-    c8p_ctx* ctx = d_eng.d_ctx;
-    const size_t n = st.pk.size();
-    {
-      sub_scope ph(d_ph, phase_clock::WAIT);
-      d_eng.check(A.wait(ctx, st.ticket), "wait");               // kernels + the downloads enqueued behind them
+    std::unique_lock<std::mutex> lk(d_mu);
+    while (!d_quit.load()) {
+      if (d_fly.empty()) { d_cv_work.wait(lk); continue; }
+      stage& st = d_st[d_fly.front()];
+      lk.unlock();
+      std::vector<out_pkt> local;
+      std::string err;
+      try {
+        int spins = 0;
+        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want && !d_quit.load()) {
+          if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
+          if (us_since(st.t_submit) > 20000000) throw std::runtime_error("c8p_blocks: a batch's completion word did not arrive within 20 s");
+        }
+        if (!d_quit.load()) replay(st, local);
+      } catch (const std::exception& e) { err = e.what(); }
+      lk.lock();
+      if (d_quit.load()) break;
+      if (!err.empty()) { d_werr = err; d_cv_done.notify_all(); break; }
+      const bool was_empty = d_outq.empty();
+      for (out_pkt& o : local) d_outq.push_back(std::move(o));
+      if (d_eng.d_cfg.fused) {
+        d_fused_ids.push_back(st.fb_id);
+        if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
+      }
+      st.res.reset(); st.fb.reset();
+      st.pk.clear(); st.iq.clear(); st.chan.clear(); st.iq_items = 0;
+      st.state = stage::FREE;
+      d_fly.pop_front();
+      d_ph.us[phase_clock::REPLAY] += d_replay_us; d_replay_us = 0;
+      d_cv_done.notify_all();
+      d_timer.poke();                              // (a stage is free: a batch that has waited its time can go now)
+      if (was_empty && !d_outq.empty() && d_io) { lk.unlock(); d_io->wake(); lk.lock(); }      // no input may be coming that would get general_work called
     }
-    sub_scope ph(d_ph, phase_clock::REPLAY);
+  }
+
+  // one completed batch -> out-packets (the reference's tags, and where its LLR items are).  Completion thread, no lock held: reads the
+  // stage's downloads, touches nothing the scheduler thread uses.
+  void replay(stage& st, std::vector<out_pkt>& out)
+  {
+    const tick_t t0 = now_tick();
+    const size_t n = st.pk.size();
     const c8p_pkt_tags* tags = st.tags.data();
     const bool fused = d_eng.d_cfg.fused;
     std::shared_ptr<result> res = st.res;
-    st.res.reset();
     long fb_id = 0;
     if (fused) {                                   // the whole batch behind ONE handle; a packet's tag names its index
       fb_id = g_fused_next.fetch_add(1);
-      d_fused_ids.push_back(fb_id);
-      if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
+      st.fb_id = fb_id;
       fused_park(fb_id, st.fb);
-      st.fb.reset();
     }
-    bool selected = false;
+    out.reserve(n);
     for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = tags[p];
       if (t.status != C8P_ST_OK) continue;          // DEMOD_S_CLEAN without tags: nothing reaches decode
-      d_outq.emplace_back();
-      out_pkt& o = d_outq.back();
+      out.emplace_back();
+      out_pkt& o = out.back();
       o.tags.reserve(16);
       auto L = [&](const char* k, long v) { o.tags.emplace_back(k, tag_value::from_long(v)); };
       auto F = [&](const char* k, float v) { o.tags.emplace_back(k, tag_value::from_float(v)); };
@@ -791,9 +847,7 @@ private:
       F("rssi", t.rssi);
       L("format", t.format); L("mcs", t.mcs); L("len", t.len); L("cr", t.cr); L("ampdu", t.ampdu); L("trellis", t.trellis);
       if (t.is_ndp) {
-        std::vector<gr_complex> c(128);
-        if (!selected) { d_eng.check(A.select(ctx, st.ticket), "select"); selected = true; }
-        d_eng.check(A.fetch(ctx, C8P_BUF_MUCHAN, c.data(), 128 * p * sizeof(gr_complex), 128 * sizeof(gr_complex)));
+        std::vector<gr_complex> c(st.muchan.data() + 128 * p, st.muchan.data() + 128 * p + 128);
         o.tags.emplace_back("mu2x1chan", tag_value::from_c32vector(c));
       }
       L("total", t.total);
@@ -803,7 +857,7 @@ private:
         o.llr = (d_out_dev ? static_cast<const float*>(res->dev_llr.p) : res->llr.data()) + t.llr_off;
       } else L("c8p_fused", (fb_id << C8P_FUSED_IDX_BITS) | (long)p);
     }
-    st.pk.clear(); st.iq.clear(); st.chan.clear(); st.iq_items = 0; st.ticket = 0;
+    d_replay_us += std::chrono::duration<double, std::micro>(now_tick() - t0).count();
   }
 
   int drain(float* out, int noutput_items)
@@ -878,8 +932,17 @@ private:
   bool d_mode_known = false, d_in_dev = false, d_out_dev = false;     // pinned scheduler buffers on the input ports / the output port
   c8p_pkt_in d_cur;
   int d_have = 0;
-  stage d_st[2];
-  int d_fill = 0;                                  // the stage being gathered; the other one may be in flight
+  enum { NST = 4 };
+  stage d_st[NST];
+  int d_fill = 0;                                  // the stage being gathered (FILLING); d_fly: the ones in flight, in submit order
+  std::deque<int> d_fly;
+  std::unique_lock<std::mutex>* d_lk = nullptr;    // the lock of the caller that may wait inside submit (general_work / flush; not the timer)
+  std::condition_variable d_cv_work, d_cv_done;    // a batch went in flight / a stage became free
+  std::thread d_worker;
+  std::atomic<bool> d_quit{false};
+  std::string d_werr;                              // an error met on the completion thread: thrown by the next general_work
+  uint32_t d_flag_seq = 0;
+  double d_replay_us = 0;                          // (completion thread's clock, folded into d_ph under the mutex)
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   std::vector<c8p_piece> d_opieces;
@@ -1154,17 +1217,22 @@ class decode_front : public decode
 {
 public:
   decode_front(bool ifdebug, const c8p_api& api, const batching_cfg& cfg)
-      : d_eng(api, cfg), d_debug(ifdebug), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api)},
+      : d_eng(api, cfg), d_debug(ifdebug), d_st{stage(&d_eng.d_api), stage(&d_eng.d_api), stage(&d_eng.d_api), stage(&d_eng.d_api)},
         d_timer(d_mu, [this](tick_t& w) { return next_deadline(w); }, [this] { age_check(); })
   {
     memset(d_vhtMcsCount, 0, sizeof(d_vhtMcsCount));
     memset(d_legacyMcsCount, 0, sizeof(d_legacyMcsCount));
     memset(d_htMcsCount, 0, sizeof(d_htMcsCount));
-    if (cfg.flush_when_idle) d_timer.start();       // (its results are messages: published from the timer thread, no call needed)
+    d_st[0].state = stage::FILLING;
+    d_worker = std::thread([this] { worker(); });      // (its results are messages: published from the completion thread, no call needed)
+    if (cfg.flush_when_idle) d_timer.start();
   }
   ~decode_front() override
   {
     d_timer.stop();
+    { std::lock_guard<std::mutex> g(d_mu); d_quit.store(true); }
+    d_cv_work.notify_all();
+    if (d_worker.joinable()) d_worker.join();
     for (stage& st : d_st) { d_eng.dev_release(st.d_llr); d_eng.dev_release(st.d_mu); }
   }
 
@@ -1184,8 +1252,11 @@ public:
   int general_work(int /*noutput_items*/, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& /*output_items*/) override
   {
-    std::lock_guard<std::mutex> g(d_mu);
+    std::unique_lock<std::mutex> lk(d_mu);
+    d_lk = &lk;
+    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
+    if (!d_werr.empty()) throw std::runtime_error(d_werr);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     if (!d_mode_known) { d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0); d_mode_known = true; }
     const float* in = static_cast<const float*>(input_items[0]);
@@ -1263,48 +1334,46 @@ public:
       cons = d_lane.settle(d_eng, rd, used, d_ph);
     }
     d_io->consume_each(cons);
-    const bool pending = !d_st[d_fill].tags.empty() || d_st[d_fill ^ 1].ticket != 0;
-    if (pending) d_timer.poke();
+    if (!d_st[d_fill].tags.empty()) d_timer.poke();
     return 0;
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    std::lock_guard<std::mutex> g(d_mu);
+    std::unique_lock<std::mutex> lk(d_mu);
+    d_lk = &lk;
+    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
     if (!d_st[d_fill].tags.empty()) submit(true);
-    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+    while (!d_fly.empty() && d_werr.empty()) d_cv_done.wait(lk);      // everything in flight has been published
+    if (!d_werr.empty()) throw std::runtime_error(d_werr);
   }
 
   bool next_deadline(tick_t& when)     // see demod_front
   {
-    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
-    bool have = false;
-    if (!d_st[d_fill].tags.empty()) { when = d_st[d_fill].t_first + w; have = true; }
-    const stage& fl = d_st[d_fill ^ 1];
-    if (fl.ticket && (!have || fl.t_submit + w < when)) { when = fl.t_submit + w; have = true; }
-    return have;
+    if (d_st[d_fill].tags.empty() || free_stage() < 0) return false;
+    when = d_st[d_fill].t_first + std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    return true;
   }
 
   void age_check()           // see demod_front::age_check
   {
-    const long w = d_eng.d_cfg.max_wait_us;
-    if (!d_st[d_fill].tags.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
-    stage& fl = d_st[d_fill ^ 1];
-    if (fl.ticket && us_since(fl.t_submit) >= w) collect(fl);
+    if (!d_st[d_fill].tags.empty() && us_since(d_st[d_fill].t_first) >= d_eng.d_cfg.max_wait_us && (d_lk || free_stage() >= 0)) submit(false);
   }
 
 private:
   struct stage {
-    explicit stage(const c8p_api* a) : llr(a), outs(a), pdu(a) {}
+    explicit stage(const c8p_api* a) : flag(a), llr(a), outs(a), pdu(a) {}
+    enum { FREE, FILLING, INFLIGHT } state = FREE;      // FILLING: the scheduler thread's; INFLIGHT: the completion thread's
+    pinned_vec<uint32_t> flag;        // the engine writes flag_want here behind the batch's kernels and downloads
+    uint32_t flag_want = 0;
     pinned_vec<float> llr;            // host staging (a pageable input buffer only)
     dev_buf d_llr, d_mu;              // a pinned input buffer: the batch's LLR arena on the device, filled by the calls' gathers
     size_t llr_items = 0;
     bool any_mu = false;              // a packet of the batch carries "mu2x1chan" (an NDP): its captures have to travel too
     std::vector<c8p_pkt_tags> tags;
     std::vector<gr_complex> mu;
-    int ticket = 0;
     tick_t t_first, t_submit;
-    pinned_vec<c8p_pkt_out> outs;     // downloads enqueued at submit time, right behind the kernels: collect() only waits
+    pinned_vec<c8p_pkt_out> outs;     // downloads enqueued at submit time, right behind the kernels (one c8p_fetch_gather)
     pinned_vec<uint8_t> pdu;          // (the whole fixed-stride PDU arena: ~1 MB per 256 packets)
   };
 
@@ -1322,6 +1391,13 @@ private:
     return off;
   }
 
+  int free_stage() const
+  {
+    for (int i = 0; i < NST; i++) if (d_st[i].state == stage::FREE) return i;
+    return -1;
+  }
+
+  // see demod_front::submit: nothing is collected here, the completion thread publishes the batch when its completion word arrives
   void submit(bool last)
   {
     stage& st = d_st[d_fill];
@@ -1334,7 +1410,6 @@ private:
       if (!d_in_dev) part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
       part_mu.assign(st.mu.end() - 128, st.mu.end());
     }
-    if (!d_eng.d_two_resident && d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);     // one slot: its arenas are about to be reused
     c8p_decode_in b;
     memset(&b, 0, sizeof(b));
     b.n_pkt = (int32_t)st.tags.size(); b.tags = st.tags.data();
@@ -1360,7 +1435,6 @@ private:
     {
       sub_scope ph(d_ph, phase_clock::SUBMIT);
       d_eng.check(A.decode(d_eng.d_ctx, &b), "decode");
-      st.ticket = A.ticket(d_eng.d_ctx);
       st.t_submit = now_tick();
     }
     {
@@ -1375,44 +1449,79 @@ private:
       st.pdu.reserve(d_hwm_pdu);
       st.outs.resize_uninit(st.tags.size());
       st.pdu.resize_uninit(pbytes);
-      c8p_fetch_piece fp[2];                       // results + PDU arena with one launch behind the kernels (see demod_front::submit)
+      if (st.flag.empty()) st.flag.resize_uninit(1);
+      st.flag_want = ++d_flag_seq ? d_flag_seq : ++d_flag_seq;
+      __atomic_store_n(st.flag.data(), 0u, __ATOMIC_RELAXED);
+      c8p_fetch_piece fp[3];                       // results + PDU arena + the completion word with one launch behind the kernels
       memset(fp, 0, sizeof(fp));
-      fp[0].which = C8P_BUF_OUT; fp[0].bytes = st.tags.size() * sizeof(c8p_pkt_out); fp[0].dst = st.outs.data();
-      fp[1].which = C8P_BUF_PDU; fp[1].bytes = pbytes & ~(uint64_t)3; fp[1].dst = st.pdu.data();
-      d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, pbytes ? 2 : 1), "c8p_fetch_gather");
+      int nfp = 0;
+      fp[nfp].which = C8P_BUF_OUT; fp[nfp].bytes = st.tags.size() * sizeof(c8p_pkt_out); fp[nfp].dst = st.outs.data(); nfp++;
+      if (pbytes) { fp[nfp].which = C8P_BUF_PDU; fp[nfp].bytes = pbytes & ~(uint64_t)3; fp[nfp].dst = st.pdu.data(); nfp++; }
+      fp[nfp].which = C8P_BUF_FLAG; fp[nfp].offset = st.flag_want; fp[nfp].dst = st.flag.data(); nfp++;
+      d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, nfp), "c8p_fetch_gather");
     }
-    stage& prev = d_st[d_fill ^ 1];
-    if (prev.ticket) collect(prev);
-    if (last) collect(st);
-    else d_fill ^= 1;
-    if (last && part && d_in_dev) d_fill ^= 1;      // (see demod_front::submit: never a move inside one device arena)
+    const int old = d_fill;
+    st.state = stage::INFLIGHT;
+    d_fly.push_back(old);
+    d_cv_work.notify_one();
+    int nx = free_stage();
+    if (nx < 0 || last) {
+      sub_scope pw(d_ph, phase_clock::WAIT);
+      if (!d_lk) throw std::runtime_error("c8p_blocks: submit without a free stage from a caller that cannot wait");
+      while ((((nx = free_stage()) < 0) || (last && !d_fly.empty())) && d_werr.empty()) d_cv_done.wait(*d_lk);
+      if (!d_werr.empty()) throw std::runtime_error(d_werr);
+    }
+    if (nx == old) { for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; } }
+    d_st[nx].state = stage::FILLING;
+    d_fill = nx;
     if (part) {
-      stage& nx = d_st[d_fill];
-      d_cur.llr_off = llr_alloc(nx, (size_t)std::max(d_cur.total, 0));
+      stage& from = d_st[old];
+      stage& to = d_st[nx];
+      d_cur.llr_off = llr_alloc(to, (size_t)std::max(d_cur.total, 0));
       if (d_have) {
-        if (!d_in_dev) memcpy(nx.llr.data() + d_cur.llr_off, part_llr.data(), sizeof(float) * (size_t)d_have);
-        else d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<float*>(nx.d_llr.p) + d_cur.llr_off, static_cast<const float*>(st.d_llr.p) + part_off,
+        if (!d_in_dev) memcpy(to.llr.data() + d_cur.llr_off, part_llr.data(), sizeof(float) * (size_t)d_have);
+        else d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<float*>(to.d_llr.p) + d_cur.llr_off, static_cast<const float*>(from.d_llr.p) + part_off,
                                       sizeof(float) * (size_t)d_have), "partial packet move");
       }
-      if (d_cur_mu) nx.any_mu = true;
-      nx.mu.insert(nx.mu.end(), part_mu.begin(), part_mu.end());
+      if (d_cur_mu) to.any_mu = true;
+      to.mu.insert(to.mu.end(), part_mu.begin(), part_mu.end());
     }
   }
 
-  void collect(stage& st)
+  // the completion thread (see demod_front::worker): publishes a batch's PDUs and debug lines when its completion word has arrived
+  void worker()
   {
-    const c8p_api& A = d_eng.d_api;
-    c8p_ctx* ctx = d_eng.d_ctx;
-    const size_t n = st.tags.size();
-    {
-      sub_scope ph(d_ph, phase_clock::WAIT);
-      d_eng.check(A.wait(ctx, st.ticket), "wait");
+    std::unique_lock<std::mutex> lk(d_mu);
+    while (!d_quit.load()) {
+      if (d_fly.empty()) { d_cv_work.wait(lk); continue; }
+      stage& st = d_st[d_fly.front()];
+      lk.unlock();
+      std::string err;
+      double us = 0;
+      try {
+        int spins = 0;
+        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want && !d_quit.load()) {
+          if (++spins < 2000) { __builtin_ia32_pause(); continue; }
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
+          if (us_since(st.t_submit) > 20000000) throw std::runtime_error("c8p_blocks: a batch's completion word did not arrive within 20 s");
+        }
+        if (!d_quit.load()) {
+          const tick_t t0 = now_tick();
+          const size_t n = st.tags.size();
+          for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], st.outs.data()[p], st.pdu.data());
+          us = std::chrono::duration<double, std::micro>(now_tick() - t0).count();
+        }
+      } catch (const std::exception& e) { err = e.what(); }
+      lk.lock();
+      if (d_quit.load()) break;
+      if (!err.empty()) { d_werr = err; d_cv_done.notify_all(); break; }
+      st.tags.clear(); st.llr.clear(); st.mu.clear(); st.llr_items = 0; st.any_mu = false;
+      st.state = stage::FREE;
+      d_fly.pop_front();
+      d_ph.us[phase_clock::REPLAY] += us;
+      d_cv_done.notify_all();
+      d_timer.poke();
     }
-    const c8p_pkt_out* outs = st.outs.data();
-    const uint8_t* pdu = st.pdu.data();
-    sub_scope phr(d_ph, phase_clock::REPLAY);
-    for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], outs[p], pdu);
-    st.tags.clear(); st.llr.clear(); st.mu.clear(); st.llr_items = 0; st.any_mu = false; st.ticket = 0;
   }
 
   // one packet's records {u16 len, blob} out of a PDU arena -> messages, with the reference's debug lines
@@ -1435,7 +1544,8 @@ private:
   void publish_fused()
   {
     if (!d_st[d_fill].tags.empty()) submit(true);
-    else if (d_st[d_fill ^ 1].ticket) collect(d_st[d_fill ^ 1]);
+    while (!d_fly.empty() && d_werr.empty()) { sub_scope pw(d_ph, phase_clock::WAIT); d_cv_done.wait(*d_lk); }
+    if (!d_werr.empty()) throw std::runtime_error(d_werr);
     const long id = d_cur_fused >> C8P_FUSED_IDX_BITS;
     const size_t idx = (size_t)(d_cur_fused & ((1L << C8P_FUSED_IDX_BITS) - 1));
     if (id != d_fb_id) {                           // the next batch: the one before it has been published, it leaves the registry
@@ -1483,8 +1593,16 @@ private:
   long d_fb_id = 0;                                // fused mode: the batch whose packets are arriving
   std::shared_ptr<fused_batch> d_fb;
   pdu_t d_msg;                                     // (reused: its blob keeps its capacity)
-  stage d_st[2];
-  int d_fill = 0;
+  enum { NST = 4 };
+  stage d_st[NST];
+  int d_fill = 0;                                  // the stage being gathered; d_fly: the ones in flight, in submit order
+  std::deque<int> d_fly;
+  std::unique_lock<std::mutex>* d_lk = nullptr;    // the lock of the caller that may wait inside submit (general_work / flush; not the timer)
+  std::condition_variable d_cv_work, d_cv_done;
+  std::thread d_worker;
+  std::atomic<bool> d_quit{false};
+  std::string d_werr;
+  uint32_t d_flag_seq = 0;
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
