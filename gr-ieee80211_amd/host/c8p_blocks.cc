@@ -436,15 +436,14 @@ public:
         d_timer(d_mu, [this](tick_t& w) { return next_deadline(w); }, [this] { on_timer(); })
   {
     d_st[0].state = stage::FILLING;
-    d_worker = std::thread([this] { worker(); });
+    // batches in flight: one less than the engine keeps slots (a submit into a slot whose batch is still running blocks inside the
+    // engine), at least one, at most the ring allows
+    d_max_fly = (int)std::max<int64_t>(1, std::min<int64_t>(NST - 1, api.counter(d_eng.d_ctx, C8P_CNT_SLOTS) - 1));
     if (cfg.flush_when_idle) d_timer.start();
   }
   ~demod_front() override
   {
     d_timer.stop();
-    { std::lock_guard<std::mutex> g(d_mu); d_quit.store(true); }
-    d_cv_work.notify_all();
-    if (d_worker.joinable()) d_worker.join();
     fused_purge(d_fused_ids);                      // the batches this front parked and no decode picked up
     d_outq.clear(); d_hold.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
     for (stage& st : d_st) { d_eng.dev_release(st.d_iq); d_eng.dev_release(st.d_chan); }
@@ -470,12 +469,10 @@ public:
   int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& output_items) override
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    d_lk = &lk;
-    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
-    if (!d_werr.empty()) throw std::runtime_error(d_werr);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
+    reap(false);                                   // batches whose completion word has arrived: their packets join the output queue
     if (!d_mode_known) {
       d_in_dev = d_eng.d_cfg.pinned_io;
       for (int p = 0; p < d_nports; p++) d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p);
@@ -549,35 +546,45 @@ public:
     }
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
-    if (!d_st[d_fill].pk.empty()) d_timer.poke();
+    if (!d_st[d_fill].pk.empty() || !d_fly.empty()) d_timer.poke();
     if (d_out_dev) return produced;
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    d_lk = &lk;
-    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_st[d_fill].pk.empty()) submit(true);
-    while (!d_fly.empty() && d_werr.empty()) d_cv_done.wait(lk);      // everything in flight has been replayed
-    if (!d_werr.empty()) throw std::runtime_error(d_werr);
+    while (!d_fly.empty()) reap(true);             // everything in flight has been replayed
   }
 
-  // the timer thread (holds d_mu): when has the batch being gathered waited max_wait_us?  (Batches in flight need no deadline: the
-  // completion thread replays each the moment its results are in host memory.)
+  // the timer thread (holds d_mu): when does the oldest thing this front is sitting on reach max_wait_us?
   bool next_deadline(tick_t& when)
   {
-    if (d_st[d_fill].pk.empty() || free_stage() < 0) return false;       // (no stage to go on with: the completion thread pokes when one frees up)
-    when = d_st[d_fill].t_first + std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
-    return true;
+    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    bool have = false;
+    if (!d_st[d_fill].pk.empty()) { when = d_st[d_fill].t_first + w; have = true; }
+    if (!d_fly.empty()) {
+      const stage& fl = d_st[d_fly.front()];
+      if (!have || fl.t_submit + w < when) { when = fl.t_submit + w; have = true; }
+    }
+    return have;
   }
-  void on_timer() { age_check(); }
+  void on_timer()
+  {
+    const size_t before = d_outq.size();
+    age_check();
+    if (d_outq.size() > before && d_io) d_io->wake();      // no input is coming that would get general_work called: ask for a call
+  }
 
-  // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us
+  // latency bound: a gathered batch is submitted once its first packet has waited max_wait_us (it stays in flight); a batch in flight
+  // is replayed when its completion word is there, and waited for once it is that old
   void age_check()
   {
-    if (!d_st[d_fill].pk.empty() && us_since(d_st[d_fill].t_first) >= d_eng.d_cfg.max_wait_us && (d_lk || free_stage() >= 0)) submit(false);
+    const long w = d_eng.d_cfg.max_wait_us;
+    if (!d_st[d_fill].pk.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
+    reap(false);
+    if (!d_fly.empty() && us_since(d_st[d_fly.front()].t_submit) >= w) reap(true);
   }
 
 private:
@@ -590,7 +597,7 @@ private:
   };
   struct stage {              // one batch being gathered / in flight: its arenas must stay untouched until the submit has completed
     explicit stage(const c8p_api* a) : iq(a), chan(a), tags(a), muchan(a), flag(a) {}
-    enum { FREE, FILLING, INFLIGHT } state = FREE;      // FILLING: the scheduler thread's; INFLIGHT: the completion thread's
+    enum { FREE, FILLING, INFLIGHT } state = FREE;
     pinned_vec<gr_complex> iq, chan;    // host staging (iq: pageable input buffers only)
     dev_buf d_iq, d_chan;               // pinned input buffers: the batch's arenas on the device, filled by the gathers
     size_t iq_items = 0;                // ... and the items laid out in d_iq so far
@@ -598,7 +605,7 @@ private:
     tick_t t_first, t_submit;   // when the first packet was complete / when the batch was submitted
     pinned_vec<c8p_pkt_tags> tags;      // downloads enqueued at submit time, right behind the kernels (one c8p_fetch_gather): they run while
     pinned_vec<gr_complex> muchan;      // the next batches are gathered; the NDP captures ride along (1 KB per packet)
-    pinned_vec<uint32_t> flag;          // ... and behind them the engine writes flag_want here: the completion thread polls this word
+    pinned_vec<uint32_t> flag;          // ... and behind them the engine writes flag_want here: reap() looks at this word
     uint32_t flag_want = 0;
     std::shared_ptr<result> res;
     std::shared_ptr<fused_batch> fb;    // fused mode: the decoded results, handed to decode as they are
@@ -663,11 +670,13 @@ private:
     return -1;
   }
 
-  // Submit the batch being gathered and go on with a free stage.  Nothing is collected here: the batch's downloads and a completion
-  // word follow its kernels (c8p_fetch_gather), and the completion thread replays it when the word arrives.  The caller holds d_mu;
-  // general_work / flush may wait for a stage (d_lk), the timer only submits when one is free.  last: return when nothing is in flight.
+  // Submit the batch being gathered and go on with a free stage.  The batch's downloads and a completion word follow its kernels
+  // (c8p_fetch_gather); reap() replays it once the word has arrived — the engine is not asked (no c8p_wait: a stream synchronisation
+  // costs 5-10 us a batch even when the batch is long done).  At most d_max_fly batches are in flight: the oldest is waited for first.
+  // last: return when nothing is in flight.
   void submit(bool last)
   {
+    while ((int)d_fly.size() >= d_max_fly) reap(true);
     stage& st = d_st[d_fill];
     const c8p_api& A = d_eng.d_api;
     // a packet that is still being received lives at the end of this stage's arenas: it moves to the next stage
@@ -745,20 +754,15 @@ private:
       d_eng.check(A.fetch_gather(d_eng.d_ctx, fp, nfp), "c8p_fetch_gather");
     }
     ph.end();
-    // hand the batch to the completion thread; go on with a free stage (wait for one if every other stage is in flight)
+    // the batch is in flight; go on with a free stage (there is one: the ring has more stages than batches may be in flight)
     const int old = d_fill;
     st.state = stage::INFLIGHT;
     d_fly.push_back(old);
-    d_cv_work.notify_one();
-    int nx = free_stage();
-    if (nx < 0 || last) {
-      sub_scope pw(d_ph, phase_clock::WAIT);
-      if (!d_lk) throw std::runtime_error("c8p_blocks: submit without a free stage from a caller that cannot wait");
-      while ((((nx = free_stage()) < 0) || (last && !d_fly.empty())) && d_werr.empty()) d_cv_done.wait(*d_lk);
-      if (!d_werr.empty()) throw std::runtime_error(d_werr);
-    }
+    if (last) while (!d_fly.empty()) reap(true);
+    int nx = -1;
     // (device arenas: a packet that is still being received always moves to ANOTHER stage's arena, never inside one)
-    if (nx == old) { for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; } }
+    for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; }
+    if (nx < 0) throw std::runtime_error("c8p_blocks: no free stage");
     d_st[nx].state = stage::FILLING;
     d_fill = nx;
     if (d_state == S_COLLECT) {
@@ -777,32 +781,28 @@ private:
     }
   }
 
-  // The completion thread: batches in submit order; polls the batch's completion word (pinned host memory the engine writes behind the
-  // batch's kernels and downloads — no call into the engine, whose contexts are not locked), replays the batch into out-packets WITHOUT
-  // the front's mutex, then hands them over under it and frees the stage.
-  void worker()
+  // Replays every in-flight batch whose completion word has arrived, oldest first (block: waits for the oldest one's).  The word is
+  // pinned host memory the engine writes behind the batch's kernels and downloads: a load, no call into the engine.  Caller holds d_mu.
+  bool reap(bool block)
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    while (!d_quit.load()) {
-      if (d_fly.empty()) { d_cv_work.wait(lk); continue; }
+    bool any = false;
+    while (!d_fly.empty()) {
       stage& st = d_st[d_fly.front()];
-      lk.unlock();
-      std::vector<out_pkt> local;
-      std::string err;
-      try {
+      if (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want) {
+        if (!block) break;
+        sub_scope pw(d_ph, phase_clock::WAIT);
         int spins = 0;
-        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want && !d_quit.load()) {
-          if (++spins < 2000) { __builtin_ia32_pause(); continue; }
-          std::this_thread::sleep_for(std::chrono::microseconds(20));
+        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want) {
+          if (++spins < 4000) { __builtin_ia32_pause(); continue; }
+          std::this_thread::sleep_for(std::chrono::microseconds(10));
           if (us_since(st.t_submit) > 20000000) throw std::runtime_error("c8p_blocks: a batch's completion word did not arrive within 20 s");
         }
-        if (!d_quit.load()) replay(st, local);
-      } catch (const std::exception& e) { err = e.what(); }
-      lk.lock();
-      if (d_quit.load()) break;
-      if (!err.empty()) { d_werr = err; d_cv_done.notify_all(); break; }
-      const bool was_empty = d_outq.empty();
-      for (out_pkt& o : local) d_outq.push_back(std::move(o));
+      }
+      block = false;
+      sub_scope ph(d_ph, phase_clock::REPLAY);
+      d_local.clear();
+      replay(st, d_local);
+      for (out_pkt& o : d_local) d_outq.push_back(std::move(o));
       if (d_eng.d_cfg.fused) {
         d_fused_ids.push_back(st.fb_id);
         if (d_fused_ids.size() > 2 * C8P_FUSED_MAX) d_fused_ids.erase(d_fused_ids.begin(), d_fused_ids.begin() + (std::ptrdiff_t)C8P_FUSED_MAX);
@@ -811,18 +811,14 @@ private:
       st.pk.clear(); st.iq.clear(); st.chan.clear(); st.iq_items = 0;
       st.state = stage::FREE;
       d_fly.pop_front();
-      d_ph.us[phase_clock::REPLAY] += d_replay_us; d_replay_us = 0;
-      d_cv_done.notify_all();
-      d_timer.poke();                              // (a stage is free: a batch that has waited its time can go now)
-      if (was_empty && !d_outq.empty() && d_io) { lk.unlock(); d_io->wake(); lk.lock(); }      // no input may be coming that would get general_work called
+      any = true;
     }
+    return any;
   }
 
-  // one completed batch -> out-packets (the reference's tags, and where its LLR items are).  Completion thread, no lock held: reads the
-  // stage's downloads, touches nothing the scheduler thread uses.
+  // one completed batch -> out-packets (the reference's tags, and where its LLR items are)
   void replay(stage& st, std::vector<out_pkt>& out)
   {
-    const tick_t t0 = now_tick();
     const size_t n = st.pk.size();
     const c8p_pkt_tags* tags = st.tags.data();
     const bool fused = d_eng.d_cfg.fused;
@@ -857,7 +853,6 @@ private:
         o.llr = (d_out_dev ? static_cast<const float*>(res->dev_llr.p) : res->llr.data()) + t.llr_off;
       } else L("c8p_fused", (fb_id << C8P_FUSED_IDX_BITS) | (long)p);
     }
-    d_replay_us += std::chrono::duration<double, std::micro>(now_tick() - t0).count();
   }
 
   int drain(float* out, int noutput_items)
@@ -936,13 +931,9 @@ private:
   stage d_st[NST];
   int d_fill = 0;                                  // the stage being gathered (FILLING); d_fly: the ones in flight, in submit order
   std::deque<int> d_fly;
-  std::unique_lock<std::mutex>* d_lk = nullptr;    // the lock of the caller that may wait inside submit (general_work / flush; not the timer)
-  std::condition_variable d_cv_work, d_cv_done;    // a batch went in flight / a stage became free
-  std::thread d_worker;
-  std::atomic<bool> d_quit{false};
-  std::string d_werr;                              // an error met on the completion thread: thrown by the next general_work
+  int d_max_fly = 2;                               // batches in flight at most
+  std::vector<out_pkt> d_local;
   uint32_t d_flag_seq = 0;
-  double d_replay_us = 0;                          // (completion thread's clock, folded into d_ph under the mutex)
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   std::vector<c8p_piece> d_opieces;
@@ -1224,15 +1215,12 @@ public:
     memset(d_legacyMcsCount, 0, sizeof(d_legacyMcsCount));
     memset(d_htMcsCount, 0, sizeof(d_htMcsCount));
     d_st[0].state = stage::FILLING;
-    d_worker = std::thread([this] { worker(); });      // (its results are messages: published from the completion thread, no call needed)
-    if (cfg.flush_when_idle) d_timer.start();
+    d_max_fly = (int)std::max<int64_t>(1, std::min<int64_t>(NST - 1, api.counter(d_eng.d_ctx, C8P_CNT_SLOTS) - 1));
+    if (cfg.flush_when_idle) d_timer.start();       // (its results are messages: published from the timer thread, no call needed)
   }
   ~decode_front() override
   {
     d_timer.stop();
-    { std::lock_guard<std::mutex> g(d_mu); d_quit.store(true); }
-    d_cv_work.notify_all();
-    if (d_worker.joinable()) d_worker.join();
     for (stage& st : d_st) { d_eng.dev_release(st.d_llr); d_eng.dev_release(st.d_mu); }
   }
 
@@ -1252,12 +1240,10 @@ public:
   int general_work(int /*noutput_items*/, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& /*output_items*/) override
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    d_lk = &lk;
-    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
-    if (!d_werr.empty()) throw std::runtime_error(d_werr);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
+    reap(false);                                   // batches whose completion word has arrived are published
     if (!d_mode_known) { d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0); d_mode_known = true; }
     const float* in = static_cast<const float*>(input_items[0]);
     int nproc = ninput_items[0];
@@ -1334,36 +1320,41 @@ public:
       cons = d_lane.settle(d_eng, rd, used, d_ph);
     }
     d_io->consume_each(cons);
-    if (!d_st[d_fill].tags.empty()) d_timer.poke();
+    if (!d_st[d_fill].tags.empty() || !d_fly.empty()) d_timer.poke();
     return 0;
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    d_lk = &lk;
-    struct unset { std::unique_lock<std::mutex>** p; ~unset() { *p = nullptr; } } un{&d_lk};
+    std::lock_guard<std::mutex> g(d_mu);
     if (!d_st[d_fill].tags.empty()) submit(true);
-    while (!d_fly.empty() && d_werr.empty()) d_cv_done.wait(lk);      // everything in flight has been published
-    if (!d_werr.empty()) throw std::runtime_error(d_werr);
+    while (!d_fly.empty()) reap(true);             // everything in flight has been published
   }
 
   bool next_deadline(tick_t& when)     // see demod_front
   {
-    if (d_st[d_fill].tags.empty() || free_stage() < 0) return false;
-    when = d_st[d_fill].t_first + std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
-    return true;
+    const auto w = std::chrono::microseconds(d_eng.d_cfg.max_wait_us);
+    bool have = false;
+    if (!d_st[d_fill].tags.empty()) { when = d_st[d_fill].t_first + w; have = true; }
+    if (!d_fly.empty()) {
+      const stage& fl = d_st[d_fly.front()];
+      if (!have || fl.t_submit + w < when) { when = fl.t_submit + w; have = true; }
+    }
+    return have;
   }
 
   void age_check()           // see demod_front::age_check
   {
-    if (!d_st[d_fill].tags.empty() && us_since(d_st[d_fill].t_first) >= d_eng.d_cfg.max_wait_us && (d_lk || free_stage() >= 0)) submit(false);
+    const long w = d_eng.d_cfg.max_wait_us;
+    if (!d_st[d_fill].tags.empty() && us_since(d_st[d_fill].t_first) >= w) submit(false);
+    reap(false);
+    if (!d_fly.empty() && us_since(d_st[d_fly.front()].t_submit) >= w) reap(true);
   }
 
 private:
   struct stage {
     explicit stage(const c8p_api* a) : flag(a), llr(a), outs(a), pdu(a) {}
-    enum { FREE, FILLING, INFLIGHT } state = FREE;      // FILLING: the scheduler thread's; INFLIGHT: the completion thread's
+    enum { FREE, FILLING, INFLIGHT } state = FREE;
     pinned_vec<uint32_t> flag;        // the engine writes flag_want here behind the batch's kernels and downloads
     uint32_t flag_want = 0;
     pinned_vec<float> llr;            // host staging (a pageable input buffer only)
@@ -1397,9 +1388,10 @@ private:
     return -1;
   }
 
-  // see demod_front::submit: nothing is collected here, the completion thread publishes the batch when its completion word arrives
+  // see demod_front::submit: nothing is collected here, reap() publishes the batch when its completion word has arrived
   void submit(bool last)
   {
+    while ((int)d_fly.size() >= d_max_fly) reap(true);
     stage& st = d_st[d_fill];
     const c8p_api& A = d_eng.d_api;
     const bool part = d_state == S_COLLECT && d_cur_fused < 0;      // a packet still being received moves to the next stage
@@ -1463,15 +1455,10 @@ private:
     const int old = d_fill;
     st.state = stage::INFLIGHT;
     d_fly.push_back(old);
-    d_cv_work.notify_one();
-    int nx = free_stage();
-    if (nx < 0 || last) {
-      sub_scope pw(d_ph, phase_clock::WAIT);
-      if (!d_lk) throw std::runtime_error("c8p_blocks: submit without a free stage from a caller that cannot wait");
-      while ((((nx = free_stage()) < 0) || (last && !d_fly.empty())) && d_werr.empty()) d_cv_done.wait(*d_lk);
-      if (!d_werr.empty()) throw std::runtime_error(d_werr);
-    }
-    if (nx == old) { for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; } }
+    if (last) while (!d_fly.empty()) reap(true);
+    int nx = -1;
+    for (int i = 0; i < NST; i++) if (i != old && d_st[i].state == stage::FREE) { nx = i; break; }      // (never a move inside one device arena)
+    if (nx < 0) throw std::runtime_error("c8p_blocks: no free stage");
     d_st[nx].state = stage::FILLING;
     d_fill = nx;
     if (part) {
@@ -1488,40 +1475,32 @@ private:
     }
   }
 
-  // the completion thread (see demod_front::worker): publishes a batch's PDUs and debug lines when its completion word has arrived
-  void worker()
+  // publishes every in-flight batch whose completion word has arrived, oldest first (see demod_front::reap)
+  bool reap(bool block)
   {
-    std::unique_lock<std::mutex> lk(d_mu);
-    while (!d_quit.load()) {
-      if (d_fly.empty()) { d_cv_work.wait(lk); continue; }
+    bool any = false;
+    while (!d_fly.empty()) {
       stage& st = d_st[d_fly.front()];
-      lk.unlock();
-      std::string err;
-      double us = 0;
-      try {
+      if (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want) {
+        if (!block) break;
+        sub_scope pw(d_ph, phase_clock::WAIT);
         int spins = 0;
-        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want && !d_quit.load()) {
-          if (++spins < 2000) { __builtin_ia32_pause(); continue; }
-          std::this_thread::sleep_for(std::chrono::microseconds(20));
+        while (__atomic_load_n(st.flag.data(), __ATOMIC_ACQUIRE) != st.flag_want) {
+          if (++spins < 4000) { __builtin_ia32_pause(); continue; }
+          std::this_thread::sleep_for(std::chrono::microseconds(10));
           if (us_since(st.t_submit) > 20000000) throw std::runtime_error("c8p_blocks: a batch's completion word did not arrive within 20 s");
         }
-        if (!d_quit.load()) {
-          const tick_t t0 = now_tick();
-          const size_t n = st.tags.size();
-          for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], st.outs.data()[p], st.pdu.data());
-          us = std::chrono::duration<double, std::micro>(now_tick() - t0).count();
-        }
-      } catch (const std::exception& e) { err = e.what(); }
-      lk.lock();
-      if (d_quit.load()) break;
-      if (!err.empty()) { d_werr = err; d_cv_done.notify_all(); break; }
+      }
+      block = false;
+      sub_scope phr(d_ph, phase_clock::REPLAY);
+      const size_t n = st.tags.size();
+      for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], st.outs.data()[p], st.pdu.data());
       st.tags.clear(); st.llr.clear(); st.mu.clear(); st.llr_items = 0; st.any_mu = false;
       st.state = stage::FREE;
       d_fly.pop_front();
-      d_ph.us[phase_clock::REPLAY] += us;
-      d_cv_done.notify_all();
-      d_timer.poke();
+      any = true;
     }
+    return any;
   }
 
   // one packet's records {u16 len, blob} out of a PDU arena -> messages, with the reference's debug lines
@@ -1544,8 +1523,7 @@ private:
   void publish_fused()
   {
     if (!d_st[d_fill].tags.empty()) submit(true);
-    while (!d_fly.empty() && d_werr.empty()) { sub_scope pw(d_ph, phase_clock::WAIT); d_cv_done.wait(*d_lk); }
-    if (!d_werr.empty()) throw std::runtime_error(d_werr);
+    while (!d_fly.empty()) reap(true);
     const long id = d_cur_fused >> C8P_FUSED_IDX_BITS;
     const size_t idx = (size_t)(d_cur_fused & ((1L << C8P_FUSED_IDX_BITS) - 1));
     if (id != d_fb_id) {                           // the next batch: the one before it has been published, it leaves the registry
@@ -1597,11 +1575,7 @@ private:
   stage d_st[NST];
   int d_fill = 0;                                  // the stage being gathered; d_fly: the ones in flight, in submit order
   std::deque<int> d_fly;
-  std::unique_lock<std::mutex>* d_lk = nullptr;    // the lock of the caller that may wait inside submit (general_work / flush; not the timer)
-  std::condition_variable d_cv_work, d_cv_done;
-  std::thread d_worker;
-  std::atomic<bool> d_quit{false};
-  std::string d_werr;
+  int d_max_fly = 2;                               // batches in flight at most
   uint32_t d_flag_seq = 0;
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
