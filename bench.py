@@ -345,7 +345,7 @@ def main():
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
             if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
-            r = bb.run(2048, batches=(256, 1024), quiet=True, batch=(pk, iq, chan, expected))                # the blocks' own (pinned) buffers
+            r = bb.run(2048, batches=(256, 512, 1024), quiet=True, batch=(pk, iq, chan, expected))           # the blocks' own (pinned) buffers
             r64 = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
             rpg = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
             rfl = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS

@@ -1620,10 +1620,12 @@ extern "C" void* c8p_dev_alloc(c8p_ctx* c, uint64_t bytes)
 }
 extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
 {
-  if (!c || !p) return;
-  (void)hipSetDevice(c->device);
-  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-  if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
+  if (!p) return;
+  if (c) {                                     // (NULL: the ctx that allocated it is gone, and with it anything it had in flight)
+    (void)hipSetDevice(c->device);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
+  }
   (void)hipFree(p);
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c);

@@ -96,6 +96,11 @@ bool batching_cfg::default_pinned_io()
   const char* e = getenv("C8P_PINNED_IO");
   return !(e && e[0] == '0');
 }
+bool batching_cfg::default_llr_handle()
+{
+  const char* e = getenv("C8P_LLR_HANDLE");
+  return !(e && e[0] == '0');
+}
 bool batching_cfg::default_defer_consume()
 {
   const char* e = getenv("C8P_DEFER_CONSUME");
@@ -217,6 +222,34 @@ struct tag_cursor {
     return false;
   }
 };
+// Plain mode's hand-over of a batch's LLR arena on the device (batching_cfg::llr_handle): what `decode` needs to decode a packet of the
+// batch where it lies — base address, arena size, every packet's offset — and something that keeps the memory alive.
+struct llr_batch {
+  std::shared_ptr<void> keep;         // demod's result object (owns the device buffer)
+  const float* base = nullptr;        // device address of the arena copy
+  uint64_t n_floats = 0;
+  std::vector<uint64_t> llr_off;      // per packet of the batch (c8p_pkt_tags.llr_off)
+};
+static std::mutex g_llr_mu;
+static std::map<long, std::shared_ptr<llr_batch>> g_llr;
+static void llr_park(long id, std::shared_ptr<llr_batch> b)
+{
+  std::lock_guard<std::mutex> g(g_llr_mu);
+  g_llr[id] = std::move(b);
+  while (g_llr.size() > 64) g_llr.erase(g_llr.begin());       // (a decode that never comes: the oldest go; each holds tens of MB of device memory)
+}
+static std::shared_ptr<llr_batch> llr_find(long id)
+{
+  std::lock_guard<std::mutex> g(g_llr_mu);
+  auto it = g_llr.find(id);
+  return it == g_llr.end() ? std::shared_ptr<llr_batch>() : it->second;
+}
+static void llr_purge(const std::vector<long>& ids)
+{
+  std::lock_guard<std::mutex> g(g_llr_mu);
+  for (long id : ids) g_llr.erase(id);
+}
+
 static const tag_value* find_tag(const std::vector<tag_t>& tags, const char* key)
 {
   for (const auto& t : tags) if (t.key == key) return &t.value;
@@ -313,10 +346,19 @@ public:
     c.abi_version = C8P_ABI_VERSION; c.device = cfg.device;
     d_ctx = d_api.create(&c);
     if (!d_ctx) throw std::runtime_error("c8p_create failed: no usable HIP device (there is no CPU fallback)");
+    d_cell->ctx = d_ctx; d_cell->dev_free = d_api.dev_free;
     // (The fronts keep several batches in flight; everything they need of a batch is downloaded behind its kernels, so the engine's
     // result arenas need not stay resident: any C8P_SLOTS works — with one slot a submit waits inside the engine for its predecessor.)
   }
-  ~engine_holder() { if (d_ctx) d_api.destroy(d_ctx); }
+  ~engine_holder()
+  {
+    { std::lock_guard<std::mutex> g(d_cell->mu); d_cell->ctx = nullptr; }      // device buffers that outlive this engine are freed without it
+    if (d_ctx) d_api.destroy(d_ctx);
+  }
+  // A device buffer of this engine that something else may still hold when the engine goes (a batch's LLR arena in the hands of
+  // another block): freed through the cell — with the ctx while it lives (c8p_dev_free waits for the copy streams), without it after.
+  struct ctx_cell { std::mutex mu; c8p_ctx* ctx = nullptr; void (*dev_free)(c8p_ctx*, void*) = nullptr; };
+  std::shared_ptr<ctx_cell> d_cell = std::make_shared<ctx_cell>();
   void check(int rc, const char* what = "")
   {
     if (rc != C8P_OK) throw std::runtime_error(std::string("c8p error ") + std::to_string(rc) + " " + what + ": " + d_api.last_error(d_ctx));
@@ -445,6 +487,7 @@ public:
   {
     d_timer.stop();
     fused_purge(d_fused_ids);                      // the batches this front parked and no decode picked up
+    llr_purge(d_llr_ids);
     d_outq.clear(); d_hold.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
     for (stage& st : d_st) { d_eng.dev_release(st.d_iq); d_eng.dev_release(st.d_chan); }
   }
@@ -589,9 +632,16 @@ public:
 
 private:
   struct result {             // downloaded arenas of one batch, shared by its packets until they have been drained
-    result(engine_holder* e) : eng(e), llr(&e->d_api) {}
-    ~result() { eng->dev_release(dev_llr); }
-    engine_holder* eng;
+    result(engine_holder* e) : eng(e), cell(e->d_cell), llr(&e->d_api) {}
+    ~result()
+    {
+      if (!dev_llr.p) return;
+      std::lock_guard<std::mutex> g(cell->mu);
+      cell->dev_free(cell->ctx, dev_llr.p);        // (ctx may be gone: c8p_dev_free(NULL, p) just frees)
+    }
+    engine_holder* eng;                // (only valid while the front lives: used by acquire() on its thread)
+    std::shared_ptr<engine_holder::ctx_cell> cell;
+    uint64_t n_llr = 0;               // floats of the arena copy
     pinned_vec<float> llr;            // pageable output buffer: the LLR arena on the host
     dev_buf dev_llr;                  // pinned output buffer: a device copy of the LLR arena (the engine's own is recycled with its slot)
   };
@@ -736,6 +786,7 @@ private:
         if (!d_eng.d_cfg.fused) {
           A.buffer(d_eng.d_ctx, C8P_BUF_LLR, &bytes);
           st.res = acquire(bytes / sizeof(float), n);
+          st.res->n_llr = bytes / sizeof(float);
           if (!d_out_dev) st.res->llr.resize_uninit(bytes / sizeof(float));
         } else {
           A.buffer(d_eng.d_ctx, C8P_BUF_PDU, &pbytes);
@@ -829,6 +880,17 @@ private:
       st.fb_id = fb_id;
       fused_park(fb_id, st.fb);
     }
+    long lb_id = 0;
+    if (!fused && d_out_dev && d_eng.d_cfg.llr_handle && res && res->dev_llr.p) {   // the arena copy behind a handle (batching_cfg::llr_handle)
+      std::shared_ptr<llr_batch> lb = std::make_shared<llr_batch>();
+      lb->keep = res; lb->base = static_cast<const float*>(res->dev_llr.p); lb->n_floats = res->n_llr;
+      lb->llr_off.resize(n);
+      for (size_t p = 0; p < n; p++) lb->llr_off[p] = tags[p].llr_off;
+      lb_id = g_fused_next.fetch_add(1);
+      llr_park(lb_id, std::move(lb));
+      d_llr_ids.push_back(lb_id);
+      if (d_llr_ids.size() > 128) d_llr_ids.erase(d_llr_ids.begin(), d_llr_ids.begin() + 64);
+    }
     out.reserve(n);
     for (size_t p = 0; p < n; p++) {
       const c8p_pkt_tags& t = tags[p];
@@ -851,6 +913,7 @@ private:
       if (!fused) {
         o.res = res; o.on_device = d_out_dev;
         o.llr = (d_out_dev ? static_cast<const float*>(res->dev_llr.p) : res->llr.data()) + t.llr_off;
+        if (lb_id) L("c8p_llr", (lb_id << C8P_FUSED_IDX_BITS) | (long)p);
       } else L("c8p_fused", (fb_id << C8P_FUSED_IDX_BITS) | (long)p);
     }
   }
@@ -944,6 +1007,7 @@ private:
   size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;
   std::deque<out_pkt> d_outq;
   std::vector<long> d_fused_ids;                   // batches this front parked in g_fused (the last 256-512 of them)
+  std::vector<long> d_llr_ids;                     // ... and in g_llr
   latency_timer d_timer;                           // last member: its thread uses everything above
 };
 
@@ -1260,11 +1324,11 @@ public:
         tag_span tg;
         uint64_t next = 0;
         if (!d_tc.at(rd + (uint64_t)used, rd + (uint64_t)nproc, tg, next)) { used = (int)(next - rd); continue; }
-        stage& st = d_st[d_fill];
         memset(&d_cur, 0, sizeof(d_cur));
         d_cur.status = C8P_ST_OK;
         d_cur.format = d_cur.len = d_cur.total = d_cur.cr = d_cur.mcs = d_cur.ampdu = d_cur.trellis = 99999;
         d_cur_fused = -1;
+        long llr_h = -1;
         const tag_value* mu = nullptr;
         for (const tag_t* t = tg.first; t != tg.last; ++t) {        // one pass over the item's tags (demod_impl.cc:224-253 writes up to fourteen)
           const std::string& k = t->key;
@@ -1282,21 +1346,39 @@ public:
           else if (k == "sssnr0") d_cur.sssnr0 = v.as_float();
           else if (k == "sssnr1") d_cur.sssnr1 = v.as_float();
           else if (k == "c8p_fused") d_cur_fused = v.as_long();
+          else if (k == "c8p_llr") llr_h = v.as_long();
           else if (k == "mu2x1chan") mu = &v;
         }
         d_cur.is_ndp = d_cur.trellis == 0;
+        d_cur_ext = false;
         if (d_cur_fused < 0) {
-          d_cur.llr_off = llr_alloc(st, (size_t)std::max(d_cur.total, 0));
+          // the packet's LLR items: behind a handle of a demod mirror of this process (on the device already: the items in the
+          // stream are skipped), or in the stream (gathered / copied into the batch's arena)
+          if (llr_h >= 0 && d_eng.d_cfg.llr_handle) {
+            const long id = llr_h >> C8P_FUSED_IDX_BITS;
+            const size_t idx = (size_t)(llr_h & ((1L << C8P_FUSED_IDX_BITS) - 1));
+            if (id != d_lb_id) {                   // the next batch: the one before it leaves the registry (its packets hold it until decoded)
+              if (d_lb) llr_purge(std::vector<long>(1, d_lb_id));
+              d_lb = llr_find(id);
+              d_lb_id = id;
+            }
+            if (d_lb && idx < d_lb->llr_off.size()) { d_cur_ext = true; d_cur.llr_off = d_lb->llr_off[idx]; }
+          }
+          if (!d_cur_ext) {
+            // (a batch reads ONE arena: packets of the stream do not join a batch of handle packets)
+            if (d_st[d_fill].src_id != 0 && !d_st[d_fill].tags.empty()) submit(false);
+            d_st[d_fill].src_id = 0; d_st[d_fill].src.reset();
+            d_cur.llr_off = llr_alloc(d_st[d_fill], (size_t)std::max(d_cur.total, 0));
+          }
           d_cur_mu = mu != nullptr;
-          if (mu) st.any_mu = true;
-          for (int i = 0; i < 128; i++) st.mu.push_back(mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f));
+          for (int i = 0; i < 128; i++) d_cur_muv[i] = mu && (int)mu->v.size() > i ? mu->v[i] : gr_complex(0.f, 0.f);
         }
         d_have = 0;
         d_state = S_COLLECT;
       }
-      stage& st = d_st[d_fill];
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.total - d_have);
-      if (take > 0 && d_cur_fused < 0) {
+      if (take > 0 && d_cur_fused < 0 && !d_cur_ext) {
+        stage& st = d_st[d_fill];
         if (d_in_dev) d_lane.add(in + used, d_cur.llr_off + (uint64_t)d_have, (uint64_t)take, C8P_FMT_F32);
         else memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
       }
@@ -1306,8 +1388,15 @@ public:
         if (d_cur.total <= 0) used++;        // a tag set announcing no items: step over its item (the reference livelocks here)
         if (d_cur_fused >= 0) publish_fused();
         else {
+          const long want_src = d_cur_ext ? d_lb_id : 0;
+          if (!d_st[d_fill].tags.empty() && d_st[d_fill].src_id != want_src) submit(false);      // one arena per batch
+          stage& st = d_st[d_fill];
+          st.src_id = want_src;
+          if (d_cur_ext) st.src = d_lb;
           if (st.tags.empty()) st.t_first = now_tick();
           st.tags.push_back(d_cur);
+          if (d_cur_mu) st.any_mu = true;
+          st.mu.insert(st.mu.end(), d_cur_muv, d_cur_muv + 128);
           if ((int)st.tags.size() >= d_eng.d_cfg.max_batch) submit(false);
         }
       }
@@ -1361,6 +1450,8 @@ private:
     dev_buf d_llr, d_mu;              // a pinned input buffer: the batch's LLR arena on the device, filled by the calls' gathers
     size_t llr_items = 0;
     bool any_mu = false;              // a packet of the batch carries "mu2x1chan" (an NDP): its captures have to travel too
+    long src_id = 0;                  // != 0: the batch's LLR items lie in a demod mirror's arena copy (llr_batch), not in this stage's
+    std::shared_ptr<llr_batch> src;
     std::vector<c8p_pkt_tags> tags;
     std::vector<gr_complex> mu;
     tick_t t_first, t_submit;
@@ -1394,18 +1485,26 @@ private:
     while ((int)d_fly.size() >= d_max_fly) reap(true);
     stage& st = d_st[d_fill];
     const c8p_api& A = d_eng.d_api;
-    const bool part = d_state == S_COLLECT && d_cur_fused < 0;      // a packet still being received moves to the next stage
+    const bool part = d_state == S_COLLECT && d_cur_fused < 0 && !d_cur_ext;      // a packet still being received moves to the next stage
     std::vector<float> part_llr;
-    std::vector<gr_complex> part_mu;
     const uint64_t part_off = d_cur.llr_off;
-    if (part) {
-      if (!d_in_dev) part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
-      part_mu.assign(st.mu.end() - 128, st.mu.end());
-    }
+    if (part && !d_in_dev) part_llr.assign(st.llr.data() + d_cur.llr_off, st.llr.data() + d_cur.llr_off + d_have);
     c8p_decode_in b;
     memset(&b, 0, sizeof(b));
     b.n_pkt = (int32_t)st.tags.size(); b.tags = st.tags.data();
-    if (!d_in_dev) {
+    if (st.src_id) {
+      // every packet of the batch lies in a demod mirror's device copy of its LLR arena (complete: that batch was replayed before its
+      // tags went out): decoded where it is
+      sub_scope pg(d_ph, phase_clock::GATHER);
+      if (st.any_mu) {
+        d_eng.dev_reserve(st.d_mu, st.mu.size() * sizeof(gr_complex), 0);
+        d_eng.check(A.copy_async(d_eng.d_ctx, st.d_mu.p, st.mu.data(), st.mu.size() * sizeof(gr_complex)), "mu2x1chan upload");
+        d_eng.check(A.copy_fence(d_eng.d_ctx), "c8p_copy_fence");
+      }
+      b.mem = C8P_MEM_DEVICE;
+      b.llr = st.src->base; b.n_llr = st.src->n_floats;
+      b.mu2x1chan = st.any_mu ? static_cast<const c8p_c32*>(st.d_mu.p) : nullptr;
+    } else if (!d_in_dev) {
       b.mem = C8P_MEM_HOST;
       if (st.llr.empty()) *st.llr.grow(1) = 0.f;
       b.llr = st.llr.data(); b.n_llr = st.llr.size();
@@ -1470,8 +1569,6 @@ private:
         else d_eng.check(A.copy_async(d_eng.d_ctx, static_cast<float*>(to.d_llr.p) + d_cur.llr_off, static_cast<const float*>(from.d_llr.p) + part_off,
                                       sizeof(float) * (size_t)d_have), "partial packet move");
       }
-      if (d_cur_mu) to.any_mu = true;
-      to.mu.insert(to.mu.end(), part_mu.begin(), part_mu.end());
     }
   }
 
@@ -1496,6 +1593,7 @@ private:
       const size_t n = st.tags.size();
       for (size_t p = 0; p < n; p++) publish_packet(st.tags[p], st.outs.data()[p], st.pdu.data());
       st.tags.clear(); st.llr.clear(); st.mu.clear(); st.llr_items = 0; st.any_mu = false;
+      st.src.reset(); st.src_id = 0;
       st.state = stage::FREE;
       d_fly.pop_front();
       any = true;
@@ -1568,6 +1666,10 @@ private:
   int d_have = 0;
   long d_cur_fused = -1;
   bool d_cur_mu = false;                           // the packet being received carries "mu2x1chan"
+  gr_complex d_cur_muv[128];                       // ... its values (zeros otherwise): joins the batch with the packet
+  bool d_cur_ext = false;                          // ... its LLR items lie behind a handle ("c8p_llr"): the items in the stream are skipped
+  long d_lb_id = 0;                                // the demod batch whose handle packets are arriving
+  std::shared_ptr<llr_batch> d_lb;
   long d_fb_id = 0;                                // fused mode: the batch whose packets are arriving
   std::shared_ptr<fused_batch> d_fb;
   pdu_t d_msg;                                     // (reused: its blob keeps its capacity)

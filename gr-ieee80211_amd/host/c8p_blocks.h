@@ -156,6 +156,12 @@ struct batching_cfg {
   // waited for at the end of the same call (what a single-mapped custom buffer that relocates unread items asks for).
   bool pinned_io = default_pinned_io();
   bool defer_consume = default_defer_consume();
+  // Plain mode, demod's output buffer pinned: demod keeps the device copy of a batch's LLR arena it fills the output buffer from and
+  // names it in a tag ("c8p_llr": batch id << 20 | packet index).  A decode mirror of the same process that meets the tag decodes the
+  // packet out of that copy and skips its `total` items — which ARE in the stream, written, for whoever else reads them: the LLR
+  // stream then crosses the link once (up) instead of twice.  Environment C8P_LLR_HANDLE=0 turns it off (decode gathers the items).
+  bool llr_handle = default_llr_handle();
+  static bool default_llr_handle();
   static bool default_fused();
   static bool default_pinned_io();
   static bool default_defer_consume();

@@ -492,7 +492,7 @@ void  c8p_host_free(void* p);
  * c8p_copy_wait returns when everything enqueued so far has been done.  The engine's submits do NOT wait for these copies. */
 typedef struct c8p_span { uint64_t dst_off, src_off, n; } c8p_span;      /* item (c8p_c32) offsets from dst / src, item count */
 void* c8p_dev_alloc(c8p_ctx* ctx, uint64_t bytes);
-void  c8p_dev_free(c8p_ctx* ctx, void* p);
+void  c8p_dev_free(c8p_ctx* ctx, void* p);      /* waits for the ctx's copy streams first; ctx may be NULL when it has been destroyed */
 int   c8p_copy_async(c8p_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int   c8p_copy_spans(c8p_ctx* ctx, c8p_c32* dst, const c8p_c32* src, const c8p_span* spans, int32_t n);   /* spans: host memory */
 int   c8p_copy_wait(c8p_ctx* ctx);

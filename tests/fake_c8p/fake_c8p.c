@@ -214,7 +214,7 @@ int64_t c8p_counter(c8p_ctx* c, int which)
 /* caller arenas: "device" memory is the heap here, the copies are immediate */
 void* c8p_dev_alloc(c8p_ctx* c, uint64_t bytes) { (void)c; return calloc(bytes ? bytes : 1, 1); }
 static void run_pending(c8p_ctx* c);
-void c8p_dev_free(c8p_ctx* c, void* p) { run_pending(c); free(p); }
+void c8p_dev_free(c8p_ctx* c, void* p) { if (c) run_pending(c); free(p); }
 /* The copy stream is ASYNCHRONOUS here too, so that a caller that releases a gather's source too early (a block mirror consuming
  * scheduler items whose gather it has not waited for) or forgets c8p_copy_fence before a submit FAILS on this backend as it would race
  * on the device: a c8p_copy_gather only records its pieces; they are executed — in order — by whatever the header says completes or

@@ -383,6 +383,47 @@ def test_block_mirror_with_and_without_pinned_buffers(n_ant, pinned_io, defer, c
     assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
 
 
+@pytest.mark.parametrize("handle", ["1", "0"])
+def test_plain_chain_with_and_without_the_llr_handle(handle, monkeypatch):
+    """batching_cfg::llr_handle (plain mode on pinned buffers): demod names the device copy of a batch's LLR arena in a "c8p_llr" tag and
+    decode decodes the packets out of it, skipping their items in the stream — which are written all the same (the captured stream
+    equals the oracle's LLRs either way); without the handle decode gathers the items out of the edge.  Same PDUs, same debug lines."""
+    monkeypatch.setenv("C8P_LLR_HANDLE", handle)
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    res = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 5)
+    assert check_against_oracle(res, pk, iq, chan) >= 20
+    assert any(k == "c8p_llr" for _, k, _ in res[1]) == (handle == "1")
+    ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    msgs, dbg = _chain_threads(FAKE, pk, iq, chan, 1, 7, False, pinned_io=True, defer_consume=True, poison=True, chunk=3000, nout=5000)
+    assert msgs == ref[2] and dbg == ref[3]
+
+
+def test_llr_handles_survive_the_demod_that_made_them():
+    """decode holds the batch whose handle packets it is working on; the demod mirror that made it may be destroyed meanwhile: its
+    registry entries go with it (later packets fall back to the items in the stream), the arena copy decode still holds is freed
+    through the engine's cell without the context (c8p_dev_free(NULL, p)) when decode lets go of it."""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=6)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=4096, nout=8192)
+    llr, tags = dem.output(), dem.tags()
+    assert any(k == "c8p_llr" for _, k, _ in tags)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=4)
+    half = (len(llr) // 2) & ~1
+    dec.push_items(0, llr[:half])
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run(chunk=4096, nout=8192, flush_at_end=False)
+    dem.close()                                                # the demod goes while decode sits on one of its batches
+    dec.push_items(0, llr[half:])
+    dec.run(chunk=4096, nout=8192)
+    assert dec.messages() == ref[2] and dec.debug_lines() == ref[3]
+    dec.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 @pytest.mark.parametrize("defer", [False, True])
 def test_pinned_buffers_under_random_scheduler_chunks(seed, defer):
@@ -450,7 +491,7 @@ def test_fused_demod_emits_the_reference_tags_plus_a_handle():
     plain = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
     assert len(llr) == len(plain[0])                                   # same item counts (values unwritten)
     strip = [(o, k) for o, k, _ in tags if k != "c8p_fused"]
-    assert strip == [(o, k) for o, k, _ in plain[1]]
+    assert strip == [(o, k) for o, k, _ in plain[1] if k != "c8p_llr"]       # (plain mode on pinned buffers adds its own handle tag)
     handles = [v for _, k, v in tags if k == "c8p_fused"]
     assert len(handles) == len({o for o, _, _ in tags}) and len(set(handles)) == len(handles)
 
@@ -524,7 +565,8 @@ def test_live_scheduler_equals_the_flushed_run_on_a_long_stream():
         for off, key, val in tags:
             dec.push_tag(off, key, val)
         (dec.run_live(chunk=3000, nout=5000, linger_ms=100) if live else dec.run(chunk=3000, nout=5000))
-        outs.append((llr, [(o, k, v if not isinstance(v, np.ndarray) else v.tobytes()) for o, k, v in tags], dec.messages()))
+        # (the handle tags name a batch by a process-wide counter: not part of the comparison)
+        outs.append((llr, [(o, k, v if not isinstance(v, np.ndarray) else v.tobytes()) for o, k, v in tags if k != "c8p_llr"], dec.messages()))
         dem.close(); dec.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
 
