@@ -368,7 +368,7 @@ def main():
                 "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
                                       "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},
                 "note": "block_chain_* (and legs.block_chain / block_fused) = custom_buffers: the edge buffers are allocated through the mirrors' buffer type "
-                        "(GNU Radio 3.10 custom buffers: pinned host memory, 8 MB per edge, a call sees half), the packets are gathered out of them by the "
+                        "(GNU Radio 3.10 custom buffers: pinned host memory, 8 MB for the sample edge and 16 MB for the LLR edge, a call sees half), the packets are gathered out of them by the "
                         "device and demod's LLR items are written into them by the device; the two scheduler threads sit on two cores that share an L3 "
                         "(hostbind.cpu_pair_sharing_l3: what a flowgraph sets with the blocks' core affinity)"}
             out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]

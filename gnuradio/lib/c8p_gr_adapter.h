@@ -149,6 +149,8 @@ private:
   // io_signature names it — which the impl classes' constructors do; a flowgraph that overrides it gets pageable staging back
   bool input_is_pinned(unsigned port) override { return this->input_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
   bool output_is_pinned(unsigned port) override { return this->output_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
+  // what c8p_pinned_buffer::make_buffer allocates at least: megabytes, so the fronts gather (c8p_blocks.h: C8P_GATHER_MIN_BUFFER)
+  size_t input_buffer_bytes(unsigned port) override { return input_is_pinned(port) ? (size_t)C8P_PINNED_BUFFER_MIN_BYTES : 0; }
 
   std::shared_ptr<c8p::c8p_block> d_front;
 };

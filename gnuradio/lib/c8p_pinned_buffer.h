@@ -45,7 +45,8 @@
 #include "c8p_rx.h"
 
 #ifndef C8P_PINNED_BUFFER_MIN_BYTES
-#define C8P_PINNED_BUFFER_MIN_BYTES (8u << 20)   // 8 MB per edge: a general_work call then sees up to 4 MB (bench.py: "custom_buffers")
+#define C8P_PINNED_BUFFER_MIN_BYTES (8u << 20)   // 8 MB for an edge of complex items, twice that for the float LLR edge (a packet's LLRs are
+                                                  // 1.6 x its samples): a general_work call then sees up to half of it (bench.py: "custom_buffers")
 #endif
 
 namespace gr {
@@ -86,7 +87,7 @@ public:
                                      gr::block_sptr link, gr::block_sptr buf_owner)
   {
     // the scheduler asks for its default (64 KB); an edge of this module holds megabytes (see the header comment)
-    const size_t want = (C8P_PINNED_BUFFER_MIN_BYTES + sizeof_item - 1) / sizeof_item;
+    const size_t want = ((sizeof_item == sizeof(float) ? 2u : 1u) * (size_t)C8P_PINNED_BUFFER_MIN_BYTES + sizeof_item - 1) / sizeof_item;
     if ((size_t)nitems < want) nitems = (int)want;
     c8p_pinned_buffer* b = new c8p_pinned_buffer(nitems, sizeof_item, downstream_lcm_nitems, downstream_max_out_mult, link, buf_owner);
     gr::buffer_sptr p(b);

@@ -96,6 +96,12 @@ bool batching_cfg::default_pinned_io()
   const char* e = getenv("C8P_PINNED_IO");
   return !(e && e[0] == '0');
 }
+// C8P_GATHER_MIN_BUFFER in the environment overrides the header's threshold (bytes; 0: always gather out of a pinned buffer — the tests)
+static size_t gather_min_buffer()
+{
+  const char* e = getenv("C8P_GATHER_MIN_BUFFER");
+  return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)C8P_GATHER_MIN_BUFFER;
+}
 bool batching_cfg::default_llr_handle()
 {
   const char* e = getenv("C8P_LLR_HANDLE");
@@ -518,7 +524,10 @@ public:
     reap(false);                                   // batches whose completion word has arrived: their packets join the output queue
     if (!d_mode_known) {
       d_in_dev = d_eng.d_cfg.pinned_io;
-      for (int p = 0; p < d_nports; p++) d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p);
+      for (int p = 0; p < d_nports; p++) {
+        const size_t cap = d_io->input_buffer_bytes((unsigned)p);
+        d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p) && (cap == 0 || cap >= gather_min_buffer());
+      }
       d_out_dev = d_eng.d_cfg.pinned_io && !d_eng.d_cfg.fused && d_io->output_is_pinned(0);
       d_mode_known = true;
     }
@@ -1308,7 +1317,11 @@ public:
     if (!d_timer.error.empty()) throw std::runtime_error(d_timer.error);
     phase_clock::scope ph_all(d_ph, phase_clock::CUT);
     reap(false);                                   // batches whose completion word has arrived are published
-    if (!d_mode_known) { d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0); d_mode_known = true; }
+    if (!d_mode_known) {
+      const size_t cap = d_io->input_buffer_bytes(0);
+      d_in_dev = d_eng.d_cfg.pinned_io && d_io->input_is_pinned(0) && (cap == 0 || cap >= gather_min_buffer());
+      d_mode_known = true;
+    }
     const float* in = static_cast<const float*>(input_items[0]);
     int nproc = ninput_items[0];
     const uint64_t rd = d_io->nitems_read(0);

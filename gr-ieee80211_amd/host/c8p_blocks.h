@@ -92,7 +92,12 @@ public:
   // (false: an ordinary pageable buffer — the fronts then stage through pinned copies of their own, as in rounds 1-4).
   virtual bool input_is_pinned(unsigned port) { return false; }
   virtual bool output_is_pinned(unsigned port) { return false; }
+  // ... and how large the input buffer is (0: not known, taken to be large).  A gather takes ~18 us from enqueue to done whatever its
+  // size: below C8P_GATHER_MIN_BUFFER a call's window is so small that copying it into pinned staging on the CPU (and letting a copy
+  // engine upload the batch) is faster, and a front does that even when the buffer is pinned.
+  virtual size_t input_buffer_bytes(unsigned port) { return 0; }
 };
+#define C8P_GATHER_MIN_BUFFER (2u << 20)
 
 // the C ABI the blocks call; defaults to the symbols of libc8p_rx.so, tests inject another table
 struct c8p_api {

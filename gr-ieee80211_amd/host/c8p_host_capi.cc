@@ -130,6 +130,9 @@ struct harness : public block_io {
   // the front's latency timer asks for a call (results became ready while no input was arriving)
   void wake() override { { std::lock_guard<std::mutex> g(wake_mu); woken = true; } wake_cv.notify_all(); }
   bool input_is_pinned(unsigned port) override { return port < in.size() && in[port].pinned; }
+  // the buffer a scheduler would have given this port: twice what a call is offered (set by the run loops before their first call)
+  size_t in_cap_bytes = 0;
+  size_t input_buffer_bytes(unsigned) override { return in_cap_bytes; }
   bool output_is_pinned(unsigned) override { return pinned_out; }
   // an output buffer of n floats, from the block's allocator when its io_signature says so
   struct obuf_t {
@@ -241,6 +244,7 @@ int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pin
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 {
   harness* h = static_cast<harness*>(p);
+  h->in_cap_bytes = 2 * (size_t)std::max(chunk, 1) * h->item_size;
   try {
     long calls = 0;
     int idle = 0, starved = 0;
@@ -338,6 +342,8 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   const bool pin_edge = A->pinned_out || B->in[0].pinned;
   harness* owner = A->pinned_out ? A : B;
   A->pinned_out = pin_edge; B->in[0].pinned = pin_edge;          // what the two blocks are told about the edge
+  A->in_cap_bytes = 2 * (size_t)std::max(chunk, 1) * A->item_size;
+  B->in_cap_bytes = 2 * std::max((size_t)std::max(chunk, 1), (size_t)std::max(nout, 1) * fpi) * sizeof(float);
   const size_t seg_floats = std::max<size_t>((size_t)std::max(nout, 1) * fpi * 16, (size_t)1 << 23);
   struct segment { float* items = nullptr; size_t n = 0; bool closed = false; };      // n, closed: under mu
   segment segs[3];
@@ -522,6 +528,7 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
 long c8ph_run_live(void* p, int chunk, int nout, int linger_ms)
 {
   harness* h = static_cast<harness*>(p);
+  h->in_cap_bytes = 2 * (size_t)std::max(chunk, 1) * h->item_size;
   try {
     long calls = 0;
     const size_t fpi = std::max<size_t>(h->out_size / sizeof(float), 1);

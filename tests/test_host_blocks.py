@@ -17,6 +17,13 @@ from gr_ieee80211_amd import blocks
 FAKE = os.path.join(ROOT, "tests", "fake_c8p", "libc8p_fake.so")
 
 
+@pytest.fixture(autouse=True)
+def gather_at_any_size(monkeypatch):
+    """the fronts gather out of a pinned buffer only when it is megabytes large (C8P_GATHER_MIN_BUFFER): here always, so that the
+    small streams of these tests go through the gather path whenever a test asks for pinned buffers"""
+    monkeypatch.setenv("C8P_GATHER_MIN_BUFFER", "0")
+
+
 @pytest.fixture(scope="module", autouse=True)
 def built():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gr-ieee80211_amd", "host")])
@@ -397,6 +404,24 @@ def test_plain_chain_with_and_without_the_llr_handle(handle, monkeypatch):
     ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
     msgs, dbg = _chain_threads(FAKE, pk, iq, chan, 1, 7, False, pinned_io=True, defer_consume=True, poison=True, chunk=3000, nout=5000)
     assert msgs == ref[2] and dbg == ref[3]
+
+
+def test_small_pinned_buffers_are_staged_not_gathered(monkeypatch):
+    """below C8P_GATHER_MIN_BUFFER (2 MB of input buffer) a front copies the call's window into pinned staging itself even though the
+    buffer is pinned — a gather's ~18 us of latency per call is more than that copy; same results either way"""
+    monkeypatch.delenv("C8P_GATHER_MIN_BUFFER", raising=False)
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    for chunk, nout in ((3000, 5000), (1 << 19, 1 << 21)):
+        dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7, fused=False, pinned_io=True)
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=7, fused=False, pinned_io=True)
+        blocks.feed_demod(dem, pk, iq, chan)
+        blocks.run_chain(dem, dec, chunk=chunk, nout=nout)
+        gathered = dem.host_phase_us()["gather_enqueue"] > 0
+        assert gathered == (chunk >= 1 << 19)
+        assert dec.messages() == ref[2] and dec.debug_lines() == ref[3]
+        dem.close(); dec.close()
 
 
 def test_llr_handles_survive_the_demod_that_made_them():
