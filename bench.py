@@ -323,7 +323,9 @@ def main():
     if use_dist:
         bindings = [None] * world
         dist.all_gather_object(bindings, binding)
-    if world > 1 and not args.no_host_legs:
+    # (C8P_TEST_MULTI_LEG=1 under a one-rank torch.distributed.run: the leg's code path — LiveShard, the gathers of the per-rank
+    # records — on the one GPU a development box has; tools/probes and the GPU test that exercises it)
+    if (world > 1 or (use_dist and os.environ.get("C8P_TEST_MULTI_LEG") == "1")) and not args.no_host_legs:
         guard = LegGuard(out, rank, float(os.environ.get("C8P_HOST_LEG_TIMEOUT_S", "240")), "multi_gpu_host_fed")
         try:
             mine = multi_gpu_host_fed(torch, dev, local, rank, world, pk, iq_dev, chan_dev)

@@ -11,6 +11,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 from c8p_testlib import ROOT
 
 FACTOR = 0.7          # a leg of the driver's run may be at most this much worse than the committed line's
@@ -264,3 +266,27 @@ def test_bench_refuses_a_world_that_is_not_what_was_asked_for():
     assert p.returncode != 0 and "refusing" in p.stderr and not p.stdout.strip()
     p = run_bench("--gpus", "2")                         # no GPUs here: the launcher says so instead of measuring one GPU
     assert p.returncode != 0 and "GPU(s) are visible" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_multi_gpu_host_fed_leg_runs_under_a_one_rank_launch():
+    """bench.py's world > 1 leg (live ingest through shard.LiveShard + the PCIe-inclusive c8p_rx, per-rank records gathered) on the one
+    GPU a development box has: a one-rank torch.distributed.run with C8P_TEST_MULTI_LEG=1.  The line carries the rank's figures, the
+    NUMA binding record, and every pushed PDU was delivered."""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, C8P_TEST_MULTI_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2", "--repeats", "1", "--min-timed-s", "0", "--no-cpu", "--no-frontend",
+           "--no-configs", "--no-sensitivity", "--no-stream"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    mg = j["multi_gpu_host_fed"]
+    assert mg["ranks_ok"] == 1 and "error" not in mg["per_rank"][0], mg
+    r = mg["per_rank"][0]
+    assert r["live_streams"]["global_streams"] == [0, 64, 64] and r["live_streams"]["streams_at_realtime"] > 50
+    lo, hi = r["live_streams"]["pdus_in_the_items_pushed"]
+    assert lo <= r["live_streams"]["pdus_ok"] <= hi
+    assert r["pcie_inclusive_packets_per_s"] > 3e5
+    assert j["host_binding"][0]["rank"] == 0 and "numa_node" in j["host_binding"][0]
