@@ -1137,6 +1137,19 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12, detail=Non
         return len(pk) * steps / dt
 
     def gather_path():
+        # the copy stream of this leg on 2 CUs of every XCD (C8P_COPY_CUS = 16, read when the ctx first copies; the engine's default for
+        # complex64 pieces is 32, tuned on the live ingest): one 150 MB piece keeps few waves busy and every CU it does not hold stays with
+        # the decoder — 16 / 32 / 64 / no mask: 1.49 / 1.44 / 1.41 / 1.20 M packets/s on one box (profiles/r5n/pcie_copy_cus.txt)
+        cus_env = os.environ.get("C8P_COPY_CUS")
+        if cus_env is None:
+            os.environ["C8P_COPY_CUS"] = "16"
+        try:
+            return gather_path_()
+        finally:
+            if cus_env is None:
+                del os.environ["C8P_COPY_CUS"]
+
+    def gather_path_():
         eng = engine.Engine(device=local)
         L = eng.L
         # one arena per set: [iq | chan] (chan starts on a 16-byte boundary: iq_dev.n is even or padded)
@@ -1182,6 +1195,7 @@ def pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, steps=12, detail=Non
     rate, down, up = gather_path()
     if detail is not None:
         detail["gather_path_packets_per_s"] = rate
+        detail["copy_stream_cus"] = os.environ.get("C8P_COPY_CUS", "16 (this leg's choice; engine default 32)")
         detail["host_to_device_GBps"] = rate / len(pk) * down / 1e9
         detail["device_to_host_GBps"] = rate / len(pk) * up / 1e9
         detail["bytes_per_step"] = {"down": down, "up": up}
