@@ -347,10 +347,10 @@ def main():
             bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
             if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
-            r = bb.run(2048, batches=(256, 512, 1024), quiet=True, batch=(pk, iq, chan, expected))           # the blocks' own (pinned) buffers
-            r64 = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
-            rpg = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
-            rfl = bb.run(2048, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
+            r = bb.run(4096, batches=(256, 512, 1024), quiet=True, batch=(pk, iq, chan, expected))           # the blocks' own (pinned) buffers
+            r64 = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
+            rpg = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
+            rfl = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
             try:
                 out["block_rx_chain"] = bb.rx_chain_rate(local=local)
                 out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
@@ -385,7 +385,7 @@ def main():
                                      "submitted before step i is waited for; block_chain: the gr::ieee80211::demod -> decode "
                                      "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
                                      "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
-                                     "over 2048 packets, max_batch 256, %d of 2048 PDUs correct in the worst leg" % r["pdus_ok_min"])
+                                     "over 4096 packets, max_batch 256 / 512 / 1024 (the best), %d of 4096 PDUs correct in the worst leg" % r["pdus_ok_min"])
         if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)

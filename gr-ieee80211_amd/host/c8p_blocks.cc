@@ -557,20 +557,31 @@ public:
         for (const tag_t* t = tg.first; t != tg.last; ++t) {        // one pass over the item's tags (signal_impl.cc:135-143 writes eight)
           const std::string& k = t->key;
           const tag_value& v = t->value;
-          if (k == "cfo") d_cur.cfo = v.as_float();
-          else if (k == "snr") d_cur.snr = v.as_float();
-          else if (k == "rssi") d_cur.rssi = v.as_float();
-          else if (k == "seq") d_cur.seq = (int32_t)v.as_long();
-          else if (k == "mcs") d_cur.lsig_mcs = (int32_t)v.as_long();
-          else if (k == "len") d_cur.lsig_len = (int32_t)v.as_long();
-          else if (k == "nsamp") d_cur.lsig_nsamp = (int32_t)v.as_long();
-          else if (k == "chan") ch = &v;
+          const char* kc = k.data();
+          switch (k.size()) {                                       // (by length, then one memcmp: no chain of string compares)
+            case 3:
+              if (!memcmp(kc, "cfo", 3)) d_cur.cfo = v.as_float();
+              else if (!memcmp(kc, "snr", 3)) d_cur.snr = v.as_float();
+              else if (!memcmp(kc, "seq", 3)) d_cur.seq = (int32_t)v.as_long();
+              else if (!memcmp(kc, "mcs", 3)) d_cur.lsig_mcs = (int32_t)v.as_long();
+              else if (!memcmp(kc, "len", 3)) d_cur.lsig_len = (int32_t)v.as_long();
+              break;
+            case 4:
+              if (!memcmp(kc, "rssi", 4)) d_cur.rssi = v.as_float();
+              else if (!memcmp(kc, "chan", 4)) ch = &v;
+              break;
+            case 5:
+              if (!memcmp(kc, "nsamp", 5)) d_cur.lsig_nsamp = (int32_t)v.as_long();
+              break;
+            default: break;
+          }
         }
         d_cur.n_ant = (uint8_t)d_nports; d_cur.mupos = (uint8_t)(d_mupos ? 1 : 0);
         d_cur.n_items = (uint32_t)std::max(d_cur.lsig_nsamp, 0) + 320u;     // demod_impl.cc:92
         d_cur.chan_off = (uint32_t)st.chan.size();
         gr_complex* c = st.chan.grow(64);
-        for (int i = 0; i < 64; i++) c[i] = ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f);
+        if (ch && ch->v.size() >= 64) memcpy(static_cast<void*>(c), ch->v.data(), 64 * sizeof(gr_complex));
+        else for (int i = 0; i < 64; i++) c[i] = ch && (int)ch->v.size() > i ? ch->v[i] : gr_complex(0.f, 0.f);
         for (int p = 0; p < d_nports; p++) d_cur.iq_off[p] = iq_alloc(st, d_cur.n_items);
         d_have = 0;
         d_state = S_COLLECT;
@@ -1346,21 +1357,35 @@ public:
         for (const tag_t* t = tg.first; t != tg.last; ++t) {        // one pass over the item's tags (demod_impl.cc:224-253 writes up to fourteen)
           const std::string& k = t->key;
           const tag_value& v = t->value;
-          if (k == "format") d_cur.format = (int32_t)v.as_long();
-          else if (k == "len") d_cur.len = (int32_t)v.as_long();
-          else if (k == "total") d_cur.total = (int32_t)v.as_long();
-          else if (k == "cr") d_cur.cr = (int32_t)v.as_long();
-          else if (k == "mcs") d_cur.mcs = (int32_t)v.as_long();
-          else if (k == "ampdu") d_cur.ampdu = (int32_t)v.as_long();
-          else if (k == "trellis") d_cur.trellis = (int32_t)v.as_long();
-          else if (k == "cfo") d_cur.cfo = v.as_float();
-          else if (k == "snr") d_cur.snr = v.as_float();
-          else if (k == "rssi") d_cur.rssi = v.as_float();
-          else if (k == "sssnr0") d_cur.sssnr0 = v.as_float();
-          else if (k == "sssnr1") d_cur.sssnr1 = v.as_float();
-          else if (k == "c8p_fused") d_cur_fused = v.as_long();
-          else if (k == "c8p_llr") llr_h = v.as_long();
-          else if (k == "mu2x1chan") mu = &v;
+          const char* kc = k.data();
+          switch (k.size()) {                                       // (by length, then one memcmp)
+            case 2: if (!memcmp(kc, "cr", 2)) d_cur.cr = (int32_t)v.as_long(); break;
+            case 3:
+              if (!memcmp(kc, "len", 3)) d_cur.len = (int32_t)v.as_long();
+              else if (!memcmp(kc, "mcs", 3)) d_cur.mcs = (int32_t)v.as_long();
+              else if (!memcmp(kc, "cfo", 3)) d_cur.cfo = v.as_float();
+              else if (!memcmp(kc, "snr", 3)) d_cur.snr = v.as_float();
+              break;
+            case 4: if (!memcmp(kc, "rssi", 4)) d_cur.rssi = v.as_float(); break;
+            case 5:
+              if (!memcmp(kc, "total", 5)) d_cur.total = (int32_t)v.as_long();
+              else if (!memcmp(kc, "ampdu", 5)) d_cur.ampdu = (int32_t)v.as_long();
+              break;
+            case 6:
+              if (!memcmp(kc, "format", 6)) d_cur.format = (int32_t)v.as_long();
+              else if (!memcmp(kc, "sssnr0", 6)) d_cur.sssnr0 = v.as_float();
+              else if (!memcmp(kc, "sssnr1", 6)) d_cur.sssnr1 = v.as_float();
+              break;
+            case 7:
+              if (!memcmp(kc, "trellis", 7)) d_cur.trellis = (int32_t)v.as_long();
+              else if (!memcmp(kc, "c8p_llr", 7)) llr_h = v.as_long();
+              break;
+            case 9:
+              if (!memcmp(kc, "c8p_fused", 9)) d_cur_fused = v.as_long();
+              else if (!memcmp(kc, "mu2x1chan", 9)) mu = &v;
+              break;
+            default: break;
+          }
         }
         d_cur.is_ndp = d_cur.trellis == 0;
         d_cur_ext = false;
