@@ -681,13 +681,32 @@ private:
     std::shared_ptr<fused_batch> fb;    // fused mode: the decoded results, handed to decode as they are
     long fb_id = 0;
   };
-  struct out_pkt {
-    std::vector<std::pair<std::string, tag_value>> tags;
+  struct out_pkt {             // one accepted packet waiting for output space: the downloaded tag record (its stream tags are made from it
+    c8p_pkt_tags t;            // when its first item goes out: emit_tags), where its LLR items are, how many have gone out
+    long handle = -1;          // fused mode: the "c8p_fused" value; plain mode with llr_handle: the "c8p_llr" value
     std::shared_ptr<result> res;
     const float* llr = nullptr;       // host copy (pageable output) or device copy (pinned output); null (fused mode): the items are
     bool on_device = false;           // produced, their values are not written
     size_t n = 0, sent = 0;
+    std::vector<gr_complex> mu;       // an NDP's capture (tag "mu2x1chan"), empty otherwise
   };
+
+  // the reference's tags on the packet's first item (demod_impl.cc:224-253, demod2_impl.cc:230-250), in its order, + this front's handle
+  void emit_tags(const out_pkt& o, uint64_t off)
+  {
+    static const std::string K_cfo("cfo"), K_snr("snr"), K_s0("sssnr0"), K_s1("sssnr1"), K_rssi("rssi"), K_format("format"), K_mcs("mcs"), K_len("len"),
+        K_cr("cr"), K_ampdu("ampdu"), K_trellis("trellis"), K_mu("mu2x1chan"), K_total("total"), K_fused("c8p_fused"), K_llr("c8p_llr");
+    const c8p_pkt_tags& t = o.t;
+    auto L = [&](const std::string& k, long v) { d_io->add_item_tag(0, off, k, tag_value::from_long(v)); };
+    auto F = [&](const std::string& k, float v) { d_io->add_item_tag(0, off, k, tag_value::from_float(v)); };
+    F(K_cfo, t.cfo); F(K_snr, t.snr);
+    if (t.format == C8P_F_VHT) { F(K_s0, t.sssnr0); if (d_nports == 2 && t.nss == 2) F(K_s1, t.sssnr1); }
+    F(K_rssi, t.rssi);
+    L(K_format, t.format); L(K_mcs, t.mcs); L(K_len, t.len); L(K_cr, t.cr); L(K_ampdu, t.ampdu); L(K_trellis, t.trellis);
+    if (t.is_ndp) d_io->add_item_tag(0, off, K_mu, tag_value::from_c32vector(o.mu));
+    L(K_total, t.total);
+    if (o.handle >= 0) L(d_eng.d_cfg.fused ? K_fused : K_llr, o.handle);
+  }
 
   // where the next packet's items go in the batch's arena
   uint64_t iq_alloc(stage& st, uint32_t n)
@@ -917,24 +936,14 @@ private:
       if (t.status != C8P_ST_OK) continue;          // DEMOD_S_CLEAN without tags: nothing reaches decode
       out.emplace_back();
       out_pkt& o = out.back();
-      o.tags.reserve(16);
-      auto L = [&](const char* k, long v) { o.tags.emplace_back(k, tag_value::from_long(v)); };
-      auto F = [&](const char* k, float v) { o.tags.emplace_back(k, tag_value::from_float(v)); };
-      F("cfo", t.cfo); F("snr", t.snr);
-      if (t.format == C8P_F_VHT) { F("sssnr0", t.sssnr0); if (d_nports == 2 && t.nss == 2) F("sssnr1", t.sssnr1); }
-      F("rssi", t.rssi);
-      L("format", t.format); L("mcs", t.mcs); L("len", t.len); L("cr", t.cr); L("ampdu", t.ampdu); L("trellis", t.trellis);
-      if (t.is_ndp) {
-        std::vector<gr_complex> c(st.muchan.data() + 128 * p, st.muchan.data() + 128 * p + 128);
-        o.tags.emplace_back("mu2x1chan", tag_value::from_c32vector(c));
-      }
-      L("total", t.total);
+      o.t = t;
+      if (t.is_ndp) o.mu.assign(st.muchan.data() + 128 * p, st.muchan.data() + 128 * p + 128);
       o.n = (size_t)std::max(t.total, 0);
       if (!fused) {
         o.res = res; o.on_device = d_out_dev;
         o.llr = (d_out_dev ? static_cast<const float*>(res->dev_llr.p) : res->llr.data()) + t.llr_off;
-        if (lb_id) L("c8p_llr", (lb_id << C8P_FUSED_IDX_BITS) | (long)p);
-      } else L("c8p_fused", (fb_id << C8P_FUSED_IDX_BITS) | (long)p);
+        if (lb_id) o.handle = (lb_id << C8P_FUSED_IDX_BITS) | (long)p;
+      } else o.handle = (fb_id << C8P_FUSED_IDX_BITS) | (long)p;
     }
   }
 
@@ -944,8 +953,7 @@ private:
     int produced = 0;
     while (!d_outq.empty() && produced < noutput_items) {
       out_pkt& o = d_outq.front();
-      if (o.sent == 0)
-        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + produced, kv.first, kv.second);
+      if (o.sent == 0) emit_tags(o, d_io->nitems_written(0) + (uint64_t)produced);
       const size_t k = std::min(o.n - o.sent, (size_t)(noutput_items - produced));
       // (fused mode: the items exist and are counted, their VALUES ARE NOT WRITTEN — c8p_blocks.h; 57 KB of zeros per packet was a
       // third of this thread's time, and nothing downstream of a fused demod may read them)
@@ -976,8 +984,7 @@ private:
     d_opieces.clear();
     while (!d_outq.empty() && pos < (size_t)noutput_items) {
       out_pkt& o = d_outq.front();
-      if (o.sent == 0)
-        for (auto& kv : o.tags) d_io->add_item_tag(0, d_io->nitems_written(0) + pos, kv.first, kv.second);
+      if (o.sent == 0) emit_tags(o, d_io->nitems_written(0) + (uint64_t)pos);
       const size_t k = std::min(o.n - o.sent, (size_t)noutput_items - pos);
       if (k && o.llr) {
         c8p_piece pc;
