@@ -45,8 +45,10 @@
 #include "c8p_rx.h"
 
 #ifndef C8P_PINNED_BUFFER_MIN_BYTES
-#define C8P_PINNED_BUFFER_MIN_BYTES (8u << 20)   // 8 MB for an edge of complex items, twice that for the float LLR edge (a packet's LLRs are
-                                                  // 1.6 x its samples): a general_work call then sees up to half of it (bench.py: "custom_buffers")
+#define C8P_PINNED_BUFFER_MIN_BYTES (16u << 20)  // 16 MB an edge: a general_work call then sees up to half of it (bench.py: "custom_buffers").  A
+                                                  // front keeps two gathers of a third of its window under way (~45 us each from launch to done) while
+                                                  // it cuts the next third: with 4 MB of samples a call that third is cut faster than a gather takes
+                                                  // and the thread waits 0.35 us per packet (615 k packets/s fused); with 8 MB a call 0.26 (690 k)
 #endif
 
 namespace gr {
@@ -87,7 +89,7 @@ public:
                                      gr::block_sptr link, gr::block_sptr buf_owner)
   {
     // the scheduler asks for its default (64 KB); an edge of this module holds megabytes (see the header comment)
-    const size_t want = ((sizeof_item == sizeof(float) ? 2u : 1u) * (size_t)C8P_PINNED_BUFFER_MIN_BYTES + sizeof_item - 1) / sizeof_item;
+    const size_t want = ((size_t)C8P_PINNED_BUFFER_MIN_BYTES + sizeof_item - 1) / sizeof_item;
     if ((size_t)nitems < want) nitems = (int)want;
     c8p_pinned_buffer* b = new c8p_pinned_buffer(nitems, sizeof_item, downstream_lcm_nitems, downstream_max_out_mult, link, buf_owner);
     gr::buffer_sptr p(b);

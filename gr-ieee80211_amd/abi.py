@@ -11,6 +11,7 @@ ABI_VERSION = 4
 MEM_HOST, MEM_DEVICE, MEM_PINNED = 0, 1, 2
 MEM_SC16, MEM_SC8 = 0x100, 0x200          # flags on the kind for RawChain.push*: int16 / int8 I/Q pairs
 FMT_C32, FMT_SC16, FMT_SC8, FMT_F32 = 0, 1, 2, 3
+PIECE_TO_HOST, PIECE_UNORDERED = 1, 2      # c8p_piece.rsv
 F_L, F_HT, F_VHT, F_VHT_MU, F_VHT_CHAN = 0, 1, 2, 3, 20
 CR_12, CR_23, CR_34, CR_56 = 0, 1, 2, 3
 ST_OK, ST_REJ_VHT, ST_REJ_HT, ST_REJ_SHORT, ST_REJ_UNSUP = 0, 1, 2, 3, 4

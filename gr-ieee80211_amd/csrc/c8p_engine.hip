@@ -261,6 +261,15 @@ struct c8p_ctx {
   bool out_dirty = false;                            // something was enqueued on out_stream since the last mark
   hipEvent_t ev_fence = nullptr;                     // c8p_copy_fence: what the next submit's stream waits for
   bool fence_pending = false;
+  // C8P_PIECE_UNORDERED gathers alternate between the copy stream and this twin of it (same CU mask): gather k + 1 is launched and
+  // ramps up while gather k drains, instead of starting when it has finished.  Marks, fences and waits cover both.
+  hipStream_t copy_stream_b = nullptr;
+  hipEvent_t b_ev[64] = {};
+  bool b_ev_valid[64] = {};
+  bool b_dirty = false, b_fence_dirty = false, b_next = false;
+  hipEvent_t ev_fence_b = nullptr;
+  bool fence_b_pending = false;
+  uint32_t copy_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static bool grow_log() { static const bool on = getenv("C8P_GROW_LOG") != nullptr; return on; }
@@ -387,6 +396,9 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->out_stream) { (void)hipStreamSynchronize(c->out_stream); (void)hipStreamDestroy(c->out_stream); }
   for (hipEvent_t e : c->out_ev) if (e) (void)hipEventDestroy(e);
+  if (c->copy_stream_b) { (void)hipStreamSynchronize(c->copy_stream_b); (void)hipStreamDestroy(c->copy_stream_b); }
+  for (hipEvent_t e : c->b_ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_fence_b) (void)hipEventDestroy(c->ev_fence_b);
   if (c->span_stream) { (void)hipStreamSynchronize(c->span_stream); (void)hipStreamDestroy(c->span_stream); }
   if (c->ev_before_spans) (void)hipEventDestroy(c->ev_before_spans);
   if (c->ev_spans) (void)hipEventDestroy(c->ev_spans);
@@ -619,6 +631,7 @@ static int run_decode_kernels(c8p_ctx* c, int n, const c8p_pkt_tags* d_tags, con
 static int honour_fence(c8p_ctx* c)
 {
   std::lock_guard<std::mutex> g(c->copy_mu);
+  if (c->fence_b_pending) { HIPCHK(c, hipStreamWaitEvent(c->s->stream, c->ev_fence_b, 0)); c->fence_b_pending = false; }
   if (!c->fence_pending) return C8P_OK;
   HIPCHK(c, hipStreamWaitEvent(c->s->stream, c->ev_fence, 0));
   c->fence_pending = false;
@@ -1625,6 +1638,7 @@ extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
     (void)hipSetDevice(c->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
+    if (c->copy_stream_b) (void)hipStreamSynchronize(c->copy_stream_b);
   }
   (void)hipFree(p);
 }
@@ -1649,7 +1663,7 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
     if (ncu < 0 || ncu >= dev_cus || dev_cus > 256) ncu = 0;
     bool masked = false;
     if (ncu > 0) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t* mask = c->copy_mask;
       for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
       masked = hipExtStreamCreateWithCUMask(&c->copy_stream, 8, mask) == hipSuccess;
       if (!masked) { (void)hipGetLastError(); c->copy_stream = nullptr; }
@@ -1683,6 +1697,14 @@ extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
     c->out_ev_valid[slot] = true;
     c->out_dirty = false;
   }
+  c->b_ev_valid[slot] = false;
+  if (c->b_dirty) {                            // ... and the unordered gathers that went to the copy stream's twin
+    hipEvent_t& eb = c->b_ev[slot];
+    if (!eb && hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) return 0;
+    if (hipEventRecord(eb, c->copy_stream_b) != hipSuccess) return 0;
+    c->b_ev_valid[slot] = true;
+    c->b_dirty = false;
+  }
   return ++c->copy_marks;
 }
 extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
@@ -1690,15 +1712,47 @@ extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
   if (!c) return C8P_EINVAL;
   if (mark == 0) return c8p_copy_wait(c);
   if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
-  hipEvent_t e = nullptr, eo = nullptr;
+  hipEvent_t e = nullptr, eo = nullptr, eb = nullptr;
   {
     std::lock_guard<std::mutex> g(c->copy_mu);
     if (mark > c->copy_marks) return C8P_EINVAL;
     e = c->copy_ev[(mark - 1) % 64];            // (re-recorded by a later mark if 64 marks have passed: a later point of the same stream)
     if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
+    if (c->b_ev_valid[(mark - 1) % 64]) eb = c->b_ev[(mark - 1) % 64];
   }
-  if (hipEventSynchronize(e) != hipSuccess) return C8P_EHIP;
-  return (!eo || hipEventSynchronize(eo) == hipSuccess) ? C8P_OK : C8P_EHIP;
+  // a short wait is spun out on the event's state: hipEventSynchronize puts the thread to sleep on the signal's interrupt after a few
+  // microseconds, and a gather of the block fronts (20-50 us) then took 100-250 us to be noticed (profiles/r5q/gather_waits.txt)
+  for (hipEvent_t ev : {e, eb, eo}) {
+    if (!ev) continue;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipEventQuery(ev)) == hipErrorNotReady) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) { q = hipEventSynchronize(ev); break; }
+      __builtin_ia32_pause();
+    }
+    if (q != hipSuccess) { (void)hipGetLastError(); return C8P_EHIP; }
+  }
+  return C8P_OK;
+}
+extern "C" int c8p_copy_mark_done(c8p_ctx* c, uint64_t mark)
+{
+  if (!c || mark == 0) return C8P_EINVAL;
+  if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
+  hipEvent_t e = nullptr, eo = nullptr, eb = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c->copy_mu);
+    if (mark > c->copy_marks) return C8P_EINVAL;
+    e = c->copy_ev[(mark - 1) % 64];
+    if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
+    if (c->b_ev_valid[(mark - 1) % 64]) eb = c->b_ev[(mark - 1) % 64];
+  }
+  for (hipEvent_t ev : {e, eb, eo}) {
+    if (!ev) continue;
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    if (q != hipSuccess) { (void)hipGetLastError(); return C8P_EHIP; }
+  }
+  return 1;
 }
 extern "C" int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes)
 {
@@ -1960,7 +2014,22 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   // device -> host pieces (the caller says so) on the stream of that direction; a long list stays on the copy stream (its table lives there)
   bool to_host = inl;
   for (int i = 0; i < n && to_host; i++) to_host = (pieces[i].rsv & C8P_PIECE_TO_HOST) != 0;
-  const hipStream_t gst = to_host ? c->out_stream : c->copy_stream;
+  // host -> device pieces whose caller needs no order among its gathers (C8P_PIECE_UNORDERED on every piece, a short list): every other
+  // one on the copy stream's twin
+  bool unordered = inl && !to_host;
+  for (int i = 0; i < n && unordered; i++) unordered = (pieces[i].rsv & C8P_PIECE_UNORDERED) != 0;
+  bool on_b = false;
+  if (unordered) {
+    std::lock_guard<std::mutex> g(c->copy_mu);
+    if (!c->copy_stream_b) {
+      if (c->copy_cus) { if (hipExtStreamCreateWithCUMask(&c->copy_stream_b, 8, c->copy_mask) != hipSuccess) { (void)hipGetLastError(); c->copy_stream_b = nullptr; } }
+      if (!c->copy_stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream_b, hipStreamNonBlocking));
+    }
+    on_b = c->b_next;
+    c->b_next = !c->b_next;
+    if (on_b) c->b_dirty = c->b_fence_dirty = true;
+  }
+  const hipStream_t gst = to_host ? c->out_stream : on_b ? c->copy_stream_b : c->copy_stream;
   if (to_host) { std::lock_guard<std::mutex> g(c->copy_mu); c->out_dirty = true; }
   PieceTab itab;
   PieceDev* hp = itab.p;
@@ -2076,6 +2145,12 @@ extern "C" int c8p_copy_fence(c8p_ctx* c)
   }
   HIPCHK(c, hipEventRecord(c->ev_fence, c->copy_stream));
   c->fence_pending = true;
+  if (c->b_fence_dirty) {
+    if (!c->ev_fence_b) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence_b, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_fence_b, c->copy_stream_b));
+    c->fence_b_pending = true;
+    c->b_fence_dirty = false;
+  }
   return C8P_OK;
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c)
@@ -2085,6 +2160,7 @@ extern "C" int c8p_copy_wait(c8p_ctx* c)
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   if (c->span_stream) HIPCHK(c, hipStreamSynchronize(c->span_stream));
   if (c->out_stream) HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  if (c->copy_stream_b) HIPCHK(c, hipStreamSynchronize(c->copy_stream_b));
   return C8P_OK;
 }
 

@@ -68,6 +68,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.copy_gather = (int (*)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t))sym("c8p_copy_gather");
   a.copy_mark = (uint64_t (*)(c8p_ctx*))sym("c8p_copy_mark");
   a.copy_wait_mark = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_wait_mark");
+  a.copy_mark_done = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_mark_done");
   a.copy_fence = (int (*)(c8p_ctx*))sym("c8p_copy_fence");
   a.fetch_gather = (int (*)(c8p_ctx*, const c8p_fetch_piece*, int32_t))sym("c8p_fetch_gather");
   return a;
@@ -101,6 +102,11 @@ static size_t gather_min_buffer()
 {
   const char* e = getenv("C8P_GATHER_MIN_BUFFER");
   return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)C8P_GATHER_MIN_BUFFER;
+}
+static int env_int(const char* name, int dflt)
+{
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
 }
 bool batching_cfg::default_llr_handle()
 {
@@ -408,8 +414,18 @@ struct gather_lane {
   // the gathers that have been enqueued and not waited for, oldest first: the copy-stream mark behind each and the scan position it
   // covers.  A call consumes what the gathers of TWO calls ago moved (DEPTH = 2: a gather takes ~20 us from enqueue to done whatever
   // its size — launch, PCIe round trips, the event — and a call of a busy block comes round faster than that)
-  enum { DEPTH = 2 };
-  struct pend_t { uint64_t mark, scan; };
+  int DEPTH = env_int("C8P_GATHER_DEPTH", 2);
+  bool unordered = env_int("C8P_GATHER_UNORDERED", 1) != 0;
+  struct pend_t { uint64_t mark, scan; tick_t t_enq; };
+  // C8P_GATHER_STATS=1: what the waits of `settle` were, printed when the front goes (tools/probes/chain_quick.py)
+  struct stats_t { bool on = env_int("C8P_GATHER_STATS", 0) != 0; long calls = 0, waits = 0, slow = 0; double us = 0, worst = 0, age_slow = 0, age_fast = 0; uint64_t items = 0; } stats;
+  ~gather_lane()
+  {
+    if (stats.on && stats.calls)
+      fprintf(stderr, "gather_lane: %ld settles, %ld with a wait (%ld over 5 us), %.0f us waited (worst %.0f), %.0f items a gather, depth %d; enqueue -> noticed done: "
+              "%.0f us after a wait over 5 us, %.0f us after a shorter one\n", stats.calls, stats.waits, stats.slow, stats.us, stats.worst,
+              (double)stats.items / std::max(1L, stats.calls), DEPTH, stats.age_slow / std::max(1L, stats.slow), stats.age_fast / std::max(1L, stats.waits - stats.slow));
+  }
   std::deque<pend_t> pend;
   // How far this call looks.  A scheduler offers a block everything its input buffer holds; a front that cut all of it at once would then
   // find nothing new in the next call and could only wait for its own gather.  With deferred consume it takes a THIRD of the largest
@@ -421,7 +437,7 @@ struct gather_lane {
   {
     hwm_window = std::max(hwm_window, nproc);
     if (!E.d_cfg.defer_consume) return nproc;
-    const int third = std::max(hwm_window / 3, 4096);
+    const int third = std::max(hwm_window / (DEPTH + 1), 4096);
     return std::min(nproc, used + third);
   }
   void add(const void* src, uint64_t dst_off, uint64_t n, uint32_t fmt)
@@ -436,6 +452,7 @@ struct gather_lane {
     c8p_piece pc;
     memset(&pc, 0, sizeof(pc));
     pc.src = src; pc.dst_off = dst_off; pc.n = n; pc.trusted = 1; pc.fmt = fmt; pc.scale = 1.0f;
+    pc.rsv = unordered ? C8P_PIECE_UNORDERED : 0u;     // (every piece has its own place in the batch's arena: the gathers of a lane may pass each other)
     pieces.push_back(pc);
   }
   void flush(engine_holder& E, void* dst)
@@ -455,7 +472,7 @@ struct gather_lane {
     if (dirty) {
       const uint64_t m = A.copy_mark(E.d_ctx);
       if (!m) throw std::runtime_error("c8p_copy_mark failed");
-      pend.push_back(pend_t{m, scan_abs});
+      pend.push_back(pend_t{m, scan_abs, now_tick()});
       dirty = false;
     } else if (!pend.empty()) pend.back().scan = scan_abs;                           // (items without a gather of their own: skipped ones)
     sub_scope w(ph, phase_clock::GWAIT);
@@ -463,10 +480,22 @@ struct gather_lane {
     // scheduler has nothing more to offer until these items are let go of)
     const size_t keep = (E.d_cfg.defer_consume && fresh) ? (size_t)DEPTH : 0;
     uint64_t done_scan = rd;
+    const tick_t t0 = stats.on ? now_tick() : tick_t();
+    const bool waited = pend.size() > keep;
+    const tick_t t_enq = waited ? pend.front().t_enq : tick_t();
     while (pend.size() > keep) {
       E.check(A.copy_wait_mark(E.d_ctx, pend.front().mark), "c8p_copy_wait_mark");
       done_scan = std::max(done_scan, pend.front().scan);
       pend.pop_front();
+    }
+    if (stats.on) {
+      const double u = std::chrono::duration<double, std::micro>(now_tick() - t0).count();
+      stats.calls++; stats.items += (uint64_t)used;
+      if (waited) {
+        const double age = std::chrono::duration<double, std::micro>(now_tick() - t_enq).count();
+        stats.waits++; stats.us += u; stats.worst = std::max(stats.worst, u);
+        if (u > 5.0) { stats.slow++; stats.age_slow += age; } else stats.age_fast += age;
+      }
     }
     if (pend.empty()) return used;
     return (int)std::min<uint64_t>(done_scan - rd, (uint64_t)used);
@@ -492,9 +521,13 @@ public:
   ~demod_front() override
   {
     d_timer.stop();
+    if (d_scat_stats.launches && env_int("C8P_GATHER_STATS", 0))
+      fprintf(stderr, "llr scatter: %ld launches of %.0f items; waits: throttle %ld (%.0f us), space taken %ld (%.0f us), no progress %ld (%.0f us)\n",
+              d_scat_stats.launches, d_scat_stats.items / (double)d_scat_stats.launches, d_scat_stats.n[0], d_scat_stats.us[0], d_scat_stats.n[1],
+              d_scat_stats.us[1], d_scat_stats.n[2], d_scat_stats.us[2]);
     fused_purge(d_fused_ids);                      // the batches this front parked and no decode picked up
     llr_purge(d_llr_ids);
-    d_outq.clear(); d_hold.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
+    d_outq.clear(); d_scat.clear(); d_pool.clear();    // (results own device memory of d_eng's ctx)
     for (stage& st : d_st) { d_eng.dev_release(st.d_iq); d_eng.dev_release(st.d_chan); }
   }
 
@@ -535,9 +568,8 @@ public:
     for (int p = 1; p < d_nports; p++) nproc = std::min(nproc, ninput_items[p]);
     const uint64_t rd = d_io->nitems_read(0);
     // A pinned output buffer: the LLR items that are ready start moving — one kernel that writes them where the scheduler wants them —
-    // and are REPORTED by the next call, when the device has had a scheduler round trip to write them (drain_scatter)
-    int produced = 0;
-    if (d_out_dev) produced = drain_scatter(static_cast<float*>(output_items[0]), noutput_items);
+    // and are REPORTED at the end of the call in which they have arrived (scatter_place / scatter_report)
+    if (d_out_dev) scatter_place(static_cast<float*>(output_items[0]), noutput_items);
     int used = 0;
     if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
       if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
@@ -610,7 +642,7 @@ public:
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     if (!d_st[d_fill].pk.empty() || !d_fly.empty()) d_timer.poke();
-    if (d_out_dev) return produced;
+    if (d_out_dev) return scatter_report(noutput_items, cons > 0);
     return drain(static_cast<float*>(output_items[0]), noutput_items);
   }
 
@@ -834,7 +866,7 @@ private:
       }
       if (!d_eng.d_cfg.fused) {       // the whole LLR arena (laid out for the worst case per n_items: ~1.8x what VHT packets use):
         // to the host (a pageable output buffer: drain() copies the packets' items out of it) or into a device buffer of this front
-        // (a pinned one: drain_scatter() moves the items from there, however long the scheduler takes to offer the space)
+        // (a pinned one: scatter_place() moves the items from there, however long the scheduler takes to offer the space)
         if (bytes) d_eng.check(A.fetch_async(d_eng.d_ctx, C8P_BUF_LLR, d_out_dev ? st.res->dev_llr.p : (void*)st.res->llr.data(), 0, bytes), "llr");
       } else {
         piece(C8P_BUF_OUT, st.fb->outs.data(), n * sizeof(c8p_pkt_out), 0);
@@ -966,22 +998,47 @@ private:
 
   // drain() for a pinned output buffer: the items of every packet that fits go from the front's device copy of the LLR arena into the
   // scheduler's buffer with ONE c8p_copy_gather (device -> pinned host: the shader cores write over PCIe), only the bytes the packets
-  // use (the arena's layout is ~1.8x that), no host copy in between.  The items are written AHEAD: this call places them behind what
-  // earlier calls placed and reports what the PREVIOUS call placed — [0, d_ready) of the space it is given is complete, [d_ready,
-  // d_ready + d_inflight) is being written (d_mark).  A scheduler's output pointer continues where produce() stopped, so the items
-  // of this call are where the next call's space begins (c8p_blocks.h, output_ahead).
-  int drain_scatter(float* out, int noutput_items)
+  // use (the arena's layout is ~1.8x that), no host copy in between.  The items are written AHEAD: a call places them behind what
+  // earlier calls placed (scatter_place, at the start of general_work) and reports what has ARRIVED by its end (scatter_report) —
+  // [0, d_ready) of the space it is given is complete, [d_ready, d_ready + d_inflight) is being written by up to SCAT_DEPTH launches
+  // (d_scat).  A scheduler's output pointer continues where produce() stopped, so the items placed by this call are where a later
+  // call's space begins (c8p_blocks.h, output_ahead).  Nothing is waited for while the call makes progress some other way: an 8 MB
+  // scatter takes 180 us, and the version that waited for the previous call's scatter at the start of every call spent 1.1-1.3 us per
+  // packet doing so (profiles/r5q).
+  enum { SCAT_DEPTH = 3 };
+  struct scat_t { uint64_t mark; size_t n; std::vector<std::shared_ptr<result>> hold; };   // (its arenas are being read until the mark)
+  struct scat_stats_t { long n[3] = {0, 0, 0}; double us[3] = {0, 0, 0}; long launches = 0; double items = 0; } d_scat_stats;   // C8P_GATHER_STATS
+  void scatter_collect(bool block_oldest, int why = 0)
+  {
+    const c8p_api& A = d_eng.d_api;
+    while (!d_scat.empty()) {
+      scat_t& sc = d_scat.front();
+      if (block_oldest) {
+        sub_scope w(d_ph, phase_clock::GWAIT);
+        const tick_t t0 = now_tick();
+        d_eng.check(A.copy_wait_mark(d_eng.d_ctx, sc.mark), "c8p_copy_wait_mark");
+        d_scat_stats.n[why]++; d_scat_stats.us[why] += std::chrono::duration<double, std::micro>(now_tick() - t0).count();
+        block_oldest = false;
+      } else {
+        const int done = A.copy_mark_done(d_eng.d_ctx, sc.mark);
+        if (done < 0) d_eng.check(done, "c8p_copy_mark_done");
+        if (!done) return;
+      }
+      d_ready += sc.n; d_inflight -= sc.n;
+      d_scat.pop_front();
+    }
+  }
+  void scatter_place(float* out, int noutput_items)
   {
     sub_scope ph(d_ph, phase_clock::DRAIN);
     const c8p_api& A = d_eng.d_api;
-    if (d_inflight) {
-      sub_scope w(d_ph, phase_clock::GWAIT);
-      d_eng.check(A.copy_wait_mark(d_eng.d_ctx, d_mark), "c8p_copy_wait_mark");
-      d_ready += d_inflight; d_inflight = 0;
-      d_hold.clear();
-    }
-    size_t pos = d_ready;
+    scatter_collect(false);
+    if (d_outq.empty()) return;
+    while (d_scat.size() >= (size_t)SCAT_DEPTH) scatter_collect(true, 0);
+    size_t pos = d_ready + d_inflight;
+    const size_t pos0 = pos;
     d_opieces.clear();
+    scat_t sc;
     while (!d_outq.empty() && pos < (size_t)noutput_items) {
       out_pkt& o = d_outq.front();
       if (o.sent == 0) emit_tags(o, d_io->nitems_written(0) + (uint64_t)pos);
@@ -994,15 +1051,36 @@ private:
         d_opieces.push_back(pc);
       }
       o.sent += k; pos += k;
-      if (o.sent == o.n) { d_hold.push_back(std::move(o.res)); d_outq.pop_front(); }    // (its arena is being read until the mark)
+      if (o.sent == o.n) { if (sc.hold.empty() || sc.hold.back() != o.res) sc.hold.push_back(std::move(o.res)); d_outq.pop_front(); }
     }
-    if (pos > d_ready) {
-      if (!d_opieces.empty()) {
-        d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
-        d_mark = A.copy_mark(d_eng.d_ctx);
-        if (!d_mark) throw std::runtime_error("c8p_copy_mark failed");
-        d_inflight = pos - d_ready;
-      } else d_ready = pos;                          // (packets without items: nothing to wait for)
+    if (pos == pos0) return;
+    if (d_opieces.empty()) {                         // (packets without items: nothing to wait for, but they keep their place in the order)
+      if (d_scat.empty()) d_ready += pos - pos0; else { d_scat.back().n += pos - pos0; d_inflight += pos - pos0; }
+      return;
+    }
+    d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
+    sc.mark = A.copy_mark(d_eng.d_ctx);
+    if (!sc.mark) throw std::runtime_error("c8p_copy_mark failed");
+    sc.n = pos - pos0;
+    d_scat_stats.launches++; d_scat_stats.items += (double)sc.n;
+    d_inflight += sc.n;
+    d_scat.push_back(std::move(sc));
+  }
+  // the end of the call: what has arrived is reported.  A call that has consumed input waits for nothing.  One that has not and would
+  // report nothing waits for its oldest scatter (a scheduler does not call again a block that made no progress until a neighbour
+  // does); if its space is taken up by what is under way — a scheduler at the end of its buffer asks for exactly those items, without
+  // input — it waits for all of them
+  int scatter_report(int noutput_items, bool progressed)
+  {
+    sub_scope ph(d_ph, phase_clock::DRAIN);
+    scatter_collect(false);
+    if (!d_scat.empty()) {
+      const bool taken = d_ready + d_inflight >= (size_t)noutput_items;
+      if (!progressed) {
+        if (taken) while (!d_scat.empty() && d_ready < (size_t)noutput_items) scatter_collect(true, 1);
+        else if (d_ready == 0) scatter_collect(true, 2);
+      } else if (taken && d_ready == 0 && d_outq.size() > 2 * (size_t)d_eng.d_cfg.max_batch)
+        scatter_collect(true, 0);                    // (input is being cut faster than the link takes the items away: no further ahead than this)
     }
     const size_t produced = std::min(d_ready, (size_t)noutput_items);
     d_ready -= produced;
@@ -1027,9 +1105,9 @@ private:
   tag_cursor d_tc;
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   std::vector<c8p_piece> d_opieces;
-  size_t d_ready = 0, d_inflight = 0;              // drain_scatter: items placed in the output buffer and not reported yet (complete / being written)
-  uint64_t d_mark = 0;                             // ... the copy-stream mark behind the ones being written
-  std::vector<std::shared_ptr<result>> d_pool, d_hold;
+  size_t d_ready = 0, d_inflight = 0;              // scatter_place: items placed in the output buffer and not reported yet (complete / being written)
+  std::deque<scat_t> d_scat;                       // ... the launches that write them, oldest first
+  std::vector<std::shared_ptr<result>> d_pool;
   std::vector<std::shared_ptr<fused_batch>> d_fpool;
   size_t d_hwm_llr = 0, d_hwm_pkt = 0, d_hwm_pdu = 0;
   std::deque<out_pkt> d_outq;

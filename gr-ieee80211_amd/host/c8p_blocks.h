@@ -132,6 +132,7 @@ struct c8p_api {
   int (*copy_gather)(c8p_ctx*, c8p_c32*, const c8p_piece*, int32_t);
   uint64_t (*copy_mark)(c8p_ctx*);
   int (*copy_wait_mark)(c8p_ctx*, uint64_t);
+  int (*copy_mark_done)(c8p_ctx*, uint64_t);
   int (*copy_fence)(c8p_ctx*);
   int (*fetch_gather)(c8p_ctx*, const c8p_fetch_piece*, int32_t);
 };

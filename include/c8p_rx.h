@@ -499,7 +499,9 @@ int   c8p_copy_wait(c8p_ctx* ctx);
 /* A mark on the copy stream: c8p_copy_mark returns a ticket (> 0) for "every copy enqueued so far"; c8p_copy_wait_mark(ticket) returns
  * when those copies are done — from any thread, also while another thread keeps enqueuing copies on the same ctx (the one exception
  * to "a ctx is not internally locked": marks and c8p_copy_async / c8p_copy_spans may be called concurrently).  The last 64 marks can
- * be waited for; an older ticket waits for a newer mark (never too little). */
+ * be waited for; an older ticket waits for a newer mark (never too little).  c8p_copy_mark_done(ticket) asks without waiting: 1 = those
+ * copies are done, 0 = not yet, < 0 an error — how a caller that keeps several gathers in flight (the demod mirror's LLR output, written
+ * ahead) collects the finished ones on its way past. */
 /* n pieces gathered into dst by ONE kernel launch on the copy stream: piece i = n items from src (device memory, or host memory the
  * device can read: c8p_host_alloc / hipHostMalloc / hipHostRegister-ed) to dst + dst_off.  The shader cores read the host memory
  * over PCIe themselves, so no DMA engine is involved and the rate does not depend on the size of the pieces (54-57 GB/s alone;
@@ -521,13 +523,19 @@ typedef struct c8p_piece {
                                — one hipPointerGetAttributes per piece costs ~4 us, a millisecond per round of 256 pushes               */
   uint32_t fmt;             /* C8P_FMT_* (one c8p_copy_gather call may mix them, except C8P_FMT_F32 with the others: dst_off units differ)     */
   float    scale;           /* C8P_FMT_SC16 / _SC8: item = ((float)i * scale, (float)q * scale), one float32 multiply each             */
-  uint32_t rsv;             /* C8P_PIECE_TO_HOST or 0 (every piece of a call the same)                                                 */
+  uint32_t rsv;             /* C8P_PIECE_TO_HOST, C8P_PIECE_UNORDERED or 0 (every piece of a call the same)                            */
 } c8p_piece;
 /* c8p_piece.rsv: the pieces of this call travel FROM the device TO host memory.  Such a call (up to C8P_GATHER_INLINE pieces) runs on a
  * copy stream of its own, so that a block that feeds the device and drains it at the same time (the demod mirror: samples down, LLR
  * items up) uses both directions of the link at once instead of queueing one transfer behind the other — each launch takes ~18 us
  * from enqueue to done whatever its size.  c8p_copy_mark / _wait_mark / _wait cover both streams. */
 #define C8P_PIECE_TO_HOST 1u
+/* c8p_piece.rsv, host -> device pieces (every piece of a call the same, up to C8P_GATHER_INLINE pieces): this call needs no order against the
+ * ctx's other gathers — only marks, fences and waits, which cover it.  Such calls alternate between the copy stream and a twin of it: the
+ * next gather is launched and ramps up while this one drains (a stream starts a kernel when the one before it has finished:
+ * 1.4 MB gathers back to back 29.9 -> 27.8 us apiece, 46.8 -> 50.3 GB/s, tools/probes/link_duplex.py).  Without the flag two gathers of one
+ * ctx run in the order they were enqueued (the second may overwrite what the first wrote). */
+#define C8P_PIECE_UNORDERED 2u
 /* C8P_FMT_SC16: what the radio puts on the wire.  The reference's flowgraph takes its stream from a UHD source with the default wire
  * format sc16 and CPU format fc32 (/root/reference/examples/rx.grc:689 `otw: ''`, :744 `type: fc32`): the host converts every sample
  * to float before the first block sees it.  Here the 4-byte samples cross PCIe and the gather kernel converts them on their way into
@@ -541,6 +549,7 @@ typedef struct c8p_piece {
 int   c8p_copy_gather(c8p_ctx* ctx, c8p_c32* dst, const c8p_piece* pieces, int32_t n);           /* pieces: host memory */
 uint64_t c8p_copy_mark(c8p_ctx* ctx);
 int   c8p_copy_wait_mark(c8p_ctx* ctx, uint64_t mark);
+int   c8p_copy_mark_done(c8p_ctx* ctx, uint64_t mark);
 /* The NEXT submit of this ctx (c8p_demod / c8p_decode / c8p_rx) waits ON THE DEVICE for every copy enqueued on the copy stream so far:
  * how a caller that fills its own C8P_MEM_DEVICE arenas with c8p_copy_gather / c8p_copy_async hands them to a submit without
  * blocking a host thread in between (the block mirrors: pieces of the scheduler's pinned input buffer -> the batch's arena -> c8p_rx). */

@@ -18,6 +18,7 @@ struct c8p_ctx {
   const c8p_c32* det_raw; uint64_t det_raw_n;                                           /* C8P_BUF_DET_RAW: the caller's items */
   int n_sig; c8p_pkt_in* sig_pkt; c8p_c32* sig_iq; uint64_t n_sig_iq; c8p_c32* sig_chan;
   struct res r[SLOTS];
+  uint64_t asked_mark;                                        /* c8p_copy_mark_done: the mark last asked about */
   struct pend *pend_head, *pend_tail;                       /* c8p_copy_gather calls not yet executed (see run_pending) */
   int cur, seq, slots;
   struct res* s;      /* selected submit */
@@ -220,7 +221,7 @@ void c8p_dev_free(c8p_ctx* c, void* p) { if (c) run_pending(c); free(p); }
  * on the device: a c8p_copy_gather only records its pieces; they are executed — in order — by whatever the header says completes or
  * orders them: c8p_copy_wait / _wait_mark, c8p_copy_fence, a later copy on the same stream (c8p_copy_async, c8p_copy_spans, a long
  * c8p_copy_gather, which waits for the stream), c8p_dev_free.  Submits do NOT run them. */
-struct pend { c8p_c32* dst; c8p_piece* pc; int n; struct pend* next; };
+struct pend { c8p_c32* dst; c8p_piece* pc; int n, unordered; struct pend *next, *rnext; };
 static int run_gather(c8p_c32* dst, const c8p_piece* pc, int32_t n)
 {
   for (int i = 0; i < n; i++) {
@@ -246,7 +247,12 @@ static void run_pending(c8p_ctx* c)
 {
   struct pend* p = c->pend_head;
   c->pend_head = c->pend_tail = NULL;
-  while (p) { struct pend* nx = p->next; run_gather(p->dst, p->pc, p->n); free(p->pc); free(p); p = nx; }
+  /* C8P_PIECE_UNORDERED calls first, newest first (they promised not to depend on any order), then the others in the order they came */
+  struct pend* rev = NULL;
+  for (struct pend* q = p; q; q = q->next)
+    if (q->n > 0 && q->n <= C8P_GATHER_INLINE && (q->pc[0].rsv & C8P_PIECE_UNORDERED)) { q->unordered = 1; q->rnext = rev; rev = q; }
+  for (struct pend* q = rev; q; q = q->rnext) run_gather(q->dst, q->pc, q->n);
+  while (p) { struct pend* nx = p->next; if (!p->unordered) run_gather(p->dst, p->pc, p->n); free(p->pc); free(p); p = nx; }
 }
 int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { run_pending(c); memmove(dst, src, bytes); return C8P_OK; }
 int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* sp, int32_t n)
@@ -274,6 +280,15 @@ int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pc, int32_t n)
 int c8p_copy_wait(c8p_ctx* c) { run_pending(c); return C8P_OK; }
 uint64_t c8p_copy_mark(c8p_ctx* c) { return (uint64_t)++c->submits; }
 int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark) { (void)mark; run_pending(c); return C8P_OK; }
+/* the first question about a mark finds its copies still on their way (nothing has been moved), the second one finds them done */
+int c8p_copy_mark_done(c8p_ctx* c, uint64_t mark)
+{
+  if (!mark || mark > (uint64_t)c->submits) return C8P_EINVAL;
+  if (!c->pend_head) return 1;
+  if (c->asked_mark != mark) { c->asked_mark = mark; return 0; }
+  run_pending(c);
+  return 1;
+}
 int c8p_copy_fence(c8p_ctx* c) { run_pending(c); return C8P_OK; }
 int c8p_sync(c8p_ctx* c) { (void)c; return C8P_OK; }
 

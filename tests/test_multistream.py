@@ -533,6 +533,71 @@ def test_copy_gather_moves_f32_pieces_both_ways_exactly(n_pieces):
     e.close()
 
 
+def unordered_gathers_and_mark_done(L, ctx, alloc_dst, read_dst, pinned):
+    """24 C8P_PIECE_UNORDERED gathers (they alternate between the copy stream and its twin) into disjoint stretches of one arena, one mark
+    behind them: c8p_copy_mark_done goes from "not yet" (or straight) to 1 and never back, c8p_copy_wait_mark then returns at once, and
+    every stretch has arrived; a mark that does not exist is refused"""
+    import ctypes as C
+    rng = np.random.default_rng(23)
+    n_each, k = 50_000, 24
+    src = pinned(n_each * k)
+    src[:] = rng.normal(size=n_each * k).astype(np.float32)
+    dst = alloc_dst(n_each * k + 16)
+    for i in range(k):
+        pc = (abi.Piece * 1)(abi.Piece(src.ctypes.data + 4 * n_each * i, 5 + n_each * i, n_each, 1, abi.FMT_F32, 1.0, abi.PIECE_UNORDERED))
+        assert L.c8p_copy_gather(ctx, C.c_void_p(dst), pc, 1) == 0
+    mark = L.c8p_copy_mark(ctx)
+    assert mark > 0
+    assert L.c8p_copy_mark_done(ctx, mark + 1) == -22 and L.c8p_copy_mark_done(ctx, 0) == -22
+    seen_done = False
+    for _ in range(2_000_000):
+        d = L.c8p_copy_mark_done(ctx, mark)
+        assert d in (0, 1) and not (seen_done and d == 0)
+        if d == 1:
+            seen_done = True
+            break
+    assert seen_done
+    assert L.c8p_copy_mark_done(ctx, mark) == 1 and L.c8p_copy_wait_mark(ctx, mark) == 0
+    got = read_dst(dst, n_each * k + 16)
+    assert np.array_equal(got[5:5 + n_each * k].view(np.uint32), src.view(np.uint32))
+    assert L.c8p_copy_fence(ctx) == 0 and L.c8p_copy_wait(ctx) == 0
+
+
+def test_unordered_gathers_and_mark_done_on_the_fake_engine():
+    import ctypes as C, os
+    from gr_ieee80211_amd import blocks
+    L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_c8p", "libc8p_fake.so"))
+    L.c8p_create.restype = C.c_void_p
+    L.c8p_copy_mark.restype = C.c_uint64
+    L.c8p_copy_mark.argtypes = [C.c_void_p]
+    L.c8p_copy_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.c8p_copy_mark_done.argtypes = [C.c_void_p, C.c_uint64]
+    L.c8p_copy_wait_mark.argtypes = [C.c_void_p, C.c_uint64]
+    L.c8p_copy_fence.argtypes = [C.c_void_p]
+    L.c8p_copy_wait.argtypes = [C.c_void_p]
+    L.c8p_destroy.argtypes = [C.c_void_p]
+    ctx = L.c8p_create(None)
+    keep = []
+    def alloc(n):
+        a = np.full(n, -1.0, np.float32); keep.append(a); return a.ctypes.data
+    unordered_gathers_and_mark_done(L, ctx, alloc, lambda p, n: keep[-1], lambda n: np.zeros(n, np.float32))
+    L.c8p_destroy(ctx)
+
+
+@pytest.mark.gpu
+def test_unordered_gathers_and_mark_done_on_the_engine():
+    import torch
+    from gr_ieee80211_amd import engine
+    e = engine.Engine(device=0)
+    box = {}
+    def alloc(n):
+        box["dst"] = torch.full((n,), -1.0, dtype=torch.float32, device="cuda:0"); torch.cuda.synchronize(); return box["dst"].data_ptr()
+    def pinned(n):
+        box["src"] = torch.empty(n, dtype=torch.float32).pin_memory(); return box["src"].numpy()
+    unordered_gathers_and_mark_done(e.L, e.ctx, alloc, lambda p, n: box["dst"].cpu().numpy(), pinned)
+    e.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cus", ["default", "0"])
 def test_copy_spans_moves_exactly_the_spans(cus, monkeypatch):

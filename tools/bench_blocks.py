@@ -69,10 +69,11 @@ def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bit
 
 # What one general_work call is offered / may produce: (items of the demod input per call, LLR items of its output per call).
 # "custom": the edge buffers come from the blocks' own buffer type (pinned host memory, c8p_block::buffer_alloc) and that type sizes
-# them — 8 MB for an edge of complex items, 16 MB for the LLR edge (a cfg-2 packet is 35 KB of samples and 57 KB of LLRs), of which a
-# call sees half: 524 288 complex items in, 2 097 152 floats out.  "sched64k": the sizes rounds 1-4 measured with (512 KB / 1 MB a
-# call), kept for continuity.
-IO_SIZES = {"custom": (1 << 19, 1 << 21), "sched64k": (1 << 16, 1 << 18)}
+# them — 16 MB an edge (gnuradio/lib/c8p_pinned_buffer.h; a cfg-2 packet is 35 KB of samples and 57 KB of LLRs), of which a call sees
+# half: 1 048 576 complex items in, 2 097 152 floats out.  "custom8": the sample edge at 8 MB, as the round's first profiles had it
+# (the thread then waits for its gathers: fused 595-615 k against 686-697 k on one box).  "sched64k": the sizes rounds 1-4 measured
+# with (512 KB / 1 MB a call), kept for continuity.
+IO_SIZES = {"custom": (1 << 20, 1 << 21), "custom8": (1 << 19, 1 << 21), "custom32": (1 << 21, 1 << 22), "sched64k": (1 << 16, 1 << 18)}
 
 
 def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto"):
