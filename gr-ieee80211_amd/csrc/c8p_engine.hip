@@ -1720,8 +1720,9 @@ extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
     if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
     if (c->b_ev_valid[(mark - 1) % 64]) eb = c->b_ev[(mark - 1) % 64];
   }
-  // a short wait is spun out on the event's state: hipEventSynchronize puts the thread to sleep on the signal's interrupt after a few
-  // microseconds, and a gather of the block fronts (20-50 us) then took 100-250 us to be noticed (profiles/r5q/gather_waits.txt)
+  // a short wait is spun out on the event's state before hipEventSynchronize (which may put the thread to sleep on the signal's
+  // interrupt) is asked: the block fronts wait 20-50 us for a gather, thousands of times a second (profiles/r5q/gather_waits.txt: the
+  // waits themselves did not get shorter — what is waited for is the gather)
   for (hipEvent_t ev : {e, eb, eo}) {
     if (!ev) continue;
     const auto t0 = std::chrono::steady_clock::now();
