@@ -545,7 +545,7 @@ def dry_launch(args):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(1e-4 * (1 + rank))                    # (rank r is r times slower: the max-reduction and the per-rank spread have something to show)
+        time.sleep(2e-3 * (1 + rank))                    # (rank r is r times slower: the max-reduction and the per-rank spread have something to show)
     mine = time.perf_counter() - t0
     if use_dist:
         dist.barrier()

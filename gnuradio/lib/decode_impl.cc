@@ -11,7 +11,6 @@ decode_impl::decode_impl(bool ifdebug)
 {
   message_port_register_out(pmt::mp("out"));     // decode_impl.cc:39
   c8p::batching_cfg cfg;
-  cfg.defer_consume = false;                     // (see demod_impl.cc)
   attach(c8p::decode::make(ifdebug, c8p::default_c8p_api(), cfg));
 }
 

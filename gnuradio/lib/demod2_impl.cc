@@ -12,7 +12,6 @@ demod2_impl::demod2_impl()
                            gr::io_signature::make(1, 1, sizeof(float), c8p_pinned_buffer::type))
 {
   c8p::batching_cfg cfg;
-  cfg.defer_consume = false;                     // (see demod_impl.cc)
   attach(c8p::demod2::make(c8p::default_c8p_api(), cfg));
 }
 

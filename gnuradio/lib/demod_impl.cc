@@ -17,7 +17,6 @@ demod_impl::demod_impl(int mupos, int mugid)
                           gr::io_signature::make(1, 1, sizeof(float), c8p_pinned_buffer::type))
 {
   c8p::batching_cfg cfg;
-  cfg.defer_consume = false;                     // a single-mapped buffer relocates unread items: no gather in flight across calls
   attach(c8p::demod::make(mupos, mugid, c8p::default_c8p_api(), cfg));   // loads libc8p_rx.so (C8P_RX_LIB or the loader path); throws without a HIP device
 }
 

@@ -38,6 +38,7 @@ def lib():
         L.c8ph_create_ex2.restype = C.c_void_p
         L.c8ph_create_ex2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.c8ph_set_poison.argtypes = [C.c_void_p, C.c_int]
+        L.c8ph_set_relocate.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_output_pinned.argtypes = [C.c_void_p]
         L.c8ph_run_chain.restype = C.c_long
@@ -149,6 +150,11 @@ class Block:
     def set_poison(self, on):
         """from now on consumed input items are overwritten at once (a test: nothing may still be reading them)"""
         self.L.c8ph_set_poison(self.h, int(on))
+
+    def set_relocate(self, every):
+        """every n-th general_work call of run() finds the unread items of its pinned input buffers moved to other memory (announced with
+        c8p::buffer_will_move, the old memory overwritten): what a single-mapped GNU Radio buffer does at its end.  0: never"""
+        self.L.c8ph_set_relocate(self.h, int(every))
 
     def input_pinned(self, port=0):
         return bool(self.L.c8ph_input_pinned(self.h, port))

@@ -108,6 +108,26 @@ static int env_int(const char* name, int dflt)
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
 }
+// the fronts of this process, for buffer_will_move
+static std::mutex g_fronts_mu;
+static std::vector<c8p_block*> g_fronts;
+struct front_registration {
+  c8p_block* b;
+  explicit front_registration(c8p_block* b_) : b(b_) { std::lock_guard<std::mutex> g(g_fronts_mu); g_fronts.push_back(b); }
+  void leave()
+  {
+    if (!b) return;
+    std::lock_guard<std::mutex> g(g_fronts_mu);
+    g_fronts.erase(std::remove(g_fronts.begin(), g_fronts.end(), b), g_fronts.end());
+    b = nullptr;
+  }
+  ~front_registration() { leave(); }
+};
+void buffer_will_move(const void* base, size_t bytes)
+{
+  std::lock_guard<std::mutex> g(g_fronts_mu);           // (a front leaves the list before anything of it is destroyed)
+  for (c8p_block* b : g_fronts) b->quiesce(base, bytes);
+}
 bool batching_cfg::default_llr_handle()
 {
   const char* e = getenv("C8P_LLR_HANDLE");
@@ -384,16 +404,20 @@ public:
     return v;
   }
   // device memory a front keeps across submits (the arenas its gathers fill): grown x 2, the first keep_bytes moved along by a copy
-  // on the copy stream (behind every gather enqueued so far); c8p_dev_free waits for that stream before it frees
+  // on the copy stream (behind every gather enqueued so far); c8p_dev_free waits for the copy streams before it frees
   struct dev_buf { void* p = nullptr; size_t cap = 0; };
   void dev_reserve(dev_buf& b, size_t bytes, size_t keep_bytes)
   {
     if (bytes <= b.cap) return;
-    const size_t nc = std::max<size_t>(std::max(bytes, 2 * b.cap), 1u << 20);
+    // (C8P_ARENA_MIN: the tests make the arenas start tiny, so that they grow while gathers into them are under way)
+    static const size_t arena_min = (size_t)std::max(env_int("C8P_ARENA_MIN", 1 << 20), 64);
+    const size_t nc = std::max<size_t>(std::max(bytes, 2 * b.cap), arena_min);
     void* q = d_api.dev_alloc(d_ctx, nc);
     if (!q) throw std::runtime_error(std::string("c8p_dev_alloc failed: ") + d_api.last_error(d_ctx));
     if (b.p) {
-      if (keep_bytes) check(d_api.copy_async(d_ctx, q, b.p, keep_bytes), "arena move");
+      // (the gathers that fill the old arena may be on either of two copy streams — C8P_PIECE_UNORDERED — and the move runs on one of
+      // them: everything enqueued so far is waited for first.  Arenas grow in a front's first batches and then no more)
+      if (keep_bytes) { check(d_api.copy_wait(d_ctx), "c8p_copy_wait"); check(d_api.copy_async(d_ctx, q, b.p, keep_bytes), "arena move"); }
       d_api.dev_free(d_ctx, b.p);
     }
     b.p = q; b.cap = nc;
@@ -416,15 +440,20 @@ struct gather_lane {
   // its size — launch, PCIe round trips, the event — and a call of a busy block comes round faster than that)
   int DEPTH = env_int("C8P_GATHER_DEPTH", 2);
   bool unordered = env_int("C8P_GATHER_UNORDERED", 1) != 0;
-  struct pend_t { uint64_t mark, scan; tick_t t_enq; };
+  // Without deferred consume a call waits for its own gathers before it returns: they then start while the call is still cutting —
+  // every C8P_GATHER_CHUNK bytes of pieces go at once — and only the last one is still on its way when the call comes to wait
+  size_t chunk_bytes = (size_t)env_int("C8P_GATHER_CHUNK", 1 << 20), pending_bytes = 0;
+  bool want_flush(const engine_holder& E) const { return !E.d_cfg.defer_consume && pending_bytes >= chunk_bytes; }
+  struct pend_t { uint64_t mark, scan; tick_t t_enq; uintptr_t lo, hi; };      // [lo, hi): the host addresses its gathers read
   // C8P_GATHER_STATS=1: what the waits of `settle` were, printed when the front goes (tools/probes/chain_quick.py)
-  struct stats_t { bool on = env_int("C8P_GATHER_STATS", 0) != 0; long calls = 0, waits = 0, slow = 0; double us = 0, worst = 0, age_slow = 0, age_fast = 0; uint64_t items = 0; } stats;
+  struct stats_t { bool on = env_int("C8P_GATHER_STATS", 0) != 0; long calls = 0, waits = 0, slow = 0; double us = 0, worst = 0, age_slow = 0, age_fast = 0, flush_bytes = 0; long flushes = 0; uint64_t items = 0; } stats;
   ~gather_lane()
   {
     if (stats.on && stats.calls)
       fprintf(stderr, "gather_lane: %ld settles, %ld with a wait (%ld over 5 us), %.0f us waited (worst %.0f), %.0f items a gather, depth %d; enqueue -> noticed done: "
-              "%.0f us after a wait over 5 us, %.0f us after a shorter one\n", stats.calls, stats.waits, stats.slow, stats.us, stats.worst,
-              (double)stats.items / std::max(1L, stats.calls), DEPTH, stats.age_slow / std::max(1L, stats.slow), stats.age_fast / std::max(1L, stats.waits - stats.slow));
+              "%.0f us after a wait over 5 us, %.0f us after a shorter one; %ld gathers of %.0f KB\n", stats.calls, stats.waits, stats.slow, stats.us, stats.worst,
+              (double)stats.items / std::max(1L, stats.calls), DEPTH, stats.age_slow / std::max(1L, stats.slow), stats.age_fast / std::max(1L, stats.waits - stats.slow),
+              stats.flushes, stats.flush_bytes / 1024.0 / std::max(1L, stats.flushes));
   }
   std::deque<pend_t> pend;
   // How far this call looks.  A scheduler offers a block everything its input buffer holds; a front that cut all of it at once would then
@@ -443,12 +472,18 @@ struct gather_lane {
   void add(const void* src, uint64_t dst_off, uint64_t n, uint32_t fmt)
   {
     if (!n) return;
+    const size_t isz = fmt == C8P_FMT_F32 ? 4 : 8;
+    pending_bytes += isz * (size_t)n;
     // (a packet cut by a call boundary continues where the last piece ended, in the buffer and in the arena: one piece)
     if (!pieces.empty()) {
       c8p_piece& b = pieces.back();
-      const size_t isz = fmt == C8P_FMT_F32 ? 4 : 8;
-      if (b.fmt == fmt && (const char*)b.src + b.n * isz == (const char*)src && b.dst_off + b.n == dst_off) { b.n += n; return; }
+      if (b.fmt == fmt && (const char*)b.src + b.n * isz == (const char*)src && b.dst_off + b.n == dst_off) {
+        b.n += n;
+        src_hi = std::max(src_hi, (uintptr_t)src + isz * (size_t)n);
+        return;
+      }
     }
+    src_lo = std::min(src_lo, (uintptr_t)src); src_hi = std::max(src_hi, (uintptr_t)src + isz * (size_t)n);
     c8p_piece pc;
     memset(&pc, 0, sizeof(pc));
     pc.src = src; pc.dst_off = dst_off; pc.n = n; pc.trusted = 1; pc.fmt = fmt; pc.scale = 1.0f;
@@ -460,6 +495,8 @@ struct gather_lane {
     if (pieces.empty()) return;
     E.check(E.d_api.copy_gather(E.d_ctx, static_cast<c8p_c32*>(dst), pieces.data(), (int32_t)pieces.size()), "c8p_copy_gather");
     pieces.clear();
+    if (stats.on) { stats.flushes++; stats.flush_bytes += (double)pending_bytes; }
+    pending_bytes = 0;
     dirty = true;
   }
   // at the end of a call that looked at the items [rd, rd + used): how many of them may be consumed now
@@ -472,7 +509,8 @@ struct gather_lane {
     if (dirty) {
       const uint64_t m = A.copy_mark(E.d_ctx);
       if (!m) throw std::runtime_error("c8p_copy_mark failed");
-      pend.push_back(pend_t{m, scan_abs, now_tick()});
+      pend.push_back(pend_t{m, scan_abs, now_tick(), src_lo, src_hi});
+      src_lo = UINTPTR_MAX; src_hi = 0;
       dirty = false;
     } else if (!pend.empty()) pend.back().scan = scan_abs;                           // (items without a gather of their own: skipped ones)
     sub_scope w(ph, phase_clock::GWAIT);
@@ -500,6 +538,14 @@ struct gather_lane {
     if (pend.empty()) return used;
     return (int)std::min<uint64_t>(done_scan - rd, (uint64_t)used);
   }
+  // buffer_will_move: the newest gather that reads [base, base + bytes) has finished when this returns (a mark covers what came before it)
+  void wait_range(engine_holder& E, const void* base, size_t bytes)
+  {
+    const uintptr_t lo = (uintptr_t)base, hi = lo + bytes;
+    for (auto it = pend.rbegin(); it != pend.rend(); ++it)
+      if (it->lo < hi && lo < it->hi) { E.check(E.d_api.copy_wait_mark(E.d_ctx, it->mark), "c8p_copy_wait_mark"); return; }
+  }
+  uintptr_t src_lo = UINTPTR_MAX, src_hi = 0;    // the pieces enqueued since the last mark
   bool dirty = false;                    // a gather has been enqueued since the last mark
 };
 
@@ -520,6 +566,7 @@ public:
   }
   ~demod_front() override
   {
+    d_reg.leave();
     d_timer.stop();
     if (d_scat_stats.launches && env_int("C8P_GATHER_STATS", 0))
       fprintf(stderr, "llr scatter: %ld launches of %.0f items; waits: throttle %ld (%.0f us), space taken %ld (%.0f us), no progress %ld (%.0f us)\n",
@@ -544,6 +591,14 @@ public:
     for (auto& r : req) r = (d_outq.empty() && !d_ready && !d_inflight) ? noutput_items : 0;
   }
   int output_ahead() override { std::lock_guard<std::mutex> g(d_mu); return (int)(d_ready + d_inflight); }
+  void quiesce(const void* base, size_t bytes) override
+  {
+    std::lock_guard<std::mutex> g(d_mu);
+    d_lane.wait_range(d_eng, base, bytes);
+    const uintptr_t lo = (uintptr_t)base, hi = lo + bytes;
+    for (auto it = d_scat.rbegin(); it != d_scat.rend(); ++it)
+      if (it->lo < hi && lo < it->hi) { d_eng.check(d_eng.d_api.copy_wait_mark(d_eng.d_ctx, it->mark), "c8p_copy_wait_mark"); break; }
+  }
 
   std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
   void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
@@ -626,6 +681,7 @@ public:
         else memcpy(static_cast<void*>(st.iq.data() + d_cur.iq_off[p] + d_have), src, sizeof(gr_complex) * (size_t)take);
       }
       d_have += take; used += take;
+      if (d_in_dev && d_lane.want_flush(d_eng)) { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, st.d_iq.p); }
       if (d_have == (int)d_cur.n_items) {
         if (st.pk.empty()) st.t_first = now_tick();
         st.pk.push_back(d_cur);
@@ -633,17 +689,21 @@ public:
         if ((int)st.pk.size() >= d_eng.d_cfg.max_batch) submit(false);
       }
     }
+    // the call's last pieces start moving; what else the call has to do — replay the batches that have arrived, hand out items — is done
+    // while they do, and only then are the gathers asked about (settle)
+    if (d_in_dev) { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_iq.p); }
     if (d_eng.d_cfg.flush_when_idle) age_check();
+    const int drained = d_out_dev ? 0 : drain(static_cast<float*>(output_items[0]), noutput_items);
     int cons = used;
     if (d_in_dev) {
-      { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_iq.p); }
+      { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_iq.p); }     // (age_check may have moved to a new stage: nothing left then)
       cons = d_lane.settle(d_eng, rd, used, d_ph);
     }
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     if (!d_st[d_fill].pk.empty() || !d_fly.empty()) d_timer.poke();
     if (d_out_dev) return scatter_report(noutput_items, cons > 0);
-    return drain(static_cast<float*>(output_items[0]), noutput_items);
+    return drained;
   }
 
   void flush() override      // complete packets go now; a packet still being received stays behind
@@ -749,7 +809,7 @@ private:
     if (st.iq_items * sizeof(gr_complex) > st.d_iq.cap) {
       // (pieces carry offsets; the base they are added to is about to change: what was cut so far goes to the old arena first)
       d_lane.flush(d_eng, st.d_iq.p);
-      const size_t first = (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 4096u * (size_t)d_nports * sizeof(gr_complex);
+      const size_t first = env_int("C8P_ARENA_MIN", 0) ? 0 : (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 4096u * (size_t)d_nports * sizeof(gr_complex);
       d_eng.dev_reserve(st.d_iq, std::max(first, (size_t)st.iq_items * sizeof(gr_complex)), (size_t)off * sizeof(gr_complex));
     }
     return off;
@@ -1003,10 +1063,11 @@ private:
   // [0, d_ready) of the space it is given is complete, [d_ready, d_ready + d_inflight) is being written by up to SCAT_DEPTH launches
   // (d_scat).  A scheduler's output pointer continues where produce() stopped, so the items placed by this call are where a later
   // call's space begins (c8p_blocks.h, output_ahead).  Nothing is waited for while the call makes progress some other way: an 8 MB
-  // scatter takes 180 us, and the version that waited for the previous call's scatter at the start of every call spent 1.1-1.3 us per
-  // packet doing so (profiles/r5q).
+  // scatter takes 180 us, and the version that waited for the previous call's scatter at the start of every call spent 0.9 us per
+  // packet doing so (profiles/r5q/gather_waits.txt; the chain did not get faster for it — the link carries both directions out of
+  // one budget, DESIGN.md §7 — but the items are reported a call earlier).
   enum { SCAT_DEPTH = 3 };
-  struct scat_t { uint64_t mark; size_t n; std::vector<std::shared_ptr<result>> hold; };   // (its arenas are being read until the mark)
+  struct scat_t { uint64_t mark; size_t n; std::vector<std::shared_ptr<result>> hold; uintptr_t lo = 0, hi = 0; };   // (its arenas are being read until the mark; [lo, hi): where it writes)
   struct scat_stats_t { long n[3] = {0, 0, 0}; double us[3] = {0, 0, 0}; long launches = 0; double items = 0; } d_scat_stats;   // C8P_GATHER_STATS
   void scatter_collect(bool block_oldest, int why = 0)
   {
@@ -1062,6 +1123,7 @@ private:
     sc.mark = A.copy_mark(d_eng.d_ctx);
     if (!sc.mark) throw std::runtime_error("c8p_copy_mark failed");
     sc.n = pos - pos0;
+    sc.lo = (uintptr_t)(out + pos0); sc.hi = (uintptr_t)(out + pos);
     d_scat_stats.launches++; d_scat_stats.items += (double)sc.n;
     d_inflight += sc.n;
     d_scat.push_back(std::move(sc));
@@ -1113,7 +1175,8 @@ private:
   std::deque<out_pkt> d_outq;
   std::vector<long> d_fused_ids;                   // batches this front parked in g_fused (the last 256-512 of them)
   std::vector<long> d_llr_ids;                     // ... and in g_llr
-  latency_timer d_timer;                           // last member: its thread uses everything above
+  latency_timer d_timer;                           // its thread uses everything above
+  front_registration d_reg{this};                  // buffer_will_move finds the front from here to the top of its destructor
 };
 
 demod::sptr demod::make(int mupos, int mugid) { return make(mupos, mugid, default_api(), batching_cfg()); }
@@ -1389,9 +1452,12 @@ public:
   }
   ~decode_front() override
   {
+    d_reg.leave();
     d_timer.stop();
     for (stage& st : d_st) { d_eng.dev_release(st.d_llr); d_eng.dev_release(st.d_mu); }
   }
+
+  void quiesce(const void* base, size_t bytes) override { std::lock_guard<std::mutex> g(d_mu); d_lane.wait_range(d_eng, base, bytes); }
 
   // the io_signature's buffer type (c8p_blocks.h): the LLR stream arrives in pinned host memory
   bool wants_pinned_input(unsigned) const override { return d_eng.d_cfg.pinned_io; }
@@ -1502,8 +1568,10 @@ public:
       const int take = (int)std::min<int64_t>(nproc - used, (int64_t)d_cur.total - d_have);
       if (take > 0 && d_cur_fused < 0 && !d_cur_ext) {
         stage& st = d_st[d_fill];
-        if (d_in_dev) d_lane.add(in + used, d_cur.llr_off + (uint64_t)d_have, (uint64_t)take, C8P_FMT_F32);
-        else memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
+        if (d_in_dev) {
+          d_lane.add(in + used, d_cur.llr_off + (uint64_t)d_have, (uint64_t)take, C8P_FMT_F32);
+          if (d_lane.want_flush(d_eng)) { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, st.d_llr.p); }
+        } else memcpy(st.llr.data() + d_cur.llr_off + d_have, in + used, sizeof(float) * (size_t)take);
       }
       d_have += std::max(take, 0); used += std::max(take, 0);
       if (d_have >= d_cur.total) {
@@ -1525,6 +1593,7 @@ public:
       }
     }
     used = std::min(used, nproc);
+    if (d_in_dev) { sub_scope pg(d_ph, phase_clock::GATHER); d_lane.flush(d_eng, d_st[d_fill].d_llr.p); }      // (under way while the batches that arrived are published)
     if (d_eng.d_cfg.flush_when_idle) age_check();
     int cons = used;
     if (d_in_dev) {
@@ -1590,7 +1659,7 @@ private:
     st.llr_items += n;
     if (st.llr_items * sizeof(float) > st.d_llr.cap) {
       d_lane.flush(d_eng, st.d_llr.p);             // (what was cut so far goes to the old arena; the move below follows it)
-      const size_t first = (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 16384u * sizeof(float);
+      const size_t first = env_int("C8P_ARENA_MIN", 0) ? 0 : (size_t)std::max(d_eng.d_cfg.max_batch, 1) * 16384u * sizeof(float);
       d_eng.dev_reserve(st.d_llr, std::max(first, st.llr_items * sizeof(float)), (size_t)off * sizeof(float));
     }
     return off;
@@ -1806,7 +1875,8 @@ private:
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   uint64_t d_nPktCorrect = 0, d_legacyMcsCount[8], d_vhtMcsCount[10], d_htMcsCount[8];
   size_t d_hwm_pdu = 0;
-  latency_timer d_timer;                           // last member: its thread uses everything above
+  latency_timer d_timer;                           // its thread uses everything above
+  front_registration d_reg{this};
 };
 
 decode::sptr decode::make(bool ifdebug) { return make(ifdebug, default_api(), batching_cfg()); }

@@ -193,16 +193,27 @@ public:
   virtual void* buffer_alloc(size_t bytes) { return nullptr; }
   virtual void buffer_free(void* p) {}
   // Items of output port 0 this block has placed in the output buffer BEYOND what it has reported as produced (demod with a pinned
-  // output buffer: the device is still writing them; they are reported by the next call).  They sit at the start of the space the next
-  // call is given — a scheduler's ring continues where the last call's produce() stopped — so whoever moves the block's output
-  // pointer somewhere else (a buffer that is not a ring and has come to its end) first calls general_work with noutput_items = this
-  // number: the block then reports them and places nothing new.
+  // output buffer: the device is still writing them; they are reported by the call at whose end they have arrived).  They sit at the
+  // start of the space the next call is given — a scheduler's ring continues where the last call's produce() stopped — so whoever moves
+  // the block's output pointer somewhere else (a buffer that is not a ring and has come to its end) first calls general_work with
+  // noutput_items = this number and no input: the block then waits for them, reports them and places nothing new.
   virtual int output_ahead() { return 0; }
+  // buffer_will_move (below): wait for every copy this block has under way that reads or writes [base, base + bytes)
+  virtual void quiesce(const void* base, size_t bytes) {}
   void set_io(block_io* io) { d_io = io; }
 
 protected:
   block_io* d_io = nullptr;
 };
+
+// A scheduler buffer that is about to MOVE items it has handed out says so first, from whatever thread: every front of this process waits
+// for the copies it has under way that read or write [base, base + bytes) — items it has cut and not consumed yet (batching_cfg::
+// defer_consume), LLR items it has placed and not reported (output_ahead).  GNU Radio's single-mapped custom buffers relocate unread
+// items to the start of the buffer when a reader or the writer is blocked at its end (gr::buffer_single_mapped::input_blocked_callback /
+// output_blocked_callback): gnuradio/lib/c8p_pinned_buffer.h calls this from both before it lets the base class move anything, which is
+// what makes deferred consume safe on such a buffer.  The items themselves need no attention: what has been cut lives in the batch's
+// device arena, and a front counts in absolute items, not addresses.
+void buffer_will_move(const void* base, size_t bytes);
 
 class demod : virtual public c8p_block
 {

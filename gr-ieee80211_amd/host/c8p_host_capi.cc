@@ -43,6 +43,22 @@ struct harness : public block_io {
   std::vector<ibuf> in;
   bool pinned_out = false;
   bool poison = false;                          // consumed input items are overwritten at once (a test: nothing may still be reading them)
+  // != 0: every `relocate`-th call of c8ph_run finds the unread items of its pinned input buffers MOVED to other memory, as a single-mapped
+  // GNU Radio buffer moves them when a reader is blocked at its end: buffer_will_move first, then the copy, then the old memory is overwritten
+  int relocate = 0;
+  std::vector<std::pair<void*, bool>> graveyard; // ... the old buffers (kept to the end: a front that ignores the announcement reads 0xff, not freed memory)
+  void relocate_inputs()
+  {
+    for (ibuf& b : in) {
+      if (!b.pinned || !b.p || b.size == b.pos) continue;
+      buffer_will_move(b.p, b.cap);
+      uint8_t* np = static_cast<uint8_t*>(balloc(b.cap, true));
+      memcpy(np + b.pos, b.p + b.pos, b.size - b.pos);
+      memset(b.p, 0xff, b.cap);
+      graveyard.emplace_back(b.p, true);
+      b.p = np;
+    }
+  }
   void* balloc(size_t bytes, bool pinned) { void* q = pinned ? blk->buffer_alloc(bytes) : malloc(bytes); if (!q) throw std::runtime_error("harness: no memory for a buffer"); return q; }
   void bfree(void* q, bool pinned) { if (!q) return; if (pinned) blk->buffer_free(q); else free(q); }
   void setup_buffers()
@@ -65,6 +81,8 @@ struct harness : public block_io {
   void release_buffers()
   {
     for (ibuf& b : in) { bfree(b.p, b.pinned); b.p = nullptr; }
+    for (auto& g : graveyard) bfree(g.first, g.second);
+    graveyard.clear();
     for (float* q : edge) bfree(q, edge_pinned);
     edge.clear();
   }
@@ -238,6 +256,8 @@ void c8ph_set_jitter(void* p, unsigned long long seed) { static_cast<harness*>(p
 // from now on every consumed input item (and every recycled buffer of c8ph_run_chain's edge) is overwritten with 0xff bytes at once: a
 // block that lets go of items something is still reading — a gather it has not waited for — produces wrong results instead of passing by luck
 void c8ph_set_poison(void* p, int on) { static_cast<harness*>(p)->poison = on != 0; }
+// every n-th call of c8ph_run finds its pinned input buffers relocated (harness::relocate); 0: never
+void c8ph_set_relocate(void* p, int every) { static_cast<harness*>(p)->relocate = every > 0 ? every : 0; }
 int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->input_is_pinned((unsigned)port) ? 1 : 0; }
 int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
 
@@ -298,6 +318,7 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
         const size_t aq = h->avail(q);
         nin[q] = (int)std::min<size_t>(aq, (size_t)n + h->rnd() % 97);
       }
+      if (h->relocate && calls % h->relocate == h->relocate - 1) h->relocate_inputs();
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
       wrap_if_needed(std::max(nout, 1));

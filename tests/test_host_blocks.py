@@ -390,6 +390,46 @@ def test_block_mirror_with_and_without_pinned_buffers(n_ant, pinned_io, defer, c
     assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
 
 
+@pytest.mark.parametrize("n_ant", [1, 2])
+@pytest.mark.parametrize("every", [1, 2, 5])
+def test_deferred_consume_survives_a_buffer_that_relocates_its_items(n_ant, every):
+    """A single-mapped GNU Radio buffer MOVES unread items to its start when a reader is blocked at its end.  With deferred consume a front
+    has gathers under way on exactly such items; the buffer announces the move (c8p::buffer_will_move, gnuradio/lib/c8p_pinned_buffer.h)
+    and the front waits for them first.  Here the harness moves the unread items of the pinned input buffers to other memory before every
+    1st / 2nd / 5th call and overwrites the old memory; the test engine runs a gather only when something waits for it."""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=FAKE, max_batch=5, pinned_io=True, defer_consume=True)
+    dem.set_poison(True); dem.set_relocate(every)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=700, nout=3000)
+    llr, tags = dem.output(), dem.tags()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=5, pinned_io=True, defer_consume=True)
+    dec.set_poison(True); dec.set_relocate(every)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run(chunk=2500, nout=3000)
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
+
+
+@pytest.mark.parametrize("defer", [False, True])
+@pytest.mark.parametrize("max_batch", [3, 64])
+def test_arenas_that_grow_while_gathers_fill_them(defer, max_batch, monkeypatch):
+    """A batch's device arena grows while the call's gathers into it are under way (C8P_ARENA_MIN makes it start at 4 KB): what has been cut
+    so far must have ARRIVED before the old arena's contents move to the new one — the gathers are C8P_PIECE_UNORDERED, they run on either
+    of two copy streams and the move is ordered behind one of them only (the test engine leaves them pending past a c8p_copy_async)."""
+    monkeypatch.setenv("C8P_ARENA_MIN", "4096")
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    ref = chain(FAKE, pk, iq, chan, 1, 4096, 8192, 256)
+    for chunk, nout in ((1500, 3000), (20000, 60000)):
+        msgs, dbg = _chain_threads(FAKE, pk, iq, chan, 1, max_batch, False, pinned_io=True, defer_consume=defer, poison=True, chunk=chunk, nout=nout)
+        assert msgs == ref[2] and dbg == ref[3]
+
+
 @pytest.mark.parametrize("handle", ["1", "0"])
 def test_plain_chain_with_and_without_the_llr_handle(handle, monkeypatch):
     """batching_cfg::llr_handle (plain mode on pinned buffers): demod names the device copy of a batch's LLR arena in a "c8p_llr" tag and
