@@ -351,6 +351,7 @@ def main():
             r64 = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
             rpg = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
             rfl = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
+            rnd = bb.run(4096, batches=(512,), quiet=True, batch=(pk, iq, chan, expected), defer_consume=False)  # ... every call waits for its own gathers
             try:
                 out["block_rx_chain"] = bb.rx_chain_rate(local=local)
                 out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
@@ -366,6 +367,10 @@ def main():
                                    "chain_threads_on_cpus": r.get("chain_threads_on_cpus")},
                 "custom_buffers_threads_floating": {"items_per_call": rfl["items_per_call"], "chain": rfl["chain_packets_per_s"], "chain_fused": rfl["chain_fused_packets_per_s"],
                                                     "note": "the two scheduler threads wherever the OS puts them (no core affinity set on the blocks)"},
+                "custom_buffers_consume_at_once": {"items_per_call": rnd["items_per_call"], "chain": rnd["chain_packets_per_s"], "chain_fused": rnd["chain_fused_packets_per_s"],
+                                                   "note": "batching_cfg::defer_consume off (C8P_DEFER_CONSUME=0): a call consumes what it looked at and waits for its gathers "
+                                                           "before it returns; the default — items let go of two calls late — needs a buffer that announces when it moves "
+                                                           "items (c8p::buffer_will_move; gnuradio/lib/c8p_pinned_buffer.h does)"},
                 "sched64k_pinned": {"items_per_call": r64["items_per_call"], "chain": r64["chain_packets_per_s"], "chain_fused": r64["chain_fused_packets_per_s"]},
                 "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
                                       "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},

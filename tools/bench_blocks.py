@@ -76,10 +76,10 @@ def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bit
 IO_SIZES = {"custom": (1 << 20, 1 << 21), "custom8": (1 << 19, 1 << 21), "custom32": (1 << 21, 1 << 22), "sched64k": (1 << 16, 1 << 18)}
 
 
-def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto"):
+def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto", defer_consume=None):
     """every figure is the median of PASSES passes over the same block instances after a first untimed one (which grows the
     pinned staging and the device arenas, creates streams, pages the library in).  batch = (descriptors, iq, chan, expected PDUs) on
-    the host; None: host_batch(n).  io: a key of IO_SIZES; pinned_io: batching_cfg::pinned_io (None: its default)"""
+    the host; None: host_batch(n).  io: a key of IO_SIZES; pinned_io / defer_consume: batching_cfg's fields of those names (None: their defaults)"""
     pk, iq, chan, exp = batch if batch is not None else host_batch(n)
     pk, exp = pk[:n], exp[:n]
     chunk_in, nout_llr = IO_SIZES[io]
@@ -93,7 +93,7 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinne
         os.environ.pop("C8P_CHAIN_PIN", None)
     best = {}
     for max_batch in batches:
-        dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False, pinned_io=pinned_io)
+        dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=False, pinned_io=pinned_io, defer_consume=defer_consume)
         n_in = blocks.feed_demod(dem, pk, iq, chan)
         dem.run(chunk=chunk_in, nout=nout_llr)
         llr, tags = dem.output(), dem.tags()                 # the LLR stream + tags feed the decode-alone measurement
@@ -104,7 +104,7 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinne
             t0 = time.perf_counter(); dem.run(chunk=chunk_in, nout=nout_llr); ts.append(time.perf_counter() - t0)
         t_dem = float(np.median(ts))
         dem.close()
-        dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=False, pinned_io=pinned_io)
+        dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=False, pinned_io=pinned_io, defer_consume=defer_consume)
         ts = []
         for rep in range(1 + PASSES):
             dec.push_items(0, llr)
@@ -118,8 +118,8 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinne
         res = {"packets": n, "max_batch": max_batch, "io": io, "items_per_call": {"demod_in": chunk_in, "llr": nout_llr}, "demod_block_packets_per_s": round(n / t_dem),
                "decode_block_packets_per_s": round(n / t_dec), "pdus_ok_decode_alone": ok_dec}
         for fused in (False, True):
-            dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=fused, pinned_io=pinned_io)
-            dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=fused, pinned_io=pinned_io)
+            dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, fused=fused, pinned_io=pinned_io, defer_consume=defer_consume)
+            dec = blocks.Block(blocks.DECODE, max_batch=max_batch, fused=fused, pinned_io=pinned_io, defer_consume=defer_consume)
             ts = []
             for rep in range(1 + PASSES):
                 blocks.feed_demod(dem, pk, iq, chan, base=rep * n_in)
