@@ -586,6 +586,39 @@ def test_chain_on_two_threads_on_gpu(fused):
     assert dbg == ref[3]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_asynchronous_paths_of_the_fronts_on_the_engine(fused, monkeypatch):
+    """What the fake-engine tests above model, on the device itself: arenas that start at 4 KB and grow while gathers fill them, consumed
+    items overwritten at once (deferred consume), scatters written ahead, batches of 3 / 7 / 64 in flight, small and large windows — PDUs
+    and debug lines equal the oracle-checked two-pass run; then each mirror alone with its input buffers RELOCATED before every second
+    call (announced through c8p::buffer_will_move): the LLR stream, the tags and the PDUs are the same again."""
+    monkeypatch.setenv("C8P_ARENA_MIN", "4096")
+    b, _ = sweep_batch(snr_db=28.0, seed=6)
+    pk, iq, chan = split(b, 1)
+    ref = chain(None, pk, iq, chan, 1, 1000, 4096, 16)
+    assert check_against_oracle(ref, pk, iq, chan) >= 10
+    for chunk, nout, max_batch in ((1500, 3000, 3), (20000, 60000, 64), (4096, 8192, 7)):
+        msgs, dbg = _chain_threads(None, pk, iq, chan, 1, max_batch, fused, pinned_io=True, defer_consume=True, poison=True, chunk=chunk, nout=nout)
+        assert msgs == ref[2] and dbg == ref[3], (chunk, nout, max_batch)
+    if fused:
+        return
+    dem = blocks.Block(blocks.DEMOD, max_batch=5, pinned_io=True, defer_consume=True)
+    dem.set_poison(True); dem.set_relocate(2)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=700, nout=3000)
+    llr, tags = dem.output(), dem.tags()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, max_batch=5, pinned_io=True, defer_consume=True)
+    dec.set_poison(True); dec.set_relocate(2)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run(chunk=2500, nout=3000)
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert check_against_oracle(res, pk, iq, chan) >= 10
+
+
 # ---------------------------------------------------------------------------------------------- a live scheduler (no dry calls, no flush)
 def test_a_burst_comes_out_without_further_input_and_without_flush():
     """The GNU Radio scheduler never calls a block that has no input, and demod's input is bursty (signal emits items only during
