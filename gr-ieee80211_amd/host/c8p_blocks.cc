@@ -493,7 +493,11 @@ struct gather_lane {
   void flush(engine_holder& E, void* dst)
   {
     if (pieces.empty()) return;
-    E.check(E.d_api.copy_gather(E.d_ctx, static_cast<c8p_c32*>(dst), pieces.data(), (int32_t)pieces.size()), "c8p_copy_gather");
+    // (at most C8P_GATHER_INLINE pieces a launch: a longer list goes through the engine's one table in pinned memory, and the call then
+    // first waits for everything the copy stream holds — two antennas are two pieces per packet, 150 of them in a third of a window)
+    for (size_t i = 0; i < pieces.size(); i += C8P_GATHER_INLINE)
+      E.check(E.d_api.copy_gather(E.d_ctx, static_cast<c8p_c32*>(dst), pieces.data() + i, (int32_t)std::min<size_t>(C8P_GATHER_INLINE, pieces.size() - i)),
+              "c8p_copy_gather");
     pieces.clear();
     if (stats.on) { stats.flushes++; stats.flush_bytes += (double)pending_bytes; }
     pending_bytes = 0;
@@ -631,6 +635,7 @@ public:
       used = (int)std::min<uint64_t>(d_lane.scan_abs - rd, (uint64_t)nproc);
     }
     nproc = d_lane.cap_window(d_eng, used, nproc);
+    const int used_before = used;                  // (items beyond this are new to the front: cutting them is progress, consumed or not)
     d_tc.load(d_io, rd + (uint64_t)used, rd + (uint64_t)nproc);
     while (used < nproc) {
       if (d_state == S_RDTAG) {
@@ -702,7 +707,7 @@ public:
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     if (!d_st[d_fill].pk.empty() || !d_fly.empty()) d_timer.poke();
-    if (d_out_dev) return scatter_report(noutput_items, cons > 0);
+    if (d_out_dev) return scatter_report(noutput_items, cons > 0 || used > used_before);
     return drained;
   }
 
@@ -1119,7 +1124,9 @@ private:
       if (d_scat.empty()) d_ready += pos - pos0; else { d_scat.back().n += pos - pos0; d_inflight += pos - pos0; }
       return;
     }
-    d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data(), (int32_t)d_opieces.size()), "c8p_copy_gather (llr out)");
+    for (size_t i = 0; i < d_opieces.size(); i += C8P_GATHER_INLINE)       // (short lists: each launch stays on the device -> host stream and enqueues only)
+      d_eng.check(A.copy_gather(d_eng.d_ctx, reinterpret_cast<c8p_c32*>(out), d_opieces.data() + i,
+                                (int32_t)std::min<size_t>(C8P_GATHER_INLINE, d_opieces.size() - i)), "c8p_copy_gather (llr out)");
     sc.mark = A.copy_mark(d_eng.d_ctx);
     if (!sc.mark) throw std::runtime_error("c8p_copy_mark failed");
     sc.n = pos - pos0;
@@ -1128,10 +1135,10 @@ private:
     d_inflight += sc.n;
     d_scat.push_back(std::move(sc));
   }
-  // the end of the call: what has arrived is reported.  A call that has consumed input waits for nothing.  One that has not and would
-  // report nothing waits for its oldest scatter (a scheduler does not call again a block that made no progress until a neighbour
-  // does); if its space is taken up by what is under way — a scheduler at the end of its buffer asks for exactly those items, without
-  // input — it waits for all of them
+  // the end of the call: what has arrived is reported.  A call that has cut or consumed input waits for nothing.  One that has not and
+  // would report nothing waits for its oldest scatter (a call without any progress is repeated at once: it would spin) — also when its
+  // space is taken up by what is under way (a scheduler at the end of its buffer keeps offering what is left of it until the block
+  // has reported everything it placed there)
   int scatter_report(int noutput_items, bool progressed)
   {
     sub_scope ph(d_ph, phase_clock::DRAIN);
@@ -1139,8 +1146,7 @@ private:
     if (!d_scat.empty()) {
       const bool taken = d_ready + d_inflight >= (size_t)noutput_items;
       if (!progressed) {
-        if (taken) while (!d_scat.empty() && d_ready < (size_t)noutput_items) scatter_collect(true, 1);
-        else if (d_ready == 0) scatter_collect(true, 2);
+        if (d_ready == 0) scatter_collect(true, taken ? 1 : 2);
       } else if (taken && d_ready == 0 && d_outq.size() > 2 * (size_t)d_eng.d_cfg.max_batch)
         scatter_collect(true, 0);                    // (input is being cut faster than the link takes the items away: no further ahead than this)
     }

@@ -196,7 +196,8 @@ public:
   // output buffer: the device is still writing them; they are reported by the call at whose end they have arrived).  They sit at the
   // start of the space the next call is given — a scheduler's ring continues where the last call's produce() stopped — so whoever moves
   // the block's output pointer somewhere else (a buffer that is not a ring and has come to its end) first calls general_work with
-  // noutput_items = this number and no input: the block then waits for them, reports them and places nothing new.
+  // noutput_items = this number, as often as it takes to bring it to zero: the block reports what has arrived (it waits for its oldest
+  // launch when nothing has) and places nothing new.
   virtual int output_ahead() { return 0; }
   // buffer_will_move (below): wait for every copy this block has under way that reads or writes [base, base + bytes)
   virtual void quiesce(const void* base, size_t bytes) {}

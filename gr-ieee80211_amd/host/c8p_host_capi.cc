@@ -287,8 +287,7 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     };
     auto wrap_if_needed = [&](int want_items) {
       if (ocap - wpos >= (size_t)want_items * fpi) return;
-      const int ahead = h->blk->output_ahead();
-      if (ahead > 0) {                                              // a call without input and with room for exactly the items under way
+      for (int ahead; (ahead = h->blk->output_ahead()) > 0;) {      // calls without input and with room for exactly the items under way
         gr_vector_int nin0(h->nports, 0);
         gr_vector_const_void_star ins0(h->nports);
         for (int q = 0; q < h->nports; q++) ins0[q] = h->rd(q);
@@ -358,7 +357,8 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   // has produced while A goes on producing.  A ring is stood in for by three long segments that are used in turn (A moves on when the
   // space left in one is less than a call's worth, B when it has consumed a closed one to its end): no item ever moves.  The memory
   // comes from the blocks' buffer type when either names one for this edge (pinned host memory), as flat_flowgraph::allocate_buffer
-  // picks an edge's gr::buffer_type.
+  // picks an edge's gr::buffer_type.  The segments are address space only: the edge HOLDS what a buffer of two calls' worth holds
+  // (edge_cap: 16 MB when a call is offered 8 MB) — A is offered no more than the room B has left by consuming, and waits when there is none.
   const size_t fpi = std::max<size_t>(A->out_size / sizeof(float), 1);
   const bool pin_edge = A->pinned_out || B->in[0].pinned;
   harness* owner = A->pinned_out ? A : B;
@@ -366,6 +366,8 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   A->in_cap_bytes = 2 * (size_t)std::max(chunk, 1) * A->item_size;
   B->in_cap_bytes = 2 * std::max((size_t)std::max(chunk, 1), (size_t)std::max(nout, 1) * fpi) * sizeof(float);
   const size_t seg_floats = std::max<size_t>((size_t)std::max(nout, 1) * fpi * 16, (size_t)1 << 23);
+  const size_t edge_cap = 2 * (size_t)std::max(nout, 1) * fpi;   // floats
+  size_t a_reported = 0, b_consumed = 0;                         // floats A has reported as produced / B has consumed (b_consumed: under mu)
   struct segment { float* items = nullptr; size_t n = 0; bool closed = false; };      // n, closed: under mu
   segment segs[3];
   {
@@ -409,13 +411,13 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
         gr_vector_const_void_star ins(A->nports);
         for (int qq = 0; qq < A->nports; qq++) ins[qq] = A->rd(qq);
         if (cur >= 0 && seg_floats - wpos < (size_t)std::max(nout, 1) * fpi) {     // not a call's worth of space left: the next segment
-          const int ahead = A->blk->output_ahead();                                // (items the block has placed beyond what it reported)
-          if (ahead > 0) {
+          for (int ahead; (ahead = A->blk->output_ahead()) > 0;) {                 // (items the block has placed beyond what it reported)
             gr_vector_int nin0(A->nports, 0);
             gr_vector_void_star outs0(1, segs[cur].items + wpos);
             A->consumed_this_call = 0;
             const size_t tb = A->out_tags.size();
             const int produced = A->blk->general_work(ahead, nin0, ins, outs0);
+            a_reported += (size_t)produced * fpi;
             calls_a++;
             for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
             A->n_read += A->consumed_this_call;
@@ -441,12 +443,28 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
           filled.push_back(cur);
           wpos = 0;
         }
+        // the room the edge has: what A has reported and B has not consumed is in it (items A has placed ahead lie at the start of the
+        // space it is offered and are part of that offer)
+        int nout_call = nout;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          for (;;) {
+            const size_t held = a_reported - b_consumed;
+            nout_call = (int)std::min<size_t>((size_t)std::max(nout, 1), held < edge_cap ? (edge_cap - held) / fpi : 0);
+            if (nout_call > 0 || failed) break;
+            const clk::time_point tw = clk::now();
+            cv.wait(lk);
+            a_wait += secs(tw, clk::now());
+          }
+          if (failed) break;
+        }
         gr_vector_void_star outs(1, segs[cur].items + wpos);
         A->consumed_this_call = 0;
         const size_t tags_before = A->out_tags.size();
         const clk::time_point tg = clk::now();
-        const int produced = A->blk->general_work(nout, nin, ins, outs);
+        const int produced = A->blk->general_work(nout_call, nin, ins, outs);
         a_work += secs(tg, clk::now());
+        a_reported += (size_t)produced * fpi;
         calls_a++;
         for (int qq = 0; qq < A->nports; qq++) A->advance(qq, (size_t)A->consumed_this_call);
         A->n_read += A->consumed_this_call;
@@ -520,6 +538,7 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
       if (B->poison && B->consumed_this_call) memset(segs[cur].items + rpos, 0xff, (size_t)B->consumed_this_call * sizeof(float));
       rpos += (size_t)B->consumed_this_call;
       B->n_read += B->consumed_this_call;
+      if (B->consumed_this_call) { { std::lock_guard<std::mutex> g(mu); b_consumed += (size_t)B->consumed_this_call; } cv.notify_all(); }
       fruitless = B->consumed_this_call == 0 ? fruitless + 1 : 0;
     }
     // the producer is done and everything it made was offered: a few dry calls, then end of stream

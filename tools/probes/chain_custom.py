@@ -14,13 +14,13 @@ mb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 io = sys.argv[2] if len(sys.argv) > 2 else "custom"
 mode = sys.argv[3] if len(sys.argv) > 3 else "both"
 passes = int(os.environ.get("PASSES", "8"))
-n = 4096
+n = int(os.environ.get("N_PKT", "4096"))
 pk, iq, chan, exp = bb.host_batch(n)
 chunk_in, nout_llr = bb.IO_SIZES[io]
 pin = hostbind.cpu_pair_sharing_l3()
 if pin:
     os.environ["C8P_CHAIN_PIN"] = "%d,%d" % tuple(pin)
-out = {"depth": os.environ.get("C8P_GATHER_DEPTH"), "max_batch": mb, "io": io, "pin": pin}
+out = {"n": n, "depth": os.environ.get("C8P_GATHER_DEPTH"), "max_batch": mb, "io": io, "pin": pin}
 for fused in ((False, True) if mode == "both" else (mode == "fused",)):
     dem = blocks.Block(blocks.DEMOD, max_batch=mb, fused=fused)
     dec = blocks.Block(blocks.DECODE, max_batch=mb, fused=fused)
