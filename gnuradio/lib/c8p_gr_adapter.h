@@ -127,8 +127,19 @@ private:
       case c8p::tag_value::FLOAT: p = pmt::from_float(val.f); break;
       default: p = pmt::init_c32vector(val.v.size(), val.v); break;
     }
-    gr::block::add_item_tag(port, offset, pmt::string_to_symbol(key), p, this->alias_pmt());   // demod_impl.cc:224-253
+    gr::block::add_item_tag(port, offset, key_symbol(key), p, this->alias_pmt());   // demod_impl.cc:224-253
   }
+
+  // the interned symbol of a tag key: the fronts write 14 tags per packet with ~16 distinct keys, and pmt::string_to_symbol is a lookup
+  // in the process-wide symbol table under its mutex — the block keeps the symbols it has used (scheduler thread only)
+  pmt::pmt_t key_symbol(const std::string& key)
+  {
+    for (const auto& kv : d_key_syms)
+      if (kv.first == key) return kv.second;
+    d_key_syms.emplace_back(key, pmt::string_to_symbol(key));
+    return d_key_syms.back().second;
+  }
+  std::vector<std::pair<std::string, pmt::pmt_t>> d_key_syms;
 
   void consume_each(int n) override { gr::block::consume_each(n); }
 
