@@ -410,7 +410,7 @@ public:
   {
     if (bytes <= b.cap) return;
     // (C8P_ARENA_MIN: the tests make the arenas start tiny, so that they grow while gathers into them are under way)
-    static const size_t arena_min = (size_t)std::max(env_int("C8P_ARENA_MIN", 1 << 20), 64);
+    const size_t arena_min = (size_t)std::max(env_int("C8P_ARENA_MIN", 1 << 20), 64);      // (read per call: arenas grow a handful of times in a front's life)
     const size_t nc = std::max<size_t>(std::max(bytes, 2 * b.cap), arena_min);
     void* q = d_api.dev_alloc(d_ctx, nc);
     if (!q) throw std::runtime_error(std::string("c8p_dev_alloc failed: ") + d_api.last_error(d_ctx));
