@@ -1103,12 +1103,16 @@ private:
     while (d_scat.size() >= (size_t)SCAT_DEPTH) scatter_collect(true, 0);
     size_t pos = d_ready + d_inflight;
     const size_t pos0 = pos;
+    // one launch takes a THIRD of the space at most: the space then holds up to SCAT_DEPTH launches, the next is placed while the ones
+    // before it are still being written, and the link always has one queued (a launch that fills the whole space is the only one under
+    // way, and the link idles from its end until the call that notices)
+    const size_t stop = std::min((size_t)noutput_items, pos0 + std::max<size_t>((size_t)noutput_items / SCAT_DEPTH, 1u << 16));
     d_opieces.clear();
     scat_t sc;
-    while (!d_outq.empty() && pos < (size_t)noutput_items) {
+    while (!d_outq.empty() && pos < stop) {
       out_pkt& o = d_outq.front();
       if (o.sent == 0) emit_tags(o, d_io->nitems_written(0) + (uint64_t)pos);
-      const size_t k = std::min(o.n - o.sent, (size_t)noutput_items - pos);
+      const size_t k = std::min(o.n - o.sent, stop - pos);
       if (k && o.llr) {
         c8p_piece pc;
         memset(&pc, 0, sizeof(pc));
