@@ -1727,10 +1727,13 @@ extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
     if (!ev) continue;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t q;
+    bool spun = false;
     while ((q = hipEventQuery(ev)) == hipErrorNotReady) {
+      spun = true;
       if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) { q = hipEventSynchronize(ev); break; }
       __builtin_ia32_pause();
     }
+    if (spun) (void)hipGetLastError();            // ("not ready" must not be what the thread's next hipGetLastError finds)
     if (q != hipSuccess) { (void)hipGetLastError(); return C8P_EHIP; }
   }
   return C8P_OK;
