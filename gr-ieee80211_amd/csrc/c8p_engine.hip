@@ -638,8 +638,25 @@ static int honour_fence(c8p_ctx* c)
   return C8P_OK;
 }
 
+// C8P_SUBMIT_TLOG=1: where the host time of submit_demod goes (microseconds, summed over the submits of the process; printed at exit)
+struct SubmitLog {
+  bool on = getenv("C8P_SUBMIT_TLOG") != nullptr;
+  double us[7] = {0, 0, 0, 0, 0, 0, 0};
+  long n = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() { if (on) t = std::chrono::steady_clock::now(); }
+  void lap(int k) { if (!on) return; const auto u = std::chrono::steady_clock::now(); us[k] += std::chrono::duration<double, std::micro>(u - t).count(); t = u; }
+  ~SubmitLog()
+  {
+    if (on && n) fprintf(stderr, "[c8p submit] %ld submits; us per submit: slot's stream synchronised %.1f, events drained %.1f, fence %.1f, plan + arenas %.1f, staging %.1f, upload + classify (+ demod) launches %.1f, "
+                                 "decode launches %.1f\n", n, us[5] / n, us[6] / n, us[0] / n, us[1] / n, us[2] / n, us[3] / n, us[4] / n);
+  }
+};
+static SubmitLog g_submit_log;
+
 static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
 {
+  g_submit_log.start();
   if (!c) return C8P_EINVAL;
   if (!in || in->n_pkt < 0 || (in->n_pkt > 0 && (!in->pkts || !in->iq || !in->chan))) { c->err = "bad batch"; return C8P_EINVAL; }
   if (in->mem != C8P_MEM_HOST && in->mem != C8P_MEM_DEVICE) { c->err = "bad mem kind"; return C8P_EINVAL; }
@@ -648,8 +665,11 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   c->cur = (c->cur + 1) % (int)c->slots.size(); c->seq++; c->slots[c->cur].ticket = c->seq;
   c->s = &c->slots[c->cur];
   HIPCHK(c, hipStreamSynchronize(c->s->stream));
+  g_submit_log.lap(5);
   drain_events(c);
+  g_submit_log.lap(6);
   { const int rf = honour_fence(c); if (rf != C8P_OK) return rf; }
+  g_submit_log.lap(0);
   const int n = in->n_pkt;
   c->s->n_pkt = n;
   for (int i = 0; i < C8P_BUF_COUNT; i++) { c->s->used[i] = 0; c->s->ptr[i] = nullptr; }
@@ -664,6 +684,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   if ((rc = ensure_demod_arenas(c, n, P, in->mem == C8P_MEM_HOST ? in->n_iq : 0, in->mem == C8P_MEM_HOST ? in->n_chan : 0)) != C8P_OK) return rc;
   const c8p_pkt_in* d_pk = (const c8p_pkt_in*)((char*)c->s->d_stage.p + o_pk);
   const PktLayout* d_lay = (const PktLayout*)((char*)c->s->d_stage.p + o_lay);
+  g_submit_log.lap(1);
 
   const cf* d_iq = (const cf*)in->iq;
   const cf* d_chan = (const cf*)in->chan;
@@ -695,6 +716,7 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
       d_order = (const uint32_t*)((char*)c->s->d_stage.p + o_ord);
     }
   }
+  g_submit_log.lap(2);
   {
     KTimer kt(c, C8P_K_LAYOUT);
     HIPCHK(c, upload(c->s->stream, c->s->d_stage.p, c->s->h_stage, d_order ? stage_bytes : o_ord));
@@ -722,8 +744,10 @@ static int submit_demod(c8p_ctx* c, const c8p_batch_in* in, bool with_decode)
   c->s->used[C8P_BUF_LLR] = (fused && !c->keep_llr) ? 0 : sizeof(float) * P.llr; c->s->ptr[C8P_BUF_LLR] = c->s->d_llr.p;
   // (keep_llr = 2, the tap: the kernels do not write the padding between two packets' LLR areas, and the tests read only the areas)
   c->s->used[C8P_BUF_MUCHAN] = sizeof(cf) * 128 * (size_t)n; c->s->ptr[C8P_BUF_MUCHAN] = c->s->d_muchan.p;
-  if (!with_decode) return C8P_OK;
+  g_submit_log.lap(3);
+  if (!with_decode) { g_submit_log.n++; return C8P_OK; }
   const RxFuse rx = {d_pk, d_iq, d_chan, any_2ant, d_order};
+  struct Fin { ~Fin() { g_submit_log.lap(4); g_submit_log.n++; } } fin;
   return run_decode_kernels(c, n, (const c8p_pkt_tags*)c->s->d_tags.p, d_lay, (const float*)c->s->d_llr.p, (const cf*)c->s->d_muchan.p, P, &rx,
                             (const FinCold*)((char*)c->s->d_stage.p + o_cold));
 }
