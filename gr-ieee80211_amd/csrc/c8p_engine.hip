@@ -1694,10 +1694,13 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
     }
     if (!masked) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     c->copy_cus = masked ? ncu : 0;
-    HIPCHK(c, hipStreamCreateWithFlags(&c->span_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_before_spans, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_spans, hipEventDisableTiming));
+    // (both side streams from the start.  Created at their first use instead — a process's streams share four hardware queues, and the
+    // idea was to leave them to the submit streams — the device -> host stream lands on a queue a submit stream uses: block chain plain
+    // 275-301 k against 327-335 k packets/s on one box, fused no different; profiles/r5q/submit_breakdown.txt)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->span_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
   }
   return C8P_OK;
 }
@@ -2057,8 +2060,8 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
     c->b_next = !c->b_next;
     if (on_b) c->b_dirty = c->b_fence_dirty = true;
   }
-  const hipStream_t gst = to_host ? c->out_stream : on_b ? c->copy_stream_b : c->copy_stream;
   if (to_host) { std::lock_guard<std::mutex> g(c->copy_mu); c->out_dirty = true; }
+  const hipStream_t gst = to_host ? c->out_stream : on_b ? c->copy_stream_b : c->copy_stream;
   PieceTab itab;
   PieceDev* hp = itab.p;
   if (!inl) {
