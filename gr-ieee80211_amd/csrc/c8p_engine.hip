@@ -1700,7 +1700,17 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
     // idea was to leave them to the submit streams — the device -> host stream lands on a queue a submit stream uses: block chain plain
     // 275-301 k against 327-335 k packets/s on one box, fused no different; profiles/r5q/submit_breakdown.txt)
     HIPCHK(c, hipStreamCreateWithFlags(&c->span_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+    // The device -> host stream on a hardware queue of its own: a process's ordinary streams share four of them (GPU_MAX_HW_QUEUES) and this
+    // one would sit behind a submit stream's 0.3 ms kernels; a stream with a CU mask gets its own queue, and the mask names every CU.  Block
+    // chain plain 345-353 k against 331-336 k packets/s, alternated on one box (C8P_OUT_OWN_QUEUE=0: the shared queue;
+    // profiles/r5q/submit_breakdown.txt).  The same for the submit streams: no difference, chain or headline (measured, not kept).
+    const char* oq = getenv("C8P_OUT_OWN_QUEUE");
+    if (!(oq && oq[0] == '0') && dev_cus > 0 && dev_cus <= 256) {
+      uint32_t all[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < dev_cus; i++) all[i >> 5] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&c->out_stream, 8, all) != hipSuccess) { (void)hipGetLastError(); c->out_stream = nullptr; }
+    }
+    if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
   }
   return C8P_OK;
 }
