@@ -489,23 +489,19 @@ def test_llr_handles_survive_the_demod_that_made_them():
     dec.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-@pytest.mark.parametrize("defer", [False, True])
-def test_pinned_buffers_under_random_scheduler_chunks(seed, defer):
-    """pinned buffers + a scheduler that hands out random item counts (sometimes fewer than the block has already looked at, sometimes
-    none): consumed items are overwritten at once"""
+def pinned_buffers_under_random_scheduler_chunks(engine_lib, seed, defer, relocate=0):
     rng = np.random.default_rng(40 + seed)
     n_ant = 1 + seed % 2
     b, _ = sweep_batch(snr_db=28.0, seed=5)
     pk, iq, chan = split(b, n_ant)
-    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
-    dem.set_poison(True)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=engine_lib, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
+    dem.set_poison(True); dem.set_relocate(relocate)
     blocks.feed_demod(dem, pk, iq, chan)
     dem.set_jitter(5000 + seed)
     dem.run(chunk=int(rng.integers(100, 3000)), nout=int(rng.integers(50, 5000)))
     llr, tags = dem.output(), dem.tags()
-    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
-    dec.set_poison(True)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=engine_lib, max_batch=int(rng.integers(1, 9)), pinned_io=True, defer_consume=defer)
+    dec.set_poison(True); dec.set_relocate(relocate)
     dec.push_items(0, llr)
     for off, key, val in tags:
         dec.push_tag(off, key, val)
@@ -514,6 +510,26 @@ def test_pinned_buffers_under_random_scheduler_chunks(seed, defer):
     res = (llr, tags, dec.messages(), dec.debug_lines())
     dem.close(); dec.close()
     assert check_against_oracle(res, pk, iq, chan) >= 10
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("defer", [False, True])
+def test_pinned_buffers_under_random_scheduler_chunks(seed, defer):
+    """pinned buffers + a scheduler that hands out random item counts (sometimes fewer than the block has already looked at, sometimes
+    none): consumed items are overwritten at once; with deferred consume also with the unread items moved before every third call"""
+    pinned_buffers_under_random_scheduler_chunks(FAKE, seed, defer)
+    if defer:
+        pinned_buffers_under_random_scheduler_chunks(FAKE, seed, defer, relocate=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_pinned_buffers_under_random_scheduler_chunks_on_the_engine(seed, monkeypatch):
+    """the same on the device: random item counts per call, consumed items overwritten at once, unread items moved before every third call,
+    arenas that start at 4 KB; one and two antennas"""
+    monkeypatch.setenv("C8P_ARENA_MIN", "4096")
+    pinned_buffers_under_random_scheduler_chunks(None, seed, True, relocate=3)
+    pinned_buffers_under_random_scheduler_chunks(None, seed, False)
 
 
 @pytest.mark.parametrize("fused", [False, True])
