@@ -108,7 +108,17 @@ __global__ __launch_bounds__(64) void k_llr_check(const c8p_pkt_tags* __restrict
   float mneg = 0.0f;
   if (decodable(t)) {
     const float* L = llr + t.llr_off;
-    for (int i = lane_id(); i < t.total; i += 64) { const float v = L[i]; bad |= bad_llr(v); mneg = fmaxf(mneg, -v); }
+    // (eight loads in flight per lane: one wave reads its packet's 57 KB alone, and with one load per trip round the loop the kernel took
+    // 170-190 us whatever the batch — 224 memory latencies in a row; OR and max do not care about the order)
+    int i = lane_id();
+    for (; i + 64 * 7 < t.total; i += 64 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = L[i + 64 * k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { bad |= bad_llr(v[k]); mneg = fmaxf(mneg, -v[k]); }
+    }
+    for (; i < t.total; i += 64) { const float v = L[i]; bad |= bad_llr(v); mneg = fmaxf(mneg, -v); }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mneg = fmaxf(mneg, __shfl_xor(mneg, o, 64));
