@@ -8,6 +8,7 @@ the fronts' timers — to the CPUs of the GPU's node and makes that node the pre
 no arithmetic."""
 import ctypes
 import os
+import time
 import re
 
 
@@ -125,24 +126,75 @@ def _compact(cpus):
     return ",".join(out)
 
 
-def cpu_pair_sharing_l3(sysfs="/sys"):
+def _cpu_jiffies(procfs):
+    """per logical CPU: (busy, total) jiffies since boot, from <procfs>/stat; {} when it cannot be read"""
+    out = {}
+    try:
+        with open(os.path.join(procfs, "stat")) as f:
+            for line in f:
+                m = re.match(r"cpu(\d+)\s+(.*)", line)
+                if not m:
+                    continue
+                v = [int(x) for x in m.group(2).split()]
+                idle = v[3] + (v[4] if len(v) > 4 else 0)
+                out[int(m.group(1))] = (sum(v) - idle, sum(v))
+    except (OSError, ValueError):
+        return {}
+    return out
+
+
+def cpu_pair_sharing_l3(sysfs="/sys", procfs="/proc", sample_s=0.05, allowed=None):
     """Two logical CPUs of this process's cpuset on DIFFERENT cores that share a last-level cache: where two scheduler threads that hand
     items and tags to each other (demod -> decode) belong — GNU Radio: block::set_processor_affinity / the blocks' "Core Affinity" in
     GRC.  On a two-socket, multi-CCD host threads left to the OS end up on different CCDs or sockets and every hand-over is a
     cross-fabric cache-line transfer (measured: the block chain at 250-350 k packets/s floating, 440-450 k on two cores of one CCD).
-    None when the topology cannot be read."""
-    try:
-        allowed = sorted(os.sched_getaffinity(0))
-    except AttributeError:
-        return None
+    The hosts of this pool are shared (load averages of 30-50 on 256 CPUs): of all such pairs the one whose cores were the least busy
+    during `sample_s` seconds is taken (per core: the busier of its hardware threads, <procfs>/stat); sample_s = 0 or an unreadable
+    stat file: the first pair.  None when the topology cannot be read."""
+    if allowed is None:
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            return None
+    allowed = sorted(allowed)
+    aset = set(allowed)
+    groups, seen = [], set()                     # per last-level cache: its cores, each as the tuple of its allowed hardware threads
     for c0 in allowed:
+        if c0 in seen:
+            continue
         base = os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c0)
-        l3 = parse_cpulist(_read(os.path.join(base, "cache", "index3", "shared_cpu_list")))
-        sib = set(parse_cpulist(_read(os.path.join(base, "topology", "thread_siblings_list"))) or [c0])
-        for c1 in l3:
-            if c1 in allowed and c1 not in sib:
-                return (c0, c1)
-    return None
+        l3 = [c for c in parse_cpulist(_read(os.path.join(base, "cache", "index3", "shared_cpu_list"))) if c in aset]
+        if not l3:
+            continue
+        cores, in_core = [], set()
+        for c in l3:
+            if c in in_core:
+                continue
+            every = parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c, "topology", "thread_siblings_list"))) or [c]
+            sib = tuple(x for x in every if x in aset) or (c,)
+            in_core.update(sib)
+            cores.append((sib, tuple(every)))              # (ours to run on, all of the core's: a neighbour's thread loads the core too)
+        seen.update(l3)
+        if len(cores) >= 2:
+            groups.append(cores)
+    if not groups:
+        return None
+    busy = {}
+    if sample_s > 0:
+        a = _cpu_jiffies(procfs)
+        if a:
+            time.sleep(sample_s)
+            b = _cpu_jiffies(procfs)
+            for c, (b1, t1) in b.items():
+                if c in a and t1 > a[c][1]:
+                    busy[c] = (b1 - a[c][0]) / (t1 - a[c][1])
+    best, best_load = None, None
+    for cores in groups:
+        ranked = sorted(cores, key=lambda c: (max(busy.get(x, 0.0) for x in c[1]), c[0][0]))
+        load = sum(max(busy.get(x, 0.0) for x in c[1]) for c in ranked[:2])
+        if best is None or load < best_load - 1e-9:
+            best, best_load = tuple(sorted((ranked[0][0][0], ranked[1][0][0]))), load
+    return best
 
 
 def hip_runtimes_mapped():

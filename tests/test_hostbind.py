@@ -69,3 +69,44 @@ def test_no_gpu_no_binding(monkeypatch):
 
 def test_at_most_one_hip_runtime_here():
     assert len(hostbind.assert_single_hip_runtime()) <= 1
+
+
+def fake_topology(tmp_path, l3_groups, smt):
+    """cpuN/cache/index3/shared_cpu_list and cpuN/topology/thread_siblings_list for groups of cores; smt: {cpu: sibling}"""
+    for grp in l3_groups:
+        txt = ",".join(str(c) for c in grp)
+        for c in grp:
+            d = tmp_path / "devices" / "system" / "cpu" / ("cpu%d" % c)
+            (d / "cache" / "index3").mkdir(parents=True)
+            (d / "cache" / "index3" / "shared_cpu_list").write_text(txt + "\n")
+            (d / "topology").mkdir(parents=True)
+            sib = sorted({c, smt.get(c, c)})
+            (d / "topology" / "thread_siblings_list").write_text(",".join(str(x) for x in sib) + "\n")
+    return str(tmp_path)
+
+
+def test_cpu_pair_shares_a_cache_and_avoids_busy_cores(tmp_path, monkeypatch):
+    """two cores of one last-level cache, never two threads of one core; of all such pairs the least busy one (a shared host)"""
+    sysfs = fake_topology(tmp_path / "sys", [[0, 1, 2, 3, 8, 9, 10, 11], [4, 5, 6, 7, 12, 13, 14, 15]], {c: c + 8 for c in range(8)} | {c + 8: c for c in range(8)})
+    allowed = list(range(16))
+    assert hostbind.cpu_pair_sharing_l3(sysfs, sample_s=0, allowed=allowed) == (0, 1)
+    assert hostbind.cpu_pair_sharing_l3(sysfs, sample_s=0, allowed=[0, 8, 4, 5]) == (4, 5)          # 0 and 8 are one core
+    assert hostbind.cpu_pair_sharing_l3(sysfs, sample_s=0, allowed=[0, 8]) is None
+    # busy fractions between two readings of <procfs>/stat: core 0 (its sibling 8 is busy), cores 1 and 2 busy; 3 idle; the second cache idle
+    snaps = [{c: (0, 1000) for c in range(16)}, {c: (0, 2000) for c in range(16)}]
+    for c, b in ((8, 900), (1, 800), (2, 700)):
+        snaps[1][c] = (b, 2000)
+    it = iter(snaps)
+    monkeypatch.setattr(hostbind, "_cpu_jiffies", lambda procfs: next(it))
+    monkeypatch.setattr(hostbind.time, "sleep", lambda s: None)
+    assert hostbind.cpu_pair_sharing_l3(sysfs, sample_s=0.01, allowed=allowed) == (4, 5)
+    snaps[1][4] = snaps[1][5] = snaps[1][6] = snaps[1][7] = (1000, 2000)                            # the second cache all busy: the best of the first
+    it = iter(snaps)
+    assert hostbind.cpu_pair_sharing_l3(sysfs, sample_s=0.01, allowed=allowed) == (2, 3)           # (cores 3 and 2: 0 + 0.7; the second cache: 1.0 + 1.0)
+
+
+def test_cpu_jiffies_reads_proc_stat(tmp_path):
+    (tmp_path / "stat").write_text("cpu  10 0 10 100 0 0 0 0 0 0\ncpu0 5 0 5 80 10 0 0 0 0 0\ncpu1 50 0 20 20 0 0 10 0 0 0\nintr 1 2 3\n")
+    j = hostbind._cpu_jiffies(str(tmp_path))
+    assert j == {0: (10, 100), 1: (80, 100)}
+    assert hostbind._cpu_jiffies(str(tmp_path / "nothing")) == {}
