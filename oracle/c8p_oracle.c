@@ -171,9 +171,83 @@ int c8po_table(int which, int sub, int32_t* dst, int cap)
 }
 
 /* ------------------------------------------------------------------ FFT (demod_impl.cc:541-547 → gr::fft::fft_complex_fwd(64)) */
+/* The pinned model (0) is the exact DFT rounded once to float.  The reference's transform is FFTW3f, whose float rounding depends on
+ * the plan it picks and which cannot be built here; models 1-3 are float32 transforms of three different operation orders, there ONLY so
+ * that tests/test_oracle_golden.py can measure how far the LLR stream moves when the FFT rounds in float (NOTES/parity.md): radix-2
+ * decimation in time, radix-4 decimation in frequency, and the plain 64-term sum in float (the worst of the three by construction). */
+static int FFT_MODEL = 0;
+void c8po_set_fft_model(int m) { FFT_MODEL = m; }
+int c8po_get_fft_model(void) { return FFT_MODEL; }
+static void fft64_f32_radix2_dit(const cf* in, cf* out)
+{
+  float xr[64], xi[64];
+  for (int n = 0; n < 64; n++) {
+    int r = 0;
+    for (int b = 0; b < 6; b++) r |= ((n >> b) & 1) << (5 - b);
+    xr[r] = in[n].re; xi[r] = in[n].im;
+  }
+  for (int len = 2; len <= 64; len <<= 1) {
+    const int half = len >> 1, step = 64 / len;
+    for (int i = 0; i < 64; i += len)
+      for (int k = 0; k < half; k++) {
+        const float c = (float)TW_C[k * step], s = (float)-TW_S[k * step];
+        const float ur = xr[i + k], ui = xi[i + k];
+        const float vr = xr[i + k + half] * c - xi[i + k + half] * s, vi = xr[i + k + half] * s + xi[i + k + half] * c;
+        xr[i + k] = ur + vr; xi[i + k] = ui + vi;
+        xr[i + k + half] = ur - vr; xi[i + k + half] = ui - vi;
+      }
+  }
+  for (int k = 0; k < 64; k++) { out[k].re = xr[k]; out[k].im = xi[k]; }
+}
+static void fft64_f32_radix4_dif(const cf* in, cf* out)
+{
+  float xr[64], xi[64];
+  for (int n = 0; n < 64; n++) { xr[n] = in[n].re; xi[n] = in[n].im; }
+  for (int len = 64; len >= 4; len >>= 2) {           /* three stages: 64, 16, 4 */
+    const int q = len >> 2, step = 64 / len;
+    for (int i = 0; i < 64; i += len)
+      for (int k = 0; k < q; k++) {
+        const float ar = xr[i + k], ai = xi[i + k], br = xr[i + k + q], bi = xi[i + k + q];
+        const float cr = xr[i + k + 2 * q], ci = xi[i + k + 2 * q], dr = xr[i + k + 3 * q], di = xi[i + k + 3 * q];
+        const float s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+        const float s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
+        const float y0r = s0r + s2r, y0i = s0i + s2i;               /* bin 0 of the 4-point DFT */
+        const float y2r = s0r - s2r, y2i = s0i - s2i;               /* bin 2 */
+        const float y1r = s1r + s3i, y1i = s1i - s3r;               /* bin 1: s1 - j s3 */
+        const float y3r = s1r - s3i, y3i = s1i + s3r;               /* bin 3: s1 + j s3 */
+        const float c1 = (float)TW_C[k * step], n1 = (float)-TW_S[k * step];
+        const float c2 = (float)TW_C[(2 * k * step) & 63], n2 = (float)-TW_S[(2 * k * step) & 63];
+        const float c3 = (float)TW_C[(3 * k * step) & 63], n3 = (float)-TW_S[(3 * k * step) & 63];
+        xr[i + k] = y0r; xi[i + k] = y0i;
+        xr[i + k + q] = y1r * c1 - y1i * n1; xi[i + k + q] = y1r * n1 + y1i * c1;
+        xr[i + k + 2 * q] = y2r * c2 - y2i * n2; xi[i + k + 2 * q] = y2r * n2 + y2i * c2;
+        xr[i + k + 3 * q] = y3r * c3 - y3i * n3; xi[i + k + 3 * q] = y3r * n3 + y3i * c3;
+      }
+  }
+  for (int n = 0; n < 64; n++) {                       /* base-4 digit reversal */
+    const int r = ((n & 3) << 4) | (n & 12) | ((n >> 4) & 3);
+    out[r].re = xr[n]; out[r].im = xi[n];
+  }
+}
+static void fft64_f32_direct(const cf* in, cf* out)
+{
+  for (int k = 0; k < 64; k++) {
+    float sr = 0.0f, si = 0.0f;
+    for (int n = 0; n < 64; n++) {
+      const int t = (k * n) & 63;
+      const float c = (float)TW_C[t], s = (float)-TW_S[t];
+      sr += in[n].re * c - in[n].im * s;
+      si += in[n].re * s + in[n].im * c;
+    }
+    out[k].re = sr; out[k].im = si;
+  }
+}
 void c8po_fft64(const cf* in, cf* out)
 {
   c8po_init();
+  if (FFT_MODEL == 1) { fft64_f32_radix2_dit(in, out); return; }
+  if (FFT_MODEL == 2) { fft64_f32_radix4_dif(in, out); return; }
+  if (FFT_MODEL == 3) { fft64_f32_direct(in, out); return; }
   for (int k = 0; k < 64; k++) {
     double sr = 0.0, si = 0.0;
     for (int n = 0; n < 64; n++) {
