@@ -295,8 +295,11 @@ def main():
         if rv:
             out["roofline_valu"] = rv
         if not args.no_frontend and world == 1:
-            out["frontend_detect"] = frontend_detect(torch, dev, local)
-            fe_unit = out["frontend_detect"].pop("_unit", None)
+            try:                                     # (a leg must not cost the headline)
+                out["frontend_detect"] = frontend_detect(torch, dev, local)
+                fe_unit = out["frontend_detect"].pop("_unit", None)
+            except Exception as e:
+                out["frontend_detect"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_configs and world == 1:
             out["configs"] = config_legs(torch, dev, local, args.snr)
         if not args.no_sensitivity and world == 1 and not other:
@@ -339,67 +342,74 @@ def main():
     if rank == 0:
         out["host_binding"] = bindings
         if not args.no_host_legs and world == 1:
-            # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
-            out["pcie_inclusive_detail"] = {}
-            out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, detail=out["pcie_inclusive_detail"])
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("bench_blocks", os.path.join(ROOT, "tools", "bench_blocks.py"))
-            bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
-            if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
-                iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
-            r = bb.run(4096, batches=(256, 512, 1024), quiet=True, batch=(pk, iq, chan, expected))           # the blocks' own (pinned) buffers
-            r64 = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
-            rpg = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
-            rfl = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
-            rnd = bb.run(4096, batches=(512,), quiet=True, batch=(pk, iq, chan, expected), defer_consume=False)  # ... every call waits for its own gathers
-            try:
-                out["block_rx_chain"] = bb.rx_chain_rate(local=local)
-                out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
-                out["block_rx_chain"]["note"] = ("gr::ieee80211::rx_chain (host/c8p_rx_chain.cc): rx.grc's whole receive chain for 8 radios as ONE "
-                                                 "block of the mirror, fed raw item streams in scheduler-sized chunks; every port's items are "
-                                                 "copied once into pinned memory, one round per 524 288 items per stream")
+            try:                                 # (a host leg must not cost the headline: the line is printed whatever happens here)
+                # what a host-fed caller sees — never `value`: inputs start in pinned host memory and the results come back
+                out["pcie_inclusive_detail"] = {}
+                out["pcie_inclusive_packets_per_s"] = pcie_inclusive(pk, iq_dev, chan_dev, torch, dev, local, detail=out["pcie_inclusive_detail"])
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("bench_blocks", os.path.join(ROOT, "tools", "bench_blocks.py"))
+                bb = importlib.util.module_from_spec(spec); spec.loader.exec_module(bb)
+                if iq is None:      # the block mirrors are fed host item streams: bring the boundary arenas back once
+                    iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
+                r = bb.run(4096, batches=(256, 512, 1024), quiet=True, batch=(pk, iq, chan, expected))           # the blocks' own (pinned) buffers
+                r64 = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k")      # rounds 1-4's call sizes
+                rpg = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), io="sched64k", pinned_io=False)   # ... and pageable buffers
+                rfl = bb.run(4096, batches=(256,), quiet=True, batch=(pk, iq, chan, expected), pin=None)           # custom buffers, threads left to the OS
+                rnd = bb.run(4096, batches=(512,), quiet=True, batch=(pk, iq, chan, expected), defer_consume=False)  # ... every call waits for its own gathers
+                try:
+                    out["block_rx_chain"] = bb.rx_chain_rate(local=local)
+                    out["block_rx_chain"]["sc16_ports"] = bb.rx_chain_rate(local=local, bits=16)
+                    out["block_rx_chain"]["note"] = ("gr::ieee80211::rx_chain (host/c8p_rx_chain.cc): rx.grc's whole receive chain for 8 radios as ONE "
+                                                     "block of the mirror, fed raw item streams in scheduler-sized chunks; every port's items are "
+                                                     "copied once into pinned memory, one round per 524 288 items per stream")
+                except Exception as e:
+                    out["block_rx_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
+                out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
+                out["block_chain_variants"] = {
+                    "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"],
+                                       "chain_threads_on_cpus": r.get("chain_threads_on_cpus")},
+                    "custom_buffers_threads_floating": {"items_per_call": rfl["items_per_call"], "chain": rfl["chain_packets_per_s"], "chain_fused": rfl["chain_fused_packets_per_s"],
+                                                        "note": "the two scheduler threads wherever the OS puts them (no core affinity set on the blocks)"},
+                    "custom_buffers_consume_at_once": {"items_per_call": rnd["items_per_call"], "chain": rnd["chain_packets_per_s"], "chain_fused": rnd["chain_fused_packets_per_s"],
+                                                       "note": "batching_cfg::defer_consume off (C8P_DEFER_CONSUME=0): a call consumes what it looked at and waits for its gathers "
+                                                               "before it returns; the default — items let go of two calls late — needs a buffer that announces when it moves "
+                                                               "items (c8p::buffer_will_move; gnuradio/lib/c8p_pinned_buffer.h does)"},
+                    "sched64k_pinned": {"items_per_call": r64["items_per_call"], "chain": r64["chain_packets_per_s"], "chain_fused": r64["chain_fused_packets_per_s"]},
+                    "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
+                                          "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},
+                    "note": "block_chain_* (and legs.block_chain / block_fused) = custom_buffers: the edge buffers are allocated through the mirrors' buffer type "
+                            "(GNU Radio 3.10 custom buffers: pinned host memory, 16 MB an edge, a call sees half), the packets are gathered out of them by the "
+                            "device and demod's LLR items are written into them by the device; the two scheduler threads sit on two cores that share an L3 "
+                            "(hostbind.cpu_pair_sharing_l3: what a flowgraph sets with the blocks' core affinity)"}
+                out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
+                out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
+                out["host_phase_us"] = {"chain": r.get("chain_host_phase_us_per_packet"), "chain_fused": r.get("chain_fused_host_phase_us_per_packet"),
+                                        "note": "host microseconds per packet inside the demod / decode block mirrors, by phase (exclusive): "
+                                                "cut_and_stage = tag reads + the copy of the items into pinned staging, submit = the c8p_* call, "
+                                                "wait = blocked on the batch, fetch = synchronous result copies, replay = tags / PDUs / debug lines, "
+                                                "drain = the LLR items into the output buffer; wall = chain time per packet (two threads)"}
+                out["host_legs_note"] = ("pcie_inclusive: the arenas start in pinned host memory every step (one c8p_copy_gather + c8p_copy_fence, then "
+                                         "c8p_rx on the device copy), c8p_pkt_out + PDU arena fetched back to pinned memory behind the kernels, step i+1 "
+                                         "submitted before step i is waited for; block_chain: the gr::ieee80211::demod -> decode "
+                                         "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
+                                         "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
+                                         "over 4096 packets, max_batch 256 / 512 / 1024 (the best), %d of 4096 PDUs correct in the worst leg" % r["pdus_ok_min"])
             except Exception as e:
-                out["block_rx_chain"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            out["block_chain_packets_per_s"] = r["chain_packets_per_s"]
-            out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
-            out["block_chain_variants"] = {
-                "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"],
-                                   "chain_threads_on_cpus": r.get("chain_threads_on_cpus")},
-                "custom_buffers_threads_floating": {"items_per_call": rfl["items_per_call"], "chain": rfl["chain_packets_per_s"], "chain_fused": rfl["chain_fused_packets_per_s"],
-                                                    "note": "the two scheduler threads wherever the OS puts them (no core affinity set on the blocks)"},
-                "custom_buffers_consume_at_once": {"items_per_call": rnd["items_per_call"], "chain": rnd["chain_packets_per_s"], "chain_fused": rnd["chain_fused_packets_per_s"],
-                                                   "note": "batching_cfg::defer_consume off (C8P_DEFER_CONSUME=0): a call consumes what it looked at and waits for its gathers "
-                                                           "before it returns; the default — items let go of two calls late — needs a buffer that announces when it moves "
-                                                           "items (c8p::buffer_will_move; gnuradio/lib/c8p_pinned_buffer.h does)"},
-                "sched64k_pinned": {"items_per_call": r64["items_per_call"], "chain": r64["chain_packets_per_s"], "chain_fused": r64["chain_fused_packets_per_s"]},
-                "sched64k_pageable": {"items_per_call": rpg["items_per_call"], "chain": rpg["chain_packets_per_s"], "chain_fused": rpg["chain_fused_packets_per_s"],
-                                      "note": "what rounds 1-4 measured: ordinary scheduler buffers, every packet staged through pinned copies on the host"},
-                "note": "block_chain_* (and legs.block_chain / block_fused) = custom_buffers: the edge buffers are allocated through the mirrors' buffer type "
-                        "(GNU Radio 3.10 custom buffers: pinned host memory, 16 MB an edge, a call sees half), the packets are gathered out of them by the "
-                        "device and demod's LLR items are written into them by the device; the two scheduler threads sit on two cores that share an L3 "
-                        "(hostbind.cpu_pair_sharing_l3: what a flowgraph sets with the blocks' core affinity)"}
-            out["block_demod_packets_per_s"] = r["demod_block_packets_per_s"]
-            out["block_decode_packets_per_s"] = r["decode_block_packets_per_s"]
-            out["host_phase_us"] = {"chain": r.get("chain_host_phase_us_per_packet"), "chain_fused": r.get("chain_fused_host_phase_us_per_packet"),
-                                    "note": "host microseconds per packet inside the demod / decode block mirrors, by phase (exclusive): "
-                                            "cut_and_stage = tag reads + the copy of the items into pinned staging, submit = the c8p_* call, "
-                                            "wait = blocked on the batch, fetch = synchronous result copies, replay = tags / PDUs / debug lines, "
-                                            "drain = the LLR items into the output buffer; wall = chain time per packet (two threads)"}
-            out["host_legs_note"] = ("pcie_inclusive: the arenas start in pinned host memory every step (one c8p_copy_gather + c8p_copy_fence, then "
-                                     "c8p_rx on the device copy), c8p_pkt_out + PDU arena fetched back to pinned memory behind the kernels, step i+1 "
-                                     "submitted before step i is waited for; block_chain: the gr::ieee80211::demod -> decode "
-                                     "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
-                                     "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
-                                     "over 4096 packets, max_batch 256 / 512 / 1024 (the best), %d of 4096 PDUs correct in the worst leg" % r["pdus_ok_min"])
+                import traceback
+                out["host_legs_error"] = "%s: %s | %s" % (type(e).__name__, e, traceback.format_exc(limit=3).replace("\n", " / "))
         if not args.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             if iq is None:      # the oracle runs on the host: bring the boundary arenas back once
                 iq, chan = arenas_to_host(torch, dev, iq_dev, chan_dev)
             out["cpu_baseline"] = cpu_baseline(pk, iq, chan)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
-            out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
-            if isinstance(out.get("frontend_detect"), dict) and fe_unit is not None:
-                out["frontend_detect"]["raw_stream_cpu_baseline"] = cpu_baseline_raw_stream(fe_unit)
+            try:                                     # (the extra CPU legs must not cost the line either)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pk, iq, chan, out["cpu_baseline"]["value"])
+                out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline_all_cores"]["value"]
+                if isinstance(out.get("frontend_detect"), dict) and fe_unit is not None:
+                    out["frontend_detect"]["raw_stream_cpu_baseline"] = cpu_baseline_raw_stream(fe_unit)
+            except Exception as e:
+                out["cpu_extra_legs_error"] = "%s: %s" % (type(e).__name__, e)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
