@@ -368,7 +368,8 @@ def main():
                 out["block_chain_fused_packets_per_s"] = r["chain_fused_packets_per_s"]
                 out["block_chain_variants"] = {
                     "custom_buffers": {"items_per_call": r["items_per_call"], "chain": r["chain_packets_per_s"], "chain_fused": r["chain_fused_packets_per_s"],
-                                       "chain_threads_on_cpus": r.get("chain_threads_on_cpus")},
+                                       "chain_threads_on_cpus": r.get("chain_threads_on_cpus"),
+                                   "mode_when_nothing_is_said": r.get("chain_default_mode"), "pdus_ok_in_that_mode": r.get("pdus_ok_chain_default")},
                     "custom_buffers_threads_floating": {"items_per_call": rfl["items_per_call"], "chain": rfl["chain_packets_per_s"], "chain_fused": rfl["chain_fused_packets_per_s"],
                                                         "note": "the two scheduler threads wherever the OS puts them (no core affinity set on the blocks)"},
                     "custom_buffers_consume_at_once": {"items_per_call": rnd["items_per_call"], "chain": rnd["chain_packets_per_s"], "chain_fused": rnd["chain_fused_packets_per_s"],
@@ -393,7 +394,7 @@ def main():
                                          "c8p_rx on the device copy), c8p_pkt_out + PDU arena fetched back to pinned memory behind the kernels, step i+1 "
                                          "submitted before step i is waited for; block_chain: the gr::ieee80211::demod -> decode "
                                          "mirrors (host/c8p_blocks.cc) fed tagged host item streams on two threads, LLR stream through "
-                                         "host memory; block_chain_fused: the same with batching_cfg::fused (C8P_FUSED=1); medians of 5 passes "
+                                         "host memory; block_chain_fused: the same with batching_cfg::fused (the default of a demod whose only reader is decode: fused_auto); medians of 5 passes "
                                          "over 4096 packets, max_batch 256 / 512 / 1024 (the best), %d of 4096 PDUs correct in the worst leg" % r["pdus_ok_min"])
             except Exception as e:
                 import traceback

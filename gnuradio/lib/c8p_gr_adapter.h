@@ -51,13 +51,23 @@
 //   input_signature() / output_signature() -> io_signature::sptr   gr::basic_block (3.10 basic_block.h); NOT used by the reference
 //   io_signature::stream_buffer_type(size_t)                     3.10 io_signature.h (custom buffers: see c8p_pinned_buffer.h, which
 //                                                                continues this list with the gr::buffer members the buffer type uses)
+//   gr::block::detail() -> block_detail_sptr                     NOT used by the reference.  The four members behind
+//   gr::block_detail::noutputs(), output(unsigned) -> buffer_sptr  output_feeds_only_decode(): who reads demod's LLR port?  3.10 block.h,
+//   gr::buffer::nreaders(), reader(size_t) -> buffer_reader*     block_detail.h, buffer.h, buffer_reader.h as we read them.  Building with
+//   gr::buffer_reader::link() -> block_sptr                      -DC8P_GR_NO_TOPOLOGY leaves them out (fused mode is then C8P_FUSED=1 only)
 //
-// Five members have no call site in the reference (stop, _post, the three predicates + symbol_to_string / to_double / PMT_T): those
-// are the first things to look at if the module does not build against a real GNU Radio.
+// Members without a call site in the reference (stop, _post, the three predicates + symbol_to_string / to_double / PMT_T, and the
+// topology walk above): those are the first things to look at if the module does not build against a real GNU Radio.
 #ifndef INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 #define INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 
 #include <gnuradio/block.h>
+#ifndef C8P_GR_NO_TOPOLOGY
+#include <gnuradio/block_detail.h>
+#include <gnuradio/buffer.h>
+#include <gnuradio/buffer_reader.h>
+#endif
+#include <gnuradio/ieee80211/decode.h>
 #include <gnuradio/io_signature.h>
 #include <pmt/pmt.h>
 
@@ -162,6 +172,29 @@ private:
   bool output_is_pinned(unsigned port) override { return this->output_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
   // what c8p_pinned_buffer::make_buffer allocates at least: megabytes, so the fronts gather (c8p_blocks.h: C8P_GATHER_MIN_BUFFER)
   size_t input_buffer_bytes(unsigned port) override { return input_is_pinned(port) ? (size_t)C8P_PINNED_BUFFER_MIN_BYTES : 0; }
+
+  // Who reads this output port (c8p::block_io::output_feeds_only_decode)?  Every reader of the edge's buffer must be this module's decode
+  // block for a demod front to run fused by default (c8p::batching_cfg::fused_auto): nothing else ever looks at the LLR item values
+  // then.  The flat flowgraph has attached detail, buffers and readers before any scheduler thread calls general_work.
+  int output_feeds_only_decode(unsigned port) override
+  {
+#ifdef C8P_GR_NO_TOPOLOGY
+    (void)port;
+    return -1;
+#else
+    try {
+      gr::block_detail_sptr d = this->detail();
+      if (!d || (int)port >= d->noutputs()) return -1;
+      gr::buffer_sptr b = d->output(port);
+      if (!b || b->nreaders() == 0) return -1;
+      for (size_t i = 0; i < b->nreaders(); i++)
+        if (!std::dynamic_pointer_cast<gr::ieee80211::decode>(b->reader(i)->link())) return 0;
+      return 1;
+    } catch (...) {                                    // (a reader whose block is gone: the flowgraph is being torn down)
+      return -1;
+    }
+#endif
+  }
 
   std::shared_ptr<c8p::c8p_block> d_front;
 };

@@ -41,6 +41,7 @@ def lib():
         L.c8ph_set_relocate.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_output_pinned.argtypes = [C.c_void_p]
+        L.c8ph_fused_state.argtypes = [C.c_void_p]
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
@@ -107,7 +108,8 @@ def lib():
 class Block:
     def __init__(self, kind, mupos=0, ifdebug=False, engine_lib=None, max_batch=256, flush_when_idle=True, fused=None, item_format=0, scale=0.0,
                  pinned_io=None, defer_consume=None):
-        """fused: batching_cfg::fused (None = its default, the environment variable C8P_FUSED); item_format / scale: rx_chain only — the
+        """fused: batching_cfg::fused (None = the defaults: the environment's C8P_FUSED, and when that is unset the flowgraph decides —
+        a demod whose LLR port is read by the decode mirror only, as in run_chain, runs fused); item_format / scale: rx_chain only — the
         ports carry complex64 (0), int16 pairs (abi.FMT_SC16) or int8 pairs (abi.FMT_SC8) and the engine converts with `scale`;
         pinned_io / defer_consume: batching_cfg's fields of those names (None = their defaults, C8P_PINNED_IO / C8P_DEFER_CONSUME): the
         harness allocates a port's buffer through the block's buffer type — pinned host memory — when the block names one"""
@@ -161,6 +163,12 @@ class Block:
 
     def output_pinned(self):
         return bool(self.L.c8ph_output_pinned(self.h))
+
+    def fused_state(self):
+        """demod / demod2: True / False = the front runs fused / plain; None = not decided yet (batching_cfg::fused_auto decides at the
+        first general_work call, from who reads the LLR port) or not a demod block"""
+        v = int(self.L.c8ph_fused_state(self.h))
+        return None if v < 0 else bool(v)
 
     def set_jitter(self, seed):
         """random item counts per general_work call from now on (0 = off): what a busy scheduler hands a block"""

@@ -92,6 +92,11 @@ bool batching_cfg::default_fused()
   const char* e = getenv("C8P_FUSED");
   return e && e[0] == '1';
 }
+bool batching_cfg::default_fused_auto()
+{
+  const char* e = getenv("C8P_FUSED");
+  return !e || !*e || !strcmp(e, "auto");
+}
 bool batching_cfg::default_pinned_io()
 {
   const char* e = getenv("C8P_PINNED_IO");
@@ -595,6 +600,7 @@ public:
     for (auto& r : req) r = (d_outq.empty() && !d_ready && !d_inflight) ? noutput_items : 0;
   }
   int output_ahead() override { std::lock_guard<std::mutex> g(d_mu); return (int)(d_ready + d_inflight); }
+  int fused_state() override { std::lock_guard<std::mutex> g(d_mu); return d_mode_known ? (d_eng.d_cfg.fused ? 1 : 0) : -1; }
   void quiesce(const void* base, size_t bytes) override
   {
     std::lock_guard<std::mutex> g(d_mu);
@@ -620,6 +626,8 @@ public:
         const size_t cap = d_io->input_buffer_bytes((unsigned)p);
         d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p) && (cap == 0 || cap >= gather_min_buffer());
       }
+      // the cfg left fused / plain open: fused when nothing but decode mirrors reads the LLR port (c8p_blocks.h, batching_cfg::fused_auto)
+      if (!d_eng.d_cfg.fused && d_eng.d_cfg.fused_auto && d_io->output_feeds_only_decode(0) == 1) d_eng.d_cfg.fused = true;
       d_out_dev = d_eng.d_cfg.pinned_io && !d_eng.d_cfg.fused && d_io->output_is_pinned(0);
       d_mode_known = true;
     }
@@ -1469,6 +1477,7 @@ public:
 
   void quiesce(const void* base, size_t bytes) override { std::lock_guard<std::mutex> g(d_mu); d_lane.wait_range(d_eng, base, bytes); }
 
+  bool is_decode_front() const override { return true; }
   // the io_signature's buffer type (c8p_blocks.h): the LLR stream arrives in pinned host memory
   bool wants_pinned_input(unsigned) const override { return d_eng.d_cfg.pinned_io; }
   void* buffer_alloc(size_t bytes) override { return d_eng.d_api.host_alloc(bytes); }

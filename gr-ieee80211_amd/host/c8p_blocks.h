@@ -96,6 +96,10 @@ public:
   // size: below C8P_GATHER_MIN_BUFFER a call's window is so small that copying it into pinned staging on the CPU (and letting a copy
   // engine upload the batch) is faster, and a front does that even when the buffer is pinned.
   virtual size_t input_buffer_bytes(unsigned port) { return 0; }
+  // Who reads this output port?  1: only decode mirrors of this process (c8p_block::is_decode_front) — what rx.grc / rx2.grc wire behind
+  // demod / demod2; 0: at least one other reader; -1: the scheduler side cannot tell.  A demod front whose cfg leaves the choice open
+  // (batching_cfg::fused_auto) runs fused exactly when this says 1: nothing but the decode mirror ever looks at the item values then.
+  virtual int output_feeds_only_decode(unsigned port) { return -1; }
 };
 #define C8P_GATHER_MIN_BUFFER (2u << 20)
 
@@ -150,12 +154,16 @@ struct batching_cfg {
                                 // never calls a block that has no input, and demod's input is bursty (signal emits items only
                                 // during packets), so without the timer the last packets of a burst would wait for the next one
   int device = 0;
-  // Fused demod -> decode (default: environment C8P_FUSED=1).  When both mirrors sit in one flowgraph the float LLR stream
+  // Fused demod -> decode (forced on by the environment's C8P_FUSED=1; see fused_auto for the default).  When both mirrors sit in one flowgraph the float LLR stream
   // between them only exists to carry packets from one block to the next; in fused mode `demod` runs c8p_rx (demod + decode on
   // the device, the LLRs never leave HBM), emits the reference's tags plus "c8p_fused" (a handle) on the first of `total`
   // items whose VALUES ARE NOT WRITTEN, and `decode` publishes the PDUs behind the handle instead of decoding the items.
   // Tags, item counts, PDU bytes and debug lines are unchanged; anything else that reads the LLR items must not use it.
   bool fused = default_fused();
+  // ... and when `fused` is false: decide at the first general_work call, from the flowgraph — fused if block_io::output_feeds_only_decode
+  // says that every reader of the LLR port is a decode mirror (the reference's own flowgraphs), plain otherwise.  Default: on unless the
+  // environment sets C8P_FUSED (1: always fused, 0: never, "auto": this).  A caller that sets `fused` itself should clear it.
+  bool fused_auto = default_fused_auto();
   // Custom buffers (block_io::input_is_pinned / output_is_pinned): use them when the scheduler provides them (default; environment
   // C8P_PINNED_IO=0 turns it off).  defer_consume: a front then consumes the items of a general_work call during the NEXT call, when
   // the gather that moves them has had a scheduler round trip to finish — nothing waits for the link; 0 (C8P_DEFER_CONSUME=0): the gather is
@@ -169,6 +177,7 @@ struct batching_cfg {
   bool llr_handle = default_llr_handle();
   static bool default_llr_handle();
   static bool default_fused();
+  static bool default_fused_auto();
   static bool default_pinned_io();
   static bool default_defer_consume();
   static int default_max_wait_us();
@@ -199,6 +208,11 @@ public:
   // noutput_items = this number, as often as it takes to bring it to zero: the block reports what has arrived (it waits for its oldest
   // launch when nothing has) and places nothing new.
   virtual int output_ahead() { return 0; }
+  // true for the decode mirror (what a scheduler-side block_io::output_feeds_only_decode looks for in the readers of an edge)
+  virtual bool is_decode_front() const { return false; }
+  // demod / demod2: 1 / 0 = runs fused / plain (decided at the first general_work call when the cfg left it open), -1 = not decided
+  // yet or not a demod front
+  virtual int fused_state() { return -1; }
   // buffer_will_move (below): wait for every copy this block has under way that reads or writes [base, base + bytes)
   virtual void quiesce(const void* base, size_t bytes) {}
   void set_io(block_io* io) { d_io = io; }

@@ -152,6 +152,10 @@ struct harness : public block_io {
   size_t in_cap_bytes = 0;
   size_t input_buffer_bytes(unsigned) override { return in_cap_bytes; }
   bool output_is_pinned(unsigned) override { return pinned_out; }
+  // c8ph_run_chain knows the edge it stands for: 1 when the block behind it is the decode mirror, 0 when it is anything else; a block run
+  // by itself (c8ph_run) has no reader the harness could know of
+  int feeds_decode = -1;
+  int output_feeds_only_decode(unsigned) override { return feeds_decode; }
   // an output buffer of n floats, from the block's allocator when its io_signature says so
   struct obuf_t {
     harness* h; float* p; bool pinned;
@@ -170,7 +174,8 @@ struct harness : public block_io {
 
 extern "C" {
 
-// fused: 0 / 1 = batching_cfg::fused, -1 = its default (environment C8P_FUSED)
+// fused: 0 / 1 = batching_cfg::fused (fused_auto off), -1 = the defaults (environment C8P_FUSED; unset: decided from the flowgraph —
+// c8ph_run_chain tells a demod whose reader is the decode mirror so, and it then runs fused)
 // pinned_io / defer_consume: 0 / 1 = batching_cfg's fields, -1 = their defaults (environment C8P_PINNED_IO, C8P_DEFER_CONSUME)
 void* c8ph_create_ex2(int kind, int mupos, int ifdebug, const char* lib, int max_batch, int flush_idle, int fused, int pinned_io, int defer_consume,
                       char* errbuf, int errcap)
@@ -179,7 +184,7 @@ void* c8ph_create_ex2(int kind, int mupos, int ifdebug, const char* lib, int max
     harness* h = new harness();
     c8p_api api = load_c8p_api(lib);
     batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
-    if (fused >= 0) cfg.fused = fused != 0;
+    if (fused >= 0) { cfg.fused = fused != 0; cfg.fused_auto = false; }      // (said explicitly: nothing left to decide from the flowgraph)
     if (pinned_io >= 0) cfg.pinned_io = pinned_io != 0;
     if (defer_consume >= 0) cfg.defer_consume = defer_consume != 0;
     if (kind == 0) { h->blk = demod::make(mupos, 0, api, cfg); h->nports = 1; }
@@ -260,6 +265,8 @@ void c8ph_set_poison(void* p, int on) { static_cast<harness*>(p)->poison = on !=
 void c8ph_set_relocate(void* p, int every) { static_cast<harness*>(p)->relocate = every > 0 ? every : 0; }
 int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->input_is_pinned((unsigned)port) ? 1 : 0; }
 int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
+// c8p_block::fused_state: 1 / 0 = the demod front runs fused / plain, -1 = not decided yet (no general_work call so far) or no demod
+int c8ph_fused_state(void* p) { return static_cast<harness*>(p)->blk->fused_state(); }
 
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 {
@@ -363,6 +370,7 @@ long c8ph_run_chain(void* pa, void* pb, int chunk, int nout)
   const bool pin_edge = A->pinned_out || B->in[0].pinned;
   harness* owner = A->pinned_out ? A : B;
   A->pinned_out = pin_edge; B->in[0].pinned = pin_edge;          // what the two blocks are told about the edge
+  A->feeds_decode = B->blk->is_decode_front() ? 1 : 0;           // ... and who reads it (block_io::output_feeds_only_decode)
   A->in_cap_bytes = 2 * (size_t)std::max(chunk, 1) * A->item_size;
   B->in_cap_bytes = 2 * std::max((size_t)std::max(chunk, 1), (size_t)std::max(nout, 1) * fpi) * sizeof(float);
   const size_t seg_floats = std::max<size_t>((size_t)std::max(nout, 1) * fpi * 16, (size_t)1 << 23);

@@ -1,6 +1,7 @@
 // declarations only (tests/gr_api_decls/README.md): the members of gr::basic_block / gr::block that gnuradio/lib/ uses, with the
 // access levels and signatures of GNU Radio 3.10 (gnuradio/basic_block.h, gnuradio/block.h, gnuradio/tags.h, gnuradio/sptr_magic.h)
 #pragma once
+#include <gnuradio/block_detail.h>
 #include <gnuradio/io_signature.h>
 #include <gnuradio/types.h>
 #include <pmt/pmt.h>
@@ -53,6 +54,7 @@ public:
   uint64_t nitems_read(unsigned int which_input);
   uint64_t nitems_written(unsigned int which_output);
   void set_tag_propagation_policy(tag_propagation_policy_t p);
+  block_detail_sptr detail() const;             // set by the flat flowgraph before the block's thread starts
 
 protected:
   block(void);

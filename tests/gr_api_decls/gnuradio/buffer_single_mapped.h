@@ -7,6 +7,11 @@
 #include <memory>
 namespace gr {
 typedef std::function<void*(void*, const void*, std::size_t)> mem_func_t;
+class buffer_reader                            // gnuradio/buffer_reader.h
+{
+public:
+  block_sptr link() const;                     // the block that reads via this reader
+};
 class buffer
 {
 public:
@@ -15,6 +20,8 @@ public:
   virtual void* write_pointer() = 0;
   virtual const void* _read_pointer(unsigned int read_index) = 0;
   bool allocate_buffer(int nitems);
+  size_t nreaders() const;                       // gnuradio/buffer.h: the readers attached to this buffer
+  buffer_reader* reader(size_t index);
 
 protected:
   buffer(int nitems, size_t sizeof_item, uint64_t downstream_lcm_nitems, uint32_t downstream_max_out_mult, block_sptr link);

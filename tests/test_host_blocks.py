@@ -865,3 +865,36 @@ def test_rx_chain_block_on_the_engine():
     assert run_rx_chain(ENGINE_LIB, 430, K=3, per_round=4000, jitter=11) >= 15
     assert run_rx_chain(ENGINE_LIB, 420, K=3, bits=16) >= 15
     assert run_rx_chain(ENGINE_LIB, 420, K=3, per_round=5000, jitter=5, bits=8) >= 15
+
+
+def test_fused_is_the_default_when_demod_feeds_only_decode(monkeypatch):
+    """batching_cfg::fused_auto (VERDICT r4 1a): with nothing said (no fused argument, no C8P_FUSED in the environment) a demod front whose LLR
+    port is read by the decode mirror only — what rx.grc wires, and what the chain harness tells it through
+    block_io::output_feeds_only_decode — runs fused; run by itself (its reader unknown) it stays plain and writes its items; C8P_FUSED=0
+    keeps it plain in the chain too; the PDUs and debug lines are the same in all of them."""
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    want = None
+    for env, expect in ((None, True), ("0", False), ("auto", True), ("1", True)):
+        if env is None:
+            monkeypatch.delenv("C8P_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("C8P_FUSED", env)
+        dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7)
+        dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=7)
+        assert dem.fused_state() is None                       # nothing decided before the first call
+        blocks.feed_demod(dem, pk, iq, chan)
+        blocks.run_chain(dem, dec, chunk=3000, nout=5000)
+        assert dem.fused_state() is expect, (env, dem.fused_state())
+        got = (dec.messages(), dec.debug_lines())
+        dem.close(); dec.close()
+        want = want or got
+        assert got == want, env
+        assert len(got[0]) >= 10
+    monkeypatch.delenv("C8P_FUSED", raising=False)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7)      # by itself: who reads the port is unknown -> plain, items written
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=4096, nout=8192)
+    assert dem.fused_state() is False
+    assert not any(k == "c8p_fused" for _, k, _ in dem.tags())
+    dem.close()

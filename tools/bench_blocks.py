@@ -5,7 +5,7 @@ thread (thread-per-block).  Three figures per batch size:
   demod_block / decode_block   one block alone (its output is counted, not kept)
   chain                        demod -> decode through the float LLR stream, as rx.grc wires them: the stream crosses
                                PCIe twice (57 KB per packet down, 57 KB up)
-  chain_fused                  batching_cfg::fused (C8P_FUSED=1): demod runs c8p_rx, decode publishes behind the handle;
+  chain_fused                  batching_cfg::fused (what a demod -> decode flowgraph gets by default — fused_auto — or C8P_FUSED=1): demod runs c8p_rx, decode publishes behind the handle;
                                35 KB per packet up, 1.5 KB down
   rx_chain                     rx.grc's whole receive chain for K radios as ONE block (host/c8p_rx_chain.cc): raw 20 MS/s item streams in,
                                PDUs out; 8 B per item down, the PDUs up
@@ -135,6 +135,17 @@ def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinne
             res[key + "_host_phase_us_per_packet"] = {"demod": {k: round(v / tot, 3) for k, v in dem.host_phase_us().items()},
                                                        "decode": {k: round(v / tot, 3) for k, v in dec.host_phase_us().items()},
                                                        "wall": round(1e6 * dt / n, 3)}
+            dem.close(); dec.close()
+        if "chain_default_mode" not in best:
+            # what the pair does when nothing is said (fused=None, no C8P_FUSED): the demod front learns from the scheduler side that its only
+            # reader is the decode mirror and runs fused (batching_cfg::fused_auto)
+            dem = blocks.Block(blocks.DEMOD, max_batch=max_batch, pinned_io=pinned_io, defer_consume=defer_consume)
+            dec = blocks.Block(blocks.DECODE, max_batch=max_batch, pinned_io=pinned_io, defer_consume=defer_consume)
+            blocks.feed_demod(dem, pk, iq, chan)
+            blocks.run_chain(dem, dec, chunk=chunk_in, nout=nout_llr)
+            ok = sum(1 for (ln, m), e in zip(dec.messages()[-n:], exp) if m == e)
+            best["chain_default_mode"] = {True: "fused", False: "plain", None: "undecided"}[dem.fused_state()] + (" (C8P_FUSED=%s)" % os.environ["C8P_FUSED"] if "C8P_FUSED" in os.environ else "")
+            best["pdus_ok_chain_default"] = ok
             dem.close(); dec.close()
         if not quiet:
             print(json.dumps(res), flush=True)
