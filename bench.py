@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PROFILE_EVERY = 4                        # c8p_cfg.profile: sample the per-kernel HIP events on every 4th submit
 # The committed rocprofv3 profile the line's counter-derived figures come from (roofline.traffic, roofline_valu.counters, the opcode
 # costs): ONE directory, named here and in the line — taken with tools/profile_gpu.sh + tools/summarize_prof.py on the code as it is.
-PROFILE_TAG = os.environ.get("C8P_PROFILE_TAG", "r5p")
+PROFILE_TAG = os.environ.get("C8P_PROFILE_TAG", "r5t")
 
 
 def main():
