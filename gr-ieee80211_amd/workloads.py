@@ -88,6 +88,8 @@ WORKLOADS = {
     # not BASELINE configs: random formats / MCS / lengths per packet (differential and soak tests)
     "random1": (-1, 0, 1, 1, 0, None, 0, 8021700, "random legacy / HT / VHT, MCS and length (14-3000 bytes) per packet, one stream"),
     "random2": (-2, 0, 2, 2, 0, H22, 0, 8021800, "random HT MCS 8-15 / VHT 2 x MCS 0-8 and length (14-3000 bytes) per packet, two streams on two antennas"),
+    "randommu0": (-3, 0, 2, 1, 0, H_MU[0:1], 0, 8021900, "VHT 2-user MU-MIMO, each user's MCS (0-8) and MPDU length (14-1500 bytes) random per packet, station 0"),
+    "randommu1": (-3, 0, 2, 1, 0, H_MU[1:2], 1, 8021900, "the same packets at station 1"),
 }
 
 
@@ -114,7 +116,7 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
     seed_base = sb if seed_base is None else seed_base
     GAP = 120
     pk = np.zeros(n, abi.TX_PKT_DT)
-    mu = np.zeros(n if fmt == 3 else 0, abi.TX_MU_DT)
+    mu = np.zeros(n if fmt in (3, -3) else 0, abi.TX_MU_DT)
     arena, exp = [], []
     off = 0
 
@@ -126,11 +128,21 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
     fmt_cfg = fmt
     for p in range(n):
         rng = np.random.default_rng(seed_base + seed + p)
-        if fmt_cfg < 0:                                    # random1 / random2: this packet's own format, rate and length
+        if fmt_cfg in (-1, -2):                            # random1 / random2: this packet's own format, rate and length
             fmt = int(rng.integers(0, 3)) if fmt_cfg == -1 else int(rng.integers(1, 3))
             mcs = int(rng.integers(0, 8 if fmt < 2 else 9))
             mlen = int(rng.integers(14, 3000))
-        lens = (100, 60) if fmt == 3 else (mlen,)
+        mcs_u1 = mcs
+        if fmt_cfg == -3:                                  # randommu0 / 1: both users' rate and length drawn per packet
+            fmt = 3
+            mcs, mcs_u1 = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+            # both users are padded to the longer one's symbol count, and the padded data field of EITHER must fit the decoder's trellis
+            # limit (32 782 steps, decode_impl.cc:93): a common symbol budget first, then each user's length inside it
+            ndbps = (26, 52, 78, 104, 156, 208, 234, 260, 312)
+            nsym_t = int(rng.integers(2, min(110, 32782 // max(ndbps[mcs], ndbps[mcs_u1])) + 1))
+            lens = tuple(int(rng.integers(14, max(15, min(1500, (nsym_t * ndbps[m_] - 22) // 8 - 8)))) for m_ in (mcs, mcs_u1))
+        else:
+            lens = (100, 60) if fmt == 3 else (mlen,)
         mpdus = []
         for ln in lens:
             body = bytes(rng.integers(0, 256, size=ln - 4, dtype=np.uint8))
@@ -141,10 +153,10 @@ def workload_on_device(kind, n, snr_db, seed, torch, dev, local=0, mcs=None, see
         pk[p]["mult"] = 12.0 * (np.sqrt(2.0) if nchain == 2 else 1.0)
         pk[p]["flags"] = 0 if window else abi.TX_NO_WINDOW
         if fmt == 3:
-            mu[p]["psdu_off"], mu[p]["len"], mu[p]["mcs"], mu[p]["group_id"], mu[p]["q_off"] = put(ps[1]), len(ps[1]), mcs, 2, 0
+            mu[p]["psdu_off"], mu[p]["len"], mu[p]["mcs"], mu[p]["group_id"], mu[p]["q_off"] = put(ps[1]), len(ps[1]), mcs_u1, 2, 0
         m = mpdus[mupos]
-        exp.append(bytes([min(fmt, 2), len(m) % 256, len(m) // 256]) + m + bytes([mcs + 8 if (fmt == 1 and nchain == 2) else mcs]))
-    fmt = fmt_cfg
+        exp.append(bytes([min(fmt, 2), len(m) % 256, len(m) // 256]) + m + bytes([mcs + 8 if (fmt == 1 and nchain == 2) else (mcs_u1 if (fmt == 3 and mupos == 1) else mcs)]))
+    fmt = 3 if fmt_cfg == -3 else fmt_cfg
     bfq = None
     if fmt == 3:           # zero-forcing steering (tools/cmu_v3/cmu_ap.py:182-189): nulls the other user's stream at each station
         q = np.linalg.inv(np.asarray(H_MU, np.complex128))

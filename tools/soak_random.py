@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/soak_random.py — randomized differential soak: batches of packets of random format (legacy / HT / VHT), rate, length (14-3000
-bytes) and stream count, each batch at a random SNR (6-34 dB), with or without the toolbox's windowed symbol edges, through a flat or a
+bytes) and stream count (one stream; two streams on two antennas; a 2-user MU-MIMO packet with each user's rate and length random,
+received at station 0 or 1), each batch at a random SNR (6-34 dB), with or without the toolbox's windowed symbol edges, through a flat or a
 random 2-5 tap channel, decoded by c8p_rx as it ships (the un-tapped default) and compared with the oracle PACKET BY PACKET on all host
 cores: status, the whole tag set, failure counts, PDU bytes — failing frames included.
 
@@ -64,7 +65,8 @@ def main():
     tot = n_ok = n_fail = n_rej = 0
     t0 = time.time()
     for k in range(batches):
-        kind = "random2" if rng.uniform() < 0.3 else "random1"
+        u = rng.uniform()
+        kind = "random2" if u < 0.3 else ("randommu0" if u < 0.36 else ("randommu1" if u < 0.42 else "random1"))
         snr = float(rng.uniform(6.0, 34.0))
         window = bool(rng.uniform() < 0.25)
         taps = random_taps(rng) if rng.uniform() < 0.5 else None
@@ -127,7 +129,7 @@ def main():
                 if t["status"] == abi.ST_OK and t["trellis"] > 0 and not t["is_ndp"]:
                     assert np.array_equal(dres[q]["sbits"], sb) and np.array_equal(dres[q]["bits"], ub), where
                     bits_n += len(ub)
-        print("batch %2d  %s  %4.1f dB  %s  %s: %d packets, %d PDUs, %d FCS failures, %d not decodable — all equal to the oracle"
+        print("batch %2d  %-9s  %4.1f dB  %s  %s: %d packets, %d PDUs, %d FCS failures, %d not decodable — all equal to the oracle"
               % (k, kind, snr, "windowed" if window else "clean   ", "flat  " if taps is None else "%d taps" % len(taps), len(pk), b_ok, b_fail, b_rej), flush=True)
         del keep
     e.close()
