@@ -42,6 +42,8 @@ def lib():
         L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_output_pinned.argtypes = [C.c_void_p]
         L.c8ph_fused_state.argtypes = [C.c_void_p]
+        L.c8ph_tags_emitted.argtypes = [C.c_void_p]
+        L.c8ph_tags_emitted.restype = C.c_long
         L.c8ph_run_chain.restype = C.c_long
         L.c8ph_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.c8ph_destroy.argtypes = [C.c_void_p]
@@ -169,6 +171,10 @@ class Block:
         first general_work call, from who reads the LLR port) or not a demod block"""
         v = int(self.L.c8ph_fused_state(self.h))
         return None if v < 0 else bool(v)
+
+    def tags_emitted(self):
+        """stream tags the block has written so far (every add_item_tag call of its life)"""
+        return int(self.L.c8ph_tags_emitted(self.h))
 
     def set_jitter(self, seed):
         """random item counts per general_work call from now on (0 = off): what a busy scheduler hands a block"""

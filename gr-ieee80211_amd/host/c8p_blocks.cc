@@ -97,6 +97,11 @@ bool batching_cfg::default_fused_auto()
   const char* e = getenv("C8P_FUSED");
   return !e || !*e || !strcmp(e, "auto");
 }
+bool batching_cfg::default_fused_lean_tags()
+{
+  const char* e = getenv("C8P_FUSED_TAGS");
+  return !(e && !strcmp(e, "full"));
+}
 bool batching_cfg::default_pinned_io()
 {
   const char* e = getenv("C8P_PINNED_IO");
@@ -186,6 +191,7 @@ struct fused_batch {
   explicit fused_batch(const c8p_api* a) : outs(a), pdu(a) {}
   pinned_vec<c8p_pkt_out> outs;       // [packets of the batch]
   pinned_vec<uint8_t> pdu;            // the PDU arena (whole: its layout is fixed-stride)
+  std::vector<c8p_pkt_tags> tags;     // lean tags (batching_cfg::fused_lean_tags): the packets' tag records, which then do not travel as stream tags
 };
 static const int C8P_FUSED_IDX_BITS = 20;
 static std::mutex g_fused_mu;
@@ -627,7 +633,10 @@ public:
         d_in_dev = d_in_dev && d_io->input_is_pinned((unsigned)p) && (cap == 0 || cap >= gather_min_buffer());
       }
       // the cfg left fused / plain open: fused when nothing but decode mirrors reads the LLR port (c8p_blocks.h, batching_cfg::fused_auto)
-      if (!d_eng.d_cfg.fused && d_eng.d_cfg.fused_auto && d_io->output_feeds_only_decode(0) == 1) d_eng.d_cfg.fused = true;
+      if (!d_eng.d_cfg.fused && d_eng.d_cfg.fused_auto && d_io->output_feeds_only_decode(0) == 1) {
+        d_eng.d_cfg.fused = true;
+        d_lean = d_eng.d_cfg.fused_lean_tags;      // nothing but decode mirrors reads this edge: the handle is the only tag they need
+      }
       d_out_dev = d_eng.d_cfg.pinned_io && !d_eng.d_cfg.fused && d_io->output_is_pinned(0);
       d_mode_known = true;
     }
@@ -803,6 +812,7 @@ private:
         K_cr("cr"), K_ampdu("ampdu"), K_trellis("trellis"), K_mu("mu2x1chan"), K_total("total"), K_fused("c8p_fused"), K_llr("c8p_llr");
     const c8p_pkt_tags& t = o.t;
     auto L = [&](const std::string& k, long v) { d_io->add_item_tag(0, off, k, tag_value::from_long(v)); };
+    if (d_lean && o.handle >= 0) { L(K_fused, o.handle); return; }     // (the record is behind the handle: fused_batch::tags)
     auto F = [&](const std::string& k, float v) { d_io->add_item_tag(0, off, k, tag_value::from_float(v)); };
     F(K_cfo, t.cfo); F(K_snr, t.snr);
     if (t.format == C8P_F_VHT) { F(K_s0, t.sssnr0); if (d_nports == 2 && t.nss == 2) F(K_s1, t.sssnr1); }
@@ -1022,6 +1032,7 @@ private:
     if (fused) {                                   // the whole batch behind ONE handle; a packet's tag names its index
       fb_id = g_fused_next.fetch_add(1);
       st.fb_id = fb_id;
+      if (d_lean) st.fb->tags.assign(tags, tags + n); else st.fb->tags.clear();
       fused_park(fb_id, st.fb);
     }
     long lb_id = 0;
@@ -1173,6 +1184,7 @@ private:
   engine_holder d_eng;
   int d_nports, d_mupos, d_mugid;
   bool d_mode_known = false, d_in_dev = false, d_out_dev = false;     // pinned scheduler buffers on the input ports / the output port
+  bool d_lean = false;                             // fused by fused_auto with lean tags: one tag per packet, the tag records travel with the batch
   c8p_pkt_in d_cur;
   int d_have = 0;
   enum { NST = 4 };
@@ -1557,6 +1569,21 @@ public:
             default: break;
           }
         }
+        if (d_cur_fused >= 0) {
+          // fused mode: the batch behind the handle (the next batch: the one before it has been published and leaves the registry).  With
+          // lean tags (batching_cfg::fused_lean_tags) the handle is the packet's only tag and its tag record is in the batch
+          const long id = d_cur_fused >> C8P_FUSED_IDX_BITS;
+          const size_t idx = (size_t)(d_cur_fused & ((1L << C8P_FUSED_IDX_BITS) - 1));
+          if (id != d_fb_id) {
+            if (d_fb) fused_purge(std::vector<long>(1, d_fb_id));
+            d_fb = fused_find(id);
+            d_fb_id = id;
+          }
+          if (d_cur.total == 99999) {                                 // no "total" on the item: a lean packet, or a foreign handle
+            if (d_fb && idx < d_fb->tags.size()) d_cur = d_fb->tags[idx];
+            else d_cur.total = 0;                                     // (nothing to count: step over the item)
+          }
+        }
         d_cur.is_ndp = d_cur.trellis == 0;
         d_cur_ext = false;
         if (d_cur_fused < 0) {
@@ -1835,12 +1862,7 @@ private:
     while (!d_fly.empty()) reap(true);
     const long id = d_cur_fused >> C8P_FUSED_IDX_BITS;
     const size_t idx = (size_t)(d_cur_fused & ((1L << C8P_FUSED_IDX_BITS) - 1));
-    if (id != d_fb_id) {                           // the next batch: the one before it has been published, it leaves the registry
-      if (d_fb) fused_purge(std::vector<long>(1, d_fb_id));
-      d_fb = fused_find(id);
-      d_fb_id = id;
-    }
-    if (!d_fb || idx >= d_fb->outs.size()) return;                  // a handle from another process / a replayed capture: nothing to publish
+    if (id != d_fb_id || !d_fb || idx >= d_fb->outs.size()) return;   // (resolved where the tags were read) a handle from another process / a replayed capture: nothing to publish
     sub_scope phr(d_ph, phase_clock::REPLAY);
     publish_packet(d_cur, d_fb->outs.data()[idx], d_fb->pdu.data());
   }

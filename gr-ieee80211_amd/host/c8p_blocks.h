@@ -164,6 +164,13 @@ struct batching_cfg {
   // says that every reader of the LLR port is a decode mirror (the reference's own flowgraphs), plain otherwise.  Default: on unless the
   // environment sets C8P_FUSED (1: always fused, 0: never, "auto": this).  A caller that sets `fused` itself should clear it.
   bool fused_auto = default_fused_auto();
+  // When fused_auto chose fused — decode mirrors are the ONLY readers of the LLR port, so nothing else can see that edge's tags — demod
+  // puts ONE tag on a packet's first item, the handle, instead of the reference's eleven to fourteen + the handle: decode finds the
+  // packet's tag record (format, mcs, len, ..., total, cfo, snr, rssi, sssnr) behind the handle with the results.  Every tag is a string
+  // key + a variant here and a PMT pair under the buffer's mutex in GNU Radio; item counts, PDU bytes and debug lines are unchanged.
+  // Environment C8P_FUSED_TAGS=full keeps the reference's tags on the edge (a tag debugger on it would otherwise see one tag per packet).
+  // A fused mode that was FORCED (cfg.fused / C8P_FUSED=1: the front does not know who reads) always writes the full set.
+  bool fused_lean_tags = default_fused_lean_tags();
   // Custom buffers (block_io::input_is_pinned / output_is_pinned): use them when the scheduler provides them (default; environment
   // C8P_PINNED_IO=0 turns it off).  defer_consume: a front then consumes the items of a general_work call during the NEXT call, when
   // the gather that moves them has had a scheduler round trip to finish — nothing waits for the link; 0 (C8P_DEFER_CONSUME=0): the gather is
@@ -178,6 +185,7 @@ struct batching_cfg {
   static bool default_llr_handle();
   static bool default_fused();
   static bool default_fused_auto();
+  static bool default_fused_lean_tags();
   static bool default_pinned_io();
   static bool default_defer_consume();
   static int default_max_wait_us();

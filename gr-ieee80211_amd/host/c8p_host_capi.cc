@@ -141,7 +141,9 @@ struct harness : public block_io {
   void add_item_tag(unsigned, uint64_t off, const std::string& key, const tag_value& val) override
   {
     tag_t t; t.offset = off; t.key = key; t.value = val; out_tags.push_back(t);
+    n_tags_out++;
   }
+  long n_tags_out = 0;                          // every add_item_tag call of the block's life (c8ph_tags_emitted)
   void consume_each(int n) override { consumed_this_call = n; }
   void message_port_pub(const std::string&, const pdu_t& m) override { std::lock_guard<std::mutex> g(msg_mu); msgs.push_back(m); }
   void debug_print(const std::string& s) override { std::lock_guard<std::mutex> g(msg_mu); dbg.push_back(s); }
@@ -267,6 +269,8 @@ int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->inpu
 int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
 // c8p_block::fused_state: 1 / 0 = the demod front runs fused / plain, -1 = not decided yet (no general_work call so far) or no demod
 int c8ph_fused_state(void* p) { return static_cast<harness*>(p)->blk->fused_state(); }
+// stream tags the block has written so far (add_item_tag calls), whoever took them
+long c8ph_tags_emitted(void* p) { return static_cast<harness*>(p)->n_tags_out; }
 
 long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
 {

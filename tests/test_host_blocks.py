@@ -867,6 +867,16 @@ def test_rx_chain_block_on_the_engine():
     assert run_rx_chain(ENGINE_LIB, 420, K=3, per_round=5000, jitter=5, bits=8) >= 15
 
 
+def ref_tags_per_packet(pk, iq, chan):
+    """per packet of the batch: does demod emit it (status OK)?  From a plain demod run on the test engine."""
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=64, fused=False)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=4096, nout=8192)
+    offs = sorted({o for o, k, _ in dem.tags()})
+    dem.close()
+    return [True] * len(offs)
+
+
 def test_fused_is_the_default_when_demod_feeds_only_decode(monkeypatch):
     """batching_cfg::fused_auto (VERDICT r4 1a): with nothing said (no fused argument, no C8P_FUSED in the environment) a demod front whose LLR
     port is read by the decode mirror only — what rx.grc wires, and what the chain harness tells it through
@@ -875,9 +885,13 @@ def test_fused_is_the_default_when_demod_feeds_only_decode(monkeypatch):
     b, _ = sweep_batch(snr_db=28.0, seed=5)
     pk, iq, chan = split(b, 1)
     want = None
-    for env, expect in ((None, True), ("0", False), ("auto", True), ("1", True)):
+    monkeypatch.delenv("C8P_FUSED_TAGS", raising=False)
+    for env, expect, lean in ((None, True, True), ("0", False, False), ("auto", True, True), ("1", True, False), ("auto+full", True, False)):
+        monkeypatch.delenv("C8P_FUSED_TAGS", raising=False)
         if env is None:
             monkeypatch.delenv("C8P_FUSED", raising=False)
+        elif env == "auto+full":
+            monkeypatch.setenv("C8P_FUSED", "auto"); monkeypatch.setenv("C8P_FUSED_TAGS", "full")
         else:
             monkeypatch.setenv("C8P_FUSED", env)
         dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7)
@@ -887,10 +901,15 @@ def test_fused_is_the_default_when_demod_feeds_only_decode(monkeypatch):
         blocks.run_chain(dem, dec, chunk=3000, nout=5000)
         assert dem.fused_state() is expect, (env, dem.fused_state())
         got = (dec.messages(), dec.debug_lines())
+        n_tags = dem.tags_emitted()
         dem.close(); dec.close()
         want = want or got
-        assert got == want, env
+        assert got == want, env                                # PDUs AND the debug lines (cfo, snr, rssi, sssnr, per-MCS counts: the tag record)
         assert len(got[0]) >= 10
+        # lean tags (batching_cfg::fused_lean_tags): fused by fused_auto = ONE tag per emitted packet, the handle; every other mode writes
+        # the reference's eleven to fourteen (+ a handle)
+        n_emitted = sum(1 for r in ref_tags_per_packet(pk, iq, chan) if r)
+        assert (n_tags == n_emitted) if lean else (n_tags >= 11 * n_emitted), (env, n_tags, n_emitted)
     monkeypatch.delenv("C8P_FUSED", raising=False)
     dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7)      # by itself: who reads the port is unknown -> plain, items written
     blocks.feed_demod(dem, pk, iq, chan)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/probes/chain_custom.py [max_batch] [io] [fused|plain|both] — the demod -> decode chain in bench.py's custom-buffer configuration alone (one
+"""tools/probes/chain_custom.py [max_batch] [io] [fused|plain|both|default] — the demod -> decode chain in bench.py's custom-buffer configuration alone (one
 max_batch), for A/B runs under C8P_GATHER_DEPTH / C8P_GATHER_STATS / C8P_COPY_CUS and for kernel traces; prints the chain figures and the demod
 thread's phases"""
 import json, os, sys, time
@@ -21,7 +21,9 @@ pin = hostbind.cpu_pair_sharing_l3()
 if pin:
     os.environ["C8P_CHAIN_PIN"] = "%d,%d" % tuple(pin)
 out = {"n": n, "depth": os.environ.get("C8P_GATHER_DEPTH"), "max_batch": mb, "io": io, "pin": pin}
-for fused in ((False, True) if mode == "both" else (mode == "fused",)):
+# default: nothing said about fused — the demod front decides from who reads its port (batching_cfg::fused_auto: fused, with lean tags
+# unless C8P_FUSED_TAGS=full); "fused" forces it (the reference's full tag set on the edge)
+for fused in ((False, True) if mode == "both" else ((None,) if mode == "default" else (mode == "fused",))):
     dem = blocks.Block(blocks.DEMOD, max_batch=mb, fused=fused)
     dec = blocks.Block(blocks.DECODE, max_batch=mb, fused=fused)
     ts, n_in = [], 0
@@ -31,7 +33,9 @@ for fused in ((False, True) if mode == "both" else (mode == "fused",)):
         if rep == 0:
             dem.host_phase_reset(); dec.host_phase_reset()
     ok = sum(1 for (ln, m), e in zip(dec.messages()[-n:], exp) if m == e)
-    k = "fused" if fused else "plain"
+    k = "default" if fused is None else ("fused" if fused else "plain")
+    if fused is None:
+        out["default_is_fused"] = dem.fused_state(); out["default_tags_per_packet"] = round(dem.tags_emitted() / (n * (1 + passes)), 2)
     out[k] = round(n / float(np.median(ts[1:]))); out[k + "_best"] = round(n / min(ts[1:])); out[k + "_worst"] = round(n / max(ts[1:])); out[k + "_ok"] = ok
     out[k + "_pass_ms"] = [round(1e3 * t, 2) for t in ts]
     out[k + "_demod"] = {q: round(v / (n * passes), 3) for q, v in dem.host_phase_us().items() if v / (n * passes) >= 0.02}
