@@ -54,6 +54,7 @@ timeout 600 $W/rx_live -l $FAKE -r 5000 -s $(cat $W/scale.txt) $W/radio0.sc16 $W
 timeout 600 $W/blocks_driver $FAKE 6000 $W/radio0.c64 $W/radio1.c64 $W/radio2.c64 2>> $W/err.txt | tail -2
 timeout 600 $W/chain_driver $FAKE $W/packets.bin 0 2>> $W/err.txt | tail -1
 timeout 600 $W/chain_driver $FAKE $W/packets.bin 1 2>> $W/err.txt | tail -1
+timeout 600 $W/chain_driver $FAKE $W/packets.bin -1 2>> $W/err.txt | tail -1     # nothing said: fused_auto decides (fused, lean tags)
 echo "ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $W/err.txt)"
 grep -A6 'WARNING: ThreadSanitizer' $W/err.txt | head -40
 make -s -C oracle clean && make -s -C oracle

@@ -17,7 +17,7 @@ long c8ph_msg_count(void* p);
 
 int main(int argc, char** argv)
 {
-  if (argc < 4) { fprintf(stderr, "usage: %s libengine.so packets.bin fused(0|1)\n", argv[0]); return 1; }
+  if (argc < 4) { fprintf(stderr, "usage: %s libengine.so packets.bin fused(0|1|-1 = the defaults: fused_auto)\n", argv[0]); return 1; }
   char err[512] = "";
   void* dem = c8ph_create_ex(0, 0, 0, argv[1], 8, 1, atoi(argv[3]), err, (int)sizeof(err));
   void* dec = c8ph_create_ex(2, 0, 0, argv[1], 8, 1, atoi(argv[3]), err, (int)sizeof(err));
