@@ -36,9 +36,14 @@ def test_bench_line_carries_the_contract_keys():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # frac is the step's figure: algorithmic bytes of a launch over ms_per_step
-    want = r["alg_bytes_per_packet"] * r["packets_per_launch"] / (j["ms_per_step"] * 1e-3) / 1e9
-    assert abs(r["achieved"] - want) / want < 1e-6
+    # achieved / frac: the algorithmic bytes of a launch over the dominant kernel's average launch duration (lines up to profiles/r5t: over
+    # ms_per_step, the exclusive figure beside it as achieved_exclusive); the other of the two is in the object as well
+    bytes_launch = r["alg_bytes_per_packet"] * r["packets_per_launch"]
+    want_step = bytes_launch / (j["ms_per_step"] * 1e-3) / 1e9
+    assert abs(r["achieved_step"] - want_step) / want_step < 1e-6
+    assert abs(r["achieved"] - r["achieved_exclusive"]) < 1e-9 or abs(r["achieved"] - r["achieved_step"]) < 1e-9
+    k_ms = r["exclusive_avg_launch_ms"][r["kernel"]]
+    assert abs(r["achieved_exclusive"] - bytes_launch / (k_ms * 1e-3) / 1e9) / r["achieved_exclusive"] < 2e-3      # (k_ms is rounded to 0.1 us in the line)
     assert abs(j["value"] - j["n_gpus"] * r["packets_per_launch"] / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
