@@ -173,8 +173,8 @@ private:
   // what c8p_pinned_buffer::make_buffer allocates at least: megabytes, so the fronts gather (c8p_blocks.h: C8P_GATHER_MIN_BUFFER)
   size_t input_buffer_bytes(unsigned port) override { return input_is_pinned(port) ? (size_t)C8P_PINNED_BUFFER_MIN_BYTES : 0; }
 
-  // Who reads this output port (c8p::block_io::output_feeds_only_decode)?  Every reader of the edge's buffer must be this module's decode
-  // block for a demod front to run fused by default (c8p::batching_cfg::fused_auto): nothing else ever looks at the LLR item values
+  // Who reads this output port (c8p::block_io::output_feeds_only_decode)?  The edge's buffer must have ONE reader, this module's decode
+  // block, for a demod front to run fused by default (c8p::batching_cfg::fused_auto): nothing else ever looks at the LLR item values
   // then.  The flat flowgraph has attached detail, buffers and readers before any scheduler thread calls general_work.
   int output_feeds_only_decode(unsigned port) override
   {
@@ -187,9 +187,10 @@ private:
       if (!d || (int)port >= d->noutputs()) return -1;
       gr::buffer_sptr b = d->output(port);
       if (!b || b->nreaders() == 0) return -1;
-      for (size_t i = 0; i < b->nreaders(); i++)
-        if (!std::dynamic_pointer_cast<gr::ieee80211::decode>(b->reader(i)->link())) return 0;
-      return 1;
+      // exactly ONE reader, and it is the decode block: a batch's hand-over leaves the registry when its reader moves on to the next
+      // batch, so two decode blocks on one edge must get the items themselves (plain mode)
+      if (b->nreaders() != 1) return 0;
+      return std::dynamic_pointer_cast<gr::ieee80211::decode>(b->reader(0)->link()) ? 1 : 0;
     } catch (...) {                                    // (a reader whose block is gone: the flowgraph is being torn down)
       return -1;
     }

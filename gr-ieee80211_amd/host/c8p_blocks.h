@@ -96,8 +96,9 @@ public:
   // size: below C8P_GATHER_MIN_BUFFER a call's window is so small that copying it into pinned staging on the CPU (and letting a copy
   // engine upload the batch) is faster, and a front does that even when the buffer is pinned.
   virtual size_t input_buffer_bytes(unsigned port) { return 0; }
-  // Who reads this output port?  1: only decode mirrors of this process (c8p_block::is_decode_front) — what rx.grc / rx2.grc wire behind
-  // demod / demod2; 0: at least one other reader; -1: the scheduler side cannot tell.  A demod front whose cfg leaves the choice open
+  // Who reads this output port?  1: ONE reader, and it is a decode mirror of this process (c8p_block::is_decode_front) — what rx.grc /
+  // rx2.grc wire behind demod / demod2; 0: another reader, or more than one (a batch's hand-over is released by the reader that moves on
+  // to the next batch: two decode blocks on one edge get the items themselves); -1: the scheduler side cannot tell.  A demod front whose cfg leaves the choice open
   // (batching_cfg::fused_auto) runs fused exactly when this says 1: nothing but the decode mirror ever looks at the item values then.
   virtual int output_feeds_only_decode(unsigned port) { return -1; }
 };
