@@ -92,7 +92,10 @@ def main():
     from gr_ieee80211_amd import hostbind
     # this rank's host side — the engines' stage threads, the fronts' timers, RCCL's proxy threads, every pinned allocation — on the NUMA
     # node its GPU hangs off (reported in the line: host_binding)
-    binding = hostbind.bind_rank(local, torch)
+    try:
+        binding = hostbind.bind_rank(local, torch)
+    except Exception as e:                               # (a platform whose sysfs this has not met: the rank runs unbound and says so)
+        binding = {"gpu": int(local), "affinity": "kept (bind_rank failed: %s: %s)" % (type(e).__name__, e), "mempolicy": "kept"}
     binding["rank"] = rank
     if use_dist:
         import torch.distributed as dist
