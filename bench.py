@@ -983,13 +983,17 @@ def sensitivity_legs(torch, dev, local, n_pkt, headline, timed_s=0.35):
                 step(i)
             eng.sync()
             k = int(max(8, timed_s / max((time.perf_counter() - t) / 8, 1e-6)))
-            t = time.perf_counter()
-            for i in range(k):
-                step(i)
-            eng.sync()
-            dt = time.perf_counter() - t
+            dts = []
+            for _w in range(2):                         # two timed windows, the better one counts: these hosts are shared, and one window in
+                t = time.perf_counter()                 # ten or twenty meets a neighbour's burst (a leg once read 0.88 of the headline, the
+                for i in range(k):                      # next run 1.04: profiles/r5v)
+                    step(i)
+                eng.sync()
+                dts.append(time.perf_counter() - t)
+            dt = min(dts)
             pps = len(pk) * k / dt
             res[name] = {"workload": what + ", %d packets/step" % len(pk), "packets_per_s": pps, "ms_per_step": 1e3 * dt / k, "steps": k,
+                         "windows_ms_per_step": [round(1e3 * d_ / k, 4) for d_ in dts],
                          "vs_headline": pps / headline if headline else None, "fcs_ok_fraction": n_ok / max(len(pk), 1),
                          "exact_kernel_packets": int(rng_flags.sum()),
                          "float_step_block_fraction": float(flt_blocks[lean].sum()) / max(1, int((tr[lean] // 30).sum())),
@@ -1005,7 +1009,7 @@ def sensitivity_legs(torch, dev, local, n_pkt, headline, timed_s=0.35):
         except Exception as e:                            # (a leg must not cost the headline)
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     eng.close()
-    res["note"] = ("same batch size and timing code as the headline (inputs resident, K steps of c8p_rx between two syncs, ~%.2f s timed each); "
+    res["note"] = ("same batch size and timing code as the headline (inputs resident, K steps of c8p_rx between two syncs, two windows of ~%.2f s each, the better one counts: windows_ms_per_step has both); "
                    "vs_headline = packets_per_s / value.  mixed_formats is NOT the same unit of work per packet: random rate and length put ~4 x the air "
                    "time of a cfg-2 packet into the average packet (items_per_packet_mean; a 3000-byte BPSK frame is 1000 symbols to demodulate for "
                    "24 000 trellis steps, a cfg-2 frame 46 symbols for 11 960) — compare air_items_per_s (cfg 2: 4400 items per packet); the engine "
@@ -1308,8 +1312,14 @@ def raw_stream_chain(torch, dev, local, arr, n, reps, unit, segments=24):
                             reserve_pkt_items=unit_len, reserve_host=True)
         segs = [(arr.ptr, n)] * segments
         warm = h.run(segs[:4])                                                # untimed, the same handle: streams, clocks
-        st = h.run(segs)
-        out.update(chain_report(st, h.timeline(), reps))
+        runs = []
+        for _r in range(2):                                                   # two runs of 24 segments (~35 ms each), the better one counts: on these
+            st = h.run(segs)                                                  # shared hosts one run in ten meets a burst of a neighbour's (a run once
+            runs.append((st, h.timeline()))                                   # read 2.4 M packets/s between two of 4.3-4.6 M: profiles/r5v)
+        rate = [r_[0]["steady_pdus"] / max(r_[0]["steady_s"], 1e-9) for r_ in runs]
+        st, tl = runs[int(np.argmax(rate))]
+        out.update(chain_report(st, tl, reps))
+        out["runs_packets_per_s"] = [round(v) for v in rate]
         out["warmup"] = {"segments": warm["segments"], "arena_growths": warm["arena_growths"], "first_segment_ms": round(1e3 * warm["first_segment_s"], 3)}
     except Exception as e:
         out["error"] = "%s: %s" % (type(e).__name__, e)
