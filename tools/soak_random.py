@@ -11,6 +11,7 @@ split: every batch ALSO goes through the two entry points the block mirrors call
 <= 1e-5 on every item, the largest difference is printed) and c8p_decode on those items (PDUs, decoded and pre-descramble bits equal
 to the oracle's, failing frames included).
 
+TEST INFRASTRUCTURE (it drives the engine and checks it with oracle/ through tests/c8p_testlib, as tools/soak.py does): not part of the product.
 Prints one line per batch and a summary; exits non-zero at the first difference.  (tests/test_gpu_parity.py's soak covers the BASELINE
 configs at fixed operating points; this one covers what lies between them.)"""
 import ctypes
