@@ -5,6 +5,7 @@
 set -u
 HERE=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$HERE"
+rm -f "$HERE/gnuradio/ci/side_by_side.json"
 export C8P_RX_LIB="$HERE/gr-ieee80211_amd/libc8p_rx.so"
 python3 -m pytest tests/test_gnuradio_flowgraph.py tests/test_gnuradio_packaging.py -m "gpu or not gpu" -q -rs --junitxml="$HERE/gnuradio/ci/junit.xml"
 RC=$?
@@ -38,6 +39,10 @@ rec = {"when": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "pytest_exit_
        "head": out(["git", "-C", root, "rev-parse", "HEAD"]),
        "passed": sum(t["result"] == "passed" for t in tests), "failed": sum(t["result"] == "failed" for t in tests),
        "skipped": sum(t["result"].startswith("skipped") for t in tests), "tests": tests}
+try:     # the reference's own C++ blocks beside ours on the same IQ (test_reference_cxx_side_by_side): max |LLR difference|, tags, PDUs
+    rec["reference_cxx_side_by_side"] = json.load(open(root + "/gnuradio/ci/side_by_side.json"))
+except Exception:
+    rec["reference_cxx_side_by_side"] = "not run (gnuradio/ci/build_reference.sh <checkout> first)"
 json.dump(rec, open(root + "/GRCI.json", "w"), indent=1)
 print("GRCI.json: %d passed, %d failed, %d skipped (GNU Radio %s)" % (rec["passed"], rec["failed"], rec["skipped"], rec["gnuradio"]))
 P

@@ -61,7 +61,20 @@
 #ifndef INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 #define INCLUDED_IEEE80211_C8P_GR_ADAPTER_H
 
+// SAFE MODE — the part of this header a first run against an untried GNU Radio should rely on.  Everything in the audit list that the
+// reference does NOT use (custom buffers, the walk over the readers of an edge, _post) can be left out:
+//   at run time   C8P_GR_SAFE=1 in the environment: the io_signatures name default buffers, the fronts stage items through their own pinned
+//                 copies, the edge demod -> decode carries every item value and every reference tag (plain mode), no timer thread — the
+//                 members marked (*) below are compiled in but never called;
+//   at build time -DC8P_GR_STOCK_API_ONLY (cmake -DC8P_STOCK_API_ONLY=ON): the same, and those members are not even compiled — what is
+//                 left is gr::block, io_signature::make(min, max, size), tags, messages and PMTs exactly as the reference's blocks use them.
+// Without either, a port whose buffer turns out NOT to be one of the module's pinned buffers (the pointer general_work is handed is
+// checked against the buffers c8p_pinned_buffer has allocated) is treated as an ordinary buffer, and a reader walk that throws or finds
+// something unexpected answers "cannot tell", which means plain mode.
 #include <gnuradio/block.h>
+#if defined(C8P_GR_STOCK_API_ONLY) && !defined(C8P_GR_NO_TOPOLOGY)
+#define C8P_GR_NO_TOPOLOGY
+#endif
 #ifndef C8P_GR_NO_TOPOLOGY
 #include <gnuradio/block_detail.h>
 #include <gnuradio/buffer.h>
@@ -77,10 +90,39 @@
 #include <vector>
 
 #include "c8p_blocks.h"
+#ifndef C8P_GR_STOCK_API_ONLY
 #include "c8p_pinned_buffer.h"
+#endif
 
 namespace gr {
 namespace ieee80211 {
+
+// true: nothing beyond the reference's own use of GNU Radio (see SAFE MODE above)
+inline bool c8p_gr_safe()
+{
+#ifdef C8P_GR_STOCK_API_ONLY
+  return true;
+#else
+  return c8p::batching_cfg::safe_mode();
+#endif
+}
+// the io_signature of n stream ports of `item` bytes: the module's pinned buffer type, or GNU Radio's default in safe mode
+inline gr::io_signature::sptr c8p_stream_sig(int n, size_t item)
+{
+#ifndef C8P_GR_STOCK_API_ONLY
+  if (!c8p_gr_safe()) return gr::io_signature::make(n, n, (int)item, c8p_pinned_buffer::type);
+#endif
+  return gr::io_signature::make(n, n, (int)item);
+}
+// the cfg a block of this module hands its front
+inline c8p::batching_cfg c8p_gr_cfg()
+{
+  c8p::batching_cfg cfg;                 // (its defaults are the safe ones under C8P_GR_SAFE=1)
+#ifdef C8P_GR_STOCK_API_ONLY
+  cfg.fused = cfg.fused_auto = cfg.pinned_io = cfg.defer_consume = cfg.llr_handle = cfg.flush_when_idle = false;
+#endif
+  return cfg;
+}
 
 template <class API>
 class c8p_gr_block : public API, private c8p::block_io
@@ -90,8 +132,11 @@ public:
   {
     this->set_tag_propagation_policy(gr::block::TPP_DONT);          // demod_impl.cc:44, decode_impl.cc:41
     // wake(): a message to a port of its own is how a block gets its scheduler thread to run when no stream item arrives
-    this->message_port_register_in(pmt::mp("c8p_tick"));
-    this->set_msg_handler(pmt::mp("c8p_tick"), [](pmt::pmt_t) {});
+    // (safe mode: no timer thread, nobody to wake, no extra port on the block)
+    if (!c8p_gr_safe()) {
+      this->message_port_register_in(pmt::mp("c8p_tick"));
+      this->set_msg_handler(pmt::mp("c8p_tick"), [](pmt::pmt_t) {});
+    }
   }
 
   // gr::block
@@ -99,7 +144,10 @@ public:
   int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                    gr_vector_void_star& output_items) override
   {
-    return d_front->general_work(noutput_items, ninput_items, input_items, output_items);
+    d_in_now = &input_items; d_out_now = &output_items;             // (input_is_pinned / output_is_pinned look at the pointers)
+    const int produced = d_front->general_work(noutput_items, ninput_items, input_items, output_items);
+    d_in_now = nullptr; d_out_now = nullptr;
+    return produced;
   }
   // a finite flowgraph (file source) stops once the input is consumed: whatever the front still holds goes out now
   bool stop() override { d_front->flush(); return gr::block::stop(); }
@@ -164,14 +212,39 @@ private:
 
   // the front's latency timer collected results while no input was arriving: after the (empty) handler the scheduler thread
   // evaluates forecast() — which asks for no input while results wait for output space — and calls general_work()
-  void wake() override { this->_post(pmt::mp("c8p_tick"), pmt::PMT_T); }
+#ifdef C8P_GR_STOCK_API_ONLY
+  void wake() override {}
+  bool input_is_pinned(unsigned) override { return false; }
+  bool output_is_pinned(unsigned) override { return false; }
+  size_t input_buffer_bytes(unsigned) override { return 0; }
+#else
+  void wake() override { if (!c8p_gr_safe()) this->_post(pmt::mp("c8p_tick"), pmt::PMT_T); }      // (*)
 
   // custom buffers (c8p_pinned_buffer.h): the scheduler allocated this port's buffer through the module's buffer type when the
-  // io_signature names it — which the impl classes' constructors do; a flowgraph that overrides it gets pageable staging back
-  bool input_is_pinned(unsigned port) override { return this->input_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
-  bool output_is_pinned(unsigned port) override { return this->output_signature()->stream_buffer_type(port) == c8p_pinned_buffer::type; }
+  // io_signature names it — which the impl classes' constructors do — AND the pointer this call was handed lies in a buffer that type
+  // has allocated (the fronts ask during general_work): a flowgraph that overrides the type, or a scheduler that did not honour it,
+  // gets pageable staging back instead of a device read of memory the device cannot see
+  bool port_is_pinned(gr::io_signature::sptr sig, unsigned port, const void* now)                  // (*)
+  {
+    if (c8p_gr_safe() || !(sig->stream_buffer_type(port) == c8p_pinned_buffer::type)) return false;
+    if (now && !c8p_pinned_buffer::owns(now)) {
+      if (!d_warned) std::cerr << "ieee80211 (c8p): a port's io_signature names the pinned buffer type but its items are not in one: staged copies" << std::endl;
+      d_warned = true;
+      return false;
+    }
+    return true;
+  }
+  bool input_is_pinned(unsigned port) override
+  {
+    return port_is_pinned(this->input_signature(), port, d_in_now && port < d_in_now->size() ? (*d_in_now)[port] : nullptr);
+  }
+  bool output_is_pinned(unsigned port) override
+  {
+    return port_is_pinned(this->output_signature(), port, d_out_now && port < d_out_now->size() ? (*d_out_now)[port] : nullptr);
+  }
   // what c8p_pinned_buffer::make_buffer allocates at least: megabytes, so the fronts gather (c8p_blocks.h: C8P_GATHER_MIN_BUFFER)
   size_t input_buffer_bytes(unsigned port) override { return input_is_pinned(port) ? (size_t)C8P_PINNED_BUFFER_MIN_BYTES : 0; }
+#endif
 
   // Who reads this output port (c8p::block_io::output_feeds_only_decode)?  The edge's buffer must have ONE reader, this module's decode
   // block, for a demod front to run fused by default (c8p::batching_cfg::fused_auto): nothing else ever looks at the LLR item values
@@ -182,6 +255,7 @@ private:
     (void)port;
     return -1;
 #else
+    if (c8p_gr_safe()) return -1;
     try {
       gr::block_detail_sptr d = this->detail();
       if (!d || (int)port >= d->noutputs()) return -1;
@@ -198,6 +272,9 @@ private:
   }
 
   std::shared_ptr<c8p::c8p_block> d_front;
+  const gr_vector_const_void_star* d_in_now = nullptr;     // the pointers of the general_work call in progress
+  const gr_vector_void_star* d_out_now = nullptr;
+  bool d_warned = false;
 };
 
 } // namespace ieee80211

@@ -14,8 +14,9 @@
 // A single-mapped buffer RELOCATES unread items when a reader or the writer is blocked at its end, and the fronts keep gathers under
 // way on items they have cut and not consumed yet (batching_cfg::defer_consume: consuming them two calls later is worth 25 % of the
 // fused chain's rate, 690-716 k against 546-559 k packets/s) and scatters on LLR items they have placed and not reported yet.  So both
-// blocked callbacks first ANNOUNCE the move (c8p::buffer_will_move: every front of the process waits for the copies it has under way
-// on this buffer's memory — rare: once per trip round a 16 MB buffer) and only then let the base class move anything.  What a front
+// blocked callbacks first ANNOUNCE the move (c8p::buffer_move_scope: every front of the process waits for the copies it has under way
+// on this buffer's memory — rare: once per trip round a 16 MB buffer — and the items a demod front has placed ahead of the write
+// position are carried along) and only then let the base class move anything.  What a front
 // has cut lives in its batch's device arena by then, and it counts in absolute items, not addresses: the move itself does not concern it.
 //
 // AUDIT LIST (continues the one in c8p_gr_adapter.h) — GNU Radio members used here, none of which the reference uses (it predates
@@ -41,8 +42,12 @@
 #include <gnuradio/buffer_single_mapped.h>
 #include <gnuradio/buffer_type.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <functional>
+#include <mutex>
+#include <vector>
 
 #include "c8p_blocks.h"
 #include "c8p_rx.h"
@@ -62,7 +67,21 @@ class c8p_pinned_buffer : public gr::buffer_single_mapped
 public:
   static gr::buffer_type type;
 
-  ~c8p_pinned_buffer() override { if (d_pinned) c8p_host_free(d_pinned); }
+  ~c8p_pinned_buffer() override
+  {
+    if (!d_pinned) return;
+    { std::lock_guard<std::mutex> g(reg_mu()); auto& r = reg(); r.erase(std::remove_if(r.begin(), r.end(), [this](const range& x) { return x.lo == (uintptr_t)d_pinned; }), r.end()); }
+    c8p_host_free(d_pinned);
+  }
+
+  // is `p` inside a buffer this type has allocated?  (the adapter checks the pointers general_work is handed before a front lets the
+  // device read or write them: an io_signature that names the type proves nothing about what the scheduler did with it)
+  static bool owns(const void* p)
+  {
+    std::lock_guard<std::mutex> g(reg_mu());
+    for (const range& x : reg()) if ((uintptr_t)p >= x.lo && (uintptr_t)p < x.hi) return true;
+    return false;
+  }
 
   // nothing to do after the writer's work(): the memory the writer wrote IS what the device reads
   void post_work(int /*nitems*/) override {}
@@ -72,21 +91,30 @@ public:
     d_pinned = static_cast<char*>(c8p_host_alloc((uint64_t)final_nitems * sizeof_item));
     if (!d_pinned) return false;
     d_base = d_pinned;
+    { std::lock_guard<std::mutex> g(reg_mu()); reg().push_back(range{(uintptr_t)d_pinned, (uintptr_t)d_pinned + final_nitems * sizeof_item}); }
     return true;
   }
 
   void* write_pointer() override { return &d_base[d_write_index * d_sizeof_item]; }
   const void* _read_pointer(unsigned int read_index) override { return &d_base[read_index * d_sizeof_item]; }
 
+  // Both callbacks may change d_write_index (input: += the blocked reader's gap; output: back by the smallest read index).  A demod
+  // front in plain mode has LLR items placed AHEAD of d_write_index (the device writes them before produce() reports them): the scope
+  // waits for them, saves them, and puts them back at the new write position (c8p_blocks.h, buffer_move_scope) — the base class moves
+  // only what has been produced.  A front that still finds its output space somewhere else throws instead of reporting garbage.
   bool input_blocked_callback(int items_required, int items_avail, unsigned read_index) override
   {
-    c8p::buffer_will_move(d_base, (size_t)d_bufsize * d_sizeof_item);
-    return input_blocked_callback_logic(items_required, items_avail, read_index, d_base, mem_copy, mem_move);
+    c8p::buffer_move_scope mv(d_base, (size_t)d_bufsize * d_sizeof_item);
+    const bool moved = input_blocked_callback_logic(items_required, items_avail, read_index, d_base, mem_copy, mem_move);
+    mv.moved_to(write_pointer());
+    return moved;
   }
   bool output_blocked_callback(int output_multiple, bool force) override
   {
-    c8p::buffer_will_move(d_base, (size_t)d_bufsize * d_sizeof_item);
-    return output_blocked_callback_logic(output_multiple, force, d_base, mem_move);
+    c8p::buffer_move_scope mv(d_base, (size_t)d_bufsize * d_sizeof_item);
+    const bool moved = output_blocked_callback_logic(output_multiple, force, d_base, mem_move);
+    mv.moved_to(write_pointer());
+    return moved;
   }
 
   // the factory gr::buffer_type carries (gnuradio/buffer_type.h: factory_func_ptr)
@@ -108,6 +136,9 @@ private:
       : gr::buffer_single_mapped(nitems, sizeof_item, downstream_lcm_nitems, downstream_max_out_mult, link, buf_owner)
   {
   }
+  struct range { uintptr_t lo, hi; };
+  static std::vector<range>& reg() { static std::vector<range> r; return r; }
+  static std::mutex& reg_mu() { static std::mutex m; return m; }
   static void* mem_copy(void* d, const void* s, std::size_t n) { return std::memcpy(d, s, n); }
   static void* mem_move(void* d, const void* s, std::size_t n) { return std::memmove(d, s, n); }
   char* d_pinned = nullptr;

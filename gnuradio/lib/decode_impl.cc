@@ -6,11 +6,11 @@ namespace ieee80211 {
 decode::sptr decode::make(bool ifdebug) { return gnuradio::make_block_sptr<decode_impl>(ifdebug); }
 
 decode_impl::decode_impl(bool ifdebug)
-    : gr::block("decode", gr::io_signature::make(1, 1, sizeof(float), c8p_pinned_buffer::type), gr::io_signature::make(0, 0, 0)),
-      c8p_gr_block<decode>("decode", gr::io_signature::make(1, 1, sizeof(float), c8p_pinned_buffer::type), gr::io_signature::make(0, 0, 0))
+    : gr::block("decode", c8p_stream_sig(1, sizeof(float)), gr::io_signature::make(0, 0, 0)),            // decode_impl.cc:35-38
+      c8p_gr_block<decode>("decode", c8p_stream_sig(1, sizeof(float)), gr::io_signature::make(0, 0, 0))
 {
   message_port_register_out(pmt::mp("out"));     // decode_impl.cc:39
-  c8p::batching_cfg cfg;
+  c8p::batching_cfg cfg = c8p_gr_cfg();
   attach(c8p::decode::make(ifdebug, c8p::default_c8p_api(), cfg));
 }
 

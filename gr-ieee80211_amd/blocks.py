@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libc8p_blocks.so")
-ENGINE_LIB = os.path.join(_HERE, "libc8p_rx.so")
+# (C8P_LIB: another build of the same library, as in engine.py — A/B runs; still no fallback)
+ENGINE_LIB = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 _LIB = None
 
 DEMOD, DEMOD2, DECODE, SIGNAL, SIGNAL2, DETECT = 0, 1, 2, 3, 4, 5
@@ -39,6 +40,8 @@ def lib():
         L.c8ph_create_ex2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.c8ph_set_poison.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_set_relocate.argtypes = [C.c_void_p, C.c_int]
+        L.c8ph_set_move_out.argtypes = [C.c_void_p, C.c_int]
+        L.c8ph_moves_done.argtypes = [C.c_void_p]; L.c8ph_moves_done.restype = C.c_long
         L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_output_pinned.argtypes = [C.c_void_p]
         L.c8ph_fused_state.argtypes = [C.c_void_p]
@@ -159,6 +162,15 @@ class Block:
         """every n-th general_work call of run() finds the unread items of its pinned input buffers moved to other memory (announced with
         c8p::buffer_will_move, the old memory overwritten): what a single-mapped GNU Radio buffer does at its end.  0: never"""
         self.L.c8ph_set_relocate(self.h, int(every))
+
+    def set_move_out(self, every):
+        """every n-th general_work call of run() finds its output position moved somewhere else in the output buffer WITHOUT the items
+        placed ahead being drained first (output_ahead), the move bracketed by c8p::buffer_move_scope and everything else in the buffer
+        overwritten: what GNU Radio's single-mapped buffers do from their blocked callbacks (gnuradio/lib/c8p_pinned_buffer.h).  0: never"""
+        self.L.c8ph_set_move_out(self.h, int(every))
+
+    def moves_done(self):
+        return int(self.L.c8ph_moves_done(self.h))
 
     def input_pinned(self, port=0):
         return bool(self.L.c8ph_input_pinned(self.h, port))

@@ -256,17 +256,27 @@ struct c8p_ctx {
   hipEvent_t copy_ev[64] = {};
   uint64_t copy_marks = 0;
   hipStream_t out_stream = nullptr;                  // c8p_copy_gather with C8P_PIECE_TO_HOST pieces: device -> host, the link's other direction
-  hipEvent_t out_ev[64] = {};                        // ... what a mark records there (only while out_dirty)
-  bool out_ev_valid[64] = {};
-  bool out_dirty = false;                            // something was enqueued on out_stream since the last mark
+  // ... what a mark records there, when something was enqueued there since the last mark (out_dirty, set AFTER the launch); out_of[k]:
+  // what mark k waits for on that stream — its own event, or the newest one an earlier mark recorded (out_last): a mark covers
+  // everything enqueued before it on all three streams, whichever mark recorded it
+  hipEvent_t out_ev[64] = {};
+  hipEvent_t out_of[64] = {};
+  hipEvent_t out_last = nullptr;
+  bool out_dirty = false;
+  // (every record there has a generation number; a waiter that has seen generation g complete never asks about g or older again: the
+  // inherited events are usually long done, and a query costs a microsecond or two thousands of times a second)
+  uint64_t out_gen = 0, out_done_gen = 0, b_gen = 0, b_done_gen = 0;
+  uint64_t out_of_gen[64] = {}, b_of_gen[64] = {};
   hipEvent_t ev_fence = nullptr;                     // c8p_copy_fence: what the next submit's stream waits for
   bool fence_pending = false;
   // C8P_PIECE_UNORDERED gathers alternate between the copy stream and this twin of it (same CU mask): gather k + 1 is launched and
   // ramps up while gather k drains, instead of starting when it has finished.  Marks, fences and waits cover both.
   hipStream_t copy_stream_b = nullptr;
   hipEvent_t b_ev[64] = {};
-  bool b_ev_valid[64] = {};
-  bool b_dirty = false, b_fence_dirty = false, b_next = false;
+  hipEvent_t b_of[64] = {};
+  hipEvent_t b_last = nullptr;
+  bool b_dirty = false, b_next = false;
+  hipEvent_t ev_async_b = nullptr;                   // c8p_copy_async: the copy stream behind its twin
   hipEvent_t ev_fence_b = nullptr;
   bool fence_b_pending = false;
   uint32_t copy_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -399,6 +409,7 @@ extern "C" void c8p_destroy(c8p_ctx* c)
   if (c->copy_stream_b) { (void)hipStreamSynchronize(c->copy_stream_b); (void)hipStreamDestroy(c->copy_stream_b); }
   for (hipEvent_t e : c->b_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_fence_b) (void)hipEventDestroy(c->ev_fence_b);
+  if (c->ev_async_b) (void)hipEventDestroy(c->ev_async_b);
   if (c->span_stream) { (void)hipStreamSynchronize(c->span_stream); (void)hipStreamDestroy(c->span_stream); }
   if (c->ev_before_spans) (void)hipEventDestroy(c->ev_before_spans);
   if (c->ev_spans) (void)hipEventDestroy(c->ev_spans);
@@ -1711,6 +1722,10 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
       if (hipExtStreamCreateWithCUMask(&c->out_stream, 8, all) != hipSuccess) { (void)hipGetLastError(); c->out_stream = nullptr; }
     }
     if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+    // the copy stream's twin (same CU mask) with the others, not at the first unordered gather: c8p_dev_free on another thread reads the
+    // handle without the lock, and marks / fences / c8p_copy_async record on it every time
+    if (c->copy_cus) { if (hipExtStreamCreateWithCUMask(&c->copy_stream_b, 8, c->copy_mask) != hipSuccess) { (void)hipGetLastError(); c->copy_stream_b = nullptr; } }
+    if (!c->copy_stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream_b, hipStreamNonBlocking));
   }
   return C8P_OK;
 }
@@ -1726,41 +1741,64 @@ extern "C" uint64_t c8p_copy_mark(c8p_ctx* c)
   }
   if (hipEventRecord(e, c->copy_stream) != hipSuccess) return 0;
   const size_t slot = c->copy_marks % 64;
-  c->out_ev_valid[slot] = false;
-  if (c->out_dirty) {                          // ... and what went the other way (its own stream)
+  // ... and what went the other way (its own stream), and the unordered gathers on the copy stream's twin: recorded when something was
+  // enqueued there since the last mark; a mark that records nothing there still WAITS for the newest event an earlier mark recorded
+  // (out_of / b_of) — a mark covers everything enqueued before it on any of the three streams, which is what the callers assume
+  // (gather_lane::wait_range waits for the newest overlapping mark only).  Round 5 forgot the earlier events: waiting for mark M2 (a
+  // gather on the copy stream) did not wait for M1's gather on the twin.  Recording on all three streams at every mark
+  // instead costs the block chain 10-20 % of its rate (profiles/r6a/README.txt): three records and up to three queries per mark.
+  if (c->out_dirty) {
     hipEvent_t& eo = c->out_ev[slot];
     if (!eo && hipEventCreateWithFlags(&eo, hipEventDisableTiming) != hipSuccess) return 0;
     if (hipEventRecord(eo, c->out_stream) != hipSuccess) return 0;
-    c->out_ev_valid[slot] = true;
+    c->out_last = eo;
     c->out_dirty = false;
+    c->out_gen++;
   }
-  c->b_ev_valid[slot] = false;
-  if (c->b_dirty) {                            // ... and the unordered gathers that went to the copy stream's twin
+  c->out_of[slot] = c->out_last; c->out_of_gen[slot] = c->out_gen;
+  if (c->b_dirty) {
     hipEvent_t& eb = c->b_ev[slot];
     if (!eb && hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) return 0;
     if (hipEventRecord(eb, c->copy_stream_b) != hipSuccess) return 0;
-    c->b_ev_valid[slot] = true;
+    c->b_last = eb;
     c->b_dirty = false;
+    c->b_gen++;
   }
+  c->b_of[slot] = c->b_last; c->b_of_gen[slot] = c->b_gen;
   return ++c->copy_marks;
+}
+// the events mark `mark` stands for: the copy stream's own, and — unless a waiter has already seen that generation complete — the newest
+// ones of the device -> host stream and of the copy stream's twin at the time of the mark
+struct MarkEvents { hipEvent_t e = nullptr, eo = nullptr, eb = nullptr; uint64_t go = 0, gb = 0; };
+static bool mark_events(c8p_ctx* c, uint64_t mark, MarkEvents& m)
+{
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  if (mark > c->copy_marks) return false;
+  const size_t k = (mark - 1) % 64;
+  m.e = c->copy_ev[k];                          // (re-recorded by a later mark if 64 marks have passed: a later point of the same stream)
+  m.go = c->out_of_gen[k]; m.gb = c->b_of_gen[k];
+  if (m.go > c->out_done_gen) m.eo = c->out_of[k];
+  if (m.gb > c->b_done_gen) m.eb = c->b_of[k];
+  return true;
+}
+static void mark_seen_done(c8p_ctx* c, const MarkEvents& m, bool o_done, bool b_done)
+{
+  if (!(o_done && m.eo) && !(b_done && m.eb)) return;
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  if (o_done && m.eo) c->out_done_gen = std::max(c->out_done_gen, m.go);
+  if (b_done && m.eb) c->b_done_gen = std::max(c->b_done_gen, m.gb);
 }
 extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
 {
   if (!c) return C8P_EINVAL;
   if (mark == 0) return c8p_copy_wait(c);
   if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
-  hipEvent_t e = nullptr, eo = nullptr, eb = nullptr;
-  {
-    std::lock_guard<std::mutex> g(c->copy_mu);
-    if (mark > c->copy_marks) return C8P_EINVAL;
-    e = c->copy_ev[(mark - 1) % 64];            // (re-recorded by a later mark if 64 marks have passed: a later point of the same stream)
-    if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
-    if (c->b_ev_valid[(mark - 1) % 64]) eb = c->b_ev[(mark - 1) % 64];
-  }
+  MarkEvents m;
+  if (!mark_events(c, mark, m)) return C8P_EINVAL;
   // a short wait is spun out on the event's state before hipEventSynchronize (which may put the thread to sleep on the signal's
   // interrupt) is asked: the block fronts wait 20-50 us for a gather, thousands of times a second (profiles/r5q/gather_waits.txt: the
   // waits themselves did not get shorter — what is waited for is the gather)
-  for (hipEvent_t ev : {e, eb, eo}) {
+  for (hipEvent_t ev : {m.e, m.eb, m.eo}) {
     if (!ev) continue;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t q;
@@ -1773,34 +1811,41 @@ extern "C" int c8p_copy_wait_mark(c8p_ctx* c, uint64_t mark)
     if (spun) (void)hipGetLastError();            // ("not ready" must not be what the thread's next hipGetLastError finds)
     if (q != hipSuccess) { (void)hipGetLastError(); return C8P_EHIP; }
   }
+  mark_seen_done(c, m, true, true);
   return C8P_OK;
 }
 extern "C" int c8p_copy_mark_done(c8p_ctx* c, uint64_t mark)
 {
   if (!c || mark == 0) return C8P_EINVAL;
   if (hipSetDevice(c->device) != hipSuccess) return C8P_EHIP;
-  hipEvent_t e = nullptr, eo = nullptr, eb = nullptr;
-  {
-    std::lock_guard<std::mutex> g(c->copy_mu);
-    if (mark > c->copy_marks) return C8P_EINVAL;
-    e = c->copy_ev[(mark - 1) % 64];
-    if (c->out_ev_valid[(mark - 1) % 64]) eo = c->out_ev[(mark - 1) % 64];
-    if (c->b_ev_valid[(mark - 1) % 64]) eb = c->b_ev[(mark - 1) % 64];
-  }
-  for (hipEvent_t ev : {e, eb, eo}) {
+  MarkEvents m;
+  if (!mark_events(c, mark, m)) return C8P_EINVAL;
+  bool o_done = false, b_done = false;
+  int res = 1;
+  for (hipEvent_t ev : {m.eb, m.eo, m.e}) {
     if (!ev) continue;
     const hipError_t q = hipEventQuery(ev);
-    if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); res = 0; break; }
     if (q != hipSuccess) { (void)hipGetLastError(); return C8P_EHIP; }
+    if (ev == m.eb) b_done = true;
+    if (ev == m.eo) o_done = true;
   }
-  return 1;
+  mark_seen_done(c, m, o_done, b_done);
+  return res;
 }
 extern "C" int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes)
 {
   if (!c || (bytes && (!dst || !src))) return C8P_EINVAL;
   int rc;
   if ((rc = copy_stream_of(c)) != C8P_OK) return rc;
-  if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->copy_stream));
+  if (!bytes) return C8P_OK;
+  // behind every gather enqueued so far, on EITHER copy stream: unordered gathers alternate between the copy stream and its twin, and what
+  // this call moves (the block fronts: a partly received packet, device to device) may have been written by one on the twin
+  std::lock_guard<std::mutex> g(c->copy_mu);
+  if (!c->ev_async_b) HIPCHK(c, hipEventCreateWithFlags(&c->ev_async_b, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_async_b, c->copy_stream_b));
+  HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_async_b, 0));
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->copy_stream));
   return C8P_OK;
 }
 // a wave = one chunk of 512 items of one span: the span table is searched once per wave (a uniform walk), then every lane has eight
@@ -2062,15 +2107,9 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   bool on_b = false;
   if (unordered) {
     std::lock_guard<std::mutex> g(c->copy_mu);
-    if (!c->copy_stream_b) {
-      if (c->copy_cus) { if (hipExtStreamCreateWithCUMask(&c->copy_stream_b, 8, c->copy_mask) != hipSuccess) { (void)hipGetLastError(); c->copy_stream_b = nullptr; } }
-      if (!c->copy_stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream_b, hipStreamNonBlocking));
-    }
     on_b = c->b_next;
     c->b_next = !c->b_next;
-    if (on_b) c->b_dirty = c->b_fence_dirty = true;
   }
-  if (to_host) { std::lock_guard<std::mutex> g(c->copy_mu); c->out_dirty = true; }
   const hipStream_t gst = to_host ? c->out_stream : on_b ? c->copy_stream_b : c->copy_stream;
   PieceTab itab;
   PieceDev* hp = itab.p;
@@ -2124,6 +2163,12 @@ extern "C" int c8p_copy_gather(c8p_ctx* c, c8p_c32* dst, const c8p_piece* pieces
   if (total[1]) hipLaunchKernelGGL(k_copy_gather_q<4>, grid(total[1], C8P_GATHER_WGS), dim3(256), 0, gst, (cf*)dst, inl ? nullptr : dp + first_of[1], sub(1), cnt[1], total[1]);
   if (total[2]) hipLaunchKernelGGL(k_copy_gather_q<2>, grid(total[2], C8P_GATHER_WGS / 4), dim3(256), 0, gst, (cf*)dst, inl ? nullptr : dp + first_of[2], sub(2), cnt[2], total[2]);
   if (total[3]) hipLaunchKernelGGL(k_copy_gather_w, grid(total[3], C8P_GATHER_WGS), dim3(256), 0, gst, (unsigned*)dst, inl ? nullptr : dp + first_of[3], sub(3), cnt[3], total[3]);
+  // the dirty bits AFTER the launches: a mark or fence on another thread that slips in between cannot clear a bit for work that is not
+  // on the stream yet (it would never be covered: ADVICE r5); at worst a later mark records once more than it had to
+  if (to_host || on_b) {
+    std::lock_guard<std::mutex> g(c->copy_mu);
+    if (to_host) c->out_dirty = true; else c->b_dirty = true;
+  }
   HIPCHK(c, hipGetLastError());
   return C8P_OK;
 }
@@ -2186,12 +2231,9 @@ extern "C" int c8p_copy_fence(c8p_ctx* c)
   }
   HIPCHK(c, hipEventRecord(c->ev_fence, c->copy_stream));
   c->fence_pending = true;
-  if (c->b_fence_dirty) {
-    if (!c->ev_fence_b) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence_b, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_fence_b, c->copy_stream_b));
-    c->fence_b_pending = true;
-    c->b_fence_dirty = false;
-  }
+  if (!c->ev_fence_b) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence_b, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_fence_b, c->copy_stream_b));      // (the twin as well, every time)
+  c->fence_b_pending = true;
   return C8P_OK;
 }
 extern "C" int c8p_copy_wait(c8p_ctx* c)

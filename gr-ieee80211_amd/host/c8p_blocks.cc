@@ -87,15 +87,21 @@ int batching_cfg::default_max_wait_us()
   return e && atoi(e) > 0 ? atoi(e) : 1000;
 }
 
+bool batching_cfg::safe_mode()
+{
+  const char* e = getenv("C8P_GR_SAFE");
+  return e && e[0] == '1';
+}
+bool batching_cfg::default_flush_when_idle() { return !safe_mode(); }
 bool batching_cfg::default_fused()
 {
   const char* e = getenv("C8P_FUSED");
-  return e && e[0] == '1';
+  return !safe_mode() && e && e[0] == '1';
 }
 bool batching_cfg::default_fused_auto()
 {
   const char* e = getenv("C8P_FUSED");
-  return !e || !*e || !strcmp(e, "auto");
+  return !safe_mode() && (!e || !*e || !strcmp(e, "auto"));
 }
 bool batching_cfg::default_fused_lean_tags()
 {
@@ -105,7 +111,7 @@ bool batching_cfg::default_fused_lean_tags()
 bool batching_cfg::default_pinned_io()
 {
   const char* e = getenv("C8P_PINNED_IO");
-  return !(e && e[0] == '0');
+  return !safe_mode() && !(e && e[0] == '0');
 }
 // C8P_GATHER_MIN_BUFFER in the environment overrides the header's threshold (bytes; 0: always gather out of a pinned buffer — the tests)
 static size_t gather_min_buffer()
@@ -138,15 +144,33 @@ void buffer_will_move(const void* base, size_t bytes)
   std::lock_guard<std::mutex> g(g_fronts_mu);           // (a front leaves the list before anything of it is destroyed)
   for (c8p_block* b : g_fronts) b->quiesce(base, bytes);
 }
+// (g_fronts_mu stays held from the constructor to the destructor: no front is created or destroyed while a buffer moves; a front's
+// own mutex is taken inside move_begin — the order is always g_fronts_mu, then the front's)
+buffer_move_scope::buffer_move_scope(const void* base, size_t bytes)
+{
+  g_fronts_mu.lock();
+  for (c8p_block* b : g_fronts) if (b->move_begin(base, bytes)) d_held.push_back(b);
+}
+void buffer_move_scope::moved_to(void* new_write_ptr)
+{
+  if (d_done) return;
+  d_done = true;
+  for (c8p_block* b : d_held) b->move_end(new_write_ptr);
+}
+buffer_move_scope::~buffer_move_scope()
+{
+  if (!d_done) for (c8p_block* b : d_held) b->move_end(nullptr);
+  g_fronts_mu.unlock();
+}
 bool batching_cfg::default_llr_handle()
 {
   const char* e = getenv("C8P_LLR_HANDLE");
-  return !(e && e[0] == '0');
+  return !safe_mode() && !(e && e[0] == '0');
 }
 bool batching_cfg::default_defer_consume()
 {
   const char* e = getenv("C8P_DEFER_CONSUME");
-  return !(e && e[0] == '0');
+  return !safe_mode() && !(e && e[0] == '0');
 }
 
 // growable array in pinned host memory (uninitialised growth: no zero fill of tens of megabytes per batch).  Holds the allocator's two
@@ -616,6 +640,35 @@ public:
       if (it->lo < hi && lo < it->hi) { d_eng.check(d_eng.d_api.copy_wait_mark(d_eng.d_ctx, it->mark), "c8p_copy_wait_mark"); break; }
   }
 
+  // a buffer moves (c8p_blocks.h, buffer_move_scope): the input side as quiesce(); items placed ahead in an output buffer that lies in
+  // the range are waited for — every launch that writes them — and saved, and d_mu stays held until move_end has put them back
+  bool move_begin(const void* base, size_t bytes) override
+  {
+    d_mu.lock();
+    bool held = false;
+    try {
+      d_lane.wait_range(d_eng, base, bytes);
+      const uintptr_t lo = (uintptr_t)base, hi = lo + bytes, at = (uintptr_t)d_ahead_ptr;
+      if (d_ready + d_inflight > 0 && d_ahead_ptr && at >= lo && at < hi) {
+        while (!d_scat.empty()) scatter_collect(true, 1);            // all of [0, d_ready) is in the buffer now
+        d_saved.assign(d_ahead_ptr, d_ahead_ptr + d_ready);
+        held = true;
+      }
+    } catch (...) { d_mu.unlock(); throw; }
+    if (!held) d_mu.unlock();
+    return held;
+  }
+  void move_end(void* new_write_ptr) override      // (d_mu is held: move_begin returned true)
+  {
+    if (new_write_ptr && new_write_ptr != (void*)d_ahead_ptr) {
+      memcpy(new_write_ptr, d_saved.data(), d_saved.size() * sizeof(float));
+      d_ahead_ptr = static_cast<float*>(new_write_ptr);
+      d_ahead_moves++;
+    }
+    d_saved.clear();
+    d_mu.unlock();
+  }
+
   std::string host_phase_us() override { std::lock_guard<std::mutex> g(d_mu); return d_ph.str(); }
   void host_phase_reset() override { std::lock_guard<std::mutex> g(d_mu); d_ph = phase_clock(); }
 
@@ -645,7 +698,15 @@ public:
     const uint64_t rd = d_io->nitems_read(0);
     // A pinned output buffer: the LLR items that are ready start moving — one kernel that writes them where the scheduler wants them —
     // and are REPORTED at the end of the call in which they have arrived (scatter_place / scatter_report)
-    if (d_out_dev) scatter_place(static_cast<float*>(output_items[0]), noutput_items);
+    if (d_out_dev) {
+      // items placed ahead sit where this call's space begins: a scheduler that moved its write position without saying so
+      // (buffer_move_scope, or calls that drain output_ahead first) would have this call report whatever lies here instead — say so
+      if (d_ready + d_inflight > 0 && d_ahead_ptr != static_cast<float*>(output_items[0]))
+        throw std::runtime_error("c8p_blocks: demod's output space moved while " + std::to_string(d_ready + d_inflight) +
+                                 " LLR items placed ahead of produce() were not reported (the buffer must bracket its moves with "
+                                 "c8p::buffer_move_scope, or call general_work(output_ahead()) until it is 0 first)");
+      scatter_place(static_cast<float*>(output_items[0]), noutput_items);
+    }
     int used = 0;
     if (d_in_dev) {                                // items cut by an earlier call whose gather had not been waited for: still here
       if (d_lane.scan_abs < rd) d_lane.scan_abs = rd;
@@ -724,7 +785,11 @@ public:
     d_io->consume_each(cons);
     // (the timer sleeps without a deadline while this front holds nothing: tell it when that may have changed — not on every call)
     if (!d_st[d_fill].pk.empty() || !d_fly.empty()) d_timer.poke();
-    if (d_out_dev) return scatter_report(noutput_items, cons > 0 || used > used_before);
+    if (d_out_dev) {
+      const int produced = scatter_report(noutput_items, cons > 0 || used > used_before);
+      d_ahead_ptr = static_cast<float*>(output_items[0]) + produced;     // where what is still ahead sits = where the next call's space begins
+      return produced;
+    }
     return drained;
   }
 
@@ -1198,6 +1263,9 @@ private:
   gather_lane d_lane;                              // pieces always belong to d_st[d_fill]
   std::vector<c8p_piece> d_opieces;
   size_t d_ready = 0, d_inflight = 0;              // scatter_place: items placed in the output buffer and not reported yet (complete / being written)
+  float* d_ahead_ptr = nullptr;                    // ... where they begin (the last call's output pointer + what it reported)
+  std::vector<float> d_saved;                      // move_begin .. move_end: the items ahead, while the buffer moves
+  long d_ahead_moves = 0;
   std::deque<scat_t> d_scat;                       // ... the launches that write them, oldest first
   std::vector<std::shared_ptr<result>> d_pool;
   std::vector<std::shared_ptr<fused_batch>> d_fpool;

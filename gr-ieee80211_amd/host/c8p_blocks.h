@@ -149,7 +149,15 @@ c8p_api default_c8p_api();
 struct batching_cfg {
   int max_batch = 256;          // packets per c8p_* call
   int detect_items = 1 << 20;   // detect: raw items gathered per c8p_detect call
-  bool flush_when_idle = true;  // submit a partial batch once its oldest packet has waited max_wait_us (bounds latency in a live
+  // SAFE MODE (environment C8P_GR_SAFE=1): a front that uses nothing of its scheduler beyond what the reference's own blocks use — no
+  // custom buffers (pinned_io off: items staged through the front's own pinned copies), no look at who reads the LLR edge (fused_auto
+  // off: plain mode, every item value and every reference tag on the edge), consume in the call that cut the items, no handle tags,
+  // no timer thread (flush_when_idle off: a partial batch goes out at the end of a general_work call that finds it old enough, and at
+  // stop()).  Every default below returns its safe value then, whatever the other switches say.  The GNU Radio adapters
+  // (gnuradio/lib/c8p_gr_adapter.h) name default buffers in their io_signatures in this mode; it is what a first run against an
+  // untried GNU Radio installation should use, and what -DC8P_GR_STOCK_API_ONLY builds compile in for good.
+  static bool safe_mode();
+  bool flush_when_idle = default_flush_when_idle();  // submit a partial batch once its oldest packet has waited max_wait_us (bounds latency in a live
                                 // flowgraph; a saturated one fills whole batches between two checks and is never cut short)
   int max_wait_us = default_max_wait_us();   // 1000, or the environment's C8P_MAX_WAIT_US; checked at the end of every general_work call AND by a timer thread of the front: the scheduler
                                 // never calls a block that has no input, and demod's input is bursty (signal emits items only
@@ -184,6 +192,7 @@ struct batching_cfg {
   // stream then crosses the link once (up) instead of twice.  Environment C8P_LLR_HANDLE=0 turns it off (decode gathers the items).
   bool llr_handle = default_llr_handle();
   static bool default_llr_handle();
+  static bool default_flush_when_idle();
   static bool default_fused();
   static bool default_fused_auto();
   static bool default_fused_lean_tags();
@@ -224,6 +233,12 @@ public:
   virtual int fused_state() { return -1; }
   // buffer_will_move (below): wait for every copy this block has under way that reads or writes [base, base + bytes)
   virtual void quiesce(const void* base, size_t bytes) {}
+  // buffer_move_scope (below): quiesce(), and when this block has output items placed ahead (output_ahead() > 0) INSIDE the range: keep
+  // its general_work out (the block's own mutex stays held), save those items, return true.  move_end (only after a true move_begin):
+  // the saved items go to `new_write_ptr` — where the buffer's write position is now, i.e. where the next call's output space begins —
+  // and general_work may run again.
+  virtual bool move_begin(const void* base, size_t bytes) { quiesce(base, bytes); return false; }
+  virtual void move_end(void* new_write_ptr) {}
   void set_io(block_io* io) { d_io = io; }
 
 protected:
@@ -238,6 +253,29 @@ protected:
 // what makes deferred consume safe on such a buffer.  The items themselves need no attention: what has been cut lives in the batch's
 // device arena, and a front counts in absolute items, not addresses.
 void buffer_will_move(const void* base, size_t bytes);
+
+// A buffer that moves its WRITE position without asking the writer first — GNU Radio's single-mapped custom buffers do, from either
+// blocked callback: input_blocked_callback_logic shifts [0, write) up by the reader's gap and sets d_write_index += gap,
+// output_blocked_callback_logic shifts the unread items down — would leave the items a demod front has placed AHEAD of the write position
+// (output_ahead) behind: the next call would report whatever lies at the new position.  The scope brackets the move:
+//     { c8p::buffer_move_scope mv(base, bytes);  ... the buffer moves its items and its write index ...;  mv.moved_to(write_pointer()); }
+// Its constructor does what buffer_will_move does (every front waits for its copies on the range) and, for the front that has items
+// ahead in the range, holds that front and saves them; moved_to puts them back at the new write position; the destructor lets the front
+// run again (without moved_to the items stay where they were: the buffer did not move).  gnuradio/lib/c8p_pinned_buffer.h uses it in both
+// callbacks; the mirror's harness has an edge of that kind to test it with (c8ph_run, C8P_MIRROR_MOVES).
+class buffer_move_scope
+{
+public:
+  buffer_move_scope(const void* base, size_t bytes);
+  void moved_to(void* new_write_ptr);
+  ~buffer_move_scope();
+  buffer_move_scope(const buffer_move_scope&) = delete;
+  buffer_move_scope& operator=(const buffer_move_scope&) = delete;
+
+private:
+  std::vector<c8p_block*> d_held;
+  bool d_done = false;
+};
 
 class demod : virtual public c8p_block
 {

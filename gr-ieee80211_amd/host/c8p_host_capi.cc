@@ -46,6 +46,11 @@ struct harness : public block_io {
   // != 0: every `relocate`-th call of c8ph_run finds the unread items of its pinned input buffers MOVED to other memory, as a single-mapped
   // GNU Radio buffer moves them when a reader is blocked at its end: buffer_will_move first, then the copy, then the old memory is overwritten
   int relocate = 0;
+  // != 0: every `move_out`-th call of c8ph_run finds its OUTPUT position moved the way GNU Radio's single-mapped buffers move it from
+  // their blocked callbacks — without draining output_ahead first: the move is bracketed by c8p::buffer_move_scope (what
+  // gnuradio/lib/c8p_pinned_buffer.h does), everything the scope has not saved is overwritten with NaNs
+  int move_out = 0;
+  long moves_done = 0;
   std::vector<std::pair<void*, bool>> graveyard; // ... the old buffers (kept to the end: a front that ignores the announcement reads 0xff, not freed memory)
   void relocate_inputs()
   {
@@ -185,7 +190,7 @@ void* c8ph_create_ex2(int kind, int mupos, int ifdebug, const char* lib, int max
   try {
     harness* h = new harness();
     c8p_api api = load_c8p_api(lib);
-    batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0;
+    batching_cfg cfg; cfg.max_batch = max_batch; cfg.flush_when_idle = flush_idle != 0 && !batching_cfg::safe_mode();
     if (fused >= 0) { cfg.fused = fused != 0; cfg.fused_auto = false; }      // (said explicitly: nothing left to decide from the flowgraph)
     if (pinned_io >= 0) cfg.pinned_io = pinned_io != 0;
     if (defer_consume >= 0) cfg.defer_consume = defer_consume != 0;
@@ -265,6 +270,9 @@ void c8ph_set_jitter(void* p, unsigned long long seed) { static_cast<harness*>(p
 void c8ph_set_poison(void* p, int on) { static_cast<harness*>(p)->poison = on != 0; }
 // every n-th call of c8ph_run finds its pinned input buffers relocated (harness::relocate); 0: never
 void c8ph_set_relocate(void* p, int every) { static_cast<harness*>(p)->relocate = every > 0 ? every : 0; }
+// every n-th call of c8ph_run finds its output position moved under a c8p::buffer_move_scope (harness::move_out); 0: never
+void c8ph_set_move_out(void* p, int every) { static_cast<harness*>(p)->move_out = every > 0 ? every : 0; }
+long c8ph_moves_done(void* p) { return static_cast<harness*>(p)->moves_done; }
 int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->input_is_pinned((unsigned)port) ? 1 : 0; }
 int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
 // c8p_block::fused_state: 1 / 0 = the demod front runs fused / plain, -1 = not decided yet (no general_work call so far) or no demod
@@ -284,6 +292,10 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
     // beyond what it reported: c8p_block::output_ahead); at the end of the buffer the block is first asked for exactly those items
     const size_t ocap = (size_t)std::max(nout, 1) * fpi * 4;
     harness::obuf_t ob0(h, ocap), ob1(h, ocap);
+    // (however this function is left — a block that throws has launches under way that write into ob0 — they are waited for before
+    // the buffer is freed)
+    struct out_guard { float* p; size_t bytes; ~out_guard() { try { buffer_will_move(p, bytes); } catch (...) {} } } og{ob0.p, ocap * sizeof(float)};
+    (void)og;
     size_t wpos = 0;
     auto take = [&](int produced, const float* o0, const float* o1) {
       if (!h->capture) {
@@ -331,6 +343,21 @@ long c8ph_run(void* p, int chunk, int nout, int flush_at_end)
       if (h->relocate && calls % h->relocate == h->relocate - 1) h->relocate_inputs();
       gr_vector_const_void_star ins(h->nports);
       for (int q = 0; q < h->nports; q++) ins[q] = h->rd(q);
+      if (h->move_out && h->nout == 1 && calls % h->move_out == h->move_out - 1) {
+        // the write position jumps (to the start of the buffer, or a quarter in when it is there already) with items possibly placed ahead
+        const size_t ahead = (size_t)h->blk->output_ahead() * fpi;
+        const size_t to = wpos ? 0 : ocap / 4;
+        if (to + ahead + (size_t)std::max(nout, 1) * fpi <= ocap) {
+          if (getenv("C8P_TEST_UNBRACKETED_MOVE")) wpos = to;      // (a test: a mover that does not follow the protocol must be caught)
+          else {
+            buffer_move_scope mv(ob0.p, ocap * sizeof(float));
+            memset(ob0.p, 0xff, ocap * sizeof(float));              // what the scope has not saved is gone
+            wpos = to;
+            mv.moved_to(ob0.p + wpos);
+          }
+          h->moves_done++;
+        }
+      }
       wrap_if_needed(std::max(nout, 1));
       float* const obuf = ob0.p + wpos; float* const obuf1 = ob1.p + wpos;
       gr_vector_void_star outs(1, obuf);

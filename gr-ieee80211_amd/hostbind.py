@@ -54,6 +54,12 @@ def numa_node_of_pci(addr, sysfs="/sys"):
     if not addr:
         return None
     v = _read(os.path.join(sysfs, "bus", "pci", "devices", addr, "numa_node"))
+    if v is None and addr.endswith(".0"):         # (torch tells domain:bus:device, not the function: any function of the device will do)
+        import glob
+        for d in sorted(glob.glob(os.path.join(sysfs, "bus", "pci", "devices", addr[:-1] + "*"))):
+            v = _read(os.path.join(d, "numa_node"))
+            if v is not None:
+                break
     try:
         return int(v)
     except (TypeError, ValueError):
@@ -72,8 +78,12 @@ def _set_preferred_node(node):
     libc = ctypes.CDLL(None, use_errno=True)
     mask = (ctypes.c_ulong * 16)()
     mask[node // (8 * ctypes.sizeof(ctypes.c_ulong))] |= 1 << (node % (8 * ctypes.sizeof(ctypes.c_ulong)))
-    SYS_set_mempolicy = 238                                   # x86-64
-    rc = libc.syscall(SYS_set_mempolicy, _MPOL_PREFERRED, ctypes.byref(mask), 16 * 8 * ctypes.sizeof(ctypes.c_ulong))
+    # the syscall number is per architecture (238 is migrate_pages on aarch64): known machines only, anything else keeps its policy
+    import platform
+    nr = {"x86_64": 238, "amd64": 238, "aarch64": 237, "arm64": 237}.get(platform.machine().lower())
+    if nr is None:
+        return False
+    rc = libc.syscall(nr, _MPOL_PREFERRED, ctypes.byref(mask), 16 * 8 * ctypes.sizeof(ctypes.c_ulong))
     return rc == 0
 
 

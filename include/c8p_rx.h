@@ -531,7 +531,10 @@ typedef struct c8p_piece {
  * from enqueue to done whatever its size.  c8p_copy_mark / _wait_mark / _wait cover both streams. */
 #define C8P_PIECE_TO_HOST 1u
 /* c8p_piece.rsv, host -> device pieces (every piece of a call the same, up to C8P_GATHER_INLINE pieces): this call needs no order against the
- * ctx's other gathers — only marks, fences and waits, which cover it.  Such calls alternate between the copy stream and a twin of it: the
+ * ctx's other gathers — only marks, fences, waits and c8p_copy_async (which runs behind EVERY gather enqueued before it, on either
+ * stream: the block fronts move a partly received packet out of an arena such gathers fill), which cover it.  A mark covers everything
+ * enqueued before it on the copy stream, its twin and the device -> host stream, whichever earlier mark recorded it: waiting for the
+ * newest of several marks is enough.  Such calls alternate between the copy stream and a twin of it: the
  * next gather is launched and ramps up while this one drains (a stream starts a kernel when the one before it has finished:
  * 1.4 MB gathers back to back 29.9 -> 27.8 us apiece, 46.8 -> 50.3 GB/s, tools/probes/link_duplex.py).  Without the flag two gathers of one
  * ctx run in the order they were enqueued (the second may overwrite what the first wrote). */

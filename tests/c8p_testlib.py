@@ -19,6 +19,15 @@ CONSUMED = 224        # signal_impl.cc:154 — items consumed before the first i
 PAD = 320             # signal_impl.cc:194-202
 
 
+def bench_legs():
+    """tools/bench_legs.py as a module (bench.py's legs: sharded_stream, usable_cores, ...)"""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import bench_legs as m
+    return m
+
+
 def oracle():
     from oracle import oracle_py
     return oracle_py

@@ -254,22 +254,8 @@ static void run_pending(c8p_ctx* c)
   for (struct pend* q = rev; q; q = q->rnext) run_gather(q->dst, q->pc, q->n);
   while (p) { struct pend* nx = p->next; if (!p->unordered) run_gather(p->dst, p->pc, p->n); free(p->pc); free(p); p = nx; }
 }
-/* what a copy on the copy stream is ordered behind: the gathers of that stream — NOT the C8P_PIECE_UNORDERED ones, half of which run on
- * the stream's twin (they stay pending: a caller that moves an arena they fill must wait for them first) */
-static void run_pending_ordered(c8p_ctx* c)
-{
-  struct pend *p = c->pend_head, *keep_head = NULL, *keep_tail = NULL;
-  c->pend_head = c->pend_tail = NULL;
-  while (p) {
-    struct pend* nx = p->next;
-    p->next = NULL;
-    if (p->n > 0 && p->n <= C8P_GATHER_INLINE && (p->pc[0].rsv & C8P_PIECE_UNORDERED)) { if (keep_tail) keep_tail->next = p; else keep_head = p; keep_tail = p; }
-    else { run_gather(p->dst, p->pc, p->n); free(p->pc); free(p); }
-    p = nx;
-  }
-  c->pend_head = keep_head; c->pend_tail = keep_tail;
-}
-int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { run_pending_ordered(c); memmove(dst, src, bytes); return C8P_OK; }
+/* (round 6: c8p_copy_async is ordered behind the C8P_PIECE_UNORDERED gathers as well — include/c8p_rx.h) */
+int c8p_copy_async(c8p_ctx* c, void* dst, const void* src, uint64_t bytes) { run_pending(c); memmove(dst, src, bytes); return C8P_OK; }
 int c8p_copy_spans(c8p_ctx* c, c8p_c32* dst, const c8p_c32* src, const c8p_span* sp, int32_t n)
 {
   run_pending(c);

@@ -78,15 +78,17 @@ def test_bindings_and_adapters_keep_names_and_signatures():
     assert 'm, "demod2"' in bind["demod2"] and 'm, "decode"' in bind["decode"] and 'py::arg("ifdebug")' in bind["decode"]
     mod = open(os.path.join(GR, "python", "ieee80211", "bindings", "python_bindings.cc")).read()
     assert "PYBIND11_MODULE(ieee80211_python, m)" in mod
-    # the reference's ports (stream counts, item sizes); round 5: every stream port also names the module's buffer type (pinned host
-    # memory, gnuradio/lib/c8p_pinned_buffer.h) — the fourth argument of GNU Radio 3.10's io_signature::make
-    sig = {"demod": ("make(1, 1, sizeof(gr_complex), c8p_pinned_buffer::type)", "make(1, 1, sizeof(float), c8p_pinned_buffer::type)"),     # demod_impl.cc:36-37
-           "demod2": ("make(2, 2, sizeof(gr_complex), c8p_pinned_buffer::type)", "make(1, 1, sizeof(float), c8p_pinned_buffer::type)"),    # demod2_impl.cc:36-37
-           "decode": ("make(1, 1, sizeof(float), c8p_pinned_buffer::type)", "make(0, 0, 0)")}                                               # decode_impl.cc:35-38
+    # the reference's ports (stream counts, item sizes) through c8p_stream_sig: the module's buffer type as the fourth argument of GNU Radio
+    # 3.10's io_signature::make, or — safe mode — exactly the reference's three-argument call
+    sig = {"demod": ("c8p_stream_sig(1, sizeof(gr_complex))", "c8p_stream_sig(1, sizeof(float))"),      # demod_impl.cc:36-37
+           "demod2": ("c8p_stream_sig(2, sizeof(gr_complex))", "c8p_stream_sig(1, sizeof(float))"),     # demod2_impl.cc:36-37
+           "decode": ("c8p_stream_sig(1, sizeof(float))", "gr::io_signature::make(0, 0, 0)")}           # decode_impl.cc:35-38
     for b, (i, o) in sig.items():
         src = open(os.path.join(GR, "lib", b + "_impl.cc")).read()
-        assert "io_signature::" + i in src and "io_signature::" + o in src
+        assert i in src and o in src
         assert re.search(r"%s::sptr %s::make\(" % (b, b), src)
+    ad0 = open(os.path.join(GR, "lib", "c8p_gr_adapter.h")).read()
+    assert "gr::io_signature::make(n, n, (int)item, c8p_pinned_buffer::type)" in ad0 and "return gr::io_signature::make(n, n, (int)item);" in ad0
     assert 'message_port_register_out(pmt::mp("out"))' in open(os.path.join(GR, "lib", "decode_impl.cc")).read()
     ad = open(os.path.join(GR, "lib", "c8p_gr_adapter.h")).read()
     assert "TPP_DONT" in ad and 'pmt::mp("len")' in ad and "pmt::make_blob" in ad
@@ -106,7 +108,73 @@ def test_adapters_type_check_against_the_gnu_radio_3_10_api_declarations():
            "-I" + os.path.join(ROOT, "gr-ieee80211_amd", "host")]
     srcs = [os.path.join(GR, "lib", f) for f in ("demod_impl.cc", "demod2_impl.cc", "decode_impl.cc")] + \
            [os.path.join(ROOT, "gr-ieee80211_amd", "host", "c8p_blocks.cc")]
-    for src in srcs:
-        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-DC8P_MIRROR_NS=c8p",
-                            "-Dgnuradio_ieee80211_EXPORTS"] + inc + [src], capture_output=True, text=True)
-        assert r.returncode == 0, src + "\n" + r.stderr[-4000:]
+    for extra in ([], ["-DC8P_GR_STOCK_API_ONLY"]):                # the full adapters, and the build that uses the stock gr::block API only
+        for src in srcs:
+            r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-DC8P_MIRROR_NS=c8p",
+                                "-Dgnuradio_ieee80211_EXPORTS"] + extra + inc + [src], capture_output=True, text=True)
+            assert r.returncode == 0, " ".join(extra) + " " + src + "\n" + r.stderr[-4000:]
+
+
+def test_stock_api_only_build_touches_no_custom_buffer_topology_or_post_member():
+    """-DC8P_GR_STOCK_API_ONLY: after the preprocessor, what is left of the adapters names none of the GNU Radio members the reference does not
+    use itself — no buffer_single_mapped / buffer_type / block_detail / buffer_reader, no stream_buffer_type, no _post, no detail().  That is
+    the build whose every GNU Radio call has a call site in the reference (c8p_gr_adapter.h's audit list), so it is the one to try first."""
+    decls = os.path.join(ROOT, "tests", "gr_api_decls")
+    inc = ["-I" + decls, "-I" + os.path.join(GR, "include"), "-I" + os.path.join(GR, "lib"), "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "gr-ieee80211_amd", "host")]
+    for b in ("demod", "demod2", "decode"):
+        r = subprocess.run(["g++", "-std=c++17", "-E", "-P", "-DC8P_MIRROR_NS=c8p", "-Dgnuradio_ieee80211_EXPORTS", "-DC8P_GR_STOCK_API_ONLY"] + inc +
+                           [os.path.join(GR, "lib", b + "_impl.cc")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = r.stdout
+        ours = text[text.index("c8p_gr_safe"):]                        # from the adapter on (what precedes it is GNU Radio's own headers / the decls)
+        for banned in ("buffer_single_mapped", "c8p_pinned_buffer", "stream_buffer_type", "block_detail", "buffer_reader", "_post(", "detail()", "nreaders"):
+            assert banned not in ours, (b, banned)
+        assert "set_tag_propagation_policy" in ours and "get_tags_in_range" in ours and "message_port_pub" in ours
+
+
+def test_side_by_side_comparison_of_two_edge_dumps(tmp_path):
+    """gnuradio/ci/dump_chain.py compare — the half of test_reference_cxx_side_by_side that needs no GNU Radio: two dumps of the demod ->
+    decode edge (items, tags, PDUs).  Equal dumps pass (this module's own c8p_* tags are reported, not compared); one LLR item off by
+    2e-5, a differing integer tag, a missing PDU or a computed float tag off by 1e-3 each fail, by name."""
+    import json
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(GR, "ci"))
+    import dump_chain
+
+    def write(d, llr, tags, pdus):
+        os.makedirs(d, exist_ok=True)
+        np.asarray(llr, np.float32).tofile(os.path.join(d, "llr.f32"))
+        json.dump(tags, open(os.path.join(d, "tags.json"), "w"))
+        json.dump(pdus, open(os.path.join(d, "pdus.json"), "w"))
+    rng = np.random.default_rng(5)
+    llr = rng.normal(0, 2, 4000).astype(np.float32)
+    tags = [[0, "format", 2], [0, "len", 1458], [0, "cfo", 1234.5], [0, "sssnr0", 19.638828], [0, "total", 2000],
+            [2000, "format", 0], [2000, "len", 100], [2000, "total", 2000], [2000, "mu2x1chan", [[1.0, 0.5], [0.25, -1.0]]]]
+    pdus = ["0201", "00aa"]
+    ref, ours = str(tmp_path / "ref"), str(tmp_path / "ours")
+    write(ref, llr, tags, pdus)
+    write(ours, llr + np.float32(4e-6) * np.sign(llr), tags + [[0, "c8p_llr", 77]], pdus)
+    r = dump_chain.compare_dumps(ref, ours)
+    assert r["ok"] and r["our_own_tags_on_the_edge"] == ["c8p_llr"] and 0 < r["llr_max_abs_diff"] <= 1e-5 and r["llr_sign_flips"] == 0
+    bad = llr.copy(); bad[123] += 2e-5
+    write(ours, bad, tags, pdus)
+    r = dump_chain.compare_dumps(ref, ours)
+    assert not r["ok"] and r["llr_items_over_tolerance"] == 1 and r["llr_worst_item"]["index"] == 123 and r["tags_equal"] and r["pdus_equal"]
+    t2 = [list(t) for t in tags]; t2[1][2] = 1454
+    write(ours, llr, t2, pdus)
+    r = dump_chain.compare_dumps(ref, ours)
+    assert not r["ok"] and not r["tags_equal"] and r["tag_differences"][0]["key"] == "len"
+    t3 = [list(t) for t in tags]; t3[3][2] = 19.66
+    write(ours, llr, t3, pdus)
+    assert not dump_chain.compare_dumps(ref, ours)["tags_equal"]
+    write(ours, llr, tags, pdus[:1])
+    r = dump_chain.compare_dumps(ref, ours)
+    assert not r["ok"] and not r["pdus_equal"]
+    write(ours, llr[:-1], tags, pdus)
+    assert dump_chain.compare_dumps(ref, ours)["llr_max_abs_diff"] is None
+    # the command line: exit status 1 and a JSON record
+    p = subprocess.run([sys.executable, os.path.join(GR, "ci", "dump_chain.py"), "compare", ref, ours, "--json", str(tmp_path / "r.json")], capture_output=True, text=True)
+    assert p.returncode == 1 and json.load(open(tmp_path / "r.json"))["ok"] is False

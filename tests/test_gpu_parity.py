@@ -503,7 +503,8 @@ def test_sharded_stream_over_rccl_world_of_one():
     gather_results — with backend nccl (= RCCL) on the one GPU a test box has (the 2- and 3-rank logic runs under gloo in
     tests/test_shard_gloo.py).  sharded_stream() itself asserts that the gathered arenas hold every transmitted MPDU."""
     import torch
-    import bench
+    from c8p_testlib import bench_legs
+    bench = bench_legs()
     dev = torch.device("cuda", 0)
     res = bench.sharded_stream(torch, dev, 0, 0, 1, False, 600, 1, 1, sub=128)
     assert res["packets"] == 600 and res["pdus_gathered"] == res["pdus_equal_to_transmitted"] >= 590
@@ -827,7 +828,8 @@ def test_soak_full_size_batches_against_the_oracle_on_all_cores():
     C8P_SOAK_N = packets per batch (default 4096 for cfg 1 / 2, half of it for cfg 3 / 4, a quarter per MU station)."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    from bench import usable_cores
+    from c8p_testlib import bench_legs
+    usable_cores = bench_legs().usable_cores
     from c8p_cases import workload_on_device
     n = int(os.environ.get("C8P_SOAK_N", "4096"))
     o = oracle()
@@ -907,7 +909,8 @@ def test_random_packets_all_flavours_and_the_oracle(kind, snr):
     (the oracle on all host cores); every published PDU is the transmitted MPDU."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    from bench import usable_cores
+    from c8p_testlib import bench_legs
+    usable_cores = bench_legs().usable_cores
     from c8p_cases import workload_on_device
     n = int(os.environ.get("C8P_SOAK_N", "300"))
     pk, A, C_, exp, keep = workload_on_device(kind, n, snr, 4242, torch, torch.device("cuda", 0), 0)

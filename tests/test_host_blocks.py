@@ -415,6 +415,58 @@ def test_deferred_consume_survives_a_buffer_that_relocates_its_items(n_ant, ever
     assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
 
 
+def moved_output_run(engine_lib, n_ant, every, nout, max_batch=5):
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, n_ant)
+    dem = blocks.Block(blocks.DEMOD if n_ant == 1 else blocks.DEMOD2, engine_lib=engine_lib, max_batch=max_batch, pinned_io=True, defer_consume=True, fused=False)
+    assert dem.output_pinned()
+    dem.set_poison(True); dem.set_move_out(every)
+    blocks.feed_demod(dem, pk, iq, chan)
+    dem.run(chunk=700, nout=nout)
+    llr, tags, moves = dem.output(), dem.tags(), dem.moves_done()
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=engine_lib, max_batch=max_batch)
+    dec.push_items(0, llr)
+    for off, key, val in tags:
+        dec.push_tag(off, key, val)
+    dec.run(chunk=2500, nout=3000)
+    res = (llr, tags, dec.messages(), dec.debug_lines())
+    dem.close(); dec.close()
+    assert moves >= 3
+    assert check_against_oracle(res, pk, iq, chan) >= (20 if n_ant == 1 else 10)
+
+
+@pytest.mark.parametrize("n_ant", [1, 2])
+@pytest.mark.parametrize("every,nout", [(1, 3000), (2, 3000), (3, 700), (5, 40000)])
+def test_items_placed_ahead_survive_a_buffer_that_moves_its_write_position(n_ant, every, nout):
+    """demod writes LLR items into a pinned output buffer AHEAD of produce(); GNU Radio's single-mapped buffers move the write
+    position from their blocked callbacks (d_write_index += gap, or back to the start) without asking the writer, so the items ahead would
+    stay behind and the next call would report whatever lies at the new position.  The buffer brackets its moves with
+    c8p::buffer_move_scope: the front waits for the launches that write those items, they are saved, and put back where the write
+    position is afterwards.  Here the harness moves the output position before every 1st / 2nd / 3rd / 5th call and fills the rest of
+    the buffer with NaNs; items, tags, PDUs as the oracle's."""
+    moved_output_run(FAKE, n_ant, every, nout)
+
+
+def test_a_buffer_that_moves_without_saying_so_is_caught(monkeypatch):
+    """the same moves WITHOUT the scope (C8P_TEST_UNBRACKETED_MOVE=1: the harness just changes the position): the front refuses to report
+    items from a place it did not put them — an error, not garbage LLRs with correct tags"""
+    monkeypatch.setenv("C8P_TEST_UNBRACKETED_MOVE", "1")
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=5, pinned_io=True, defer_consume=True, fused=False)
+    dem.set_move_out(1)
+    blocks.feed_demod(dem, pk, iq, chan)
+    with pytest.raises(RuntimeError, match="output space moved"):
+        dem.run(chunk=700, nout=3000)
+    dem.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every,nout", [(1, 3000), (3, 40000)])
+def test_items_placed_ahead_survive_a_moving_buffer_on_the_engine(every, nout):
+    moved_output_run(None, 1, every, nout, max_batch=16)
+
+
 @pytest.mark.parametrize("defer", [False, True])
 @pytest.mark.parametrize("max_batch", [3, 64])
 def test_arenas_that_grow_while_gathers_fill_them(defer, max_batch, monkeypatch):
@@ -917,3 +969,31 @@ def test_fused_is_the_default_when_demod_feeds_only_decode(monkeypatch):
     assert dem.fused_state() is False
     assert not any(k == "c8p_fused" for _, k, _ in dem.tags())
     dem.close()
+
+
+def test_safe_mode_uses_nothing_but_the_reference_blocks_own_scheduler_calls(monkeypatch):
+    """C8P_GR_SAFE=1 (batching_cfg::safe_mode; the GNU Radio adapters' fallback for an installation they have never met, and what
+    -DC8P_GR_STOCK_API_ONLY compiles in): ordinary buffers on every port, the demod -> decode edge in plain mode whoever reads it — every
+    item value written, the reference's eleven to fourteen tags per packet, no handle tags — items consumed in the call that cut them, no
+    timer thread.  Other switches do not override it.  PDUs, debug lines, LLR items and tags as the oracle's."""
+    monkeypatch.setenv("C8P_GR_SAFE", "1")
+    monkeypatch.setenv("C8P_FUSED", "1"); monkeypatch.setenv("C8P_PINNED_IO", "1")           # (safe mode wins)
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    # the chain on two threads, nothing said about fused / pinned: the harness tells demod that decode is its only reader (fused_auto would fuse)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=7)
+    dec = blocks.Block(blocks.DECODE, ifdebug=True, engine_lib=FAKE, max_batch=7)
+    assert not dem.input_pinned(0) and not dem.output_pinned() and not dec.input_pinned(0)
+    blocks.feed_demod(dem, pk, iq, chan)
+    blocks.run_chain(dem, dec, chunk=3000, nout=5000)
+    assert dem.fused_state() is False
+    chain_out = (dec.messages(), dec.debug_lines())
+    n_tags = dem.tags_emitted()
+    dem.close(); dec.close()
+    n_emitted = sum(1 for r in ref_tags_per_packet(pk, iq, chan) if r)
+    assert n_tags >= 10 * n_emitted                   # (a legacy packet has ten: format mcs len cr ampdu trellis total cfo snr rssi)
+    # the same blocks one after the other: the items and tags of the edge are the reference's, nothing else on it
+    res = chain(FAKE, pk, iq, chan, 1, 3000, 5000, 7)
+    assert check_against_oracle(res, pk, iq, chan) >= 20
+    assert not any(k.startswith("c8p_") for _, k, _ in res[1])
+    assert (res[2], res[3]) == chain_out

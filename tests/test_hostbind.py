@@ -110,3 +110,24 @@ def test_cpu_jiffies_reads_proc_stat(tmp_path):
     j = hostbind._cpu_jiffies(str(tmp_path))
     assert j == {0: (10, 100), 1: (80, 100)}
     assert hostbind._cpu_jiffies(str(tmp_path / "nothing")) == {}
+
+
+def test_eight_gpus_on_two_sockets_bind_four_ranks_to_each(tmp_path, monkeypatch):
+    """the node the driver's scaling run uses: 8 GPUs, 4 per socket (an MI355X platform's usual PCIe addresses), 2 NUMA nodes of 8 CPUs in
+    this fixture (the test's own cpuset is stood in for: every CPU allowed).  Rank r finds GPU r's node and the node's CPUs; ranks 0-3
+    land on node 0, 4-7 on node 1; a device whose function 0 is not listed (SR-IOV: only .1) is still found."""
+    addrs = ["0000:05:00.0", "0000:15:00.0", "0000:65:00.0", "0000:75:00.0", "0000:85:00.0", "0000:95:00.0", "0000:e5:00.0", "0000:f5:00.1"]
+    for i, a in enumerate(addrs):
+        d = tmp_path / "bus" / "pci" / "devices" / a
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % (i // 4))
+    for n, txt in {0: "0-7", 1: "8-15"}.items():
+        nd = tmp_path / "devices" / "system" / "node" / ("node%d" % n)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(txt + "\n")
+    monkeypatch.setattr(hostbind, "gpu_pci_address", lambda local, torch=None: addrs[local][:-1] + "0")      # (torch reports no function)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
+    got = [hostbind.bind_rank(r, sysfs=str(tmp_path), apply=False) for r in range(8)]
+    assert [g["numa_node"] for g in got] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [g["cpus"] for g in got] == ["0-7"] * 4 + ["8-15"] * 4 and all(g["cpu_count"] == 8 for g in got)
+    assert all(g["affinity"].startswith("not applied") for g in got)

@@ -76,12 +76,13 @@ def rx_chain_rate(K=8, items_per_stream=1 << 22, per_round=1 << 19, local=0, bit
 IO_SIZES = {"custom": (1 << 20, 1 << 21), "custom8": (1 << 19, 1 << 21), "custom32": (1 << 21, 1 << 22), "sched64k": (1 << 16, 1 << 18)}
 
 
-def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto", defer_consume=None):
+def run(n=4096, batches=(256, 1024), quiet=False, batch=None, io="custom", pinned_io=None, pin="auto", defer_consume=None, passes=None):
     """every figure is the median of PASSES passes over the same block instances after a first untimed one (which grows the
     pinned staging and the device arenas, creates streams, pages the library in).  batch = (descriptors, iq, chan, expected PDUs) on
     the host; None: host_batch(n).  io: a key of IO_SIZES; pinned_io / defer_consume: batching_cfg's fields of those names (None: their defaults)"""
     pk, iq, chan, exp = batch if batch is not None else host_batch(n)
     pk, exp = pk[:n], exp[:n]
+    PASSES = passes or globals()["PASSES"]
     chunk_in, nout_llr = IO_SIZES[io]
     # the chain's two scheduler threads on two cores that share an L3 (GNU Radio: the blocks' core affinity); pin=None: left to the OS
     if pin == "auto":

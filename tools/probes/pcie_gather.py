@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 load_package()
 import torch
-import bench
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench_legs as bench  # noqa: E402  (the legs moved out of bench.py in round 6)
 from gr_ieee80211_amd.workloads import workload_on_device
 dev = torch.device("cuda:0")
 pk, iq_dev, chan_dev, exp, keep = workload_on_device("cfg2", 4096, 30.0, 0, torch, dev, 0)

@@ -2,5 +2,5 @@
 import json, sys
 for line in sys.stdin:
     if line.startswith('{"metric"'):
-        j = json.loads(line); x = j["roofline"]["exclusive_avg_launch_ms"]
-        print(sys.argv[1], round(j["value"]), round(j["ms_per_step"], 4), "excl fwd", x["viterbi_fwd"], "fin", x["finish"], "fcs", j["config"].get("fcs_ok_fraction"))
+        j = json.loads(line); x = j["roofline"]
+        print(sys.argv[1], round(j["value"]), round(j["ms_per_step"], 4), "excl", x["kernel"], x["launch_ms"], "fcs", j["config"].get("fcs_ok_fraction"))

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 torch.cuda.init()                  # (before the engine library brings up its own view of the runtime: pinned sc16 buffers come from torch)
-from bench import usable_cores  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_legs import usable_cores  # noqa: E402
 from c8p_testlib import oracle, oracle_rx  # noqa: E402
 from gr_ieee80211_amd import blocks  # noqa: E402
 from test_detect_frontend import scan_rule, sig_events  # noqa: E402

@@ -27,7 +27,8 @@ import torch  # noqa: E402
 torch.zeros(1, device="cuda")
 from concurrent.futures import ThreadPoolExecutor  # noqa: E402
 
-from bench import usable_cores  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_legs import usable_cores  # noqa: E402
 from c8p_smoke import close_or_both_nan  # noqa: E402
 from c8p_testlib import abi, oracle  # noqa: E402
 from gr_ieee80211_amd import engine  # noqa: E402

@@ -21,6 +21,9 @@ def short(name):
 
 b = open(os.path.join(src, "bench.json")).read().strip().splitlines()
 open(os.path.join(dst, "bench.json"), "w").write(b[-1] + "\n" if b else "")
+for extra in ("bench_detail.json", "bench_driver_cmd.json", "bench_driver_cmd_detail.json"):      # the full record (--legs full) and the driver's command
+    if os.path.exists(os.path.join(src, extra)):
+        open(os.path.join(dst, extra), "w").write(open(os.path.join(src, extra)).read().strip() + "\n")
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(dst, "kernel_stats.csv"), "w").write(open(f).read())
 for f in glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recursive=True):      # C8P_SLOTS=1: averages = exclusive durations
