@@ -148,7 +148,10 @@ __device__ __forceinline__ void lds_tap(float* __restrict__ dst, const float* sr
 // loop's range is rare: the wave flags it and stops; k_finish demodulates a flagged packet into the LLR arena (redemod_packet), runs the
 // clamp-exact forward pass and goes on with its traceback.  Symbols that only carry padding behind the last trellis step are not demodulated at all.
 #define C8P_LBUF 688
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
+#ifndef C8P_RX1_WAVES
+#define C8P_RX1_WAVES 6      // waves per SIMD k_rx_1ss_lds is compiled for (7 was tried in round 6: see NOTES/decoder.md)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C8P_RX1_WAVES, C8P_RX1_WAVES))) void k_rx_1ss_lds(const c8p_pkt_in* __restrict__ pk, const cf* __restrict__ iq, const cf* __restrict__ chan,
                                                 const PktLayout* __restrict__ lay, const DevTables* __restrict__ T,
                                                 const c8p_pkt_tags* __restrict__ tags, const cf* __restrict__ Hin, float* __restrict__ llr_tap,
                                                 ulonglong2* __restrict__ surv, uint32_t* __restrict__ flags, int n,
@@ -204,6 +207,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   // per round, not per symbol.
   const int needed = __builtin_amdgcn_readfirstlane(llr_needed(t.cr, Tn));   // LLRs the trellis consumes; symbols behind them are padding
   int s = 0;
+  // Experiment build only (-DC8P_EXPERIMENTS -DC8P_EXP_PHASE=k, tools/probes/phase_account.py; NOTES/decoder.md "where the wave's time goes"):
+  // k = 0: the wave's shader cycles (s_memtime) by phase — demodulating symbols / the block loop / the rest — go to C8P_BUF_DECSTAT instead of
+  // the statistics; k = 1: the demodulator alone (no block loop, no tail); k = 2: the block loop alone (the buffer filled with a constant
+  // instead of demodulated symbols).  1 and 2 are what the per-phase PMC passes run; their PDUs are meaningless (bench.py --no-check).
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+  const unsigned long long ph_t0 = __builtin_readcyclecounter();
+  unsigned long long ph_dem = 0, ph_blk = 0;
+#define C8P_PH_NOW() __builtin_readcyclecounter()
+#endif
   while (s < t.nsym && s * t.ncbps < needed) {
     // Nothing that depends on the lane lives across a phase: the lane index is taken afresh (opaque) in each, the decoder's state
     // (metric, survivor offset) waits in LDS while the symbols are demodulated, its lane constants were written there once, and
@@ -213,8 +225,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       park[wv][lane_p] = make_uint2(__float_as_uint(S.pre), S.voff);
       asm volatile("; decoder state parked" : "=v"(S.pre), "=v"(S.voff));
     }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+    const unsigned long long ph_a = C8P_PH_NOW();
+#endif
 #pragma unroll 1
     do {
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE) && C8P_EXP_PHASE == 2
+      {                                              // no demodulator: ncbps LLRs of +3 (positive drift: the integer loop, as on real data)
+        const int lane_s = lane_fresh();
+        for (int i = lane_s; i < t.ncbps; i += 64) lb[have + i] = 3.0f;
+        have += t.ncbps; s++;
+        continue;
+      }
+#endif
       const int lane_s = lane_fresh();
       const cf xnext = x1[(uint32_t)((s + 1 < t.nsym ? s + 1 : s) * t.nsymsamp + lane_s)];
       cf Hs = parkH[wv][lane_s];
@@ -235,6 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       negb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(
           fmaxf(negb, __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(neg), 63)) * wfac))));
     } while (s < t.nsym && s * t.ncbps < needed && have + t.ncbps <= C8P_LBUF);
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+    const unsigned long long ph_b = C8P_PH_NOW();
+    ph_dem += ph_b - ph_a;
+#endif
     const int lane_d = lane_fresh();               // (again: the decoder's per-lane addresses and the pieces of the constant unpack must
                                                    // not be hoisted out of the loop either)
     {
@@ -256,12 +283,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       lean_k_unpack<false>(kc.x, lane_d, K);          // (the float step's class masks are made where a float block runs)
       const float bound = lean_bound(negb);
       const int upto = done + nb;
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+      const unsigned long long ph_c = C8P_PH_NOW();
+#endif
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE) && C8P_EXP_PHASE == 1
+      S.done = upto;                                 // (the demodulator alone: the blocks are counted, not run)
+      asm volatile("" :: "v"(K[0].a), "v"(init), "v"(flip), "v"(bound));
+#else
       switch (t.cr) {
         case C8P_CR_12: lean_blocks_l<C8P_CR_12>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
         case C8P_CR_23: lean_blocks_l<C8P_CR_23>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
         case C8P_CR_34: lean_blocks_l<C8P_CR_34>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
         default:        lean_blocks_l<C8P_CR_56>(S, K, init, flip, bound, lb, lane_d, sv, upto, segn); break;
       }
+#endif
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+      ph_blk += C8P_PH_NOW() - ph_c;
+#endif
       // what is left over moves to the front (< nlb <= 60 LLRs unless the full blocks are all done; one lane each, 64 per pass)
       const int used = nb * nlb;
       have -= used;
@@ -276,6 +314,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   }
   const int lane_t = lane_fresh();
   if (lane_t == 0) { flags[n + p] = (uint32_t)S.nflt; flags[2 * n + p] = __float_as_uint(negb); }   // C8P_BUF_DECSTAT
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE) && C8P_EXP_PHASE == 1
+  return;
+#endif
   LeanK K[6];
   lean_k_unpack(parkK[wv][lane_t].x, lane_t, K);
   switch (t.cr) {
@@ -284,6 +325,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     case C8P_CR_34: lean_tail_l<C8P_CR_34>(S, K, lb, have, lane_t, Tn, sv); break;
     default:        lean_tail_l<C8P_CR_56>(S, K, lb, have, lane_t, Tn, sv); break;
   }
+#if defined(C8P_EXPERIMENTS) && defined(C8P_EXP_PHASE)
+  // [n + p]: the wave's cycles in all, [2n + p]: demodulation >> 6 in the high half, block loop >> 6 in the low half (a packet takes ~10^6)
+  if (lane_t == 0) {
+    const unsigned long long all = C8P_PH_NOW() - ph_t0;
+    flags[n + p] = (uint32_t)all;
+    flags[2 * n + p] = ((uint32_t)(ph_dem >> 6) << 16) | ((uint32_t)(ph_blk >> 6) & 0xffffu);
+  }
+#endif
 }
 
 // ---- two streams on two antennas (demod2's 2x2 path, BASELINE configs[2]) with the LLR stream kept on chip ------------------------
