@@ -1163,10 +1163,23 @@ def run_multi_gpu(ctx, out, args, emit):
     """every rank, world > 1 (or a one-rank torch.distributed.run with C8P_TEST_MULTI_LEG=1): BASELINE configs[3] as ONE stream scattered
     from rank 0, and the host-fed legs on all ranks at once.  Each runs under a watchdog on every rank, so that neither an exception on
     one rank nor a collective that never returns can cost the headline, which is complete when this is called."""
+    import signal
     import torch.distributed as dist
     torch, dev, local, rank, world = ctx["torch"], ctx["dev"], ctx["local"], ctx["rank"], ctx["world"]
+    # These legs have never met more than one GPU.  An exception is caught and a hang is timed out (LegGuard); if a PEER dies instead
+    # (a signal inside a collective), the launcher ends the survivors with SIGTERM: rank 0 then prints the headline line as it stands
+    # — measured and complete before any of this started — and leaves.
+    if rank == 0 and out is not None:
+        def on_term(signum, frame):
+            out["multi_gpu_legs_error"] = "a peer rank died during the multi-GPU legs (SIGTERM from the launcher); the headline was measured before them"
+            emit(out)
+            os._exit(0)
+        try:
+            signal.signal(signal.SIGTERM, on_term)
+        except (ValueError, OSError):
+            pass
     if not args.no_stream and world > 1:
-        guard = LegGuard(out, rank, float(os.environ.get("C8P_STREAM_LEG_TIMEOUT_S", "180")), "sharded_stream", emit)
+        guard = LegGuard(out, rank, float(os.environ.get("C8P_STREAM_LEG_TIMEOUT_S", "120")), "sharded_stream", emit)
         try:
             stream_res = sharded_stream(torch, dev, local, rank, world, True, args.stream_packets, args.stream_steps, 1)
         except Exception as e:                           # (the peers are then stuck in a collective: their guards end them)
@@ -1177,7 +1190,7 @@ def run_multi_gpu(ctx, out, args, emit):
         if rank == 0:
             out["sharded_stream"] = stream_res
     if not args.no_host_legs:
-        guard = LegGuard(out, rank, float(os.environ.get("C8P_HOST_LEG_TIMEOUT_S", "240")), "multi_gpu_host_fed", emit)
+        guard = LegGuard(out, rank, float(os.environ.get("C8P_HOST_LEG_TIMEOUT_S", "150")), "multi_gpu_host_fed", emit)
         try:
             mine = multi_gpu_host_fed(torch, dev, local, rank, world, ctx["pk"], ctx["iq_dev"], ctx["chan_dev"])
         except Exception as e:
@@ -1187,3 +1200,8 @@ def run_multi_gpu(ctx, out, args, emit):
         guard.done()
         if rank == 0:
             out["multi_gpu_host_fed"] = summarize_host_fed(every)
+    if rank == 0 and out is not None:
+        try:
+            signal.signal(signal.SIGTERM, signal.SIG_DFL)
+        except (ValueError, OSError):
+            pass
