@@ -105,6 +105,7 @@ public:
   bool input_blocked_callback(int items_required, int items_avail, unsigned read_index) override
   {
     c8p::buffer_move_scope mv(d_base, (size_t)d_bufsize * d_sizeof_item);
+    if (!mv.ok()) return false;                     // a front is busy on this memory and did not let go in time: not now
     const bool moved = input_blocked_callback_logic(items_required, items_avail, read_index, d_base, mem_copy, mem_move);
     mv.moved_to(write_pointer());
     return moved;
@@ -112,6 +113,7 @@ public:
   bool output_blocked_callback(int output_multiple, bool force) override
   {
     c8p::buffer_move_scope mv(d_base, (size_t)d_bufsize * d_sizeof_item);
+    if (!mv.ok()) return false;
     const bool moved = output_blocked_callback_logic(output_multiple, force, d_base, mem_move);
     mv.moved_to(write_pointer());
     return moved;

@@ -146,10 +146,29 @@ void buffer_will_move(const void* base, size_t bytes)
 }
 // (g_fronts_mu stays held from the constructor to the destructor: no front is created or destroyed while a buffer moves; a front's
 // own mutex is taken inside move_begin — the order is always g_fronts_mu, then the front's)
-buffer_move_scope::buffer_move_scope(const void* base, size_t bytes)
+buffer_move_scope::buffer_move_scope(const void* base, size_t bytes, int64_t timeout_us)
 {
   g_fronts_mu.lock();
-  for (c8p_block* b : g_fronts) if (b->move_begin(base, bytes)) d_held.push_back(b);
+  for (c8p_block* b : g_fronts) {
+    const int r = b->move_begin(base, bytes, timeout_us);
+    if (r > 0) d_held.push_back(b);
+    if (r < 0) {                                 // one front could not be held: let go of the others, the buffer stays where it is
+      for (c8p_block* h : d_held) h->move_end(nullptr);
+      d_held.clear();
+      d_ok = false; d_done = true;
+      break;
+    }
+  }
+}
+// a front's own mutex, tried for at most timeout_us (see buffer_move_scope: never waited for without a bound)
+static bool try_lock_for(std::mutex& m, int64_t timeout_us)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    if (m.try_lock()) return true;
+    if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_us) return false;
+    std::this_thread::yield();
+  }
 }
 void buffer_move_scope::moved_to(void* new_write_ptr)
 {
@@ -642,9 +661,9 @@ public:
 
   // a buffer moves (c8p_blocks.h, buffer_move_scope): the input side as quiesce(); items placed ahead in an output buffer that lies in
   // the range are waited for — every launch that writes them — and saved, and d_mu stays held until move_end has put them back
-  bool move_begin(const void* base, size_t bytes) override
+  int move_begin(const void* base, size_t bytes, int64_t timeout_us) override
   {
-    d_mu.lock();
+    if (!try_lock_for(d_mu, timeout_us)) return -1;
     bool held = false;
     try {
       d_lane.wait_range(d_eng, base, bytes);
@@ -656,7 +675,7 @@ public:
       }
     } catch (...) { d_mu.unlock(); throw; }
     if (!held) d_mu.unlock();
-    return held;
+    return held ? 1 : 0;
   }
   void move_end(void* new_write_ptr) override      // (d_mu is held: move_begin returned true)
   {
@@ -1556,6 +1575,13 @@ public:
   }
 
   void quiesce(const void* base, size_t bytes) override { std::lock_guard<std::mutex> g(d_mu); d_lane.wait_range(d_eng, base, bytes); }
+  int move_begin(const void* base, size_t bytes, int64_t timeout_us) override
+  {
+    if (!try_lock_for(d_mu, timeout_us)) return -1;
+    std::lock_guard<std::mutex> g(d_mu, std::adopt_lock);
+    d_lane.wait_range(d_eng, base, bytes);
+    return 0;
+  }
 
   bool is_decode_front() const override { return true; }
   // the io_signature's buffer type (c8p_blocks.h): the LLR stream arrives in pinned host memory

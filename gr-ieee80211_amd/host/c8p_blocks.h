@@ -237,7 +237,10 @@ public:
   // its general_work out (the block's own mutex stays held), save those items, return true.  move_end (only after a true move_begin):
   // the saved items go to `new_write_ptr` — where the buffer's write position is now, i.e. where the next call's output space begins —
   // and general_work may run again.
-  virtual bool move_begin(const void* base, size_t bytes) { quiesce(base, bytes); return false; }
+  // Returns 1: held (move_end must follow); 0: nothing of this block is in the way; -1: the block could not be got hold of within
+  // timeout_us (its general_work is running and does not return — e.g. it waits for a lock the mover holds): nothing is held, the
+  // mover must not move now.
+  virtual int move_begin(const void* base, size_t bytes, int64_t timeout_us) { quiesce(base, bytes); return 0; }
   virtual void move_end(void* new_write_ptr) {}
   void set_io(block_io* io) { d_io = io; }
 
@@ -261,12 +264,16 @@ void buffer_will_move(const void* base, size_t bytes);
 //     { c8p::buffer_move_scope mv(base, bytes);  ... the buffer moves its items and its write index ...;  mv.moved_to(write_pointer()); }
 // Its constructor does what buffer_will_move does (every front waits for its copies on the range) and, for the front that has items
 // ahead in the range, holds that front and saves them; moved_to puts them back at the new write position; the destructor lets the front
-// run again (without moved_to the items stay where they were: the buffer did not move).  gnuradio/lib/c8p_pinned_buffer.h uses it in both
+// run again (without moved_to the items stay where they were: the buffer did not move).  A front is taken hold of with a TIMEOUT
+// (its own mutex is tried, not waited for: a scheduler that calls the buffer's callback with a lock held that the front's running
+// general_work needs — add_item_tag takes the buffer's — must not deadlock here): ok() == false means some front could not be held,
+// nothing is held, and the buffer must NOT move now (its callback returns false: the scheduler comes back later).  gnuradio/lib/c8p_pinned_buffer.h uses it in both
 // callbacks; the mirror's harness has an edge of that kind to test it with (c8ph_run, C8P_MIRROR_MOVES).
 class buffer_move_scope
 {
 public:
-  buffer_move_scope(const void* base, size_t bytes);
+  buffer_move_scope(const void* base, size_t bytes, int64_t timeout_us = 20000);
+  bool ok() const { return d_ok; }
   void moved_to(void* new_write_ptr);
   ~buffer_move_scope();
   buffer_move_scope(const buffer_move_scope&) = delete;
@@ -274,7 +281,7 @@ public:
 
 private:
   std::vector<c8p_block*> d_held;
-  bool d_done = false;
+  bool d_done = false, d_ok = true;
 };
 
 class demod : virtual public c8p_block
