@@ -441,3 +441,64 @@ def test_the_one_estimator_is_a_median_of_windows():
     assert ws["n"] == 3 and ws["min"] < 0.6 * ws["median"] and ws["median"] <= ws["max"] and w["per_s"] == ws["median"]
     assert calls["sync"] == 4 and calls["n"] == 4 + 3 * w["steps"]
     assert 100 / 6e-4 < w["per_s"] < 100 / 2e-4          # ~0.2-0.3 ms a step: the disturbed window did not become the figure
+
+
+def test_a_leg_that_hangs_costs_the_leg_not_the_line(tmp_path):
+    """tools/bench_legs.LegGuard around a leg that never returns (a collective whose peer is gone): after the timeout rank 0 prints the
+    headline line as it stands — short, parseable, the leg named as failed — and the process leaves with status 0"""
+    detail = str(tmp_path / "d.json")
+    code = r'''
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.join(%r, "tools"))
+import bench_legs, bench_line
+args = argparse.Namespace(detail=%r)
+out = {"metric": "RX packets/s (20 MHz VHT MCS7 1458 B)", "value": 6.5e6, "unit": "packets/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 5.04,
+       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "w", "parallelism": "p"},
+       "roofline": {"bound": "hbm", "kernel": "viterbi_fwd", "achieved": 238.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.03, "traffic": 5.4e8}}
+g = bench_legs.LegGuard(out, 0, 0.3, "sharded_stream", lambda o: bench_line.finish(o, args))
+time.sleep(30)                      # the leg: never returns
+print("NOT REACHED")
+''' % (ROOT, detail)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr[-1500:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "NOT REACHED" not in p.stdout
+    j = json.loads(lines[0])
+    check_short_line(j, lines[0])
+    assert j["value"] == 6.5e6 and j["n_gpus"] == 8 and j["legs_failed"] == ["sharded_stream"] and j["roofline"]["frac"] == 0.03
+    d = json.load(open(detail))
+    assert "no result after" in d["sharded_stream"]["error"] and "abandoned" in p.stderr
+
+
+def test_leg_budget_skips_what_does_not_fit_and_isolates_a_failing_leg(monkeypatch):
+    """tools/bench_legs.run_single_gpu with the legs stubbed: they run in the order of the line's `legs`, a leg that would start after the
+    deadline is listed in legs_skipped (the driver's command keeps its wall clock), a leg that throws is recorded and the next one runs"""
+    import argparse
+    import time
+    from c8p_testlib import bench_legs
+    bl = bench_legs()
+    ran = []
+    monkeypatch.setattr(bl, "config_legs", lambda *a, **k: ran.append("configs") or {"cfg1": {"packets_per_s": 1.0}})
+
+    def pcie(*a, **k):
+        ran.append("pcie")
+        raise RuntimeError("link down")
+    monkeypatch.setattr(bl, "pcie_inclusive", pcie)
+    monkeypatch.setattr(bl, "arenas_to_host", lambda *a: (None, None))
+    monkeypatch.setattr(bl, "block_chain_legs", lambda out, *a: (ran.append("blocks"), time.sleep(0.25), out.update(block_chain_packets_per_s=3.0)))
+    monkeypatch.setattr(bl, "sensitivity_legs", lambda *a, **k: ran.append("sens") or {})
+    monkeypatch.setattr(bl, "sharded_stream", lambda *a, **k: ran.append("stream") or {})
+    monkeypatch.setattr(bl, "frontend_detect", lambda *a, **k: ran.append("frontend") or {})
+    args = argparse.Namespace(workload="cfg2", snr=30.0, no_configs=False, no_host_legs=False, no_sensitivity=False, no_stream=False, no_frontend=False,
+                              stream_packets=1, stream_steps=1)
+    ctx = {"torch": None, "dev": None, "local": 0, "pk": [0] * 4, "iq_dev": None, "chan_dev": None, "expected": [], "use_dist": False}
+    out = {"value": 1.0}
+    bl.run_single_gpu(ctx, out, args, False, time.perf_counter() + 0.2, lambda o: None)
+    assert ran == ["configs", "pcie", "blocks"]                    # the 0.25 s leg ran past the deadline: what follows is skipped, in order
+    assert out["legs_skipped"] == ["sensitivity", "sharded_stream", "frontend_detect"]
+    assert "link down" in out["pcie_inclusive_error"] and out["block_chain_packets_per_s"] == 3.0 and out["configs"]["cfg1"]["packets_per_s"] == 1.0
+    assert set(out["leg_wall_s"]) == {"configs", "pcie_inclusive", "block_chain"} and out["leg_wall_s"]["block_chain"] >= 0.25
+    ran.clear()
+    out = {"value": 1.0}
+    bl.run_single_gpu(ctx, out, args, True, None, lambda o: None)   # --legs full: no deadline, every leg
+    assert ran == ["configs", "pcie", "blocks", "sens", "stream", "frontend"] and "legs_skipped" not in out
