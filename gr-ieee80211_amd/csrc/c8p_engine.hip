@@ -250,6 +250,7 @@ struct c8p_ctx {
   hipEvent_t ev_before_spans = nullptr, ev_spans = nullptr;
   bool spans_pending = false;                        // a span copy the next mark / wait has to include
   int copy_cus = 0;                                  // CUs the copy stream may use (0: all)
+  int opt_copy_cus = -1;                             // c8p_option(C8P_OPT_COPY_CUS): what the caller asked for (-1: the defaults)
   Buf d_spans; void* h_spans = nullptr; size_t h_spans_cap = 0;
   void* d_spans2 = nullptr; void* h_spans2 = nullptr; size_t spans2_cap = 0;      // c8p_copy_spans' own table
   std::mutex copy_mu;                                // marks against copies enqueued from another thread
@@ -1677,6 +1678,18 @@ extern "C" void c8p_dev_free(c8p_ctx* c, void* p)
   }
   (void)hipFree(p);
 }
+extern "C" int c8p_option(c8p_ctx* c, int which, int64_t value)
+{
+  if (!c) return C8P_EINVAL;
+  if (which == C8P_OPT_COPY_CUS) {
+    std::lock_guard<std::mutex> g(c->copy_mu);
+    if (c->copy_stream || value < 0 || value > 256) { c->err = "c8p_option(C8P_OPT_COPY_CUS): 0..256, before the ctx's first copy"; return C8P_EINVAL; }
+    c->opt_copy_cus = (int)value;
+    return C8P_OK;
+  }
+  c->err = "c8p_option: unknown option";
+  return C8P_EINVAL;
+}
 extern "C" int c8p_copy_wait(c8p_ctx* c);
 static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
 {
@@ -1692,7 +1705,7 @@ static int copy_stream_of(c8p_ctx* c, int first_fmt = C8P_FMT_C32)
     // 32 / 48 / 64 CUs, ms per round: 64 streams of complex64 5.28-5.40 / 5.76 / 5.66; 128 of sc16 6.32 / 5.94 / 5.96; 128 of sc8 4.29 /
     // 4.23 / 3.76 — narrow items leave the link slack and the conversion wants lanes: the first gather's item format decides.
     const char* ce = getenv("C8P_COPY_CUS");
-    int ncu = ce ? atoi(ce) : (first_fmt == C8P_FMT_C32 ? 32 : 64);
+    int ncu = ce ? atoi(ce) : c->opt_copy_cus >= 0 ? c->opt_copy_cus : (first_fmt == C8P_FMT_C32 ? 32 : 64);
     int dev_cus = 0;
     if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) dev_cus = 0;
     if (ncu < 0 || ncu >= dev_cus || dev_cus > 256) ncu = 0;

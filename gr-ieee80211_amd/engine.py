@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("C8P_LIB") or os.path.join(_HERE, "libc8p_rx.so")
 SYMBOLS = ["c8p_create", "c8p_destroy", "c8p_last_error", "c8p_demod", "c8p_decode", "c8p_rx", "c8p_sync",
            "c8p_buffer", "c8p_fetch", "c8p_kernel_time", "c8p_profile_reset", "c8p_table", "c8p_abi_sizes", "c8p_signal",
            "c8p_detect", "c8p_tx", "c8p_tx_plan_of", "c8p_tx_plan_mu", "c8p_ticket", "c8p_select", "c8p_fetch_async", "c8p_wait", "c8p_done",
-           "c8p_host_alloc", "c8p_host_free", "c8p_selftest", "c8p_detect_multi", "c8p_reserve", "c8p_counter",
+           "c8p_host_alloc", "c8p_host_free", "c8p_selftest", "c8p_detect_multi", "c8p_reserve", "c8p_counter", "c8p_option",
            "c8p_dev_alloc", "c8p_dev_free", "c8p_copy_async", "c8p_copy_spans", "c8p_copy_wait", "c8p_copy_mark", "c8p_copy_wait_mark", "c8p_copy_mark_done", "c8p_copy_gather", "c8p_copy_fence", "c8p_fetch_gather"]
 
 _LIB = None
@@ -73,6 +73,7 @@ def load_library():
     L.c8p_reserve.argtypes = [C.c_void_p, C.POINTER(abi.ReserveIn)]
     L.c8p_counter.restype = C.c_int64
     L.c8p_counter.argtypes = [C.c_void_p, C.c_int]
+    L.c8p_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     L.c8p_dev_alloc.restype = C.c_void_p
     L.c8p_dev_alloc.argtypes = [C.c_void_p, C.c_uint64]
     L.c8p_dev_free.argtypes = [C.c_void_p, C.c_void_p]

@@ -71,6 +71,7 @@ c8p_api load_c8p_api(const std::string& so_path)
   a.copy_mark_done = (int (*)(c8p_ctx*, uint64_t))sym("c8p_copy_mark_done");
   a.copy_fence = (int (*)(c8p_ctx*))sym("c8p_copy_fence");
   a.fetch_gather = (int (*)(c8p_ctx*, const c8p_fetch_piece*, int32_t))sym("c8p_fetch_gather");
+  a.option = (int (*)(c8p_ctx*, int, int64_t))dlsym(h, "c8p_option");      // (optional)
   return a;
 }
 
@@ -433,6 +434,9 @@ public:
     d_ctx = d_api.create(&c);
     if (!d_ctx) throw std::runtime_error("c8p_create failed: no usable HIP device (there is no CPU fallback)");
     d_cell->ctx = d_ctx; d_cell->dev_free = d_api.dev_free;
+    // a front's gathers are 2-3 MB a call: on 16 CUs they leave more of the chip to the chain's kernels than on the engine's default 32
+    // (include/c8p_rx.h, C8P_OPT_COPY_CUS; the environment's C8P_COPY_CUS overrides)
+    if (d_api.option) (void)d_api.option(d_ctx, C8P_OPT_COPY_CUS, 16);
     // (The fronts keep several batches in flight; everything they need of a batch is downloaded behind its kernels, so the engine's
     // result arenas need not stay resident: any C8P_SLOTS works — with one slot a submit waits inside the engine for its predecessor.)
   }

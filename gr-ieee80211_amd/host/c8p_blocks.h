@@ -140,6 +140,7 @@ struct c8p_api {
   int (*copy_mark_done)(c8p_ctx*, uint64_t);
   int (*copy_fence)(c8p_ctx*);
   int (*fetch_gather)(c8p_ctx*, const c8p_fetch_piece*, int32_t);
+  int (*option)(c8p_ctx*, int, int64_t) = nullptr;      // c8p_option: optional (round 6) — a library without it is used as it is
 };
 // resolves the table from a shared library path (dlopen); throws std::runtime_error if a symbol is missing
 c8p_api load_c8p_api(const std::string& so_path);

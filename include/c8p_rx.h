@@ -572,6 +572,16 @@ int   c8p_copy_fence(c8p_ctx* ctx);
 #define C8P_CNT_COUNT            8
 int64_t c8p_counter(c8p_ctx* ctx, int which);        /* < 0: C8P_EINVAL */
 
+/* Per-ctx options a caller sets right after c8p_create (round 6; an added entry point, the structs and C8P_ABI_VERSION are unchanged:
+ * a caller looks it up and goes without when an older library does not have it).  None changes results.
+ *   C8P_OPT_COPY_CUS   compute units the ctx's copy streams (c8p_copy_gather, c8p_copy_async) may use, set before the first copy; the
+ *                      environment's C8P_COPY_CUS still overrides it.  The default (32 for 8-byte items, 64 for sc16 / sc8) is tuned for
+ *                      the live ingest's 268 MB rounds; a block front that gathers 2-3 MB per general_work call leaves more of the chip to
+ *                      the chain's kernels with 16 (fused demod -> decode chain 704-721 k against 656-676 k packets/s, alternated on one
+ *                      box: profiles/r6c/chain_copy_cus.txt), and that is what host/c8p_blocks.cc asks for.  0: no mask.            */
+#define C8P_OPT_COPY_CUS 1
+int c8p_option(c8p_ctx* ctx, int which, int64_t value);      /* C8P_EINVAL: unknown option, a value out of range, or too late */
+
 /* profile=1: accumulated HIP-event time and launch count of one kernel since the last reset. */
 int c8p_kernel_time(c8p_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
 int c8p_profile_reset(c8p_ctx* ctx);

@@ -202,6 +202,7 @@ int c8p_detect_multi(c8p_ctx* c, const c8p_detect_multi_in* in)
   return C8P_OK;
 }
 int c8p_reserve(c8p_ctx* c, const c8p_reserve_in* in) { (void)c; (void)in; return C8P_OK; }
+int c8p_option(c8p_ctx* c, int which, int64_t value) { return (c && which == C8P_OPT_COPY_CUS && value >= 0 && value <= 256) ? C8P_OK : C8P_EINVAL; }
 int64_t c8p_counter(c8p_ctx* c, int which)
 {
   switch (which) {

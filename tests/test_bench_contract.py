@@ -248,6 +248,18 @@ def find(whole, frag, path):
     return hits[0] if hits else None
 
 
+# legs whose figure is made by host threads and the PCIe link of a SHARED box (two scheduler threads on two cores, pinned-memory rings):
+# one driver run in three on this pool meets a neighbour's burst that takes a whole 2 s leg down to a third (gpurun_out/r6z2: 735 k,
+# 215 k, 730 k packets/s fused, the headline of the same three runs 6.56 / 6.57 / 6.57 M).  They are compared with a factor that still
+# catches a broken path (an order of magnitude) and does not turn the host's noise into a red suite.
+HOST_BOUND = ("block_chain", "block_fused", "block_rx_chain", "pcie", "raw_chain_pcie", "live_streams", "pcie_inclusive", "ms_per_segment")
+HOST_FACTOR = 0.25
+
+
+def factor_of(path):
+    return HOST_FACTOR if any(h in k for k in path for h in HOST_BOUND) else FACTOR
+
+
 def regressions(driver_whole, driver_frag, committed_flat):
     bad = []
     for path, bigger in LEGS:
@@ -255,7 +267,7 @@ def regressions(driver_whole, driver_frag, committed_flat):
         if d is None or c is None or c <= 0 or d <= 0:
             continue
         ratio = d / c if bigger else c / d
-        if ratio < FACTOR:
+        if ratio < factor_of(path):
             bad.append((".".join(path), d, c, round(ratio, 3)))
     return bad
 

@@ -87,3 +87,25 @@ def test_a_mark_covers_the_twin_streams_earlier_gathers():
         L.c8p_dev_free(eng.ctx, C.c_void_p(arena))
         L.c8p_host_free(C.c_void_p(hs)); L.c8p_host_free(C.c_void_p(hb))
         eng.close()
+
+
+def test_copy_cus_option_is_taken_before_the_first_copy_only():
+    """c8p_option(C8P_OPT_COPY_CUS): how many CUs the ctx's copy streams may use — what the block fronts set to 16; refused once the copy
+    streams exist, for values out of range and for unknown options"""
+    eng = engine.Engine(device=0)
+    L = eng.L
+    try:
+        assert L.c8p_option(eng.ctx, 1, 16) == 0
+        assert L.c8p_option(eng.ctx, 1, 300) == -22 and L.c8p_option(eng.ctx, 99, 1) == -22
+        hs, a_s = pinned(L, 1024, 2.0)
+        dst = L.c8p_dev_alloc(eng.ctx, 8 * 1024)
+        p1 = (abi.Piece * 1)(abi.Piece(hs, 0, 1024, 1, abi.FMT_C32, 0.0, 0))
+        eng._chk(L.c8p_copy_gather(eng.ctx, C.c_void_p(dst), p1, 1))
+        out = np.zeros(2048, np.float32)
+        eng._chk(L.c8p_copy_async(eng.ctx, C.c_void_p(out.ctypes.data), C.c_void_p(dst), 8 * 1024))
+        eng._chk(L.c8p_copy_wait(eng.ctx))
+        assert np.all(out == 2.0)
+        assert L.c8p_option(eng.ctx, 1, 8) == -22           # too late: the streams exist
+        L.c8p_dev_free(eng.ctx, C.c_void_p(dst)); L.c8p_host_free(C.c_void_p(hs))
+    finally:
+        eng.close()
