@@ -82,6 +82,11 @@ c8p_api default_c8p_api()
 }
 static c8p_api default_api() { return default_c8p_api(); }
 
+int batching_cfg::default_max_batch()
+{
+  const char* e = getenv("C8P_MAX_BATCH");
+  return e && atoi(e) > 0 ? atoi(e) : 512;
+}
 int batching_cfg::default_max_wait_us()
 {
   const char* e = getenv("C8P_MAX_WAIT_US");

@@ -148,7 +148,9 @@ c8p_api load_c8p_api(const std::string& so_path);
 c8p_api default_c8p_api();
 
 struct batching_cfg {
-  int max_batch = 256;          // packets per c8p_* call
+  int max_batch = default_max_batch();   // packets per c8p_* call: 512, or the environment's C8P_MAX_BATCH.  (Measured on the demod -> decode chain,
+                                // cfg-2 packets: 256 / 512 / 1024 = 565 / 693 / 690 k packets/s fused, profiles/r6c/chain_fused_sweep.txt; a batch that
+                                // does not fill is cut short after max_wait_us, so the size bounds throughput, not latency.  Until round 6: 256.)
   int detect_items = 1 << 20;   // detect: raw items gathered per c8p_detect call
   // SAFE MODE (environment C8P_GR_SAFE=1): a front that uses nothing of its scheduler beyond what the reference's own blocks use — no
   // custom buffers (pinned_io off: items staged through the front's own pinned copies), no look at who reads the LLR edge (fused_auto
@@ -192,6 +194,7 @@ struct batching_cfg {
   // packet out of that copy and skips its `total` items — which ARE in the stream, written, for whoever else reads them: the LLR
   // stream then crosses the link once (up) instead of twice.  Environment C8P_LLR_HANDLE=0 turns it off (decode gathers the items).
   bool llr_handle = default_llr_handle();
+  static int default_max_batch();
   static bool default_llr_handle();
   static bool default_flush_when_idle();
   static bool default_fused();
