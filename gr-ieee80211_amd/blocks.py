@@ -42,6 +42,7 @@ def lib():
         L.c8ph_set_relocate.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_set_move_out.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_moves_done.argtypes = [C.c_void_p]; L.c8ph_moves_done.restype = C.c_long
+        L.c8ph_try_move.argtypes = [C.c_int]
         L.c8ph_input_pinned.argtypes = [C.c_void_p, C.c_int]
         L.c8ph_output_pinned.argtypes = [C.c_void_p]
         L.c8ph_fused_state.argtypes = [C.c_void_p]

@@ -273,6 +273,9 @@ void c8ph_set_relocate(void* p, int every) { static_cast<harness*>(p)->relocate 
 // every n-th call of c8ph_run finds its output position moved under a c8p::buffer_move_scope (harness::move_out); 0: never
 void c8ph_set_move_out(void* p, int every) { static_cast<harness*>(p)->move_out = every > 0 ? every : 0; }
 long c8ph_moves_done(void* p) { return static_cast<harness*>(p)->moves_done; }
+// a buffer somewhere wants to move, from ANOTHER thread than the block's: can every front be got hold of within timeout_us?  (1 / 0;
+// the range is nobody's, so nothing is saved or moved — the test is about the bounded wait of c8p::buffer_move_scope)
+int c8ph_try_move(int timeout_us) { static char nobody[16]; buffer_move_scope mv(nobody, sizeof(nobody), timeout_us); return mv.ok() ? 1 : 0; }
 int c8ph_input_pinned(void* p, int port) { return static_cast<harness*>(p)->input_is_pinned((unsigned)port) ? 1 : 0; }
 int c8ph_output_pinned(void* p) { return static_cast<harness*>(p)->output_is_pinned(0) ? 1 : 0; }
 // c8p_block::fused_state: 1 / 0 = the demod front runs fused / plain, -1 = not decided yet (no general_work call so far) or no demod

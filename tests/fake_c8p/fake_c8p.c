@@ -1,8 +1,10 @@
 /* TEST-ONLY stand-in for libc8p_rx.so: the same C entry points on top of the CPU oracle, so the host-side block
  * mirror (batching, tag replay, PDU publishing) can be exercised without a GPU.  Never shipped, never used by the
  * product path, bench.py or smoke(). */
+#define _POSIX_C_SOURCE 200809L   /* nanosleep (a test knob) under -std=c11 */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "c8p_rx.h"
 #include "c8p_oracle.h"
 
@@ -102,6 +104,7 @@ const char* c8p_last_error(const c8p_ctx* c) { (void)c; return "fake backend"; }
 
 int c8p_demod(c8p_ctx* c, const c8p_batch_in* in)
 {
+  { const char* e = getenv("C8P_FAKE_SUBMIT_SLEEP_US"); if (e && atoi(e) > 0) { struct timespec ts = {atoi(e) / 1000000, (long)(atoi(e) % 1000000) * 1000L}; nanosleep(&ts, NULL); } }     /* (a test: a submit that takes long, under the front's lock) */
   next_slot(c);
   c->s->n = in->n_pkt;
   c->s->tags = (c8p_pkt_tags*)calloc((size_t)in->n_pkt + 1, sizeof(c8p_pkt_tags));

@@ -997,3 +997,42 @@ def test_safe_mode_uses_nothing_but_the_reference_blocks_own_scheduler_calls(mon
     assert check_against_oracle(res, pk, iq, chan) >= 20
     assert not any(k.startswith("c8p_") for _, k, _ in res[1])
     assert (res[2], res[3]) == chain_out
+
+
+def test_a_buffer_move_never_waits_for_a_busy_front_without_a_bound(monkeypatch):
+    """c8p::buffer_move_scope takes hold of a front with a bounded try-lock: a scheduler may call a buffer's blocked callback while holding a
+    lock the front's RUNNING general_work needs (add_item_tag takes the buffer's mutex in GNU Radio) — waiting for the front there would
+    deadlock.  Here the test engine's submits sleep 30 ms under the front's lock while another thread asks to move a buffer: with a 2 ms
+    bound the scope gives up (ok() == false: the callback returns false, the scheduler comes back later), with a generous one it gets
+    through between two calls; the run itself is undisturbed."""
+    import threading
+    import time
+    monkeypatch.setenv("C8P_FAKE_SUBMIT_SLEEP_US", "30000")
+    b, _ = sweep_batch(snr_db=28.0, seed=5)
+    pk, iq, chan = split(b, 1)
+    dem = blocks.Block(blocks.DEMOD, engine_lib=FAKE, max_batch=3, fused=False)
+    blocks.feed_demod(dem, pk, iq, chan)
+    L = blocks.lib()
+    seen = {"short": [], "long": []}
+    stop = threading.Event()
+
+    def mover():
+        while not stop.is_set():
+            t = time.perf_counter()
+            seen["short"].append((L.c8ph_try_move(2000), time.perf_counter() - t))
+            time.sleep(0.002)
+        seen["long"].append(L.c8ph_try_move(2000000))
+    th = threading.Thread(target=mover)
+    th.start()
+    try:
+        dem.run(chunk=700, nout=3000)                   # ~12 submits of 30 ms each: the front's lock is held most of the time
+    finally:
+        stop.set(); th.join()
+    llr, tags = dem.output(), dem.tags()
+    dem.close()
+    oks = [ok for ok, _ in seen["short"]]
+    assert 0 in oks, "the front was never busy when asked"                      # it gave up at least once ...
+    assert max(dt for _, dt in seen["short"]) < 0.2                              # ... and never waited much beyond its bound
+    assert seen["long"] == [1]                                                   # with time it gets through
+    ref = oracle_rx(pk, iq, chan)
+    assert len(llr) == sum(len(r["llr"]) for r in ref if r["tags"]["status"] == 0)
