@@ -337,8 +337,9 @@ def test_the_drivers_own_lines_are_within_a_factor_of_the_committed_ones():
         assert not new, "%s against %s: %s" % (name, os.path.relpath(cf, ROOT), new)
         stale = [k for k in known if k not in [b[0] for b in bad]]
         assert not stale, "%s: acknowledged regressions that the check no longer sees: %s" % (name, stale)
-        if n >= 6:                                        # round 6 on: the driver must have PARSED the line (a line it cannot parse is unmeasured)
-            p_ = d.get("parsed")
+        ran_ok = d.get("rc") == 0 and not d.get("lease_fault") and (d.get("run") or {}).get("status", "ok") == "ok"
+        if n >= 6 and ran_ok:                             # round 6 on: a run that ended well must have been PARSED (a line the driver cannot
+            p_ = d.get("parsed")                          # parse is unmeasured); a box that died under the driver is not this test's business
             assert p_ and "roofline" in p_ and "cpu_baseline" in p_ and p_.get("value"), "%s: the driver did not parse the bench line" % name
         checked += 1
     assert checked == len([f for f in recs if committed_for_round(int(re.search(r"r(\d+)", os.path.basename(f)).group(1)))])
